@@ -1,0 +1,265 @@
+"""TEST INFRASTRUCTURE ONLY: ctypes loader for the CPU oracle (oracle/liboracle.so, prefix ``orc_``) and, when it
+has been built in this container, the real reference hot path (oracle/_ref/libref.so, prefix ``ref_``).
+
+Both libraries export the same stage-level entry points, so one wrapper class drives either. Nothing in
+``libfluid_amd/`` imports this module; only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg do.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "liboracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libref.so")
+
+# Reference layouts: include/fluid/simulation.h:24-34 and include/fluid/mac_grid.h:15-27.
+PARTICLE_DTYPE = np.dtype(
+    [("pos", "<f8", 3), ("vel", "<f8", 3), ("cx", "<f8", 3), ("cy", "<f8", 3), ("cz", "<f8", 3),
+     ("old_pos", "<f8", 3), ("raw", "<u8")]
+)
+CELL_DTYPE = np.dtype([("vel", "<f8", 3), ("type", "u1"), ("pad", "u1", 7)])
+assert PARTICLE_DTYPE.itemsize == 152 and CELL_DTYPE.itemsize == 32
+
+AIR, FLUID, SOLID = 1, 2, 4
+PIC, FLIP, APIC = 0, 1, 2
+
+
+def build(force=False):
+    """Compile liboracle.so (always possible: plain C) and oracle/_ref (only where /root/reference exists)."""
+    src = os.path.join(HERE, "oracle.c")
+    if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", HERE, os.path.join(HERE, "liboracle.so")])
+    ref_src = os.path.join(HERE, "ref_harness.cpp")
+    if os.path.isdir(os.environ.get("REFERENCE_DIR", "/root/reference")):
+        if force or not os.path.exists(REF_SO) or os.path.getmtime(REF_SO) < os.path.getmtime(ref_src):
+            subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+_vp, _sz, _dbl, _int = C.c_void_p, C.c_size_t, C.c_double, C.c_int
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class _Lib:
+    def __init__(self, path, prefix):
+        self.lib = C.CDLL(path)
+        self.prefix = prefix
+        sig = {
+            "create": (_vp, [_sz, _sz, _sz, _dbl, _vp, _vp, _int, _dbl, _dbl]),
+            "destroy": (None, [_vp]),
+            "set_extrapolation_iterations": (None, [_vp, _sz]),
+            "set_pcg_params": (None, [_vp, _dbl, _dbl, _dbl, _sz]),
+            "set_solid_cells": (None, [_vp, _vp, _sz]),
+            "set_particles": (None, [_vp, _vp, _sz]),
+            "num_particles": (_sz, [_vp]),
+            "get_particles": (None, [_vp, _vp]),
+            "get_cells": (None, [_vp, _vp]),
+            "set_cells": (None, [_vp, _vp]),
+            "get_old_cells": (None, [_vp, _vp]),
+            "hash": (None, [_vp]),
+            "num_fluid_cells": (_sz, [_vp]),
+            "get_fluid_cells": (None, [_vp, _vp]),
+            "get_space_hash": (None, [_vp, _vp, _vp]),
+            "p2g": (None, [_vp]),
+            "add_gravity": (None, [_vp, _dbl]),
+            "build_system": (None, [_vp, _dbl]),
+            "get_abits": (None, [_vp, _vp]),
+            "get_b": (None, [_vp, _vp]),
+            "get_precon": (None, [_vp, _vp]),
+            "apply_precon": (None, [_vp, _vp, _vp]),
+            "apply_a": (None, [_vp, _vp, _vp]),
+            "solve": (None, [_vp, _dbl, _vp, _vp, _vp]),
+            "apply_pressure": (None, [_vp, _dbl, _vp]),
+            "extrapolate": (None, [_vp]),
+            "g2p": (None, [_vp]),
+            "cfl": (_dbl, [_vp]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(self.lib, prefix + name)
+            fn.restype, fn.argtypes = res, args
+            setattr(self, name, fn)
+        for name, (res, args) in {
+            "hot_step": (None, [_vp, _dbl, _vp, _vp, _vp]),
+            "advect": (None, [_vp, _dbl]),
+            "detect_collisions": (None, [_vp]),
+            "correct_positions": (None, [_vp, _dbl]),
+            "time_step": (None, [_vp, _dbl, _vp, _vp]),
+        }.items():
+            fn = getattr(self.lib, prefix + name, None)
+            if fn is not None:
+                fn.restype, fn.argtypes = res, args
+            setattr(self, name, fn)
+
+
+_libs = {}
+
+
+def _get(kind):
+    if kind not in _libs:
+        build()
+        _libs[kind] = _Lib(ORACLE_SO, "orc_") if kind == "oracle" else _Lib(REF_SO, "ref_")
+    return _libs[kind]
+
+
+class CpuSim:
+    """Stage-level driver for the oracle (kind='oracle') or the real reference (kind='ref')."""
+
+    def __init__(self, size, cell_size=1.0, offset=(0.0, 0.0, 0.0), gravity=(0.0, -981.0, 0.0), method=APIC,
+                 blending=1.0, density=1.0, kind="oracle"):
+        self.L = _get(kind)
+        self.size = tuple(int(s) for s in size)
+        self.ncells = self.size[0] * self.size[1] * self.size[2]
+        off = np.asarray(offset, dtype=np.float64)
+        g = np.asarray(gravity, dtype=np.float64)
+        self.h = C.c_void_p(self.L.create(*self.size, float(cell_size), _ptr(off), _ptr(g), int(method),
+                                          float(blending), float(density)))
+        self._built = False
+
+    def close(self):
+        if self.h:
+            self.L.destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- state ---------------------------------------------------------------------------------------------
+    def set_solid_cells(self, xyz):
+        xyz = np.ascontiguousarray(xyz, dtype=np.int32).reshape(-1, 3)
+        self.L.set_solid_cells(self.h, _ptr(xyz), xyz.shape[0])
+
+    def set_particles(self, parts):
+        parts = np.ascontiguousarray(parts, dtype=PARTICLE_DTYPE)
+        self.L.set_particles(self.h, _ptr(parts), parts.shape[0])
+
+    def particles(self):
+        out = np.empty(self.L.num_particles(self.h), dtype=PARTICLE_DTYPE)
+        self.L.get_particles(self.h, _ptr(out))
+        return out
+
+    def cells(self):
+        out = np.empty(self.ncells, dtype=CELL_DTYPE)
+        self.L.get_cells(self.h, _ptr(out))
+        return out
+
+    def set_cells(self, cells):
+        cells = np.ascontiguousarray(cells, dtype=CELL_DTYPE)
+        assert cells.shape[0] == self.ncells
+        self.L.set_cells(self.h, _ptr(cells))
+
+    def old_cells(self):
+        out = np.empty(self.ncells, dtype=CELL_DTYPE)
+        self.L.get_old_cells(self.h, _ptr(out))
+        return out
+
+    def set_extrapolation_iterations(self, n):
+        self.L.set_extrapolation_iterations(self.h, int(n))
+
+    def set_pcg_params(self, tau=0.97, sigma=0.25, tol=1e-6, maxit=200):
+        self.L.set_pcg_params(self.h, tau, sigma, tol, maxit)
+
+    # -- stages ------------------------------------------------------------------------------------------
+    def hash(self):
+        self.L.hash(self.h)
+
+    def fluid_cells(self):
+        out = np.empty(self.L.num_fluid_cells(self.h), dtype=np.uint64)
+        self.L.get_fluid_cells(self.h, _ptr(out))
+        return out
+
+    def space_hash(self):
+        b = np.empty(self.ncells, dtype=np.uint64)
+        c = np.empty(self.ncells, dtype=np.uint64)
+        self.L.get_space_hash(self.h, _ptr(b), _ptr(c))
+        return b, c
+
+    def p2g(self):
+        self.L.p2g(self.h)
+
+    def add_gravity(self, dt):
+        self.L.add_gravity(self.h, dt)
+
+    def build_system(self, dt):
+        self.L.build_system(self.h, dt)
+        self._n = self.L.num_fluid_cells(self.h)
+
+    def abits(self):
+        out = np.empty(self._n, dtype=np.uint8)
+        self.L.get_abits(self.h, _ptr(out))
+        return out
+
+    def b(self):
+        out = np.empty(self._n, dtype=np.float64)
+        self.L.get_b(self.h, _ptr(out))
+        return out
+
+    def precon(self):
+        out = np.empty(self._n, dtype=np.float64)
+        self.L.get_precon(self.h, _ptr(out))
+        return out
+
+    def apply_precon(self, r):
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        z = np.zeros_like(r)
+        self.L.apply_precon(self.h, _ptr(r), _ptr(z))
+        return z
+
+    def apply_a(self, v):
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        out = np.zeros_like(v)
+        self.L.apply_a(self.h, _ptr(v), _ptr(out))
+        return out
+
+    def solve(self, dt):
+        n = self.L.num_fluid_cells(self.h)
+        self._n = n
+        p = np.zeros(max(n, 1), dtype=np.float64)
+        res = C.c_double(0.0)
+        it = C.c_uint64(0)
+        self.L.solve(self.h, dt, _ptr(p), C.byref(res), C.byref(it))
+        return p[:n], res.value, it.value
+
+    def apply_pressure(self, dt, p):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        self.L.apply_pressure(self.h, dt, _ptr(p))
+
+    def extrapolate(self):
+        self.L.extrapolate(self.h)
+
+    def g2p(self):
+        self.L.g2p(self.h)
+
+    def cfl(self):
+        return self.L.cfl(self.h)
+
+    def hot_step(self, dt):
+        """hash -> p2g -> gravity -> solve -> apply -> extrapolate -> g2p; returns (p, residual, iters)."""
+        if self.L.hot_step is not None:
+            self.L.hash(self.h)
+            n = self.L.num_fluid_cells(self.h)
+            p = np.zeros(max(n, 1), dtype=np.float64)
+            res = C.c_double(0.0)
+            it = C.c_uint64(0)
+            self.L.hot_step(self.h, dt, _ptr(p), C.byref(res), C.byref(it))
+            return p[:n], res.value, it.value
+        self.hash()
+        self.p2g()
+        self.add_gravity(dt)
+        self.build_system(dt)
+        p, res, it = self.solve(dt)
+        self.apply_pressure(dt, p)
+        self.extrapolate()
+        self.g2p()
+        return p, res, it

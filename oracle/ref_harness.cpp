@@ -1,0 +1,276 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into or called by the product path.
+//
+// oracle/ref_harness.cpp : C entry points around the *real* lukedan/libfluid hot path.
+//
+// This file contains no reference code. It is a unity translation unit that #includes the reference's own
+// sources where they lie under $REFERENCE_DIR (default /root/reference) and wraps them with `extern "C"`
+// stage-level entry points, so that tests can (a) pin oracle/oracle.c against the true reference and
+// (b) generate the golden vectors in tests/golden/ (tests/golden/make_golden.py).
+// Output goes to oracle/_ref/libref.so (git-ignored). When /root/reference is absent (GPU box) this file is
+// simply not built; nothing at run time depends on it.
+//
+// pcg32: reference include/fluid/simulation.h:11 does `#include <pcg_random.hpp>` from an un-vendored submodule
+// (.gitmodules:1-3). The genuine pcg-cpp header ships inside this image's pyarrow wheel
+// (.../pyarrow/include/arrow/vendored/pcg/pcg_random.hpp, namespace arrow_vendored); the Makefile puts that
+// directory on the include path and the using-declaration below lifts pcg32 to the global namespace. No stand-in
+// header is written. The RNG touches seeding and the coincident-particle jitter only (simulation.h:85,101,
+// simulation.cpp:141-145,573,587); none of the hot-path arithmetic depends on it, and the harness injects
+// particles rather than seeding them.
+//
+// Private/protected members of fluid::simulation / fluid::pressure_solver are reached with the
+// `#define private public` technique after all standard headers have been included.
+
+#include <algorithm>
+#include <atomic>
+#include <cassert>
+#include <cmath>
+#include <condition_variable>
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <initializer_list>
+#include <iostream>
+#include <limits>
+#include <memory>
+#include <mutex>
+#include <optional>
+#include <random>
+#include <thread>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#include <pcg_random.hpp>
+using arrow_vendored::pcg32;
+
+#define private public
+#define protected public
+#include "src/mac_grid.cpp"
+#include "src/simulation.cpp"
+#include "src/pressure_solver.cpp"
+#undef private
+#undef protected
+
+namespace {
+	using fluid::vec3d;
+	using fluid::vec3s;
+	using sim_t = fluid::simulation;
+
+	struct ref_ctx {
+		sim_t sim;
+		std::vector<vec3s> fluid_cells;
+		std::unique_ptr<fluid::pressure_solver> solver;
+		std::vector<double> precon;
+	};
+
+	static_assert(sizeof(sim_t::particle) == 152, "particle layout (SURVEY 8: 152-B AoS)");
+	static_assert(sizeof(fluid::mac_grid::cell) == 32, "cell layout (SURVEY 8: 32-B AoS)");
+}
+
+extern "C" {
+	void *ref_create(
+		std::size_t nx, std::size_t ny, std::size_t nz, double cell_size,
+		const double *offset, const double *gravity, int method, double blending, double density
+	) {
+		auto *c = new ref_ctx();
+		c->sim.resize(vec3s(nx, ny, nz));
+		c->sim.cell_size = cell_size;
+		c->sim.grid_offset = vec3d(offset[0], offset[1], offset[2]);
+		c->sim.gravity = vec3d(gravity[0], gravity[1], gravity[2]);
+		c->sim.simulation_method = static_cast<sim_t::method>(method);
+		c->sim.blending_factor = blending;
+		c->sim.density = density;
+		return c;
+	}
+	void ref_destroy(void *h) {
+		delete static_cast<ref_ctx*>(h);
+	}
+	void ref_set_extrapolation_iterations(void *h, std::size_t n) {
+		static_cast<ref_ctx*>(h)->sim.velocity_extrapolation_iterations = n;
+	}
+
+	void ref_set_solid_cells(void *h, const int *xyz, std::size_t k) {
+		auto &g = static_cast<ref_ctx*>(h)->sim.grid().grid();
+		for (std::size_t i = 0; i < k; ++i) {
+			g(vec3s(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2])).cell_type = fluid::mac_grid::cell::type::solid;
+		}
+	}
+
+	void ref_set_particles(void *h, const void *aos152, std::size_t n) {
+		auto &ps = static_cast<ref_ctx*>(h)->sim.particles();
+		ps.resize(n);
+		std::memcpy(static_cast<void*>(ps.data()), aos152, n * sizeof(sim_t::particle));
+	}
+	std::size_t ref_num_particles(void *h) {
+		return static_cast<ref_ctx*>(h)->sim.particles().size();
+	}
+	void ref_get_particles(void *h, void *aos152) {
+		auto &ps = static_cast<ref_ctx*>(h)->sim.particles();
+		std::memcpy(aos152, static_cast<const void*>(ps.data()), ps.size() * sizeof(sim_t::particle));
+	}
+
+	void ref_get_cells(void *h, void *aos32) {
+		auto &g = static_cast<ref_ctx*>(h)->sim.grid().grid();
+		std::memcpy(aos32, static_cast<const void*>(&g[0]), g.get_array_size(g.get_size()) * 32);
+	}
+	void ref_set_cells(void *h, const void *aos32) {
+		auto &g = static_cast<ref_ctx*>(h)->sim.grid().grid();
+		std::memcpy(static_cast<void*>(&g[0]), aos32, g.get_array_size(g.get_size()) * 32);
+	}
+	void ref_get_old_cells(void *h, void *aos32) {
+		auto &g = static_cast<ref_ctx*>(h)->sim._old_grid.grid();
+		std::memcpy(aos32, static_cast<const void*>(&g[0]), g.get_array_size(g.get_size()) * 32);
+	}
+
+	/// simulation::update_and_hash_particles (src/simulation.cpp:251-264).
+	void ref_hash(void *h) {
+		static_cast<ref_ctx*>(h)->sim.update_and_hash_particles();
+	}
+	std::size_t ref_num_fluid_cells(void *h) {
+		return static_cast<ref_ctx*>(h)->sim._fluid_cells.size();
+	}
+	void ref_get_fluid_cells(void *h, std::uint64_t *out) {
+		auto &fc = static_cast<ref_ctx*>(h)->sim._fluid_cells;
+		for (std::size_t i = 0; i < fc.size(); ++i) {
+			out[i] = fc[i];
+		}
+	}
+	/// _space_hash begin/count per cell (src/simulation.cpp:266-291).
+	void ref_get_space_hash(void *h, std::uint64_t *begin, std::uint64_t *count) {
+		auto &sh = static_cast<ref_ctx*>(h)->sim._space_hash;
+		std::size_t n = sh.get_array_size(sh.get_size());
+		for (std::size_t i = 0; i < n; ++i) {
+			begin[i] = sh[i].begin;
+			count[i] = sh[i].count;
+		}
+	}
+
+	/// simulation::_transfer_to_grid (src/simulation.cpp:400-412).
+	void ref_p2g(void *h) {
+		static_cast<ref_ctx*>(h)->sim._transfer_to_grid();
+	}
+	/// gravity loop (src/simulation.cpp:72-78).
+	void ref_add_gravity(void *h, double dt) {
+		auto &sim = static_cast<ref_ctx*>(h)->sim;
+		auto sz = sim.grid().grid().get_size();
+		for (std::size_t z = 0; z < sz.z; ++z) {
+			for (std::size_t y = 0; y < sz.y; ++y) {
+				for (std::size_t x = 0; x < sz.x; ++x) {
+					sim.grid().grid()(x, y, z).velocities_posface += sim.gravity * dt;
+				}
+			}
+		}
+	}
+
+	/// fluid cell list + pressure_solver ctor + the set-up half of solve() (src/simulation.cpp:83-99,
+	/// src/pressure_solver.cpp:20-25).
+	void ref_build_system(void *h, double dt) {
+		auto *c = static_cast<ref_ctx*>(h);
+		c->fluid_cells.clear();
+		for (std::size_t raw : c->sim._fluid_cells) {
+			c->fluid_cells.emplace_back(c->sim.grid().grid().index_from_raw(raw));
+		}
+		c->solver = std::make_unique<fluid::pressure_solver>(c->sim, c->fluid_cells);
+		auto &s = *c->solver;
+		s._compute_fluid_cell_indices();
+		s._a_scale = dt / (c->sim.density * c->sim.cell_size * c->sim.cell_size);
+		s._compute_a_matrix();
+		c->precon = s._compute_preconditioner();
+	}
+	void ref_set_pcg_params(void *h, double tau, double sigma, double tol, std::size_t maxit) {
+		auto &s = *static_cast<ref_ctx*>(h)->solver;
+		s.tau = tau;
+		s.sigma = sigma;
+		s.tolerance = tol;
+		s.max_iterations = maxit;
+	}
+	/// cell_data as one byte: bits 0-2 nonsolid_neighbors, bit 3 fluid_xpos, bit 4 fluid_ypos, bit 5 fluid_zpos.
+	void ref_get_abits(void *h, std::uint8_t *out) {
+		auto &s = *static_cast<ref_ctx*>(h)->solver;
+		for (std::size_t i = 0; i < s._a.size(); ++i) {
+			out[i] = static_cast<std::uint8_t>(
+				s._a[i].nonsolid_neighbors | (s._a[i].fluid_xpos << 3) | (s._a[i].fluid_ypos << 4) |
+				(s._a[i].fluid_zpos << 5)
+			);
+		}
+	}
+	void ref_get_b(void *h, double *out) {
+		auto b = static_cast<ref_ctx*>(h)->solver->_compute_b_vector();
+		std::copy(b.begin(), b.end(), out);
+	}
+	void ref_get_precon(void *h, double *out) {
+		auto &p = static_cast<ref_ctx*>(h)->precon;
+		std::copy(p.begin(), p.end(), out);
+	}
+	void ref_apply_precon(void *h, const double *r, double *z) {
+		auto *c = static_cast<ref_ctx*>(h);
+		std::size_t n = c->fluid_cells.size();
+		std::vector<double> rv(r, r + n), zv(n, 0.0), q(n, 0.0);
+		c->solver->_apply_preconditioner(zv, q, c->precon, rv);
+		std::copy(zv.begin(), zv.end(), z);
+	}
+	void ref_apply_a(void *h, const double *v, double *out) {
+		auto *c = static_cast<ref_ctx*>(h);
+		std::size_t n = c->fluid_cells.size();
+		std::vector<double> vv(v, v + n), ov(n, 0.0);
+		c->solver->_apply_a(ov, vv);
+		std::copy(ov.begin(), ov.end(), out);
+	}
+	/// pressure_solver::solve (src/pressure_solver.cpp:19-71). Rebuilds the system like the reference does.
+	void ref_solve(void *h, double dt, double *p, double *residual, std::uint64_t *iters) {
+		auto *c = static_cast<ref_ctx*>(h);
+		auto [pv, res, it] = c->solver->solve(dt);
+		std::copy(pv.begin(), pv.end(), p);
+		*residual = res;
+		*iters = it;
+	}
+	/// pressure_solver::apply_pressure (src/pressure_solver.cpp:73-148).
+	void ref_apply_pressure(void *h, double dt, const double *p) {
+		auto *c = static_cast<ref_ctx*>(h);
+		std::vector<double> pv(p, p + c->fluid_cells.size());
+		c->solver->apply_pressure(dt, pv);
+	}
+	/// simulation::_extrapolate_velocities (src/simulation.cpp:685-754).
+	void ref_extrapolate(void *h) {
+		auto *c = static_cast<ref_ctx*>(h);
+		c->sim._extrapolate_velocities(c->fluid_cells);
+	}
+	/// simulation::_transfer_from_grid (src/simulation.cpp:548-560).
+	void ref_g2p(void *h) {
+		static_cast<ref_ctx*>(h)->sim._transfer_from_grid();
+	}
+	double ref_cfl(void *h) {
+		return static_cast<ref_ctx*>(h)->sim.cfl();
+	}
+	/// Per-step stages outside the hot path, exposed for the "next" rows.
+	void ref_advect(void *h, double dt) {
+		static_cast<ref_ctx*>(h)->sim._advect_particles(dt);
+	}
+	void ref_detect_collisions(void *h) {
+		auto &sim = static_cast<ref_ctx*>(h)->sim;
+		sim._detect_collisions();
+		for (auto &p : sim._particles) {
+			p.old_position = p.position;
+		}
+	}
+	void ref_correct_positions(void *h, double dt) {
+		static_cast<ref_ctx*>(h)->sim._correct_positions(dt);
+	}
+	/// Full simulation::time_step(dt) (src/simulation.cpp:43-125); pressure/residual/iters of the step are
+	/// captured through post_pressure_solve_callback (include/fluid/simulation.h:166).
+	void ref_time_step(void *h, double dt, double *residual, std::uint64_t *iters) {
+		auto &sim = static_cast<ref_ctx*>(h)->sim;
+		sim.post_pressure_solve_callback = [&](double, std::vector<double>&, double res, std::size_t it) {
+			if (residual) {
+				*residual = res;
+			}
+			if (iters) {
+				*iters = it;
+			}
+		};
+		sim.time_step(dt);
+		sim.post_pressure_solve_callback = nullptr;
+	}
+}
