@@ -1,0 +1,161 @@
+/* libfluid_amd.h -- C ABI of the MI355X-native PIC/FLIP/APIC hot path (drop-in for lukedan/libfluid's per-step path).
+ *
+ * The reference has no FFI: its boundary is the C++ class fluid::simulation (include/fluid/simulation.h:21-280) used
+ * identically by the testbed (testbed/main.cpp:91-99,189) and the Maya GridNode (plugins/maya/nodes/grid_node.cpp:
+ * 256-274,351-357). This header is the thin layer the north star asks for *beneath* a class with that surface
+ * (libfluid_amd/host/simulation.h): plain pointers and sizes, host layouts exactly as the reference holds them.
+ *
+ *   particles : simulation::particle, 152-B fp64 AoS {position, velocity, cx, cy, cz, old_position, raw_cell_index}
+ *               (include/fluid/simulation.h:24-34)
+ *   cells     : mac_grid::cell, 32-B AoS {vec3d velocities_posface, u8 type{air=1,fluid=2,solid=4}, pad}, x fastest
+ *               (include/fluid/mac_grid.h:15-27, include/fluid/data_structures/grid.h:11-12)
+ *   solids    : flat int[3k] (x,y,z) triples as the Maya plugin passes them (plugins/maya/nodes/grid_node.cpp:330-339)
+ *   pressure  : double[n] in the reference's unknown order = ascending raw cell index of occupied cells
+ *               (src/simulation.cpp:83-94, include/fluid/simulation.h:166)
+ *
+ * Every function returns LFA_OK (0) or a negative LFA_E_* code; lfa_last_error() gives the text. The library never
+ * keeps a host pointer past the call. One host thread per handle; different handles are independent.
+ * There is no CPU fallback: without a usable HIP device lfa_create fails with LFA_E_NO_DEVICE.
+ */
+#ifndef LIBFLUID_AMD_H
+#define LIBFLUID_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lfa_sim lfa_sim;
+
+enum {
+	LFA_OK = 0,
+	LFA_E_INVALID = -1,      /* bad argument / size / state */
+	LFA_E_NO_DEVICE = -2,    /* no HIP device or device init failed */
+	LFA_E_HIP = -3,          /* a HIP runtime call failed */
+	LFA_E_OOM = -4,          /* device allocation failed */
+	LFA_E_NAN = -5,          /* NaN/Inf detected in the pressure solve */
+	LFA_E_UNSUPPORTED = -6,  /* parameter combination not implemented on the device path */
+	LFA_W_PCG_NOT_CONVERGED = 1 /* warning: PCG stopped at max_iterations (reference is silent: pressure_solver.cpp:45) */
+};
+
+/* simulation::method, include/fluid/simulation.h:44-48 */
+enum { LFA_PIC = 0, LFA_FLIP_BLEND = 1, LFA_APIC = 2 };
+/* P2G scatter variant (BASELINE config 2: "P2G atomics vs LDS-binned") */
+enum { LFA_P2G_LDS_BINNED = 0, LFA_P2G_GLOBAL_ATOMIC = 1 };
+/* MIC(0) schedule. EXACT = hyperplane order over tiles: the same recurrence as pressure_solver.cpp:244-332, hence the
+ * same iteration counts as the reference. TILED = MIC(0) restricted to 8x8x8 tiles (couplings across tile faces
+ * dropped from the preconditioner only): one launch per application, more iterations, same converged pressure. */
+enum { LFA_PRECOND_MIC0_TILED = 0, LFA_PRECOND_MIC0_EXACT = 1 };
+/* arithmetic type of the PCG vectors */
+enum { LFA_PCG_F32 = 0, LFA_PCG_F64 = 1 };
+
+/* Public fields of fluid::simulation (include/fluid/simulation.h:179-190) and fluid::pressure_solver
+ * (include/fluid/pressure_solver.h:38-42), same names and defaults, plus device-path selectors. */
+typedef struct lfa_params {
+	double grid_offset[3];
+	double gravity[3];
+	double cell_size;             /* reference default NaN: must be set */
+	double blending_factor;       /* 1.0 */
+	double density;               /* 1.0 */
+	double boundary_skin_width;   /* 0.1 (used by the "next" rows only) */
+	double correction_stiffness;  /* 5.0 (used by the "next" rows only) */
+	double cfl_number;            /* 3.0 */
+	uint64_t velocity_extrapolation_iterations; /* 1; device path supports 0..8 */
+	int32_t simulation_method;    /* LFA_APIC */
+	double tau, sigma, tolerance; /* 0.97, 0.25, 1e-6 */
+	uint64_t max_iterations;      /* 200 */
+	int32_t p2g_variant;          /* LFA_P2G_LDS_BINNED */
+	int32_t precond;              /* LFA_PRECOND_MIC0_TILED */
+	int32_t pcg_dtype;            /* LFA_PCG_F32 */
+	int32_t apic_unscaled_kernel; /* 1 = keep the reference quirk simulation.cpp:367-369 (only differs when cell_size != 1;
+	                                 the device path then returns LFA_E_UNSUPPORTED), 0 = divide by cell_size */
+} lfa_params;
+
+/* -- lifetime ------------------------------------------------------------------------------------------------ */
+void lfa_default_params(lfa_params *p);
+/* simulation::resize (include/fluid/simulation.h:57) + device selection. device < 0 => current device. */
+int lfa_create(lfa_sim **out, uint64_t nx, uint64_t ny, uint64_t nz, int device);
+void lfa_destroy(lfa_sim *s);
+const char *lfa_last_error(const lfa_sim *s); /* s may be NULL: error of the last failed lfa_create on this thread */
+int lfa_set_params(lfa_sim *s, const lfa_params *p);
+int lfa_get_params(const lfa_sim *s, lfa_params *p);
+int lfa_synchronize(lfa_sim *s);
+/* HIP stream all kernels of this handle are launched on (hipStream_t as void*), for external timing/graphs. */
+void *lfa_stream(lfa_sim *s);
+
+/* -- data in / out (reference host layouts) ------------------------------------------------------------------ */
+/* Replaces the particle set (simulation::particles(), include/fluid/simulation.h:142). Converts to the device layout
+ * (fp32 SoA, cell-relative positions) and computes the clamped cell key of src/simulation.cpp:251-261 in fp64. */
+int lfa_upload_particles(lfa_sim *s, const void *aos152, uint64_t n);
+/* Writes velocity, cx, cy, cz and raw_cell_index (x-fastest raw index, as the reference stores it) of every particle
+ * back into the caller's array, in upload order (particle i of the upload is element i). position/old_position are
+ * written too (reconstructed from the device's cell-relative representation) only if write_positions != 0. */
+int lfa_download_particles(lfa_sim *s, void *aos152, uint64_t n, int write_positions);
+uint64_t lfa_num_particles(const lfa_sim *s);
+/* Synthetic dam-break block [lo,hi) in cells, 8 jittered particles per cell, generated on the device; bit-identical
+ * to libfluid_amd/scenes.py:seed_block. */
+int lfa_seed_block(lfa_sim *s, const int64_t lo[3], const int64_t hi[3], uint64_t seed);
+/* Marks cells solid (flat int[3k] triples). lfa_clear_solid_cells resets every cell to non-solid. */
+int lfa_set_solid_cells(lfa_sim *s, const int32_t *xyz, uint64_t k);
+int lfa_clear_solid_cells(lfa_sim *s);
+/* Whole MAC grid in the reference layout (32-B AoS, x fastest). upload takes velocities and solid flags. */
+int lfa_upload_cells(lfa_sim *s, const void *aos32);
+int lfa_download_cells(lfa_sim *s, void *aos32);
+int lfa_download_old_cells(lfa_sim *s, void *aos32); /* FLIP's _old_grid (src/simulation.cpp:340-344) */
+
+/* -- hot-path stages, individually callable for parity tests ---------------------------------- */
+/* a2: bins particles by 8x8x8 tile and counts particles per cell (src/simulation.cpp:251-291). */
+int lfa_hash_particles(lfa_sim *s);
+uint64_t lfa_num_fluid_cells(lfa_sim *s);
+/* _fluid_cells: ascending raw indices of cells holding particles (include/fluid/simulation.h:209). */
+int lfa_download_fluid_cells(lfa_sim *s, uint64_t *raw, uint64_t n);
+/* per-cell particle counts (the `count` half of _space_hash, include/fluid/simulation.h:193-197,207), x fastest. */
+int lfa_download_cell_counts(lfa_sim *s, uint32_t *count);
+/* a4-a6: simulation::_transfer_to_grid (src/simulation.cpp:400-412). */
+int lfa_p2g(lfa_sim *s);
+/* a7: gravity loop (src/simulation.cpp:72-78). */
+int lfa_add_gravity(lfa_sim *s, double dt);
+/* a8-a12: unknown set, A bits, divergence rhs, MIC(0) factor (src/pressure_solver.cpp:19-25,150-294). */
+int lfa_build_system(lfa_sim *s, double dt);
+int lfa_download_abits(lfa_sim *s, uint8_t *bits, uint64_t n);   /* bits0-2 nonsolid, 3 xpos, 4 ypos, 5 zpos */
+int lfa_download_rhs(lfa_sim *s, double *b, uint64_t n);
+int lfa_download_precon(lfa_sim *s, double *precon, uint64_t n);
+/* a13/a14 in isolation (vectors in the reference's unknown order). */
+int lfa_apply_preconditioner(lfa_sim *s, const double *r, double *z, uint64_t n);
+int lfa_apply_a(lfa_sim *s, const double *v, double *out, uint64_t n);
+/* a16: pressure_solver::solve (src/pressure_solver.cpp:19-71); includes lfa_build_system like the reference's solve().
+ * Returns LFA_W_PCG_NOT_CONVERGED if it stopped at max_iterations. */
+int lfa_pcg_solve(lfa_sim *s, double dt, double *residual, uint64_t *iterations);
+int lfa_download_pressure(lfa_sim *s, double *p, uint64_t n);
+int lfa_upload_pressure(lfa_sim *s, const double *p, uint64_t n); /* a host callback may edit it (simulation.h:166) */
+/* a17: pressure_solver::apply_pressure (src/pressure_solver.cpp:73-148). */
+int lfa_apply_pressure(lfa_sim *s, double dt);
+/* a18: simulation::_extrapolate_velocities (src/simulation.cpp:685-754). */
+int lfa_extrapolate(lfa_sim *s);
+/* a19-a20: simulation::_transfer_from_grid (src/simulation.cpp:548-560). */
+int lfa_g2p(lfa_sim *s);
+/* a21: simulation::cfl (src/simulation.cpp:199-205); +inf when every velocity is zero. */
+int lfa_cfl(lfa_sim *s, double *out);
+
+/* One pass of the hot path, device resident, no host synchronisation except the PCG convergence polls:
+ * hash -> P2G -> gravity -> build+PCG -> apply pressure -> extrapolate -> G2P  (src/simulation.cpp:62-66,72-78,
+ * 83-104,119-121). residual/iterations may be NULL. */
+int lfa_step_hot(lfa_sim *s, double dt, double *residual, uint64_t *iterations);
+
+/* -- measurement --------------------------------------------------------------------------------------------- */
+/* Per-stage device time of the last lfa_step_hot, measured with HIP events on the handle's stream (milliseconds):
+ * [0] hash/bin [1] P2G [2] gravity [3] build system [4] PCG loop [5] apply pressure [6] extrapolate [7] G2P
+ * [8] P2G scatter kernel alone [9] mean PCG iteration (PCG loop / iterations). Enabled by lfa_enable_timing(s,1). */
+#define LFA_NUM_TIMERS 10
+int lfa_enable_timing(lfa_sim *s, int on);
+int lfa_get_timings(lfa_sim *s, double ms[LFA_NUM_TIMERS]);
+/* counts of the last step: [0] particles [1] unknowns (fluid cells) [2] tiles holding particles [3] tiles processed
+ * by grid kernels (dilated set) [4] padded cell count */
+int lfa_get_counts(lfa_sim *s, uint64_t counts[5]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

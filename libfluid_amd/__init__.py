@@ -1,0 +1,328 @@
+"""libfluid_amd -- MI355X-native PIC/FLIP/APIC hot path behind libfluid's ``fluid::simulation`` step API.
+
+The product is the C-ABI shared library ``libfluid_amd.so`` (include/libfluid_amd.h, kernels in csrc/) plus the C++17 host
+class in host/simulation.h. This module is the thin ctypes binding the tests and bench.py use to call that C ABI; it
+adds no computation of its own and has no CPU fallback: loading fails loudly when the HIP library is missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import scenes  # noqa: F401
+from .scenes import CELL_DTYPE, PARTICLE_DTYPE  # noqa: F401
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfluid_amd.so")
+
+PIC, FLIP_BLEND, APIC = 0, 1, 2
+P2G_LDS_BINNED, P2G_GLOBAL_ATOMIC = 0, 1
+PRECOND_MIC0_TILED, PRECOND_MIC0_EXACT = 0, 1
+PCG_F32, PCG_F64 = 0, 1
+OK, W_PCG_NOT_CONVERGED = 0, 1
+NUM_TIMERS = 10
+TIMER_NAMES = ["bin", "p2g", "gravity", "build_system", "pcg_loop", "apply_pressure", "extrapolate", "g2p",
+               "p2g_scatter_kernel", "pcg_iteration_mean"]
+
+
+class Params(C.Structure):
+    """lfa_params (include/libfluid_amd.h) == public fields of fluid::simulation / fluid::pressure_solver."""
+    _fields_ = [
+        ("grid_offset", C.c_double * 3),
+        ("gravity", C.c_double * 3),
+        ("cell_size", C.c_double),
+        ("blending_factor", C.c_double),
+        ("density", C.c_double),
+        ("boundary_skin_width", C.c_double),
+        ("correction_stiffness", C.c_double),
+        ("cfl_number", C.c_double),
+        ("velocity_extrapolation_iterations", C.c_uint64),
+        ("simulation_method", C.c_int32),
+        ("tau", C.c_double),
+        ("sigma", C.c_double),
+        ("tolerance", C.c_double),
+        ("max_iterations", C.c_uint64),
+        ("p2g_variant", C.c_int32),
+        ("precond", C.c_int32),
+        ("pcg_dtype", C.c_int32),
+        ("apic_unscaled_kernel", C.c_int32),
+    ]
+
+
+class LibfluidError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libfluid_amd error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+# name -> (restype, argtypes); also the list the CPU test checks against include/libfluid_amd.h
+_vp, _u64, _dbl, _int = C.c_void_p, C.c_uint64, C.c_double, C.c_int
+SIGNATURES = {
+    "lfa_default_params": (None, [C.POINTER(Params)]),
+    "lfa_create": (_int, [C.POINTER(_vp), _u64, _u64, _u64, _int]),
+    "lfa_destroy": (None, [_vp]),
+    "lfa_last_error": (C.c_char_p, [_vp]),
+    "lfa_set_params": (_int, [_vp, C.POINTER(Params)]),
+    "lfa_get_params": (_int, [_vp, C.POINTER(Params)]),
+    "lfa_synchronize": (_int, [_vp]),
+    "lfa_stream": (_vp, [_vp]),
+    "lfa_upload_particles": (_int, [_vp, _vp, _u64]),
+    "lfa_download_particles": (_int, [_vp, _vp, _u64, _int]),
+    "lfa_num_particles": (_u64, [_vp]),
+    "lfa_seed_block": (_int, [_vp, _vp, _vp, _u64]),
+    "lfa_set_solid_cells": (_int, [_vp, _vp, _u64]),
+    "lfa_clear_solid_cells": (_int, [_vp]),
+    "lfa_upload_cells": (_int, [_vp, _vp]),
+    "lfa_download_cells": (_int, [_vp, _vp]),
+    "lfa_download_old_cells": (_int, [_vp, _vp]),
+    "lfa_hash_particles": (_int, [_vp]),
+    "lfa_num_fluid_cells": (_u64, [_vp]),
+    "lfa_download_fluid_cells": (_int, [_vp, _vp, _u64]),
+    "lfa_download_cell_counts": (_int, [_vp, _vp]),
+    "lfa_p2g": (_int, [_vp]),
+    "lfa_add_gravity": (_int, [_vp, _dbl]),
+    "lfa_build_system": (_int, [_vp, _dbl]),
+    "lfa_download_abits": (_int, [_vp, _vp, _u64]),
+    "lfa_download_rhs": (_int, [_vp, _vp, _u64]),
+    "lfa_download_precon": (_int, [_vp, _vp, _u64]),
+    "lfa_apply_preconditioner": (_int, [_vp, _vp, _vp, _u64]),
+    "lfa_apply_a": (_int, [_vp, _vp, _vp, _u64]),
+    "lfa_pcg_solve": (_int, [_vp, _dbl, C.POINTER(_dbl), C.POINTER(_u64)]),
+    "lfa_download_pressure": (_int, [_vp, _vp, _u64]),
+    "lfa_upload_pressure": (_int, [_vp, _vp, _u64]),
+    "lfa_apply_pressure": (_int, [_vp, _dbl]),
+    "lfa_extrapolate": (_int, [_vp]),
+    "lfa_g2p": (_int, [_vp]),
+    "lfa_cfl": (_int, [_vp, C.POINTER(_dbl)]),
+    "lfa_step_hot": (_int, [_vp, _dbl, C.POINTER(_dbl), C.POINTER(_u64)]),
+    "lfa_enable_timing": (_int, [_vp, _int]),
+    "lfa_get_timings": (_int, [_vp, C.POINTER(_dbl * NUM_TIMERS)]),
+    "lfa_get_counts": (_int, [_vp, C.POINTER(_u64 * 5)]),
+}
+
+
+def load_library():
+    """Loads libfluid_amd.so and binds every entry point of include/libfluid_amd.h. Raises if the library is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback for the hot path)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def default_params():
+    p = Params()
+    load_library().lfa_default_params(C.byref(p))
+    return p
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Sim:
+    """Handle to a device-resident simulation; mirrors the stage-level C ABI one-to-one."""
+
+    def __init__(self, size, cell_size=1.0, offset=(0.0, 0.0, 0.0), gravity=(0.0, -981.0, 0.0), method=APIC,
+                 blending=1.0, density=1.0, device=-1, **extra):
+        self.lib = load_library()
+        self.size = tuple(int(s) for s in size)
+        self.ncells = self.size[0] * self.size[1] * self.size[2]
+        h = C.c_void_p()
+        rc = self.lib.lfa_create(C.byref(h), *self.size, int(device))
+        if rc != 0:
+            raise LibfluidError(rc, self.lib.lfa_last_error(None).decode())
+        self.h = h
+        p = default_params()
+        p.cell_size = float(cell_size)
+        for k in range(3):
+            p.grid_offset[k] = float(offset[k])
+            p.gravity[k] = float(gravity[k])
+        p.simulation_method = int(method)
+        p.blending_factor = float(blending)
+        p.density = float(density)
+        self.params = p
+        self.set_params(**extra)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lfa_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise LibfluidError(rc, self.lib.lfa_last_error(self.h).decode())
+        return rc
+
+    def set_params(self, **kw):
+        for k, v in kw.items():
+            if not hasattr(self.params, k):
+                raise AttributeError(k)
+            setattr(self.params, k, v)
+        self._chk(self.lib.lfa_set_params(self.h, C.byref(self.params)))
+
+    def synchronize(self):
+        self._chk(self.lib.lfa_synchronize(self.h))
+
+    @property
+    def stream(self):
+        return self.lib.lfa_stream(self.h)
+
+    # -- data ----------------------------------------------------------------------------------------------
+    def upload_particles(self, parts):
+        parts = np.ascontiguousarray(parts, dtype=PARTICLE_DTYPE)
+        self._chk(self.lib.lfa_upload_particles(self.h, _ptr(parts), parts.shape[0]))
+
+    def download_particles(self, into=None, write_positions=False):
+        n = self.num_particles
+        out = np.zeros(n, dtype=PARTICLE_DTYPE) if into is None else into
+        self._chk(self.lib.lfa_download_particles(self.h, _ptr(out), n, 1 if (write_positions or into is None) else 0))
+        return out
+
+    @property
+    def num_particles(self):
+        return int(self.lib.lfa_num_particles(self.h))
+
+    def seed_block(self, lo, hi, seed=scenes.SEED):
+        lo = np.asarray(lo, dtype=np.int64)
+        hi = np.asarray(hi, dtype=np.int64)
+        self._chk(self.lib.lfa_seed_block(self.h, _ptr(lo), _ptr(hi), int(seed)))
+
+    def set_solid_cells(self, xyz):
+        xyz = np.ascontiguousarray(xyz, dtype=np.int32).reshape(-1, 3)
+        self._chk(self.lib.lfa_set_solid_cells(self.h, _ptr(xyz), xyz.shape[0]))
+
+    def clear_solid_cells(self):
+        self._chk(self.lib.lfa_clear_solid_cells(self.h))
+
+    def upload_cells(self, cells):
+        cells = np.ascontiguousarray(cells, dtype=CELL_DTYPE)
+        assert cells.shape[0] == self.ncells
+        self._chk(self.lib.lfa_upload_cells(self.h, _ptr(cells)))
+
+    def cells(self):
+        out = np.zeros(self.ncells, dtype=CELL_DTYPE)
+        self._chk(self.lib.lfa_download_cells(self.h, _ptr(out)))
+        return out
+
+    def old_cells(self):
+        out = np.zeros(self.ncells, dtype=CELL_DTYPE)
+        self._chk(self.lib.lfa_download_old_cells(self.h, _ptr(out)))
+        return out
+
+    # -- stages ------------------------------------------------------------------------------------------
+    def hash(self):
+        self._chk(self.lib.lfa_hash_particles(self.h))
+
+    @property
+    def num_fluid_cells(self):
+        return int(self.lib.lfa_num_fluid_cells(self.h))
+
+    def fluid_cells(self):
+        n = self.num_fluid_cells
+        out = np.zeros(n, dtype=np.uint64)
+        self._chk(self.lib.lfa_download_fluid_cells(self.h, _ptr(out), n))
+        return out
+
+    def cell_counts(self):
+        out = np.zeros(self.ncells, dtype=np.uint32)
+        self._chk(self.lib.lfa_download_cell_counts(self.h, _ptr(out)))
+        return out
+
+    def p2g(self):
+        self._chk(self.lib.lfa_p2g(self.h))
+
+    def add_gravity(self, dt):
+        self._chk(self.lib.lfa_add_gravity(self.h, float(dt)))
+
+    def build_system(self, dt):
+        self._chk(self.lib.lfa_build_system(self.h, float(dt)))
+
+    def _vec(self, fn, dtype=np.float64):
+        n = self.num_fluid_cells
+        out = np.zeros(n, dtype=dtype)
+        self._chk(fn(self.h, _ptr(out), n))
+        return out
+
+    def abits(self):
+        return self._vec(self.lib.lfa_download_abits, np.uint8)
+
+    def b(self):
+        return self._vec(self.lib.lfa_download_rhs)
+
+    def precon(self):
+        return self._vec(self.lib.lfa_download_precon)
+
+    def pressure(self):
+        return self._vec(self.lib.lfa_download_pressure)
+
+    def upload_pressure(self, p):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        self._chk(self.lib.lfa_upload_pressure(self.h, _ptr(p), p.shape[0]))
+
+    def apply_precon(self, r):
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        z = np.zeros_like(r)
+        self._chk(self.lib.lfa_apply_preconditioner(self.h, _ptr(r), _ptr(z), r.shape[0]))
+        return z
+
+    def apply_a(self, v):
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        out = np.zeros_like(v)
+        self._chk(self.lib.lfa_apply_a(self.h, _ptr(v), _ptr(out), v.shape[0]))
+        return out
+
+    def solve(self, dt):
+        """Returns (pressure in the reference's unknown order, residual, iterations, return code)."""
+        res, it = C.c_double(0.0), C.c_uint64(0)
+        rc = self._chk(self.lib.lfa_pcg_solve(self.h, float(dt), C.byref(res), C.byref(it)))
+        return self.pressure(), res.value, it.value, rc
+
+    def apply_pressure(self, dt):
+        self._chk(self.lib.lfa_apply_pressure(self.h, float(dt)))
+
+    def extrapolate(self):
+        self._chk(self.lib.lfa_extrapolate(self.h))
+
+    def g2p(self):
+        self._chk(self.lib.lfa_g2p(self.h))
+
+    def cfl(self):
+        out = C.c_double(0.0)
+        self._chk(self.lib.lfa_cfl(self.h, C.byref(out)))
+        return out.value
+
+    def step_hot(self, dt):
+        """One device-resident pass of the hot path; returns (residual, iterations, return code)."""
+        res, it = C.c_double(0.0), C.c_uint64(0)
+        rc = self._chk(self.lib.lfa_step_hot(self.h, float(dt), C.byref(res), C.byref(it)))
+        return res.value, it.value, rc
+
+    # -- measurement ---------------------------------------------------------------------------------------
+    def enable_timing(self, on=True):
+        self._chk(self.lib.lfa_enable_timing(self.h, 1 if on else 0))
+
+    def timings(self):
+        arr = (C.c_double * NUM_TIMERS)()
+        self._chk(self.lib.lfa_get_timings(self.h, C.byref(arr)))
+        return dict(zip(TIMER_NAMES, list(arr)))
+
+    def counts(self):
+        arr = (C.c_uint64 * 5)()
+        self._chk(self.lib.lfa_get_counts(self.h, C.byref(arr)))
+        return dict(zip(["particles", "unknowns", "particle_tiles", "processed_tiles", "padded_cells"], list(arr)))

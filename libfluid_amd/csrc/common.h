@@ -1,0 +1,177 @@
+// libfluid_amd/csrc/common.h -- device state, blocked-grid indexing and small device helpers shared by all kernels.
+//
+// Data layout in HBM:
+//  * The MAC grid is stored TILE-MAJOR: 8x8x8 tiles (512 cells, 2 KiB per fp32 field), tile id x-fastest, cells inside a
+//    tile x-fastest. A tile is the unit of work of every grid kernel (one wave owns one tile in the PCG kernels, one
+//    workgroup in the transfer kernels), so every field access of a tile is one contiguous 2 KiB run.
+//    The reference's x-fastest dense layout (include/fluid/data_structures/grid.h:11-12,23-32) exists only at the
+//    boundary (upload/download kernels re-index).
+//  * Particles are fp32 SoA, binned by tile (not by cell): key = blocked cell index, t = position inside the cell in
+//    cell units (exact integer part kept in the key, so precision is 2^-24 of a cell everywhere in the domain).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/libfluid_amd.h"
+
+#define LFA_TILE 8
+#define LFA_TILE_CELLS 512
+#define LFA_HALO 10            // tile + 1-cell ring
+#define LFA_HALO_CELLS 1000
+#define LFA_WAVE 64
+
+// cell type bits: reference values (include/fluid/mac_grid.h:17-21) + "outside the grid" marker for padding cells.
+#define CT_AIR 1
+#define CT_FLUID 2
+#define CT_SOLID 4
+#define CT_OUTSIDE 0x80
+
+// abits byte: bits0-2 nonsolid_neighbors, bit3/4/5 fluid_{x,y,z}pos (include/fluid/pressure_solver.h:17-26),
+// bit6 = "is an unknown" (cell holds particles), bit7 = cell type is fluid.
+#define AB_UNKNOWN 0x40
+#define AB_FLUID 0x80
+
+struct ParticleSoA {
+	uint32_t *key = nullptr;  // blocked cell index
+	float *t[3] = {nullptr, nullptr, nullptr};
+	float *v[3] = {nullptr, nullptr, nullptr};
+	float *c[9] = {nullptr};  // cx.xyz, cy.xyz, cz.xyz
+	uint32_t *id = nullptr;   // index in the caller's array (upload order)
+	void *base = nullptr;
+};
+
+struct GridDims {
+	int nx, ny, nz;     // real grid
+	int ntx, nty, ntz;  // tiles
+	int nt;             // ntx*nty*ntz
+};
+
+struct lfa_sim {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	GridDims g{};
+	size_t nc = 0, ncp = 0;  // real / padded cell count
+	lfa_params prm{};
+	std::string err;
+
+	// particles
+	size_t np = 0, pcap = 0;
+	ParticleSoA pb[2];
+	int cur = 0;
+	uint32_t *rank = nullptr;
+	bool binned = false;
+
+	// tiles
+	uint32_t *tile_count = nullptr, *tile_start = nullptr;  // nt, nt+1
+	uint32_t *tile_flag = nullptr, *tile_scan = nullptr;    // nt
+	int *ptiles = nullptr, *dtiles = nullptr;               // nt
+	int *tile_pslot = nullptr;                               // nt : slot in ptiles or -1
+	int n_ptiles = 0, n_dtiles = 0;
+	uint32_t *scan_tmp = nullptr;
+	size_t scan_tmp_len = 0;
+	uint32_t *h_pinned = nullptr;  // small pinned scratch for device->host scalars
+
+	// grid (blocked layout, ncp entries)
+	float *u = nullptr, *v = nullptr, *w = nullptr;
+	float *uo = nullptr, *vo = nullptr, *wo = nullptr;
+	uint8_t *ctype = nullptr, *solid = nullptr;
+	uint32_t *cell_count = nullptr;
+	float *stage = nullptr;  // P2G per-tile partial sums [n_ptiles][6][1000]
+	size_t stage_tiles = 0;
+	float *acc = nullptr;    // global-atomic P2G accumulators [6][ncp]
+	double bg[3] = {0, 0, 0};  // velocity of every cell outside the processed (dilated) tile set
+	bool grid_valid = false;   // P2G has run since the last upload
+
+	// pressure system
+	uint8_t *abits = nullptr;
+	void *vp = nullptr, *vr = nullptr, *vz = nullptr, *vs = nullptr, *vpre = nullptr, *vq = nullptr;
+	size_t vec_elem = 0;  // element size the vectors are currently allocated for
+	double *partials = nullptr;  // reduction partials
+	int *pcg_state = nullptr;    // [0] done_iter  [1] nan flag
+	double *pcg_hist = nullptr;  // residual per iteration
+	int *level_tiles = nullptr;  // ptile slots sorted by tile level (exact MIC)
+	std::vector<int> level_offsets;  // host: start of every level in level_tiles
+	double a_scale = 0.0, sys_dt = -1.0;
+	uint64_t n_unknowns = 0;
+	bool system_valid = false, unknown_count_valid = false;
+	double last_residual = 0.0;
+	uint64_t last_iters = 0;
+
+	// boundary scratch
+	void *io_buf = nullptr;
+	size_t io_cap = 0;
+	uint32_t *raw_scan = nullptr;  // nc+1 : raw-order unknown numbering
+
+	// timing
+	bool timing = false;
+	hipEvent_t ev[24];
+	bool ev_created = false;
+	double ms[LFA_NUM_TIMERS] = {0};
+};
+
+// ---------------------------------------------------------------------------------------------------- error handling
+int lfa_fail(lfa_sim *s, int code, const char *fmt, ...);
+#define LFA_HIP(s, call)                                                                                   \
+	do {                                                                                                    \
+		hipError_t e_ = (call);                                                                             \
+		if (e_ != hipSuccess)                                                                               \
+			return lfa_fail((s), e_ == hipErrorOutOfMemory ? LFA_E_OOM : LFA_E_HIP, "%s failed: %s (%s:%d)", \
+			                #call, hipGetErrorString(e_), __FILE__, __LINE__);                              \
+	} while (0)
+#define LFA_TRY(call)          \
+	do {                       \
+		int rc_ = (call);      \
+		if (rc_ < 0) return rc_; \
+	} while (0)
+#define LFA_LAUNCH_CHECK(s) LFA_HIP(s, hipGetLastError())
+
+// ---------------------------------------------------------------------------------------------------- indexing
+__host__ __device__ inline uint32_t blocked_index(const GridDims &g, int x, int y, int z) {
+	int tile = (x >> 3) + g.ntx * ((y >> 3) + g.nty * (z >> 3));
+	return (uint32_t)tile * LFA_TILE_CELLS + (uint32_t)((x & 7) | ((y & 7) << 3) | ((z & 7) << 6));
+}
+__host__ __device__ inline void tile_coords(const GridDims &g, int tile, int &tx, int &ty, int &tz) {
+	tx = tile % g.ntx;
+	int r = tile / g.ntx;
+	ty = r % g.nty;
+	tz = r / g.nty;
+}
+__host__ __device__ inline bool in_grid(const GridDims &g, int x, int y, int z) {
+	return (unsigned)x < (unsigned)g.nx && (unsigned)y < (unsigned)g.ny && (unsigned)z < (unsigned)g.nz;
+}
+/// Raw (reference, x-fastest) index of a blocked index; valid only for cells inside the real grid.
+__host__ __device__ inline uint64_t raw_from_blocked(const GridDims &g, uint32_t b) {
+	int tile = (int)(b >> 9), l = (int)(b & 511);
+	int tx, ty, tz;
+	tile_coords(g, tile, tx, ty, tz);
+	int x = tx * 8 + (l & 7), y = ty * 8 + ((l >> 3) & 7), z = tz * 8 + (l >> 6);
+	return (uint64_t)x + (uint64_t)g.nx * ((uint64_t)y + (uint64_t)g.ny * (uint64_t)z);
+}
+
+// ---------------------------------------------------------------------------------------------------- wave helpers
+template <typename T> __device__ inline T wave_sum(T v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+	return v;
+}
+template <typename T> __device__ inline T wave_max(T v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		T other = __shfl_xor(v, o, 64);
+		v = other > v ? other : v;
+	}
+	return v;
+}
+
+// generic exclusive scan of uint32 (scan.hip); out may alias in. Returns total in *total_dev (device) if non-null.
+int lfa_exclusive_scan_u32(lfa_sim *s, const uint32_t *in, uint32_t *out, size_t n, uint32_t *total_dev);
+
+// stage entry points implemented per file
+int lfa_particles_alloc(lfa_sim *s, size_t n);
+int lfa_ensure_io(lfa_sim *s, size_t bytes);
+int lfa_pcg_alloc(lfa_sim *s);
+int lfa_number_unknowns(lfa_sim *s);

@@ -1,0 +1,901 @@
+// libfluid_amd/csrc/core.hip -- handle lifetime, parameters, device scan, particle/grid boundary conversion and the
+// particle binning stage (reference rows a1, a2, a21, a22 of SURVEY.md section 8).
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "common.h"
+
+static thread_local std::string g_create_error;
+
+int lfa_fail(lfa_sim *s, int code, const char *fmt, ...) {
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	if (s) s->err = buf;
+	else g_create_error = buf;
+	return code;
+}
+
+// =============================================================================================== exclusive scan
+namespace {
+constexpr int SCAN_BS = 256, SCAN_IPT = 8, SCAN_TILE = SCAN_BS * SCAN_IPT;
+
+__device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t *lds, uint32_t &total) {
+	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+	uint32_t incl = v;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		uint32_t t = __shfl_up(incl, o, 64);
+		if (lane >= o) incl += t;
+	}
+	if (lane == 63) lds[wid] = incl;
+	__syncthreads();
+	uint32_t woff = 0, tot = 0;
+#pragma unroll
+	for (int i = 0; i < SCAN_BS / 64; ++i) {
+		uint32_t x = lds[i];
+		if (i < wid) woff += x;
+		tot += x;
+	}
+	__syncthreads();
+	total = tot;
+	return woff + incl - v;
+}
+
+__global__ void __launch_bounds__(SCAN_BS) k_scan_reduce(const uint32_t *in, uint32_t *block_sums, size_t n) {
+	__shared__ uint32_t lds[SCAN_BS / 64];
+	size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_IPT;
+	uint32_t sum = 0;
+#pragma unroll
+	for (int k = 0; k < SCAN_IPT; ++k)
+		if (base + k < n) sum += in[base + k];
+	sum = wave_sum(sum);
+	if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = sum;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t t = 0;
+		for (int i = 0; i < SCAN_BS / 64; ++i) t += lds[i];
+		block_sums[blockIdx.x] = t;
+	}
+}
+
+__global__ void __launch_bounds__(SCAN_BS)
+k_scan_local(const uint32_t *in, uint32_t *out, const uint32_t *block_offsets, size_t n, uint32_t *total_out) {
+	__shared__ uint32_t lds[SCAN_BS / 64];
+	size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_IPT;
+	uint32_t x[SCAN_IPT], sum = 0;
+#pragma unroll
+	for (int k = 0; k < SCAN_IPT; ++k) {
+		x[k] = base + k < n ? in[base + k] : 0u;
+		sum += x[k];
+	}
+	uint32_t total;
+	uint32_t off = block_exclusive_scan(sum, lds, total) + (block_offsets ? block_offsets[blockIdx.x] : 0u);
+#pragma unroll
+	for (int k = 0; k < SCAN_IPT; ++k) {
+		if (base + k < n) out[base + k] = off;
+		off += x[k];
+	}
+	if (total_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_BS - 1) *total_out = off;
+}
+}  // namespace
+
+static int scan_rec(lfa_sim *s, const uint32_t *in, uint32_t *out, size_t n, uint32_t *tmp, uint32_t *total_dev) {
+	size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+	if (nb == 1) {
+		hipLaunchKernelGGL(k_scan_local, dim3(1), dim3(SCAN_BS), 0, s->stream, in, out, (const uint32_t *)nullptr, n,
+		                   total_dev);
+		LFA_LAUNCH_CHECK(s);
+		return LFA_OK;
+	}
+	hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_BS), 0, s->stream, in, tmp, n);
+	LFA_LAUNCH_CHECK(s);
+	LFA_TRY(scan_rec(s, tmp, tmp, nb, tmp + ((nb + 3) & ~(size_t)3), nullptr));
+	hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nb), dim3(SCAN_BS), 0, s->stream, in, out, (const uint32_t *)tmp, n,
+	                   total_dev);
+	LFA_LAUNCH_CHECK(s);
+	return LFA_OK;
+}
+
+int lfa_exclusive_scan_u32(lfa_sim *s, const uint32_t *in, uint32_t *out, size_t n, uint32_t *total_dev) {
+	if (n == 0) {
+		if (total_dev) LFA_HIP(s, hipMemsetAsync(total_dev, 0, 4, s->stream));
+		return LFA_OK;
+	}
+	size_t need = 0;
+	for (size_t m = n; m > SCAN_TILE;) {
+		m = (m + SCAN_TILE - 1) / SCAN_TILE;
+		need += (m + 3) & ~(size_t)3;
+	}
+	need += 16;
+	if (need > s->scan_tmp_len) {
+		if (s->scan_tmp) LFA_HIP(s, hipFree(s->scan_tmp));
+		s->scan_tmp = nullptr;
+		LFA_HIP(s, hipMalloc(&s->scan_tmp, need * 4));
+		s->scan_tmp_len = need;
+	}
+	return scan_rec(s, in, out, n, s->scan_tmp, total_dev);
+}
+
+// =============================================================================================== lifetime
+extern "C" void lfa_default_params(lfa_params *p) {
+	memset(p, 0, sizeof *p);
+	// include/fluid/simulation.h:179-190, include/fluid/pressure_solver.h:38-42
+	p->cell_size = NAN;
+	p->blending_factor = 1.0;
+	p->density = 1.0;
+	p->boundary_skin_width = 0.1;
+	p->correction_stiffness = 5.0;
+	p->cfl_number = 3.0;
+	p->velocity_extrapolation_iterations = 1;
+	p->simulation_method = LFA_APIC;
+	p->tau = 0.97;
+	p->sigma = 0.25;
+	p->tolerance = 1e-6;
+	p->max_iterations = 200;
+	p->p2g_variant = LFA_P2G_LDS_BINNED;
+	p->precond = LFA_PRECOND_MIC0_TILED;
+	p->pcg_dtype = LFA_PCG_F32;
+	p->apic_unscaled_kernel = 1;
+}
+
+template <typename T> static int dev_alloc(lfa_sim *s, T **p, size_t count, bool zero) {
+	*p = nullptr;
+	if (count == 0) count = 1;
+	hipError_t e = hipMalloc((void **)p, count * sizeof(T));
+	if (e != hipSuccess)
+		return lfa_fail(s, LFA_E_OOM, "hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
+	if (zero) LFA_HIP(s, hipMemsetAsync(*p, 0, count * sizeof(T), s->stream));
+	return LFA_OK;
+}
+
+__global__ void k_init_ctype(uint8_t *ctype, uint8_t *solid, GridDims g, size_t ncp) {
+	size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= ncp) return;
+	int tile = (int)(b >> 9), l = (int)(b & 511), tx, ty, tz;
+	tile_coords(g, tile, tx, ty, tz);
+	bool in = in_grid(g, tx * 8 + (l & 7), ty * 8 + ((l >> 3) & 7), tz * 8 + (l >> 6));
+	ctype[b] = in ? CT_AIR : (CT_SOLID | CT_OUTSIDE);
+	solid[b] = in ? 0 : 1;
+}
+
+extern "C" int lfa_create(lfa_sim **out, uint64_t nx, uint64_t ny, uint64_t nz, int device) {
+	if (!out) return lfa_fail(nullptr, LFA_E_INVALID, "lfa_create: out is NULL");
+	*out = nullptr;
+	if (nx == 0 || ny == 0 || nz == 0 || nx > 4096 || ny > 4096 || nz > 4096)
+		return lfa_fail(nullptr, LFA_E_INVALID, "lfa_create: grid size %llux%llux%llu out of range",
+		                (unsigned long long)nx, (unsigned long long)ny, (unsigned long long)nz);
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+		return lfa_fail(nullptr, LFA_E_NO_DEVICE, "lfa_create: no HIP device available (there is no CPU fallback)");
+	if (device < 0) {
+		if (hipGetDevice(&device) != hipSuccess) device = 0;
+	}
+	if (device >= ndev) return lfa_fail(nullptr, LFA_E_NO_DEVICE, "lfa_create: device %d of %d", device, ndev);
+	if (hipSetDevice(device) != hipSuccess) return lfa_fail(nullptr, LFA_E_NO_DEVICE, "hipSetDevice(%d) failed", device);
+
+	lfa_sim *s = new lfa_sim();
+	s->device = device;
+	GridDims &g = s->g;
+	g.nx = (int)nx; g.ny = (int)ny; g.nz = (int)nz;
+	g.ntx = (g.nx + 7) / 8; g.nty = (g.ny + 7) / 8; g.ntz = (g.nz + 7) / 8;
+	g.nt = g.ntx * g.nty * g.ntz;
+	s->nc = (size_t)nx * ny * nz;
+	s->ncp = (size_t)g.nt * LFA_TILE_CELLS;
+	if (s->ncp >= ((size_t)1 << 32)) {
+		delete s;
+		return lfa_fail(nullptr, LFA_E_INVALID, "lfa_create: more than 2^32 padded cells");
+	}
+	lfa_default_params(&s->prm);
+	int rc = LFA_OK;
+	auto chk = [&](int r) { if (rc == LFA_OK && r != LFA_OK) rc = r; };
+	if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
+		delete s;
+		return lfa_fail(nullptr, LFA_E_HIP, "hipStreamCreate failed");
+	}
+	chk(dev_alloc(s, &s->tile_count, g.nt + 1, true));
+	chk(dev_alloc(s, &s->tile_start, g.nt + 1, true));
+	chk(dev_alloc(s, &s->tile_flag, g.nt + 1, true));
+	chk(dev_alloc(s, &s->tile_scan, g.nt + 1, true));
+	chk(dev_alloc(s, &s->ptiles, g.nt, true));
+	chk(dev_alloc(s, &s->dtiles, g.nt, true));
+	chk(dev_alloc(s, &s->tile_pslot, g.nt, true));
+	chk(dev_alloc(s, &s->level_tiles, g.nt, true));
+	chk(dev_alloc(s, &s->u, s->ncp, true));
+	chk(dev_alloc(s, &s->v, s->ncp, true));
+	chk(dev_alloc(s, &s->w, s->ncp, true));
+	chk(dev_alloc(s, &s->ctype, s->ncp, true));
+	chk(dev_alloc(s, &s->solid, s->ncp, true));
+	chk(dev_alloc(s, &s->cell_count, s->ncp, true));
+	chk(dev_alloc(s, &s->abits, s->ncp, true));
+	chk(dev_alloc(s, &s->partials, 6 * 2048, true));
+	chk(dev_alloc(s, &s->pcg_state, 16, true));
+	chk(dev_alloc(s, &s->pcg_hist, 4096, true));
+	if (rc == LFA_OK && hipHostMalloc((void **)&s->h_pinned, 4096, hipHostMallocDefault) != hipSuccess)
+		rc = lfa_fail(s, LFA_E_HIP, "hipHostMalloc failed");
+	if (rc == LFA_OK) {
+		hipLaunchKernelGGL(k_init_ctype, dim3((unsigned)((s->ncp + 255) / 256)), dim3(256), 0, s->stream, s->ctype,
+		                   s->solid, s->g, s->ncp);
+		if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess)
+			rc = lfa_fail(s, LFA_E_HIP, "grid initialisation kernel failed (is the code object built for this GPU?)");
+	}
+	if (rc != LFA_OK) {
+		g_create_error = s->err;
+		lfa_destroy(s);
+		return rc;
+	}
+	*out = s;
+	return LFA_OK;
+}
+
+static void free_soa(ParticleSoA &p) {
+	if (p.base) (void)hipFree(p.base);
+	p = ParticleSoA();
+}
+
+extern "C" void lfa_destroy(lfa_sim *s) {
+	if (!s) return;
+	(void)hipSetDevice(s->device);
+	if (s->stream) (void)hipStreamSynchronize(s->stream);
+	free_soa(s->pb[0]);
+	free_soa(s->pb[1]);
+	void *ptrs[] = {s->rank, s->tile_count, s->tile_start, s->tile_flag, s->tile_scan, s->ptiles, s->dtiles,
+	                s->tile_pslot, s->scan_tmp, s->u, s->v, s->w, s->uo, s->vo, s->wo, s->ctype, s->solid,
+	                s->cell_count, s->stage, s->acc, s->abits, s->vp, s->vr, s->vz, s->vs, s->vpre, s->vq,
+	                s->partials, s->pcg_state, s->pcg_hist, s->level_tiles, s->io_buf, s->raw_scan};
+	for (void *p : ptrs)
+		if (p) (void)hipFree(p);
+	if (s->h_pinned) (void)hipHostFree(s->h_pinned);
+	if (s->ev_created)
+		for (auto &e : s->ev) (void)hipEventDestroy(e);
+	if (s->stream) (void)hipStreamDestroy(s->stream);
+	delete s;
+}
+
+extern "C" const char *lfa_last_error(const lfa_sim *s) { return s ? s->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int lfa_set_params(lfa_sim *s, const lfa_params *p) {
+	if (!s || !p) return LFA_E_INVALID;
+	if (!(p->cell_size > 0.0)) return lfa_fail(s, LFA_E_INVALID, "cell_size must be > 0 (got %g)", p->cell_size);
+	if (p->simulation_method < 0 || p->simulation_method > 2) return lfa_fail(s, LFA_E_INVALID, "bad simulation_method");
+	if (p->velocity_extrapolation_iterations > 8)
+		return lfa_fail(s, LFA_E_UNSUPPORTED, "velocity_extrapolation_iterations > 8 exceeds the 1-tile dilation");
+	if (p->max_iterations > 4000) return lfa_fail(s, LFA_E_INVALID, "max_iterations > 4000");
+	if (p->simulation_method == LFA_APIC && p->apic_unscaled_kernel && p->cell_size != 1.0)
+		return lfa_fail(s, LFA_E_UNSUPPORTED,
+		                "APIC with the reference's unscaled kernel (simulation.cpp:367-369) is only implemented for "
+		                "cell_size == 1; set apic_unscaled_kernel = 0");
+	if (p->pcg_dtype != s->prm.pcg_dtype) s->system_valid = false;
+	s->prm = *p;
+	return LFA_OK;
+}
+extern "C" int lfa_get_params(const lfa_sim *s, lfa_params *p) {
+	if (!s || !p) return LFA_E_INVALID;
+	*p = s->prm;
+	return LFA_OK;
+}
+extern "C" int lfa_synchronize(lfa_sim *s) {
+	if (!s) return LFA_E_INVALID;
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	return LFA_OK;
+}
+extern "C" void *lfa_stream(lfa_sim *s) { return s ? (void *)s->stream : nullptr; }
+extern "C" uint64_t lfa_num_particles(const lfa_sim *s) { return s ? s->np : 0; }
+
+int lfa_ensure_io(lfa_sim *s, size_t bytes) {
+	if (bytes <= s->io_cap) return LFA_OK;
+	if (s->io_buf) LFA_HIP(s, hipFree(s->io_buf));
+	s->io_buf = nullptr;
+	s->io_cap = 0;
+	hipError_t e = hipMalloc(&s->io_buf, bytes);
+	if (e != hipSuccess) return lfa_fail(s, LFA_E_OOM, "hipMalloc(%zu) for the boundary buffer failed", bytes);
+	s->io_cap = bytes;
+	return LFA_OK;
+}
+
+// =============================================================================================== particles in/out
+int lfa_particles_alloc(lfa_sim *s, size_t n) {
+	if (n <= s->pcap) return LFA_OK;
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	size_t cap = (n + 1023) & ~(size_t)1023;
+	for (int b = 0; b < 2; ++b) {
+		free_soa(s->pb[b]);
+		ParticleSoA &p = s->pb[b];
+		hipError_t e = hipMalloc(&p.base, cap * 17 * 4);
+		if (e != hipSuccess) return lfa_fail(s, LFA_E_OOM, "hipMalloc of particle SoA (%zu particles) failed", cap);
+		float *f = (float *)p.base;
+		p.key = (uint32_t *)f;
+		for (int k = 0; k < 3; ++k) p.t[k] = f + cap * (1 + k);
+		for (int k = 0; k < 3; ++k) p.v[k] = f + cap * (4 + k);
+		for (int k = 0; k < 9; ++k) p.c[k] = f + cap * (7 + k);
+		p.id = (uint32_t *)(f + cap * 16);
+	}
+	if (s->rank) LFA_HIP(s, hipFree(s->rank));
+	s->rank = nullptr;
+	LFA_HIP(s, hipMalloc(&s->rank, cap * 4));
+	s->pcap = cap;
+	return LFA_OK;
+}
+
+struct IngestParams {
+	double off[3], h;
+};
+
+/// Position -> (clamped cell, in-cell fraction). The cell is computed in fp64 with a true division exactly like
+/// src/simulation.cpp:253-257 (std::max(pos,0) -> size_t cast -> min(..., size-1)), so keys are bit-exact.
+/// The fraction is fp32 in [0,1]; it is 1.0f only when the position lies on/over the max face (the reference's
+/// unclamped index == size case, src/simulation.cpp:13-23), otherwise it is kept strictly below 1.
+__device__ inline void cell_and_fraction(double pos, double off, double h, int n, int &cell, float &t) {
+	double gp = (pos - off) / h;
+	double m = gp < 0.0 ? 0.0 : gp;
+	int c = m >= (double)n ? n - 1 : (int)m;
+	if (c > n - 1) c = n - 1;
+	double td = gp - (double)c;
+	float tf = (float)td;
+	if (!(tf > 0.0f)) tf = 0.0f;
+	if (td < 1.0 && tf >= 1.0f) tf = 0.99999994f;
+	if (tf > 1.0f) tf = 1.0f;
+	cell = c;
+	t = tf;
+}
+
+__global__ void k_ingest(const double *aos, size_t n, ParticleSoA p, GridDims g, IngestParams ip) {
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const double *q = aos + i * 19;
+	int c[3];
+	float t[3];
+	cell_and_fraction(q[0], ip.off[0], ip.h, g.nx, c[0], t[0]);
+	cell_and_fraction(q[1], ip.off[1], ip.h, g.ny, c[1], t[1]);
+	cell_and_fraction(q[2], ip.off[2], ip.h, g.nz, c[2], t[2]);
+	p.key[i] = blocked_index(g, c[0], c[1], c[2]);
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		p.t[k][i] = t[k];
+		p.v[k][i] = (float)q[3 + k];
+	}
+#pragma unroll
+	for (int k = 0; k < 9; ++k) p.c[k][i] = (float)q[6 + k];
+	p.id[i] = (uint32_t)i;
+}
+
+extern "C" int lfa_upload_particles(lfa_sim *s, const void *aos152, uint64_t n) {
+	if (!s || (!aos152 && n)) return LFA_E_INVALID;
+	if (!(s->prm.cell_size > 0.0)) return lfa_fail(s, LFA_E_INVALID, "set cell_size (lfa_set_params) before uploading");
+	if (n >= ((uint64_t)1 << 32)) return lfa_fail(s, LFA_E_INVALID, "more than 2^32 particles");
+	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_particles_alloc(s, n));
+	s->np = n;
+	s->binned = false;
+	s->grid_valid = false;
+	s->system_valid = false;
+	s->unknown_count_valid = false;
+	s->cur = 0;
+	if (n == 0) return LFA_OK;
+	LFA_TRY(lfa_ensure_io(s, n * 152));
+	LFA_HIP(s, hipMemcpyAsync(s->io_buf, aos152, n * 152, hipMemcpyHostToDevice, s->stream));
+	IngestParams ip;
+	for (int k = 0; k < 3; ++k) ip.off[k] = s->prm.grid_offset[k];
+	ip.h = s->prm.cell_size;
+	hipLaunchKernelGGL(k_ingest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, (const double *)s->io_buf,
+	                   (size_t)n, s->pb[0], s->g, ip);
+	LFA_LAUNCH_CHECK(s);
+	LFA_HIP(s, hipStreamSynchronize(s->stream));  // the host buffer may be reused by the caller
+	return LFA_OK;
+}
+
+__global__ void k_export(double *aos, size_t n, ParticleSoA p, GridDims g, IngestParams ip, int write_pos) {
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	double *q = aos + (size_t)p.id[i] * 19;
+	uint32_t b = p.key[i];
+	if (write_pos) {
+		int tile = (int)(b >> 9), l = (int)(b & 511), tx, ty, tz;
+		tile_coords(g, tile, tx, ty, tz);
+		int c[3] = {tx * 8 + (l & 7), ty * 8 + ((l >> 3) & 7), tz * 8 + (l >> 6)};
+#pragma unroll
+		for (int k = 0; k < 3; ++k) {
+			double x = ip.off[k] + ((double)c[k] + (double)p.t[k][i]) * ip.h;
+			q[k] = x;
+			q[15 + k] = x;
+		}
+	}
+#pragma unroll
+	for (int k = 0; k < 3; ++k) q[3 + k] = (double)p.v[k][i];
+#pragma unroll
+	for (int k = 0; k < 9; ++k) q[6 + k] = (double)p.c[k][i];
+	((uint64_t *)q)[18] = raw_from_blocked(g, b);
+}
+
+extern "C" int lfa_download_particles(lfa_sim *s, void *aos152, uint64_t n, int write_positions) {
+	if (!s || (!aos152 && n)) return LFA_E_INVALID;
+	if (n != s->np) return lfa_fail(s, LFA_E_INVALID, "download of %llu particles but %zu are resident",
+	                                (unsigned long long)n, s->np);
+	if (n == 0) return LFA_OK;
+	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_ensure_io(s, n * 152));
+	// start from the caller's records so fields the device does not own (positions unless asked) survive
+	LFA_HIP(s, hipMemcpyAsync(s->io_buf, aos152, n * 152, hipMemcpyHostToDevice, s->stream));
+	IngestParams ip;
+	for (int k = 0; k < 3; ++k) ip.off[k] = s->prm.grid_offset[k];
+	ip.h = s->prm.cell_size;
+	hipLaunchKernelGGL(k_export, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, (double *)s->io_buf,
+	                   (size_t)n, s->pb[s->cur], s->g, ip, write_positions);
+	LFA_LAUNCH_CHECK(s);
+	LFA_HIP(s, hipMemcpyAsync(aos152, s->io_buf, n * 152, hipMemcpyDeviceToHost, s->stream));
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	return LFA_OK;
+}
+
+// ---- synthetic dam-break block, twin of libfluid_amd/scenes.py:seed_block
+__device__ inline uint64_t splitmix64(uint64_t x) {
+	x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+	x ^= x >> 27; x *= 0x94D049BB133111EBull;
+	x ^= x >> 31;
+	return x;
+}
+__global__ void k_seed_block(size_t n, ParticleSoA p, GridDims g, IngestParams ip, int lox, int loy, int loz, int ex,
+                             int ey, uint64_t seed) {
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	size_t ci = i >> 3;
+	int sub = (int)(i & 7);
+	int cell[3] = {lox + (int)(ci % ex), loy + (int)((ci / ex) % ey), loz + (int)(ci / ((size_t)ex * ey))};
+	int sb[3] = {sub & 1, (sub >> 1) & 1, (sub >> 2) & 1};
+	int c[3];
+	float t[3];
+	const int nn[3] = {g.nx, g.ny, g.nz};
+#pragma unroll
+	for (int a = 0; a < 3; ++a) {
+		uint64_t ctr = 3ull * (uint64_t)i + (uint64_t)a;
+		uint64_t x = seed + (ctr + 1ull) * 0x9E3779B97F4A7C15ull;
+		double uu = (double)(splitmix64(x) >> 11) * (1.0 / 9007199254740992.0);
+		double pos = ip.off[a] + ((double)cell[a] + ((double)sb[a] + uu) * 0.5) * ip.h;
+		cell_and_fraction(pos, ip.off[a], ip.h, nn[a], c[a], t[a]);
+	}
+	p.key[i] = blocked_index(g, c[0], c[1], c[2]);
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		p.t[k][i] = t[k];
+		p.v[k][i] = 0.0f;
+	}
+#pragma unroll
+	for (int k = 0; k < 9; ++k) p.c[k][i] = 0.0f;
+	p.id[i] = (uint32_t)i;
+}
+
+extern "C" int lfa_seed_block(lfa_sim *s, const int64_t lo[3], const int64_t hi[3], uint64_t seed) {
+	if (!s || !lo || !hi) return LFA_E_INVALID;
+	if (!(s->prm.cell_size > 0.0)) return lfa_fail(s, LFA_E_INVALID, "set cell_size before seeding");
+	const int nn[3] = {s->g.nx, s->g.ny, s->g.nz};
+	for (int a = 0; a < 3; ++a)
+		if (lo[a] < 0 || hi[a] > nn[a] || lo[a] >= hi[a]) return lfa_fail(s, LFA_E_INVALID, "seed block outside the grid");
+	size_t n = (size_t)(hi[0] - lo[0]) * (size_t)(hi[1] - lo[1]) * (size_t)(hi[2] - lo[2]) * 8;
+	if (n >= ((size_t)1 << 32)) return lfa_fail(s, LFA_E_INVALID, "more than 2^32 particles");
+	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_particles_alloc(s, n));
+	s->np = n;
+	s->binned = false;
+	s->grid_valid = false;
+	s->system_valid = false;
+	s->unknown_count_valid = false;
+	s->cur = 0;
+	IngestParams ip;
+	for (int k = 0; k < 3; ++k) ip.off[k] = s->prm.grid_offset[k];
+	ip.h = s->prm.cell_size;
+	hipLaunchKernelGGL(k_seed_block, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, s->pb[0], s->g, ip,
+	                   (int)lo[0], (int)lo[1], (int)lo[2], (int)(hi[0] - lo[0]), (int)(hi[1] - lo[1]), seed);
+	LFA_LAUNCH_CHECK(s);
+	return LFA_OK;
+}
+
+// =============================================================================================== solids / cells
+__global__ void k_set_solid(const int32_t *xyz, size_t k, uint8_t *solid, uint8_t *ctype, GridDims g) {
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= k) return;
+	int x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+	if (!in_grid(g, x, y, z)) return;
+	uint32_t b = blocked_index(g, x, y, z);
+	solid[b] = 1;
+	ctype[b] = CT_SOLID;
+}
+
+extern "C" int lfa_set_solid_cells(lfa_sim *s, const int32_t *xyz, uint64_t k) {
+	if (!s || (!xyz && k)) return LFA_E_INVALID;
+	if (k == 0) return LFA_OK;
+	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_ensure_io(s, k * 12));
+	LFA_HIP(s, hipMemcpyAsync(s->io_buf, xyz, k * 12, hipMemcpyHostToDevice, s->stream));
+	hipLaunchKernelGGL(k_set_solid, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, s->stream,
+	                   (const int32_t *)s->io_buf, (size_t)k, s->solid, s->ctype, s->g);
+	LFA_LAUNCH_CHECK(s);
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	s->system_valid = false;
+	return LFA_OK;
+}
+
+extern "C" int lfa_clear_solid_cells(lfa_sim *s) {
+	if (!s) return LFA_E_INVALID;
+	LFA_HIP(s, hipSetDevice(s->device));
+	hipLaunchKernelGGL(k_init_ctype, dim3((unsigned)((s->ncp + 255) / 256)), dim3(256), 0, s->stream, s->ctype, s->solid,
+	                   s->g, s->ncp);
+	LFA_LAUNCH_CHECK(s);
+	s->system_valid = false;
+	s->grid_valid = false;
+	return LFA_OK;
+}
+
+struct CellAos {
+	double vel[3];
+	uint8_t type;
+	uint8_t pad[7];
+};
+
+/// dense x-fastest 32-B AoS <- blocked fp32 SoA. Grid kernels only touch the processed (dilated) tile set; every other
+/// tile is implicit: its value is the base (0 after a P2G, the stored value after an explicit upload) plus the
+/// background `bg` = gravity accumulated since then (src/simulation.cpp:72-78 adds g*dt to EVERY cell).
+__global__ void k_export_cells(CellAos *out, GridDims g, size_t nc, const float *u, const float *v, const float *w,
+                               const uint8_t *ctype, const uint8_t *solid, const uint32_t *tile_flag, int have_dilated,
+                               int explicit_base, double bgx, double bgy, double bgz) {
+	size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= nc) return;
+	int x = (int)(r % g.nx), y = (int)((r / g.nx) % g.ny), z = (int)(r / ((size_t)g.nx * g.ny));
+	uint32_t b = blocked_index(g, x, y, z);
+	CellAos c;
+	memset(&c, 0, sizeof c);
+	bool active = have_dilated && tile_flag[b >> 9] != 0;
+	if (active) {
+		c.vel[0] = (double)u[b]; c.vel[1] = (double)v[b]; c.vel[2] = (double)w[b];
+		c.type = ctype[b] & 7;
+	} else if (explicit_base) {
+		c.vel[0] = (double)u[b] + bgx; c.vel[1] = (double)v[b] + bgy; c.vel[2] = (double)w[b] + bgz;
+		c.type = ctype[b] & 7;
+	} else {
+		c.vel[0] = bgx; c.vel[1] = bgy; c.vel[2] = bgz;
+		c.type = solid[b] ? CT_SOLID : CT_AIR;
+	}
+	out[r] = c;
+}
+
+static int export_cells(lfa_sim *s, void *aos32, const float *u, const float *v, const float *w, bool old) {
+	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_ensure_io(s, s->nc * 32));
+	hipLaunchKernelGGL(k_export_cells, dim3((unsigned)((s->nc + 255) / 256)), dim3(256), 0, s->stream,
+	                   (CellAos *)s->io_buf, s->g, s->nc, u, v, w, s->ctype, s->solid, s->tile_flag, s->binned ? 1 : 0,
+	                   s->grid_valid ? 0 : 1, old ? 0.0 : s->bg[0], old ? 0.0 : s->bg[1], old ? 0.0 : s->bg[2]);
+	LFA_LAUNCH_CHECK(s);
+	LFA_HIP(s, hipMemcpyAsync(aos32, s->io_buf, s->nc * 32, hipMemcpyDeviceToHost, s->stream));
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	return LFA_OK;
+}
+
+extern "C" int lfa_download_cells(lfa_sim *s, void *aos32) {
+	if (!s || !aos32) return LFA_E_INVALID;
+	return export_cells(s, aos32, s->u, s->v, s->w, false);
+}
+extern "C" int lfa_download_old_cells(lfa_sim *s, void *aos32) {
+	if (!s || !aos32) return LFA_E_INVALID;
+	if (!s->uo) return lfa_fail(s, LFA_E_INVALID, "no old grid: FLIP P2G has not run");
+	return export_cells(s, aos32, s->uo, s->vo, s->wo, true);
+}
+
+__global__ void k_import_cells(const CellAos *in, GridDims g, size_t nc, float *u, float *v, float *w, uint8_t *ctype,
+                               uint8_t *solid) {
+	size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= nc) return;
+	int x = (int)(r % g.nx), y = (int)((r / g.nx) % g.ny), z = (int)(r / ((size_t)g.nx * g.ny));
+	uint32_t b = blocked_index(g, x, y, z);
+	CellAos c = in[r];
+	u[b] = (float)c.vel[0]; v[b] = (float)c.vel[1]; w[b] = (float)c.vel[2];
+	ctype[b] = c.type & 7;
+	solid[b] = (c.type & CT_SOLID) ? 1 : 0;
+}
+
+extern "C" int lfa_upload_cells(lfa_sim *s, const void *aos32) {
+	if (!s || !aos32) return LFA_E_INVALID;
+	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_ensure_io(s, s->nc * 32));
+	LFA_HIP(s, hipMemcpyAsync(s->io_buf, aos32, s->nc * 32, hipMemcpyHostToDevice, s->stream));
+	hipLaunchKernelGGL(k_import_cells, dim3((unsigned)((s->nc + 255) / 256)), dim3(256), 0, s->stream,
+	                   (const CellAos *)s->io_buf, s->g, s->nc, s->u, s->v, s->w, s->ctype, s->solid);
+	LFA_LAUNCH_CHECK(s);
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	// an uploaded grid is fully explicit: no implicit background, every tile counts as processed
+	s->grid_valid = false;
+	s->bg[0] = s->bg[1] = s->bg[2] = 0.0;
+	s->system_valid = false;
+	return LFA_OK;
+}
+
+// =============================================================================================== binning (a2)
+/// Pass 1: particles per tile + rank of each particle inside its tile. One atomic per (wave, distinct tile):
+/// particles arrive tile-coherent (they were binned last step and move < 1 tile), so a wave sees 1-3 distinct tiles.
+__global__ void k_tile_count(const uint32_t *key, size_t n, uint32_t *tile_count, uint32_t *rank) {
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	bool live = i < n;
+	uint32_t tile = live ? key[i] >> 9 : 0xFFFFFFFFu;
+	const int lane = threadIdx.x & 63;
+	uint32_t my_rank = 0;
+	unsigned long long todo = __ballot(live);
+	while (todo) {
+		int leader = __ffsll((long long)todo) - 1;
+		uint32_t t = __shfl(tile, leader, 64);
+		unsigned long long same = __ballot(live && tile == t) & todo;
+		uint32_t base = 0;
+		if (lane == leader) base = atomicAdd(&tile_count[t], (uint32_t)__popcll(same));
+		base = __shfl(base, leader, 64);
+		if (live && tile == t) my_rank = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+		todo &= ~same;
+	}
+	if (live) rank[i] = my_rank;
+}
+
+__global__ void k_tile_flags(const uint32_t *tile_count, uint32_t *flag, int nt) {
+	int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t < nt) flag[t] = tile_count[t] > 0 ? 1u : 0u;
+}
+__global__ void k_compact_tiles(const uint32_t *flag, const uint32_t *scan, int *list, int *slot_of, int nt) {
+	int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= nt) return;
+	if (flag[t]) {
+		list[scan[t]] = t;
+		if (slot_of) slot_of[t] = (int)scan[t];
+	} else if (slot_of) {
+		slot_of[t] = -1;
+	}
+}
+/// Every tile within one tile of a particle tile gets processed by the grid kernels (P2G reaches 1 cell, extrapolation
+/// up to 8 cells, G2P 2 cells beyond a particle's cell).
+__global__ void k_dilate(const int *ptiles, int n_ptiles, uint32_t *flag, GridDims g) {
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_ptiles * 27) return;
+	int t = ptiles[i / 27], o = i % 27, tx, ty, tz;
+	tile_coords(g, t, tx, ty, tz);
+	int x = tx + o % 3 - 1, y = ty + (o / 3) % 3 - 1, z = tz + o / 9 - 1;
+	if ((unsigned)x < (unsigned)g.ntx && (unsigned)y < (unsigned)g.nty && (unsigned)z < (unsigned)g.ntz)
+		flag[x + g.ntx * (y + g.nty * z)] = 1u;
+}
+
+/// Pass 2: move every particle to its tile's segment. With `shuffle` the slot inside the segment is a multiplicative
+/// permutation of the rank, which separates particles of one cell (uploads arrive cell-sorted; neighbouring lanes
+/// hitting one cell would serialise the LDS atomics of the P2G scatter).
+__global__ void k_tile_scatter(size_t n, ParticleSoA src, ParticleSoA dst, const uint32_t *rank,
+                               const uint32_t *tile_start, const uint32_t *tile_count, int shuffle) {
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	uint32_t key = src.key[i], tile = key >> 9, r = rank[i];
+	if (shuffle) {
+		uint32_t cnt = tile_count[tile];
+		if (cnt % 1000003u != 0) r = (uint32_t)(((uint64_t)r * 1000003ull) % cnt);
+	}
+	size_t d = (size_t)tile_start[tile] + r;
+	dst.key[d] = key;
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		dst.t[k][d] = src.t[k][i];
+		dst.v[k][d] = src.v[k][i];
+	}
+#pragma unroll
+	for (int k = 0; k < 9; ++k) dst.c[k][d] = src.c[k][i];
+	dst.id[d] = src.id[i];
+}
+
+/// Particles per cell for every processed tile (the `count` half of _space_hash, src/simulation.cpp:266-291);
+/// tiles of the dilated set that hold no particles get zeros.
+__global__ void __launch_bounds__(256)
+k_cell_count(const int *dtiles, int n_dtiles, const uint32_t *key, const uint32_t *tile_start, uint32_t *cell_count) {
+	__shared__ uint32_t cnt[LFA_TILE_CELLS];
+	for (int slot = blockIdx.x; slot < n_dtiles; slot += gridDim.x) {
+		int tile = dtiles[slot];
+		cnt[threadIdx.x] = 0;
+		cnt[threadIdx.x + 256] = 0;
+		__syncthreads();
+		uint32_t b = tile_start[tile], e = tile_start[tile + 1];
+		for (uint32_t i = b + threadIdx.x; i < e; i += 256) atomicAdd(&cnt[key[i] & 511], 1u);
+		__syncthreads();
+		cell_count[(size_t)tile * LFA_TILE_CELLS + threadIdx.x] = cnt[threadIdx.x];
+		cell_count[(size_t)tile * LFA_TILE_CELLS + 256 + threadIdx.x] = cnt[threadIdx.x + 256];
+		__syncthreads();
+	}
+}
+
+extern "C" int lfa_hash_particles(lfa_sim *s) {
+	if (!s) return LFA_E_INVALID;
+	LFA_HIP(s, hipSetDevice(s->device));
+	const GridDims &g = s->g;
+	const int nt = g.nt;
+	const size_t n = s->np;
+	ParticleSoA &src = s->pb[s->cur], &dst = s->pb[s->cur ^ 1];
+	LFA_HIP(s, hipMemsetAsync(s->tile_count, 0, (size_t)(nt + 1) * 4, s->stream));
+	if (n) {
+		hipLaunchKernelGGL(k_tile_count, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, src.key, n,
+		                   s->tile_count, s->rank);
+		LFA_LAUNCH_CHECK(s);
+	}
+	// tile_start[0..nt] (exclusive scan; entry nt = total because tile_count[nt] == 0)
+	LFA_TRY(lfa_exclusive_scan_u32(s, s->tile_count, s->tile_start, (size_t)nt + 1, nullptr));
+	// particle tiles
+	hipLaunchKernelGGL(k_tile_flags, dim3((nt + 255) / 256), dim3(256), 0, s->stream, s->tile_count, s->tile_flag, nt);
+	LFA_LAUNCH_CHECK(s);
+	LFA_TRY(lfa_exclusive_scan_u32(s, s->tile_flag, s->tile_scan, (size_t)nt, (uint32_t *)s->pcg_state + 8));
+	hipLaunchKernelGGL(k_compact_tiles, dim3((nt + 255) / 256), dim3(256), 0, s->stream, s->tile_flag, s->tile_scan,
+	                   s->ptiles, s->tile_pslot, nt);
+	LFA_LAUNCH_CHECK(s);
+	LFA_HIP(s, hipMemcpyAsync(s->h_pinned, (uint32_t *)s->pcg_state + 8, 4, hipMemcpyDeviceToHost, s->stream));
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	s->n_ptiles = (int)s->h_pinned[0];
+	// dilated set
+	LFA_HIP(s, hipMemsetAsync(s->tile_flag, 0, (size_t)(nt + 1) * 4, s->stream));
+	if (s->n_ptiles) {
+		hipLaunchKernelGGL(k_dilate, dim3((s->n_ptiles * 27 + 255) / 256), dim3(256), 0, s->stream, s->ptiles,
+		                   s->n_ptiles, s->tile_flag, g);
+		LFA_LAUNCH_CHECK(s);
+	}
+	LFA_TRY(lfa_exclusive_scan_u32(s, s->tile_flag, s->tile_scan, (size_t)nt, (uint32_t *)s->pcg_state + 9));
+	hipLaunchKernelGGL(k_compact_tiles, dim3((nt + 255) / 256), dim3(256), 0, s->stream, s->tile_flag, s->tile_scan,
+	                   s->dtiles, (int *)nullptr, nt);
+	LFA_LAUNCH_CHECK(s);
+	LFA_HIP(s, hipMemcpyAsync(s->h_pinned, (uint32_t *)s->pcg_state + 9, 4, hipMemcpyDeviceToHost, s->stream));
+	if (n) {
+		hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, src, dst,
+		                   s->rank, s->tile_start, s->tile_count, s->binned ? 0 : 1);
+		LFA_LAUNCH_CHECK(s);
+		s->cur ^= 1;
+	}
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	s->n_dtiles = (int)s->h_pinned[0];
+	if (s->n_dtiles) {
+		int grid = s->n_dtiles < 8192 ? s->n_dtiles : 8192;
+		hipLaunchKernelGGL(k_cell_count, dim3(grid), dim3(256), 0, s->stream, s->dtiles, s->n_dtiles,
+		                   s->pb[s->cur].key, s->tile_start, s->cell_count);
+		LFA_LAUNCH_CHECK(s);
+	}
+	s->binned = true;
+	s->system_valid = false;
+	s->unknown_count_valid = false;
+	return LFA_OK;
+}
+
+// ---- fluid-cell list at the boundary (reference order = ascending raw index)
+__global__ void k_raw_unknown_flags(GridDims g, size_t nc, const uint32_t *cell_count, const uint32_t *tile_flag,
+                                    uint32_t *flag) {
+	size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= nc) return;
+	int x = (int)(r % g.nx), y = (int)((r / g.nx) % g.ny), z = (int)(r / ((size_t)g.nx * g.ny));
+	uint32_t b = blocked_index(g, x, y, z);
+	flag[r] = (tile_flag[b >> 9] && cell_count[b] > 0) ? 1u : 0u;
+}
+
+/// Numbers the unknowns in the reference's order; raw_scan[r] = unknown index of raw cell r (valid where flagged).
+int lfa_number_unknowns(lfa_sim *s) {
+	if (s->unknown_count_valid) return LFA_OK;
+	if (!s->binned) return lfa_fail(s, LFA_E_INVALID, "call lfa_hash_particles first");
+	if (!s->raw_scan) LFA_HIP(s, hipMalloc(&s->raw_scan, (s->nc + 1) * 4));
+	hipLaunchKernelGGL(k_raw_unknown_flags, dim3((unsigned)((s->nc + 255) / 256)), dim3(256), 0, s->stream, s->g, s->nc,
+	                   s->cell_count, s->tile_flag, s->raw_scan);
+	LFA_LAUNCH_CHECK(s);
+	LFA_TRY(lfa_exclusive_scan_u32(s, s->raw_scan, s->raw_scan, s->nc, (uint32_t *)s->pcg_state + 10));
+	LFA_HIP(s, hipMemcpyAsync(s->h_pinned, (uint32_t *)s->pcg_state + 10, 4, hipMemcpyDeviceToHost, s->stream));
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	s->n_unknowns = s->h_pinned[0];
+	s->unknown_count_valid = true;
+	return LFA_OK;
+}
+
+extern "C" uint64_t lfa_num_fluid_cells(lfa_sim *s) {
+	if (!s || lfa_number_unknowns(s) != LFA_OK) return 0;
+	return s->n_unknowns;
+}
+
+__global__ void k_export_fluid_cells(GridDims g, size_t nc, const uint32_t *cell_count, const uint32_t *tile_flag,
+                                     const uint32_t *raw_scan, uint64_t *out) {
+	size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= nc) return;
+	int x = (int)(r % g.nx), y = (int)((r / g.nx) % g.ny), z = (int)(r / ((size_t)g.nx * g.ny));
+	uint32_t b = blocked_index(g, x, y, z);
+	if (tile_flag[b >> 9] && cell_count[b] > 0) out[raw_scan[r]] = r;
+}
+
+extern "C" int lfa_download_fluid_cells(lfa_sim *s, uint64_t *raw, uint64_t n) {
+	if (!s || (!raw && n)) return LFA_E_INVALID;
+	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_number_unknowns(s));
+	if (n != s->n_unknowns) return lfa_fail(s, LFA_E_INVALID, "fluid cell count is %llu", (unsigned long long)s->n_unknowns);
+	if (n == 0) return LFA_OK;
+	LFA_TRY(lfa_ensure_io(s, n * 8));
+	hipLaunchKernelGGL(k_export_fluid_cells, dim3((unsigned)((s->nc + 255) / 256)), dim3(256), 0, s->stream, s->g, s->nc,
+	                   s->cell_count, s->tile_flag, s->raw_scan, (uint64_t *)s->io_buf);
+	LFA_LAUNCH_CHECK(s);
+	LFA_HIP(s, hipMemcpyAsync(raw, s->io_buf, n * 8, hipMemcpyDeviceToHost, s->stream));
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	return LFA_OK;
+}
+
+__global__ void k_export_counts(GridDims g, size_t nc, const uint32_t *cell_count, const uint32_t *tile_flag,
+                                uint32_t *out) {
+	size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= nc) return;
+	int x = (int)(r % g.nx), y = (int)((r / g.nx) % g.ny), z = (int)(r / ((size_t)g.nx * g.ny));
+	uint32_t b = blocked_index(g, x, y, z);
+	out[r] = tile_flag[b >> 9] ? cell_count[b] : 0u;
+}
+
+extern "C" int lfa_download_cell_counts(lfa_sim *s, uint32_t *count) {
+	if (!s || !count) return LFA_E_INVALID;
+	if (!s->binned) return lfa_fail(s, LFA_E_INVALID, "call lfa_hash_particles first");
+	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_ensure_io(s, s->nc * 4));
+	hipLaunchKernelGGL(k_export_counts, dim3((unsigned)((s->nc + 255) / 256)), dim3(256), 0, s->stream, s->g, s->nc,
+	                   s->cell_count, s->tile_flag, (uint32_t *)s->io_buf);
+	LFA_LAUNCH_CHECK(s);
+	LFA_HIP(s, hipMemcpyAsync(count, s->io_buf, s->nc * 4, hipMemcpyDeviceToHost, s->stream));
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	return LFA_OK;
+}
+
+// =============================================================================================== CFL (a21)
+__global__ void __launch_bounds__(256) k_max_speed2(size_t n, const float *vx, const float *vy, const float *vz, double *partials) {
+	__shared__ double lds[4];
+	double m = 0.0;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+		double x = vx[i], y = vy[i], z = vz[i];
+		double l = x * x + y * y + z * z;
+		m = l > m ? l : m;
+	}
+	m = wave_max(m);
+	if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = m;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		for (int i = 1; i < 4; ++i) m = lds[i] > m ? lds[i] : m;
+		partials[blockIdx.x] = m;
+	}
+}
+
+extern "C" int lfa_cfl(lfa_sim *s, double *out) {
+	if (!s || !out) return LFA_E_INVALID;
+	LFA_HIP(s, hipSetDevice(s->device));
+	double m = 0.0;
+	if (s->np) {
+		int grid = (int)((s->np + 255) / 256);
+		if (grid > 1024) grid = 1024;
+		const ParticleSoA &p = s->pb[s->cur];
+		hipLaunchKernelGGL(k_max_speed2, dim3(grid), dim3(256), 0, s->stream, s->np, p.v[0], p.v[1], p.v[2], s->partials);
+		LFA_LAUNCH_CHECK(s);
+		std::vector<double> h(grid);
+		LFA_HIP(s, hipMemcpyAsync(h.data(), s->partials, grid * 8, hipMemcpyDeviceToHost, s->stream));
+		LFA_HIP(s, hipStreamSynchronize(s->stream));
+		for (double x : h) m = x > m ? x : m;
+	}
+	*out = s->prm.cell_size / sqrt(m);  // +inf when all velocities are zero, like src/simulation.cpp:204
+	return LFA_OK;
+}
+
+// =============================================================================================== timing / counts
+extern "C" int lfa_enable_timing(lfa_sim *s, int on) {
+	if (!s) return LFA_E_INVALID;
+	LFA_HIP(s, hipSetDevice(s->device));
+	if (on && !s->ev_created) {
+		for (auto &e : s->ev) LFA_HIP(s, hipEventCreate(&e));
+		s->ev_created = true;
+	}
+	s->timing = on != 0;
+	return LFA_OK;
+}
+extern "C" int lfa_get_timings(lfa_sim *s, double ms[LFA_NUM_TIMERS]) {
+	if (!s || !ms) return LFA_E_INVALID;
+	for (int i = 0; i < LFA_NUM_TIMERS; ++i) ms[i] = s->ms[i];
+	return LFA_OK;
+}
+extern "C" int lfa_get_counts(lfa_sim *s, uint64_t counts[5]) {
+	if (!s || !counts) return LFA_E_INVALID;
+	counts[0] = s->np;
+	counts[1] = lfa_num_fluid_cells(s);
+	counts[2] = (uint64_t)s->n_ptiles;
+	counts[3] = (uint64_t)s->n_dtiles;
+	counts[4] = s->ncp;
+	return LFA_OK;
+}

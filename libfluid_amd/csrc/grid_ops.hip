@@ -1,0 +1,440 @@
+// libfluid_amd/csrc/grid_ops.hip -- MAC-grid stencil stages around the pressure solve
+// and the grid-to-particle transfer (a19, a20).
+//
+// All kernels walk the tile lists built by lfa_hash_particles: `ptiles` (tiles holding particles = tiles holding PCG
+// unknowns) and `dtiles` (their 27-neighbourhoods). A cell outside the dilated set is never read as data: its type is
+// solid/air from the persistent solid mask and it is never an unknown (cell_type_at / is_unknown_at below).
+#include "common.h"
+#include "pcg.h"
+
+namespace {
+
+struct GridView {
+	GridDims g;
+	const uint8_t *ctype, *solid;
+	const uint32_t *cell_count, *tile_flag;
+};
+/// mac_grid::get_cell_and_type (src/mac_grid.cpp:26-31): outside the grid => solid.
+__device__ inline int cell_type_at(const GridView &gv, int x, int y, int z) {
+	if (!in_grid(gv.g, x, y, z)) return CT_SOLID;
+	uint32_t b = blocked_index(gv.g, x, y, z);
+	if (gv.tile_flag[b >> 9]) return gv.ctype[b] & 7;
+	return gv.solid[b] ? CT_SOLID : CT_AIR;
+}
+/// Membership in the reference's _fluid_cells list (cells holding particles, src/simulation.cpp:83-94).
+__device__ inline bool is_unknown_at(const GridView &gv, int x, int y, int z) {
+	if (!in_grid(gv.g, x, y, z)) return false;
+	uint32_t b = blocked_index(gv.g, x, y, z);
+	return gv.tile_flag[b >> 9] && gv.cell_count[b] > 0;
+}
+
+// ---------------------------------------------------------------------------------------------- a10: A bits
+/// pressure_solver::_compute_a_matrix (src/pressure_solver.cpp:160-178) for every cell of every particle tile;
+/// non-unknown cells get 0 so that the PCG kernels can use the byte as a mask.
+__global__ void __launch_bounds__(256) k_abits(const int *ptiles, int n_ptiles, GridView gv, uint8_t *abits) {
+	for (int slot = blockIdx.x; slot < n_ptiles; slot += gridDim.x) {
+		const int tile = ptiles[slot];
+		int tx, ty, tz;
+		tile_coords(gv.g, tile, tx, ty, tz);
+#pragma unroll
+		for (int half = 0; half < 2; ++half) {
+			const int l = threadIdx.x + 256 * half;
+			const int x = tx * 8 + (l & 7), y = ty * 8 + ((l >> 3) & 7), z = tz * 8 + (l >> 6);
+			const size_t b = (size_t)tile * LFA_TILE_CELLS + l;
+			uint8_t a = 0;
+			if (in_grid(gv.g, x, y, z) && gv.cell_count[b] > 0) {
+				const int txp = cell_type_at(gv, x + 1, y, z), typ = cell_type_at(gv, x, y + 1, z),
+				          tzp = cell_type_at(gv, x, y, z + 1);
+				int ns = (txp != CT_SOLID) + (typ != CT_SOLID) + (tzp != CT_SOLID) +
+				         (cell_type_at(gv, x - 1, y, z) != CT_SOLID) + (cell_type_at(gv, x, y - 1, z) != CT_SOLID) +
+				         (cell_type_at(gv, x, y, z - 1) != CT_SOLID);
+				a = (uint8_t)(ns | ((txp == CT_FLUID) << 3) | ((typ == CT_FLUID) << 4) | ((tzp == CT_FLUID) << 5) |
+				              AB_UNKNOWN | (((gv.ctype[b] & 7) == CT_FLUID) ? AB_FLUID : 0));
+			}
+			abits[b] = a;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------- a11: divergence rhs
+/// pressure_solver::_compute_b_vector (src/pressure_solver.cpp:180-242), same term order; writes r = b for every cell
+/// of every particle tile (0 where the cell is not an unknown) and zeroes p.
+template <typename real>
+__global__ void __launch_bounds__(256)
+k_rhs(const int *ptiles, int n_ptiles, GridView gv, const float *u, const float *v, const float *w, real *r, real *p,
+      float inv_h, double *part_b2) {
+	__shared__ double lds[4];
+	double acc = 0.0;
+	for (int slot = blockIdx.x; slot < n_ptiles; slot += gridDim.x) {
+		const int tile = ptiles[slot];
+		int tx, ty, tz;
+		tile_coords(gv.g, tile, tx, ty, tz);
+#pragma unroll
+		for (int half = 0; half < 2; ++half) {
+			const int l = threadIdx.x + 256 * half;
+			const int x = tx * 8 + (l & 7), y = ty * 8 + ((l >> 3) & 7), z = tz * 8 + (l >> 6);
+			const size_t b = (size_t)tile * LFA_TILE_CELLS + l;
+			real out = (real)0;
+			if (in_grid(gv.g, x, y, z) && gv.cell_count[b] > 0) {
+				const float vx = u[b], vy = v[b], vz = w[b];
+				float val = -(vx + vy + vz);
+				if (x > 0) {
+					uint32_t n = blocked_index(gv.g, x - 1, y, z);
+					float f = u[n];
+					val += f;
+					if (cell_type_at(gv, x - 1, y, z) == CT_SOLID) val -= f;
+				}
+				if (y > 0) {
+					uint32_t n = blocked_index(gv.g, x, y - 1, z);
+					float f = v[n];
+					val += f;
+					if (cell_type_at(gv, x, y - 1, z) == CT_SOLID) val -= f;
+				}
+				if (z > 0) {
+					uint32_t n = blocked_index(gv.g, x, y, z - 1);
+					float f = w[n];
+					val += f;
+					if (cell_type_at(gv, x, y, z - 1) == CT_SOLID) val -= f;
+				}
+				if (cell_type_at(gv, x + 1, y, z) == CT_SOLID) val += vx;
+				if (cell_type_at(gv, x, y + 1, z) == CT_SOLID) val += vy;
+				if (cell_type_at(gv, x, y, z + 1) == CT_SOLID) val += vz;
+				out = (real)(inv_h * val);
+				acc += (double)out * (double)out;
+			}
+			r[b] = out;
+			p[b] = (real)0;
+		}
+	}
+	acc = wave_sum(acc);
+	if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+	__syncthreads();
+	if (threadIdx.x == 0) part_b2[blockIdx.x] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+}
+
+// ---------------------------------------------------------------------------------------------- a17: pressure gradient
+/// pressure_solver::apply_pressure (src/pressure_solver.cpp:73-148) restated per FACE instead of per unknown: the +d
+/// face of cell c (neighbour n = c + d) receives, in the reference's visiting order (c before n),
+///   from c if c is an unknown:  n non-solid ? u -= coeff*((n fluid ? p[n] : 0) - p[c]) : u = 0
+///   from n if n is an unknown:  c air ? u -= coeff*p[n] : (c solid ? u = 0 : nothing)
+template <typename real>
+__global__ void __launch_bounds__(256)
+k_apply_pressure(const int *dtiles, int n_dtiles, GridView gv, float *u, float *v, float *w, const real *p, float coeff) {
+	for (int slot = blockIdx.x; slot < n_dtiles; slot += gridDim.x) {
+		const int tile = dtiles[slot];
+		int tx, ty, tz;
+		tile_coords(gv.g, tile, tx, ty, tz);
+#pragma unroll
+		for (int half = 0; half < 2; ++half) {
+			const int l = threadIdx.x + 256 * half;
+			const int x = tx * 8 + (l & 7), y = ty * 8 + ((l >> 3) & 7), z = tz * 8 + (l >> 6);
+			if (!in_grid(gv.g, x, y, z)) continue;
+			const size_t b = (size_t)tile * LFA_TILE_CELLS + l;
+			const bool uc = gv.cell_count[b] > 0;
+			const int tc = gv.ctype[b] & 7;
+			const float pc = uc ? (float)p[b] : 0.0f;
+			float *vel[3] = {u, v, w};
+#pragma unroll
+			for (int d = 0; d < 3; ++d) {
+				const int nx = x + (d == 0), ny = y + (d == 1), nz = z + (d == 2);
+				const int tn = cell_type_at(gv, nx, ny, nz);
+				const bool un = is_unknown_at(gv, nx, ny, nz);
+				if (!uc && !un) continue;
+				float val = vel[d][b];
+				const float pn = un ? (float)p[blocked_index(gv.g, nx, ny, nz)] : 0.0f;
+				if (uc) {
+					if (tn != CT_SOLID) val -= coeff * ((tn == CT_FLUID ? pn : 0.0f) - pc);
+					else val = 0.0f;
+				}
+				if (un) {
+					if (tc == CT_AIR) val -= coeff * pn;
+					else if (tc == CT_SOLID) val = 0.0f;
+				}
+				vel[d][b] = val;
+			}
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------- a18: extrapolation
+/// One iteration of simulation::_extrapolate_velocities (src/simulation.cpp:700-752). Reads only valid cells and writes
+/// only invalid ones, so the sweep is order independent and runs in place.
+__global__ void __launch_bounds__(256)
+k_extrapolate(const int *dtiles, int n_dtiles, GridView gv, float *u, float *v, float *w, const uint8_t *valid_in,
+              uint8_t *valid_out) {
+	for (int slot = blockIdx.x; slot < n_dtiles; slot += gridDim.x) {
+		const int tile = dtiles[slot];
+		int tx, ty, tz;
+		tile_coords(gv.g, tile, tx, ty, tz);
+#pragma unroll
+		for (int half = 0; half < 2; ++half) {
+			const int l = threadIdx.x + 256 * half;
+			const int x = tx * 8 + (l & 7), y = ty * 8 + ((l >> 3) & 7), z = tz * 8 + (l >> 6);
+			const size_t b = (size_t)tile * LFA_TILE_CELLS + l;
+			if (!in_grid(gv.g, x, y, z)) {
+				if (valid_out) valid_out[b] = 0;
+				continue;
+			}
+			auto valid_at = [&](int xx, int yy, int zz) -> bool {
+				if (!valid_in) return is_unknown_at(gv, xx, yy, zz);
+				if (!in_grid(gv.g, xx, yy, zz)) return false;
+				uint32_t n = blocked_index(gv.g, xx, yy, zz);
+				return gv.tile_flag[n >> 9] && valid_in[n];
+			};
+			if (valid_at(x, y, z)) {
+				if (valid_out) valid_out[b] = 1;
+				continue;
+			}
+			int cnt = 0;
+			float sum[3] = {0.f, 0.f, 0.f};
+			int tpos[3] = {CT_SOLID, CT_SOLID, CT_SOLID};
+#pragma unroll
+			for (int d = 0; d < 3; ++d) {
+				const int c[3] = {x, y, z};
+				const int n_[3] = {gv.g.nx, gv.g.ny, gv.g.nz};
+				if (c[d] > 0) {
+					const int xx = x - (d == 0), yy = y - (d == 1), zz = z - (d == 2);
+					if (valid_at(xx, yy, zz)) {
+						uint32_t n = blocked_index(gv.g, xx, yy, zz);
+						sum[0] += u[n]; sum[1] += v[n]; sum[2] += w[n];
+						++cnt;
+					}
+				}
+				if (c[d] + 1 < n_[d]) {
+					const int xx = x + (d == 0), yy = y + (d == 1), zz = z + (d == 2);
+					if (valid_at(xx, yy, zz)) {
+						uint32_t n = blocked_index(gv.g, xx, yy, zz);
+						sum[0] += u[n]; sum[1] += v[n]; sum[2] += w[n];
+						tpos[d] = gv.ctype[n] & 7;
+						++cnt;
+					}
+				}
+			}
+			if (cnt > 0) {
+				const int mine = gv.ctype[b] & 7;
+				const float fc = (float)cnt;
+				if (mine == tpos[0]) u[b] = sum[0] / fc;
+				if (mine == tpos[1]) v[b] = sum[1] / fc;
+				if (mine == tpos[2]) w[b] = sum[2] / fc;
+			}
+			if (valid_out) valid_out[b] = cnt > 0 ? 1 : 0;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------- a19/a20: G2P
+/// Staggered sample of mac_grid::get_face_samples (src/mac_grid.cpp:51-112) for halo position (hx,hy,hz) of a tile:
+/// out-of-range cells replicate the border cell, and the component along a clamped axis is zero; note that the LAST
+/// cell of an axis counts as clamped (_clamp returns `clamped` for val >= max, :42-50).
+__device__ inline float clamped_sample(const GridDims &g, const float *f, int comp, int x, int y, int z) {
+	const int c[3] = {x, y, z};
+	const int n[3] = {g.nx, g.ny, g.nz};
+	if (c[comp] < 0 || c[comp] >= n[comp] - 1) return 0.0f;
+	const int xx = min(max(x, 0), g.nx - 1), yy = min(max(y, 0), g.ny - 1), zz = min(max(z, 0), g.nz - 1);
+	return f[blocked_index(g, xx, yy, zz)];
+}
+
+__device__ inline float lerp_ref(float a, float b, float t) { return a * (1.0f - t) + b * t; }  // include/fluid/misc.h:20-22
+
+struct G2PParams {
+	int method;
+	float blend;
+	float h;      // cell_size: _grad_kernel divides by it (src/simulation.cpp:223)
+};
+
+/// One workgroup per particle tile: stage u,v,w (and FLIP's old grid) of the tile + 1-cell ring in LDS with the
+/// clamping rule applied, then every particle of the tile gathers its 3x8 samples from LDS.
+/// PIC :447-461, FLIP blend :463-505, APIC + _calculate_c_vector :507-546.
+template <int METHOD>
+__global__ void __launch_bounds__(256)
+k_g2p(const int *ptiles, int n_ptiles, GridDims g, ParticleSoA p, const uint32_t *tile_start, const float *u,
+      const float *v, const float *w, const float *uo, const float *vo, const float *wo, G2PParams gp) {
+	constexpr int NF = METHOD == LFA_FLIP_BLEND ? 6 : 3;
+	__shared__ float lds[NF * LFA_HALO_CELLS];
+	for (int slot = blockIdx.x; slot < n_ptiles; slot += gridDim.x) {
+		const int tile = ptiles[slot];
+		int tx, ty, tz;
+		tile_coords(g, tile, tx, ty, tz);
+		__syncthreads();
+		for (int i = threadIdx.x; i < LFA_HALO_CELLS; i += 256) {
+			const int hx = i % 10, hy = (i / 10) % 10, hz = i / 100;
+			const int x = tx * 8 + hx - 1, y = ty * 8 + hy - 1, z = tz * 8 + hz - 1;
+			lds[i] = clamped_sample(g, u, 0, x, y, z);
+			lds[LFA_HALO_CELLS + i] = clamped_sample(g, v, 1, x, y, z);
+			lds[2 * LFA_HALO_CELLS + i] = clamped_sample(g, w, 2, x, y, z);
+			if (METHOD == LFA_FLIP_BLEND) {
+				lds[3 * LFA_HALO_CELLS + i] = clamped_sample(g, uo, 0, x, y, z);
+				lds[4 * LFA_HALO_CELLS + i] = clamped_sample(g, vo, 1, x, y, z);
+				lds[5 * LFA_HALO_CELLS + i] = clamped_sample(g, wo, 2, x, y, z);
+			}
+		}
+		__syncthreads();
+		const uint32_t beg = tile_start[tile], end = tile_start[tile + 1];
+		for (uint32_t i = beg + threadIdx.x; i < end; i += 256) {
+			const int l = (int)(p.key[i] & 511);
+			const int lc[3] = {l & 7, (l >> 3) & 7, l >> 6};
+			const float t[3] = {p.t[0][i], p.t[1][i], p.t[2][i]};
+			float vnew[3], vold[3];
+			float cvec[9];
+#pragma unroll
+			for (int comp = 0; comp < 3; ++comp) {
+				// (b, f) per axis exactly as in the P2G scatter: own axis -> (idx-1, t), other axes -> (d-1, tmid)
+				int b[3];
+				float f[3];
+#pragma unroll
+				for (int a = 0; a < 3; ++a) {
+					if (a == comp) {
+						b[a] = t[a] >= 1.0f ? 0 : -1;
+						f[a] = t[a] >= 1.0f ? 0.0f : t[a];
+					} else {
+						b[a] = t[a] < 0.5f ? -1 : 0;
+						f[a] = t[a] < 0.5f ? t[a] + 0.5f : t[a] - 0.5f;
+					}
+				}
+				const int base = (lc[0] + 1 + b[0]) + 10 * (lc[1] + 1 + b[1]) + 100 * (lc[2] + 1 + b[2]);
+				float s[8];
+#pragma unroll
+				for (int k = 0; k < 8; ++k)
+					s[k] = lds[comp * LFA_HALO_CELLS + base + (k & 1) + 10 * ((k >> 1) & 1) + 100 * (k >> 2)];
+				// trilerp nesting of include/fluid/misc.h:24-36: x innermost, then y, then z
+				vnew[comp] = lerp_ref(lerp_ref(lerp_ref(s[0], s[1], f[0]), lerp_ref(s[2], s[3], f[0]), f[1]),
+				                      lerp_ref(lerp_ref(s[4], s[5], f[0]), lerp_ref(s[6], s[7], f[0]), f[1]), f[2]);
+				if (METHOD == LFA_FLIP_BLEND) {
+					float o[8];
+#pragma unroll
+					for (int k = 0; k < 8; ++k)
+						o[k] = lds[(3 + comp) * LFA_HALO_CELLS + base + (k & 1) + 10 * ((k >> 1) & 1) + 100 * (k >> 2)];
+					vold[comp] = lerp_ref(lerp_ref(lerp_ref(o[0], o[1], f[0]), lerp_ref(o[2], o[3], f[0]), f[1]),
+					                      lerp_ref(lerp_ref(o[4], o[5], f[0]), lerp_ref(o[6], o[7], f[0]), f[1]), f[2]);
+				}
+				if (METHOD == LFA_APIC) {
+					// _calculate_c_vector: sum_k grad_kernel(f - corner_k) * s_k, _grad_kernel sign rule d > 0 ? -1 : +1
+					float cx = 0.f, cy = 0.f, cz = 0.f;
+#pragma unroll
+					for (int k = 0; k < 8; ++k) {
+						const float px = f[0] - (float)(k & 1), py = f[1] - (float)((k >> 1) & 1), pz = f[2] - (float)(k >> 2);
+						const float sx = px > 0.f ? -1.f : 1.f, sy = py > 0.f ? -1.f : 1.f, sz = pz > 0.f ? -1.f : 1.f;
+						const float ax = 1.f - fabsf(px), ay = 1.f - fabsf(py), az = 1.f - fabsf(pz);
+						cx = cx + (sx * ay * az / gp.h) * s[k];
+						cy = cy + (ax * sy * az / gp.h) * s[k];
+						cz = cz + (ax * ay * sz / gp.h) * s[k];
+					}
+					cvec[3 * comp] = cx; cvec[3 * comp + 1] = cy; cvec[3 * comp + 2] = cz;
+				}
+			}
+			if (METHOD == LFA_FLIP_BLEND) {
+#pragma unroll
+				for (int k = 0; k < 3; ++k) p.v[k][i] = vnew[k] + (p.v[k][i] - vold[k]) * gp.blend;
+			} else {
+#pragma unroll
+				for (int k = 0; k < 3; ++k) p.v[k][i] = vnew[k];
+			}
+			if (METHOD == LFA_APIC) {
+#pragma unroll
+				for (int k = 0; k < 9; ++k) p.c[k][i] = cvec[k];
+			}
+		}
+	}
+}
+}  // namespace
+
+static int grid_blocks(int n) { return n < 16384 ? (n > 0 ? n : 1) : 16384; }
+static GridView make_view(lfa_sim *s) { return GridView{s->g, s->ctype, s->solid, s->cell_count, s->tile_flag}; }
+
+/// a8-a11: unknown set, A bits and divergence; r = b, p = 0. The MIC(0) factor is built by pcg.hip.
+int lfa_build_rhs(lfa_sim *s, double dt) {
+	if (!s->binned) return lfa_fail(s, LFA_E_INVALID, "lfa_build_system: call lfa_hash_particles first");
+	LFA_TRY(lfa_pcg_alloc(s));
+	s->a_scale = dt / (s->prm.density * s->prm.cell_size * s->prm.cell_size);  // src/pressure_solver.cpp:22
+	s->sys_dt = dt;
+	if (!s->n_ptiles) return LFA_OK;
+	GridView gv = make_view(s);
+	hipLaunchKernelGGL(k_abits, dim3(grid_blocks(s->n_ptiles)), dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, gv,
+	                   s->abits);
+	LFA_LAUNCH_CHECK(s);
+	const int G = pcg_grid(s->n_ptiles);
+	const float inv_h = (float)(1.0 / s->prm.cell_size);
+	if (s->prm.pcg_dtype == LFA_PCG_F64)
+		hipLaunchKernelGGL(k_rhs<double>, dim3(G), dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, gv, s->u, s->v, s->w,
+		                   (double *)s->vr, (double *)s->vp, inv_h, s->partials + PART_B2);
+	else
+		hipLaunchKernelGGL(k_rhs<float>, dim3(G), dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, gv, s->u, s->v, s->w,
+		                   (float *)s->vr, (float *)s->vp, inv_h, s->partials + PART_B2);
+	LFA_LAUNCH_CHECK(s);
+	return LFA_OK;
+}
+
+extern "C" int lfa_apply_pressure(lfa_sim *s, double dt) {
+	if (!s) return LFA_E_INVALID;
+	if (!s->binned || !s->vp) return lfa_fail(s, LFA_E_INVALID, "lfa_apply_pressure: no pressure on the device");
+	LFA_HIP(s, hipSetDevice(s->device));
+	if (!s->n_dtiles) return LFA_OK;
+	const float coeff = (float)(dt / (s->prm.density * s->prm.cell_size));  // src/pressure_solver.cpp:74
+	GridView gv = make_view(s);
+	dim3 grid(grid_blocks(s->n_dtiles));
+	if (s->prm.pcg_dtype == LFA_PCG_F64)
+		hipLaunchKernelGGL(k_apply_pressure<double>, grid, dim3(256), 0, s->stream, s->dtiles, s->n_dtiles, gv, s->u, s->v,
+		                   s->w, (const double *)s->vp, coeff);
+	else
+		hipLaunchKernelGGL(k_apply_pressure<float>, grid, dim3(256), 0, s->stream, s->dtiles, s->n_dtiles, gv, s->u, s->v,
+		                   s->w, (const float *)s->vp, coeff);
+	LFA_LAUNCH_CHECK(s);
+	return LFA_OK;
+}
+
+extern "C" int lfa_extrapolate(lfa_sim *s) {
+	if (!s) return LFA_E_INVALID;
+	if (!s->binned) return lfa_fail(s, LFA_E_INVALID, "lfa_extrapolate: call lfa_hash_particles first");
+	LFA_HIP(s, hipSetDevice(s->device));
+	const int iters = (int)s->prm.velocity_extrapolation_iterations;
+	if (!s->n_dtiles || iters == 0) return LFA_OK;
+	GridView gv = make_view(s);
+	dim3 grid(grid_blocks(s->n_dtiles));
+	if (iters == 1) {
+		hipLaunchKernelGGL(k_extrapolate, grid, dim3(256), 0, s->stream, s->dtiles, s->n_dtiles, gv, s->u, s->v, s->w,
+		                   (const uint8_t *)nullptr, (uint8_t *)nullptr);
+		LFA_LAUNCH_CHECK(s);
+		return LFA_OK;
+	}
+	// several iterations: cells made valid by iteration i are used from iteration i+1 on (src/simulation.cpp:694-698).
+	// The validity masks live in the (otherwise idle at this point) PCG scratch vector q: two byte planes.
+	LFA_TRY(lfa_pcg_alloc(s));
+	uint8_t *va = (uint8_t *)s->vq, *vb = va + s->ncp;
+	for (int i = 0; i < iters; ++i) {
+		hipLaunchKernelGGL(k_extrapolate, grid, dim3(256), 0, s->stream, s->dtiles, s->n_dtiles, gv, s->u, s->v, s->w,
+		                   i == 0 ? (const uint8_t *)nullptr : (const uint8_t *)va, vb);
+		LFA_LAUNCH_CHECK(s);
+		uint8_t *t = va; va = vb; vb = t;
+	}
+	return LFA_OK;
+}
+
+extern "C" int lfa_g2p(lfa_sim *s) {
+	if (!s) return LFA_E_INVALID;
+	if (!s->binned) return lfa_fail(s, LFA_E_INVALID, "lfa_g2p: call lfa_hash_particles first");
+	LFA_HIP(s, hipSetDevice(s->device));
+	if (!s->n_ptiles) return LFA_OK;
+	G2PParams gp;
+	gp.method = s->prm.simulation_method;
+	gp.blend = (float)s->prm.blending_factor;
+	gp.h = (float)s->prm.cell_size;
+	dim3 grid(grid_blocks(s->n_ptiles));
+	const ParticleSoA &p = s->pb[s->cur];
+	switch (s->prm.simulation_method) {
+	case LFA_PIC:
+		hipLaunchKernelGGL(k_g2p<LFA_PIC>, grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, s->g, p, s->tile_start,
+		                   s->u, s->v, s->w, s->uo, s->vo, s->wo, gp);
+		break;
+	case LFA_FLIP_BLEND:
+		if (!s->uo) return lfa_fail(s, LFA_E_INVALID, "lfa_g2p: FLIP needs the old grid written by lfa_p2g");
+		hipLaunchKernelGGL(k_g2p<LFA_FLIP_BLEND>, grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, s->g, p,
+		                   s->tile_start, s->u, s->v, s->w, s->uo, s->vo, s->wo, gp);
+		break;
+	default:
+		hipLaunchKernelGGL(k_g2p<LFA_APIC>, grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, s->g, p, s->tile_start,
+		                   s->u, s->v, s->w, s->uo, s->vo, s->wo, gp);
+		break;
+	}
+	LFA_LAUNCH_CHECK(s);
+	return LFA_OK;
+}

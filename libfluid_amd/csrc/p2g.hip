@@ -1,0 +1,345 @@
+// libfluid_amd/csrc/p2g.hip -- particle-to-grid transfer on the MAC grid.
+//
+// Reference: simulation::_transfer_to_grid_{pic,flip,apic} (src/simulation.cpp:293-398) is a serial GATHER: every cell
+// visits the particles of its 27 neighbour cells and evaluates the trilinear hat (_kernel, :207-213) at its three
+// face centres. Here it is the transposed SCATTER: each particle touches exactly the 2x2x2 face samples per component
+// whose hat weight is non-zero, evaluated in cell-relative coordinates (key = cell, t = fraction in the cell):
+//     axis a of component c:  s = t_a - (a == c ? 1 : 1/2),  b = floor(s) in {-1,0},  f = s - b
+//     target cell offset  b + i (i = 0,1), 1-D weight  (1-f, f),  (p - face)_a / h = f - i
+// which is the same set of (cell, weight) pairs the gather produces.
+//
+// Two variants (BASELINE config 2):
+//   LDS-binned   one workgroup per particle tile accumulates (sum w v, sum w) for its 10x10x10 halo block in LDS
+//                (ds_add_f32), streams the tile's particles once, coalesced, and stores the block to a per-tile
+//                staging slab; the finalize kernel adds the up to 8 overlapping slabs per cell in a fixed order.
+//                No global atomics.
+//   global-atomic one thread per particle, 48 global_atomic_add_f32 into dense accumulators.
+// Finalize = normalise (weight > 1e-6 else 0, :324/:383), cell typing (:329-334), APIC boundary-face zeroing
+// (_remove_boundary_velocities :428-445), FLIP's old-grid copy (:340-344) and, inside lfa_step_hot, gravity (:72-78).
+#include "common.h"
+
+namespace {
+
+/// (b, f) of one axis. `own` = this axis is the component's own (non-staggered) axis.
+/// own: s = t - 1  -> b = -1, f = t (b = 0, f = 0 when the particle sits on the max face, t == 1);
+/// else: s = t - 1/2 -> (b, f) = (-1, t + 1/2) or (0, t - 1/2): the `tmid` of src/mac_grid.cpp:80-93.
+__device__ inline void axis_bf(float t, bool own, int &b, float &f) {
+	if (own) {
+		b = t >= 1.0f ? 0 : -1;
+		f = t >= 1.0f ? 0.0f : t;
+	} else {
+		b = t < 0.5f ? -1 : 0;
+		f = t < 0.5f ? t + 0.5f : t - 0.5f;
+	}
+}
+
+/// Accumulates one particle into a 10x10x10 block of (sum_wv, sum_w) pairs per component.
+/// acc layout: [comp][2][1000], halo cell index = hx + 10 hy + 100 hz.
+template <bool APIC, typename AddFn>
+__device__ inline void scatter_particle(int lx, int ly, int lz, const float t[3], const float v[3], const float c[9],
+                                        float hworld, AddFn add) {
+#pragma unroll
+	for (int comp = 0; comp < 3; ++comp) {
+		int b[3];
+		float f[3];
+#pragma unroll
+		for (int a = 0; a < 3; ++a) axis_bf(t[a], a == comp, b[a], f[a]);
+		const int hx0 = lx + 1 + b[0], hy0 = ly + 1 + b[1], hz0 = lz + 1 + b[2];
+		float wx[2] = {1.0f - f[0], f[0]}, wy[2] = {1.0f - f[1], f[1]}, wz[2] = {1.0f - f[2], f[2]};
+		float ax[2] = {0.f, 0.f}, ay[2] = {0.f, 0.f}, az[2] = {0.f, 0.f};
+		if (APIC) {
+			// affine term dot(c_comp, face - p) (src/simulation.cpp:371-375); (face - p)_a = -(f_a - i) * h
+			const float *cc = c + 3 * comp;
+#pragma unroll
+			for (int i = 0; i < 2; ++i) {
+				ax[i] = -hworld * cc[0] * (f[0] - (float)i);
+				ay[i] = -hworld * cc[1] * (f[1] - (float)i);
+				az[i] = -hworld * cc[2] * (f[2] - (float)i);
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < 2; ++k)
+#pragma unroll
+			for (int j = 0; j < 2; ++j)
+#pragma unroll
+				for (int i = 0; i < 2; ++i) {
+					float wgt = (wx[i] * wy[j]) * wz[k];  // product order of _kernel, src/simulation.cpp:209-212
+					float val = APIC ? v[comp] + ((ax[i] + ay[j]) + az[k]) : v[comp];
+					add(comp, hx0 + i, hy0 + j, hz0 + k, wgt * val, wgt);
+				}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ LDS-binned
+template <bool APIC>
+__global__ void __launch_bounds__(256)
+k_p2g_binned(const int *ptiles, int n_ptiles, ParticleSoA p, const uint32_t *tile_start, float *stage, float hworld) {
+	__shared__ float acc[6 * LFA_HALO_CELLS];
+	for (int slot = blockIdx.x; slot < n_ptiles; slot += gridDim.x) {
+		const int tile = ptiles[slot];
+		for (int i = threadIdx.x; i < 6 * LFA_HALO_CELLS; i += 256) acc[i] = 0.0f;
+		__syncthreads();
+		const uint32_t beg = tile_start[tile], end = tile_start[tile + 1];
+		for (uint32_t i = beg + threadIdx.x; i < end; i += 256) {
+			const uint32_t key = p.key[i];
+			const int l = (int)(key & 511);
+			float t[3] = {p.t[0][i], p.t[1][i], p.t[2][i]};
+			float v[3] = {p.v[0][i], p.v[1][i], p.v[2][i]};
+			float c[9];
+			if (APIC) {
+#pragma unroll
+				for (int k = 0; k < 9; ++k) c[k] = p.c[k][i];
+			}
+			scatter_particle<APIC>(l & 7, (l >> 3) & 7, l >> 6, t, v, c, hworld,
+			                       [&](int comp, int hx, int hy, int hz, float wv, float wgt) {
+				                       float *a = acc + comp * 2 * LFA_HALO_CELLS + hx + 10 * hy + 100 * hz;
+				                       atomicAdd(a, wv);
+				                       atomicAdd(a + LFA_HALO_CELLS, wgt);
+			                       });
+		}
+		__syncthreads();
+		float *out = stage + (size_t)slot * 6 * LFA_HALO_CELLS;
+		for (int i = threadIdx.x; i < 6 * LFA_HALO_CELLS; i += 256) out[i] = acc[i];
+		__syncthreads();
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ global atomics
+__global__ void k_zero_acc(const int *dtiles, int n_dtiles, float *acc, size_t ncp) {
+	int slot = blockIdx.x;
+	if (slot >= n_dtiles) return;
+	size_t base = (size_t)dtiles[slot] * LFA_TILE_CELLS;
+	for (int k = 0; k < 6; ++k) {
+		acc[k * ncp + base + threadIdx.x] = 0.0f;
+		acc[k * ncp + base + 256 + threadIdx.x] = 0.0f;
+	}
+}
+
+template <bool APIC>
+__global__ void __launch_bounds__(256)
+k_p2g_atomic(size_t n, ParticleSoA p, float *acc, size_t ncp, GridDims g, float hworld) {
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t key = p.key[i];
+	const int tile = (int)(key >> 9), l = (int)(key & 511);
+	int tx, ty, tz;
+	tile_coords(g, tile, tx, ty, tz);
+	const int cx = tx * 8 + (l & 7), cy = ty * 8 + ((l >> 3) & 7), cz = tz * 8 + (l >> 6);
+	float t[3] = {p.t[0][i], p.t[1][i], p.t[2][i]};
+	float v[3] = {p.v[0][i], p.v[1][i], p.v[2][i]};
+	float c[9];
+	if (APIC) {
+#pragma unroll
+		for (int k = 0; k < 9; ++k) c[k] = p.c[k][i];
+	}
+	// local coords 0 here: hx = 1 + b + i  => cell offset = hx - 1
+	scatter_particle<APIC>(0, 0, 0, t, v, c, hworld, [&](int comp, int hx, int hy, int hz, float wv, float wgt) {
+		int x = cx + hx - 1, y = cy + hy - 1, z = cz + hz - 1;
+		if (!in_grid(g, x, y, z)) return;
+		size_t b = blocked_index(g, x, y, z);
+		unsafeAtomicAdd(acc + (size_t)(2 * comp) * ncp + b, wv);
+		unsafeAtomicAdd(acc + (size_t)(2 * comp + 1) * ncp + b, wgt);
+	});
+}
+
+// ------------------------------------------------------------------------------------------------ finalize
+struct FinalizeParams {
+	int method;        // LFA_PIC / FLIP / APIC
+	float g[3];        // gravity * dt when fused, else 0
+	int fuse_gravity;
+};
+
+template <bool BINNED>
+__global__ void __launch_bounds__(256)
+k_p2g_finalize(const int *dtiles, int n_dtiles, GridDims g, const int *tile_pslot, const float *stage, const float *acc,
+               size_t ncp, const uint32_t *cell_count, const uint8_t *solid, float *u, float *v, float *w, float *uo,
+               float *vo, float *wo, uint8_t *ctype, FinalizeParams fp) {
+	for (int slot = blockIdx.x; slot < n_dtiles; slot += gridDim.x) {
+		const int tile = dtiles[slot];
+		int tx, ty, tz;
+		tile_coords(g, tile, tx, ty, tz);
+#pragma unroll
+		for (int half = 0; half < 2; ++half) {
+			const int l = threadIdx.x + 256 * half;
+			const int lx = l & 7, ly = (l >> 3) & 7, lz = l >> 6;
+			const size_t b = (size_t)tile * LFA_TILE_CELLS + l;
+			const int x = tx * 8 + lx, y = ty * 8 + ly, z = tz * 8 + lz;
+			float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+			if (BINNED) {
+				// fixed visiting order => the sum does not depend on which workgroup ran first
+				for (int oz = -1; oz <= 1; ++oz) {
+					if ((oz == -1 && lz != 0) || (oz == 1 && lz != 7)) continue;
+					const int nz_ = tz + oz;
+					if ((unsigned)nz_ >= (unsigned)g.ntz) continue;
+					for (int oy = -1; oy <= 1; ++oy) {
+						if ((oy == -1 && ly != 0) || (oy == 1 && ly != 7)) continue;
+						const int ny_ = ty + oy;
+						if ((unsigned)ny_ >= (unsigned)g.nty) continue;
+						for (int ox = -1; ox <= 1; ++ox) {
+							if ((ox == -1 && lx != 0) || (ox == 1 && lx != 7)) continue;
+							const int nx_ = tx + ox;
+							if ((unsigned)nx_ >= (unsigned)g.ntx) continue;
+							const int ps = tile_pslot[nx_ + g.ntx * (ny_ + g.nty * nz_)];
+							if (ps < 0) continue;
+							const int h = (lx - 8 * ox + 1) + 10 * (ly - 8 * oy + 1) + 100 * (lz - 8 * oz + 1);
+							const float *src = stage + (size_t)ps * 6 * LFA_HALO_CELLS + h;
+#pragma unroll
+							for (int k = 0; k < 6; ++k) s[k] += src[k * LFA_HALO_CELLS];
+						}
+					}
+				}
+			} else {
+#pragma unroll
+				for (int k = 0; k < 6; ++k) s[k] = acc[(size_t)k * ncp + b];
+			}
+			const bool inside = in_grid(g, x, y, z);
+			float vel[3];
+#pragma unroll
+			for (int k = 0; k < 3; ++k) vel[k] = s[2 * k + 1] > 1e-6f ? s[2 * k] / s[2 * k + 1] : 0.0f;
+			uint8_t type;
+			if (!inside) {
+				vel[0] = vel[1] = vel[2] = 0.0f;
+				type = CT_SOLID | CT_OUTSIDE;
+			} else if (solid[b]) {
+				type = CT_SOLID;
+			} else {
+				type = cell_count[b] > 0 ? CT_FLUID : CT_AIR;
+			}
+			const bool bx = x == g.nx - 1, by = y == g.ny - 1, bz = z == g.nz - 1;
+			if (fp.method == LFA_FLIP_BLEND && inside) {
+				uo[b] = bx ? 0.0f : vel[0];
+				vo[b] = by ? 0.0f : vel[1];
+				wo[b] = bz ? 0.0f : vel[2];
+			}
+			if (fp.method == LFA_APIC) {
+				if (bx) vel[0] = 0.0f;
+				if (by) vel[1] = 0.0f;
+				if (bz) vel[2] = 0.0f;
+			}
+			if (fp.fuse_gravity && inside) {
+				vel[0] += fp.g[0]; vel[1] += fp.g[1]; vel[2] += fp.g[2];
+			}
+			u[b] = vel[0]; v[b] = vel[1]; w[b] = vel[2];
+			ctype[b] = type;
+		}
+	}
+}
+
+__global__ void __launch_bounds__(256)
+k_add_gravity(const int *dtiles, int n_dtiles, GridDims g, float *u, float *v, float *w, float gx, float gy, float gz) {
+	for (int slot = blockIdx.x; slot < n_dtiles; slot += gridDim.x) {
+		const int tile = dtiles[slot];
+		int tx, ty, tz;
+		tile_coords(g, tile, tx, ty, tz);
+#pragma unroll
+		for (int half = 0; half < 2; ++half) {
+			const int l = threadIdx.x + 256 * half;
+			if (!in_grid(g, tx * 8 + (l & 7), ty * 8 + ((l >> 3) & 7), tz * 8 + (l >> 6))) continue;
+			const size_t b = (size_t)tile * LFA_TILE_CELLS + l;
+			u[b] += gx; v[b] += gy; w[b] += gz;
+		}
+	}
+}
+}  // namespace
+
+static int grid_blocks(int n) { return n < 16384 ? (n > 0 ? n : 1) : 16384; }
+
+int lfa_p2g_run(lfa_sim *s, bool fuse_gravity, double dt) {
+	if (!s->binned) return lfa_fail(s, LFA_E_INVALID, "lfa_p2g: call lfa_hash_particles first");
+	LFA_HIP(s, hipSetDevice(s->device));
+	const int method = s->prm.simulation_method;
+	const bool apic = method == LFA_APIC;
+	if (method == LFA_FLIP_BLEND && !s->uo) {
+		LFA_HIP(s, hipMalloc(&s->uo, s->ncp * 4));
+		LFA_HIP(s, hipMalloc(&s->vo, s->ncp * 4));
+		LFA_HIP(s, hipMalloc(&s->wo, s->ncp * 4));
+		LFA_HIP(s, hipMemsetAsync(s->uo, 0, s->ncp * 4, s->stream));
+		LFA_HIP(s, hipMemsetAsync(s->vo, 0, s->ncp * 4, s->stream));
+		LFA_HIP(s, hipMemsetAsync(s->wo, 0, s->ncp * 4, s->stream));
+	}
+	const float hworld = (float)s->prm.cell_size;
+	const ParticleSoA &p = s->pb[s->cur];
+	const bool binned = s->prm.p2g_variant == LFA_P2G_LDS_BINNED;
+	if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[16], s->stream));
+	if (binned) {
+		if ((size_t)s->n_ptiles > s->stage_tiles) {
+			if (s->stage) LFA_HIP(s, hipFree(s->stage));
+			s->stage = nullptr;
+			size_t want = (size_t)s->n_ptiles + (size_t)s->n_ptiles / 4 + 16;
+			hipError_t e = hipMalloc(&s->stage, want * 6 * LFA_HALO_CELLS * 4);
+			if (e != hipSuccess) return lfa_fail(s, LFA_E_OOM, "hipMalloc of the P2G staging slabs (%zu tiles) failed", want);
+			s->stage_tiles = want;
+		}
+		if (s->n_ptiles) {
+			dim3 grid(grid_blocks(s->n_ptiles));
+			if (apic)
+				hipLaunchKernelGGL(k_p2g_binned<true>, grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, p,
+				                   s->tile_start, s->stage, hworld);
+			else
+				hipLaunchKernelGGL(k_p2g_binned<false>, grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, p,
+				                   s->tile_start, s->stage, hworld);
+			LFA_LAUNCH_CHECK(s);
+		}
+	} else {
+		if (!s->acc) {
+			hipError_t e = hipMalloc(&s->acc, s->ncp * 6 * 4);
+			if (e != hipSuccess) return lfa_fail(s, LFA_E_OOM, "hipMalloc of the atomic P2G accumulators failed");
+		}
+		if (s->n_dtiles) {
+			hipLaunchKernelGGL(k_zero_acc, dim3(s->n_dtiles), dim3(256), 0, s->stream, s->dtiles, s->n_dtiles, s->acc,
+			                   s->ncp);
+			LFA_LAUNCH_CHECK(s);
+		}
+		if (s->np) {
+			dim3 grid((unsigned)((s->np + 255) / 256));
+			if (apic)
+				hipLaunchKernelGGL(k_p2g_atomic<true>, grid, dim3(256), 0, s->stream, s->np, p, s->acc, s->ncp, s->g,
+				                   hworld);
+			else
+				hipLaunchKernelGGL(k_p2g_atomic<false>, grid, dim3(256), 0, s->stream, s->np, p, s->acc, s->ncp, s->g,
+				                   hworld);
+			LFA_LAUNCH_CHECK(s);
+		}
+	}
+	if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[17], s->stream));
+	FinalizeParams fp;
+	fp.method = method;
+	fp.fuse_gravity = fuse_gravity ? 1 : 0;
+	for (int k = 0; k < 3; ++k) fp.g[k] = fuse_gravity ? (float)(s->prm.gravity[k] * dt) : 0.0f;
+	if (s->n_dtiles) {
+		dim3 grid(grid_blocks(s->n_dtiles));
+		if (binned)
+			hipLaunchKernelGGL(k_p2g_finalize<true>, grid, dim3(256), 0, s->stream, s->dtiles, s->n_dtiles, s->g,
+			                   s->tile_pslot, s->stage, s->acc, s->ncp, s->cell_count, s->solid, s->u, s->v, s->w, s->uo,
+			                   s->vo, s->wo, s->ctype, fp);
+		else
+			hipLaunchKernelGGL(k_p2g_finalize<false>, grid, dim3(256), 0, s->stream, s->dtiles, s->n_dtiles, s->g,
+			                   s->tile_pslot, s->stage, s->acc, s->ncp, s->cell_count, s->solid, s->u, s->v, s->w, s->uo,
+			                   s->vo, s->wo, s->ctype, fp);
+		LFA_LAUNCH_CHECK(s);
+	}
+	s->grid_valid = true;
+	s->system_valid = false;
+	for (int k = 0; k < 3; ++k) s->bg[k] = fuse_gravity ? s->prm.gravity[k] * dt : 0.0;
+	return LFA_OK;
+}
+
+extern "C" int lfa_p2g(lfa_sim *s) {
+	if (!s) return LFA_E_INVALID;
+	return lfa_p2g_run(s, false, 0.0);
+}
+
+extern "C" int lfa_add_gravity(lfa_sim *s, double dt) {
+	if (!s) return LFA_E_INVALID;
+	LFA_HIP(s, hipSetDevice(s->device));
+	if (s->binned && s->n_dtiles) {
+		hipLaunchKernelGGL(k_add_gravity, dim3(grid_blocks(s->n_dtiles)), dim3(256), 0, s->stream, s->dtiles, s->n_dtiles,
+		                   s->g, s->u, s->v, s->w, (float)(s->prm.gravity[0] * dt), (float)(s->prm.gravity[1] * dt),
+		                   (float)(s->prm.gravity[2] * dt));
+		LFA_LAUNCH_CHECK(s);
+	}
+	// every cell outside the processed tiles carries the same increment implicitly (see k_export_cells)
+	for (int k = 0; k < 3; ++k) s->bg[k] += s->prm.gravity[k] * dt;
+	s->system_valid = false;
+	return LFA_OK;
+}

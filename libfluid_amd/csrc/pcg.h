@@ -1,0 +1,18 @@
+// libfluid_amd/csrc/pcg.h -- shared constants of the pressure-solve kernels.
+#pragma once
+#include "common.h"
+
+// Every reduction of the solve is deterministic: workgroup g writes one partial to partials[PART_x + g], and every
+// consumer workgroup re-adds the <= PCG_MAX_GRID partials in the same fixed order. No atomics, no host round trip.
+#define PCG_MAX_GRID 1024
+#define PCG_WAVES 4          // waves (= tiles in flight) per workgroup
+enum { PART_ZS = 0, PART_RMAX = 2048, PART_SIG0 = 4096, PART_SIG1 = 6144, PART_B2 = 8192 };  // offsets in doubles
+
+static inline int pcg_grid(int n_ptiles) {
+	int g = (n_ptiles + PCG_WAVES - 1) / PCG_WAVES;
+	if (g < 1) g = 1;
+	return g < PCG_MAX_GRID ? g : PCG_MAX_GRID;
+}
+
+int lfa_build_rhs(lfa_sim *s, double dt);
+int lfa_p2g_run(lfa_sim *s, bool fuse_gravity, double dt);

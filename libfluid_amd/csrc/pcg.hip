@@ -1,0 +1,792 @@
+// libfluid_amd/csrc/pcg.hip -- MIC(0)-preconditioned conjugate gradient on the 7-point MAC Laplacian
+// (reference src/pressure_solver.cpp:19-71,244-370).
+//
+// Layout: every PCG vector is a tile-major field over the padded grid; only tiles that hold unknowns (the particle
+// tiles) are ever touched, and entries of non-unknown cells inside those tiles are kept at exactly 0, so the matrix
+// rows need no index map (the reference's grid3<size_t> _fluid_cell_indices, pressure_solver.h:52): the off-diagonal
+// of row i towards -d is [type(i)==fluid] (that IS _a[j].fluid_dpos for an unknown j) and towards +d is bit d of a_i.
+//
+// Work decomposition: ONE WAVE OWNS ONE TILE. Lane = (x,y) column, the 8 z-cells of the column sit in registers, so a
+// tile field is read with eight 256-B coalesced wave loads. x/y neighbours and the one-cell halo go through a small
+// per-wave LDS block; waves never synchronise with each other (no s_barrier in the loops).
+//
+// MIC(0): forward/backward substitution only depends on -x,-y,-z / +x,+y,+z neighbours, so cells with equal
+// i+j+k are independent. Inside a tile the wave sweeps the 22 hyperplanes with lane (x,y) working on z = level-x-y.
+//   LFA_PRECOND_MIC0_TILED  couplings across tile faces are dropped from the preconditioner (block MIC(0)): factor and
+//                           both sweeps of a tile stay inside one wave, one launch applies M^-1 to every tile.
+//   LFA_PRECOND_MIC0_EXACT  tiles are launched hyperplane by hyperplane (tx+ty+tz) and read their predecessors' face
+//                           values: the same recurrence, hence the same numbers, as pressure_solver.cpp:244-332.
+//
+// Reductions are deterministic (pcg.h): fixed tile->wave->workgroup assignment, fixed-order partial sums.
+#include "pcg.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+namespace {
+
+#define WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <typename real> struct Vecs {
+	real *p, *r, *z, *s, *pre, *q;
+};
+
+struct TileCtx {
+	const int *ptiles;
+	int n_ptiles;
+	const int *tile_pslot;
+	GridDims g;
+};
+
+/// Tile ids of the six face neighbours that hold unknowns (-1 otherwise): order -x,+x,-y,+y,-z,+z.
+__device__ inline void face_neighbours(const TileCtx &tc, int tile, int nb[6]) {
+	int tx, ty, tz;
+	tile_coords(tc.g, tile, tx, ty, tz);
+	const int sy = tc.g.ntx, sz = tc.g.ntx * tc.g.nty;
+	nb[0] = tx > 0 ? tile - 1 : -1;
+	nb[1] = tx + 1 < tc.g.ntx ? tile + 1 : -1;
+	nb[2] = ty > 0 ? tile - sy : -1;
+	nb[3] = ty + 1 < tc.g.nty ? tile + sy : -1;
+	nb[4] = tz > 0 ? tile - sz : -1;
+	nb[5] = tz + 1 < tc.g.ntz ? tile + sz : -1;
+#pragma unroll
+	for (int k = 0; k < 6; ++k)
+		if (nb[k] >= 0 && tc.tile_pslot[nb[k]] < 0) nb[k] = -1;
+}
+
+/// Sum / max of the per-workgroup partials of the previous kernel, identical in every workgroup.
+__device__ inline double reduce_partials_sum(const double *part, int n, double *lds) {
+	double a = 0.0;
+	for (int i = threadIdx.x; i < n; i += 256) a += part[i];
+	lds[threadIdx.x] = a;
+	__syncthreads();
+	for (int o = 128; o > 0; o >>= 1) {
+		if ((int)threadIdx.x < o) lds[threadIdx.x] += lds[threadIdx.x + o];
+		__syncthreads();
+	}
+	double r = lds[0];
+	__syncthreads();
+	return r;
+}
+__device__ inline double reduce_partials_max(const double *part, int n, double *lds) {
+	double a = -INFINITY;
+	bool nan = false;
+	for (int i = threadIdx.x; i < n; i += 256) {
+		double x = part[i];
+		nan |= x != x;
+		a = x > a ? x : a;
+	}
+	lds[threadIdx.x] = nan ? NAN : a;
+	__syncthreads();
+	for (int o = 128; o > 0; o >>= 1) {
+		if ((int)threadIdx.x < o) {
+			double x = lds[threadIdx.x], y = lds[threadIdx.x + o];
+			lds[threadIdx.x] = (x != x || y != y) ? NAN : (y > x ? y : x);
+		}
+		__syncthreads();
+	}
+	double r = lds[0];
+	__syncthreads();
+	return r;
+}
+__device__ inline void block_partial_sum(double acc, double *lds, double *out) {
+	acc = wave_sum(acc);
+	__syncthreads();
+	if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+	__syncthreads();
+	if (threadIdx.x == 0) out[blockIdx.x] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+}
+
+// ================================================================================================= SpMV + dot
+/// z = A s (pressure_solver::_apply_a, src/pressure_solver.cpp:334-362, same term order) and partial dot(z, s).
+template <typename real>
+__global__ void __launch_bounds__(256)
+k_spmv(TileCtx tc, const uint8_t *abits, const real *s, real *z, real scale, double *part_zs, const int *state) {
+	__shared__ real halo[PCG_WAVES][LFA_HALO_CELLS];
+	__shared__ double red[4];
+	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
+	double acc = 0.0;
+	if (state[0] < 0) {
+		real *h = halo[wid];
+		for (int slot = blockIdx.x * PCG_WAVES + wid; slot < tc.n_ptiles; slot += gridDim.x * PCG_WAVES) {
+			const int tile = tc.ptiles[slot];
+			int nb[6];
+			face_neighbours(tc, tile, nb);
+			const size_t base = (size_t)tile * LFA_TILE_CELLS;
+			WAVE_SYNC();
+#pragma unroll
+			for (int zz = 0; zz < 8; ++zz) h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)] = s[base + zz * 64 + lane];
+			// faces: lane = (a, b) over the two in-face axes
+			h[0 + 10 * (lx + 1) + 100 * (ly + 1)] = nb[0] >= 0 ? s[(size_t)nb[0] * 512 + ly * 64 + lx * 8 + 7] : (real)0;
+			h[9 + 10 * (lx + 1) + 100 * (ly + 1)] = nb[1] >= 0 ? s[(size_t)nb[1] * 512 + ly * 64 + lx * 8 + 0] : (real)0;
+			h[(lx + 1) + 10 * 0 + 100 * (ly + 1)] = nb[2] >= 0 ? s[(size_t)nb[2] * 512 + ly * 64 + 7 * 8 + lx] : (real)0;
+			h[(lx + 1) + 10 * 9 + 100 * (ly + 1)] = nb[3] >= 0 ? s[(size_t)nb[3] * 512 + ly * 64 + 0 * 8 + lx] : (real)0;
+			h[(lx + 1) + 10 * (ly + 1) + 100 * 0] = nb[4] >= 0 ? s[(size_t)nb[4] * 512 + 7 * 64 + lane] : (real)0;
+			h[(lx + 1) + 10 * (ly + 1) + 100 * 9] = nb[5] >= 0 ? s[(size_t)nb[5] * 512 + 0 * 64 + lane] : (real)0;
+			WAVE_SYNC();
+#pragma unroll
+			for (int zz = 0; zz < 8; ++zz) {
+				const int i = (lx + 1) + 10 * (ly + 1) + 100 * (zz + 1);
+				const uint8_t a = abits[base + zz * 64 + lane];
+				real out = (real)0;
+				if (a & AB_UNKNOWN) {
+					const real F = (a & AB_FLUID) ? (real)1 : (real)0;
+					const real si = h[i];
+					real val = (real)(a & 7) * si;
+					val -= F * h[i - 1];
+					val -= F * h[i - 10];
+					val -= F * h[i - 100];
+					val -= (real)((a >> 3) & 1) * h[i + 1];
+					val -= (real)((a >> 4) & 1) * h[i + 10];
+					val -= (real)((a >> 5) & 1) * h[i + 100];
+					out = scale * val;
+					acc += (double)out * (double)si;
+				}
+				z[base + zz * 64 + lane] = out;
+			}
+		}
+	}
+	block_partial_sum(acc, red, part_zs);
+}
+
+// ================================================================================================= AXPY x2 + max
+/// p += alpha s ; r += (-alpha) z (_muladd, src/pressure_solver.cpp:364-370) ; signed max of r over the unknowns (:54).
+template <typename real>
+__global__ void __launch_bounds__(256)
+k_axpy_max(TileCtx tc, const uint8_t *abits, Vecs<real> v, const double *part_sigma, const double *part_zs, int n_part,
+           double *part_rmax, const int *state) {
+	__shared__ double lds[256];
+	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	double m = -INFINITY;
+	bool nan = false;
+	if (state[0] < 0) {
+		const double sigma = reduce_partials_sum(part_sigma, n_part, lds);
+		const double zs = reduce_partials_sum(part_zs, n_part, lds);
+		const real alpha = (real)(sigma / zs);
+		for (int slot = blockIdx.x * PCG_WAVES + wid; slot < tc.n_ptiles; slot += gridDim.x * PCG_WAVES) {
+			const size_t base = (size_t)tc.ptiles[slot] * LFA_TILE_CELLS;
+#pragma unroll
+			for (int zz = 0; zz < 8; ++zz) {
+				const size_t b = base + zz * 64 + lane;
+				if (abits[b] & AB_UNKNOWN) {
+					v.p[b] = v.p[b] + alpha * v.s[b];
+					const real rn = v.r[b] + (-alpha) * v.z[b];
+					v.r[b] = rn;
+					nan |= rn != rn;
+					m = (double)rn > m ? (double)rn : m;
+				}
+			}
+		}
+	}
+	m = wave_max(m);
+	nan = __any(nan);
+	__syncthreads();
+	if (lane == 0) lds[wid] = nan ? NAN : m;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		double r = lds[0];
+		for (int i = 1; i < 4; ++i) r = (r != r || lds[i] != lds[i]) ? NAN : (lds[i] > r ? lds[i] : r);
+		part_rmax[blockIdx.x] = r;
+	}
+}
+
+// ================================================================================================= MIC(0) factor
+/// pressure_solver::_compute_preconditioner (src/pressure_solver.cpp:244-294). EXACT: one launch per tile hyperplane,
+/// predecessors' faces read from global memory; otherwise the tile is factored on its own.
+template <typename real, bool EXACT>
+__global__ void __launch_bounds__(256)
+k_mic_factor(TileCtx tc, const int *slots, int n_slots, const uint8_t *abits, real *pre, real scale, real tau,
+             real sigma) {
+	__shared__ real lpre[PCG_WAVES][LFA_TILE_CELLS];
+	__shared__ uint8_t lab[PCG_WAVES][LFA_TILE_CELLS];
+	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
+	real *P = lpre[wid];
+	uint8_t *A = lab[wid];
+	for (int k = blockIdx.x * PCG_WAVES + wid; k < n_slots; k += gridDim.x * PCG_WAVES) {
+		const int slot = slots ? slots[k] : k;
+		const int tile = tc.ptiles[slot];
+		const size_t base = (size_t)tile * LFA_TILE_CELLS;
+		int nb[6] = {-1, -1, -1, -1, -1, -1};
+		if (EXACT) face_neighbours(tc, tile, nb);
+		WAVE_SYNC();
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) {
+			A[zz * 64 + lane] = abits[base + zz * 64 + lane];
+			P[zz * 64 + lane] = (real)0;
+		}
+		WAVE_SYNC();
+		for (int level = 0; level < 22; ++level) {
+			const int zz = level - lx - ly;
+			if (zz >= 0 && zz < 8) {
+				const int idx = zz * 64 + lane;
+				const uint8_t a = A[idx];
+				if (a & AB_UNKNOWN) {
+					real neg_e = (real)0, neg_e_tau = (real)0;
+#pragma unroll
+					for (int d = 0; d < 3; ++d) {
+						const int c = d == 0 ? lx : (d == 1 ? ly : zz);
+						const int step = d == 0 ? 1 : (d == 1 ? 8 : 64);
+						uint8_t aj = 0;
+						real pj = (real)0;
+						if (c > 0) {
+							aj = A[idx - step];
+							pj = P[idx - step];
+						} else if (EXACT && nb[2 * d] >= 0) {
+							const size_t j = (size_t)nb[2 * d] * LFA_TILE_CELLS + (idx + 7 * step);
+							aj = abits[j];
+							pj = pre[j];
+						}
+						if (aj & AB_UNKNOWN) {
+							const int bd = (aj >> (3 + d)) & 1, bo1 = (aj >> (3 + (d + 1) % 3)) & 1,
+							          bo2 = (aj >> (3 + (d + 2) % 3)) & 1;
+							const real ap = (real)bd * pj;
+							neg_e += ap * ap;
+							neg_e_tau += (real)(bd * (bo1 + bo2)) * pj * pj;
+						}
+					}
+					const real ns = (real)(a & 7);
+					real e = ns - (neg_e + tau * neg_e_tau) * scale;
+					if (e < sigma * ns) e = ns;
+					P[idx] = (real)1 / sqrt(e * scale);
+				}
+			}
+			WAVE_SYNC();
+		}
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) pre[base + zz * 64 + lane] = P[zz * 64 + lane];
+	}
+}
+
+// ================================================================================================= MIC(0) apply
+enum { SWEEP_BOTH = 0, SWEEP_FWD = 1, SWEEP_BWD = 2 };
+
+/// pressure_solver::_apply_preconditioner (src/pressure_solver.cpp:296-332).
+///  SWEEP_BOTH (tiled): z = M^-1 r for every tile in one launch + partial dot(z, r); checks convergence first.
+///  SWEEP_FWD / SWEEP_BWD (exact): one tile hyperplane per launch; q is kept in v.q between the two passes.
+template <typename real, int MODE>
+__global__ void __launch_bounds__(256)
+k_mic_apply(TileCtx tc, const int *slots, int n_slots, const uint8_t *abits, Vecs<real> v, real scale,
+            double *part_sigma, const int *state) {
+	constexpr bool EXACT = MODE != SWEEP_BOTH;
+	__shared__ real lq[PCG_WAVES][LFA_TILE_CELLS];    // r -> q -> z
+	__shared__ real lpq[PCG_WAVES][LFA_TILE_CELLS];   // pre * q
+	__shared__ real lpre[PCG_WAVES][LFA_TILE_CELLS];
+	__shared__ uint8_t lab[PCG_WAVES][LFA_TILE_CELLS];
+	__shared__ double red[4];
+	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
+	real *Q = lq[wid], *PQ = lpq[wid], *P = lpre[wid];
+	uint8_t *A = lab[wid];
+	double acc = 0.0;
+	if (state[0] < 0) {
+		for (int k = blockIdx.x * PCG_WAVES + wid; k < n_slots; k += gridDim.x * PCG_WAVES) {
+			const int slot = slots ? slots[k] : k;
+			const int tile = tc.ptiles[slot];
+			const size_t base = (size_t)tile * LFA_TILE_CELLS;
+			int nb[6] = {-1, -1, -1, -1, -1, -1};
+			if (EXACT) face_neighbours(tc, tile, nb);
+			real rr[8];
+			WAVE_SYNC();
+#pragma unroll
+			for (int zz = 0; zz < 8; ++zz) {
+				const size_t b = base + zz * 64 + lane;
+				A[zz * 64 + lane] = abits[b];
+				P[zz * 64 + lane] = v.pre[b];
+				if (MODE == SWEEP_BWD) {
+					Q[zz * 64 + lane] = v.q[b];
+				} else {
+					rr[zz] = v.r[b];
+					Q[zz * 64 + lane] = rr[zz];
+					PQ[zz * 64 + lane] = (real)0;
+				}
+			}
+			WAVE_SYNC();
+			if (MODE != SWEEP_BWD) {
+				// L q = r
+				for (int level = 0; level < 22; ++level) {
+					const int zz = level - lx - ly;
+					if (zz >= 0 && zz < 8) {
+						const int idx = zz * 64 + lane;
+						const uint8_t a = A[idx];
+						real q = (real)0;
+						if (a & AB_UNKNOWN) {
+							const real F = (a & AB_FLUID) ? (real)1 : (real)0;
+							real t = (real)0;
+#pragma unroll
+							for (int d = 0; d < 3; ++d) {
+								const int c = d == 0 ? lx : (d == 1 ? ly : zz);
+								const int step = d == 0 ? 1 : (d == 1 ? 8 : 64);
+								real pqj = (real)0;
+								if (c > 0) {
+									pqj = PQ[idx - step];
+								} else if (EXACT && nb[2 * d] >= 0) {
+									const size_t j = (size_t)nb[2 * d] * LFA_TILE_CELLS + (idx + 7 * step);
+									pqj = v.pre[j] * v.q[j];
+								}
+								t += F * pqj;
+							}
+							q = (Q[idx] + scale * t) * P[idx];
+							PQ[idx] = P[idx] * q;
+						}
+						Q[idx] = q;
+					}
+					WAVE_SYNC();
+				}
+			}
+			if (MODE == SWEEP_FWD) {
+#pragma unroll
+				for (int zz = 0; zz < 8; ++zz) v.q[base + zz * 64 + lane] = Q[zz * 64 + lane];
+				continue;
+			}
+			// L^T z = q
+			for (int level = 21; level >= 0; --level) {
+				const int zz = level - lx - ly;
+				if (zz >= 0 && zz < 8) {
+					const int idx = zz * 64 + lane;
+					const uint8_t a = A[idx];
+					real zv = (real)0;
+					if (a & AB_UNKNOWN) {
+						real t = (real)0;
+#pragma unroll
+						for (int d = 0; d < 3; ++d) {
+							const int c = d == 0 ? lx : (d == 1 ? ly : zz);
+							const int step = d == 0 ? 1 : (d == 1 ? 8 : 64);
+							real zj = (real)0;
+							if (c < 7) {
+								zj = Q[idx + step];
+							} else if (EXACT && nb[2 * d + 1] >= 0) {
+								zj = v.z[(size_t)nb[2 * d + 1] * LFA_TILE_CELLS + (idx - 7 * step)];
+							}
+							t += (real)((a >> (3 + d)) & 1) * zj;
+						}
+						zv = (Q[idx] + scale * P[idx] * t) * P[idx];
+					}
+					Q[idx] = zv;
+				}
+				WAVE_SYNC();
+			}
+#pragma unroll
+			for (int zz = 0; zz < 8; ++zz) {
+				const real zv = Q[zz * 64 + lane];
+				v.z[base + zz * 64 + lane] = zv;
+				if (MODE == SWEEP_BOTH) acc += (double)zv * (double)rr[zz];
+			}
+		}
+	}
+	if (MODE == SWEEP_BOTH) block_partial_sum(acc, red, part_sigma);
+}
+
+/// partial dot(z, r) (exact-MIC path, where the sweeps are separate launches).
+template <typename real>
+__global__ void __launch_bounds__(256)
+k_dot_zr(TileCtx tc, Vecs<real> v, double *part_sigma, const int *state) {
+	__shared__ double red[4];
+	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	double acc = 0.0;
+	if (state[0] < 0) {
+		for (int slot = blockIdx.x * PCG_WAVES + wid; slot < tc.n_ptiles; slot += gridDim.x * PCG_WAVES) {
+			const size_t base = (size_t)tc.ptiles[slot] * LFA_TILE_CELLS;
+#pragma unroll
+			for (int zz = 0; zz < 8; ++zz) acc += (double)v.z[base + zz * 64 + lane] * (double)v.r[base + zz * 64 + lane];
+		}
+	}
+	block_partial_sum(acc, red, part_sigma);
+}
+
+/// Stopping rule of pressure_solver::solve (src/pressure_solver.cpp:54-58): signed max(r) < tolerance ends the solve
+/// with iteration count i+1. One workgroup; later kernels of the stream see state[0] >= 0 and do nothing.
+__global__ void __launch_bounds__(256)
+k_check_converged(const double *part_rmax, int n_part, double tol, int iter, int *state, double *hist) {
+	__shared__ double lds[256];
+	if (state[0] >= 0) return;
+	const double rmax = reduce_partials_max(part_rmax, n_part, lds);
+	if (threadIdx.x == 0) {
+		hist[iter] = rmax;
+		if (rmax != rmax) {
+			state[1] = 1;
+			state[0] = iter + 1;
+		} else if (rmax < tol) {
+			state[0] = iter + 1;
+		}
+	}
+}
+
+/// s = z + beta s (src/pressure_solver.cpp:64-66); first = 1: s = z (:40).
+template <typename real>
+__global__ void __launch_bounds__(256)
+k_update_s(TileCtx tc, Vecs<real> v, const double *part_sig_new, const double *part_sig_old, int n_part, int first,
+           const int *state) {
+	__shared__ double lds[256];
+	if (state[0] >= 0) return;
+	real beta = (real)0;
+	if (!first) {
+		const double sn = reduce_partials_sum(part_sig_new, n_part, lds);
+		const double so = reduce_partials_sum(part_sig_old, n_part, lds);
+		beta = (real)(sn / so);
+	}
+	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	for (int slot = blockIdx.x * PCG_WAVES + wid; slot < tc.n_ptiles; slot += gridDim.x * PCG_WAVES) {
+		const size_t base = (size_t)tc.ptiles[slot] * LFA_TILE_CELLS;
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) {
+			const size_t b = base + zz * 64 + lane;
+			v.s[b] = first ? v.z[b] : v.z[b] + beta * v.s[b];
+		}
+	}
+}
+
+// ---- boundary helpers: vectors in the reference's unknown order <-> tile-major fields
+template <typename T, typename U>
+__global__ void k_gather_unknowns(GridDims g, size_t nc, const uint32_t *cell_count, const uint32_t *tile_flag,
+                                  const uint32_t *raw_scan, const T *field, U *out, int mask) {
+	size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= nc) return;
+	int x = (int)(r % g.nx), y = (int)((r / g.nx) % g.ny), z = (int)(r / ((size_t)g.nx * g.ny));
+	uint32_t b = blocked_index(g, x, y, z);
+	if (tile_flag[b >> 9] && cell_count[b] > 0) {
+		T val = field[b];
+		if (mask) val = (T)((int)val & mask);
+		out[raw_scan[r]] = (U)val;
+	}
+}
+template <typename T>
+__global__ void k_scatter_unknowns(GridDims g, size_t nc, const uint32_t *cell_count, const uint32_t *tile_flag,
+                                   const uint32_t *raw_scan, T *field, const double *in) {
+	size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= nc) return;
+	int x = (int)(r % g.nx), y = (int)((r / g.nx) % g.ny), z = (int)(r / ((size_t)g.nx * g.ny));
+	uint32_t b = blocked_index(g, x, y, z);
+	if (tile_flag[b >> 9] && cell_count[b] > 0) field[b] = (T)in[raw_scan[r]];
+}
+__global__ void k_zero_tiles(const int *ptiles, int n_ptiles, void *field, int elem) {
+	const int slot = blockIdx.x;
+	if (slot >= n_ptiles) return;
+	uint32_t *p = (uint32_t *)((char *)field + (size_t)ptiles[slot] * LFA_TILE_CELLS * elem);
+	for (int i = threadIdx.x; i < LFA_TILE_CELLS * elem / 4; i += 256) p[i] = 0u;
+}
+}  // namespace
+
+// ================================================================================================= host side
+int lfa_pcg_alloc(lfa_sim *s) {
+	const size_t elem = s->prm.pcg_dtype == LFA_PCG_F64 ? 8 : 4;
+	if (s->vp && s->vec_elem == elem) return LFA_OK;
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	void **vs[] = {&s->vp, &s->vr, &s->vz, &s->vs, &s->vpre, &s->vq};
+	for (void **v : vs) {
+		if (*v) LFA_HIP(s, hipFree(*v));
+		*v = nullptr;
+		hipError_t e = hipMalloc(v, s->ncp * elem);
+		if (e != hipSuccess) return lfa_fail(s, LFA_E_OOM, "hipMalloc of a PCG vector (%zu bytes) failed", s->ncp * elem);
+		LFA_HIP(s, hipMemsetAsync(*v, 0, s->ncp * elem, s->stream));
+	}
+	s->vec_elem = elem;
+	s->system_valid = false;
+	return LFA_OK;
+}
+
+static TileCtx make_ctx(lfa_sim *s) { return TileCtx{s->ptiles, s->n_ptiles, s->tile_pslot, s->g}; }
+template <typename real> static Vecs<real> make_vecs(lfa_sim *s) {
+	return Vecs<real>{(real *)s->vp, (real *)s->vr, (real *)s->vz, (real *)s->vs, (real *)s->vpre, (real *)s->vq};
+}
+
+/// Tile hyperplanes for the exact MIC(0) schedule: slots sorted by tx+ty+tz.
+static int build_levels(lfa_sim *s) {
+	std::vector<int> tiles(s->n_ptiles);
+	LFA_HIP(s, hipMemcpyAsync(tiles.data(), s->ptiles, (size_t)s->n_ptiles * 4, hipMemcpyDeviceToHost, s->stream));
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	const int nlev = s->g.ntx + s->g.nty + s->g.ntz - 2;
+	std::vector<int> cnt(nlev + 1, 0), lev(s->n_ptiles);
+	for (int i = 0; i < s->n_ptiles; ++i) {
+		int tx, ty, tz;
+		tile_coords(s->g, tiles[i], tx, ty, tz);
+		lev[i] = tx + ty + tz;
+		cnt[lev[i] + 1]++;
+	}
+	for (int l = 0; l < nlev; ++l) cnt[l + 1] += cnt[l];
+	s->level_offsets.assign(cnt.begin(), cnt.end());
+	std::vector<int> order(s->n_ptiles), cur(cnt.begin(), cnt.end() - 1);
+	for (int i = 0; i < s->n_ptiles; ++i) order[cur[lev[i]]++] = i;
+	LFA_HIP(s, hipMemcpyAsync(s->level_tiles, order.data(), (size_t)s->n_ptiles * 4, hipMemcpyHostToDevice, s->stream));
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	return LFA_OK;
+}
+
+template <typename real> static int mic_factor(lfa_sim *s) {
+	TileCtx tc = make_ctx(s);
+	const real scale = (real)s->a_scale, tau = (real)s->prm.tau, sigma = (real)s->prm.sigma;
+	if (s->prm.precond == LFA_PRECOND_MIC0_EXACT) {
+		LFA_TRY(build_levels(s));
+		for (size_t l = 0; l + 1 < s->level_offsets.size(); ++l) {
+			const int b = s->level_offsets[l], n = s->level_offsets[l + 1] - b;
+			if (!n) continue;
+			hipLaunchKernelGGL((k_mic_factor<real, true>), dim3((n + PCG_WAVES - 1) / PCG_WAVES), dim3(256), 0, s->stream, tc,
+			                   s->level_tiles + b, n, s->abits, (real *)s->vpre, scale, tau, sigma);
+			LFA_LAUNCH_CHECK(s);
+		}
+	} else {
+		hipLaunchKernelGGL((k_mic_factor<real, false>), dim3(pcg_grid(s->n_ptiles)), dim3(256), 0, s->stream, tc,
+		                   (const int *)nullptr, s->n_ptiles, s->abits, (real *)s->vpre, scale, tau, sigma);
+		LFA_LAUNCH_CHECK(s);
+	}
+	return LFA_OK;
+}
+
+/// z = M^-1 r and partial dot(z, r) into part_sigma.
+template <typename real> static int mic_apply(lfa_sim *s, double *part_sigma) {
+	TileCtx tc = make_ctx(s);
+	Vecs<real> v = make_vecs<real>(s);
+	const real scale = (real)s->a_scale;
+	const int G = pcg_grid(s->n_ptiles);
+	if (s->prm.precond == LFA_PRECOND_MIC0_EXACT) {
+		const int nl = (int)s->level_offsets.size() - 1;
+		for (int l = 0; l < nl; ++l) {
+			const int b = s->level_offsets[l], n = s->level_offsets[l + 1] - b;
+			if (!n) continue;
+			hipLaunchKernelGGL((k_mic_apply<real, SWEEP_FWD>), dim3((n + PCG_WAVES - 1) / PCG_WAVES), dim3(256), 0, s->stream,
+			                   tc, s->level_tiles + b, n, s->abits, v, scale, part_sigma, s->pcg_state);
+			LFA_LAUNCH_CHECK(s);
+		}
+		for (int l = nl - 1; l >= 0; --l) {
+			const int b = s->level_offsets[l], n = s->level_offsets[l + 1] - b;
+			if (!n) continue;
+			hipLaunchKernelGGL((k_mic_apply<real, SWEEP_BWD>), dim3((n + PCG_WAVES - 1) / PCG_WAVES), dim3(256), 0, s->stream,
+			                   tc, s->level_tiles + b, n, s->abits, v, scale, part_sigma, s->pcg_state);
+			LFA_LAUNCH_CHECK(s);
+		}
+		hipLaunchKernelGGL(k_dot_zr<real>, dim3(G), dim3(256), 0, s->stream, tc, v, part_sigma, s->pcg_state);
+		LFA_LAUNCH_CHECK(s);
+	} else {
+		hipLaunchKernelGGL((k_mic_apply<real, SWEEP_BOTH>), dim3(G), dim3(256), 0, s->stream, tc, (const int *)nullptr,
+		                   s->n_ptiles, s->abits, v, scale, part_sigma, s->pcg_state);
+		LFA_LAUNCH_CHECK(s);
+	}
+	return LFA_OK;
+}
+
+template <typename real> static int build_system_t(lfa_sim *s, double dt) {
+	LFA_TRY(lfa_build_rhs(s, dt));
+	if (s->n_ptiles) LFA_TRY(mic_factor<real>(s));
+	s->system_valid = true;
+	return LFA_OK;
+}
+
+extern "C" int lfa_build_system(lfa_sim *s, double dt) {
+	if (!s) return LFA_E_INVALID;
+	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_pcg_alloc(s));
+	return s->prm.pcg_dtype == LFA_PCG_F64 ? build_system_t<double>(s, dt) : build_system_t<float>(s, dt);
+}
+
+template <typename real> static int solve_t(lfa_sim *s, double dt, double *residual, uint64_t *iterations) {
+	LFA_TRY(build_system_t<real>(s, dt));
+	if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[18], s->stream));
+	s->last_residual = 0.0;
+	s->last_iters = 0;
+	if (residual) *residual = 0.0;
+	if (iterations) *iterations = 0;
+	if (!s->n_ptiles) return LFA_OK;
+	TileCtx tc = make_ctx(s);
+	Vecs<real> v = make_vecs<real>(s);
+	const int G = pcg_grid(s->n_ptiles);
+	const real scale = (real)s->a_scale;
+	double *P = s->partials;
+	// early out: sum b^2 < 1e-6 (src/pressure_solver.cpp:29-35)
+	std::vector<double> hb(G);
+	LFA_HIP(s, hipMemcpyAsync(hb.data(), P + PART_B2, (size_t)G * 8, hipMemcpyDeviceToHost, s->stream));
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	double tot = 0.0;
+	for (double x : hb) tot += x;
+	if (tot != tot) return lfa_fail(s, LFA_E_NAN, "NaN in the divergence right-hand side");
+	if (tot < 1e-6) return LFA_OK;
+
+	int init_state[2] = {-1, 0};
+	LFA_HIP(s, hipMemcpyAsync(s->pcg_state, init_state, 8, hipMemcpyHostToDevice, s->stream));
+	// z = M^-1 r ; s = z ; sigma = z.r
+	LFA_TRY(mic_apply<real>(s, P + PART_SIG0));
+	hipLaunchKernelGGL(k_update_s<real>, dim3(G), dim3(256), 0, s->stream, tc, v, P + PART_SIG0, P + PART_SIG0, G, 1,
+	                   s->pcg_state);
+	LFA_LAUNCH_CHECK(s);
+	const int maxit = (int)s->prm.max_iterations;
+	const int chunk = 8;
+	int done = -1, nan = 0, i = 0;
+	int *hstate = (int *)s->h_pinned;
+	while (i < maxit && done < 0) {
+		const int end = std::min(maxit, i + chunk);
+		for (; i < end; ++i) {
+			double *sig_old = P + ((i & 1) ? PART_SIG1 : PART_SIG0), *sig_new = P + ((i & 1) ? PART_SIG0 : PART_SIG1);
+			hipLaunchKernelGGL(k_spmv<real>, dim3(G), dim3(256), 0, s->stream, tc, s->abits, (const real *)v.s, v.z, scale,
+			                   P + PART_ZS, s->pcg_state);
+			hipLaunchKernelGGL(k_axpy_max<real>, dim3(G), dim3(256), 0, s->stream, tc, s->abits, v, sig_old, P + PART_ZS, G,
+			                   P + PART_RMAX, s->pcg_state);
+			hipLaunchKernelGGL(k_check_converged, dim3(1), dim3(256), 0, s->stream, P + PART_RMAX, G, s->prm.tolerance, i,
+			                   s->pcg_state, s->pcg_hist);
+			LFA_LAUNCH_CHECK(s);
+			LFA_TRY(mic_apply<real>(s, sig_new));
+			hipLaunchKernelGGL(k_update_s<real>, dim3(G), dim3(256), 0, s->stream, tc, v, sig_new, sig_old, G, 0,
+			                   s->pcg_state);
+			LFA_LAUNCH_CHECK(s);
+		}
+		LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 8, hipMemcpyDeviceToHost, s->stream));
+		LFA_HIP(s, hipStreamSynchronize(s->stream));
+		done = hstate[0];
+		nan = hstate[1];
+	}
+	const int iters = done >= 0 ? done : maxit;
+	double res = 0.0;
+	if (iters > 0) {
+		LFA_HIP(s, hipMemcpyAsync(s->h_pinned + 4, s->pcg_hist + (iters - 1), 8, hipMemcpyDeviceToHost, s->stream));
+		LFA_HIP(s, hipStreamSynchronize(s->stream));
+		memcpy(&res, s->h_pinned + 4, 8);
+	}
+	s->last_residual = res;
+	s->last_iters = (uint64_t)iters;
+	if (residual) *residual = res;
+	if (iterations) *iterations = (uint64_t)iters;
+	if (nan) return lfa_fail(s, LFA_E_NAN, "NaN in the PCG residual at iteration %d", iters);
+	return done >= 0 ? LFA_OK : LFA_W_PCG_NOT_CONVERGED;
+}
+
+extern "C" int lfa_pcg_solve(lfa_sim *s, double dt, double *residual, uint64_t *iterations) {
+	if (!s) return LFA_E_INVALID;
+	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_pcg_alloc(s));
+	return s->prm.pcg_dtype == LFA_PCG_F64 ? solve_t<double>(s, dt, residual, iterations)
+	                                       : solve_t<float>(s, dt, residual, iterations);
+}
+
+// ---- vectors at the boundary --------------------------------------------------------------------------------
+template <typename T, typename U> static int gather(lfa_sim *s, const T *field, U *host_out, uint64_t n, int mask) {
+	LFA_TRY(lfa_number_unknowns(s));
+	if (n != s->n_unknowns) return lfa_fail(s, LFA_E_INVALID, "expected %llu unknowns", (unsigned long long)s->n_unknowns);
+	if (!n) return LFA_OK;
+	LFA_TRY(lfa_ensure_io(s, n * sizeof(U)));
+	hipLaunchKernelGGL((k_gather_unknowns<T, U>), dim3((unsigned)((s->nc + 255) / 256)), dim3(256), 0, s->stream, s->g,
+	                   s->nc, s->cell_count, s->tile_flag, s->raw_scan, field, (U *)s->io_buf, mask);
+	LFA_LAUNCH_CHECK(s);
+	LFA_HIP(s, hipMemcpyAsync(host_out, s->io_buf, n * sizeof(U), hipMemcpyDeviceToHost, s->stream));
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	return LFA_OK;
+}
+template <typename T> static int scatter(lfa_sim *s, T *field, const double *host_in, uint64_t n) {
+	LFA_TRY(lfa_number_unknowns(s));
+	if (n != s->n_unknowns) return lfa_fail(s, LFA_E_INVALID, "expected %llu unknowns", (unsigned long long)s->n_unknowns);
+	if (!n) return LFA_OK;
+	LFA_TRY(lfa_ensure_io(s, n * 8));
+	LFA_HIP(s, hipMemcpyAsync(s->io_buf, host_in, n * 8, hipMemcpyHostToDevice, s->stream));
+	hipLaunchKernelGGL(k_zero_tiles, dim3(s->n_ptiles), dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, (void *)field,
+	                   (int)sizeof(T));
+	hipLaunchKernelGGL(k_scatter_unknowns<T>, dim3((unsigned)((s->nc + 255) / 256)), dim3(256), 0, s->stream, s->g, s->nc,
+	                   s->cell_count, s->tile_flag, s->raw_scan, field, (const double *)s->io_buf);
+	LFA_LAUNCH_CHECK(s);
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	return LFA_OK;
+}
+#define NEED_SYSTEM(s)                                                                               \
+	if (!(s)) return LFA_E_INVALID;                                                                   \
+	if (!(s)->system_valid) return lfa_fail((s), LFA_E_INVALID, "call lfa_build_system (or lfa_pcg_solve) first"); \
+	LFA_HIP((s), hipSetDevice((s)->device));
+#define F64(s) ((s)->prm.pcg_dtype == LFA_PCG_F64)
+
+extern "C" int lfa_download_abits(lfa_sim *s, uint8_t *bits, uint64_t n) {
+	NEED_SYSTEM(s);
+	return gather<uint8_t, uint8_t>(s, s->abits, bits, n, 0x3F);
+}
+extern "C" int lfa_download_rhs(lfa_sim *s, double *b, uint64_t n) {
+	NEED_SYSTEM(s);
+	return F64(s) ? gather<double, double>(s, (double *)s->vr, b, n, 0) : gather<float, double>(s, (float *)s->vr, b, n, 0);
+}
+extern "C" int lfa_download_precon(lfa_sim *s, double *p, uint64_t n) {
+	NEED_SYSTEM(s);
+	return F64(s) ? gather<double, double>(s, (double *)s->vpre, p, n, 0)
+	              : gather<float, double>(s, (float *)s->vpre, p, n, 0);
+}
+extern "C" int lfa_download_pressure(lfa_sim *s, double *p, uint64_t n) {
+	NEED_SYSTEM(s);
+	return F64(s) ? gather<double, double>(s, (double *)s->vp, p, n, 0) : gather<float, double>(s, (float *)s->vp, p, n, 0);
+}
+extern "C" int lfa_upload_pressure(lfa_sim *s, const double *p, uint64_t n) {
+	NEED_SYSTEM(s);
+	return F64(s) ? scatter<double>(s, (double *)s->vp, p, n) : scatter<float>(s, (float *)s->vp, p, n);
+}
+
+template <typename real> static int apply_precon_t(lfa_sim *s, const double *r, double *z, uint64_t n) {
+	LFA_TRY(scatter<real>(s, (real *)s->vr, r, n));
+	int init_state[2] = {-1, 0};
+	LFA_HIP(s, hipMemcpyAsync(s->pcg_state, init_state, 8, hipMemcpyHostToDevice, s->stream));
+	if (s->n_ptiles) LFA_TRY(mic_apply<real>(s, s->partials + PART_SIG0));
+	return gather<real, double>(s, (real *)s->vz, z, n, 0);
+}
+extern "C" int lfa_apply_preconditioner(lfa_sim *s, const double *r, double *z, uint64_t n) {
+	NEED_SYSTEM(s);
+	if (!r || !z) return LFA_E_INVALID;
+	return F64(s) ? apply_precon_t<double>(s, r, z, n) : apply_precon_t<float>(s, r, z, n);
+}
+template <typename real> static int apply_a_t(lfa_sim *s, const double *vin, double *out, uint64_t n) {
+	LFA_TRY(scatter<real>(s, (real *)s->vs, vin, n));
+	int init_state[2] = {-1, 0};
+	LFA_HIP(s, hipMemcpyAsync(s->pcg_state, init_state, 8, hipMemcpyHostToDevice, s->stream));
+	if (s->n_ptiles) {
+		TileCtx tc = make_ctx(s);
+		hipLaunchKernelGGL(k_spmv<real>, dim3(pcg_grid(s->n_ptiles)), dim3(256), 0, s->stream, tc, s->abits,
+		                   (const real *)s->vs, (real *)s->vz, (real)s->a_scale, s->partials + PART_ZS, s->pcg_state);
+		LFA_LAUNCH_CHECK(s);
+	}
+	return gather<real, double>(s, (real *)s->vz, out, n, 0);
+}
+extern "C" int lfa_apply_a(lfa_sim *s, const double *v, double *out, uint64_t n) {
+	NEED_SYSTEM(s);
+	if (!v || !out) return LFA_E_INVALID;
+	return F64(s) ? apply_a_t<double>(s, v, out, n) : apply_a_t<float>(s, v, out, n);
+}
+
+// ================================================================================================= whole hot path
+static int ev_rec(lfa_sim *s, int i) {
+	if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[i], s->stream));
+	return LFA_OK;
+}
+
+extern "C" int lfa_step_hot(lfa_sim *s, double dt, double *residual, uint64_t *iterations) {
+	if (!s) return LFA_E_INVALID;
+	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(ev_rec(s, 0));
+	LFA_TRY(lfa_hash_particles(s));
+	LFA_TRY(ev_rec(s, 1));
+	LFA_TRY(lfa_p2g_run(s, true, dt));  // gravity fused into the normalise pass
+	LFA_TRY(ev_rec(s, 2));
+	LFA_TRY(ev_rec(s, 3));
+	LFA_TRY(lfa_pcg_alloc(s));
+	LFA_TRY(ev_rec(s, 4));
+	double res = 0.0;
+	uint64_t it = 0;
+	int rc = lfa_pcg_solve(s, dt, &res, &it);
+	if (rc < 0) return rc;
+	LFA_TRY(ev_rec(s, 5));
+	LFA_TRY(lfa_apply_pressure(s, dt));
+	LFA_TRY(ev_rec(s, 6));
+	LFA_TRY(lfa_extrapolate(s));
+	LFA_TRY(ev_rec(s, 7));
+	LFA_TRY(lfa_g2p(s));
+	LFA_TRY(ev_rec(s, 8));
+	if (residual) *residual = res;
+	if (iterations) *iterations = it;
+	if (s->timing) {
+		LFA_HIP(s, hipEventSynchronize(s->ev[8]));
+		float ms = 0.f;
+		const int pairs[8][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 4}, {4, 5}, {5, 6}, {6, 7}, {7, 8}};
+		for (int k = 0; k < 8; ++k) {
+			LFA_HIP(s, hipEventElapsedTime(&ms, s->ev[pairs[k][0]], s->ev[pairs[k][1]]));
+			s->ms[k] = ms;
+		}
+		LFA_HIP(s, hipEventElapsedTime(&ms, s->ev[16], s->ev[17]));
+		s->ms[8] = ms;
+		if (it || s->n_ptiles) {  // split [3]/[4] at the end of the system build recorded inside the solve
+			LFA_HIP(s, hipEventElapsedTime(&ms, s->ev[4], s->ev[18]));
+			s->ms[3] = ms;
+			LFA_HIP(s, hipEventElapsedTime(&ms, s->ev[18], s->ev[5]));
+			s->ms[4] = ms;
+		}
+		s->ms[9] = it ? s->ms[4] / (double)it : 0.0;
+	}
+	return rc;
+}

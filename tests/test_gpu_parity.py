@@ -1,0 +1,290 @@
+"""GPU parity tests (-m gpu): every stage of the HIP path, called through the C ABI (libfluid_amd.so), against
+ (1) the golden vectors produced by the real reference (tests/golden/*.npz), and
+ (2) the CPU oracle (oracle/oracle.c) run here on the same seeded inputs.
+
+Bars (SURVEY.md 8d "parity gates"):
+  bit-exact   particle cell keys, per-cell particle counts, _fluid_cells, cell types, A bits, PCG iteration count
+              (exact MIC(0) schedule, fp64 vectors)
+  fp32 fields face velocities after P2G / gravity / apply / extrapolate and particle v, C after G2P: max-norm relative
+              error <= 2e-5 (fp32 storage and arithmetic against the fp64 reference; sums of O(64) terms)
+  pressure    max-norm relative error <= 1e-4 (north star), in every preconditioner / dtype combination
+"""
+import numpy as np
+import pytest
+
+import libfluid_amd as lfa
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+VEL_REL = 2e-5
+P_REL = 1e-4
+
+
+def make_gpu(name, **extra):
+    c, parts, solid = util.make_case(name)
+    s = lfa.Sim(c["size"], method=c["method"], blending=c["blend"], **extra)
+    if solid is not None:
+        s.set_solid_cells(solid)
+    s.upload_particles(parts)
+    return c, parts, solid, s
+
+
+def cells_from(vel, types):
+    cells = np.zeros(len(vel), dtype=lfa.CELL_DTYPE)
+    cells["vel"] = vel
+    cells["type"] = types
+    return cells
+
+
+@pytest.mark.parametrize("name", sorted(util.CASES))
+def test_keys_counts_and_fluid_cells_bit_exact(name):
+    c, parts, solid, s = make_gpu(name)
+    g = util.load_golden(name)
+    s.hash()
+    assert np.array_equal(s.fluid_cells(), g["fluid_cells0"])
+    assert np.array_equal(s.cell_counts(), g["counts0"])
+    out = s.download_particles(into=parts.copy())
+    assert np.array_equal(out["raw"], g["raw0"])
+    assert np.array_equal(out["pos"], parts["pos"])
+    # positions reconstructed from the device's (cell, fraction) representation: fp32 fraction of a cell
+    rec = s.download_particles()
+    assert np.abs(rec["pos"] - parts["pos"]).max() <= 2.0 ** -23
+    s.close()
+
+
+@pytest.mark.parametrize("variant", [lfa.P2G_LDS_BINNED, lfa.P2G_GLOBAL_ATOMIC])
+@pytest.mark.parametrize("name", sorted(util.CASES))
+def test_p2g_and_gravity(name, variant):
+    c, parts, solid, s = make_gpu(name, p2g_variant=variant)
+    g = util.load_golden(name)
+    s.hash()
+    s.p2g()
+    cells = s.cells()
+    assert np.array_equal(cells["type"], g["p2g_type0"])
+    util.assert_close(cells["vel"], g["p2g_vel0"], VEL_REL, "p2g velocities")
+    if c["method"] == util.FLIP:
+        util.assert_close(s.old_cells()["vel"], g["old_vel0"], VEL_REL, "flip old grid")
+    s.add_gravity(util.DT)
+    util.assert_close(s.cells()["vel"], g["grav_vel0"], VEL_REL, "after gravity")
+    s.close()
+
+
+@pytest.mark.parametrize("dtype", [lfa.PCG_F32, lfa.PCG_F64])
+@pytest.mark.parametrize("name", ["apic16", "apic16_solid", "pic_ragged", "apic_tank"])
+def test_system_matrix_rhs_and_exact_mic(name, dtype):
+    """A bits bit-exact; b, MIC(0) factor, M^-1 probe and A probe against the reference on the reference's own grid."""
+    c, parts, solid, s = make_gpu(name, precond=lfa.PRECOND_MIC0_EXACT, pcg_dtype=dtype)
+    g = util.load_golden(name)
+    s.hash()
+    s.upload_cells(cells_from(g["grav_vel0"], g["p2g_type0"]))
+    s.build_system(util.DT)
+    assert np.array_equal(s.abits(), g["abits0"])
+    rel = 1e-6 if dtype == lfa.PCG_F32 else 1e-6  # b is built from fp32 face velocities in both cases
+    util.assert_close(s.b(), g["b0"], rel, "rhs")
+    util.assert_close(s.precon(), g["precon0"], 1e-6 if dtype == lfa.PCG_F32 else 1e-13, "MIC(0) factor")
+    n = len(g["b0"])
+    probe = np.sin(np.arange(n) * 0.37) + 0.25
+    util.assert_close(s.apply_a(probe), g["Aprobe0"], 1e-6 if dtype == lfa.PCG_F32 else 1e-13, "A probe")
+    util.assert_close(s.apply_precon(probe), g["Mprobe0"], 2e-5 if dtype == lfa.PCG_F32 else 1e-12, "M^-1 probe")
+    s.close()
+
+
+@pytest.mark.parametrize("name", sorted(util.CASES))
+def test_pcg_exact_schedule_matches_reference_iterations(name):
+    """Hyperplane-ordered MIC(0) with fp64 vectors: same recurrence as the reference => same iteration count."""
+    c, parts, solid, s = make_gpu(name, precond=lfa.PRECOND_MIC0_EXACT, pcg_dtype=lfa.PCG_F64)
+    g = util.load_golden(name)
+    s.hash()
+    s.upload_cells(cells_from(g["grav_vel0"], g["p2g_type0"]))
+    p, res, it, rc = s.solve(util.DT)
+    assert rc == 0
+    assert it == int(g["iters0"])
+    assert res < 1e-6
+    util.assert_close(p, g["p0"], 1e-6, "pressure (exact MIC, f64)")
+    s.close()
+
+
+@pytest.mark.parametrize("dtype", [lfa.PCG_F32, lfa.PCG_F64])
+@pytest.mark.parametrize("precond", [lfa.PRECOND_MIC0_TILED, lfa.PRECOND_MIC0_EXACT])
+@pytest.mark.parametrize("name", ["apic16_solid", "flip16", "pic_ragged", "apic_tank"])
+def test_pcg_pressure_within_tolerance(name, precond, dtype):
+    c, parts, solid, s = make_gpu(name, precond=precond, pcg_dtype=dtype)
+    g = util.load_golden(name)
+    s.hash()
+    s.upload_cells(cells_from(g["grav_vel0"], g["p2g_type0"]))
+    p, res, it, rc = s.solve(util.DT)
+    assert rc == 0 and 0 < it <= 200 and res < 1e-6
+    util.assert_close(p, g["p0"], P_REL, "pressure")
+    s.close()
+
+
+@pytest.mark.parametrize("name", sorted(util.CASES))
+def test_apply_pressure_extrapolate_g2p(name):
+    """Each downstream stage from the reference's state of the stage before it."""
+    c, parts, solid, s = make_gpu(name)
+    g = util.load_golden(name)
+    s.hash()
+    s.upload_cells(cells_from(g["grav_vel0"], g["p2g_type0"]))
+    s.build_system(util.DT)
+    s.upload_pressure(g["p0"])
+    s.apply_pressure(util.DT)
+    util.assert_close(s.cells()["vel"], g["apply_vel0"], VEL_REL, "after apply_pressure")
+    s.upload_cells(cells_from(g["apply_vel0"], g["p2g_type0"]))
+    s.extrapolate()
+    util.assert_close(s.cells()["vel"], g["extrap_vel0"], VEL_REL, "after extrapolation")
+    if c["method"] != util.FLIP:  # FLIP needs the old grid of its own P2G: covered by the end-to-end test
+        s.upload_cells(cells_from(g["extrap_vel0"], g["p2g_type0"]))
+        s.g2p()
+        out = s.download_particles(into=parts.copy())
+        util.assert_close(out["vel"], g["g2p_vel0"], VEL_REL, "particle velocity after G2P")
+        if c["method"] == util.APIC:
+            cc = np.concatenate([out["cx"], out["cy"], out["cz"]], axis=1)
+            util.assert_close(cc, g["g2p_c0"], 5e-5, "APIC C after G2P")
+    s.close()
+
+
+@pytest.mark.parametrize("precond,dtype", [(lfa.PRECOND_MIC0_EXACT, lfa.PCG_F64), (lfa.PRECOND_MIC0_TILED, lfa.PCG_F32)])
+@pytest.mark.parametrize("name", sorted(util.CASES))
+def test_two_hot_steps_end_to_end(name, precond, dtype):
+    """Two full passes of the hot path, staged exactly like the golden run, against the reference's final state."""
+    c, parts, solid, s = make_gpu(name, precond=precond, pcg_dtype=dtype)
+    g = util.load_golden(name)
+    for st in range(2):
+        s.hash()
+        assert np.array_equal(s.fluid_cells(), g[f"fluid_cells{st}"])
+        s.p2g()
+        s.add_gravity(util.DT)
+        p, res, it, rc = s.solve(util.DT)
+        assert rc == 0
+        if precond == lfa.PRECOND_MIC0_EXACT:
+            assert abs(it - int(g[f"iters{st}"])) <= 1  # inputs carry fp32 P2G rounding here
+        util.assert_close(p, g[f"p{st}"], P_REL, f"pressure step {st}")
+        s.apply_pressure(util.DT)
+        s.extrapolate()
+        util.assert_close(s.cells()["vel"], g[f"extrap_vel{st}"], 1e-4, f"grid step {st}")
+        s.g2p()
+        out = s.download_particles(into=parts.copy())
+        util.assert_close(out["vel"], g[f"g2p_vel{st}"], 1e-4, f"particle velocity step {st}")
+        util.assert_close(np.concatenate([out["cx"], out["cy"], out["cz"]], axis=1), g[f"g2p_c{st}"], 2e-4,
+                          f"particle C step {st}", atol=1e-12)
+        assert abs(s.cfl() - float(g[f"cfl{st}"])) <= 1e-4 * float(g[f"cfl{st}"])
+    s.close()
+
+
+@pytest.mark.parametrize("name", ["apic16_solid", "flip16", "apic_ragged"])
+def test_step_hot_equals_staged_calls_and_oracle(name):
+    """lfa_step_hot (fused gravity, no intermediate downloads) against the oracle's hot_step on the same inputs."""
+    from oracle import loader as orc
+    c, parts, solid, s = make_gpu(name, precond=lfa.PRECOND_MIC0_EXACT, pcg_dtype=lfa.PCG_F64)
+    o = orc.CpuSim(c["size"], method=c["method"], blending=c["blend"])
+    if solid is not None:
+        o.set_solid_cells(solid)
+    o.set_particles(parts)
+    for st in range(2):
+        res, it, rc = s.step_hot(util.DT)
+        po, reso, ito = o.hot_step(util.DT)
+        assert rc == 0 and abs(it - ito) <= 1
+        util.assert_close(s.pressure(), po, P_REL, "pressure")
+        util.assert_close(s.cells()["vel"], o.cells()["vel"], 1e-4, "grid")
+    got = s.download_particles(into=parts.copy())
+    want = o.particles()
+    want = want[util.order_by_position(want)]
+    gi = util.order_by_position(got)
+    util.assert_close(got["vel"][gi], want["vel"], 1e-4, "particle velocities")
+    assert np.array_equal(got["raw"][gi], want["raw"])
+    s.close()
+
+
+def test_seed_block_matches_numpy_generator():
+    s = lfa.Sim((24, 16, 16))
+    s.seed_block((2, 1, 3), (10, 9, 11))
+    want = util.scenes.seed_block((2, 1, 3), (10, 9, 11))
+    got = s.download_particles()
+    assert got.shape == want.shape
+    assert np.abs(got["pos"] - want["pos"]).max() <= 2.0 ** -23
+    s.hash()
+    o = lfa.Sim((24, 16, 16))
+    o.upload_particles(want)
+    o.hash()
+    assert np.array_equal(s.cell_counts(), o.cell_counts())
+    assert np.array_equal(s.download_particles()["raw"], o.download_particles()["raw"])
+    s.close(); o.close()
+
+
+def test_particle_on_the_max_face_and_empty_set():
+    """Edge cases of SURVEY 8(a1): unclamped index == size (position exactly on the max face) and no particles."""
+    from oracle import loader as orc
+    size = (8, 8, 8)
+    parts = util.scenes.seed_block((5, 5, 5), (8, 8, 8))
+    parts["pos"][0] = (8.0, 7.25, 6.5)     # on the +x wall
+    parts["pos"][1] = (7.5, 8.0, 8.0)      # on an edge
+    parts["pos"][2] = (0.0, 6.5, 7.75)     # on the -x wall
+    parts["vel"] = np.random.default_rng(5).normal(size=(len(parts), 3))
+    s = lfa.Sim(size, precond=lfa.PRECOND_MIC0_EXACT, pcg_dtype=lfa.PCG_F64)
+    o = orc.CpuSim(size)
+    s.upload_particles(parts); o.set_particles(parts)
+    s.step_hot(util.DT); o.hot_step(util.DT)
+    assert np.array_equal(s.fluid_cells(), o.fluid_cells())
+    got = s.download_particles(into=parts.copy())
+    want = o.particles()
+    gi, wi = util.order_by_position(got), util.order_by_position(want)
+    assert np.array_equal(got["raw"][gi], want["raw"][wi])
+    util.assert_close(got["vel"][gi], want["vel"][wi], 1e-4, "velocities with wall particles")
+    util.assert_close(np.concatenate([got["cx"], got["cy"], got["cz"]], axis=1)[gi],
+                      np.concatenate([want["cx"], want["cy"], want["cz"]], axis=1)[wi], 2e-4, "C with wall particles")
+    s.close()
+    e = lfa.Sim(size)
+    e.upload_particles(np.zeros(0, dtype=lfa.PARTICLE_DTYPE))
+    res, it, rc = e.step_hot(util.DT)
+    assert (res, it, rc) == (0.0, 0, 0) and e.num_fluid_cells == 0 and np.isinf(e.cfl())
+    e.close()
+
+
+def test_multiple_extrapolation_iterations():
+    from oracle import loader as orc
+    c, parts, solid, s = make_gpu("apic16_solid", velocity_extrapolation_iterations=3)
+    o = orc.CpuSim(c["size"], method=c["method"])
+    o.set_solid_cells(solid); o.set_particles(parts); o.set_extrapolation_iterations(3)
+    o.hash(); o.p2g(); o.add_gravity(util.DT)
+    s.hash(); s.p2g(); s.add_gravity(util.DT)
+    o.build_system(util.DT); o.extrapolate()
+    s.extrapolate()
+    util.assert_close(s.cells()["vel"], o.cells()["vel"], VEL_REL, "3 extrapolation sweeps")
+    s.close()
+
+
+def test_properties_at_scale():
+    """128^3 / 2M particles (BASELINE config 2): size-independent properties instead of an oracle run.
+    - hydrostatic column: p = rho |g| depth to 1e-4, velocities stay ~0
+    - the projected grid field is divergence free (rhs of a second build ~ 0 relative to the first)
+    - binned and global-atomic P2G agree."""
+    n = 128
+    s = lfa.Sim((n, n, n), precond=lfa.PRECOND_MIC0_TILED, pcg_dtype=lfa.PCG_F32)
+    s.seed_block((0, 0, 0), (n, 32, n))  # tank filled wall to wall, 32 cells deep
+    res, it, rc = s.step_hot(util.DT)
+    assert rc == 0 and res < 1e-6
+    fc = s.fluid_cells().astype(np.int64)
+    y = (fc // n) % n
+    util.assert_close(s.pressure(), 981.0 * (32 - y), P_REL, "hydrostatic pressure at 128^3")
+    assert np.abs(s.download_particles()["vel"]).max() < 981.0 * util.DT * 1e-3
+    s.close()
+
+    s = lfa.Sim((n, n, n))
+    s.seed_block((0, 0, 0), (64, 64, 64))
+    s.hash(); s.p2g(); s.add_gravity(util.DT)
+    s.build_system(util.DT)
+    b0 = np.abs(s.b()).max()
+    p, res, it, rc = s.solve(util.DT)
+    assert rc == 0
+    s.apply_pressure(util.DT)
+    s.build_system(util.DT)
+    assert np.abs(s.b()).max() < 1e-4 * b0
+    a = s.cells()["vel"].copy()
+    s.close()
+    t = lfa.Sim((n, n, n), p2g_variant=lfa.P2G_GLOBAL_ATOMIC)
+    t.seed_block((0, 0, 0), (64, 64, 64))
+    t.hash(); t.p2g(); t.add_gravity(util.DT)
+    t.solve(util.DT); t.apply_pressure(util.DT)
+    util.assert_close(t.cells()["vel"], a, 1e-4, "binned vs atomic P2G at 128^3")
+    t.close()
