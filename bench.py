@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-steps/s (+ PCG iterations/s) of the MI355X hot path on BASELINE.json's synthetic dam break.
+
+A "step" is one device-resident pass of the hot path over the resident particle set (lfa_step_hot):
+    tile binning -> P2G -> gravity -> pressure system + MIC(0)-PCG -> pressure gradient -> extrapolation -> G2P
+(reference: src/simulation.cpp:62-66,72-78,83-104,119-121). The stages of simulation::time_step outside SURVEY.md
+section 8(a) (advect / collide / position correction, 8(f) "next" rows) are not part of the timed region.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches one rank per GPU with
+torch.distributed.run. W untimed steps, then exactly K timed steps bracketed by barrier + device synchronise, MAX over
+ranks, rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6.3 TB/s achievable
+
+# algorithmic bytes per unit; n = PCG unknowns, Np particles, Nc cells of the processed tiles
+PCG_BYTES = {"spmv_dot": 17, "axpy_max": 28, "mic_apply_dot": 34, "update_s": 12}
+
+
+def cpu_baseline(sample, steps):
+    """The oracle (plain-C fp64 restatement of the reference's serial hot path) timed on this box's host cores."""
+    import numpy as np  # noqa: F401
+    from libfluid_amd import scenes
+    from oracle import loader as orc
+    cfg = scenes.CONFIGS[sample]
+    parts = scenes.seed_block(*cfg["block"])
+    sim = orc.CpuSim(cfg["size"], method=cfg["method"], blending=cfg["blending"])
+    sim.set_particles(parts)
+    t0 = time.perf_counter()
+    iters = 0
+    for _ in range(steps):
+        _, _, it = sim.hot_step(0.033)
+        iters += it
+    dt = time.perf_counter() - t0
+    return {
+        "value": len(parts) * steps / dt, "unit": "particle-steps/s", "cores": 1, "kind": "port",
+        "sample": f"{sample}: {cfg['size'][0]}^3 grid, {len(parts)} particles, {steps} hot-path steps, "
+                  f"{iters} PCG iterations, {dt:.1f} s; serial like the reference's P2G/PCG/G2P (src/simulation.cpp:293-398,"
+                  f" src/pressure_solver.cpp:19-71), gcc -O2",
+        "pcg_iters_per_s": iters / dt,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default=None, help="C2 | C3 | C4 | C5 (default: C4 at 1 GPU, see DESIGN.md)")
+    ap.add_argument("--dt", type=float, default=0.033, help="min(3*cfl, 0.033) of simulation::time_step() at rest")
+    ap.add_argument("--precond", default="tiled", choices=["tiled", "exact"])
+    ap.add_argument("--pcg-dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--p2g", default="binned", choices=["binned", "atomic"])
+    ap.add_argument("--cpu-sample", default="C2")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import libfluid_amd as lfa
+    from libfluid_amd import scenes
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    cfg_name = args.config or "C4"
+    cfg = scenes.CONFIGS[cfg_name]
+    sim = lfa.Sim(cfg["size"], method=cfg["method"], blending=cfg["blending"], device=local_rank,
+                  precond=lfa.PRECOND_MIC0_EXACT if args.precond == "exact" else lfa.PRECOND_MIC0_TILED,
+                  pcg_dtype=lfa.PCG_F64 if args.pcg_dtype == "f64" else lfa.PCG_F32,
+                  p2g_variant=lfa.P2G_GLOBAL_ATOMIC if args.p2g == "atomic" else lfa.P2G_LDS_BINNED)
+    # z-slab domain decomposition is not built yet: at N > 1 every rank owns an independent copy of the domain
+    # (weak scaling over replicas, no data-path collective); see DESIGN.md section "multi-GPU".
+    sim.seed_block(*cfg["block"])
+    sim.enable_timing(True)
+
+    def barrier():
+        sim.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    iters_total, not_converged = 0, 0
+    for _ in range(args.warmup):
+        sim.step_hot(args.dt)
+    barrier()
+    t0 = time.perf_counter()
+    stage_ms = {}
+    for _ in range(args.steps):
+        res, it, rc = sim.step_hot(args.dt)
+        iters_total += it
+        not_converged += int(rc == lfa.W_PCG_NOT_CONVERGED)
+        for k, v in sim.timings().items():
+            stage_ms[k] = stage_ms.get(k, 0.0) + v
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    counts = sim.counts()
+    npart, n_unknowns = counts["particles"], counts["unknowns"]
+    ncell_proc = counts["processed_tiles"] * 512
+    value = npart * world * args.steps / elapsed
+    stage_ms = {k: v / args.steps for k, v in stage_ms.items()}
+    pcg_s = stage_ms["pcg_loop"] * 1e-3 * args.steps
+
+    out = {
+        "metric": "particle_steps_per_sec", "value": value, "unit": "particle-steps/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.pcg_dtype == "f32" else "f32 particles/grid, f64 PCG vectors", "data": "synthetic",
+        "config": {
+            "workload": f"{cfg_name}: {cfg['size'][0]}x{cfg['size'][1]}x{cfg['size'][2]} MAC grid, dam-break block "
+                        f"{cfg['block'][0]}-{cfg['block'][1]} cells, {npart} particles/GPU, "
+                        f"{['PIC', 'FLIP', 'APIC'][cfg['method']]} blend {cfg['blending']}, dt {args.dt}, "
+                        f"hot path only (bin+P2G+gravity+PCG+apply+extrapolate+G2P)",
+            "unknowns": n_unknowns, "particles_per_gpu": npart,
+            "precond": "MIC(0) per 8^3 tile" if args.precond == "tiled" else "MIC(0) exact (tile hyperplanes)",
+            "p2g": args.p2g, "pcg_tolerance": 1e-6, "pcg_max_iterations": 200,
+            "parallelism": "1 GPU" if world == 1 else f"{world} independent replicas (z-slab decomposition pending)",
+        },
+        "pcg": {
+            "iterations_per_step": iters_total / max(args.steps, 1),
+            "iters_per_sec": iters_total / pcg_s if pcg_s > 0 else None,
+            "unknown_iters_per_sec": n_unknowns * iters_total / pcg_s if pcg_s > 0 else None,
+            "steps_hitting_max_iterations": not_converged,
+        },
+        "stage_ms": stage_ms,
+    }
+
+    if rank == 0 and not args.no_kernel_timing:
+        # live HIP-event timing of each hot kernel on the handle's stream (mean of 20 launches)
+        apic = cfg["method"] == 2
+        kernels = {}
+        for name in ("spmv_dot", "axpy_max", "mic_apply_dot", "update_s"):
+            ms = sim.bench_kernel(name, 20)
+            b = PCG_BYTES[name] * n_unknowns * (2 if args.pcg_dtype == "f64" else 1)
+            kernels[name] = {"ms": ms, "algorithmic_bytes": b, "GBps": b / ms * 1e-6}
+        p2g_bytes = (60 if apic else 24) * npart
+        g2p_bytes = (60 if apic else (36 if cfg["method"] == 1 else 24)) * npart + \
+            (24 if cfg["method"] == 1 else 12) * ncell_proc
+        fin_bytes = (26 if cfg["method"] == 1 else 14) * ncell_proc
+        for name, b in (("g2p", g2p_bytes), ("p2g_finalize", fin_bytes), ("p2g_scatter", p2g_bytes)):
+            ms = sim.bench_kernel(name, 10)
+            kernels[name] = {"ms": ms, "algorithmic_bytes": b, "GBps": b / ms * 1e-6}
+        out["kernels"] = kernels
+        # dominant kernel = largest share of the step: iterations x per-iteration kernel time vs the one-shot kernels
+        it_per_step = iters_total / max(args.steps, 1)
+        share = {k: v["ms"] * (it_per_step if k in PCG_BYTES else 1.0) for k, v in kernels.items()}
+        dom = max(share, key=share.get)
+        out["roofline"] = {
+            "bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
+            "share_of_step_ms": share[dom],
+        }
+        pcg_iter_ms = sum(kernels[k]["ms"] for k in PCG_BYTES)
+        pcg_bytes = 91 * n_unknowns * (2 if args.pcg_dtype == "f64" else 1)
+        out["roofline_groups"] = {
+            "pcg_iteration": {"ms": pcg_iter_ms, "algorithmic_bytes": pcg_bytes, "GBps": pcg_bytes / pcg_iter_ms * 1e-6,
+                              "frac": pcg_bytes / pcg_iter_ms * 1e-6 / HBM_PEAK_GBS},
+            "p2g": {"ms": kernels["p2g_scatter"]["ms"] + kernels["p2g_finalize"]["ms"],
+                    "algorithmic_bytes": p2g_bytes + fin_bytes,
+                    "GBps": (p2g_bytes + fin_bytes) / (kernels["p2g_scatter"]["ms"] + kernels["p2g_finalize"]["ms"]) * 1e-6,
+                    "frac": (p2g_bytes + fin_bytes) / (kernels["p2g_scatter"]["ms"] + kernels["p2g_finalize"]["ms"])
+                    * 1e-6 / HBM_PEAK_GBS},
+        }
+    sim.close()
+
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_steps)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -155,6 +155,20 @@ int lfa_get_timings(lfa_sim *s, double ms[LFA_NUM_TIMERS]);
  * by grid kernels (dilated set) [4] padded cell count */
 int lfa_get_counts(lfa_sim *s, uint64_t counts[5]);
 
+/* Times `reps` back-to-back launches of one hot-path kernel on the state left by the last lfa_step_hot, with HIP
+ * events on the handle's stream; returns the mean launch duration in milliseconds. For bench.py's roofline object. */
+enum {
+	LFA_K_SPMV_DOT = 0,    /* z = A s, dot(z,s)                         algorithmic 17 n bytes */
+	LFA_K_AXPY_MAX = 1,    /* p += a s, r -= a z, max r                 algorithmic 28 n bytes */
+	LFA_K_MIC_APPLY = 2,   /* z = M^-1 r (fwd+bwd), dot(z,r)            algorithmic 34 n bytes */
+	LFA_K_UPDATE_S = 3,    /* s = z + b s                               algorithmic 12 n bytes */
+	LFA_K_P2G_SCATTER = 4, /* particles -> per-tile (sum wv, sum w)     algorithmic 60 Np (APIC) / 24 Np bytes */
+	LFA_K_P2G_FINALIZE = 5,/* normalise + type + gravity                algorithmic 14 Nc bytes (+12 Nc FLIP) */
+	LFA_K_G2P = 6,         /* grid -> particles                         algorithmic 60 Np + 12 Nc (APIC) */
+	LFA_K_BIN = 7          /* tile binning (count + scatter)            algorithmic 2*68 Np + 8 Np bytes */
+};
+int lfa_bench_kernel(lfa_sim *s, int which, int reps, double *mean_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,7 +100,10 @@ SIGNATURES = {
     "lfa_enable_timing": (_int, [_vp, _int]),
     "lfa_get_timings": (_int, [_vp, C.POINTER(_dbl * NUM_TIMERS)]),
     "lfa_get_counts": (_int, [_vp, C.POINTER(_u64 * 5)]),
+    "lfa_bench_kernel": (_int, [_vp, _int, _int, C.POINTER(_dbl)]),
 }
+KERNELS = {"spmv_dot": 0, "axpy_max": 1, "mic_apply_dot": 2, "update_s": 3, "p2g_scatter": 4, "p2g_finalize": 5,
+           "g2p": 6, "bin": 7}
 
 
 def load_library():
@@ -321,6 +324,11 @@ class Sim:
         arr = (C.c_double * NUM_TIMERS)()
         self._chk(self.lib.lfa_get_timings(self.h, C.byref(arr)))
         return dict(zip(TIMER_NAMES, list(arr)))
+
+    def bench_kernel(self, name, reps=20):
+        out = C.c_double(0.0)
+        self._chk(self.lib.lfa_bench_kernel(self.h, KERNELS[name], int(reps), C.byref(out)))
+        return out.value
 
     def counts(self):
         arr = (C.c_uint64 * 5)()

@@ -438,3 +438,5 @@ extern "C" int lfa_g2p(lfa_sim *s) {
 	LFA_LAUNCH_CHECK(s);
 	return LFA_OK;
 }
+
+int lfa_g2p_bench(lfa_sim *s) { return lfa_g2p(s); }

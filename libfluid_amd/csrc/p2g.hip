@@ -343,3 +343,50 @@ extern "C" int lfa_add_gravity(lfa_sim *s, double dt) {
 	s->system_valid = false;
 	return LFA_OK;
 }
+
+/// One launch of the P2G scatter kernel / finalize kernel / binning pass on the current state (lfa_bench_kernel).
+int lfa_p2g_bench(lfa_sim *s, int which) {
+	const ParticleSoA &p = s->pb[s->cur];
+	const bool apic = s->prm.simulation_method == LFA_APIC;
+	const float hworld = (float)s->prm.cell_size;
+	if (which == LFA_K_P2G_SCATTER) {
+		if (s->prm.p2g_variant == LFA_P2G_LDS_BINNED) {
+			if (!s->stage || (size_t)s->n_ptiles > s->stage_tiles) return lfa_fail(s, LFA_E_INVALID, "no staging slabs");
+			dim3 grid(grid_blocks(s->n_ptiles));
+			if (apic)
+				hipLaunchKernelGGL(k_p2g_binned<true>, grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, p,
+				                   s->tile_start, s->stage, hworld);
+			else
+				hipLaunchKernelGGL(k_p2g_binned<false>, grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, p,
+				                   s->tile_start, s->stage, hworld);
+		} else {
+			if (!s->acc) return lfa_fail(s, LFA_E_INVALID, "no accumulators");
+			dim3 grid((unsigned)((s->np + 255) / 256));
+			if (apic)
+				hipLaunchKernelGGL(k_p2g_atomic<true>, grid, dim3(256), 0, s->stream, s->np, p, s->acc, s->ncp, s->g, hworld);
+			else
+				hipLaunchKernelGGL(k_p2g_atomic<false>, grid, dim3(256), 0, s->stream, s->np, p, s->acc, s->ncp, s->g, hworld);
+		}
+		LFA_LAUNCH_CHECK(s);
+		return LFA_OK;
+	}
+	if (which == LFA_K_P2G_FINALIZE) {
+		FinalizeParams fp;
+		fp.method = s->prm.simulation_method;
+		fp.fuse_gravity = 0;
+		fp.g[0] = fp.g[1] = fp.g[2] = 0.f;
+		dim3 grid(grid_blocks(s->n_dtiles));
+		if (s->prm.p2g_variant == LFA_P2G_LDS_BINNED)
+			hipLaunchKernelGGL(k_p2g_finalize<true>, grid, dim3(256), 0, s->stream, s->dtiles, s->n_dtiles, s->g,
+			                   s->tile_pslot, s->stage, s->acc, s->ncp, s->cell_count, s->solid, s->u, s->v, s->w, s->uo,
+			                   s->vo, s->wo, s->ctype, fp);
+		else
+			hipLaunchKernelGGL(k_p2g_finalize<false>, grid, dim3(256), 0, s->stream, s->dtiles, s->n_dtiles, s->g,
+			                   s->tile_pslot, s->stage, s->acc, s->ncp, s->cell_count, s->solid, s->u, s->v, s->w, s->uo,
+			                   s->vo, s->wo, s->ctype, fp);
+		LFA_LAUNCH_CHECK(s);
+		return LFA_OK;
+	}
+	if (which == LFA_K_BIN) return lfa_hash_particles(s);
+	return lfa_fail(s, LFA_E_INVALID, "unknown kernel id %d", which);
+}

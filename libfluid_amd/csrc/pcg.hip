@@ -790,3 +790,64 @@ extern "C" int lfa_step_hot(lfa_sim *s, double dt, double *residual, uint64_t *i
 	}
 	return rc;
 }
+
+// ================================================================================================= measurement
+int lfa_p2g_bench(lfa_sim *s, int which);   // p2g.hip
+int lfa_g2p_bench(lfa_sim *s);              // grid_ops.hip
+
+template <typename real> static int bench_launch(lfa_sim *s, int which) {
+	TileCtx tc = make_ctx(s);
+	Vecs<real> v = make_vecs<real>(s);
+	const int G = pcg_grid(s->n_ptiles);
+	const real scale = (real)s->a_scale;
+	double *P = s->partials;
+	switch (which) {
+	case LFA_K_SPMV_DOT:
+		hipLaunchKernelGGL(k_spmv<real>, dim3(G), dim3(256), 0, s->stream, tc, s->abits, (const real *)v.s, v.z, scale,
+		                   P + PART_ZS, s->pcg_state);
+		break;
+	case LFA_K_AXPY_MAX:
+		hipLaunchKernelGGL(k_axpy_max<real>, dim3(G), dim3(256), 0, s->stream, tc, s->abits, v, P + PART_SIG0, P + PART_ZS,
+		                   G, P + PART_RMAX, s->pcg_state);
+		break;
+	case LFA_K_MIC_APPLY:
+		return mic_apply<real>(s, P + PART_SIG1);
+	case LFA_K_UPDATE_S:
+		hipLaunchKernelGGL(k_update_s<real>, dim3(G), dim3(256), 0, s->stream, tc, v, P + PART_SIG0, P + PART_SIG0, G, 0,
+		                   s->pcg_state);
+		break;
+	}
+	LFA_LAUNCH_CHECK(s);
+	return LFA_OK;
+}
+
+extern "C" int lfa_bench_kernel(lfa_sim *s, int which, int reps, double *mean_ms) {
+	if (!s || !mean_ms || reps < 1) return LFA_E_INVALID;
+	if (!s->binned || !s->n_ptiles) return lfa_fail(s, LFA_E_INVALID, "lfa_bench_kernel: run lfa_step_hot first");
+	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_enable_timing(s, s->timing ? 1 : 0));
+	if (!s->ev_created) {
+		for (auto &e : s->ev) LFA_HIP(s, hipEventCreate(&e));
+		s->ev_created = true;
+	}
+	if (which <= LFA_K_UPDATE_S) {
+		if (!s->system_valid) return lfa_fail(s, LFA_E_INVALID, "lfa_bench_kernel: no pressure system on the device");
+		int init_state[2] = {-1, 0};  // "still iterating": the kernels early-out once a solve has converged
+		LFA_HIP(s, hipMemcpyAsync(s->pcg_state, init_state, 8, hipMemcpyHostToDevice, s->stream));
+	}
+	auto once = [&]() -> int {
+		if (which <= LFA_K_UPDATE_S) return F64(s) ? bench_launch<double>(s, which) : bench_launch<float>(s, which);
+		if (which == LFA_K_G2P) return lfa_g2p_bench(s);
+		return lfa_p2g_bench(s, which);
+	};
+	LFA_TRY(once());  // warm
+	LFA_HIP(s, hipEventRecord(s->ev[20], s->stream));
+	for (int i = 0; i < reps; ++i) LFA_TRY(once());
+	LFA_HIP(s, hipEventRecord(s->ev[21], s->stream));
+	LFA_HIP(s, hipEventSynchronize(s->ev[21]));
+	float ms = 0.f;
+	LFA_HIP(s, hipEventElapsedTime(&ms, s->ev[20], s->ev[21]));
+	*mean_ms = (double)ms / reps;
+	s->system_valid = which <= LFA_K_UPDATE_S ? s->system_valid : false;
+	return LFA_OK;
+}

@@ -247,13 +247,12 @@ class CpuSim:
     def hot_step(self, dt):
         """hash -> p2g -> gravity -> solve -> apply -> extrapolate -> g2p; returns (p, residual, iters)."""
         if self.L.hot_step is not None:
-            self.L.hash(self.h)
-            n = self.L.num_fluid_cells(self.h)
-            p = np.zeros(max(n, 1), dtype=np.float64)
+            cap = max(min(self.L.num_particles(self.h), self.ncells), 1)
+            p = np.zeros(cap, dtype=np.float64)
             res = C.c_double(0.0)
             it = C.c_uint64(0)
             self.L.hot_step(self.h, dt, _ptr(p), C.byref(res), C.byref(it))
-            return p[:n], res.value, it.value
+            return p[:self.L.num_fluid_cells(self.h)], res.value, it.value
         self.hash()
         self.p2g()
         self.add_gravity(dt)
