@@ -68,6 +68,7 @@ struct lfa_sim {
 	// tiles
 	uint32_t *tile_count = nullptr, *tile_start = nullptr;  // nt, nt+1
 	uint32_t *tile_flag = nullptr, *tile_scan = nullptr;    // nt
+	uint32_t *grid_flag = nullptr;  // nt: dilated-set membership at the time of the last P2G (the tiles the grid is explicit on)
 	int *ptiles = nullptr, *dtiles = nullptr;               // nt
 	int *tile_pslot = nullptr;                               // nt : slot in ptiles or -1
 	int n_ptiles = 0, n_dtiles = 0;

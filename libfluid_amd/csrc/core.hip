@@ -201,6 +201,7 @@ extern "C" int lfa_create(lfa_sim **out, uint64_t nx, uint64_t ny, uint64_t nz, 
 	chk(dev_alloc(s, &s->tile_start, g.nt + 1, true));
 	chk(dev_alloc(s, &s->tile_flag, g.nt + 1, true));
 	chk(dev_alloc(s, &s->tile_scan, g.nt + 1, true));
+	chk(dev_alloc(s, &s->grid_flag, g.nt + 1, true));
 	chk(dev_alloc(s, &s->ptiles, g.nt, true));
 	chk(dev_alloc(s, &s->dtiles, g.nt, true));
 	chk(dev_alloc(s, &s->tile_pslot, g.nt, true));
@@ -243,7 +244,7 @@ extern "C" void lfa_destroy(lfa_sim *s) {
 	if (s->stream) (void)hipStreamSynchronize(s->stream);
 	free_soa(s->pb[0]);
 	free_soa(s->pb[1]);
-	void *ptrs[] = {s->rank, s->tile_count, s->tile_start, s->tile_flag, s->tile_scan, s->ptiles, s->dtiles,
+	void *ptrs[] = {s->grid_flag, s->rank, s->tile_count, s->tile_start, s->tile_flag, s->tile_scan, s->ptiles, s->dtiles,
 	                s->tile_pslot, s->scan_tmp, s->u, s->v, s->w, s->uo, s->vo, s->wo, s->ctype, s->solid,
 	                s->cell_count, s->stage, s->acc, s->abits, s->vp, s->vr, s->vz, s->vs, s->vpre, s->vq,
 	                s->partials, s->pcg_state, s->pcg_hist, s->level_tiles, s->io_buf, s->raw_scan};
@@ -370,8 +371,7 @@ extern "C" int lfa_upload_particles(lfa_sim *s, const void *aos152, uint64_t n) 
 	LFA_HIP(s, hipSetDevice(s->device));
 	LFA_TRY(lfa_particles_alloc(s, n));
 	s->np = n;
-	s->binned = false;
-	s->grid_valid = false;
+	s->binned = false;  // the grid stays what it was (G2P re-uploads corrected positions between apply and gather)
 	s->system_valid = false;
 	s->unknown_count_valid = false;
 	s->cur = 0;
@@ -565,7 +565,8 @@ static int export_cells(lfa_sim *s, void *aos32, const float *u, const float *v,
 	LFA_HIP(s, hipSetDevice(s->device));
 	LFA_TRY(lfa_ensure_io(s, s->nc * 32));
 	hipLaunchKernelGGL(k_export_cells, dim3((unsigned)((s->nc + 255) / 256)), dim3(256), 0, s->stream,
-	                   (CellAos *)s->io_buf, s->g, s->nc, u, v, w, s->ctype, s->solid, s->tile_flag, s->binned ? 1 : 0,
+	                   (CellAos *)s->io_buf, s->g, s->nc, u, v, w, s->ctype, s->solid,
+	                   s->grid_valid ? s->grid_flag : s->tile_flag, (s->grid_valid || s->binned) ? 1 : 0,
 	                   s->grid_valid ? 0 : 1, old ? 0.0 : s->bg[0], old ? 0.0 : s->bg[1], old ? 0.0 : s->bg[2]);
 	LFA_LAUNCH_CHECK(s);
 	LFA_HIP(s, hipMemcpyAsync(aos32, s->io_buf, s->nc * 32, hipMemcpyDeviceToHost, s->stream));

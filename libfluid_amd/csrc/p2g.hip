@@ -71,35 +71,66 @@ __device__ inline void scatter_particle(int lx, int ly, int lz, const float t[3]
 }
 
 // ------------------------------------------------------------------------------------------------ LDS-binned
+// Accumulation primitive. Measured on MI355X (tools/lds_atomic_bench.hip, lane-ops/clk/CU, random addresses):
+//   ds_add_f32 0.33 | ds_add_f64 2.3 | ds_add_u64 4.3 | ds_add_u32 6.7 | ds_write_b32 7.2
+// i.e. the fp32 LDS atomic is ~20x slower than the 64-bit integer one on gfx950. The tile therefore accumulates in
+// 64-bit FIXED POINT (2^-30 units): integer adds are associative, so the per-tile sums are also bit-reproducible
+// whatever order the lanes arrive in. |sum| < 2^21 (velocity * weight in cells/s), resolution 9.3e-10.
+#define P2G_FIX_SCALE 1073741824.0      /* 2^30 */
+#define P2G_FIX_INV (1.0 / 1073741824.0)
+/// float -> fixed via the 1.5*2^52 magic constant: two f64 ops and one 64-bit subtract (no f32->i64 convert on CDNA).
+__device__ inline unsigned long long to_fixed(float x) {
+	const double magic = 6755399441055744.0;  // 1.5 * 2^52
+	double d = fma((double)x, P2G_FIX_SCALE, magic);
+	return (unsigned long long)(__double_as_longlong(d) - __double_as_longlong(magic));
+}
+
+struct ParticleRegs {
+	uint32_t key;
+	float t[3], v[3], c[9];
+};
+template <bool APIC> __device__ inline void load_particle(const ParticleSoA &p, uint32_t i, ParticleRegs &r) {
+	r.key = p.key[i];
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		r.t[k] = p.t[k][i];
+		r.v[k] = p.v[k][i];
+	}
+	if (APIC) {
+#pragma unroll
+		for (int k = 0; k < 9; ++k) r.c[k] = p.c[k][i];
+	}
+}
+
 template <bool APIC>
 __global__ void __launch_bounds__(256)
 k_p2g_binned(const int *ptiles, int n_ptiles, ParticleSoA p, const uint32_t *tile_start, float *stage, float hworld) {
-	__shared__ float acc[6 * LFA_HALO_CELLS];
+	__shared__ unsigned long long acc[6 * LFA_HALO_CELLS];  // 48 KB: [comp][wv | w][10x10x10]
 	for (int slot = blockIdx.x; slot < n_ptiles; slot += gridDim.x) {
 		const int tile = ptiles[slot];
-		for (int i = threadIdx.x; i < 6 * LFA_HALO_CELLS; i += 256) acc[i] = 0.0f;
+		for (int i = threadIdx.x; i < 6 * LFA_HALO_CELLS; i += 256) acc[i] = 0ull;
 		__syncthreads();
 		const uint32_t beg = tile_start[tile], end = tile_start[tile + 1];
-		for (uint32_t i = beg + threadIdx.x; i < end; i += 256) {
-			const uint32_t key = p.key[i];
-			const int l = (int)(key & 511);
-			float t[3] = {p.t[0][i], p.t[1][i], p.t[2][i]};
-			float v[3] = {p.v[0][i], p.v[1][i], p.v[2][i]};
-			float c[9];
-			if (APIC) {
-#pragma unroll
-				for (int k = 0; k < 9; ++k) c[k] = p.c[k][i];
-			}
-			scatter_particle<APIC>(l & 7, (l >> 3) & 7, l >> 6, t, v, c, hworld,
+		// software pipeline: the loads of the next particle are in flight while the current one is scattered
+		ParticleRegs cur, nxt;
+		uint32_t i = beg + threadIdx.x;
+		if (i < end) load_particle<APIC>(p, i, cur);
+		for (; i < end; i += 256) {
+			const uint32_t in = i + 256;
+			if (in < end) load_particle<APIC>(p, in, nxt);
+			const int l = (int)(cur.key & 511);
+			scatter_particle<APIC>(l & 7, (l >> 3) & 7, l >> 6, cur.t, cur.v, cur.c, hworld,
 			                       [&](int comp, int hx, int hy, int hz, float wv, float wgt) {
-				                       float *a = acc + comp * 2 * LFA_HALO_CELLS + hx + 10 * hy + 100 * hz;
-				                       atomicAdd(a, wv);
-				                       atomicAdd(a + LFA_HALO_CELLS, wgt);
+				                       unsigned long long *a = acc + comp * 2 * LFA_HALO_CELLS + hx + 10 * hy + 100 * hz;
+				                       atomicAdd(a, to_fixed(wv));
+				                       atomicAdd(a + LFA_HALO_CELLS, to_fixed(wgt));
 			                       });
+			cur = nxt;
 		}
 		__syncthreads();
 		float *out = stage + (size_t)slot * 6 * LFA_HALO_CELLS;
-		for (int i = threadIdx.x; i < 6 * LFA_HALO_CELLS; i += 256) out[i] = acc[i];
+		for (int k = threadIdx.x; k < 6 * LFA_HALO_CELLS; k += 256)
+			out[k] = (float)((double)(long long)acc[k] * P2G_FIX_INV);
 		__syncthreads();
 	}
 }
@@ -318,6 +349,7 @@ int lfa_p2g_run(lfa_sim *s, bool fuse_gravity, double dt) {
 			                   s->vo, s->wo, s->ctype, fp);
 		LFA_LAUNCH_CHECK(s);
 	}
+	LFA_HIP(s, hipMemcpyAsync(s->grid_flag, s->tile_flag, (size_t)s->g.nt * 4, hipMemcpyDeviceToDevice, s->stream));
 	s->grid_valid = true;
 	s->system_valid = false;
 	for (int k = 0; k < 3; ++k) s->bg[k] = fuse_gravity ? s->prm.gravity[k] * dt : 0.0;

@@ -2,10 +2,13 @@
 in place by oracle/Makefile). Run in the build container only: `python tests/golden/make_golden.py`.
 
 The reference has no tests or fixtures of its own, so these files -- inputs are regenerated from
-libfluid_amd/scenes.py with fixed seeds, outputs are what the reference computed, stage by stage -- are the golden
-vectors that pin oracle/oracle.c (tests/test_oracle.py) and, through it, the HIP path (tests/test_gpu_parity.py).
+libfluid_amd/scenes.py with fixed seeds, outputs are what the reference computed -- are the golden vectors that pin
+oracle/oracle.c (tests/test_oracle.py) and, through it, the HIP path (tests/test_gpu_parity.py):
+  <case>.npz         every stage of two hot-path passes (tests/util.py:staged_cpu_run)
+  fullstep_flip.npz  particles after three full simulation::time_step(dt) calls (tests/test_host_class.py)
 A fixture is data only: stage outputs as fp64/integer arrays.
 """
+import ctypes as C
 import os
 import sys
 
@@ -14,6 +17,27 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tests import util  # noqa: E402
 from oracle import loader as orc  # noqa: E402
+
+
+def make_fullstep():
+    from tests.test_host_class import fullstep_inputs
+    c, parts, solid = fullstep_inputs()
+    s = orc.CpuSim(c["size"], method=c["method"], blending=c["blend"], kind="ref")
+    s.set_solid_cells(solid)
+    s.set_particles(parts)
+    iters = []
+    for _ in range(c["steps"]):
+        res, it = C.c_double(0), C.c_uint64(0)
+        s.L.time_step(s.h, c["dt"], C.byref(res), C.byref(it))  # simulation::time_step, src/simulation.cpp:43-125
+        iters.append(it.value)
+    out = s.particles()
+    ids = np.rint(out["cx"][:, 0]).astype(np.int64)
+    assert np.array_equal(np.sort(ids), np.arange(len(parts)))
+    out = out[np.argsort(ids)]
+    np.savez_compressed(util.golden_path("fullstep_flip"), pos=out["pos"], vel=out["vel"], raw=out["raw"],
+                        iters=np.array(iters))
+    print("fullstep_flip", iters, os.path.getsize(util.golden_path("fullstep_flip")) // 1024, "KiB")
+
 
 if __name__ == "__main__":
     orc.build()
@@ -24,3 +48,4 @@ if __name__ == "__main__":
         np.savez_compressed(util.golden_path(name), **rec)
         print(name, {k: int(rec[k]) for k in rec if k.startswith("iters")},
               os.path.getsize(util.golden_path(name)) // 1024, "KiB")
+    make_fullstep()
