@@ -90,9 +90,12 @@ void *lfa_stream(lfa_sim *s);
  * (fp32 SoA, cell-relative positions) and computes the clamped cell key of src/simulation.cpp:251-261 in fp64. */
 int lfa_upload_particles(lfa_sim *s, const void *aos152, uint64_t n);
 /* Writes velocity, cx, cy, cz and raw_cell_index (x-fastest raw index, as the reference stores it) of every particle
- * back into the caller's array, in upload order (particle i of the upload is element i). position/old_position are
- * written too (reconstructed from the device's cell-relative representation) only if write_positions != 0. */
-int lfa_download_particles(lfa_sim *s, void *aos152, uint64_t n, int write_positions);
+ * back into the caller's array, in upload order (particle i of the upload is element i).
+ * flags: LFA_DL_POSITIONS also writes position/old_position (reconstructed from the device's cell-relative
+ * representation); LFA_DL_KEEP_RAW leaves raw_cell_index untouched (the reference's value is the one of the last
+ * hash, src/simulation.cpp:62, not the one of the final position). */
+enum { LFA_DL_POSITIONS = 1, LFA_DL_KEEP_RAW = 2 };
+int lfa_download_particles(lfa_sim *s, void *aos152, uint64_t n, int flags);
 uint64_t lfa_num_particles(const lfa_sim *s);
 /* Synthetic dam-break block [lo,hi) in cells, 8 jittered particles per cell, generated on the device; bit-identical
  * to libfluid_amd/scenes.py:seed_block. */

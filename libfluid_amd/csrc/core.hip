@@ -388,12 +388,12 @@ extern "C" int lfa_upload_particles(lfa_sim *s, const void *aos152, uint64_t n) 
 	return LFA_OK;
 }
 
-__global__ void k_export(double *aos, size_t n, ParticleSoA p, GridDims g, IngestParams ip, int write_pos) {
+__global__ void k_export(double *aos, size_t n, ParticleSoA p, GridDims g, IngestParams ip, int flags) {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	double *q = aos + (size_t)p.id[i] * 19;
 	uint32_t b = p.key[i];
-	if (write_pos) {
+	if (flags & LFA_DL_POSITIONS) {
 		int tile = (int)(b >> 9), l = (int)(b & 511), tx, ty, tz;
 		tile_coords(g, tile, tx, ty, tz);
 		int c[3] = {tx * 8 + (l & 7), ty * 8 + ((l >> 3) & 7), tz * 8 + (l >> 6)};
@@ -408,10 +408,10 @@ __global__ void k_export(double *aos, size_t n, ParticleSoA p, GridDims g, Inges
 	for (int k = 0; k < 3; ++k) q[3 + k] = (double)p.v[k][i];
 #pragma unroll
 	for (int k = 0; k < 9; ++k) q[6 + k] = (double)p.c[k][i];
-	((uint64_t *)q)[18] = raw_from_blocked(g, b);
+	if (!(flags & LFA_DL_KEEP_RAW)) ((uint64_t *)q)[18] = raw_from_blocked(g, b);
 }
 
-extern "C" int lfa_download_particles(lfa_sim *s, void *aos152, uint64_t n, int write_positions) {
+extern "C" int lfa_download_particles(lfa_sim *s, void *aos152, uint64_t n, int flags) {
 	if (!s || (!aos152 && n)) return LFA_E_INVALID;
 	if (n != s->np) return lfa_fail(s, LFA_E_INVALID, "download of %llu particles but %zu are resident",
 	                                (unsigned long long)n, s->np);
@@ -424,7 +424,7 @@ extern "C" int lfa_download_particles(lfa_sim *s, void *aos152, uint64_t n, int 
 	for (int k = 0; k < 3; ++k) ip.off[k] = s->prm.grid_offset[k];
 	ip.h = s->prm.cell_size;
 	hipLaunchKernelGGL(k_export, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, (double *)s->io_buf,
-	                   (size_t)n, s->pb[s->cur], s->g, ip, write_positions);
+	                   (size_t)n, s->pb[s->cur], s->g, ip, flags);
 	LFA_LAUNCH_CHECK(s);
 	LFA_HIP(s, hipMemcpyAsync(aos152, s->io_buf, n * 152, hipMemcpyDeviceToHost, s->stream));
 	LFA_HIP(s, hipStreamSynchronize(s->stream));

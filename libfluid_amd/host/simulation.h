@@ -549,7 +549,7 @@ namespace fluid_amd {
 		dev = dev && _ok(lfa_upload_particles(_dev, _particles.data(), _particles.size()));
 		dev = dev && _ok(lfa_hash_particles(_dev));
 		dev = dev && _ok(lfa_g2p(_dev));
-		dev = dev && _ok(lfa_download_particles(_dev, _particles.data(), _particles.size(), 0));
+		dev = dev && _ok(lfa_download_particles(_dev, _particles.data(), _particles.size(), LFA_DL_KEEP_RAW));
 		if (dev) _pull_grid();
 		if (post_grid_to_particle_transfer_callback) post_grid_to_particle_transfer_callback(dt);
 	}

@@ -60,5 +60,6 @@ def test_full_time_steps_match_reference(tmp_path):
     # three steps of a dam break: velocities O(30), displacements O(0.5) cells; fp32 device stages vs fp64 reference
     util.assert_close(out["pos"], g["pos"], 1e-6, "positions after 3 full steps", atol=2e-4)
     util.assert_close(out["vel"], g["vel"], 2e-4, "velocities after 3 full steps")
+    # raw_cell_index is the one of the step's last hash (before position correction), as in the reference
     assert np.mean(out["raw"] == g["raw"]) > 0.999  # a particle within 1e-4 of a cell face may land next door
     assert "iterations" in r.stdout
