@@ -56,12 +56,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default=None, help="C2 | C3 | C4 | C5 (default: C4 at 1 GPU, see DESIGN.md)")
     ap.add_argument("--dt", type=float, default=0.033, help="min(3*cfl, 0.033) of simulation::time_step() at rest")
-    ap.add_argument("--precond", default="tiled", choices=["tiled", "exact"])
+    ap.add_argument("--precond", default="multilevel", choices=["multilevel", "tiled", "exact"])
     ap.add_argument("--pcg-dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--p2g", default="binned", choices=["binned", "atomic"])
-    ap.add_argument("--max-iterations", type=int, default=1000,
-                    help="PCG iteration cap; the reference's 200 (pressure_solver.h:42) is sized for its global MIC(0), "
-                         "the tile-local MIC(0) needs ~3x the iterations (DESIGN.md)")
+    ap.add_argument("--max-iterations", type=int, default=200, help="PCG iteration cap (pressure_solver.h:42)")
     ap.add_argument("--cpu-sample", default="C2")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -90,7 +88,8 @@ def main():
     cfg_name = args.config or "C4"
     cfg = scenes.CONFIGS[cfg_name]
     sim = lfa.Sim(cfg["size"], method=cfg["method"], blending=cfg["blending"], device=local_rank,
-                  precond=lfa.PRECOND_MIC0_EXACT if args.precond == "exact" else lfa.PRECOND_MIC0_TILED,
+                  precond={"exact": lfa.PRECOND_MIC0_EXACT, "tiled": lfa.PRECOND_MIC0_TILED,
+                           "multilevel": lfa.PRECOND_MULTILEVEL}[args.precond],
                   pcg_dtype=lfa.PCG_F64 if args.pcg_dtype == "f64" else lfa.PCG_F32,
                   p2g_variant=lfa.P2G_GLOBAL_ATOMIC if args.p2g == "atomic" else lfa.P2G_LDS_BINNED,
                   max_iterations=args.max_iterations)
@@ -142,7 +141,8 @@ def main():
                         f"{['PIC', 'FLIP', 'APIC'][cfg['method']]} blend {cfg['blending']}, dt {args.dt}, "
                         f"hot path only (bin+P2G+gravity+PCG+apply+extrapolate+G2P)",
             "unknowns": n_unknowns, "particles_per_gpu": npart,
-            "precond": "MIC(0) per 8^3 tile" if args.precond == "tiled" else "MIC(0) exact (tile hyperplanes)",
+            "precond": {"tiled": "MIC(0) per 8^3 tile", "exact": "MIC(0) exact (tile hyperplanes)",
+                        "multilevel": "MIC(0) per 8^3 tile + tile-aggregate coarse correction"}[args.precond],
             "p2g": args.p2g, "pcg_tolerance": 1e-6, "pcg_max_iterations": args.max_iterations,
             "parallelism": "1 GPU" if world == 1 else f"{world} independent replicas (z-slab decomposition pending)",
         },

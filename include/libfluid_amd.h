@@ -47,7 +47,11 @@ enum { LFA_P2G_LDS_BINNED = 0, LFA_P2G_GLOBAL_ATOMIC = 1 };
 /* MIC(0) schedule. EXACT = hyperplane order over tiles: the same recurrence as pressure_solver.cpp:244-332, hence the
  * same iteration counts as the reference. TILED = MIC(0) restricted to 8x8x8 tiles (couplings across tile faces
  * dropped from the preconditioner only): one launch per application, more iterations, same converged pressure. */
-enum { LFA_PRECOND_MIC0_TILED = 0, LFA_PRECOND_MIC0_EXACT = 1 };
+enum { LFA_PRECOND_MIC0_TILED = 0, LFA_PRECOND_MIC0_EXACT = 1,
+       /* MULTILEVEL = TILED + additive coarse-space correction: one piecewise-constant unknown per 8^3 tile (Galerkin
+        * operator, block MIC(0) again on 8^3 blocks of tiles) and a dense solve of the 64^3-cell aggregates on top.
+        * Restores mesh-independent-ish convergence at one launch per level. */
+       LFA_PRECOND_MULTILEVEL = 2 };
 /* arithmetic type of the PCG vectors */
 enum { LFA_PCG_F32 = 0, LFA_PCG_F64 = 1 };
 
@@ -67,7 +71,7 @@ typedef struct lfa_params {
 	double tau, sigma, tolerance; /* 0.97, 0.25, 1e-6 */
 	uint64_t max_iterations;      /* 200 */
 	int32_t p2g_variant;          /* LFA_P2G_LDS_BINNED */
-	int32_t precond;              /* LFA_PRECOND_MIC0_TILED */
+	int32_t precond;              /* LFA_PRECOND_MULTILEVEL */
 	int32_t pcg_dtype;            /* LFA_PCG_F32 */
 	int32_t apic_unscaled_kernel; /* 1 = keep the reference quirk simulation.cpp:367-369 (only differs when cell_size != 1;
 	                                 the device path then returns LFA_E_UNSUPPORTED), 0 = divide by cell_size */

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(HERE, "libfluid_amd.so")
 
 PIC, FLIP_BLEND, APIC = 0, 1, 2
 P2G_LDS_BINNED, P2G_GLOBAL_ATOMIC = 0, 1
-PRECOND_MIC0_TILED, PRECOND_MIC0_EXACT = 0, 1
+PRECOND_MIC0_TILED, PRECOND_MIC0_EXACT, PRECOND_MULTILEVEL = 0, 1, 2
 PCG_F32, PCG_F64 = 0, 1
 OK, W_PCG_NOT_CONVERGED = 0, 1
 NUM_TIMERS = 10

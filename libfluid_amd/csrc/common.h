@@ -96,6 +96,16 @@ struct lfa_sim {
 	double *pcg_hist = nullptr;  // residual per iteration
 	int *level_tiles = nullptr;  // ptile slots sorted by tile level (exact MIC)
 	std::vector<int> level_offsets;  // host: start of every level in level_tiles
+	// coarse levels of the multilevel preconditioner (pcg.hip): level 1 = one unknown per particle tile, stored as a
+	// tile-major field over the grid of tiles; level 2 = one unknown per level-1 tile, dense inverse
+	GridDims g1{};
+	size_t ncp1 = 0;
+	float *c_diag = nullptr, *c_w[3] = {nullptr, nullptr, nullptr};
+	uint8_t *c_unk = nullptr;
+	void *c_pre = nullptr, *c_r = nullptr, *c_x = nullptr, *c_r2 = nullptr, *c_x2 = nullptr, *a2inv = nullptr;
+	int *slot_l1 = nullptr, *l1_tiles = nullptr, *l1_l2 = nullptr;
+	int n_l1tiles = 0, n2 = 0, a2cap = 0;
+	size_t coarse_elem = 0;
 	double a_scale = 0.0, sys_dt = -1.0;
 	uint64_t n_unknowns = 0;
 	bool system_valid = false, unknown_count_valid = false;

@@ -138,7 +138,7 @@ extern "C" void lfa_default_params(lfa_params *p) {
 	p->tolerance = 1e-6;
 	p->max_iterations = 200;
 	p->p2g_variant = LFA_P2G_LDS_BINNED;
-	p->precond = LFA_PRECOND_MIC0_TILED;
+	p->precond = LFA_PRECOND_MULTILEVEL;
 	p->pcg_dtype = LFA_PCG_F32;
 	p->apic_unscaled_kernel = 1;
 }
@@ -247,7 +247,9 @@ extern "C" void lfa_destroy(lfa_sim *s) {
 	void *ptrs[] = {s->grid_flag, s->rank, s->tile_count, s->tile_start, s->tile_flag, s->tile_scan, s->ptiles, s->dtiles,
 	                s->tile_pslot, s->scan_tmp, s->u, s->v, s->w, s->uo, s->vo, s->wo, s->ctype, s->solid,
 	                s->cell_count, s->stage, s->acc, s->abits, s->vp, s->vr, s->vz, s->vs, s->vpre, s->vq,
-	                s->partials, s->pcg_state, s->pcg_hist, s->level_tiles, s->io_buf, s->raw_scan};
+	                s->partials, s->pcg_state, s->pcg_hist, s->level_tiles, s->io_buf, s->raw_scan, s->c_diag, s->c_w[0],
+	                s->c_w[1], s->c_w[2], s->c_unk, s->c_pre, s->c_r, s->c_x, s->c_r2, s->c_x2, s->a2inv, s->slot_l1,
+	                s->l1_tiles, s->l1_l2};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	if (s->h_pinned) (void)hipHostFree(s->h_pinned);
@@ -270,7 +272,8 @@ extern "C" int lfa_set_params(lfa_sim *s, const lfa_params *p) {
 		return lfa_fail(s, LFA_E_UNSUPPORTED,
 		                "APIC with the reference's unscaled kernel (simulation.cpp:367-369) is only implemented for "
 		                "cell_size == 1; set apic_unscaled_kernel = 0");
-	if (p->pcg_dtype != s->prm.pcg_dtype) s->system_valid = false;
+	if (p->pcg_dtype != s->prm.pcg_dtype || p->precond != s->prm.precond) s->system_valid = false;
+	if (p->precond < 0 || p->precond > 2) return lfa_fail(s, LFA_E_INVALID, "bad precond");
 	s->prm = *p;
 	return LFA_OK;
 }

@@ -155,14 +155,14 @@ k_spmv(TileCtx tc, const uint8_t *abits, const real *s, real *z, real scale, dou
 /// p += alpha s ; r += (-alpha) z (_muladd, src/pressure_solver.cpp:364-370) ; signed max of r over the unknowns (:54).
 template <typename real>
 __global__ void __launch_bounds__(256)
-k_axpy_max(TileCtx tc, const uint8_t *abits, Vecs<real> v, const double *part_sigma, const double *part_zs, int n_part,
-           double *part_rmax, const int *state) {
+k_axpy_max(TileCtx tc, const uint8_t *abits, Vecs<real> v, const double *part_sigma, int n_sigma, const double *part_zs,
+           int n_part, double *part_rmax, const int *state) {
 	__shared__ double lds[256];
 	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	double m = -INFINITY;
 	bool nan = false;
 	if (state[0] < 0) {
-		const double sigma = reduce_partials_sum(part_sigma, n_part, lds);
+		const double sigma = reduce_partials_sum(part_sigma, n_sigma, lds);
 		const double zs = reduce_partials_sum(part_zs, n_part, lds);
 		const real alpha = (real)(sigma / zs);
 		for (int slot = blockIdx.x * PCG_WAVES + wid; slot < tc.n_ptiles; slot += gridDim.x * PCG_WAVES) {
@@ -268,7 +268,7 @@ enum { SWEEP_BOTH = 0, SWEEP_FWD = 1, SWEEP_BWD = 2 };
 template <typename real, int MODE>
 __global__ void __launch_bounds__(256)
 k_mic_apply(TileCtx tc, const int *slots, int n_slots, const uint8_t *abits, Vecs<real> v, real scale,
-            double *part_sigma, const int *state) {
+            double *part_sigma, const int *state, real *coarse_r, const int *slot_l1) {
 	constexpr bool EXACT = MODE != SWEEP_BOTH;
 	__shared__ real lq[PCG_WAVES][LFA_TILE_CELLS];    // r -> q -> z
 	__shared__ real lpq[PCG_WAVES][LFA_TILE_CELLS];   // pre * q
@@ -302,6 +302,14 @@ k_mic_apply(TileCtx tc, const int *slots, int n_slots, const uint8_t *abits, Vec
 				}
 			}
 			WAVE_SYNC();
+			if (MODE == SWEEP_BOTH && coarse_r) {
+				// restriction to the coarse space (one piecewise-constant unknown per tile): r1 = sum of r over the tile
+				double sr = 0.0;
+#pragma unroll
+				for (int zz = 0; zz < 8; ++zz) sr += (double)rr[zz];
+				sr = wave_sum(sr);
+				if (lane == 0) coarse_r[slot_l1[slot]] = (real)sr;
+			}
 			if (MODE != SWEEP_BWD) {
 				// L q = r
 				for (int level = 0; level < 22; ++level) {
@@ -412,11 +420,12 @@ k_check_converged(const double *part_rmax, int n_part, double tol, int iter, int
 	}
 }
 
-/// s = z + beta s (src/pressure_solver.cpp:64-66); first = 1: s = z (:40).
+/// s = z + beta s (src/pressure_solver.cpp:64-66); first = 1: s = z (:40). With the multilevel preconditioner the
+/// coarse part of z (piecewise constant per tile, coarse_x) is added here instead of in a pass of its own.
 template <typename real>
 __global__ void __launch_bounds__(256)
 k_update_s(TileCtx tc, Vecs<real> v, const double *part_sig_new, const double *part_sig_old, int n_part, int first,
-           const int *state) {
+           const int *state, const uint8_t *abits, const real *coarse_x, const int *slot_l1) {
 	__shared__ double lds[256];
 	if (state[0] >= 0) return;
 	real beta = (real)0;
@@ -428,11 +437,218 @@ k_update_s(TileCtx tc, Vecs<real> v, const double *part_sig_new, const double *p
 	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	for (int slot = blockIdx.x * PCG_WAVES + wid; slot < tc.n_ptiles; slot += gridDim.x * PCG_WAVES) {
 		const size_t base = (size_t)tc.ptiles[slot] * LFA_TILE_CELLS;
+		const real xc = coarse_x ? coarse_x[slot_l1[slot]] : (real)0;
 #pragma unroll
 		for (int zz = 0; zz < 8; ++zz) {
 			const size_t b = base + zz * 64 + lane;
-			v.s[b] = first ? v.z[b] : v.z[b] + beta * v.s[b];
+			real z = v.z[b];
+			if (coarse_x && (abits[b] & AB_UNKNOWN)) z += xc;
+			v.s[b] = first ? z : z + beta * v.s[b];
 		}
+	}
+}
+
+// ================================================================================================= coarse levels
+// Level 1: one unknown per particle tile, Galerkin operator A1 = P^T A P for piecewise-constant P:
+//   A1[I,I] = scale * (sum_i ns_i - 2 * #coupled pairs inside I),  A1[I,I+d] = -scale * #couplings across the +d face.
+// The level-1 unknowns live on the grid of tiles, stored tile-major again (8^3 blocks of tiles), so the same
+// wave-per-tile hyperplane sweep applies with weights. Level 2: one unknown per level-1 block, A2 = P1^T A1 P1 inverted
+// densely on the host (n2 = number of 64^3-cell aggregates that hold fluid: 32 at C4).
+
+/// Level-1 coefficients from the fine A bits.
+__global__ void __launch_bounds__(256)
+k_coarse_coeffs(TileCtx tc, const uint8_t *abits, const int *slot_l1, float *c_diag, float *c_wx, float *c_wy, float *c_wz,
+                uint8_t *c_unk) {
+	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
+	for (int slot = blockIdx.x * PCG_WAVES + wid; slot < tc.n_ptiles; slot += gridDim.x * PCG_WAVES) {
+		const size_t base = (size_t)tc.ptiles[slot] * LFA_TILE_CELLS;
+		int diag = 0, wx = 0, wy = 0, wz = 0, unk = 0;
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) {
+			const int a = abits[base + zz * 64 + lane];
+			if (!(a & AB_UNKNOWN)) continue;
+			unk = 1;
+			const int bx = (a >> 3) & 1, by = (a >> 4) & 1, bz = (a >> 5) & 1;
+			diag += (a & 7) - 2 * ((lx < 7 ? bx : 0) + (ly < 7 ? by : 0) + (zz < 7 ? bz : 0));
+			wx += lx == 7 ? bx : 0;
+			wy += ly == 7 ? by : 0;
+			wz += zz == 7 ? bz : 0;
+		}
+		diag = wave_sum(diag); wx = wave_sum(wx); wy = wave_sum(wy); wz = wave_sum(wz);
+		unk = __any(unk) ? 1 : 0;
+		if (lane == 0) {
+			const int i1 = slot_l1[slot];
+			c_diag[i1] = (float)diag; c_wx[i1] = (float)wx; c_wy[i1] = (float)wy; c_wz[i1] = (float)wz;
+			c_unk[i1] = (uint8_t)unk;
+		}
+	}
+}
+
+template <typename real> struct CoarseFields {
+	const float *diag, *w[3];
+	const uint8_t *unk;
+	real *pre, *r, *x;
+};
+
+/// MIC(0) of a level-1 block (weighted version of k_mic_factor, block-local).
+template <typename real>
+__global__ void __launch_bounds__(256)
+k_coarse_factor(const int *l1_tiles, int n_l1, CoarseFields<real> c, real scale, real tau, real sigma) {
+	__shared__ real lpre[PCG_WAVES][LFA_TILE_CELLS];
+	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
+	real *P = lpre[wid];
+	for (int k = blockIdx.x * PCG_WAVES + wid; k < n_l1; k += gridDim.x * PCG_WAVES) {
+		const size_t base = (size_t)l1_tiles[k] * LFA_TILE_CELLS;
+		WAVE_SYNC();
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) P[zz * 64 + lane] = (real)0;
+		WAVE_SYNC();
+		for (int level = 0; level < 22; ++level) {
+			const int zz = level - lx - ly;
+			if (zz >= 0 && zz < 8) {
+				const int idx = zz * 64 + lane;
+				if (c.unk[base + idx]) {
+					real neg = (real)0;
+#pragma unroll
+					for (int d = 0; d < 3; ++d) {
+						const int cd = d == 0 ? lx : (d == 1 ? ly : zz);
+						const int step = d == 0 ? 1 : (d == 1 ? 8 : 64);
+						if (cd > 0 && c.unk[base + idx - step]) {
+							const size_t j = base + idx - step;
+							const real pj = P[idx - step];
+							const real ad = scale * (real)c.w[d][j], ao1 = scale * (real)c.w[(d + 1) % 3][j],
+							           ao2 = scale * (real)c.w[(d + 2) % 3][j];
+							neg += (ad * pj) * (ad * pj) + tau * ad * (ao1 + ao2) * pj * pj;
+						}
+					}
+					const real aii = scale * (real)c.diag[base + idx];
+					real e = aii - neg;
+					if (e < sigma * aii) e = aii;
+					P[idx] = (real)1 / sqrt(e);
+				}
+			}
+			WAVE_SYNC();
+		}
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) c.pre[base + zz * 64 + lane] = P[zz * 64 + lane];
+	}
+}
+
+/// x1 = M1^-1 r1 per level-1 block (weighted forward/backward substitution) and r2 = P1^T r1.
+template <typename real>
+__global__ void __launch_bounds__(256)
+k_coarse_apply(const int *l1_tiles, int n_l1, CoarseFields<real> c, real scale, real *r2) {
+	__shared__ real lq[PCG_WAVES][LFA_TILE_CELLS];
+	__shared__ real lpq[PCG_WAVES][LFA_TILE_CELLS];
+	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
+	real *Q = lq[wid], *PQ = lpq[wid];
+	for (int k = blockIdx.x * PCG_WAVES + wid; k < n_l1; k += gridDim.x * PCG_WAVES) {
+		const size_t base = (size_t)l1_tiles[k] * LFA_TILE_CELLS;
+		double sr = 0.0;
+		WAVE_SYNC();
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) {
+			const int idx = zz * 64 + lane;
+			const real r = c.unk[base + idx] ? c.r[base + idx] : (real)0;
+			Q[idx] = r;
+			PQ[idx] = (real)0;
+			sr += (double)r;
+		}
+		sr = wave_sum(sr);
+		if (lane == 0) r2[k] = (real)sr;
+		WAVE_SYNC();
+		for (int level = 0; level < 22; ++level) {
+			const int zz = level - lx - ly;
+			if (zz >= 0 && zz < 8) {
+				const int idx = zz * 64 + lane;
+				real q = (real)0;
+				if (c.unk[base + idx]) {
+					real t = (real)0;
+#pragma unroll
+					for (int d = 0; d < 3; ++d) {
+						const int cd = d == 0 ? lx : (d == 1 ? ly : zz);
+						const int step = d == 0 ? 1 : (d == 1 ? 8 : 64);
+						if (cd > 0) t += (real)c.w[d][base + idx - step] * PQ[idx - step];
+					}
+					const real p = c.pre[base + idx];
+					q = (Q[idx] + scale * t) * p;
+					PQ[idx] = p * q;
+				}
+				Q[idx] = q;
+			}
+			WAVE_SYNC();
+		}
+		for (int level = 21; level >= 0; --level) {
+			const int zz = level - lx - ly;
+			if (zz >= 0 && zz < 8) {
+				const int idx = zz * 64 + lane;
+				real zv = (real)0;
+				if (c.unk[base + idx]) {
+					real t = (real)0;
+#pragma unroll
+					for (int d = 0; d < 3; ++d) {
+						const int cd = d == 0 ? lx : (d == 1 ? ly : zz);
+						const int step = d == 0 ? 1 : (d == 1 ? 8 : 64);
+						if (cd < 7) t += (real)c.w[d][base + idx] * Q[idx + step];
+					}
+					const real p = c.pre[base + idx];
+					zv = (Q[idx] + scale * p * t) * p;
+				}
+				Q[idx] = zv;
+			}
+			WAVE_SYNC();
+		}
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) c.x[base + zz * 64 + lane] = Q[zz * 64 + lane];
+	}
+}
+
+/// Top level: x2 = A2^-1 r2 (dense), x1 += P1 x2, and the coarse part of the preconditioned dot product
+/// sigma_coarse = x1 . r1, written as one more partial. One workgroup.
+template <typename real>
+__global__ void __launch_bounds__(256)
+k_coarse_top(const int *l1_tiles, int n_l1, CoarseFields<real> c, const real *a2inv, const real *r2, real *x2,
+             double *part_sigma_extra, const int *state) {
+	__shared__ double red[4];
+	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	if (state[0] >= 0) return;
+	for (int row = threadIdx.x; row < n_l1; row += 256) {
+		double acc = 0.0;
+		for (int k = 0; k < n_l1; ++k) acc += (double)a2inv[(size_t)row * n_l1 + k] * (double)r2[k];
+		x2[row] = (real)acc;
+	}
+	__syncthreads();
+	double dotp = 0.0;
+	for (int k = wid; k < n_l1; k += 4) {
+		const size_t base = (size_t)l1_tiles[k] * LFA_TILE_CELLS;
+		const real add = x2[k];
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) {
+			const size_t i = base + zz * 64 + lane;
+			if (c.unk[i]) {
+				const real xt = c.x[i] + add;
+				c.x[i] = xt;
+				dotp += (double)xt * (double)c.r[i];
+			}
+		}
+	}
+	dotp = wave_sum(dotp);
+	if (lane == 0) red[wid] = dotp;
+	__syncthreads();
+	if (threadIdx.x == 0) *part_sigma_extra = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+/// z += P x_coarse on the unknowns (only for lfa_apply_preconditioner, which hands z to the caller).
+template <typename real>
+__global__ void __launch_bounds__(256)
+k_add_coarse(TileCtx tc, const uint8_t *abits, real *z, const real *coarse_x, const int *slot_l1) {
+	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	for (int slot = blockIdx.x * PCG_WAVES + wid; slot < tc.n_ptiles; slot += gridDim.x * PCG_WAVES) {
+		const size_t base = (size_t)tc.ptiles[slot] * LFA_TILE_CELLS;
+		const real xc = coarse_x[slot_l1[slot]];
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz)
+			if (abits[base + zz * 64 + lane] & AB_UNKNOWN) z[base + zz * 64 + lane] += xc;
 	}
 }
 
@@ -512,6 +728,176 @@ static int build_levels(lfa_sim *s) {
 	return LFA_OK;
 }
 
+
+// ---- multilevel preconditioner: host-side set-up -----------------------------------------------------------
+static bool is_ml(const lfa_sim *s) { return s->prm.precond == LFA_PRECOND_MULTILEVEL; }
+/// number of partial sums the consumers of sigma add up: one per workgroup (+1 for the coarse part of z.r)
+static int sigma_parts(const lfa_sim *s) { return pcg_grid(s->n_ptiles) + (is_ml(s) ? 1 : 0); }
+
+template <typename real> static CoarseFields<real> make_coarse(lfa_sim *s) {
+	return CoarseFields<real>{s->c_diag, {s->c_w[0], s->c_w[1], s->c_w[2]}, s->c_unk, (real *)s->c_pre, (real *)s->c_r,
+	                          (real *)s->c_x};
+}
+
+/// Dense SPD inverse by Cholesky (n2 is the number of 64^3-cell aggregates that hold fluid: tens, at most 512).
+static bool spd_inverse(std::vector<double> &a, int n) {
+	std::vector<double> l((size_t)n * n, 0.0);
+	for (int j = 0; j < n; ++j) {
+		double d = a[(size_t)j * n + j];
+		for (int k = 0; k < j; ++k) d -= l[(size_t)j * n + k] * l[(size_t)j * n + k];
+		if (!(d > 0.0)) return false;
+		d = sqrt(d);
+		l[(size_t)j * n + j] = d;
+		for (int i = j + 1; i < n; ++i) {
+			double v = a[(size_t)i * n + j];
+			for (int k = 0; k < j; ++k) v -= l[(size_t)i * n + k] * l[(size_t)j * n + k];
+			l[(size_t)i * n + j] = v / d;
+		}
+	}
+	// inverse of L (lower), then A^-1 = L^-T L^-1
+	std::vector<double> li((size_t)n * n, 0.0);
+	for (int c = 0; c < n; ++c) {
+		li[(size_t)c * n + c] = 1.0 / l[(size_t)c * n + c];
+		for (int i = c + 1; i < n; ++i) {
+			double v = 0.0;
+			for (int k = c; k < i; ++k) v -= l[(size_t)i * n + k] * li[(size_t)k * n + c];
+			li[(size_t)i * n + c] = v / l[(size_t)i * n + i];
+		}
+	}
+	for (int i = 0; i < n; ++i)
+		for (int j = 0; j <= i; ++j) {
+			double v = 0.0;
+			for (int k = i; k < n; ++k) v += li[(size_t)k * n + i] * li[(size_t)k * n + j];
+			a[(size_t)i * n + j] = a[(size_t)j * n + i] = v;
+		}
+	return true;
+}
+
+template <typename real> static int coarse_setup(lfa_sim *s) {
+	const GridDims &g = s->g;
+	GridDims &g1 = s->g1;
+	g1.nx = g.ntx; g1.ny = g.nty; g1.nz = g.ntz;
+	g1.ntx = (g1.nx + 7) / 8; g1.nty = (g1.ny + 7) / 8; g1.ntz = (g1.nz + 7) / 8;
+	g1.nt = g1.ntx * g1.nty * g1.ntz;
+	const size_t ncp1 = (size_t)g1.nt * LFA_TILE_CELLS;
+	if (ncp1 != s->ncp1 || s->coarse_elem != sizeof(real)) {
+		LFA_HIP(s, hipStreamSynchronize(s->stream));
+		void **ptrs[] = {(void **)&s->c_diag, (void **)&s->c_w[0], (void **)&s->c_w[1], (void **)&s->c_w[2],
+		                 (void **)&s->c_unk, &s->c_pre, &s->c_r, &s->c_x, &s->c_r2, &s->c_x2, (void **)&s->slot_l1,
+		                 (void **)&s->l1_tiles, (void **)&s->l1_l2};
+		for (void **p : ptrs) {
+			if (*p) LFA_HIP(s, hipFree(*p));
+			*p = nullptr;
+		}
+		LFA_HIP(s, hipMalloc(&s->c_diag, ncp1 * 4));
+		for (int d = 0; d < 3; ++d) LFA_HIP(s, hipMalloc(&s->c_w[d], ncp1 * 4));
+		LFA_HIP(s, hipMalloc(&s->c_unk, ncp1));
+		LFA_HIP(s, hipMalloc(&s->c_pre, ncp1 * sizeof(real)));
+		LFA_HIP(s, hipMalloc(&s->c_r, ncp1 * sizeof(real)));
+		LFA_HIP(s, hipMalloc(&s->c_x, ncp1 * sizeof(real)));
+		LFA_HIP(s, hipMalloc(&s->c_r2, (size_t)g1.nt * sizeof(real)));
+		LFA_HIP(s, hipMalloc(&s->c_x2, (size_t)g1.nt * sizeof(real)));
+		LFA_HIP(s, hipMalloc(&s->slot_l1, (size_t)g.nt * 4));
+		LFA_HIP(s, hipMalloc(&s->l1_tiles, (size_t)g1.nt * 4));
+		LFA_HIP(s, hipMalloc(&s->l1_l2, (size_t)g1.nt * 4));
+		s->ncp1 = ncp1;
+		s->coarse_elem = sizeof(real);
+	}
+	// level-1 index of every particle tile, list of level-1 blocks that hold unknowns
+	std::vector<int> tiles(s->n_ptiles), sl1(s->n_ptiles), l1flag(g1.nt, 0), l1list, l1l2(g1.nt, -1);
+	LFA_HIP(s, hipMemcpyAsync(tiles.data(), s->ptiles, (size_t)s->n_ptiles * 4, hipMemcpyDeviceToHost, s->stream));
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	for (int i = 0; i < s->n_ptiles; ++i) {
+		int tx, ty, tz;
+		tile_coords(g, tiles[i], tx, ty, tz);
+		sl1[i] = (int)blocked_index(g1, tx, ty, tz);
+		l1flag[sl1[i] >> 9] = 1;
+	}
+	for (int t = 0; t < g1.nt; ++t)
+		if (l1flag[t]) { l1l2[t] = (int)l1list.size(); l1list.push_back(t); }
+	s->n_l1tiles = s->n2 = (int)l1list.size();
+	LFA_HIP(s, hipMemcpyAsync(s->slot_l1, sl1.data(), (size_t)s->n_ptiles * 4, hipMemcpyHostToDevice, s->stream));
+	LFA_HIP(s, hipMemcpyAsync(s->l1_tiles, l1list.data(), l1list.size() * 4, hipMemcpyHostToDevice, s->stream));
+	LFA_HIP(s, hipMemcpyAsync(s->l1_l2, l1l2.data(), (size_t)g1.nt * 4, hipMemcpyHostToDevice, s->stream));
+	LFA_HIP(s, hipMemsetAsync(s->c_diag, 0, ncp1 * 4, s->stream));
+	for (int d = 0; d < 3; ++d) LFA_HIP(s, hipMemsetAsync(s->c_w[d], 0, ncp1 * 4, s->stream));
+	LFA_HIP(s, hipMemsetAsync(s->c_unk, 0, ncp1, s->stream));
+	LFA_HIP(s, hipMemsetAsync(s->c_r, 0, ncp1 * sizeof(real), s->stream));
+	LFA_HIP(s, hipMemsetAsync(s->c_x, 0, ncp1 * sizeof(real), s->stream));
+	LFA_HIP(s, hipMemsetAsync(s->c_pre, 0, ncp1 * sizeof(real), s->stream));
+	TileCtx tc = make_ctx(s);
+	hipLaunchKernelGGL(k_coarse_coeffs, dim3(pcg_grid(s->n_ptiles)), dim3(256), 0, s->stream, tc, s->abits, s->slot_l1,
+	                   s->c_diag, s->c_w[0], s->c_w[1], s->c_w[2], s->c_unk);
+	LFA_LAUNCH_CHECK(s);
+	CoarseFields<real> cf = make_coarse<real>(s);
+	const int g1grid = (s->n_l1tiles + PCG_WAVES - 1) / PCG_WAVES;
+	hipLaunchKernelGGL(k_coarse_factor<real>, dim3(g1grid), dim3(256), 0, s->stream, s->l1_tiles, s->n_l1tiles, cf,
+	                   (real)s->a_scale, (real)s->prm.tau, (real)s->prm.sigma);
+	LFA_LAUNCH_CHECK(s);
+	// level 2: A2 = P1^T A1 P1, assembled and inverted on the host
+	std::vector<float> hd(ncp1), hw[3] = {std::vector<float>(ncp1), std::vector<float>(ncp1), std::vector<float>(ncp1)};
+	std::vector<uint8_t> hu(ncp1);
+	LFA_HIP(s, hipMemcpyAsync(hd.data(), s->c_diag, ncp1 * 4, hipMemcpyDeviceToHost, s->stream));
+	for (int d = 0; d < 3; ++d) LFA_HIP(s, hipMemcpyAsync(hw[d].data(), s->c_w[d], ncp1 * 4, hipMemcpyDeviceToHost, s->stream));
+	LFA_HIP(s, hipMemcpyAsync(hu.data(), s->c_unk, ncp1, hipMemcpyDeviceToHost, s->stream));
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	const int n2 = s->n2;
+	std::vector<double> a2((size_t)n2 * n2, 0.0);
+	for (int k = 0; k < n2; ++k) {
+		const int t1 = l1list[k];
+		int bx, by, bz;
+		tile_coords(g1, t1, bx, by, bz);
+		for (int l = 0; l < LFA_TILE_CELLS; ++l) {
+			const size_t i = (size_t)t1 * LFA_TILE_CELLS + l;
+			if (!hu[i]) continue;
+			a2[(size_t)k * n2 + k] += s->a_scale * hd[i];
+			const int x = bx * 8 + (l & 7), y = by * 8 + ((l >> 3) & 7), z = bz * 8 + (l >> 6);
+			for (int d = 0; d < 3; ++d) {
+				if (hw[d][i] == 0.0f) continue;
+				const int xx = x + (d == 0), yy = y + (d == 1), zz = z + (d == 2);
+				if (!in_grid(g1, xx, yy, zz)) continue;
+				const int k2 = l1l2[blocked_index(g1, xx, yy, zz) >> 9];
+				if (k2 < 0) continue;
+				a2[(size_t)k * n2 + k2] -= s->a_scale * hw[d][i];
+				a2[(size_t)k2 * n2 + k] -= s->a_scale * hw[d][i];
+			}
+		}
+	}
+	std::vector<double> a2copy = a2;
+	if (!spd_inverse(a2, n2)) {
+		// singular top level (fluid with no free surface anywhere: the reference's matrix is singular too): regularise
+		a2 = a2copy;
+		double tr = 0.0;
+		for (int k = 0; k < n2; ++k) tr += a2[(size_t)k * n2 + k];
+		for (int k = 0; k < n2; ++k) a2[(size_t)k * n2 + k] += 1e-8 * tr / n2 + 1e-30;
+		if (!spd_inverse(a2, n2)) return lfa_fail(s, LFA_E_NAN, "coarse operator is not positive definite");
+	}
+	if (n2 > s->a2cap) {
+		if (s->a2inv) LFA_HIP(s, hipFree(s->a2inv));
+		s->a2inv = nullptr;
+		LFA_HIP(s, hipMalloc(&s->a2inv, (size_t)n2 * n2 * sizeof(double)));
+		s->a2cap = n2;
+	}
+	std::vector<real> inv((size_t)n2 * n2);
+	for (size_t i = 0; i < inv.size(); ++i) inv[i] = (real)a2[i];
+	LFA_HIP(s, hipMemcpyAsync(s->a2inv, inv.data(), inv.size() * sizeof(real), hipMemcpyHostToDevice, s->stream));
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	return LFA_OK;
+}
+
+/// Coarse half of z = M^-1 r: level-1 block MIC(0) + dense top level; writes the coarse share of z.r as partial G.
+template <typename real> static int coarse_apply(lfa_sim *s, double *part_sigma) {
+	CoarseFields<real> cf = make_coarse<real>(s);
+	const int g1grid = (s->n_l1tiles + PCG_WAVES - 1) / PCG_WAVES;
+	hipLaunchKernelGGL(k_coarse_apply<real>, dim3(g1grid), dim3(256), 0, s->stream, s->l1_tiles, s->n_l1tiles, cf,
+	                   (real)s->a_scale, (real *)s->c_r2);
+	hipLaunchKernelGGL(k_coarse_top<real>, dim3(1), dim3(256), 0, s->stream, s->l1_tiles, s->n_l1tiles, cf,
+	                   (const real *)s->a2inv, (const real *)s->c_r2, (real *)s->c_x2, part_sigma + pcg_grid(s->n_ptiles),
+	                   s->pcg_state);
+	LFA_LAUNCH_CHECK(s);
+	return LFA_OK;
+}
+
 template <typename real> static int mic_factor(lfa_sim *s) {
 	TileCtx tc = make_ctx(s);
 	const real scale = (real)s->a_scale, tau = (real)s->prm.tau, sigma = (real)s->prm.sigma;
@@ -528,6 +914,7 @@ template <typename real> static int mic_factor(lfa_sim *s) {
 		hipLaunchKernelGGL((k_mic_factor<real, false>), dim3(pcg_grid(s->n_ptiles)), dim3(256), 0, s->stream, tc,
 		                   (const int *)nullptr, s->n_ptiles, s->abits, (real *)s->vpre, scale, tau, sigma);
 		LFA_LAUNCH_CHECK(s);
+		if (is_ml(s)) LFA_TRY(coarse_setup<real>(s));
 	}
 	return LFA_OK;
 }
@@ -544,22 +931,26 @@ template <typename real> static int mic_apply(lfa_sim *s, double *part_sigma) {
 			const int b = s->level_offsets[l], n = s->level_offsets[l + 1] - b;
 			if (!n) continue;
 			hipLaunchKernelGGL((k_mic_apply<real, SWEEP_FWD>), dim3((n + PCG_WAVES - 1) / PCG_WAVES), dim3(256), 0, s->stream,
-			                   tc, s->level_tiles + b, n, s->abits, v, scale, part_sigma, s->pcg_state);
+			                   tc, s->level_tiles + b, n, s->abits, v, scale, part_sigma, s->pcg_state, (real *)nullptr,
+			                   (const int *)nullptr);
 			LFA_LAUNCH_CHECK(s);
 		}
 		for (int l = nl - 1; l >= 0; --l) {
 			const int b = s->level_offsets[l], n = s->level_offsets[l + 1] - b;
 			if (!n) continue;
 			hipLaunchKernelGGL((k_mic_apply<real, SWEEP_BWD>), dim3((n + PCG_WAVES - 1) / PCG_WAVES), dim3(256), 0, s->stream,
-			                   tc, s->level_tiles + b, n, s->abits, v, scale, part_sigma, s->pcg_state);
+			                   tc, s->level_tiles + b, n, s->abits, v, scale, part_sigma, s->pcg_state, (real *)nullptr,
+			                   (const int *)nullptr);
 			LFA_LAUNCH_CHECK(s);
 		}
 		hipLaunchKernelGGL(k_dot_zr<real>, dim3(G), dim3(256), 0, s->stream, tc, v, part_sigma, s->pcg_state);
 		LFA_LAUNCH_CHECK(s);
 	} else {
 		hipLaunchKernelGGL((k_mic_apply<real, SWEEP_BOTH>), dim3(G), dim3(256), 0, s->stream, tc, (const int *)nullptr,
-		                   s->n_ptiles, s->abits, v, scale, part_sigma, s->pcg_state);
+		                   s->n_ptiles, s->abits, v, scale, part_sigma, s->pcg_state, is_ml(s) ? (real *)s->c_r : (real *)nullptr,
+		                   (const int *)s->slot_l1);
 		LFA_LAUNCH_CHECK(s);
+		if (is_ml(s)) LFA_TRY(coarse_apply<real>(s, part_sigma));
 	}
 	return LFA_OK;
 }
@@ -604,8 +995,10 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 	LFA_HIP(s, hipMemcpyAsync(s->pcg_state, init_state, 8, hipMemcpyHostToDevice, s->stream));
 	// z = M^-1 r ; s = z ; sigma = z.r
 	LFA_TRY(mic_apply<real>(s, P + PART_SIG0));
-	hipLaunchKernelGGL(k_update_s<real>, dim3(G), dim3(256), 0, s->stream, tc, v, P + PART_SIG0, P + PART_SIG0, G, 1,
-	                   s->pcg_state);
+	const int NS = sigma_parts(s);
+	const real *cx = is_ml(s) ? (const real *)s->c_x : (const real *)nullptr;
+	hipLaunchKernelGGL(k_update_s<real>, dim3(G), dim3(256), 0, s->stream, tc, v, P + PART_SIG0, P + PART_SIG0, NS, 1,
+	                   s->pcg_state, s->abits, cx, (const int *)s->slot_l1);
 	LFA_LAUNCH_CHECK(s);
 	const int maxit = (int)s->prm.max_iterations;
 	const int chunk = 8;
@@ -617,14 +1010,14 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 			double *sig_old = P + ((i & 1) ? PART_SIG1 : PART_SIG0), *sig_new = P + ((i & 1) ? PART_SIG0 : PART_SIG1);
 			hipLaunchKernelGGL(k_spmv<real>, dim3(G), dim3(256), 0, s->stream, tc, s->abits, (const real *)v.s, v.z, scale,
 			                   P + PART_ZS, s->pcg_state);
-			hipLaunchKernelGGL(k_axpy_max<real>, dim3(G), dim3(256), 0, s->stream, tc, s->abits, v, sig_old, P + PART_ZS, G,
+			hipLaunchKernelGGL(k_axpy_max<real>, dim3(G), dim3(256), 0, s->stream, tc, s->abits, v, sig_old, NS, P + PART_ZS, G,
 			                   P + PART_RMAX, s->pcg_state);
 			hipLaunchKernelGGL(k_check_converged, dim3(1), dim3(256), 0, s->stream, P + PART_RMAX, G, s->prm.tolerance, i,
 			                   s->pcg_state, s->pcg_hist);
 			LFA_LAUNCH_CHECK(s);
 			LFA_TRY(mic_apply<real>(s, sig_new));
-			hipLaunchKernelGGL(k_update_s<real>, dim3(G), dim3(256), 0, s->stream, tc, v, sig_new, sig_old, G, 0,
-			                   s->pcg_state);
+			hipLaunchKernelGGL(k_update_s<real>, dim3(G), dim3(256), 0, s->stream, tc, v, sig_new, sig_old, NS, 0,
+			                   s->pcg_state, s->abits, cx, (const int *)s->slot_l1);
 			LFA_LAUNCH_CHECK(s);
 		}
 		LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 8, hipMemcpyDeviceToHost, s->stream));
@@ -714,7 +1107,14 @@ template <typename real> static int apply_precon_t(lfa_sim *s, const double *r, 
 	LFA_TRY(scatter<real>(s, (real *)s->vr, r, n));
 	int init_state[2] = {-1, 0};
 	LFA_HIP(s, hipMemcpyAsync(s->pcg_state, init_state, 8, hipMemcpyHostToDevice, s->stream));
-	if (s->n_ptiles) LFA_TRY(mic_apply<real>(s, s->partials + PART_SIG0));
+	if (s->n_ptiles) {
+		LFA_TRY(mic_apply<real>(s, s->partials + PART_SIG0));
+		if (is_ml(s)) {
+			hipLaunchKernelGGL(k_add_coarse<real>, dim3(pcg_grid(s->n_ptiles)), dim3(256), 0, s->stream, make_ctx(s), s->abits,
+			                   (real *)s->vz, (const real *)s->c_x, (const int *)s->slot_l1);
+			LFA_LAUNCH_CHECK(s);
+		}
+	}
 	return gather<real, double>(s, (real *)s->vz, z, n, 0);
 }
 extern "C" int lfa_apply_preconditioner(lfa_sim *s, const double *r, double *z, uint64_t n) {
@@ -807,14 +1207,15 @@ template <typename real> static int bench_launch(lfa_sim *s, int which) {
 		                   P + PART_ZS, s->pcg_state);
 		break;
 	case LFA_K_AXPY_MAX:
-		hipLaunchKernelGGL(k_axpy_max<real>, dim3(G), dim3(256), 0, s->stream, tc, s->abits, v, P + PART_SIG0, P + PART_ZS,
+		hipLaunchKernelGGL(k_axpy_max<real>, dim3(G), dim3(256), 0, s->stream, tc, s->abits, v, P + PART_SIG0, G, P + PART_ZS,
 		                   G, P + PART_RMAX, s->pcg_state);
 		break;
 	case LFA_K_MIC_APPLY:
 		return mic_apply<real>(s, P + PART_SIG1);
 	case LFA_K_UPDATE_S:
 		hipLaunchKernelGGL(k_update_s<real>, dim3(G), dim3(256), 0, s->stream, tc, v, P + PART_SIG0, P + PART_SIG0, G, 0,
-		                   s->pcg_state);
+		                   s->pcg_state, s->abits, is_ml(s) ? (const real *)s->c_x : (const real *)nullptr,
+		                   (const int *)s->slot_l1);
 		break;
 	}
 	LFA_LAUNCH_CHECK(s);

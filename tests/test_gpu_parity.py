@@ -108,7 +108,7 @@ def test_pcg_exact_schedule_matches_reference_iterations(name):
 
 
 @pytest.mark.parametrize("dtype", [lfa.PCG_F32, lfa.PCG_F64])
-@pytest.mark.parametrize("precond", [lfa.PRECOND_MIC0_TILED, lfa.PRECOND_MIC0_EXACT])
+@pytest.mark.parametrize("precond", [lfa.PRECOND_MIC0_TILED, lfa.PRECOND_MIC0_EXACT, lfa.PRECOND_MULTILEVEL])
 @pytest.mark.parametrize("name", ["apic16_solid", "flip16", "pic_ragged", "apic_tank"])
 def test_pcg_pressure_within_tolerance(name, precond, dtype):
     c, parts, solid, s = make_gpu(name, precond=precond, pcg_dtype=dtype)
@@ -146,7 +146,8 @@ def test_apply_pressure_extrapolate_g2p(name):
     s.close()
 
 
-@pytest.mark.parametrize("precond,dtype", [(lfa.PRECOND_MIC0_EXACT, lfa.PCG_F64), (lfa.PRECOND_MIC0_TILED, lfa.PCG_F32)])
+@pytest.mark.parametrize("precond,dtype", [(lfa.PRECOND_MIC0_EXACT, lfa.PCG_F64), (lfa.PRECOND_MIC0_TILED, lfa.PCG_F32),
+                                           (lfa.PRECOND_MULTILEVEL, lfa.PCG_F32)])
 @pytest.mark.parametrize("name", sorted(util.CASES))
 def test_two_hot_steps_end_to_end(name, precond, dtype):
     """Two full passes of the hot path, staged exactly like the golden run, against the reference's final state."""
@@ -196,6 +197,29 @@ def test_step_hot_equals_staged_calls_and_oracle(name):
     gi = util.order_by_position(got)
     util.assert_close(got["vel"][gi], want["vel"], 1e-4, "particle velocities", atol=VEL_ATOL)
     assert np.array_equal(got["raw"][gi], want["raw"])
+    s.close()
+
+
+@pytest.mark.parametrize("dtype", [lfa.PCG_F32, lfa.PCG_F64])
+def test_multilevel_preconditioner_is_symmetric_and_cuts_iterations(dtype):
+    """The coarse-space correction must keep M^-1 symmetric positive definite (CG needs it) and pay for itself."""
+    name = "apic_ragged"
+    c, parts, solid, s = make_gpu(name, precond=lfa.PRECOND_MULTILEVEL, pcg_dtype=dtype)
+    g = util.load_golden(name)
+    s.hash()
+    s.upload_cells(cells_from(g["grav_vel0"], g["p2g_type0"]))
+    s.build_system(util.DT)
+    n = len(g["b0"])
+    rng = np.random.default_rng(7)
+    x, y = rng.normal(size=n), rng.normal(size=n)
+    mx, my = s.apply_precon(x), s.apply_precon(y)
+    assert abs(y @ mx - x @ my) <= (2e-5 if dtype == lfa.PCG_F32 else 1e-11) * (abs(y @ mx) + np.linalg.norm(x) * np.linalg.norm(my))
+    assert x @ mx > 0 and y @ my > 0
+    p, res, it_ml, rc = s.solve(util.DT)
+    util.assert_close(p, g["p0"], P_REL, "pressure (multilevel)")
+    s.set_params(precond=lfa.PRECOND_MIC0_TILED)
+    _, _, it_tiled, _ = s.solve(util.DT)
+    assert it_ml <= it_tiled
     s.close()
 
 
@@ -263,7 +287,7 @@ def test_properties_at_scale():
     - the projected grid field is divergence free (rhs of a second build ~ 0 relative to the first)
     - binned and global-atomic P2G agree."""
     n = 128
-    s = lfa.Sim((n, n, n), precond=lfa.PRECOND_MIC0_TILED, pcg_dtype=lfa.PCG_F32)
+    s = lfa.Sim((n, n, n), precond=lfa.PRECOND_MULTILEVEL, pcg_dtype=lfa.PCG_F32)
     s.seed_block((0, 0, 0), (n, 32, n))  # tank filled wall to wall, 32 cells deep
     res, it, rc = s.step_hot(util.DT)
     assert rc == 0 and res < 1e-6
