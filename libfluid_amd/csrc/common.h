@@ -53,6 +53,8 @@ struct GridDims {
 struct lfa_sim {
 	int device = 0;
 	hipStream_t stream = nullptr;
+	hipStream_t stream2 = nullptr;  // side stream: the coarse levels of the preconditioner run beside the fine sweep
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	GridDims g{};
 	size_t nc = 0, ncp = 0;  // real / padded cell count
 	lfa_params prm{};

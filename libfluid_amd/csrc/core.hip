@@ -197,6 +197,12 @@ extern "C" int lfa_create(lfa_sim **out, uint64_t nx, uint64_t ny, uint64_t nz, 
 		delete s;
 		return lfa_fail(nullptr, LFA_E_HIP, "hipStreamCreate failed");
 	}
+	if (hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking) != hipSuccess ||
+	    hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess) {
+		lfa_destroy(s);
+		return lfa_fail(nullptr, LFA_E_HIP, "side stream / event creation failed");
+	}
 	chk(dev_alloc(s, &s->tile_count, g.nt + 1, true));
 	chk(dev_alloc(s, &s->tile_start, g.nt + 1, true));
 	chk(dev_alloc(s, &s->tile_flag, g.nt + 1, true));
@@ -242,6 +248,7 @@ extern "C" void lfa_destroy(lfa_sim *s) {
 	if (!s) return;
 	(void)hipSetDevice(s->device);
 	if (s->stream) (void)hipStreamSynchronize(s->stream);
+	if (s->stream2) (void)hipStreamSynchronize(s->stream2);
 	free_soa(s->pb[0]);
 	free_soa(s->pb[1]);
 	void *ptrs[] = {s->grid_flag, s->rank, s->tile_count, s->tile_start, s->tile_flag, s->tile_scan, s->ptiles, s->dtiles,
@@ -255,6 +262,9 @@ extern "C" void lfa_destroy(lfa_sim *s) {
 	if (s->h_pinned) (void)hipHostFree(s->h_pinned);
 	if (s->ev_created)
 		for (auto &e : s->ev) (void)hipEventDestroy(e);
+	if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+	if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+	if (s->stream2) (void)hipStreamDestroy(s->stream2);
 	if (s->stream) (void)hipStreamDestroy(s->stream);
 	delete s;
 }

@@ -156,7 +156,7 @@ k_spmv(TileCtx tc, const uint8_t *abits, const real *s, real *z, real scale, dou
 template <typename real>
 __global__ void __launch_bounds__(256)
 k_axpy_max(TileCtx tc, const uint8_t *abits, Vecs<real> v, const double *part_sigma, int n_sigma, const double *part_zs,
-           int n_part, double *part_rmax, const int *state) {
+           int n_part, double *part_rmax, const int *state, real *coarse_r, const int *slot_l1) {
 	__shared__ double lds[256];
 	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	double m = -INFINITY;
@@ -167,6 +167,7 @@ k_axpy_max(TileCtx tc, const uint8_t *abits, Vecs<real> v, const double *part_si
 		const real alpha = (real)(sigma / zs);
 		for (int slot = blockIdx.x * PCG_WAVES + wid; slot < tc.n_ptiles; slot += gridDim.x * PCG_WAVES) {
 			const size_t base = (size_t)tc.ptiles[slot] * LFA_TILE_CELLS;
+			double sr = 0.0;
 #pragma unroll
 			for (int zz = 0; zz < 8; ++zz) {
 				const size_t b = base + zz * 64 + lane;
@@ -176,7 +177,12 @@ k_axpy_max(TileCtx tc, const uint8_t *abits, Vecs<real> v, const double *part_si
 					v.r[b] = rn;
 					nan |= rn != rn;
 					m = (double)rn > m ? (double)rn : m;
+					sr += (double)rn;
 				}
+			}
+			if (coarse_r) {  // restriction of the new residual for the coarse levels (they run beside the fine sweep)
+				sr = wave_sum(sr);
+				if (lane == 0) coarse_r[slot_l1[slot]] = (real)sr;
 			}
 		}
 	}
@@ -638,6 +644,107 @@ k_coarse_top(const int *l1_tiles, int n_l1, CoarseFields<real> c, const real *a2
 	if (threadIdx.x == 0) *part_sigma_extra = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+/// All coarse work of one preconditioner application in ONE workgroup (used when at most 64 level-1 blocks hold fluid):
+/// per level-1 block a wave stages coefficients in LDS and runs the weighted forward/backward substitution, then the
+/// dense top-level solve, the prolongation of its result onto level 1 and the coarse share of z.r. Latency-bound by
+/// design (44 dependent LDS hyperplanes per block), so everything the sweeps touch sits in LDS.
+template <typename real, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
+k_coarse_all(const int *l1_tiles, int n_l1, CoarseFields<real> c, real scale, const real *a2inv,
+             double *part_sigma_extra, const int *state) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	if (state[0] >= 0) return;
+	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
+	// per wave: PRE, Q, PQ (real) + the three face weights as bytes (a face of a tile has at most 64 couplings)
+	real *wbase = (real *)smem + (size_t)wid * 3 * LFA_TILE_CELLS;
+	real *PRE = wbase, *Q = wbase + LFA_TILE_CELLS, *PQ = wbase + 2 * LFA_TILE_CELLS;
+	uint8_t *ub = (uint8_t *)((real *)smem + (size_t)WAVES * 3 * LFA_TILE_CELLS) + (size_t)wid * 3 * LFA_TILE_CELLS;
+	uint8_t *U[3] = {ub, ub + LFA_TILE_CELLS, ub + 2 * LFA_TILE_CELLS};
+	double *r2s = (double *)(smem + (size_t)WAVES * 3 * LFA_TILE_CELLS * (sizeof(real) + 1));
+	double *x2s = r2s + 64;
+	double *red = x2s + 64;
+	for (int k = wid; k < n_l1; k += WAVES) {
+		const size_t base = (size_t)l1_tiles[k] * LFA_TILE_CELLS;
+		double sr = 0.0;
+		WAVE_SYNC();
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) {
+			const int idx = zz * 64 + lane;
+			const bool u = c.unk[base + idx] != 0;
+			U[0][idx] = (uint8_t)c.w[0][base + idx];
+			U[1][idx] = (uint8_t)c.w[1][base + idx];
+			U[2][idx] = (uint8_t)c.w[2][base + idx];
+			PRE[idx] = u ? c.pre[base + idx] : (real)0;
+			const real r = u ? c.r[base + idx] : (real)0;
+			Q[idx] = r;
+			PQ[idx] = (real)0;
+			sr += (double)r;
+		}
+		sr = wave_sum(sr);
+		if (lane == 0) r2s[k] = sr;
+		WAVE_SYNC();
+		for (int level = 0; level < 22; ++level) {
+			const int zz = level - lx - ly;
+			if (zz >= 0 && zz < 8) {
+				const int idx = zz * 64 + lane;
+				real t = (real)0;
+				if (lx > 0) t += (real)U[0][idx - 1] * PQ[idx - 1];
+				if (ly > 0) t += (real)U[1][idx - 8] * PQ[idx - 8];
+				if (zz > 0) t += (real)U[2][idx - 64] * PQ[idx - 64];
+				const real p = PRE[idx];
+				const real q = (Q[idx] + scale * t) * p;
+				Q[idx] = q;
+				PQ[idx] = p * q;
+			}
+			WAVE_SYNC();
+		}
+		for (int level = 21; level >= 0; --level) {
+			const int zz = level - lx - ly;
+			if (zz >= 0 && zz < 8) {
+				const int idx = zz * 64 + lane;
+				real t = (real)0;
+				if (lx < 7) t += (real)U[0][idx] * Q[idx + 1];
+				if (ly < 7) t += (real)U[1][idx] * Q[idx + 8];
+				if (zz < 7) t += (real)U[2][idx] * Q[idx + 64];
+				const real p = PRE[idx];
+				Q[idx] = (Q[idx] + scale * p * t) * p;
+			}
+			WAVE_SYNC();
+		}
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) c.x[base + zz * 64 + lane] = Q[zz * 64 + lane];
+	}
+	__syncthreads();
+	for (int row = threadIdx.x; row < n_l1; row += WAVES * 64) {
+		double acc = 0.0;
+		for (int k = 0; k < n_l1; ++k) acc += (double)a2inv[(size_t)row * n_l1 + k] * r2s[k];
+		x2s[row] = acc;
+	}
+	__syncthreads();
+	double dotp = 0.0;
+	for (int k = wid; k < n_l1; k += WAVES) {
+		const size_t base = (size_t)l1_tiles[k] * LFA_TILE_CELLS;
+		const real add = (real)x2s[k];
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) {
+			const size_t i = base + zz * 64 + lane;
+			if (c.unk[i]) {
+				const real xt = c.x[i] + add;
+				c.x[i] = xt;
+				dotp += (double)xt * (double)c.r[i];
+			}
+		}
+	}
+	dotp = wave_sum(dotp);
+	if (lane == 0) red[wid] = dotp;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		double t = 0.0;
+		for (int w = 0; w < WAVES; ++w) t += red[w];
+		*part_sigma_extra = t;
+	}
+}
+
 /// z += P x_coarse on the unknowns (only for lfa_apply_preconditioner, which hands z to the caller).
 template <typename real>
 __global__ void __launch_bounds__(256)
@@ -886,14 +993,28 @@ template <typename real> static int coarse_setup(lfa_sim *s) {
 }
 
 /// Coarse half of z = M^-1 r: level-1 block MIC(0) + dense top level; writes the coarse share of z.r as partial G.
-template <typename real> static int coarse_apply(lfa_sim *s, double *part_sigma) {
+template <typename real> static int coarse_apply(lfa_sim *s, double *part_sigma, hipStream_t stream) {
 	CoarseFields<real> cf = make_coarse<real>(s);
+	double *extra = part_sigma + pcg_grid(s->n_ptiles);
+	if (s->n_l1tiles <= 64) {
+		constexpr int WAVES = sizeof(real) == 4 ? 16 : 8;
+		const size_t lds = (size_t)WAVES * 3 * LFA_TILE_CELLS * (sizeof(real) + 1) + (64 + 64 + 16) * sizeof(double);
+		static bool attr_set = false;
+		if (!attr_set) {
+			LFA_HIP(s, hipFuncSetAttribute((const void *)k_coarse_all<real, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize,
+			                               (int)lds));
+			attr_set = true;
+		}
+		hipLaunchKernelGGL((k_coarse_all<real, WAVES>), dim3(1), dim3(WAVES * 64), lds, stream, s->l1_tiles, s->n_l1tiles,
+		                   cf, (real)s->a_scale, (const real *)s->a2inv, extra, s->pcg_state);
+		LFA_LAUNCH_CHECK(s);
+		return LFA_OK;
+	}
 	const int g1grid = (s->n_l1tiles + PCG_WAVES - 1) / PCG_WAVES;
-	hipLaunchKernelGGL(k_coarse_apply<real>, dim3(g1grid), dim3(256), 0, s->stream, s->l1_tiles, s->n_l1tiles, cf,
+	hipLaunchKernelGGL(k_coarse_apply<real>, dim3(g1grid), dim3(256), 0, stream, s->l1_tiles, s->n_l1tiles, cf,
 	                   (real)s->a_scale, (real *)s->c_r2);
-	hipLaunchKernelGGL(k_coarse_top<real>, dim3(1), dim3(256), 0, s->stream, s->l1_tiles, s->n_l1tiles, cf,
-	                   (const real *)s->a2inv, (const real *)s->c_r2, (real *)s->c_x2, part_sigma + pcg_grid(s->n_ptiles),
-	                   s->pcg_state);
+	hipLaunchKernelGGL(k_coarse_top<real>, dim3(1), dim3(256), 0, stream, s->l1_tiles, s->n_l1tiles, cf,
+	                   (const real *)s->a2inv, (const real *)s->c_r2, (real *)s->c_x2, extra, s->pcg_state);
 	LFA_LAUNCH_CHECK(s);
 	return LFA_OK;
 }
@@ -919,8 +1040,9 @@ template <typename real> static int mic_factor(lfa_sim *s) {
 	return LFA_OK;
 }
 
-/// z = M^-1 r and partial dot(z, r) into part_sigma.
-template <typename real> static int mic_apply(lfa_sim *s, double *part_sigma) {
+/// z = M^-1 r and partial dot(z, r) into part_sigma. `r1_ready`: the restricted residual was already written (by
+/// k_axpy_max), so the coarse levels are forked onto the side stream and overlap the fine sweep.
+template <typename real> static int mic_apply(lfa_sim *s, double *part_sigma, bool r1_ready = false) {
 	TileCtx tc = make_ctx(s);
 	Vecs<real> v = make_vecs<real>(s);
 	const real scale = (real)s->a_scale;
@@ -946,11 +1068,19 @@ template <typename real> static int mic_apply(lfa_sim *s, double *part_sigma) {
 		hipLaunchKernelGGL(k_dot_zr<real>, dim3(G), dim3(256), 0, s->stream, tc, v, part_sigma, s->pcg_state);
 		LFA_LAUNCH_CHECK(s);
 	} else {
+		const bool fork = is_ml(s) && r1_ready;
+		if (fork) {
+			LFA_HIP(s, hipEventRecord(s->ev_fork, s->stream));
+			LFA_HIP(s, hipStreamWaitEvent(s->stream2, s->ev_fork, 0));
+			LFA_TRY(coarse_apply<real>(s, part_sigma, s->stream2));
+			LFA_HIP(s, hipEventRecord(s->ev_join, s->stream2));
+		}
 		hipLaunchKernelGGL((k_mic_apply<real, SWEEP_BOTH>), dim3(G), dim3(256), 0, s->stream, tc, (const int *)nullptr,
-		                   s->n_ptiles, s->abits, v, scale, part_sigma, s->pcg_state, is_ml(s) ? (real *)s->c_r : (real *)nullptr,
-		                   (const int *)s->slot_l1);
+		                   s->n_ptiles, s->abits, v, scale, part_sigma, s->pcg_state,
+		                   (is_ml(s) && !r1_ready) ? (real *)s->c_r : (real *)nullptr, (const int *)s->slot_l1);
 		LFA_LAUNCH_CHECK(s);
-		if (is_ml(s)) LFA_TRY(coarse_apply<real>(s, part_sigma));
+		if (fork) LFA_HIP(s, hipStreamWaitEvent(s->stream, s->ev_join, 0));
+		else if (is_ml(s)) LFA_TRY(coarse_apply<real>(s, part_sigma, s->stream));
 	}
 	return LFA_OK;
 }
@@ -1011,11 +1141,12 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 			hipLaunchKernelGGL(k_spmv<real>, dim3(G), dim3(256), 0, s->stream, tc, s->abits, (const real *)v.s, v.z, scale,
 			                   P + PART_ZS, s->pcg_state);
 			hipLaunchKernelGGL(k_axpy_max<real>, dim3(G), dim3(256), 0, s->stream, tc, s->abits, v, sig_old, NS, P + PART_ZS, G,
-			                   P + PART_RMAX, s->pcg_state);
+			                   P + PART_RMAX, s->pcg_state, is_ml(s) ? (real *)s->c_r : (real *)nullptr,
+			                   (const int *)s->slot_l1);
 			hipLaunchKernelGGL(k_check_converged, dim3(1), dim3(256), 0, s->stream, P + PART_RMAX, G, s->prm.tolerance, i,
 			                   s->pcg_state, s->pcg_hist);
 			LFA_LAUNCH_CHECK(s);
-			LFA_TRY(mic_apply<real>(s, sig_new));
+			LFA_TRY(mic_apply<real>(s, sig_new, true));
 			hipLaunchKernelGGL(k_update_s<real>, dim3(G), dim3(256), 0, s->stream, tc, v, sig_new, sig_old, NS, 0,
 			                   s->pcg_state, s->abits, cx, (const int *)s->slot_l1);
 			LFA_LAUNCH_CHECK(s);
@@ -1208,10 +1339,11 @@ template <typename real> static int bench_launch(lfa_sim *s, int which) {
 		break;
 	case LFA_K_AXPY_MAX:
 		hipLaunchKernelGGL(k_axpy_max<real>, dim3(G), dim3(256), 0, s->stream, tc, s->abits, v, P + PART_SIG0, G, P + PART_ZS,
-		                   G, P + PART_RMAX, s->pcg_state);
+		                   G, P + PART_RMAX, s->pcg_state, is_ml(s) ? (real *)s->c_r : (real *)nullptr,
+		                   (const int *)s->slot_l1);
 		break;
 	case LFA_K_MIC_APPLY:
-		return mic_apply<real>(s, P + PART_SIG1);
+		return mic_apply<real>(s, P + PART_SIG1, true);
 	case LFA_K_UPDATE_S:
 		hipLaunchKernelGGL(k_update_s<real>, dim3(G), dim3(256), 0, s->stream, tc, v, P + PART_SIG0, P + PART_SIG0, G, 0,
 		                   s->pcg_state, s->abits, is_ml(s) ? (const real *)s->c_x : (const real *)nullptr,
