@@ -151,6 +151,26 @@ int lfa_cfl(lfa_sim *s, double *out);
  * 83-104,119-121). residual/iterations may be NULL. */
 int lfa_step_hot(lfa_sim *s, double dt, double *residual, uint64_t *iterations);
 
+/* -- multi-GPU: z-slab domain decomposition ---------------------------------------------------------
+ * One handle per GPU/process, every handle created with the GLOBAL grid size. Rank r owns the tile layers
+ * [bounds[r], bounds[r+1]) (a tile layer = 8 cells in z) and the particles inside them; one ghost tile layer on each side
+ * is refreshed by nearest-neighbour exchanges (tile flags, P2G boundary planes, u/v/w/type halos, one z-slice of the PCG
+ * search vector per iteration) and three scalar all-reduces per PCG iteration. The reference has no distributed mode;
+ * this replaces nothing in it.
+ *   lfa_dist_unique_id  : rank 0 fills a 128-byte RCCL id, the caller broadcasts it (e.g. torch.distributed)
+ *   lfa_dist_init_rccl  : ncclCommInitRank on this handle's device; send/recv to z+-1 and all-reduce run on the
+ *                         handle's stream over xGMI
+ *   lfa_dist_local_*    : the same protocol between handles of ONE process (one host thread per handle), device-to-device
+ *                         copies instead of RCCL: how the slab logic is tested on a single GPU ("virtual slabs") */
+int lfa_dist_unique_id(void *id128);
+int lfa_dist_init_rccl(lfa_sim *s, int rank, int nranks, const void *id128, const int32_t *layer_bounds);
+typedef struct lfa_hub lfa_hub;
+lfa_hub *lfa_dist_local_hub_create(int nranks);
+void lfa_dist_local_hub_destroy(lfa_hub *h);
+int lfa_dist_init_local(lfa_sim *s, lfa_hub *h, int rank, const int32_t *layer_bounds);
+/* Owned tile layers of this handle ([0, ntz) without a decomposition). */
+int lfa_dist_get_slab(const lfa_sim *s, int32_t *lo, int32_t *hi);
+
 /* -- measurement --------------------------------------------------------------------------------------------- */
 /* Per-stage device time of the last lfa_step_hot, measured with HIP events on the handle's stream (milliseconds):
  * [0] hash/bin [1] P2G [2] gravity [3] build system [4] PCG loop [5] apply pressure [6] extrapolate [7] G2P

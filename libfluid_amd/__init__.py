@@ -101,6 +101,12 @@ SIGNATURES = {
     "lfa_get_timings": (_int, [_vp, C.POINTER(_dbl * NUM_TIMERS)]),
     "lfa_get_counts": (_int, [_vp, C.POINTER(_u64 * 5)]),
     "lfa_bench_kernel": (_int, [_vp, _int, _int, C.POINTER(_dbl)]),
+    "lfa_dist_unique_id": (_int, [_vp]),
+    "lfa_dist_init_rccl": (_int, [_vp, _int, _int, _vp, _vp]),
+    "lfa_dist_local_hub_create": (_vp, [_int]),
+    "lfa_dist_local_hub_destroy": (None, [_vp]),
+    "lfa_dist_init_local": (_int, [_vp, _vp, _int, _vp]),
+    "lfa_dist_get_slab": (_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
 KERNELS = {"spmv_dot": 0, "axpy_max": 1, "mic_apply_dot": 2, "update_s": 3, "p2g_scatter": 4, "p2g_finalize": 5,
            "g2p": 6, "bin": 7}
@@ -120,6 +126,40 @@ def load_library():
             fn.restype, fn.argtypes = res, args
         _lib = lib
     return _lib
+
+
+def rccl_unique_id():
+    """128-byte RCCL unique id (rank 0 creates it, the caller broadcasts it to the other ranks)."""
+    buf = np.zeros(128, dtype=np.uint8)
+    rc = load_library().lfa_dist_unique_id(_ptr(buf))
+    if rc != 0:
+        raise LibfluidError(rc, load_library().lfa_last_error(None).decode())
+    return buf.tobytes()
+
+
+def balanced_layer_bounds(ntz, nranks, lo_layer=0, hi_layer=None):
+    """Splits the tile layers [lo_layer, hi_layer) that hold fluid evenly over the ranks; the empty layers below/above go
+    to the first/last rank. Returns nranks+1 bounds partitioning [0, ntz)."""
+    hi_layer = ntz if hi_layer is None else hi_layer
+    span = max(hi_layer - lo_layer, nranks)
+    hi_layer = min(lo_layer + span, ntz)
+    lo_layer = max(hi_layer - span, 0)
+    b = [lo_layer + (span * r) // nranks for r in range(nranks + 1)]
+    b[0], b[-1] = 0, ntz
+    return b
+
+
+class LocalHub:
+    """In-process transport between the handles of several "virtual slabs" (one host thread per handle)."""
+
+    def __init__(self, nranks):
+        self.lib = load_library()
+        self.h = C.c_void_p(self.lib.lfa_dist_local_hub_create(int(nranks)))
+
+    def close(self):
+        if self.h:
+            self.lib.lfa_dist_local_hub_destroy(self.h)
+            self.h = None
 
 
 def default_params():
@@ -315,6 +355,21 @@ class Sim:
         res, it = C.c_double(0.0), C.c_uint64(0)
         rc = self._chk(self.lib.lfa_step_hot(self.h, float(dt), C.byref(res), C.byref(it)))
         return res.value, it.value, rc
+
+    # -- z-slab decomposition ------------------------------------------------------------------------------
+    def init_local_slab(self, hub, rank, layer_bounds):
+        b = np.ascontiguousarray(layer_bounds, dtype=np.int32)
+        self._chk(self.lib.lfa_dist_init_local(self.h, hub, int(rank), _ptr(b)))
+
+    def init_rccl_slab(self, rank, nranks, unique_id, layer_bounds):
+        b = np.ascontiguousarray(layer_bounds, dtype=np.int32)
+        uid = np.frombuffer(bytes(unique_id), dtype=np.uint8).copy()
+        self._chk(self.lib.lfa_dist_init_rccl(self.h, int(rank), int(nranks), _ptr(uid), _ptr(b)))
+
+    def slab(self):
+        lo, hi = C.c_int32(0), C.c_int32(0)
+        self._chk(self.lib.lfa_dist_get_slab(self.h, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
 
     # -- measurement ---------------------------------------------------------------------------------------
     def enable_timing(self, on=True):

@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfluid_amd.so")
-SOURCES = ["core.hip", "p2g.hip", "grid_ops.hip", "pcg.hip"]
+SOURCES = ["core.hip", "p2g.hip", "grid_ops.hip", "pcg.hip", "dist.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=off",
          "-Wno-unused-result"]
 
@@ -54,7 +54,7 @@ def build(force=False, verbose=False):
             if verbose and w:
                 print(w)
     if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl", "-lpthread"])
     return LIB
 
 

@@ -67,6 +67,21 @@ struct lfa_sim {
 	uint32_t *rank = nullptr;
 	bool binned = false;
 
+	// z-slab domain decomposition (dist.hip). Every rank indexes the GLOBAL grid; it owns the tile layers
+	// [slab_lo, slab_hi) and mirrors one ghost tile layer on each side. dist == nullptr: single domain.
+	struct lfa_dist *dist = nullptr;
+	int slab_lo = 0, slab_hi = 0;           // owned tile layers (z)
+	int *ptiles_all = nullptr;              // ghost-lo | owned | ghost-hi particle tiles, ascending tile id
+	int p_off = 0, n_ptiles_all = 0;        // ptiles == ptiles_all + p_off
+	int n_own_first = 0, n_own_last = 0;    // owned particle tiles in the first / last owned layer
+	int n_ghost_lo = 0, n_ghost_hi = 0;     // particle tiles of the neighbours' adjacent layers
+	int *halo_tiles = nullptr;              // [send_lo | send_hi | recv_lo | recv_hi] processed tiles of the boundary layers
+	int n_halo[4] = {0, 0, 0, 0};
+	void *xbuf[4] = {nullptr, nullptr, nullptr, nullptr};  // send_lo, send_hi, recv_lo, recv_hi
+	size_t xcap[4] = {0, 0, 0, 0};
+	double *dist_red = nullptr;             // all-reduced scalars
+	size_t np_live = 0;
+
 	// tiles
 	uint32_t *tile_count = nullptr, *tile_start = nullptr;  // nt, nt+1
 	uint32_t *tile_flag = nullptr, *tile_scan = nullptr;    // nt
@@ -188,3 +203,22 @@ int lfa_particles_alloc(lfa_sim *s, size_t n);
 int lfa_ensure_io(lfa_sim *s, size_t bytes);
 int lfa_pcg_alloc(lfa_sim *s);
 int lfa_number_unknowns(lfa_sim *s);
+
+// ---------------------------------------------------------------------------------------------------- slabs (dist.hip)
+/// Transport between z-slab neighbours. lo = rank-1, hi = rank+1; all pointers are device pointers, sizes in bytes.
+struct lfa_dist {
+	int rank = 0, nranks = 1;
+	virtual int exchange(lfa_sim *s, const void *send_lo, size_t n_send_lo, void *recv_lo, size_t n_recv_lo,
+	                     const void *send_hi, size_t n_send_hi, void *recv_hi, size_t n_recv_hi) = 0;
+	virtual int allreduce(lfa_sim *s, double *dev, int count, bool is_max) = 0;
+	virtual ~lfa_dist() {}
+};
+inline bool lfa_has_lo(const lfa_sim *s) { return s->dist && s->dist->rank > 0; }
+inline bool lfa_has_hi(const lfa_sim *s) { return s->dist && s->dist->rank + 1 < s->dist->nranks; }
+int lfa_dist_exchange_tile_layers_u32(lfa_sim *s, uint32_t *per_tile);  // own boundary layers -> neighbours' ghost layers
+int lfa_dist_build_halo_lists(lfa_sim *s);
+int lfa_dist_exchange_fields(lfa_sim *s, int nfields, void *const *fields, const int *elem_bytes);
+int lfa_dist_exchange_p2g_planes(lfa_sim *s, float *stage_all);
+int lfa_dist_exchange_slices(lfa_sim *s, void *vec, int elem_bytes);
+int lfa_dist_allreduce(lfa_sim *s, const double *partials, int n, int slot, bool is_max);  // result in dist_red[slot]
+int lfa_dist_ensure_xbuf(lfa_sim *s, int which, size_t bytes);

@@ -208,7 +208,10 @@ extern "C" int lfa_create(lfa_sim **out, uint64_t nx, uint64_t ny, uint64_t nz, 
 	chk(dev_alloc(s, &s->tile_flag, g.nt + 1, true));
 	chk(dev_alloc(s, &s->tile_scan, g.nt + 1, true));
 	chk(dev_alloc(s, &s->grid_flag, g.nt + 1, true));
-	chk(dev_alloc(s, &s->ptiles, g.nt, true));
+	chk(dev_alloc(s, &s->ptiles_all, g.nt, true));
+	s->ptiles = s->ptiles_all;
+	s->slab_lo = 0;
+	s->slab_hi = g.ntz;
 	chk(dev_alloc(s, &s->dtiles, g.nt, true));
 	chk(dev_alloc(s, &s->tile_pslot, g.nt, true));
 	chk(dev_alloc(s, &s->level_tiles, g.nt, true));
@@ -251,7 +254,8 @@ extern "C" void lfa_destroy(lfa_sim *s) {
 	if (s->stream2) (void)hipStreamSynchronize(s->stream2);
 	free_soa(s->pb[0]);
 	free_soa(s->pb[1]);
-	void *ptrs[] = {s->grid_flag, s->rank, s->tile_count, s->tile_start, s->tile_flag, s->tile_scan, s->ptiles, s->dtiles,
+	void *ptrs[] = {s->grid_flag, s->rank, s->tile_count, s->tile_start, s->tile_flag, s->tile_scan, s->ptiles_all, s->dtiles, s->halo_tiles, s->dist_red,
+	                s->xbuf[0], s->xbuf[1], s->xbuf[2], s->xbuf[3],
 	                s->tile_pslot, s->scan_tmp, s->u, s->v, s->w, s->uo, s->vo, s->wo, s->ctype, s->solid,
 	                s->cell_count, s->stage, s->acc, s->abits, s->vp, s->vr, s->vz, s->vs, s->vpre, s->vq,
 	                s->partials, s->pcg_state, s->pcg_hist, s->level_tiles, s->io_buf, s->raw_scan, s->c_diag, s->c_w[0],
@@ -260,6 +264,8 @@ extern "C" void lfa_destroy(lfa_sim *s) {
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	if (s->h_pinned) (void)hipHostFree(s->h_pinned);
+	if (s->dist) delete s->dist;
+	s->dist = nullptr;
 	if (s->ev_created)
 		for (auto &e : s->ev) (void)hipEventDestroy(e);
 	if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
@@ -357,7 +363,7 @@ __device__ inline void cell_and_fraction(double pos, double off, double h, int n
 	t = tf;
 }
 
-__global__ void k_ingest(const double *aos, size_t n, ParticleSoA p, GridDims g, IngestParams ip) {
+__global__ void k_ingest(const double *aos, size_t n, ParticleSoA p, GridDims g, IngestParams ip, int slab_lo, int slab_hi) {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	const double *q = aos + i * 19;
@@ -366,7 +372,8 @@ __global__ void k_ingest(const double *aos, size_t n, ParticleSoA p, GridDims g,
 	cell_and_fraction(q[0], ip.off[0], ip.h, g.nx, c[0], t[0]);
 	cell_and_fraction(q[1], ip.off[1], ip.h, g.ny, c[1], t[1]);
 	cell_and_fraction(q[2], ip.off[2], ip.h, g.nz, c[2], t[2]);
-	p.key[i] = blocked_index(g, c[0], c[1], c[2]);
+	// a particle outside this rank's tile layers belongs to another rank: dropped by the binning (key = invalid)
+	p.key[i] = ((c[2] >> 3) >= slab_lo && (c[2] >> 3) < slab_hi) ? blocked_index(g, c[0], c[1], c[2]) : 0xFFFFFFFFu;
 #pragma unroll
 	for (int k = 0; k < 3; ++k) {
 		p.t[k][i] = t[k];
@@ -384,6 +391,7 @@ extern "C" int lfa_upload_particles(lfa_sim *s, const void *aos152, uint64_t n) 
 	LFA_HIP(s, hipSetDevice(s->device));
 	LFA_TRY(lfa_particles_alloc(s, n));
 	s->np = n;
+	s->np_live = n;
 	s->binned = false;  // the grid stays what it was (G2P re-uploads corrected positions between apply and gather)
 	s->system_valid = false;
 	s->unknown_count_valid = false;
@@ -395,7 +403,7 @@ extern "C" int lfa_upload_particles(lfa_sim *s, const void *aos152, uint64_t n) 
 	for (int k = 0; k < 3; ++k) ip.off[k] = s->prm.grid_offset[k];
 	ip.h = s->prm.cell_size;
 	hipLaunchKernelGGL(k_ingest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, (const double *)s->io_buf,
-	                   (size_t)n, s->pb[0], s->g, ip);
+	                   (size_t)n, s->pb[0], s->g, ip, s->slab_lo, s->slab_hi);
 	LFA_LAUNCH_CHECK(s);
 	LFA_HIP(s, hipStreamSynchronize(s->stream));  // the host buffer may be reused by the caller
 	return LFA_OK;
@@ -437,7 +445,7 @@ extern "C" int lfa_download_particles(lfa_sim *s, void *aos152, uint64_t n, int 
 	for (int k = 0; k < 3; ++k) ip.off[k] = s->prm.grid_offset[k];
 	ip.h = s->prm.cell_size;
 	hipLaunchKernelGGL(k_export, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, (double *)s->io_buf,
-	                   (size_t)n, s->pb[s->cur], s->g, ip, flags);
+	                   s->np_live, s->pb[s->cur], s->g, ip, flags);
 	LFA_LAUNCH_CHECK(s);
 	LFA_HIP(s, hipMemcpyAsync(aos152, s->io_buf, n * 152, hipMemcpyDeviceToHost, s->stream));
 	LFA_HIP(s, hipStreamSynchronize(s->stream));
@@ -451,10 +459,11 @@ __device__ inline uint64_t splitmix64(uint64_t x) {
 	x ^= x >> 31;
 	return x;
 }
-__global__ void k_seed_block(size_t n, ParticleSoA p, GridDims g, IngestParams ip, int lox, int loy, int loz, int ex,
-                             int ey, uint64_t seed) {
-	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
+__global__ void k_seed_block(size_t n, size_t first, ParticleSoA p, GridDims g, IngestParams ip, int lox, int loy, int loz,
+                             int ex, int ey, uint64_t seed) {
+	size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= n) return;
+	const size_t i = j + first;  // index in the whole block
 	size_t ci = i >> 3;
 	int sub = (int)(i & 7);
 	int cell[3] = {lox + (int)(ci % ex), loy + (int)((ci / ex) % ey), loz + (int)(ci / ((size_t)ex * ey))};
@@ -470,15 +479,15 @@ __global__ void k_seed_block(size_t n, ParticleSoA p, GridDims g, IngestParams i
 		double pos = ip.off[a] + ((double)cell[a] + ((double)sb[a] + uu) * 0.5) * ip.h;
 		cell_and_fraction(pos, ip.off[a], ip.h, nn[a], c[a], t[a]);
 	}
-	p.key[i] = blocked_index(g, c[0], c[1], c[2]);
+	p.key[j] = blocked_index(g, c[0], c[1], c[2]);
 #pragma unroll
 	for (int k = 0; k < 3; ++k) {
-		p.t[k][i] = t[k];
-		p.v[k][i] = 0.0f;
+		p.t[k][j] = t[k];
+		p.v[k][j] = 0.0f;
 	}
 #pragma unroll
-	for (int k = 0; k < 9; ++k) p.c[k][i] = 0.0f;
-	p.id[i] = (uint32_t)i;
+	for (int k = 0; k < 9; ++k) p.c[k][j] = 0.0f;
+	p.id[j] = (uint32_t)j;
 }
 
 extern "C" int lfa_seed_block(lfa_sim *s, const int64_t lo[3], const int64_t hi[3], uint64_t seed) {
@@ -487,11 +496,21 @@ extern "C" int lfa_seed_block(lfa_sim *s, const int64_t lo[3], const int64_t hi[
 	const int nn[3] = {s->g.nx, s->g.ny, s->g.nz};
 	for (int a = 0; a < 3; ++a)
 		if (lo[a] < 0 || hi[a] > nn[a] || lo[a] >= hi[a]) return lfa_fail(s, LFA_E_INVALID, "seed block outside the grid");
-	size_t n = (size_t)(hi[0] - lo[0]) * (size_t)(hi[1] - lo[1]) * (size_t)(hi[2] - lo[2]) * 8;
-	if (n >= ((size_t)1 << 32)) return lfa_fail(s, LFA_E_INVALID, "more than 2^32 particles");
+	// with a slab decomposition every rank seeds the part of the block that lies in its own tile layers; the counter of
+	// the generator is the particle's index in the WHOLE block, so the union over ranks is the single-domain set
+	int64_t zlo = lo[2], zhi = hi[2];
+	if (s->dist) {
+		zlo = zlo > (int64_t)s->slab_lo * 8 ? zlo : (int64_t)s->slab_lo * 8;
+		zhi = zhi < (int64_t)s->slab_hi * 8 ? zhi : (int64_t)s->slab_hi * 8;
+		if (zhi < zlo) zhi = zlo;
+	}
+	const size_t per_layer = (size_t)(hi[0] - lo[0]) * (size_t)(hi[1] - lo[1]) * 8;
+	const size_t n = per_layer * (size_t)(zhi - zlo), first = per_layer * (size_t)(zlo - lo[2]);
+	if (per_layer * (size_t)(hi[2] - lo[2]) >= ((size_t)1 << 32)) return lfa_fail(s, LFA_E_INVALID, "more than 2^32 particles");
 	LFA_HIP(s, hipSetDevice(s->device));
 	LFA_TRY(lfa_particles_alloc(s, n));
 	s->np = n;
+	s->np_live = n;
 	s->binned = false;
 	s->grid_valid = false;
 	s->system_valid = false;
@@ -500,9 +519,11 @@ extern "C" int lfa_seed_block(lfa_sim *s, const int64_t lo[3], const int64_t hi[
 	IngestParams ip;
 	for (int k = 0; k < 3; ++k) ip.off[k] = s->prm.grid_offset[k];
 	ip.h = s->prm.cell_size;
-	hipLaunchKernelGGL(k_seed_block, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, s->pb[0], s->g, ip,
-	                   (int)lo[0], (int)lo[1], (int)lo[2], (int)(hi[0] - lo[0]), (int)(hi[1] - lo[1]), seed);
-	LFA_LAUNCH_CHECK(s);
+	if (n) {
+		hipLaunchKernelGGL(k_seed_block, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, first, s->pb[0], s->g,
+		                   ip, (int)lo[0], (int)lo[1], (int)lo[2], (int)(hi[0] - lo[0]), (int)(hi[1] - lo[1]), seed);
+		LFA_LAUNCH_CHECK(s);
+	}
 	return LFA_OK;
 }
 
@@ -630,7 +651,7 @@ extern "C" int lfa_upload_cells(lfa_sim *s, const void *aos32) {
 /// particles arrive tile-coherent (they were binned last step and move < 1 tile), so a wave sees 1-3 distinct tiles.
 __global__ void k_tile_count(const uint32_t *key, size_t n, uint32_t *tile_count, uint32_t *rank) {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	bool live = i < n;
+	bool live = i < n && key[i] != 0xFFFFFFFFu;
 	uint32_t tile = live ? key[i] >> 9 : 0xFFFFFFFFu;
 	const int lane = threadIdx.x & 63;
 	uint32_t my_rank = 0;
@@ -682,6 +703,7 @@ __global__ void k_tile_scatter(size_t n, ParticleSoA src, ParticleSoA dst, const
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	uint32_t key = src.key[i], tile = key >> 9, r = rank[i];
+	if (key == 0xFFFFFFFFu) return;
 	if (shuffle) {
 		uint32_t cnt = tile_count[tile];
 		if (cnt % 1000003u != 0) r = (uint32_t)(((uint64_t)r * 1000003ull) % cnt);
@@ -717,51 +739,116 @@ k_cell_count(const int *dtiles, int n_dtiles, const uint32_t *key, const uint32_
 	}
 }
 
+__global__ void k_compact_range(const uint32_t *flag, const uint32_t *scan, int *list, int *slot_of, int lo, int hi,
+                                int slot_base) {
+	int t = lo + blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= hi) return;
+	if (flag[t]) {
+		list[scan[t]] = t;
+		if (slot_of) slot_of[t] = slot_base + (int)scan[t];
+	} else if (slot_of) {
+		slot_of[t] = -1;
+	}
+}
+__global__ void k_fill_i32(int *p, int n, int v) {
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) p[i] = v;
+}
+__global__ void k_gather_u32(const uint32_t *src, const int *idx, int n, uint32_t *dst) {
+	int i = threadIdx.x;
+	if (i < n) dst[i] = src[idx[i]];
+}
+
+/// Compacts the flagged tiles of [lo, hi) into `list` (ascending tile id); the count is returned through the host.
+static int compact_tiles(lfa_sim *s, const uint32_t *flag, int lo, int hi, int *list, int *slot_of, int *count) {
+	*count = 0;
+	if (hi <= lo) return LFA_OK;
+	uint32_t *total = (uint32_t *)s->pcg_state + 8;
+	LFA_TRY(lfa_exclusive_scan_u32(s, flag + lo, s->tile_scan + lo, (size_t)(hi - lo), total));
+	hipLaunchKernelGGL(k_compact_range, dim3((hi - lo + 255) / 256), dim3(256), 0, s->stream, flag, s->tile_scan - 0,
+	                   list - 0, slot_of, lo, hi, 0);
+	LFA_LAUNCH_CHECK(s);
+	LFA_HIP(s, hipMemcpyAsync(s->h_pinned, total, 4, hipMemcpyDeviceToHost, s->stream));
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	*count = (int)s->h_pinned[0];
+	return LFA_OK;
+}
+
 extern "C" int lfa_hash_particles(lfa_sim *s) {
 	if (!s) return LFA_E_INVALID;
 	LFA_HIP(s, hipSetDevice(s->device));
 	const GridDims &g = s->g;
-	const int nt = g.nt;
-	const size_t n = s->np;
+	const int nt = g.nt, L = g.ntx * g.nty;
+	const size_t n = s->binned ? s->np_live : s->np;
 	ParticleSoA &src = s->pb[s->cur], &dst = s->pb[s->cur ^ 1];
+	// owned tile range, and the range including the two ghost layers
+	const int own_lo = s->slab_lo * L, own_hi = s->slab_hi * L;
+	const int all_lo = lfa_has_lo(s) ? own_lo - L : own_lo, all_hi = lfa_has_hi(s) ? own_hi + L : own_hi;
+
 	LFA_HIP(s, hipMemsetAsync(s->tile_count, 0, (size_t)(nt + 1) * 4, s->stream));
 	if (n) {
 		hipLaunchKernelGGL(k_tile_count, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, src.key, n,
 		                   s->tile_count, s->rank);
 		LFA_LAUNCH_CHECK(s);
 	}
-	// tile_start[0..nt] (exclusive scan; entry nt = total because tile_count[nt] == 0)
+	// tile_start[0..nt] (exclusive scan; entry nt = number of live particles because tile_count[nt] == 0)
 	LFA_TRY(lfa_exclusive_scan_u32(s, s->tile_count, s->tile_start, (size_t)nt + 1, nullptr));
-	// particle tiles
+	LFA_HIP(s, hipMemcpyAsync(s->h_pinned + 8, s->tile_start + nt, 4, hipMemcpyDeviceToHost, s->stream));
+
+	// ---- particle tiles: owned ones from the counts, the neighbours' adjacent layers by message
 	hipLaunchKernelGGL(k_tile_flags, dim3((nt + 255) / 256), dim3(256), 0, s->stream, s->tile_count, s->tile_flag, nt);
 	LFA_LAUNCH_CHECK(s);
-	LFA_TRY(lfa_exclusive_scan_u32(s, s->tile_flag, s->tile_scan, (size_t)nt, (uint32_t *)s->pcg_state + 8));
-	hipLaunchKernelGGL(k_compact_tiles, dim3((nt + 255) / 256), dim3(256), 0, s->stream, s->tile_flag, s->tile_scan,
-	                   s->ptiles, s->tile_pslot, nt);
+	LFA_TRY(lfa_dist_exchange_tile_layers_u32(s, s->tile_flag));
+	hipLaunchKernelGGL(k_fill_i32, dim3((nt + 255) / 256), dim3(256), 0, s->stream, s->tile_pslot, nt, -1);
 	LFA_LAUNCH_CHECK(s);
-	LFA_HIP(s, hipMemcpyAsync(s->h_pinned, (uint32_t *)s->pcg_state + 8, 4, hipMemcpyDeviceToHost, s->stream));
-	LFA_HIP(s, hipStreamSynchronize(s->stream));
-	s->n_ptiles = (int)s->h_pinned[0];
-	// dilated set
+	LFA_TRY(compact_tiles(s, s->tile_flag, all_lo, all_hi, s->ptiles_all, s->tile_pslot, &s->n_ptiles_all));
+	s->np_live = s->h_pinned[8];
+	// counts per layer group = differences of the scan at the layer boundaries
+	{
+		int marks[4] = {own_lo, own_lo + L < own_hi ? own_lo + L : own_hi, own_hi - L > own_lo ? own_hi - L : own_lo, own_hi};
+		int vals[4];
+		int *didx = s->pcg_state + 12;
+		for (int k = 0; k < 4; ++k) {
+			if (marks[k] >= all_hi) vals[k] = s->n_ptiles_all;  // the scan has no entry at the end of the range
+			else vals[k] = -1;
+		}
+		LFA_HIP(s, hipMemcpyAsync(didx, marks, 16, hipMemcpyHostToDevice, s->stream));
+		hipLaunchKernelGGL(k_gather_u32, dim3(1), dim3(64), 0, s->stream, s->tile_scan, didx, 4, (uint32_t *)s->partials);
+		LFA_LAUNCH_CHECK(s);
+		LFA_HIP(s, hipMemcpyAsync(s->h_pinned + 16, ((uint32_t *)s->partials), 16, hipMemcpyDeviceToHost, s->stream));
+		LFA_HIP(s, hipStreamSynchronize(s->stream));
+		for (int k = 0; k < 4; ++k)
+			if (vals[k] < 0) vals[k] = (int)s->h_pinned[16 + k];
+		s->p_off = vals[0];
+		s->n_ptiles = vals[3] - vals[0];
+		s->n_own_first = vals[1] - vals[0];
+		s->n_own_last = vals[3] - vals[2];
+		s->n_ghost_lo = s->p_off;
+		s->n_ghost_hi = s->n_ptiles_all - vals[3];
+		s->ptiles = s->ptiles_all + s->p_off;
+	}
+
+	// ---- processed (dilated) tiles: owned ones are the work list, the neighbours' adjacent layers arrive by message
 	LFA_HIP(s, hipMemsetAsync(s->tile_flag, 0, (size_t)(nt + 1) * 4, s->stream));
-	if (s->n_ptiles) {
-		hipLaunchKernelGGL(k_dilate, dim3((s->n_ptiles * 27 + 255) / 256), dim3(256), 0, s->stream, s->ptiles,
-		                   s->n_ptiles, s->tile_flag, g);
+	if (s->n_ptiles_all) {
+		hipLaunchKernelGGL(k_dilate, dim3((s->n_ptiles_all * 27 + 255) / 256), dim3(256), 0, s->stream, s->ptiles_all,
+		                   s->n_ptiles_all, s->tile_flag, g);
 		LFA_LAUNCH_CHECK(s);
 	}
-	LFA_TRY(lfa_exclusive_scan_u32(s, s->tile_flag, s->tile_scan, (size_t)nt, (uint32_t *)s->pcg_state + 9));
-	hipLaunchKernelGGL(k_compact_tiles, dim3((nt + 255) / 256), dim3(256), 0, s->stream, s->tile_flag, s->tile_scan,
-	                   s->dtiles, (int *)nullptr, nt);
-	LFA_LAUNCH_CHECK(s);
-	LFA_HIP(s, hipMemcpyAsync(s->h_pinned, (uint32_t *)s->pcg_state + 9, 4, hipMemcpyDeviceToHost, s->stream));
+	if (s->dist) {
+		if (own_lo > 0) LFA_HIP(s, hipMemsetAsync(s->tile_flag, 0, (size_t)own_lo * 4, s->stream));
+		if (own_hi < nt) LFA_HIP(s, hipMemsetAsync(s->tile_flag + own_hi, 0, (size_t)(nt - own_hi) * 4, s->stream));
+		LFA_TRY(lfa_dist_exchange_tile_layers_u32(s, s->tile_flag));
+	}
+	LFA_TRY(compact_tiles(s, s->tile_flag, own_lo, own_hi, s->dtiles, nullptr, &s->n_dtiles));
+	if (s->dist) LFA_TRY(lfa_dist_build_halo_lists(s));
+
 	if (n) {
 		hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, src, dst,
 		                   s->rank, s->tile_start, s->tile_count, s->binned ? 0 : 1);
 		LFA_LAUNCH_CHECK(s);
 		s->cur ^= 1;
 	}
-	LFA_HIP(s, hipStreamSynchronize(s->stream));
-	s->n_dtiles = (int)s->h_pinned[0];
 	if (s->n_dtiles) {
 		int grid = s->n_dtiles < 8192 ? s->n_dtiles : 8192;
 		hipLaunchKernelGGL(k_cell_count, dim3(grid), dim3(256), 0, s->stream, s->dtiles, s->n_dtiles,
@@ -771,6 +858,20 @@ extern "C" int lfa_hash_particles(lfa_sim *s) {
 	s->binned = true;
 	s->system_valid = false;
 	s->unknown_count_valid = false;
+	return LFA_OK;
+}
+
+/// Processed tiles of the four boundary layers: [own first | own last | ghost below | ghost above].
+int lfa_dist_build_halo_lists(lfa_sim *s) {
+	const int L = s->g.ntx * s->g.nty;
+	const int lo[4] = {s->slab_lo * L, (s->slab_hi - 1) * L, (s->slab_lo - 1) * L, s->slab_hi * L};
+	const bool on[4] = {lfa_has_lo(s), lfa_has_hi(s), lfa_has_lo(s), lfa_has_hi(s)};
+	int off = 0;
+	for (int w = 0; w < 4; ++w) {
+		s->n_halo[w] = 0;
+		if (on[w]) LFA_TRY(compact_tiles(s, s->tile_flag, lo[w], lo[w] + L, s->halo_tiles + off, nullptr, &s->n_halo[w]));
+		off += s->n_halo[w];
+	}
 	return LFA_OK;
 }
 
@@ -873,11 +974,11 @@ extern "C" int lfa_cfl(lfa_sim *s, double *out) {
 	if (!s || !out) return LFA_E_INVALID;
 	LFA_HIP(s, hipSetDevice(s->device));
 	double m = 0.0;
-	if (s->np) {
-		int grid = (int)((s->np + 255) / 256);
+	if (s->np_live) {
+		int grid = (int)((s->np_live + 255) / 256);
 		if (grid > 1024) grid = 1024;
 		const ParticleSoA &p = s->pb[s->cur];
-		hipLaunchKernelGGL(k_max_speed2, dim3(grid), dim3(256), 0, s->stream, s->np, p.v[0], p.v[1], p.v[2], s->partials);
+		hipLaunchKernelGGL(k_max_speed2, dim3(grid), dim3(256), 0, s->stream, s->np_live, p.v[0], p.v[1], p.v[2], s->partials);
 		LFA_LAUNCH_CHECK(s);
 		std::vector<double> h(grid);
 		LFA_HIP(s, hipMemcpyAsync(h.data(), s->partials, grid * 8, hipMemcpyDeviceToHost, s->stream));

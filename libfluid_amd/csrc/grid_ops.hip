@@ -339,12 +339,34 @@ k_g2p(const int *ptiles, int n_ptiles, GridDims g, ParticleSoA p, const uint32_t
 }  // namespace
 
 static int grid_blocks(int n) { return n < 16384 ? (n > 0 ? n : 1) : 16384; }
+
+/// Refreshes the ghost tile layers of the grid fields from the neighbour ranks (no-op without a decomposition).
+/// with_topology: also cell types and particle counts (they change once per step, in the P2G).
+int lfa_dist_refresh_grid(lfa_sim *s, bool with_topology) {
+	if (!s->dist) return LFA_OK;
+	void *f[9];
+	int e[9], n = 0;
+	f[n] = s->u; e[n++] = 4;
+	f[n] = s->v; e[n++] = 4;
+	f[n] = s->w; e[n++] = 4;
+	if (with_topology) {
+		f[n] = s->ctype; e[n++] = 1;
+		f[n] = s->cell_count; e[n++] = 4;
+		if (s->prm.simulation_method == LFA_FLIP_BLEND && s->uo) {
+			f[n] = s->uo; e[n++] = 4;
+			f[n] = s->vo; e[n++] = 4;
+			f[n] = s->wo; e[n++] = 4;
+		}
+	}
+	return lfa_dist_exchange_fields(s, n, f, e);
+}
 static GridView make_view(lfa_sim *s) { return GridView{s->g, s->ctype, s->solid, s->cell_count, s->tile_flag}; }
 
 /// a8-a11: unknown set, A bits and divergence; r = b, p = 0. The MIC(0) factor is built by pcg.hip.
 int lfa_build_rhs(lfa_sim *s, double dt) {
 	if (!s->binned) return lfa_fail(s, LFA_E_INVALID, "lfa_build_system: call lfa_hash_particles first");
 	LFA_TRY(lfa_pcg_alloc(s));
+	LFA_TRY(lfa_dist_refresh_grid(s, true));  // types / counts / velocities of the neighbour slab's adjacent tile layer
 	s->a_scale = dt / (s->prm.density * s->prm.cell_size * s->prm.cell_size);  // src/pressure_solver.cpp:22
 	s->sys_dt = dt;
 	if (!s->n_ptiles) return LFA_OK;
@@ -368,6 +390,8 @@ extern "C" int lfa_apply_pressure(lfa_sim *s, double dt) {
 	if (!s) return LFA_E_INVALID;
 	if (!s->binned || !s->vp) return lfa_fail(s, LFA_E_INVALID, "lfa_apply_pressure: no pressure on the device");
 	LFA_HIP(s, hipSetDevice(s->device));
+	// the +z face of the top owned cell needs the pressure of the cell above it (owned by the upper neighbour)
+	if (s->dist) LFA_TRY(lfa_dist_exchange_slices(s, s->vp, s->prm.pcg_dtype == LFA_PCG_F64 ? 8 : 4));
 	if (!s->n_dtiles) return LFA_OK;
 	const float coeff = (float)(dt / (s->prm.density * s->prm.cell_size));  // src/pressure_solver.cpp:74
 	GridView gv = make_view(s);
@@ -387,7 +411,10 @@ extern "C" int lfa_extrapolate(lfa_sim *s) {
 	if (!s->binned) return lfa_fail(s, LFA_E_INVALID, "lfa_extrapolate: call lfa_hash_particles first");
 	LFA_HIP(s, hipSetDevice(s->device));
 	const int iters = (int)s->prm.velocity_extrapolation_iterations;
-	if (!s->n_dtiles || iters == 0) return LFA_OK;
+	if (s->dist && iters > 1) return lfa_fail(s, LFA_E_UNSUPPORTED, "more than one extrapolation sweep with slabs");
+	if (iters == 0) return LFA_OK;
+	LFA_TRY(lfa_dist_refresh_grid(s, false));  // post-projection velocities of the neighbour's adjacent layer
+	if (!s->n_dtiles) return LFA_OK;
 	GridView gv = make_view(s);
 	dim3 grid(grid_blocks(s->n_dtiles));
 	if (iters == 1) {
@@ -413,6 +440,7 @@ extern "C" int lfa_g2p(lfa_sim *s) {
 	if (!s) return LFA_E_INVALID;
 	if (!s->binned) return lfa_fail(s, LFA_E_INVALID, "lfa_g2p: call lfa_hash_particles first");
 	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_dist_refresh_grid(s, false));  // extrapolated velocities of the neighbour's adjacent layer
 	if (!s->n_ptiles) return LFA_OK;
 	G2PParams gp;
 	gp.method = s->prm.simulation_method;

@@ -293,10 +293,10 @@ int lfa_p2g_run(lfa_sim *s, bool fuse_gravity, double dt) {
 	const bool binned = s->prm.p2g_variant == LFA_P2G_LDS_BINNED;
 	if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[16], s->stream));
 	if (binned) {
-		if ((size_t)s->n_ptiles > s->stage_tiles) {
+		if ((size_t)s->n_ptiles_all > s->stage_tiles) {
 			if (s->stage) LFA_HIP(s, hipFree(s->stage));
 			s->stage = nullptr;
-			size_t want = (size_t)s->n_ptiles + (size_t)s->n_ptiles / 4 + 16;
+			size_t want = (size_t)s->n_ptiles_all + (size_t)s->n_ptiles_all / 4 + 16;
 			hipError_t e = hipMalloc(&s->stage, want * 6 * LFA_HALO_CELLS * 4);
 			if (e != hipSuccess) return lfa_fail(s, LFA_E_OOM, "hipMalloc of the P2G staging slabs (%zu tiles) failed", want);
 			s->stage_tiles = want;
@@ -305,13 +305,16 @@ int lfa_p2g_run(lfa_sim *s, bool fuse_gravity, double dt) {
 			dim3 grid(grid_blocks(s->n_ptiles));
 			if (apic)
 				hipLaunchKernelGGL(k_p2g_binned<true>, grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, p,
-				                   s->tile_start, s->stage, hworld);
+				                   s->tile_start, s->stage + (size_t)s->p_off * 6 * LFA_HALO_CELLS, hworld);
 			else
 				hipLaunchKernelGGL(k_p2g_binned<false>, grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, p,
-				                   s->tile_start, s->stage, hworld);
+				                   s->tile_start, s->stage + (size_t)s->p_off * 6 * LFA_HALO_CELLS, hworld);
 			LFA_LAUNCH_CHECK(s);
 		}
+		// particles within one cell of a slab face also contribute to the neighbour rank's faces
+		LFA_TRY(lfa_dist_exchange_p2g_planes(s, s->stage));
 	} else {
+		if (s->dist) return lfa_fail(s, LFA_E_UNSUPPORTED, "the global-atomic P2G variant is single-GPU only");
 		if (!s->acc) {
 			hipError_t e = hipMalloc(&s->acc, s->ncp * 6 * 4);
 			if (e != hipSuccess) return lfa_fail(s, LFA_E_OOM, "hipMalloc of the atomic P2G accumulators failed");
@@ -321,13 +324,13 @@ int lfa_p2g_run(lfa_sim *s, bool fuse_gravity, double dt) {
 			                   s->ncp);
 			LFA_LAUNCH_CHECK(s);
 		}
-		if (s->np) {
-			dim3 grid((unsigned)((s->np + 255) / 256));
+		if (s->np_live) {
+			dim3 grid((unsigned)((s->np_live + 255) / 256));
 			if (apic)
-				hipLaunchKernelGGL(k_p2g_atomic<true>, grid, dim3(256), 0, s->stream, s->np, p, s->acc, s->ncp, s->g,
+				hipLaunchKernelGGL(k_p2g_atomic<true>, grid, dim3(256), 0, s->stream, s->np_live, p, s->acc, s->ncp, s->g,
 				                   hworld);
 			else
-				hipLaunchKernelGGL(k_p2g_atomic<false>, grid, dim3(256), 0, s->stream, s->np, p, s->acc, s->ncp, s->g,
+				hipLaunchKernelGGL(k_p2g_atomic<false>, grid, dim3(256), 0, s->stream, s->np_live, p, s->acc, s->ncp, s->g,
 				                   hworld);
 			LFA_LAUNCH_CHECK(s);
 		}
@@ -383,21 +386,22 @@ int lfa_p2g_bench(lfa_sim *s, int which) {
 	const float hworld = (float)s->prm.cell_size;
 	if (which == LFA_K_P2G_SCATTER) {
 		if (s->prm.p2g_variant == LFA_P2G_LDS_BINNED) {
-			if (!s->stage || (size_t)s->n_ptiles > s->stage_tiles) return lfa_fail(s, LFA_E_INVALID, "no staging slabs");
+			if (!s->stage || (size_t)s->n_ptiles_all > s->stage_tiles) return lfa_fail(s, LFA_E_INVALID, "no staging slabs");
 			dim3 grid(grid_blocks(s->n_ptiles));
+			float *own = s->stage + (size_t)s->p_off * 6 * LFA_HALO_CELLS;
 			if (apic)
 				hipLaunchKernelGGL(k_p2g_binned<true>, grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, p,
-				                   s->tile_start, s->stage, hworld);
+				                   s->tile_start, own, hworld);
 			else
 				hipLaunchKernelGGL(k_p2g_binned<false>, grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, p,
-				                   s->tile_start, s->stage, hworld);
+				                   s->tile_start, own, hworld);
 		} else {
 			if (!s->acc) return lfa_fail(s, LFA_E_INVALID, "no accumulators");
-			dim3 grid((unsigned)((s->np + 255) / 256));
+			dim3 grid((unsigned)((s->np_live + 255) / 256));
 			if (apic)
-				hipLaunchKernelGGL(k_p2g_atomic<true>, grid, dim3(256), 0, s->stream, s->np, p, s->acc, s->ncp, s->g, hworld);
+				hipLaunchKernelGGL(k_p2g_atomic<true>, grid, dim3(256), 0, s->stream, s->np_live, p, s->acc, s->ncp, s->g, hworld);
 			else
-				hipLaunchKernelGGL(k_p2g_atomic<false>, grid, dim3(256), 0, s->stream, s->np, p, s->acc, s->ncp, s->g, hworld);
+				hipLaunchKernelGGL(k_p2g_atomic<false>, grid, dim3(256), 0, s->stream, s->np_live, p, s->acc, s->ncp, s->g, hworld);
 		}
 		LFA_LAUNCH_CHECK(s);
 		return LFA_OK;

@@ -16,3 +16,4 @@ static inline int pcg_grid(int n_ptiles) {
 
 int lfa_build_rhs(lfa_sim *s, double dt);
 int lfa_p2g_run(lfa_sim *s, bool fuse_gravity, double dt);
+int lfa_dist_refresh_grid(lfa_sim *s, bool with_topology);

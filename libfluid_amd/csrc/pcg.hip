@@ -963,8 +963,9 @@ template <typename real> static int coarse_setup(lfa_sim *s) {
 				if (hw[d][i] == 0.0f) continue;
 				const int xx = x + (d == 0), yy = y + (d == 1), zz = z + (d == 2);
 				if (!in_grid(g1, xx, yy, zz)) continue;
-				const int k2 = l1l2[blocked_index(g1, xx, yy, zz) >> 9];
-				if (k2 < 0) continue;
+				const uint32_t j = blocked_index(g1, xx, yy, zz);
+				const int k2 = l1l2[j >> 9];
+				if (k2 < 0 || !hu[j]) continue;  // coupling to a tile of another rank's slab: not in this coarse space
 				a2[(size_t)k * n2 + k2] -= s->a_scale * hw[d][i];
 				a2[(size_t)k2 * n2 + k] -= s->a_scale * hw[d][i];
 			}
@@ -1100,34 +1101,50 @@ extern "C" int lfa_build_system(lfa_sim *s, double dt) {
 }
 
 template <typename real> static int solve_t(lfa_sim *s, double dt, double *residual, uint64_t *iterations) {
+	if (s->dist && s->prm.precond == LFA_PRECOND_MIC0_EXACT)
+		return lfa_fail(s, LFA_E_UNSUPPORTED, "the exact (hyperplane) MIC(0) schedule is single-GPU only");
 	LFA_TRY(build_system_t<real>(s, dt));
 	if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[18], s->stream));
 	s->last_residual = 0.0;
 	s->last_iters = 0;
 	if (residual) *residual = 0.0;
 	if (iterations) *iterations = 0;
-	if (!s->n_ptiles) return LFA_OK;
+	if (!s->n_ptiles && !s->dist) return LFA_OK;
 	TileCtx tc = make_ctx(s);
 	Vecs<real> v = make_vecs<real>(s);
 	const int G = pcg_grid(s->n_ptiles);
 	const real scale = (real)s->a_scale;
 	double *P = s->partials;
+	const bool dist = s->dist != nullptr;
 	// early out: sum b^2 < 1e-6 (src/pressure_solver.cpp:29-35)
-	std::vector<double> hb(G);
-	LFA_HIP(s, hipMemcpyAsync(hb.data(), P + PART_B2, (size_t)G * 8, hipMemcpyDeviceToHost, s->stream));
-	LFA_HIP(s, hipStreamSynchronize(s->stream));
 	double tot = 0.0;
-	for (double x : hb) tot += x;
+	if (dist) {
+		if (!s->n_ptiles) LFA_HIP(s, hipMemsetAsync(P + PART_B2, 0, 8, s->stream));
+		LFA_TRY(lfa_dist_allreduce(s, P + PART_B2, G, 0, false));
+		LFA_HIP(s, hipMemcpyAsync(&tot, s->dist_red, 8, hipMemcpyDeviceToHost, s->stream));
+		LFA_HIP(s, hipStreamSynchronize(s->stream));
+	} else {
+		std::vector<double> hb(G);
+		LFA_HIP(s, hipMemcpyAsync(hb.data(), P + PART_B2, (size_t)G * 8, hipMemcpyDeviceToHost, s->stream));
+		LFA_HIP(s, hipStreamSynchronize(s->stream));
+		for (double x : hb) tot += x;
+	}
 	if (tot != tot) return lfa_fail(s, LFA_E_NAN, "NaN in the divergence right-hand side");
 	if (tot < 1e-6) return LFA_OK;
 
 	int init_state[2] = {-1, 0};
 	LFA_HIP(s, hipMemcpyAsync(s->pcg_state, init_state, 8, hipMemcpyHostToDevice, s->stream));
+	const int NS = sigma_parts(s);
+	// where the consumers find a reduced scalar: the per-workgroup partials (they re-add them in a fixed order), or -
+	// with slabs - the all-reduced value
+	double *red = s->dist_red;
+	auto sig_src = [&](int parity) { return dist ? red + 3 + parity : P + (parity ? PART_SIG1 : PART_SIG0); };
+	const int n_sig = dist ? 1 : NS, n_zs = dist ? 1 : G, n_max = dist ? 1 : G;
+	const real *cx = is_ml(s) ? (const real *)s->c_x : (const real *)nullptr;
 	// z = M^-1 r ; s = z ; sigma = z.r
 	LFA_TRY(mic_apply<real>(s, P + PART_SIG0));
-	const int NS = sigma_parts(s);
-	const real *cx = is_ml(s) ? (const real *)s->c_x : (const real *)nullptr;
-	hipLaunchKernelGGL(k_update_s<real>, dim3(G), dim3(256), 0, s->stream, tc, v, P + PART_SIG0, P + PART_SIG0, NS, 1,
+	if (dist) LFA_TRY(lfa_dist_allreduce(s, P + PART_SIG0, NS, 3, false));
+	hipLaunchKernelGGL(k_update_s<real>, dim3(G), dim3(256), 0, s->stream, tc, v, sig_src(0), sig_src(0), n_sig, 1,
 	                   s->pcg_state, s->abits, cx, (const int *)s->slot_l1);
 	LFA_LAUNCH_CHECK(s);
 	const int maxit = (int)s->prm.max_iterations;
@@ -1137,17 +1154,24 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 	while (i < maxit && done < 0) {
 		const int end = std::min(maxit, i + chunk);
 		for (; i < end; ++i) {
-			double *sig_old = P + ((i & 1) ? PART_SIG1 : PART_SIG0), *sig_new = P + ((i & 1) ? PART_SIG0 : PART_SIG1);
+			const int po = i & 1, pn = po ^ 1;
+			double *sig_new_part = P + (pn ? PART_SIG1 : PART_SIG0);
+			if (dist) LFA_TRY(lfa_dist_exchange_slices(s, v.s, (int)sizeof(real)));  // search vector across the slab faces
 			hipLaunchKernelGGL(k_spmv<real>, dim3(G), dim3(256), 0, s->stream, tc, s->abits, (const real *)v.s, v.z, scale,
 			                   P + PART_ZS, s->pcg_state);
-			hipLaunchKernelGGL(k_axpy_max<real>, dim3(G), dim3(256), 0, s->stream, tc, s->abits, v, sig_old, NS, P + PART_ZS, G,
-			                   P + PART_RMAX, s->pcg_state, is_ml(s) ? (real *)s->c_r : (real *)nullptr,
-			                   (const int *)s->slot_l1);
-			hipLaunchKernelGGL(k_check_converged, dim3(1), dim3(256), 0, s->stream, P + PART_RMAX, G, s->prm.tolerance, i,
-			                   s->pcg_state, s->pcg_hist);
 			LFA_LAUNCH_CHECK(s);
-			LFA_TRY(mic_apply<real>(s, sig_new, true));
-			hipLaunchKernelGGL(k_update_s<real>, dim3(G), dim3(256), 0, s->stream, tc, v, sig_new, sig_old, NS, 0,
+			if (dist) LFA_TRY(lfa_dist_allreduce(s, P + PART_ZS, G, 1, false));
+			hipLaunchKernelGGL(k_axpy_max<real>, dim3(G), dim3(256), 0, s->stream, tc, s->abits, v, sig_src(po), n_sig,
+			                   dist ? red + 1 : P + PART_ZS, n_zs, P + PART_RMAX, s->pcg_state,
+			                   is_ml(s) ? (real *)s->c_r : (real *)nullptr, (const int *)s->slot_l1);
+			LFA_LAUNCH_CHECK(s);
+			if (dist) LFA_TRY(lfa_dist_allreduce(s, P + PART_RMAX, G, 2, true));
+			hipLaunchKernelGGL(k_check_converged, dim3(1), dim3(256), 0, s->stream, dist ? red + 2 : P + PART_RMAX, n_max,
+			                   s->prm.tolerance, i, s->pcg_state, s->pcg_hist);
+			LFA_LAUNCH_CHECK(s);
+			LFA_TRY(mic_apply<real>(s, sig_new_part, true));
+			if (dist) LFA_TRY(lfa_dist_allreduce(s, sig_new_part, NS, 3 + pn, false));
+			hipLaunchKernelGGL(k_update_s<real>, dim3(G), dim3(256), 0, s->stream, tc, v, sig_src(pn), sig_src(po), n_sig, 0,
 			                   s->pcg_state, s->abits, cx, (const int *)s->slot_l1);
 			LFA_LAUNCH_CHECK(s);
 		}
@@ -1257,6 +1281,7 @@ template <typename real> static int apply_a_t(lfa_sim *s, const double *vin, dou
 	LFA_TRY(scatter<real>(s, (real *)s->vs, vin, n));
 	int init_state[2] = {-1, 0};
 	LFA_HIP(s, hipMemcpyAsync(s->pcg_state, init_state, 8, hipMemcpyHostToDevice, s->stream));
+	if (s->dist) LFA_TRY(lfa_dist_exchange_slices(s, s->vs, (int)sizeof(real)));
 	if (s->n_ptiles) {
 		TileCtx tc = make_ctx(s);
 		hipLaunchKernelGGL(k_spmv<real>, dim3(pcg_grid(s->n_ptiles)), dim3(256), 0, s->stream, tc, s->abits,
