@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--replicas", action="store_true", help="N > 1: independent copies of the domain instead of z-slabs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -86,16 +87,33 @@ def main():
         torch.cuda.set_device(local_rank)
 
     cfg_name = args.config or "C4"
-    cfg = scenes.CONFIGS[cfg_name]
-    sim = lfa.Sim(cfg["size"], method=cfg["method"], blending=cfg["blending"], device=local_rank,
+    cfg = dict(scenes.CONFIGS[cfg_name])
+    size, (blo, bhi) = list(cfg["size"]), [list(x) for x in cfg["block"]]
+    parallelism = "1 GPU"
+    if world > 1 and not args.replicas:
+        # weak scaling: the domain and the dam-break block grow along z with the number of GPUs, every rank owns a slab
+        # as large as the single-GPU workload (BASELINE configs[3]/[4] decompose along z the same way)
+        size[2] *= world
+        bhi[2] *= world
+    sim = lfa.Sim(size, method=cfg["method"], blending=cfg["blending"], device=local_rank,
                   precond={"exact": lfa.PRECOND_MIC0_EXACT, "tiled": lfa.PRECOND_MIC0_TILED,
                            "multilevel": lfa.PRECOND_MULTILEVEL}[args.precond],
                   pcg_dtype=lfa.PCG_F64 if args.pcg_dtype == "f64" else lfa.PCG_F32,
                   p2g_variant=lfa.P2G_GLOBAL_ATOMIC if args.p2g == "atomic" else lfa.P2G_LDS_BINNED,
                   max_iterations=args.max_iterations)
-    # z-slab domain decomposition is not built yet: at N > 1 every rank owns an independent copy of the domain
-    # (weak scaling over replicas, no data-path collective); see DESIGN.md section "multi-GPU".
-    sim.seed_block(*cfg["block"])
+    if world > 1 and not args.replicas:
+        # one RCCL communicator per handle: rank 0 creates the id, torch.distributed (RCCL) broadcasts it
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(lfa.rccl_unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, src=0)
+        ntz = (size[2] + 7) // 8
+        bounds = lfa.balanced_layer_bounds(ntz, world, blo[2] // 8, (bhi[2] + 7) // 8)
+        sim.init_rccl_slab(rank, world, uid.cpu().numpy().tobytes(), bounds)
+        parallelism = f"{world} z-slabs (tile layers {bounds}), RCCL send/recv halos + scalar all-reduces over xGMI"
+    elif world > 1:
+        parallelism = f"{world} independent replicas (--replicas)"
+    sim.seed_block(blo, bhi)
     sim.enable_timing(True)
 
     def barrier():
@@ -126,7 +144,12 @@ def main():
     counts = sim.counts()
     npart, n_unknowns = counts["particles"], counts["unknowns"]
     ncell_proc = counts["processed_tiles"] * 512
-    value = npart * world * args.steps / elapsed
+    npart_total = npart
+    if dist is not None:
+        t = torch.tensor([float(npart)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        npart_total = int(t.item())
+    value = npart_total * args.steps / elapsed
     stage_ms = {k: v / args.steps for k, v in stage_ms.items()}
     pcg_s = stage_ms["pcg_loop"] * 1e-3 * args.steps
 
@@ -136,15 +159,15 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.pcg_dtype == "f32" else "f32 particles/grid, f64 PCG vectors", "data": "synthetic",
         "config": {
-            "workload": f"{cfg_name}: {cfg['size'][0]}x{cfg['size'][1]}x{cfg['size'][2]} MAC grid, dam-break block "
-                        f"{cfg['block'][0]}-{cfg['block'][1]} cells, {npart} particles/GPU, "
+            "workload": f"{cfg_name}: {size[0]}x{size[1]}x{size[2]} MAC grid, dam-break block "
+                        f"{tuple(blo)}-{tuple(bhi)} cells, {npart_total} particles, "
                         f"{['PIC', 'FLIP', 'APIC'][cfg['method']]} blend {cfg['blending']}, dt {args.dt}, "
                         f"hot path only (bin+P2G+gravity+PCG+apply+extrapolate+G2P)",
             "unknowns": n_unknowns, "particles_per_gpu": npart,
             "precond": {"tiled": "MIC(0) per 8^3 tile", "exact": "MIC(0) exact (tile hyperplanes)",
                         "multilevel": "MIC(0) per 8^3 tile + tile-aggregate coarse correction"}[args.precond],
             "p2g": args.p2g, "pcg_tolerance": 1e-6, "pcg_max_iterations": args.max_iterations,
-            "parallelism": "1 GPU" if world == 1 else f"{world} independent replicas (z-slab decomposition pending)",
+            "parallelism": parallelism,
         },
         "pcg": {
             "iterations_per_step": iters_total / max(args.steps, 1),
@@ -155,7 +178,7 @@ def main():
         "stage_ms": stage_ms,
     }
 
-    if rank == 0 and not args.no_kernel_timing:
+    if rank == 0 and world == 1 and not args.no_kernel_timing:
         # live HIP-event timing of each hot kernel on the handle's stream (mean of 20 launches)
         apic = cfg["method"] == 2
         kernels = {}
@@ -168,7 +191,7 @@ def main():
             (24 if cfg["method"] == 1 else 12) * ncell_proc
         # P2G = 60 Np + 14 Nc with Nc = ALL cells (the reference writes every cell, src/simulation.cpp:
         # 296-335); cells outside the processed tiles are implicit here (background value), a legitimate saving
-        ncell_all = cfg["size"][0] * cfg["size"][1] * cfg["size"][2]
+        ncell_all = cfg["size"][0] * cfg["size"][1] * cfg["size"][2]  # per GPU
         fin_bytes = (26 if cfg["method"] == 1 else 14) * ncell_all
         for name, b in (("g2p", g2p_bytes), ("p2g_finalize", fin_bytes), ("p2g_scatter", p2g_bytes)):
             ms = sim.bench_kernel(name, 10)

@@ -877,12 +877,13 @@ int lfa_dist_build_halo_lists(lfa_sim *s) {
 
 // ---- fluid-cell list at the boundary (reference order = ascending raw index)
 __global__ void k_raw_unknown_flags(GridDims g, size_t nc, const uint32_t *cell_count, const uint32_t *tile_flag,
-                                    uint32_t *flag) {
+                                    uint32_t *flag, int z0, int z1) {
 	size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= nc) return;
 	int x = (int)(r % g.nx), y = (int)((r / g.nx) % g.ny), z = (int)(r / ((size_t)g.nx * g.ny));
 	uint32_t b = blocked_index(g, x, y, z);
-	flag[r] = (tile_flag[b >> 9] && cell_count[b] > 0) ? 1u : 0u;
+	// with slabs only the owned cell layers [z0, z1) are numbered (ghost layers belong to the neighbours)
+	flag[r] = (z >= z0 && z < z1 && tile_flag[b >> 9] && cell_count[b] > 0) ? 1u : 0u;
 }
 
 /// Numbers the unknowns in the reference's order; raw_scan[r] = unknown index of raw cell r (valid where flagged).
@@ -891,7 +892,7 @@ int lfa_number_unknowns(lfa_sim *s) {
 	if (!s->binned) return lfa_fail(s, LFA_E_INVALID, "call lfa_hash_particles first");
 	if (!s->raw_scan) LFA_HIP(s, hipMalloc(&s->raw_scan, (s->nc + 1) * 4));
 	hipLaunchKernelGGL(k_raw_unknown_flags, dim3((unsigned)((s->nc + 255) / 256)), dim3(256), 0, s->stream, s->g, s->nc,
-	                   s->cell_count, s->tile_flag, s->raw_scan);
+	                   s->cell_count, s->tile_flag, s->raw_scan, s->slab_lo * 8, s->slab_hi * 8);
 	LFA_LAUNCH_CHECK(s);
 	LFA_TRY(lfa_exclusive_scan_u32(s, s->raw_scan, s->raw_scan, s->nc, (uint32_t *)s->pcg_state + 10));
 	LFA_HIP(s, hipMemcpyAsync(s->h_pinned, (uint32_t *)s->pcg_state + 10, 4, hipMemcpyDeviceToHost, s->stream));
@@ -907,12 +908,12 @@ extern "C" uint64_t lfa_num_fluid_cells(lfa_sim *s) {
 }
 
 __global__ void k_export_fluid_cells(GridDims g, size_t nc, const uint32_t *cell_count, const uint32_t *tile_flag,
-                                     const uint32_t *raw_scan, uint64_t *out) {
+                                     const uint32_t *raw_scan, uint64_t *out, int z0, int z1) {
 	size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= nc) return;
 	int x = (int)(r % g.nx), y = (int)((r / g.nx) % g.ny), z = (int)(r / ((size_t)g.nx * g.ny));
 	uint32_t b = blocked_index(g, x, y, z);
-	if (tile_flag[b >> 9] && cell_count[b] > 0) out[raw_scan[r]] = r;
+	if (z >= z0 && z < z1 && tile_flag[b >> 9] && cell_count[b] > 0) out[raw_scan[r]] = r;
 }
 
 extern "C" int lfa_download_fluid_cells(lfa_sim *s, uint64_t *raw, uint64_t n) {
@@ -923,7 +924,7 @@ extern "C" int lfa_download_fluid_cells(lfa_sim *s, uint64_t *raw, uint64_t n) {
 	if (n == 0) return LFA_OK;
 	LFA_TRY(lfa_ensure_io(s, n * 8));
 	hipLaunchKernelGGL(k_export_fluid_cells, dim3((unsigned)((s->nc + 255) / 256)), dim3(256), 0, s->stream, s->g, s->nc,
-	                   s->cell_count, s->tile_flag, s->raw_scan, (uint64_t *)s->io_buf);
+	                   s->cell_count, s->tile_flag, s->raw_scan, (uint64_t *)s->io_buf, s->slab_lo * 8, s->slab_hi * 8);
 	LFA_LAUNCH_CHECK(s);
 	LFA_HIP(s, hipMemcpyAsync(raw, s->io_buf, n * 8, hipMemcpyDeviceToHost, s->stream));
 	LFA_HIP(s, hipStreamSynchronize(s->stream));

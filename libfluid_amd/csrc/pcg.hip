@@ -762,12 +762,12 @@ k_add_coarse(TileCtx tc, const uint8_t *abits, real *z, const real *coarse_x, co
 // ---- boundary helpers: vectors in the reference's unknown order <-> tile-major fields
 template <typename T, typename U>
 __global__ void k_gather_unknowns(GridDims g, size_t nc, const uint32_t *cell_count, const uint32_t *tile_flag,
-                                  const uint32_t *raw_scan, const T *field, U *out, int mask) {
+                                  const uint32_t *raw_scan, const T *field, U *out, int mask, int z0, int z1) {
 	size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= nc) return;
 	int x = (int)(r % g.nx), y = (int)((r / g.nx) % g.ny), z = (int)(r / ((size_t)g.nx * g.ny));
 	uint32_t b = blocked_index(g, x, y, z);
-	if (tile_flag[b >> 9] && cell_count[b] > 0) {
+	if (z >= z0 && z < z1 && tile_flag[b >> 9] && cell_count[b] > 0) {
 		T val = field[b];
 		if (mask) val = (T)((int)val & mask);
 		out[raw_scan[r]] = (U)val;
@@ -775,12 +775,12 @@ __global__ void k_gather_unknowns(GridDims g, size_t nc, const uint32_t *cell_co
 }
 template <typename T>
 __global__ void k_scatter_unknowns(GridDims g, size_t nc, const uint32_t *cell_count, const uint32_t *tile_flag,
-                                   const uint32_t *raw_scan, T *field, const double *in) {
+                                   const uint32_t *raw_scan, T *field, const double *in, int z0, int z1) {
 	size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= nc) return;
 	int x = (int)(r % g.nx), y = (int)((r / g.nx) % g.ny), z = (int)(r / ((size_t)g.nx * g.ny));
 	uint32_t b = blocked_index(g, x, y, z);
-	if (tile_flag[b >> 9] && cell_count[b] > 0) field[b] = (T)in[raw_scan[r]];
+	if (z >= z0 && z < z1 && tile_flag[b >> 9] && cell_count[b] > 0) field[b] = (T)in[raw_scan[r]];
 }
 __global__ void k_zero_tiles(const int *ptiles, int n_ptiles, void *field, int elem) {
 	const int slot = blockIdx.x;
@@ -1210,7 +1210,7 @@ template <typename T, typename U> static int gather(lfa_sim *s, const T *field, 
 	if (!n) return LFA_OK;
 	LFA_TRY(lfa_ensure_io(s, n * sizeof(U)));
 	hipLaunchKernelGGL((k_gather_unknowns<T, U>), dim3((unsigned)((s->nc + 255) / 256)), dim3(256), 0, s->stream, s->g,
-	                   s->nc, s->cell_count, s->tile_flag, s->raw_scan, field, (U *)s->io_buf, mask);
+	                   s->nc, s->cell_count, s->tile_flag, s->raw_scan, field, (U *)s->io_buf, mask, s->slab_lo * 8, s->slab_hi * 8);
 	LFA_LAUNCH_CHECK(s);
 	LFA_HIP(s, hipMemcpyAsync(host_out, s->io_buf, n * sizeof(U), hipMemcpyDeviceToHost, s->stream));
 	LFA_HIP(s, hipStreamSynchronize(s->stream));
@@ -1225,7 +1225,8 @@ template <typename T> static int scatter(lfa_sim *s, T *field, const double *hos
 	hipLaunchKernelGGL(k_zero_tiles, dim3(s->n_ptiles), dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, (void *)field,
 	                   (int)sizeof(T));
 	hipLaunchKernelGGL(k_scatter_unknowns<T>, dim3((unsigned)((s->nc + 255) / 256)), dim3(256), 0, s->stream, s->g, s->nc,
-	                   s->cell_count, s->tile_flag, s->raw_scan, field, (const double *)s->io_buf);
+	                   s->cell_count, s->tile_flag, s->raw_scan, field, (const double *)s->io_buf, s->slab_lo * 8,
+	                   s->slab_hi * 8);
 	LFA_LAUNCH_CHECK(s);
 	LFA_HIP(s, hipStreamSynchronize(s->stream));
 	return LFA_OK;
