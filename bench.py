@@ -183,9 +183,13 @@ def main():
         apic = cfg["method"] == 2
         kernels = {}
         for name in ("spmv_dot", "axpy_max", "mic_apply_dot", "update_s"):
-            ms = sim.bench_kernel(name, 20)
+            # mic_apply_dot = the tile sweep kernel itself; the coarse levels run beside it on the side stream
+            ms = sim.bench_kernel("mic_fine" if name == "mic_apply_dot" else name, 20)
             b = PCG_BYTES[name] * n_unknowns * (2 if args.pcg_dtype == "f64" else 1)
             kernels[name] = {"ms": ms, "algorithmic_bytes": b, "GBps": b / ms * 1e-6}
+        if args.precond == "multilevel":
+            kernels["coarse_levels_side_stream"] = {"ms": sim.bench_kernel("coarse_levels", 20), "algorithmic_bytes": 0,
+                                                    "GBps": 0.0}
         p2g_bytes = (60 if apic else 24) * npart
         g2p_bytes = (60 if apic else (36 if cfg["method"] == 1 else 24)) * npart + \
             (24 if cfg["method"] == 1 else 12) * ncell_proc
@@ -199,11 +203,18 @@ def main():
         out["kernels"] = kernels
         # dominant kernel = largest share of the step: iterations x per-iteration kernel time vs the one-shot kernels
         it_per_step = iters_total / max(args.steps, 1)
-        share = {k: v["ms"] * (it_per_step if k in PCG_BYTES else 1.0) for k, v in kernels.items()}
+        share = {k: v["ms"] * (it_per_step if k in PCG_BYTES else 1.0) for k, v in kernels.items()
+                 if v["algorithmic_bytes"]}
         dom = max(share, key=share.get)
+        # HBM traffic of that kernel from the PMC passes committed under profiles/ (same command, same workload)
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_c4_pmc_traffic.json")
+        if cfg_name == "C4" and args.precond == "multilevel" and args.pcg_dtype == "f32" and os.path.exists(pmc):
+            traffic = json.load(open(pmc))["hbm_bytes_per_launch"].get(dom, {}).get("total")
         out["roofline"] = {
             "bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
+            "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
+            "algorithmic_bytes": kernels[dom]["algorithmic_bytes"], "ms": kernels[dom]["ms"],
             "share_of_step_ms": share[dom],
         }
         pcg_iter_ms = sum(kernels[k]["ms"] for k in PCG_BYTES)

@@ -192,7 +192,9 @@ enum {
 	LFA_K_P2G_SCATTER = 4, /* particles -> per-tile (sum wv, sum w)     algorithmic 60 Np (APIC) / 24 Np bytes */
 	LFA_K_P2G_FINALIZE = 5,/* normalise + type + gravity                algorithmic 14 Nc bytes (+12 Nc FLIP) */
 	LFA_K_G2P = 6,         /* grid -> particles                         algorithmic 60 Np + 12 Nc (APIC) */
-	LFA_K_BIN = 7          /* tile binning (count + scatter)            algorithmic 2*68 Np + 8 Np bytes */
+	LFA_K_BIN = 7,         /* tile binning (count + scatter)            algorithmic 2*68 Np + 8 Np bytes */
+	LFA_K_MIC_FINE = 8,    /* the tile-level sweep kernel of LFA_K_MIC_APPLY alone (k_mic_apply) */
+	LFA_K_COARSE = 9       /* the coarse levels of the multilevel preconditioner alone (side stream in the solve) */
 };
 int lfa_bench_kernel(lfa_sim *s, int which, int reps, double *mean_ms);
 

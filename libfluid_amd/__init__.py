@@ -109,7 +109,7 @@ SIGNATURES = {
     "lfa_dist_get_slab": (_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
 KERNELS = {"spmv_dot": 0, "axpy_max": 1, "mic_apply_dot": 2, "update_s": 3, "p2g_scatter": 4, "p2g_finalize": 5,
-           "g2p": 6, "bin": 7}
+           "g2p": 6, "bin": 7, "mic_fine": 8, "coarse_levels": 9}
 
 
 def load_library():

@@ -1370,6 +1370,13 @@ template <typename real> static int bench_launch(lfa_sim *s, int which) {
 		break;
 	case LFA_K_MIC_APPLY:
 		return mic_apply<real>(s, P + PART_SIG1, true);
+	case LFA_K_MIC_FINE:
+		hipLaunchKernelGGL((k_mic_apply<real, SWEEP_BOTH>), dim3(G), dim3(256), 0, s->stream, tc, (const int *)nullptr,
+		                   s->n_ptiles, s->abits, v, scale, P + PART_SIG1, s->pcg_state, (real *)nullptr, (const int *)nullptr);
+		break;
+	case LFA_K_COARSE:
+		if (!is_ml(s)) return lfa_fail(s, LFA_E_INVALID, "no coarse levels with this preconditioner");
+		return coarse_apply<real>(s, P + PART_SIG1, s->stream);
 	case LFA_K_UPDATE_S:
 		hipLaunchKernelGGL(k_update_s<real>, dim3(G), dim3(256), 0, s->stream, tc, v, P + PART_SIG0, P + PART_SIG0, G, 0,
 		                   s->pcg_state, s->abits, is_ml(s) ? (const real *)s->c_x : (const real *)nullptr,
@@ -1389,13 +1396,14 @@ extern "C" int lfa_bench_kernel(lfa_sim *s, int which, int reps, double *mean_ms
 		for (auto &e : s->ev) LFA_HIP(s, hipEventCreate(&e));
 		s->ev_created = true;
 	}
-	if (which <= LFA_K_UPDATE_S) {
+	const bool is_pcg = which <= LFA_K_UPDATE_S || which == LFA_K_MIC_FINE || which == LFA_K_COARSE;
+	if (is_pcg) {
 		if (!s->system_valid) return lfa_fail(s, LFA_E_INVALID, "lfa_bench_kernel: no pressure system on the device");
 		int init_state[2] = {-1, 0};  // "still iterating": the kernels early-out once a solve has converged
 		LFA_HIP(s, hipMemcpyAsync(s->pcg_state, init_state, 8, hipMemcpyHostToDevice, s->stream));
 	}
 	auto once = [&]() -> int {
-		if (which <= LFA_K_UPDATE_S) return F64(s) ? bench_launch<double>(s, which) : bench_launch<float>(s, which);
+		if (is_pcg) return F64(s) ? bench_launch<double>(s, which) : bench_launch<float>(s, which);
 		if (which == LFA_K_G2P) return lfa_g2p_bench(s);
 		return lfa_p2g_bench(s, which);
 	};
@@ -1407,6 +1415,6 @@ extern "C" int lfa_bench_kernel(lfa_sim *s, int which, int reps, double *mean_ms
 	float ms = 0.f;
 	LFA_HIP(s, hipEventElapsedTime(&ms, s->ev[20], s->ev[21]));
 	*mean_ms = (double)ms / reps;
-	s->system_valid = which <= LFA_K_UPDATE_S ? s->system_valid : false;
+	s->system_valid = is_pcg ? s->system_valid : false;
 	return LFA_OK;
 }
