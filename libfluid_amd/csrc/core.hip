@@ -222,9 +222,9 @@ extern "C" int lfa_create(lfa_sim **out, uint64_t nx, uint64_t ny, uint64_t nz, 
 	chk(dev_alloc(s, &s->solid, s->ncp, true));
 	chk(dev_alloc(s, &s->cell_count, s->ncp, true));
 	chk(dev_alloc(s, &s->abits, s->ncp, true));
-	chk(dev_alloc(s, &s->partials, 6 * 2048, true));
+	chk(dev_alloc(s, &s->partials, 16384, true));  // >= PART_TOTAL (pcg.h)
 	chk(dev_alloc(s, &s->pcg_state, 16, true));
-	chk(dev_alloc(s, &s->pcg_hist, 4096, true));
+	chk(dev_alloc(s, &s->pcg_hist, 8192, true));  // [0,4096) residual history, [6144,..) coarse r2 hand-off
 	if (rc == LFA_OK && hipHostMalloc((void **)&s->h_pinned, 4096, hipHostMallocDefault) != hipSuccess)
 		rc = lfa_fail(s, LFA_E_HIP, "hipHostMalloc failed");
 	if (rc == LFA_OK) {

@@ -4,9 +4,11 @@
 
 // Every reduction of the solve is deterministic: workgroup g writes one partial to partials[PART_x + g], and every
 // consumer workgroup re-adds the <= PCG_MAX_GRID partials in the same fixed order. No atomics, no host round trip.
-#define PCG_MAX_GRID 1024
+#define PCG_MAX_GRID 2048
 #define PCG_WAVES 4          // waves (= tiles in flight) per workgroup
-enum { PART_ZS = 0, PART_RMAX = 2048, PART_SIG0 = 4096, PART_SIG1 = 6144, PART_B2 = 8192 };  // offsets in doubles
+// offsets in doubles; one spare slot after the PCG_MAX_GRID workgroup partials (coarse share of sigma)
+enum { PART_STRIDE = PCG_MAX_GRID + 64, PART_ZS = 0, PART_RMAX = PART_STRIDE, PART_SIG0 = 2 * PART_STRIDE,
+       PART_SIG1 = 3 * PART_STRIDE, PART_B2 = 4 * PART_STRIDE, PART_TOTAL = 5 * PART_STRIDE };
 
 static inline int pcg_grid(int n_ptiles) {
 	int g = (n_ptiles + PCG_WAVES - 1) / PCG_WAVES;

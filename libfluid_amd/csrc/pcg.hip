@@ -91,12 +91,12 @@ __device__ inline double reduce_partials_max(const double *part, int n, double *
 	__syncthreads();
 	return r;
 }
-__device__ inline void block_partial_sum(double acc, double *lds, double *out) {
+__device__ inline void block_partial_sum(double acc, double *lds, double *out, int slot = -1) {
 	acc = wave_sum(acc);
 	__syncthreads();
 	if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
 	__syncthreads();
-	if (threadIdx.x == 0) out[blockIdx.x] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+	if (threadIdx.x == 0) out[slot >= 0 ? slot : (int)blockIdx.x] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
 }
 
 // ================================================================================================= SpMV + dot
@@ -265,28 +265,197 @@ k_mic_factor(TileCtx tc, const int *slots, int n_slots, const uint8_t *abits, re
 	}
 }
 
+// ================================================================================================= coarse block
+template <typename real> struct CoarseFields {
+	const float *diag, *w[3];
+	const uint8_t *unk;
+	real *pre, *r, *x;
+};
+
+
+/// All coarse work of one preconditioner application in ONE workgroup of WAVES waves (at most 64 level-1 blocks):
+/// per level-1 block a wave stages the coefficients in LDS and runs the weighted forward/backward substitution, then
+/// the dense top-level solve, the prolongation of its result onto level 1 and the coarse share of z.r. Latency-bound
+/// by design (44 dependent LDS hyperplanes per block), so everything the sweeps touch sits in LDS.
+/// LDS: WAVES * 3 * 512 * (sizeof(real) + 1) + 144 * 8 bytes.
+template <typename real, int WAVES>
+__device__ inline void coarse_block(char *smem, const int *l1_tiles, int n_l1, CoarseFields<real> c, real scale,
+                                    const real *a2inv, real *x2_out, double *part_sigma_extra, int cb = 0, int ncb = 1,
+                                    double *xchg = nullptr, unsigned *ticket = nullptr) {
+	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
+	// per wave: PRE, Q, PQ (real) + the three face weights as bytes (a face of a tile has at most 64 couplings)
+	real *wbase = (real *)smem + (size_t)wid * 3 * LFA_TILE_CELLS;
+	real *PRE = wbase, *Q = wbase + LFA_TILE_CELLS, *PQ = wbase + 2 * LFA_TILE_CELLS;
+	uint8_t *ub = (uint8_t *)((real *)smem + (size_t)WAVES * 3 * LFA_TILE_CELLS) + (size_t)wid * 3 * LFA_TILE_CELLS;
+	uint8_t *U[3] = {ub, ub + LFA_TILE_CELLS, ub + 2 * LFA_TILE_CELLS};
+	double *r2s = (double *)(smem + (size_t)WAVES * 3 * LFA_TILE_CELLS * (sizeof(real) + 1));
+	double *x2s = r2s + 64;
+	double *red = x2s + 64;
+	// xchg (global, several coarse workgroups): [0,64) r2 per level-1 block, [64, 64+ncb) per-workgroup x1.r1
+	if (ncb > 1) __builtin_amdgcn_s_setprio(3);  // these waves are the critical path of the launch they are embedded in
+	double dot1 = 0.0;
+	for (int k = cb * WAVES + wid; k < n_l1; k += ncb * WAVES) {
+		const size_t base = (size_t)l1_tiles[k] * LFA_TILE_CELLS;
+		double sr = 0.0;
+		real rr[8];
+		WAVE_SYNC();
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) {
+			const int idx = zz * 64 + lane;
+			const bool u = c.unk[base + idx] != 0;
+			U[0][idx] = (uint8_t)c.w[0][base + idx];
+			U[1][idx] = (uint8_t)c.w[1][base + idx];
+			U[2][idx] = (uint8_t)c.w[2][base + idx];
+			PRE[idx] = u ? c.pre[base + idx] : (real)0;
+			rr[zz] = u ? c.r[base + idx] : (real)0;
+			Q[idx] = rr[zz];
+			PQ[idx] = (real)0;
+			sr += (double)rr[zz];
+		}
+		sr = wave_sum(sr);
+		if (lane == 0) {
+			if (ncb > 1) xchg[k] = sr;
+			else r2s[k] = sr;
+		}
+		WAVE_SYNC();
+#pragma clang loop unroll(disable)
+		for (int level = 0; level < 22; ++level) {
+			const int zz = level - lx - ly;
+			if (zz >= 0 && zz < 8) {
+				const int idx = zz * 64 + lane;
+				real t = (real)0;
+				if (lx > 0) t += (real)U[0][idx - 1] * PQ[idx - 1];
+				if (ly > 0) t += (real)U[1][idx - 8] * PQ[idx - 8];
+				if (zz > 0) t += (real)U[2][idx - 64] * PQ[idx - 64];
+				const real p = PRE[idx];
+				const real q = (Q[idx] + scale * t) * p;
+				Q[idx] = q;
+				PQ[idx] = p * q;
+			}
+			WAVE_SYNC();
+		}
+#pragma clang loop unroll(disable)
+		for (int level = 21; level >= 0; --level) {
+			const int zz = level - lx - ly;
+			if (zz >= 0 && zz < 8) {
+				const int idx = zz * 64 + lane;
+				real t = (real)0;
+				if (lx < 7) t += (real)U[0][idx] * Q[idx + 1];
+				if (ly < 7) t += (real)U[1][idx] * Q[idx + 8];
+				if (zz < 7) t += (real)U[2][idx] * Q[idx + 64];
+				const real p = PRE[idx];
+				Q[idx] = (Q[idx] + scale * p * t) * p;
+			}
+			WAVE_SYNC();
+		}
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) {
+			const real x1 = Q[zz * 64 + lane];
+			c.x[base + zz * 64 + lane] = x1;
+			dot1 += (double)x1 * (double)rr[zz];
+		}
+	}
+	dot1 = wave_sum(dot1);
+	if (lane == 0) red[wid] = dot1;
+	__syncthreads();
+	double dsum = 0.0;
+	for (int w = 0; w < WAVES; ++w) dsum += red[w];
+	if (ncb > 1) {
+		// several coarse workgroups: the last one to arrive does the top-level solve. Hand-off by the agent-scope
+		// release / ticket / acquire recipe (cdna_hip_programming.md section 6, Guideline 16): every wave drains its
+		// stores, one lane releases and draws the ticket, the last arriver acquires before it reads.
+		if (threadIdx.x == 0) xchg[64 + cb] = dsum;
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		unsigned *flag = (unsigned *)(red + WAVES);
+		if (threadIdx.x == 0) {
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const unsigned last = t == (unsigned)(ncb - 1) ? 1u : 0u;
+			if (last) {
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+				__hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+			}
+			*flag = last;
+		}
+		__syncthreads();
+		if (!*flag) return;
+		for (int k = threadIdx.x; k < n_l1; k += WAVES * 64)
+			r2s[k] = __hip_atomic_load(xchg + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		dsum = 0.0;
+		for (int b = 0; b < ncb; ++b) dsum += __hip_atomic_load(xchg + 64 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+	__syncthreads();
+	// top level: x2 = A2^-1 r2 (dense). Its prolongation onto the tiles happens in k_update_s; its share of z.r is x2.r2.
+	for (int row = threadIdx.x; row < n_l1; row += WAVES * 64) {
+		double acc = 0.0;
+		for (int k = 0; k < n_l1; ++k) acc += (double)a2inv[(size_t)row * n_l1 + k] * r2s[k];
+		x2s[row] = acc * r2s[row];
+		x2_out[row] = (real)acc;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		double t = dsum;
+		for (int k = 0; k < n_l1; ++k) t += x2s[k];
+		*part_sigma_extra = t;
+	}
+}
+
+template <typename real, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
+k_coarse_all(const int *l1_tiles, int n_l1, CoarseFields<real> c, real scale, const real *a2inv, real *x2,
+             double *part_sigma_extra, const int *state) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	if (state[0] >= 0) return;
+	coarse_block<real, WAVES>(smem, l1_tiles, n_l1, c, scale, a2inv, x2, part_sigma_extra);
+}
+
 // ================================================================================================= MIC(0) apply
 enum { SWEEP_BOTH = 0, SWEEP_FWD = 1, SWEEP_BWD = 2 };
 
 /// pressure_solver::_apply_preconditioner (src/pressure_solver.cpp:296-332).
 ///  SWEEP_BOTH (tiled): z = M^-1 r for every tile in one launch + partial dot(z, r); checks convergence first.
 ///  SWEEP_FWD / SWEEP_BWD (exact): one tile hyperplane per launch; q is kept in v.q between the two passes.
-template <typename real, int MODE>
+struct CoarseArgs {
+	const int *l1_tiles;
+	int n_l1;
+	const void *a2inv;
+	void *x2;
+	double *xchg;
+	unsigned *ticket;
+};
+#define PCG_COARSE_BLOCKS 4  // workgroups of a k_mic_apply launch that do the coarse levels (16 waves in total)
+
+/// EMBED: workgroup 0 of the launch does the coarse levels of the multilevel preconditioner (coarse_block) while the
+/// other workgroups sweep the tiles; it is dispatched first and is the longest-running workgroup, so the coarse levels
+/// cost no launch, no stream hand-off and no extra time.
+template <typename real, int MODE, bool EMBED>
 __global__ void __launch_bounds__(256)
 k_mic_apply(TileCtx tc, const int *slots, int n_slots, const uint8_t *abits, Vecs<real> v, real scale,
-            double *part_sigma, const int *state, real *coarse_r, const int *slot_l1) {
+            double *part_sigma, const int *state, real *coarse_r, const int *slot_l1, CoarseFields<real> cf,
+            CoarseArgs ca) {
 	constexpr bool EXACT = MODE != SWEEP_BOTH;
-	__shared__ real lq[PCG_WAVES][LFA_TILE_CELLS];    // r -> q -> z
-	__shared__ real lpq[PCG_WAVES][LFA_TILE_CELLS];   // pre * q
-	__shared__ real lpre[PCG_WAVES][LFA_TILE_CELLS];
-	__shared__ uint8_t lab[PCG_WAVES][LFA_TILE_CELLS];
+	constexpr int FINE_LDS = PCG_WAVES * LFA_TILE_CELLS * (3 * (int)sizeof(real) + 1);
+	constexpr int COARSE_LDS = PCG_WAVES * 3 * LFA_TILE_CELLS * ((int)sizeof(real) + 1) + 160 * 8;
+	__shared__ __attribute__((aligned(16))) char lds_raw[EMBED ? (COARSE_LDS > FINE_LDS ? COARSE_LDS : FINE_LDS) : FINE_LDS];
 	__shared__ double red[4];
+	const int nblk = EMBED ? (int)gridDim.x - PCG_COARSE_BLOCKS : (int)gridDim.x,
+	          blk = EMBED ? (int)blockIdx.x - PCG_COARSE_BLOCKS : (int)blockIdx.x;
+	if (EMBED && blockIdx.x < PCG_COARSE_BLOCKS) {
+		if (state[0] < 0)
+			coarse_block<real, PCG_WAVES>(lds_raw, ca.l1_tiles, ca.n_l1, cf, scale, (const real *)ca.a2inv, (real *)ca.x2,
+			                              part_sigma + nblk, (int)blockIdx.x, PCG_COARSE_BLOCKS, ca.xchg, ca.ticket);
+		return;
+	}
 	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
-	real *Q = lq[wid], *PQ = lpq[wid], *P = lpre[wid];
-	uint8_t *A = lab[wid];
+	real *Q = (real *)lds_raw + (size_t)wid * LFA_TILE_CELLS;                                   // r -> q -> z
+	real *PQ = (real *)lds_raw + (size_t)(PCG_WAVES + wid) * LFA_TILE_CELLS;                    // pre * q
+	real *P = (real *)lds_raw + (size_t)(2 * PCG_WAVES + wid) * LFA_TILE_CELLS;
+	uint8_t *A = (uint8_t *)((real *)lds_raw + (size_t)3 * PCG_WAVES * LFA_TILE_CELLS) + (size_t)wid * LFA_TILE_CELLS;
 	double acc = 0.0;
 	if (state[0] < 0) {
-		for (int k = blockIdx.x * PCG_WAVES + wid; k < n_slots; k += gridDim.x * PCG_WAVES) {
+		for (int k = blk * PCG_WAVES + wid; k < n_slots; k += nblk * PCG_WAVES) {
 			const int slot = slots ? slots[k] : k;
 			const int tile = tc.ptiles[slot];
 			const size_t base = (size_t)tile * LFA_TILE_CELLS;
@@ -318,6 +487,7 @@ k_mic_apply(TileCtx tc, const int *slots, int n_slots, const uint8_t *abits, Vec
 			}
 			if (MODE != SWEEP_BWD) {
 				// L q = r
+#pragma clang loop unroll(disable)
 				for (int level = 0; level < 22; ++level) {
 					const int zz = level - lx - ly;
 					if (zz >= 0 && zz < 8) {
@@ -354,6 +524,7 @@ k_mic_apply(TileCtx tc, const int *slots, int n_slots, const uint8_t *abits, Vec
 				continue;
 			}
 			// L^T z = q
+#pragma clang loop unroll(disable)
 			for (int level = 21; level >= 0; --level) {
 				const int zz = level - lx - ly;
 				if (zz >= 0 && zz < 8) {
@@ -388,7 +559,7 @@ k_mic_apply(TileCtx tc, const int *slots, int n_slots, const uint8_t *abits, Vec
 			}
 		}
 	}
-	if (MODE == SWEEP_BOTH) block_partial_sum(acc, red, part_sigma);
+	if (MODE == SWEEP_BOTH) block_partial_sum(acc, red, part_sigma, blk);
 }
 
 /// partial dot(z, r) (exact-MIC path, where the sweeps are separate launches).
@@ -431,7 +602,8 @@ k_check_converged(const double *part_rmax, int n_part, double tol, int iter, int
 template <typename real>
 __global__ void __launch_bounds__(256)
 k_update_s(TileCtx tc, Vecs<real> v, const double *part_sig_new, const double *part_sig_old, int n_part, int first,
-           const int *state, const uint8_t *abits, const real *coarse_x, const int *slot_l1) {
+           const int *state, const uint8_t *abits, const real *coarse_x, const int *slot_l1, const real *coarse_x2,
+           const int *l1_l2) {
 	__shared__ double lds[256];
 	if (state[0] >= 0) return;
 	real beta = (real)0;
@@ -443,7 +615,11 @@ k_update_s(TileCtx tc, Vecs<real> v, const double *part_sig_new, const double *p
 	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	for (int slot = blockIdx.x * PCG_WAVES + wid; slot < tc.n_ptiles; slot += gridDim.x * PCG_WAVES) {
 		const size_t base = (size_t)tc.ptiles[slot] * LFA_TILE_CELLS;
-		const real xc = coarse_x ? coarse_x[slot_l1[slot]] : (real)0;
+		real xc = (real)0;
+		if (coarse_x) {  // prolongation of both coarse levels: level-1 value of the tile + top-level value of its block
+			const int i1 = slot_l1[slot];
+			xc = coarse_x[i1] + coarse_x2[l1_l2[i1 >> 9]];
+		}
 #pragma unroll
 		for (int zz = 0; zz < 8; ++zz) {
 			const size_t b = base + zz * 64 + lane;
@@ -489,12 +665,6 @@ k_coarse_coeffs(TileCtx tc, const uint8_t *abits, const int *slot_l1, float *c_d
 		}
 	}
 }
-
-template <typename real> struct CoarseFields {
-	const float *diag, *w[3];
-	const uint8_t *unk;
-	real *pre, *r, *x;
-};
 
 /// MIC(0) of a level-1 block (weighted version of k_mic_factor, block-local).
 template <typename real>
@@ -631,11 +801,7 @@ k_coarse_top(const int *l1_tiles, int n_l1, CoarseFields<real> c, const real *a2
 #pragma unroll
 		for (int zz = 0; zz < 8; ++zz) {
 			const size_t i = base + zz * 64 + lane;
-			if (c.unk[i]) {
-				const real xt = c.x[i] + add;
-				c.x[i] = xt;
-				dotp += (double)xt * (double)c.r[i];
-			}
+			if (c.unk[i]) dotp += ((double)c.x[i] + (double)add) * (double)c.r[i];  // prolongation itself: k_update_s
 		}
 	}
 	dotp = wave_sum(dotp);
@@ -644,115 +810,16 @@ k_coarse_top(const int *l1_tiles, int n_l1, CoarseFields<real> c, const real *a2
 	if (threadIdx.x == 0) *part_sigma_extra = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-/// All coarse work of one preconditioner application in ONE workgroup (used when at most 64 level-1 blocks hold fluid):
-/// per level-1 block a wave stages coefficients in LDS and runs the weighted forward/backward substitution, then the
-/// dense top-level solve, the prolongation of its result onto level 1 and the coarse share of z.r. Latency-bound by
-/// design (44 dependent LDS hyperplanes per block), so everything the sweeps touch sits in LDS.
-template <typename real, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64)
-k_coarse_all(const int *l1_tiles, int n_l1, CoarseFields<real> c, real scale, const real *a2inv,
-             double *part_sigma_extra, const int *state) {
-	extern __shared__ __attribute__((aligned(16))) char smem[];
-	if (state[0] >= 0) return;
-	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
-	// per wave: PRE, Q, PQ (real) + the three face weights as bytes (a face of a tile has at most 64 couplings)
-	real *wbase = (real *)smem + (size_t)wid * 3 * LFA_TILE_CELLS;
-	real *PRE = wbase, *Q = wbase + LFA_TILE_CELLS, *PQ = wbase + 2 * LFA_TILE_CELLS;
-	uint8_t *ub = (uint8_t *)((real *)smem + (size_t)WAVES * 3 * LFA_TILE_CELLS) + (size_t)wid * 3 * LFA_TILE_CELLS;
-	uint8_t *U[3] = {ub, ub + LFA_TILE_CELLS, ub + 2 * LFA_TILE_CELLS};
-	double *r2s = (double *)(smem + (size_t)WAVES * 3 * LFA_TILE_CELLS * (sizeof(real) + 1));
-	double *x2s = r2s + 64;
-	double *red = x2s + 64;
-	for (int k = wid; k < n_l1; k += WAVES) {
-		const size_t base = (size_t)l1_tiles[k] * LFA_TILE_CELLS;
-		double sr = 0.0;
-		WAVE_SYNC();
-#pragma unroll
-		for (int zz = 0; zz < 8; ++zz) {
-			const int idx = zz * 64 + lane;
-			const bool u = c.unk[base + idx] != 0;
-			U[0][idx] = (uint8_t)c.w[0][base + idx];
-			U[1][idx] = (uint8_t)c.w[1][base + idx];
-			U[2][idx] = (uint8_t)c.w[2][base + idx];
-			PRE[idx] = u ? c.pre[base + idx] : (real)0;
-			const real r = u ? c.r[base + idx] : (real)0;
-			Q[idx] = r;
-			PQ[idx] = (real)0;
-			sr += (double)r;
-		}
-		sr = wave_sum(sr);
-		if (lane == 0) r2s[k] = sr;
-		WAVE_SYNC();
-		for (int level = 0; level < 22; ++level) {
-			const int zz = level - lx - ly;
-			if (zz >= 0 && zz < 8) {
-				const int idx = zz * 64 + lane;
-				real t = (real)0;
-				if (lx > 0) t += (real)U[0][idx - 1] * PQ[idx - 1];
-				if (ly > 0) t += (real)U[1][idx - 8] * PQ[idx - 8];
-				if (zz > 0) t += (real)U[2][idx - 64] * PQ[idx - 64];
-				const real p = PRE[idx];
-				const real q = (Q[idx] + scale * t) * p;
-				Q[idx] = q;
-				PQ[idx] = p * q;
-			}
-			WAVE_SYNC();
-		}
-		for (int level = 21; level >= 0; --level) {
-			const int zz = level - lx - ly;
-			if (zz >= 0 && zz < 8) {
-				const int idx = zz * 64 + lane;
-				real t = (real)0;
-				if (lx < 7) t += (real)U[0][idx] * Q[idx + 1];
-				if (ly < 7) t += (real)U[1][idx] * Q[idx + 8];
-				if (zz < 7) t += (real)U[2][idx] * Q[idx + 64];
-				const real p = PRE[idx];
-				Q[idx] = (Q[idx] + scale * p * t) * p;
-			}
-			WAVE_SYNC();
-		}
-#pragma unroll
-		for (int zz = 0; zz < 8; ++zz) c.x[base + zz * 64 + lane] = Q[zz * 64 + lane];
-	}
-	__syncthreads();
-	for (int row = threadIdx.x; row < n_l1; row += WAVES * 64) {
-		double acc = 0.0;
-		for (int k = 0; k < n_l1; ++k) acc += (double)a2inv[(size_t)row * n_l1 + k] * r2s[k];
-		x2s[row] = acc;
-	}
-	__syncthreads();
-	double dotp = 0.0;
-	for (int k = wid; k < n_l1; k += WAVES) {
-		const size_t base = (size_t)l1_tiles[k] * LFA_TILE_CELLS;
-		const real add = (real)x2s[k];
-#pragma unroll
-		for (int zz = 0; zz < 8; ++zz) {
-			const size_t i = base + zz * 64 + lane;
-			if (c.unk[i]) {
-				const real xt = c.x[i] + add;
-				c.x[i] = xt;
-				dotp += (double)xt * (double)c.r[i];
-			}
-		}
-	}
-	dotp = wave_sum(dotp);
-	if (lane == 0) red[wid] = dotp;
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		double t = 0.0;
-		for (int w = 0; w < WAVES; ++w) t += red[w];
-		*part_sigma_extra = t;
-	}
-}
-
 /// z += P x_coarse on the unknowns (only for lfa_apply_preconditioner, which hands z to the caller).
 template <typename real>
 __global__ void __launch_bounds__(256)
-k_add_coarse(TileCtx tc, const uint8_t *abits, real *z, const real *coarse_x, const int *slot_l1) {
+k_add_coarse(TileCtx tc, const uint8_t *abits, real *z, const real *coarse_x, const int *slot_l1, const real *coarse_x2,
+             const int *l1_l2) {
 	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	for (int slot = blockIdx.x * PCG_WAVES + wid; slot < tc.n_ptiles; slot += gridDim.x * PCG_WAVES) {
 		const size_t base = (size_t)tc.ptiles[slot] * LFA_TILE_CELLS;
-		const real xc = coarse_x[slot_l1[slot]];
+		const int i1 = slot_l1[slot];
+		const real xc = coarse_x[i1] + coarse_x2[l1_l2[i1 >> 9]];
 #pragma unroll
 		for (int zz = 0; zz < 8; ++zz)
 			if (abits[base + zz * 64 + lane] & AB_UNKNOWN) z[base + zz * 64 + lane] += xc;
@@ -1007,7 +1074,7 @@ template <typename real> static int coarse_apply(lfa_sim *s, double *part_sigma,
 			attr_set = true;
 		}
 		hipLaunchKernelGGL((k_coarse_all<real, WAVES>), dim3(1), dim3(WAVES * 64), lds, stream, s->l1_tiles, s->n_l1tiles,
-		                   cf, (real)s->a_scale, (const real *)s->a2inv, extra, s->pcg_state);
+		                   cf, (real)s->a_scale, (const real *)s->a2inv, (real *)s->c_x2, extra, s->pcg_state);
 		LFA_LAUNCH_CHECK(s);
 		return LFA_OK;
 	}
@@ -1053,35 +1120,40 @@ template <typename real> static int mic_apply(lfa_sim *s, double *part_sigma, bo
 		for (int l = 0; l < nl; ++l) {
 			const int b = s->level_offsets[l], n = s->level_offsets[l + 1] - b;
 			if (!n) continue;
-			hipLaunchKernelGGL((k_mic_apply<real, SWEEP_FWD>), dim3((n + PCG_WAVES - 1) / PCG_WAVES), dim3(256), 0, s->stream,
+			hipLaunchKernelGGL((k_mic_apply<real, SWEEP_FWD, false>), dim3((n + PCG_WAVES - 1) / PCG_WAVES), dim3(256), 0, s->stream,
 			                   tc, s->level_tiles + b, n, s->abits, v, scale, part_sigma, s->pcg_state, (real *)nullptr,
-			                   (const int *)nullptr);
+			                   (const int *)nullptr, CoarseFields<real>{}, CoarseArgs{});
 			LFA_LAUNCH_CHECK(s);
 		}
 		for (int l = nl - 1; l >= 0; --l) {
 			const int b = s->level_offsets[l], n = s->level_offsets[l + 1] - b;
 			if (!n) continue;
-			hipLaunchKernelGGL((k_mic_apply<real, SWEEP_BWD>), dim3((n + PCG_WAVES - 1) / PCG_WAVES), dim3(256), 0, s->stream,
+			hipLaunchKernelGGL((k_mic_apply<real, SWEEP_BWD, false>), dim3((n + PCG_WAVES - 1) / PCG_WAVES), dim3(256), 0, s->stream,
 			                   tc, s->level_tiles + b, n, s->abits, v, scale, part_sigma, s->pcg_state, (real *)nullptr,
-			                   (const int *)nullptr);
+			                   (const int *)nullptr, CoarseFields<real>{}, CoarseArgs{});
 			LFA_LAUNCH_CHECK(s);
 		}
 		hipLaunchKernelGGL(k_dot_zr<real>, dim3(G), dim3(256), 0, s->stream, tc, v, part_sigma, s->pcg_state);
 		LFA_LAUNCH_CHECK(s);
 	} else {
-		const bool fork = is_ml(s) && r1_ready;
-		if (fork) {
-			LFA_HIP(s, hipEventRecord(s->ev_fork, s->stream));
-			LFA_HIP(s, hipStreamWaitEvent(s->stream2, s->ev_fork, 0));
-			LFA_TRY(coarse_apply<real>(s, part_sigma, s->stream2));
-			LFA_HIP(s, hipEventRecord(s->ev_join, s->stream2));
+		// r1_ready (inside the PCG loop): the restricted residual was written by k_axpy_max, so workgroup 0 of this very
+		// launch runs the coarse levels beside the tile sweeps. Otherwise (first application, test entry points, or
+		// more than 64 level-1 blocks) the coarse levels follow as their own launch.
+		const bool embed = is_ml(s) && r1_ready && s->n_l1tiles <= 64;
+		if (embed) {
+			CoarseArgs ca{s->l1_tiles, s->n_l1tiles, s->a2inv, s->c_x2, (double *)s->pcg_hist + 6144, (unsigned *)(s->pcg_state + 4)};
+			hipLaunchKernelGGL((k_mic_apply<real, SWEEP_BOTH, true>), dim3(G + PCG_COARSE_BLOCKS), dim3(256), 0, s->stream, tc,
+			                   (const int *)nullptr, s->n_ptiles, s->abits, v, scale, part_sigma, s->pcg_state, (real *)nullptr,
+			                   (const int *)s->slot_l1, make_coarse<real>(s), ca);
+			LFA_LAUNCH_CHECK(s);
+		} else {
+			hipLaunchKernelGGL((k_mic_apply<real, SWEEP_BOTH, false>), dim3(G), dim3(256), 0, s->stream, tc,
+			                   (const int *)nullptr, s->n_ptiles, s->abits, v, scale, part_sigma, s->pcg_state,
+			                   (is_ml(s) && !r1_ready) ? (real *)s->c_r : (real *)nullptr, (const int *)s->slot_l1,
+			                   CoarseFields<real>{}, CoarseArgs{});
+			LFA_LAUNCH_CHECK(s);
+			if (is_ml(s)) LFA_TRY(coarse_apply<real>(s, part_sigma, s->stream));
 		}
-		hipLaunchKernelGGL((k_mic_apply<real, SWEEP_BOTH>), dim3(G), dim3(256), 0, s->stream, tc, (const int *)nullptr,
-		                   s->n_ptiles, s->abits, v, scale, part_sigma, s->pcg_state,
-		                   (is_ml(s) && !r1_ready) ? (real *)s->c_r : (real *)nullptr, (const int *)s->slot_l1);
-		LFA_LAUNCH_CHECK(s);
-		if (fork) LFA_HIP(s, hipStreamWaitEvent(s->stream, s->ev_join, 0));
-		else if (is_ml(s)) LFA_TRY(coarse_apply<real>(s, part_sigma, s->stream));
 	}
 	return LFA_OK;
 }
@@ -1145,7 +1217,7 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 	LFA_TRY(mic_apply<real>(s, P + PART_SIG0));
 	if (dist) LFA_TRY(lfa_dist_allreduce(s, P + PART_SIG0, NS, 3, false));
 	hipLaunchKernelGGL(k_update_s<real>, dim3(G), dim3(256), 0, s->stream, tc, v, sig_src(0), sig_src(0), n_sig, 1,
-	                   s->pcg_state, s->abits, cx, (const int *)s->slot_l1);
+	                   s->pcg_state, s->abits, cx, (const int *)s->slot_l1, (const real *)s->c_x2, (const int *)s->l1_l2);
 	LFA_LAUNCH_CHECK(s);
 	const int maxit = (int)s->prm.max_iterations;
 	const int chunk = 8;
@@ -1172,7 +1244,7 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 			LFA_TRY(mic_apply<real>(s, sig_new_part, true));
 			if (dist) LFA_TRY(lfa_dist_allreduce(s, sig_new_part, NS, 3 + pn, false));
 			hipLaunchKernelGGL(k_update_s<real>, dim3(G), dim3(256), 0, s->stream, tc, v, sig_src(pn), sig_src(po), n_sig, 0,
-			                   s->pcg_state, s->abits, cx, (const int *)s->slot_l1);
+			                   s->pcg_state, s->abits, cx, (const int *)s->slot_l1, (const real *)s->c_x2, (const int *)s->l1_l2);
 			LFA_LAUNCH_CHECK(s);
 		}
 		LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 8, hipMemcpyDeviceToHost, s->stream));
@@ -1267,7 +1339,8 @@ template <typename real> static int apply_precon_t(lfa_sim *s, const double *r, 
 		LFA_TRY(mic_apply<real>(s, s->partials + PART_SIG0));
 		if (is_ml(s)) {
 			hipLaunchKernelGGL(k_add_coarse<real>, dim3(pcg_grid(s->n_ptiles)), dim3(256), 0, s->stream, make_ctx(s), s->abits,
-			                   (real *)s->vz, (const real *)s->c_x, (const int *)s->slot_l1);
+			                   (real *)s->vz, (const real *)s->c_x, (const int *)s->slot_l1, (const real *)s->c_x2,
+			                   (const int *)s->l1_l2);
 			LFA_LAUNCH_CHECK(s);
 		}
 	}
@@ -1371,8 +1444,9 @@ template <typename real> static int bench_launch(lfa_sim *s, int which) {
 	case LFA_K_MIC_APPLY:
 		return mic_apply<real>(s, P + PART_SIG1, true);
 	case LFA_K_MIC_FINE:
-		hipLaunchKernelGGL((k_mic_apply<real, SWEEP_BOTH>), dim3(G), dim3(256), 0, s->stream, tc, (const int *)nullptr,
-		                   s->n_ptiles, s->abits, v, scale, P + PART_SIG1, s->pcg_state, (real *)nullptr, (const int *)nullptr);
+		hipLaunchKernelGGL((k_mic_apply<real, SWEEP_BOTH, false>), dim3(G), dim3(256), 0, s->stream, tc,
+		                   (const int *)nullptr, s->n_ptiles, s->abits, v, scale, P + PART_SIG1, s->pcg_state, (real *)nullptr,
+		                   (const int *)nullptr, CoarseFields<real>{}, CoarseArgs{});
 		break;
 	case LFA_K_COARSE:
 		if (!is_ml(s)) return lfa_fail(s, LFA_E_INVALID, "no coarse levels with this preconditioner");
@@ -1380,7 +1454,7 @@ template <typename real> static int bench_launch(lfa_sim *s, int which) {
 	case LFA_K_UPDATE_S:
 		hipLaunchKernelGGL(k_update_s<real>, dim3(G), dim3(256), 0, s->stream, tc, v, P + PART_SIG0, P + PART_SIG0, G, 0,
 		                   s->pcg_state, s->abits, is_ml(s) ? (const real *)s->c_x : (const real *)nullptr,
-		                   (const int *)s->slot_l1);
+		                   (const int *)s->slot_l1, (const real *)s->c_x2, (const int *)s->l1_l2);
 		break;
 	}
 	LFA_LAUNCH_CHECK(s);
