@@ -239,7 +239,8 @@ __device__ inline float lerp_ref(float a, float b, float t) { return a * (1.0f -
 struct G2PParams {
 	int method;
 	float blend;
-	float h;      // cell_size: _grad_kernel divides by it (src/simulation.cpp:223)
+	float inv_h;  // 1 / cell_size: _grad_kernel divides by it (src/simulation.cpp:223); a multiply here (72 IEEE
+	              // divisions per particle made the kernel VALU-bound), identical for power-of-two cell sizes
 };
 
 /// One workgroup per particle tile: stage u,v,w (and FLIP's old grid) of the tile + 1-cell ring in LDS with the
@@ -315,9 +316,9 @@ k_g2p(const int *ptiles, int n_ptiles, GridDims g, ParticleSoA p, const uint32_t
 						const float px = f[0] - (float)(k & 1), py = f[1] - (float)((k >> 1) & 1), pz = f[2] - (float)(k >> 2);
 						const float sx = px > 0.f ? -1.f : 1.f, sy = py > 0.f ? -1.f : 1.f, sz = pz > 0.f ? -1.f : 1.f;
 						const float ax = 1.f - fabsf(px), ay = 1.f - fabsf(py), az = 1.f - fabsf(pz);
-						cx = cx + (sx * ay * az / gp.h) * s[k];
-						cy = cy + (ax * sy * az / gp.h) * s[k];
-						cz = cz + (ax * ay * sz / gp.h) * s[k];
+						cx = cx + (sx * ay * az * gp.inv_h) * s[k];
+						cy = cy + (ax * sy * az * gp.inv_h) * s[k];
+						cz = cz + (ax * ay * sz * gp.inv_h) * s[k];
 					}
 					cvec[3 * comp] = cx; cvec[3 * comp + 1] = cy; cvec[3 * comp + 2] = cz;
 				}
@@ -445,7 +446,7 @@ extern "C" int lfa_g2p(lfa_sim *s) {
 	G2PParams gp;
 	gp.method = s->prm.simulation_method;
 	gp.blend = (float)s->prm.blending_factor;
-	gp.h = (float)s->prm.cell_size;
+	gp.inv_h = (float)(1.0 / s->prm.cell_size);
 	dim3 grid(grid_blocks(s->n_ptiles));
 	const ParticleSoA &p = s->pb[s->cur];
 	switch (s->prm.simulation_method) {
