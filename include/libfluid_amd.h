@@ -151,6 +151,20 @@ int lfa_cfl(lfa_sim *s, double *out);
  * 83-104,119-121). residual/iterations may be NULL. */
 int lfa_step_hot(lfa_sim *s, double dt, double *residual, uint64_t *iterations);
 
+/* -- the per-step particle stages around the hot path, device resident ----------------------------
+ * lfa_advect_collide : simulation::_advect_particles (src/simulation.cpp:226-249, without fluid sources) fused with the
+ *                      _detect_collisions that follows it (:612-683, grid::march_cells grid.h:140-209; from = old position)
+ * lfa_correct_collide: simulation::_correct_positions (:562-610) fused with the _detect_collisions after it (:114-117);
+ *                      needs lfa_hash_particles of the current positions
+ * lfa_time_step      : simulation::time_step(dt) (:43-125) entirely on the device: advect+collide, hash, P2G, gravity,
+ *                      pressure solve, pressure gradient, correct+collide, extrapolate, hash, G2P. No sources, no callbacks
+ *                      (the host class falls back to stage calls when it needs them); single GPU. */
+int lfa_advect_collide(lfa_sim *s, double dt);
+int lfa_correct_collide(lfa_sim *s, double dt);
+int lfa_time_step(lfa_sim *s, double dt, double *residual, uint64_t *iterations);
+/* device time of the last lfa_time_step in ms (timing enabled): [0] advect+collide [1] correct+collide [2] whole step */
+int lfa_get_step_timings(lfa_sim *s, double ms[3]);
+
 /* -- multi-GPU: z-slab domain decomposition ---------------------------------------------------------
  * One handle per GPU/process, every handle created with the GLOBAL grid size. Rank r owns the tile layers
  * [bounds[r], bounds[r+1]) (a tile layer = 8 cells in z) and the particles inside them; one ghost tile layer on each side

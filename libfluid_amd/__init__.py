@@ -101,6 +101,10 @@ SIGNATURES = {
     "lfa_get_timings": (_int, [_vp, C.POINTER(_dbl * NUM_TIMERS)]),
     "lfa_get_counts": (_int, [_vp, C.POINTER(_u64 * 5)]),
     "lfa_bench_kernel": (_int, [_vp, _int, _int, C.POINTER(_dbl)]),
+    "lfa_advect_collide": (_int, [_vp, _dbl]),
+    "lfa_correct_collide": (_int, [_vp, _dbl]),
+    "lfa_time_step": (_int, [_vp, _dbl, C.POINTER(_dbl), C.POINTER(_u64)]),
+    "lfa_get_step_timings": (_int, [_vp, C.POINTER(_dbl * 3)]),
     "lfa_dist_unique_id": (_int, [_vp]),
     "lfa_dist_init_rccl": (_int, [_vp, _int, _int, _vp, _vp]),
     "lfa_dist_local_hub_create": (_vp, [_int]),
@@ -355,6 +359,24 @@ class Sim:
         res, it = C.c_double(0.0), C.c_uint64(0)
         rc = self._chk(self.lib.lfa_step_hot(self.h, float(dt), C.byref(res), C.byref(it)))
         return res.value, it.value, rc
+
+    # -- particle stages around the hot path, full step ---------------------------------------------------
+    def advect_collide(self, dt):
+        self._chk(self.lib.lfa_advect_collide(self.h, float(dt)))
+
+    def correct_collide(self, dt):
+        self._chk(self.lib.lfa_correct_collide(self.h, float(dt)))
+
+    def time_step(self, dt):
+        """Device-resident simulation::time_step(dt); returns (residual, iterations, return code)."""
+        res, it = C.c_double(0.0), C.c_uint64(0)
+        rc = self._chk(self.lib.lfa_time_step(self.h, float(dt), C.byref(res), C.byref(it)))
+        return res.value, it.value, rc
+
+    def step_timings(self):
+        arr = (C.c_double * 3)()
+        self._chk(self.lib.lfa_get_step_timings(self.h, C.byref(arr)))
+        return dict(zip(["advect_collide", "correct_collide", "time_step"], list(arr)))
 
     # -- z-slab decomposition ------------------------------------------------------------------------------
     def init_local_slab(self, hub, rank, layer_bounds):

@@ -98,6 +98,7 @@ struct lfa_sim {
 	float *uo = nullptr, *vo = nullptr, *wo = nullptr;
 	uint8_t *ctype = nullptr, *solid = nullptr;
 	uint32_t *cell_count = nullptr;
+	uint32_t *cell_start = nullptr;  // first entry of every cell in the cell-grouped index (rank[]), position correction only
 	float *stage = nullptr;  // P2G per-tile partial sums [n_ptiles][6][1000]
 	size_t stage_tiles = 0;
 	float *acc = nullptr;    // global-atomic P2G accumulators [6][ncp]
@@ -139,6 +140,7 @@ struct lfa_sim {
 	hipEvent_t ev[24];
 	bool ev_created = false;
 	double ms[LFA_NUM_TIMERS] = {0};
+	double ms_next[3] = {0, 0, 0};  // advect+collide, correct+collide, whole lfa_time_step
 };
 
 // ---------------------------------------------------------------------------------------------------- error handling

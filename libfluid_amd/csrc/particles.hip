@@ -1,0 +1,341 @@
+// libfluid_amd/csrc/particles.hip -- the per-step particle stages either side of the hot path:
+// advection, collision against solid cells / domain walls, position correction, and the device-resident
+// simulation::time_step built from them.
+//
+// Reference: simulation::_advect_particles src/simulation.cpp:226-249; _detect_collisions :612-683 with
+// grid::march_cells include/fluid/data_structures/grid.h:140-209; _correct_positions :562-610; time_step :43-125.
+// Positions live on the device as (cell, fraction-in-cell); the marches run in fp64 grid units (cell + fraction), which is
+// the reference's (position - grid_offset) / cell_size.
+#include <math.h>
+
+#include "common.h"
+#include "pcg.h"
+
+namespace {
+
+__device__ inline bool solid_or_outside(const GridDims &g, const uint8_t *solid, int x, int y, int z) {
+	if (!in_grid(g, x, y, z)) return true;
+	return solid[blocked_index(g, x, y, z)] != 0;
+}
+
+/// _detect_collisions for one particle, in grid units (skin = boundary_skin_width / cell_size): up to three bounces of
+/// the segment from -> to (DDA over cells, first solid/outside cell stops it `skin` short of the face and removes the
+/// normal component), then the push-out from walls / solid neighbours closer than `skin`. Result in `to`.
+__device__ inline void collide(const GridDims &g, const uint8_t *solid, double from[3], double to[3], double skin) {
+	for (int bounce = 0; bounce < 3; ++bounce) {
+		bool hit = false;
+		double diff[3], inv[3], t[3];
+		int cur[3], last[3], adv[3];
+#pragma unroll
+		for (int d = 0; d < 3; ++d) {
+			cur[d] = (int)floor(from[d]);
+			last[d] = (int)floor(to[d]);
+			diff[d] = to[d] - from[d];
+			adv[d] = diff[d] > 0.0 ? 1 : -1;
+			inv[d] = 1.0 / fabs(diff[d]);
+			t[d] = fabs((double)(cur[d] + (diff[d] > 0.0 ? 1 : 0)) - from[d]) * inv[d];
+		}
+		for (int guard = 0; guard < 4096 && (cur[0] != last[0] || cur[1] != last[1] || cur[2] != last[2]); ++guard) {
+			int dim = 0;
+			double tmin = 2.0;
+			if (t[0] < tmin) { tmin = t[0]; dim = 0; }
+			if (t[1] < tmin) { tmin = t[1]; dim = 1; }
+			if (t[2] < tmin) { tmin = t[2]; dim = 2; }
+			if (!(tmin <= 1.0)) break;  // grid.h:196-199
+			// static indexing (no scratch): update the chosen axis
+			const int a0 = dim == 0, a1 = dim == 1, a2 = dim == 2;
+			cur[0] += a0 ? adv[0] : 0; cur[1] += a1 ? adv[1] : 0; cur[2] += a2 ? adv[2] : 0;
+			if (solid_or_outside(g, solid, cur[0], cur[1], cur[2])) {
+				const double td = a0 ? t[0] : (a1 ? t[1] : t[2]);
+				const double od = a0 ? diff[0] : (a1 ? diff[1] : diff[2]);
+				const int ad = a0 ? adv[0] : (a1 ? adv[1] : adv[2]);
+				double tt = td + skin / (od * (double)(-ad));
+				if (tt < 0.0) tt = 0.0;
+#pragma unroll
+				for (int d = 0; d < 3; ++d) from[d] = tt * to[d] + (1.0 - tt) * from[d];
+				if (a0) to[0] = from[0];
+				if (a1) to[1] = from[1];
+				if (a2) to[2] = from[2];
+				hit = true;
+				break;
+			}
+			t[0] += a0 ? inv[0] : 0.0; t[1] += a1 ? inv[1] : 0.0; t[2] += a2 ? inv[2] : 0.0;
+		}
+		if (!hit) break;
+	}
+	int ci[3];
+	double cp[3];
+#pragma unroll
+	for (int d = 0; d < 3; ++d) {
+		ci[d] = (int)to[d];
+		cp[d] = to[d] - (double)ci[d];
+	}
+	const double skin_max = 1.0 - skin;
+	const int n[3] = {g.nx, g.ny, g.nz};
+#pragma unroll
+	for (int d = 0; d < 3; ++d) {
+		if (cp[d] < skin) {
+			if (ci[d] == 0 || solid_or_outside(g, solid, ci[0] - (d == 0), ci[1] - (d == 1), ci[2] - (d == 2))) to[d] += skin - cp[d];
+		}
+		if (cp[d] > skin_max) {
+			if (ci[d] + 1 >= n[d] || solid_or_outside(g, solid, ci[0] + (d == 0), ci[1] + (d == 1), ci[2] + (d == 2)))
+				to[d] += skin_max - cp[d];
+		}
+	}
+}
+
+__device__ inline void cell_of_key(const GridDims &g, uint32_t key, int c[3]) {
+	int tile = (int)(key >> 9), l = (int)(key & 511), tx, ty, tz;
+	tile_coords(g, tile, tx, ty, tz);
+	c[0] = tx * 8 + (l & 7); c[1] = ty * 8 + ((l >> 3) & 7); c[2] = tz * 8 + (l >> 6);
+}
+/// grid-unit position -> (clamped cell, fraction), the same rule as the upload path (core.hip: cell_and_fraction).
+__device__ inline void split_position(double p, int n, int &cell, float &t) {
+	double m = p < 0.0 ? 0.0 : p;
+	int c = m >= (double)n ? n - 1 : (int)m;
+	double td = p - (double)c;
+	float tf = (float)td;
+	if (!(tf > 0.0f)) tf = 0.0f;
+	if (td < 1.0 && tf >= 1.0f) tf = 0.99999994f;
+	if (tf > 1.0f) tf = 1.0f;
+	cell = c;
+	t = tf;
+}
+
+struct MoveParams {
+	double dt_over_h;   // dt / cell_size
+	double skin;        // boundary_skin_width / cell_size
+	double corr;        // dt * correction_stiffness * re / cell_size   (re = cell_size / sqrt 2)
+	double inv_re2;     // cell_size^2 / re^2 = 2
+};
+
+/// _advect_particles (x += v dt, clamp to [skin, n - skin]) fused with _detect_collisions (from = the old position).
+__global__ void __launch_bounds__(256)
+k_advect_collide(size_t n, ParticleSoA p, GridDims g, const uint8_t *solid, MoveParams mp) {
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	int c[3];
+	cell_of_key(g, p.key[i], c);
+	const int nn[3] = {g.nx, g.ny, g.nz};
+	double from[3], to[3];
+#pragma unroll
+	for (int d = 0; d < 3; ++d) {
+		from[d] = (double)c[d] + (double)p.t[d][i];
+		double x = from[d] + (double)p.v[d][i] * mp.dt_over_h;
+		const double lo = mp.skin, hi = (double)nn[d] - mp.skin;
+		to[d] = x < lo ? lo : (hi < x ? hi : x);
+	}
+	collide(g, solid, from, to, mp.skin);
+	int nc[3];
+	float nt[3];
+#pragma unroll
+	for (int d = 0; d < 3; ++d) split_position(to[d], nn[d], nc[d], nt[d]);
+	p.key[i] = blocked_index(g, nc[0], nc[1], nc[2]);
+#pragma unroll
+	for (int d = 0; d < 3; ++d) p.t[d][i] = nt[d];
+}
+
+/// Per particle tile: indices of the tile's particles grouped by cell (the `begin` half of the reference's _space_hash,
+/// include/fluid/simulation.h:193-197) - only the position correction needs cell lists.
+__global__ void __launch_bounds__(256)
+k_build_cell_index(const int *ptiles, int n_ptiles, const uint32_t *key, const uint32_t *tile_start, uint32_t *cell_start,
+                   uint32_t *cidx) {
+	__shared__ uint32_t cnt[LFA_TILE_CELLS];
+	__shared__ uint32_t wsum[4];
+	for (int slot = blockIdx.x; slot < n_ptiles; slot += gridDim.x) {
+		const int tile = ptiles[slot];
+		const uint32_t b = tile_start[tile], e = tile_start[tile + 1];
+		cnt[threadIdx.x] = 0;
+		cnt[threadIdx.x + 256] = 0;
+		__syncthreads();
+		for (uint32_t i = b + threadIdx.x; i < e; i += 256) atomicAdd(&cnt[key[i] & 511], 1u);
+		__syncthreads();
+		// exclusive scan of the 512 counts: thread t owns cells 2t, 2t+1
+		const uint32_t c0 = cnt[2 * threadIdx.x], c1 = cnt[2 * threadIdx.x + 1];
+		uint32_t incl = c0 + c1;
+		const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			uint32_t t = __shfl_up(incl, o, 64);
+			if (lane >= o) incl += t;
+		}
+		if (lane == 63) wsum[wid] = incl;
+		__syncthreads();
+		uint32_t woff = 0;
+		for (int w = 0; w < wid; ++w) woff += wsum[w];
+		const uint32_t ex = b + woff + incl - (c0 + c1);
+		__syncthreads();
+		cnt[2 * threadIdx.x] = ex;
+		cnt[2 * threadIdx.x + 1] = ex + c0;
+		cell_start[(size_t)tile * LFA_TILE_CELLS + 2 * threadIdx.x] = ex;
+		cell_start[(size_t)tile * LFA_TILE_CELLS + 2 * threadIdx.x + 1] = ex + c0;
+		__syncthreads();
+		for (uint32_t i = b + threadIdx.x; i < e; i += 256) cidx[atomicAdd(&cnt[key[i] & 511], 1u)] = i;
+		__syncthreads();
+	}
+}
+
+__device__ inline float hash_unit(uint32_t a, uint32_t b, uint32_t k) {
+	uint32_t x = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u ^ k * 0xC2B2AE3Du;
+	x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
+	return (float)(x >> 8) * (2.0f / 16777216.0f) - 1.0f;
+}
+
+/// _correct_positions (pairwise springs over the 27-cell neighbourhood, all from the OLD positions) fused with the
+/// _detect_collisions that follows it. Reads (key, t) of `p`, writes the new ones to `out`.
+__global__ void __launch_bounds__(256)
+k_correct_collide(size_t n, ParticleSoA p, uint32_t *out_key, float *out_tx, float *out_ty, float *out_tz, GridDims g,
+                  const uint8_t *solid, const uint32_t *tile_flag, const uint32_t *cell_count, const uint32_t *cell_start,
+                  const uint32_t *cidx, MoveParams mp) {
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	int c[3];
+	cell_of_key(g, p.key[i], c);
+	const float t[3] = {p.t[0][i], p.t[1][i], p.t[2][i]};
+	const int nn[3] = {g.nx, g.ny, g.nz};
+	int lo[3], hi[3];
+#pragma unroll
+	for (int d = 0; d < 3; ++d) {
+		// particle::compute_cell_index truncates WITHOUT clamping (src/simulation.cpp:13-15): a particle on the max face
+		// sits in "cell n", whose clamped neighbourhood is the last cell only (grid.h:126-135)
+		const int ci = c[d] + (t[d] >= 1.0f ? 1 : 0);
+		lo[d] = ci - 1 < 0 ? 0 : ci - 1;
+		hi[d] = ci + 1 > nn[d] - 1 ? nn[d] - 1 : ci + 1;
+	}
+	double spring[3] = {0.0, 0.0, 0.0};
+	for (int zz = lo[2]; zz <= hi[2]; ++zz)
+		for (int yy = lo[1]; yy <= hi[1]; ++yy)
+			for (int xx = lo[0]; xx <= hi[0]; ++xx) {
+				const uint32_t b = blocked_index(g, xx, yy, zz);
+				if (!tile_flag[b >> 9]) continue;
+				const uint32_t cnt = cell_count[b];
+				if (!cnt) continue;
+				const uint32_t st = cell_start[b];
+				const float ox = (float)(c[0] - xx) + t[0], oy = (float)(c[1] - yy) + t[1], oz = (float)(c[2] - zz) + t[2];
+				for (uint32_t k = 0; k < cnt; ++k) {
+					const uint32_t j = cidx[st + k];
+					if (j == (uint32_t)i) continue;
+					const float dx = ox - p.t[0][j], dy = oy - p.t[1][j], dz = oz - p.t[2][j];
+					const float d2 = dx * dx + dy * dy + dz * dz;  // grid units^2
+					if (d2 < 1e-12f) {
+						// coincident pair: the reference adds a random unit-box vector (:584-587, std::random_device)
+						spring[0] += hash_unit((uint32_t)i, j, 0); spring[1] += hash_unit((uint32_t)i, j, 1);
+						spring[2] += hash_unit((uint32_t)i, j, 2);
+					} else {
+						const float kl = 1.0f - d2 * (float)mp.inv_re2;
+						if (kl > 0.0f) {
+							const float f = kl * kl * kl * rsqrtf(d2);
+							spring[0] += (double)(f * dx); spring[1] += (double)(f * dy); spring[2] += (double)(f * dz);
+						}
+					}
+				}
+			}
+	double from[3], to[3];
+#pragma unroll
+	for (int d = 0; d < 3; ++d) {
+		from[d] = (double)c[d] + (double)t[d];
+		double x = from[d] + spring[d] * mp.corr;
+		to[d] = x < 0.0 ? 0.0 : ((double)nn[d] < x ? (double)nn[d] : x);  // clamp to [offset, grid max] (:604-609)
+	}
+	collide(g, solid, from, to, mp.skin);
+	int nc[3];
+	float nt[3];
+#pragma unroll
+	for (int d = 0; d < 3; ++d) split_position(to[d], nn[d], nc[d], nt[d]);
+	out_key[i] = blocked_index(g, nc[0], nc[1], nc[2]);
+	out_tx[i] = nt[0]; out_ty[i] = nt[1]; out_tz[i] = nt[2];
+}
+}  // namespace
+
+static MoveParams move_params(const lfa_sim *s, double dt) {
+	MoveParams mp;
+	const double h = s->prm.cell_size, re = h / sqrt(2.0);
+	mp.dt_over_h = dt / h;
+	mp.skin = s->prm.boundary_skin_width / h;
+	mp.corr = dt * s->prm.correction_stiffness * re / h;
+	mp.inv_re2 = h * h / (re * re);
+	return mp;
+}
+
+extern "C" int lfa_advect_collide(lfa_sim *s, double dt) {
+	if (!s) return LFA_E_INVALID;
+	if (s->dist) return lfa_fail(s, LFA_E_UNSUPPORTED, "particle migration between slabs is not implemented: advect on one GPU");
+	LFA_HIP(s, hipSetDevice(s->device));
+	const size_t n = s->binned ? s->np_live : s->np;
+	if (n) {
+		hipLaunchKernelGGL(k_advect_collide, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, s->pb[s->cur], s->g,
+		                   s->solid, move_params(s, dt));
+		LFA_LAUNCH_CHECK(s);
+	}
+	s->unknown_count_valid = false;
+	return LFA_OK;
+}
+
+extern "C" int lfa_correct_collide(lfa_sim *s, double dt) {
+	if (!s) return LFA_E_INVALID;
+	if (s->dist) return lfa_fail(s, LFA_E_UNSUPPORTED, "particle migration between slabs is not implemented: correct on one GPU");
+	if (!s->binned) return lfa_fail(s, LFA_E_INVALID, "lfa_correct_collide: call lfa_hash_particles first");
+	LFA_HIP(s, hipSetDevice(s->device));
+	const size_t n = s->np_live;
+	if (!n) return LFA_OK;
+	if (!s->cell_start) {
+		hipError_t e = hipMalloc(&s->cell_start, s->ncp * 4);
+		if (e != hipSuccess) return lfa_fail(s, LFA_E_OOM, "hipMalloc of the per-cell start offsets failed");
+	}
+	const int grid = s->n_ptiles < 16384 ? (s->n_ptiles > 0 ? s->n_ptiles : 1) : 16384;
+	ParticleSoA &cur = s->pb[s->cur], &oth = s->pb[s->cur ^ 1];
+	hipLaunchKernelGGL(k_build_cell_index, dim3(grid), dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, cur.key, s->tile_start,
+	                   s->cell_start, s->rank);
+	LFA_LAUNCH_CHECK(s);
+	hipLaunchKernelGGL(k_correct_collide, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, cur, oth.key, oth.t[0],
+	                   oth.t[1], oth.t[2], s->g, s->solid, s->tile_flag, s->cell_count, s->cell_start, s->rank,
+	                   move_params(s, dt));
+	LFA_LAUNCH_CHECK(s);
+	// every particle read the OLD positions of its neighbours; now publish the new ones
+	LFA_HIP(s, hipMemcpyAsync(cur.key, oth.key, n * 4, hipMemcpyDeviceToDevice, s->stream));
+	for (int d = 0; d < 3; ++d) LFA_HIP(s, hipMemcpyAsync(cur.t[d], oth.t[d], n * 4, hipMemcpyDeviceToDevice, s->stream));
+	s->unknown_count_valid = false;
+	return LFA_OK;
+}
+
+/// Device-resident simulation::time_step(dt) (src/simulation.cpp:43-125) without fluid sources and host callbacks:
+/// advect+collide, hash, P2G, gravity, pressure solve, pressure gradient, correct+collide, extrapolate, hash, G2P.
+extern "C" int lfa_time_step(lfa_sim *s, double dt, double *residual, uint64_t *iterations) {
+	if (!s) return LFA_E_INVALID;
+	LFA_HIP(s, hipSetDevice(s->device));
+	const bool tm = s->timing;
+	if (tm) LFA_HIP(s, hipEventRecord(s->ev[10], s->stream));
+	LFA_TRY(lfa_advect_collide(s, dt));
+	if (tm) LFA_HIP(s, hipEventRecord(s->ev[11], s->stream));
+	LFA_TRY(lfa_hash_particles(s));
+	LFA_TRY(lfa_p2g_run(s, true, dt));
+	double res = 0.0;
+	uint64_t it = 0;
+	int rc = lfa_pcg_solve(s, dt, &res, &it);
+	if (rc < 0) return rc;
+	LFA_TRY(lfa_apply_pressure(s, dt));
+	if (tm) LFA_HIP(s, hipEventRecord(s->ev[12], s->stream));
+	LFA_TRY(lfa_correct_collide(s, dt));
+	if (tm) LFA_HIP(s, hipEventRecord(s->ev[13], s->stream));
+	LFA_TRY(lfa_extrapolate(s));  // the valid set is the one of the P2G-time hash, like the reference (:119)
+	// the G2P gathers per tile: re-bin the corrected positions first (the grid keeps the tile set of the P2G)
+	LFA_TRY(lfa_hash_particles(s));
+	LFA_TRY(lfa_g2p(s));
+	if (tm) {
+		LFA_HIP(s, hipEventRecord(s->ev[14], s->stream));
+		LFA_HIP(s, hipEventSynchronize(s->ev[14]));
+		float ms = 0.f;
+		LFA_HIP(s, hipEventElapsedTime(&ms, s->ev[10], s->ev[11])); s->ms_next[0] = ms;  // advect + collide
+		LFA_HIP(s, hipEventElapsedTime(&ms, s->ev[12], s->ev[13])); s->ms_next[1] = ms;  // correct + collide
+		LFA_HIP(s, hipEventElapsedTime(&ms, s->ev[10], s->ev[14])); s->ms_next[2] = ms;  // whole step
+	}
+	if (residual) *residual = res;
+	if (iterations) *iterations = it;
+	return rc;
+}
+
+extern "C" int lfa_get_step_timings(lfa_sim *s, double ms[3]) {
+	if (!s || !ms) return LFA_E_INVALID;
+	for (int k = 0; k < 3; ++k) ms[k] = s->ms_next[k];
+	return LFA_OK;
+}

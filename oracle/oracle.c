@@ -663,3 +663,165 @@ void orc_hot_step(void *hh, double dt, double *p_out, double *residual, uint64_t
 	if (iters) *iters = it;
 	if (!p_out) free(p);
 }
+
+/* =================================================================================================================
+ * "Next" rows of SURVEY.md 8(f), rank 1: the per-step particle stages either side of the hot path. Same status as the
+ * rest of this file: test infrastructure, pinned against oracle/_ref (tests/test_oracle.py).
+ * ================================================================================================================= */
+
+/* simulation::_advect_particles src/simulation.cpp:226-249 (without fluid sources: no velocity coercion). */
+void orc_advect(void *hh, double dt) {
+	orc_ctx *c = (orc_ctx *)hh;
+	double lo[3], hi[3];
+	for (int d = 0; d < 3; ++d) {
+		lo[d] = c->off[d] + c->skin;
+		hi[d] = c->h * (double)c->n[d] + c->off[d] - c->skin;
+	}
+	for (size_t i = 0; i < c->np; ++i) {
+		orc_particle *p = &c->p[i];
+		for (int d = 0; d < 3; ++d) {
+			p->pos[d] += p->vel[d] * dt;
+			/* std::clamp(v, lo, hi) */
+			p->pos[d] = p->pos[d] < lo[d] ? lo[d] : (hi[d] < p->pos[d] ? hi[d] : p->pos[d]);
+		}
+	}
+}
+
+static int solid_or_outside(const orc_ctx *c, int x, int y, int z) {
+	if (x < 0 || y < 0 || z < 0) return 1;
+	if ((size_t)x >= c->n[0] || (size_t)y >= c->n[1] || (size_t)z >= c->n[2]) return 1;
+	return c->grid[raw_of(c, (size_t)x, (size_t)y, (size_t)z)].type == T_SOLID;
+}
+
+/* simulation::_detect_collisions src/simulation.cpp:612-683 with grid::march_cells grid.h:140-209, followed by
+ * old_position = position (:57-59 / :115-117). */
+void orc_detect_collisions(void *hh) {
+	orc_ctx *c = (orc_ctx *)hh;
+	const double h = c->h, skin = c->skin;
+	for (size_t pi = 0; pi < c->np; ++pi) {
+		orc_particle *p = &c->p[pi];
+		double from[3] = {p->old_pos[0], p->old_pos[1], p->old_pos[2]}, to[3] = {p->pos[0], p->pos[1], p->pos[2]};
+		for (int bounce = 0; bounce < 3; ++bounce) {
+			int hit = 0;
+			double a[3], b[3], diff[3], inv[3], t[3];
+			int cur[3], last[3], adv[3];
+			for (int d = 0; d < 3; ++d) {
+				a[d] = (from[d] - c->off[d]) / h;
+				b[d] = (to[d] - c->off[d]) / h;
+				cur[d] = (int)floor(a[d]);
+				last[d] = (int)floor(b[d]);
+				diff[d] = b[d] - a[d];
+				adv[d] = diff[d] > 0.0 ? 1 : -1;
+				inv[d] = 1.0 / fabs(diff[d]);
+				t[d] = fabs((double)(cur[d] + (diff[d] > 0.0 ? 1 : 0)) - a[d]) * inv[d];
+			}
+			while (cur[0] != last[0] || cur[1] != last[1] || cur[2] != last[2]) {
+				int dim = 0;
+				double tmin = 2.0;
+				for (int d = 0; d < 3; ++d) if (t[d] < tmin) { tmin = t[d]; dim = d; }
+				if (!(tmin <= 1.0)) break; /* "emergency break", grid.h:196-199 */
+				cur[dim] += adv[dim];
+				if (solid_or_outside(c, cur[0], cur[1], cur[2])) {
+					/* normal = -advance on `dim`; dot(to - from, normal) */
+					double dn = (to[dim] - from[dim]) * (double)(-adv[dim]);
+					double tt = t[dim] + skin / dn;
+					if (tt < 0.0) tt = 0.0;
+					for (int d = 0; d < 3; ++d) from[d] = tt * to[d] + (1.0 - tt) * from[d];
+					to[dim] = from[dim];
+					hit = 1;
+					break;
+				}
+				t[dim] += inv[dim];
+			}
+			if (!hit) break;
+		}
+		for (int d = 0; d < 3; ++d) p->pos[d] = to[d];
+		/* skin of neighbouring solid cells / walls (:654-681) */
+		double gp[3], cp[3];
+		int ci[3];
+		for (int d = 0; d < 3; ++d) {
+			gp[d] = p->pos[d] - c->off[d];
+			ci[d] = (int)(size_t)(gp[d] / h);
+			cp[d] = gp[d] - (double)ci[d] * h;
+		}
+		const double skin_max = h - skin;
+		for (int d = 0; d < 3; ++d) {
+			if (cp[d] < skin) {
+				int q[3] = {ci[0], ci[1], ci[2]};
+				q[d] -= 1;
+				if (ci[d] == 0 || solid_or_outside(c, q[0], q[1], q[2])) p->pos[d] += skin - cp[d];
+			}
+			if (cp[d] > skin_max) {
+				int q[3] = {ci[0], ci[1], ci[2]};
+				q[d] += 1;
+				if ((size_t)(ci[d] + 1) >= c->n[d] || solid_or_outside(c, q[0], q[1], q[2])) p->pos[d] += skin_max - cp[d];
+			}
+		}
+		for (int d = 0; d < 3; ++d) p->old_pos[d] = p->pos[d];
+	}
+}
+
+/* simulation::_correct_positions src/simulation.cpp:562-610. Requires the space hash of the current positions.
+ * The coincident-particle jitter (:584-587) is random by design in the reference (std::random_device); here such a
+ * pair contributes nothing, and the fixtures contain no coincident particles. */
+void orc_correct_positions(void *hh, double dt) {
+	orc_ctx *c = (orc_ctx *)hh;
+	const double re = c->h / sqrt(2.0);
+	double (*moved)[3] = (double(*)[3])malloc((c->np ? c->np : 1) * sizeof(double[3]));
+	for (size_t i = 0; i < c->np; ++i) {
+		const orc_particle *p = &c->p[i];
+		size_t ci[3];
+		for (int d = 0; d < 3; ++d) ci[d] = (size_t)((p->pos[d] - c->off[d]) / c->h); /* compute_cell_index :13-15 */
+		double spring[3] = {0, 0, 0};
+		size_t x0 = ci[0] < 1 ? 0 : ci[0] - 1, y0 = ci[1] < 1 ? 0 : ci[1] - 1, z0 = ci[2] < 1 ? 0 : ci[2] - 1;
+		size_t x1 = ci[0] + 2 < c->n[0] ? ci[0] + 2 : c->n[0], y1 = ci[1] + 2 < c->n[1] ? ci[1] + 2 : c->n[1],
+		       z1 = ci[2] + 2 < c->n[2] ? ci[2] + 2 : c->n[2];
+		for (size_t z = z0; z < z1; ++z)
+			for (size_t y = y0; y < y1; ++y)
+				for (size_t x = x0; x < x1; ++x) {
+					size_t r = raw_of(c, x, y, z);
+					const orc_particle *o = c->p + c->hbegin[r];
+					for (uint64_t k = 0; k < c->hcount[r]; ++k, ++o) {
+						if (o == p) continue;
+						double off[3] = {p->pos[0] - o->pos[0], p->pos[1] - o->pos[1], p->pos[2] - o->pos[2]};
+						double d2 = 0.0;
+						d2 += off[0] * off[0]; d2 += off[1] * off[1]; d2 += off[2] * off[2];
+						if (d2 < 1e-12) continue;
+						double kl = 1.0 - d2 / (re * re), w = 0.0;
+						if (kl > 0.0) w = kl * kl * kl;
+						double f = w / sqrt(d2);
+						for (int d = 0; d < 3; ++d) spring[d] += f * off[d];
+					}
+				}
+		const double s = dt * c->stiffness * re;
+		for (int d = 0; d < 3; ++d) moved[i][d] = p->pos[d] + spring[d] * s;
+	}
+	for (size_t i = 0; i < c->np; ++i)
+		for (int d = 0; d < 3; ++d) {
+			double hi = c->off[d] + (double)c->n[d] * c->h, v = moved[i][d];
+			c->p[i].pos[d] = v < c->off[d] ? c->off[d] : (hi < v ? hi : v);
+		}
+	free(moved);
+}
+
+/* simulation::time_step(dt) src/simulation.cpp:43-125 without sources and callbacks. */
+void orc_time_step(void *hh, double dt, double *residual, uint64_t *iters) {
+	orc_ctx *c = (orc_ctx *)hh;
+	orc_hash(c);
+	orc_advect(c, dt);
+	orc_detect_collisions(c);
+	orc_hash(c);
+	orc_p2g(c);
+	orc_add_gravity(c, dt);
+	double *p = (double *)malloc((c->nfluid ? c->nfluid : 1) * 8), res;
+	uint64_t it;
+	orc_solve(c, dt, p, &res, &it);
+	orc_apply_pressure(c, dt, p);
+	orc_correct_positions(c, dt);
+	orc_detect_collisions(c);
+	orc_extrapolate(c);
+	orc_g2p(c);
+	if (residual) *residual = res;
+	if (iters) *iters = it;
+	free(p);
+}

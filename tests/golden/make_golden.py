@@ -6,6 +6,7 @@ libfluid_amd/scenes.py with fixed seeds, outputs are what the reference computed
 oracle/oracle.c (tests/test_oracle.py) and, through it, the HIP path (tests/test_gpu_parity.py):
   <case>.npz         every stage of two hot-path passes (tests/util.py:staged_cpu_run)
   fullstep_flip.npz  particles after three full simulation::time_step(dt) calls (tests/test_host_class.py)
+  next_stages.npz    positions after advect+collide and after correct+collide (tests/test_next_rows.py)
 A fixture is data only: stage outputs as fp64/integer arrays.
 """
 import ctypes as C
@@ -39,6 +40,14 @@ def make_fullstep():
     print("fullstep_flip", iters, os.path.getsize(util.golden_path("fullstep_flip")) // 1024, "KiB")
 
 
+def make_next_stages():
+    """Particle stages around the hot path: advect -> collide -> hash -> correct -> collide."""
+    from tests.test_next_rows import next_inputs, run_next_cpu
+    rec = run_next_cpu("ref")
+    np.savez_compressed(util.golden_path("next_stages"), **rec)
+    print("next_stages", os.path.getsize(util.golden_path("next_stages")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     orc.build()
     if not orc.have_ref():
@@ -49,3 +58,4 @@ if __name__ == "__main__":
         print(name, {k: int(rec[k]) for k in rec if k.startswith("iters")},
               os.path.getsize(util.golden_path(name)) // 1024, "KiB")
     make_fullstep()
+    make_next_stages()
