@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-full-step", action="store_true")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent copies of the domain instead of z-slabs")
     args = ap.parse_args()
 
@@ -228,6 +229,21 @@ def main():
                     "frac": (p2g_bytes + fin_bytes) / (kernels["p2g_scatter"]["ms"] + kernels["p2g_finalize"]["ms"])
                     * 1e-6 / HBM_PEAK_GBS},
         }
+    if world == 1 and not args.no_full_step:
+        # beyond the headline: the device-resident simulation::time_step(dt) (hot path + advect/collide/correct, SURVEY 8f
+        # rank 1), dt = min(cfl_number * cfl, 0.033) like simulation::time_step() (src/simulation.cpp:127-129)
+        fs_ms, fs_iters, n_fs = 0.0, 0, 3
+        t1 = time.perf_counter()
+        for _ in range(n_fs):
+            dt_fs = min(3.0 * sim.cfl(), 0.033)
+            _, it, _ = sim.time_step(dt_fs)
+            fs_iters += it
+        sim.synchronize()
+        fs_s = time.perf_counter() - t1
+        out["full_time_step"] = {"steps": n_fs, "ms_per_step": 1e3 * fs_s / n_fs, "particle_steps_per_sec": npart * n_fs / fs_s,
+                                 "pcg_iterations_per_step": fs_iters / n_fs, "stage_ms": sim.step_timings(),
+                                 "note": "device resident: advect+collide, bin, P2G, PCG, apply, correct+collide, "
+                                         "extrapolate, bin, G2P"}
     sim.close()
 
     if rank == 0:

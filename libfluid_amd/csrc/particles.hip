@@ -102,6 +102,14 @@ __device__ inline void split_position(double p, int n, int &cell, float &t) {
 	t = tf;
 }
 
+#define CORR_ZT 4                          // own cells per workgroup: 8 x 8 x CORR_ZT
+#define CORR_PARTS (8 / CORR_ZT)           // workgroups per tile
+#define CORR_HCELLS (100 * (CORR_ZT + 2))  // halo block 10 x 10 x (CORR_ZT + 2)
+#define CORR_CAP 5632
+#define CORR_OWN 3072
+#define CORR_THREADS 512                   // 8 waves per workgroup, 2 workgroups per CU (LDS)
+#define CORR_CPT ((CORR_HCELLS + CORR_THREADS - 1) / CORR_THREADS)
+
 struct MoveParams {
 	double dt_over_h;   // dt / cell_size
 	double skin;        // boundary_skin_width / cell_size
@@ -186,11 +194,16 @@ __device__ inline float hash_unit(uint32_t a, uint32_t b, uint32_t k) {
 __global__ void __launch_bounds__(256)
 k_correct_collide(size_t n, ParticleSoA p, uint32_t *out_key, float *out_tx, float *out_ty, float *out_tz, GridDims g,
                   const uint8_t *solid, const uint32_t *tile_flag, const uint32_t *cell_count, const uint32_t *cell_start,
-                  const uint32_t *cidx, MoveParams mp) {
+                  const uint32_t *cidx, MoveParams mp, const uint32_t *only_flagged, const int *tile_pslot, int p_off) {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
+	const uint32_t key_i = p.key[i];
+	if (only_flagged) {  // fallback pass: only particles of the half tiles the LDS-tiled kernel could not hold
+		const int work = CORR_PARTS * (tile_pslot[key_i >> 9] - p_off) + (int)(((key_i >> 6) & 7) / CORR_ZT);
+		if (!((only_flagged[work >> 5] >> (work & 31)) & 1u)) return;
+	}
 	int c[3];
-	cell_of_key(g, p.key[i], c);
+	cell_of_key(g, key_i, c);
 	const float t[3] = {p.t[0][i], p.t[1][i], p.t[2][i]};
 	const int nn[3] = {g.nx, g.ny, g.nz};
 	int lo[3], hi[3];
@@ -245,6 +258,166 @@ k_correct_collide(size_t n, ParticleSoA p, uint32_t *out_key, float *out_tx, flo
 	out_key[i] = blocked_index(g, nc[0], nc[1], nc[2]);
 	out_tx[i] = nt[0]; out_ty[i] = nt[1]; out_tz[i] = nt[2];
 }
+
+/// LDS-tiled _correct_positions + _detect_collisions. One workgroup per (particle tile, z-half): the positions of every
+/// particle in the 10x10x6 cells around the 8x8x4 half tile are staged in LDS once (tile-relative fp32), then one thread
+/// per cell walks the 27-cell neighbourhoods of its particles out of LDS. The per-particle global gather of
+/// k_correct_collide (216 dependent index->position loads) was latency-bound: 264 ms at C4.
+/// A half tile whose neighbourhood does not fit CORR_CAP particles sets *overflow and is left to k_correct_collide.
+__global__ void __launch_bounds__(CORR_THREADS)
+k_correct_tiled(const int *ptiles, int n_ptiles, ParticleSoA p, uint32_t *out_key, float *out_tx, float *out_ty, float *out_tz,
+                GridDims g, const uint8_t *solid, const uint32_t *tile_flag, const uint32_t *cell_count,
+                const uint32_t *cell_start, const uint32_t *cidx, MoveParams mp, uint32_t *overflow_tiles) {
+	__shared__ uint32_t off[CORR_HCELLS + 1];
+	__shared__ uint32_t gstart[CORR_HCELLS];
+	__shared__ float px[CORR_CAP], py[CORR_CAP], pz[CORR_CAP];
+	__shared__ uint16_t own[CORR_OWN];  // (halo cell << 6 | index in cell) of the particles this workgroup moves
+	__shared__ uint32_t wsum[CORR_THREADS / 64], n_own;
+	const int nn[3] = {g.nx, g.ny, g.nz};
+	for (int work = blockIdx.x; work < CORR_PARTS * n_ptiles; work += gridDim.x) {
+		const int tile = ptiles[work / CORR_PARTS], half = work % CORR_PARTS;
+		int tx, ty, tz;
+		tile_coords(g, tile, tx, ty, tz);
+		const int ox = tx * 8 - 1, oy = ty * 8 - 1, oz = tz * 8 + CORR_ZT * half - 1;  // origin of the halo block
+		__syncthreads();
+		// ---- counts of the 600 halo cells, exclusive scan
+		uint32_t c3[CORR_CPT], sum = 0;
+#pragma unroll
+		for (int k = 0; k < CORR_CPT; ++k) {
+			const int h = CORR_CPT * threadIdx.x + k;
+			uint32_t cnt = 0, st = 0;
+			if (h < CORR_HCELLS) {
+				const int x = ox + h % 10, y = oy + (h / 10) % 10, z = oz + h / 100;
+				if (in_grid(g, x, y, z)) {
+					const uint32_t b = blocked_index(g, x, y, z);
+					if (tile_flag[b >> 9]) {
+						cnt = cell_count[b];
+						st = cnt ? cell_start[b] : 0;
+					}
+				}
+				gstart[h] = st;
+			}
+			c3[k] = cnt;
+			sum += cnt;
+		}
+		uint32_t incl = sum;
+		const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			uint32_t t = __shfl_up(incl, o, 64);
+			if (lane >= o) incl += t;
+		}
+		if (lane == 63) wsum[wid] = incl;
+		__syncthreads();
+		uint32_t woff = 0, total = 0;
+		for (int w = 0; w < CORR_THREADS / 64; ++w) {
+			if (w < wid) woff += wsum[w];
+			total += wsum[w];
+		}
+		uint32_t ex = woff + incl - sum;
+#pragma unroll
+		for (int k = 0; k < CORR_CPT; ++k) {
+			const int h = CORR_CPT * threadIdx.x + k;
+			if (h < CORR_HCELLS) off[h] = ex;
+			ex += c3[k];
+		}
+		if (threadIdx.x == 0) {
+			off[CORR_HCELLS] = total;
+			n_own = 0;
+		}
+		__syncthreads();
+		// own particles = those of the 8 x 8 x 4 interior cells
+		uint32_t own_total = 0;
+		{
+			const int lx = threadIdx.x & 7, ly = (threadIdx.x >> 3) & 7, lz = threadIdx.x >> 6;
+			if (threadIdx.x < 64 * CORR_ZT) {
+				const int hc = (lx + 1) + 10 * (ly + 1) + 100 * (lz + 1);
+				const uint32_t cnt = off[hc + 1] - off[hc];
+				const uint32_t base = atomicAdd(&n_own, cnt);
+				if (cnt > 63) atomicAdd(&n_own, 4096u);  // does not fit the packing: force the fallback
+				for (uint32_t k = 0; k < cnt && k < 64 && base + k < CORR_OWN; ++k) own[base + k] = (uint16_t)((hc << 6) | k);
+			}
+		}
+		__syncthreads();
+		own_total = n_own;
+		if (total > CORR_CAP || own_total > CORR_OWN) {
+			if (threadIdx.x == 0) atomicOr(&overflow_tiles[work >> 5], 1u << (work & 31));
+			continue;
+		}
+		// ---- stage positions (relative to the halo block origin, in cells)
+		for (int h = threadIdx.x; h < CORR_HCELLS; h += CORR_THREADS) {
+			const uint32_t o = off[h], cnt = off[h + 1] - o, st = gstart[h];
+			const float bx = (float)(h % 10), by = (float)((h / 10) % 10), bz = (float)(h / 100);
+			for (uint32_t k = 0; k < cnt; ++k) {
+				const uint32_t j = cidx[st + k];
+				px[o + k] = bx + p.t[0][j];
+				py[o + k] = by + p.t[1][j];
+				pz[o + k] = bz + p.t[2][j];
+			}
+		}
+		__syncthreads();
+		// ---- one thread per own particle
+		for (uint32_t w = threadIdx.x; w < own_total; w += CORR_THREADS) {
+			const int hc = (int)(own[w] >> 6);
+			const uint32_t k0 = own[w] & 63u;
+			const int cx = ox + hc % 10, cy = oy + (hc / 10) % 10, cz = oz + hc / 100;
+			const uint32_t me = off[hc] + k0;
+			const float mx = px[me], my = py[me], mz = pz[me];
+			const uint32_t j = cidx[gstart[hc] + k0];
+			const float tme[3] = {p.t[0][j], p.t[1][j], p.t[2][j]};  // exact fraction (the staged copy is block-relative)
+			const int c[3] = {cx, cy, cz};
+			int lo[3], hi[3];
+			const float re = rsqrtf((float)mp.inv_re2);  // kernel radius in cells: pairs further apart contribute exactly 0
+#pragma unroll
+			for (int d = 0; d < 3; ++d) {
+				const int ci = c[d] + (tme[d] >= 1.0f ? 1 : 0);  // unclamped index of compute_cell_index (:13-15)
+				const float tc = tme[d] >= 1.0f ? 0.0f : tme[d];
+				// the reference visits ci-1..ci+1; a neighbour cell whose nearest face is >= re away cannot hold a partner
+				lo[d] = (ci - 1 < 0 || tc >= re) ? ci : ci - 1;
+				hi[d] = (ci + 1 > nn[d] - 1 || 1.0f - tc >= re) ? ci : ci + 1;
+				if (lo[d] > nn[d] - 1) lo[d] = nn[d] - 1;
+				if (hi[d] > nn[d] - 1) hi[d] = nn[d] - 1;
+			}
+			float sx = 0.f, sy = 0.f, sz = 0.f;
+			const float inv_re2 = (float)mp.inv_re2;
+			for (int zz = lo[2]; zz <= hi[2]; ++zz)
+				for (int yy = lo[1]; yy <= hi[1]; ++yy) {
+					// the x-run of up to three cells is contiguous in the halo block: one LDS range
+					const int hrow = (lo[0] - ox) + 10 * (yy - oy) + 100 * (zz - oz);
+					const uint32_t b = off[hrow], e = off[hrow + (hi[0] - lo[0]) + 1];
+					for (uint32_t q = b; q < e; ++q) {
+						const float dx = mx - px[q], dy = my - py[q], dz = mz - pz[q];
+						const float d2 = dx * dx + dy * dy + dz * dz;
+						const float kl = 1.0f - d2 * inv_re2;
+						if (kl > 0.0f && q != me) {  // ~1 pair in 10 is inside the kernel radius
+							if (d2 < 1e-12f) {  // coincident: the reference adds a random unit-box vector (:584-587)
+								sx += hash_unit(me, q, 0); sy += hash_unit(me, q, 1); sz += hash_unit(me, q, 2);
+							} else {
+								const float f = kl * kl * kl * rsqrtf(d2);
+								sx += f * dx; sy += f * dy; sz += f * dz;
+							}
+						}
+					}
+				}
+			const double spring[3] = {(double)sx, (double)sy, (double)sz};
+			double from[3], to[3];
+#pragma unroll
+			for (int d = 0; d < 3; ++d) {
+				from[d] = (double)c[d] + (double)tme[d];
+				double x = from[d] + spring[d] * mp.corr;
+				to[d] = x < 0.0 ? 0.0 : ((double)nn[d] < x ? (double)nn[d] : x);
+			}
+			collide(g, solid, from, to, mp.skin);
+			int nc[3];
+			float nt[3];
+#pragma unroll
+			for (int d = 0; d < 3; ++d) split_position(to[d], nn[d], nc[d], nt[d]);
+			out_key[j] = blocked_index(g, nc[0], nc[1], nc[2]);
+			out_tx[j] = nt[0]; out_ty[j] = nt[1]; out_tz[j] = nt[2];
+		}
+	}
+}
+
 }  // namespace
 
 static MoveParams move_params(const lfa_sim *s, double dt) {
@@ -287,9 +460,22 @@ extern "C" int lfa_correct_collide(lfa_sim *s, double dt) {
 	hipLaunchKernelGGL(k_build_cell_index, dim3(grid), dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, cur.key, s->tile_start,
 	                   s->cell_start, s->rank);
 	LFA_LAUNCH_CHECK(s);
+	// LDS-tiled pass; half tiles whose neighbourhood exceeds the LDS capacity are flagged and redone by the global-gather
+	// kernel (restricted to those particles)
+	uint32_t *ovf = (uint32_t *)s->partials;  // scratch: 2 * n_ptiles bits
+	const size_t ovf_words = ((size_t)CORR_PARTS * s->n_ptiles + 31) / 32 + 1;
+	if (ovf_words * 4 > 16384 * 8) return lfa_fail(s, LFA_E_INVALID, "too many particle tiles for the overflow bitmap");
+	LFA_HIP(s, hipMemsetAsync(ovf, 0, ovf_words * 4, s->stream));
+	{
+		const int work = CORR_PARTS * s->n_ptiles, g2 = work < 65536 ? (work > 0 ? work : 1) : 65536;
+		hipLaunchKernelGGL(k_correct_tiled, dim3(g2), dim3(CORR_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, cur, oth.key, oth.t[0],
+		                   oth.t[1], oth.t[2], s->g, s->solid, s->tile_flag, s->cell_count, s->cell_start, s->rank,
+		                   move_params(s, dt), ovf);
+		LFA_LAUNCH_CHECK(s);
+	}
 	hipLaunchKernelGGL(k_correct_collide, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, cur, oth.key, oth.t[0],
 	                   oth.t[1], oth.t[2], s->g, s->solid, s->tile_flag, s->cell_count, s->cell_start, s->rank,
-	                   move_params(s, dt));
+	                   move_params(s, dt), (const uint32_t *)ovf, (const int *)s->tile_pslot, s->p_off);
 	LFA_LAUNCH_CHECK(s);
 	// every particle read the OLD positions of its neighbours; now publish the new ones
 	LFA_HIP(s, hipMemcpyAsync(cur.key, oth.key, n * 4, hipMemcpyDeviceToDevice, s->stream));
