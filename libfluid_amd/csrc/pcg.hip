@@ -23,6 +23,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
 
 namespace {
@@ -270,6 +272,7 @@ template <typename real> struct CoarseFields {
 	const float *diag, *w[3];
 	const uint8_t *unk;
 	real *pre, *r, *x;
+	real w1 = (real)1, w2 = (real)1;  // weights of the level-1 / level-2 corrections in the additive preconditioner
 };
 
 
@@ -350,7 +353,7 @@ __device__ inline void coarse_block(char *smem, const int *l1_tiles, int n_l1, C
 		}
 #pragma unroll
 		for (int zz = 0; zz < 8; ++zz) {
-			const real x1 = Q[zz * 64 + lane];
+			const real x1 = c.w1 * Q[zz * 64 + lane];
 			c.x[base + zz * 64 + lane] = x1;
 			dot1 += (double)x1 * (double)rr[zz];
 		}
@@ -388,9 +391,15 @@ __device__ inline void coarse_block(char *smem, const int *l1_tiles, int n_l1, C
 	}
 	__syncthreads();
 	// top level: x2 = A2^-1 r2 (dense). Its prolongation onto the tiles happens in k_update_s; its share of z.r is x2.r2.
+	// The inverse (<= 64 x 64) is staged in LDS with one coalesced pass (the sweep buffers are free now): a row loop over
+	// global memory would be n_l1 dependent L2 round trips on the critical path of the launch.
+	real *a2s = (real *)smem;
+	for (int i = threadIdx.x; i < n_l1 * n_l1; i += WAVES * 64) a2s[i] = a2inv[i];
+	__syncthreads();
 	for (int row = threadIdx.x; row < n_l1; row += WAVES * 64) {
 		double acc = 0.0;
-		for (int k = 0; k < n_l1; ++k) acc += (double)a2inv[(size_t)row * n_l1 + k] * r2s[k];
+		for (int k = 0; k < n_l1; ++k) acc += (double)a2s[row * n_l1 + k] * r2s[k];
+		acc *= (double)c.w2;
 		x2s[row] = acc * r2s[row];
 		x2_out[row] = (real)acc;
 	}
@@ -909,8 +918,11 @@ static bool is_ml(const lfa_sim *s) { return s->prm.precond == LFA_PRECOND_MULTI
 static int sigma_parts(const lfa_sim *s) { return pcg_grid(s->n_ptiles) + (is_ml(s) ? 1 : 0); }
 
 template <typename real> static CoarseFields<real> make_coarse(lfa_sim *s) {
-	return CoarseFields<real>{s->c_diag, {s->c_w[0], s->c_w[1], s->c_w[2]}, s->c_unk, (real *)s->c_pre, (real *)s->c_r,
-	                          (real *)s->c_x};
+	CoarseFields<real> cf{s->c_diag, {s->c_w[0], s->c_w[1], s->c_w[2]}, s->c_unk, (real *)s->c_pre, (real *)s->c_r,
+	                      (real *)s->c_x};
+	if (const char *e = getenv("LFA_COARSE_W1")) cf.w1 = (real)atof(e);  // experiment knobs (tools/pcg_convergence.py)
+	if (const char *e = getenv("LFA_COARSE_W2")) cf.w2 = (real)atof(e);
+	return cf;
 }
 
 /// Dense SPD inverse by Cholesky (n2 is the number of 64^3-cell aggregates that hold fluid: tens, at most 512).
