@@ -101,6 +101,10 @@ int lfa_upload_particles(lfa_sim *s, const void *aos152, uint64_t n);
 enum { LFA_DL_POSITIONS = 1, LFA_DL_KEEP_RAW = 2 };
 int lfa_download_particles(lfa_sim *s, void *aos152, uint64_t n, int flags);
 uint64_t lfa_num_particles(const lfa_sim *s);
+/* With a slab decomposition particles migrate between ranks: lfa_num_particles is the number resident on this rank
+ * after the last lfa_hash_particles, lfa_download_particles writes them in storage order, and this call returns the
+ * global id of each record (upload index / index in the seeded block). Single domain: ids[i] = i. */
+int lfa_download_particle_ids(lfa_sim *s, uint32_t *ids, uint64_t n);
 /* Synthetic dam-break block [lo,hi) in cells, 8 jittered particles per cell, generated on the device; bit-identical
  * to libfluid_amd/scenes.py:seed_block. */
 int lfa_seed_block(lfa_sim *s, const int64_t lo[3], const int64_t hi[3], uint64_t seed);
@@ -158,7 +162,10 @@ int lfa_step_hot(lfa_sim *s, double dt, double *residual, uint64_t *iterations);
  *                      needs lfa_hash_particles of the current positions
  * lfa_time_step      : simulation::time_step(dt) (:43-125) entirely on the device: advect+collide, hash, P2G, gravity,
  *                      pressure solve, pressure gradient, correct+collide, extrapolate, hash, G2P. No sources, no callbacks
- *                      (the host class falls back to stage calls when it needs them); single GPU. */
+ *                      (the host class falls back to stage calls when it needs them).
+ * With a slab decomposition both move stages end with the particle migration: particles whose cell left the owned tile
+ * layers are packed (68 B records) and handed to the neighbour rank, arrivals are appended; lfa_correct_collide first
+ * fetches ghost copies (key + fraction) of the neighbours' adjacent tile layers, so pairs across a slab face interact. */
 int lfa_advect_collide(lfa_sim *s, double dt);
 int lfa_correct_collide(lfa_sim *s, double dt);
 int lfa_time_step(lfa_sim *s, double dt, double *residual, uint64_t *iterations);

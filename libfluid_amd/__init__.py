@@ -70,6 +70,7 @@ SIGNATURES = {
     "lfa_stream": (_vp, [_vp]),
     "lfa_upload_particles": (_int, [_vp, _vp, _u64]),
     "lfa_download_particles": (_int, [_vp, _vp, _u64, _int]),
+    "lfa_download_particle_ids": (_int, [_vp, _vp, _u64]),
     "lfa_num_particles": (_u64, [_vp]),
     "lfa_seed_block": (_int, [_vp, _vp, _vp, _u64]),
     "lfa_set_solid_cells": (_int, [_vp, _vp, _u64]),
@@ -240,6 +241,13 @@ class Sim:
         out = np.zeros(n, dtype=PARTICLE_DTYPE) if into is None else into
         self._chk(self.lib.lfa_download_particles(self.h, _ptr(out), n, 1 if (write_positions or into is None) else 0))
         return out
+
+    def particle_ids(self):
+        """Global id of each record of download_particles() (slab decomposition: particles migrate between ranks)."""
+        n = self.num_particles
+        ids = np.zeros(n, dtype=np.uint32)
+        self._chk(self.lib.lfa_download_particle_ids(self.h, _ptr(ids), n))
+        return ids
 
     @property
     def num_particles(self):

@@ -81,6 +81,8 @@ struct lfa_sim {
 	size_t xcap[4] = {0, 0, 0, 0};
 	double *dist_red = nullptr;             // all-reduced scalars
 	size_t np_live = 0;
+	bool holes = false;  // slabs: leavers were invalidated in place since the last binning
+	size_t ghost_at[2] = {0, 0}, n_ghost_particles = 0;  // ghost particles (key, t only) behind the live ones
 
 	// tiles
 	uint32_t *tile_count = nullptr, *tile_start = nullptr;  // nt, nt+1
@@ -224,3 +226,6 @@ int lfa_dist_exchange_p2g_planes(lfa_sim *s, float *stage_all);
 int lfa_dist_exchange_slices(lfa_sim *s, void *vec, int elem_bytes);
 int lfa_dist_allreduce(lfa_sim *s, const double *partials, int n, int slot, bool is_max);  // result in dist_red[slot]
 int lfa_dist_ensure_xbuf(lfa_sim *s, int which, size_t bytes);
+int lfa_dist_migrate(lfa_sim *s);
+int lfa_dist_exchange_ghost_particles(lfa_sim *s);
+int lfa_particles_reserve(lfa_sim *s, size_t n_keep, size_t n_total);

@@ -341,6 +341,33 @@ int lfa_particles_alloc(lfa_sim *s, size_t n) {
 	return LFA_OK;
 }
 
+/// Grows the particle arrays to hold n_total particles, keeping the first n_keep of the current buffer.
+int lfa_particles_reserve(lfa_sim *s, size_t n_keep, size_t n_total) {
+	if (n_total <= s->pcap) return LFA_OK;
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	const size_t cap = ((n_total + n_total / 8) + 1023) & ~(size_t)1023, old_cap = s->pcap;
+	ParticleSoA keep = s->pb[s->cur];
+	void *keep_base = keep.base;
+	s->pb[s->cur].base = nullptr;  // detach so that the reallocation below does not free it
+	s->pcap = 0;
+	int rc = lfa_particles_alloc(s, cap);
+	if (rc != LFA_OK) return rc;
+	ParticleSoA &dst = s->pb[s->cur];
+	const uint32_t *src_arrays[17];
+	uint32_t *dst_arrays[17];
+	src_arrays[0] = keep.key; dst_arrays[0] = dst.key;
+	for (int k = 0; k < 3; ++k) { src_arrays[1 + k] = (uint32_t *)keep.t[k]; dst_arrays[1 + k] = (uint32_t *)dst.t[k]; }
+	for (int k = 0; k < 3; ++k) { src_arrays[4 + k] = (uint32_t *)keep.v[k]; dst_arrays[4 + k] = (uint32_t *)dst.v[k]; }
+	for (int k = 0; k < 9; ++k) { src_arrays[7 + k] = (uint32_t *)keep.c[k]; dst_arrays[7 + k] = (uint32_t *)dst.c[k]; }
+	src_arrays[16] = keep.id; dst_arrays[16] = dst.id;
+	for (int a = 0; a < 17; ++a)
+		if (n_keep) LFA_HIP(s, hipMemcpyAsync(dst_arrays[a], src_arrays[a], n_keep * 4, hipMemcpyDeviceToDevice, s->stream));
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	(void)old_cap;
+	if (keep_base) LFA_HIP(s, hipFree(keep_base));
+	return LFA_OK;
+}
+
 struct IngestParams {
 	double off[3], h;
 };
@@ -409,10 +436,11 @@ extern "C" int lfa_upload_particles(lfa_sim *s, const void *aos152, uint64_t n) 
 	return LFA_OK;
 }
 
-__global__ void k_export(double *aos, size_t n, ParticleSoA p, GridDims g, IngestParams ip, int flags) {
+__global__ void k_export(double *aos, size_t n, ParticleSoA p, GridDims g, IngestParams ip, int flags, int by_slot) {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	double *q = aos + (size_t)p.id[i] * 19;
+	// slab decomposition: particles migrate between ranks, so a rank's records come out in storage order (ids separately)
+	double *q = aos + (by_slot ? i : (size_t)p.id[i]) * 19;
 	uint32_t b = p.key[i];
 	if (flags & LFA_DL_POSITIONS) {
 		int tile = (int)(b >> 9), l = (int)(b & 511), tx, ty, tz;
@@ -437,6 +465,8 @@ extern "C" int lfa_download_particles(lfa_sim *s, void *aos152, uint64_t n, int 
 	if (n != s->np) return lfa_fail(s, LFA_E_INVALID, "download of %llu particles but %zu are resident",
 	                                (unsigned long long)n, s->np);
 	if (n == 0) return LFA_OK;
+	if (s->dist && (!s->binned || s->holes))
+		return lfa_fail(s, LFA_E_INVALID, "slab decomposition: call lfa_hash_particles before downloading particles");
 	LFA_HIP(s, hipSetDevice(s->device));
 	LFA_TRY(lfa_ensure_io(s, n * 152));
 	// start from the caller's records so fields the device does not own (positions unless asked) survive
@@ -445,9 +475,24 @@ extern "C" int lfa_download_particles(lfa_sim *s, void *aos152, uint64_t n, int 
 	for (int k = 0; k < 3; ++k) ip.off[k] = s->prm.grid_offset[k];
 	ip.h = s->prm.cell_size;
 	hipLaunchKernelGGL(k_export, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, (double *)s->io_buf,
-	                   s->np_live, s->pb[s->cur], s->g, ip, flags);
+	                   s->np_live, s->pb[s->cur], s->g, ip, flags, s->dist ? 1 : 0);
 	LFA_LAUNCH_CHECK(s);
 	LFA_HIP(s, hipMemcpyAsync(aos152, s->io_buf, n * 152, hipMemcpyDeviceToHost, s->stream));
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	return LFA_OK;
+}
+
+extern "C" int lfa_download_particle_ids(lfa_sim *s, uint32_t *ids, uint64_t n) {
+	if (!s || (!ids && n)) return LFA_E_INVALID;
+	if (n != s->np) return lfa_fail(s, LFA_E_INVALID, "download of %llu ids but %zu particles are resident", (unsigned long long)n, s->np);
+	if (n == 0) return LFA_OK;
+	LFA_HIP(s, hipSetDevice(s->device));
+	if (!s->dist) {  // single domain: record i of a download IS particle i
+		for (uint64_t i = 0; i < n; ++i) ids[i] = (uint32_t)i;
+		return LFA_OK;
+	}
+	if (!s->binned || s->holes) return lfa_fail(s, LFA_E_INVALID, "slab decomposition: call lfa_hash_particles before downloading ids");
+	LFA_HIP(s, hipMemcpyAsync(ids, s->pb[s->cur].id, n * 4, hipMemcpyDeviceToHost, s->stream));
 	LFA_HIP(s, hipStreamSynchronize(s->stream));
 	return LFA_OK;
 }
@@ -460,7 +505,7 @@ __device__ inline uint64_t splitmix64(uint64_t x) {
 	return x;
 }
 __global__ void k_seed_block(size_t n, size_t first, ParticleSoA p, GridDims g, IngestParams ip, int lox, int loy, int loz,
-                             int ex, int ey, uint64_t seed) {
+                             int ex, int ey, uint64_t seed, int global_ids) {
 	size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (j >= n) return;
 	const size_t i = j + first;  // index in the whole block
@@ -487,7 +532,7 @@ __global__ void k_seed_block(size_t n, size_t first, ParticleSoA p, GridDims g, 
 	}
 #pragma unroll
 	for (int k = 0; k < 9; ++k) p.c[k][j] = 0.0f;
-	p.id[j] = (uint32_t)j;
+	p.id[j] = (uint32_t)(global_ids ? i : j);
 }
 
 extern "C" int lfa_seed_block(lfa_sim *s, const int64_t lo[3], const int64_t hi[3], uint64_t seed) {
@@ -521,7 +566,7 @@ extern "C" int lfa_seed_block(lfa_sim *s, const int64_t lo[3], const int64_t hi[
 	ip.h = s->prm.cell_size;
 	if (n) {
 		hipLaunchKernelGGL(k_seed_block, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, first, s->pb[0], s->g,
-		                   ip, (int)lo[0], (int)lo[1], (int)lo[2], (int)(hi[0] - lo[0]), (int)(hi[1] - lo[1]), seed);
+		                   ip, (int)lo[0], (int)lo[1], (int)lo[2], (int)(hi[0] - lo[0]), (int)(hi[1] - lo[1]), seed, s->dist ? 1 : 0);
 		LFA_LAUNCH_CHECK(s);
 	}
 	return LFA_OK;
@@ -803,6 +848,8 @@ extern "C" int lfa_hash_particles(lfa_sim *s) {
 	LFA_LAUNCH_CHECK(s);
 	LFA_TRY(compact_tiles(s, s->tile_flag, all_lo, all_hi, s->ptiles_all, s->tile_pslot, &s->n_ptiles_all));
 	s->np_live = s->h_pinned[8];
+	if (s->dist) s->np = s->np_live;  // particles migrate: the resident count is the live count
+	s->holes = false;
 	// counts per layer group = differences of the scan at the layer boundaries
 	{
 		int marks[4] = {own_lo, own_lo + L < own_hi ? own_lo + L : own_hi, own_hi - L > own_lo ? own_hi - L : own_lo, own_hi};

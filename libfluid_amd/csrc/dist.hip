@@ -224,6 +224,168 @@ int lfa_dist_allreduce(lfa_sim *s, const double *partials, int n, int slot, bool
 	return s->dist->allreduce(s, s->dist_red + slot, 1, is_max);
 }
 
+
+// ================================================================================================= particle migration
+namespace {
+/// Particles whose new cell lies outside the owned tile layers leave for the neighbour slab: their 17-word records are
+/// appended to the lo / hi send buffer (wave-aggregated append) and their key is invalidated (the next binning drops it).
+__global__ void __launch_bounds__(256)
+k_pack_leavers(size_t n, ParticleSoA p, int tiles_per_layer, int slab_lo, int slab_hi, uint32_t *counters, uint32_t *buf_lo,
+               uint32_t *buf_hi, int count_only) {
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	int dest = -1;
+	uint32_t key = 0xFFFFFFFFu;
+	if (i < n) {
+		key = p.key[i];
+		if (key != 0xFFFFFFFFu) {
+			const int tz = (int)(key >> 9) / tiles_per_layer;
+			dest = tz < slab_lo ? 0 : (tz >= slab_hi ? 1 : -1);
+		}
+	}
+	const int lane = threadIdx.x & 63;
+#pragma unroll
+	for (int d = 0; d < 2; ++d) {
+		const unsigned long long m = __ballot(dest == d);
+		if (!m) continue;
+		const int leader = __ffsll((long long)m) - 1;
+		uint32_t base = 0;
+		if (lane == leader) base = atomicAdd(&counters[d], (uint32_t)__popcll(m));
+		base = __shfl(base, leader, 64);
+		if (dest == d && !count_only) {
+			uint32_t *rec = (d == 0 ? buf_lo : buf_hi) + (size_t)(base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) * 17;
+			rec[0] = key;
+#pragma unroll
+			for (int k = 0; k < 3; ++k) {
+				rec[1 + k] = __float_as_uint(p.t[k][i]);
+				rec[4 + k] = __float_as_uint(p.v[k][i]);
+			}
+#pragma unroll
+			for (int k = 0; k < 9; ++k) rec[7 + k] = __float_as_uint(p.c[k][i]);
+			rec[16] = p.id[i];
+			p.key[i] = 0xFFFFFFFFu;
+		}
+	}
+}
+__global__ void k_offset_u32(const uint32_t *in, uint32_t *out, int n, uint32_t base) {
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = in[i] + base;
+}
+__global__ void __launch_bounds__(256) k_unpack_arrivals(size_t n, const uint32_t *buf, ParticleSoA p, size_t at) {
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t *rec = buf + i * 17;
+	const size_t d = at + i;
+	p.key[d] = rec[0];
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		p.t[k][d] = __uint_as_float(rec[1 + k]);
+		p.v[k][d] = __uint_as_float(rec[4 + k]);
+	}
+#pragma unroll
+	for (int k = 0; k < 9; ++k) p.c[k][d] = __uint_as_float(rec[7 + k]);
+	p.id[d] = rec[16];
+}
+}  // namespace
+
+int lfa_particles_reserve(lfa_sim *s, size_t n_keep, size_t n_total);  // core.hip
+
+/// After a stage that moves particles (advect+collide, correct+collide): hand the particles that left the slab to the
+/// neighbour ranks and take theirs. Moves of more than one slab per step are not handled (CFL bounds a step to 3 cells).
+int lfa_dist_migrate(lfa_sim *s) {
+	if (!s->dist) return LFA_OK;
+	const size_t n = s->binned ? s->np_live : s->np;
+	uint32_t *cnt = (uint32_t *)(s->dist_red + 32);  // [0,1] leaving lo/hi, [2,3] arriving from lo/hi
+	LFA_HIP(s, hipMemsetAsync(cnt, 0, 16, s->stream));
+	const int tpl = s->g.ntx * s->g.nty;
+	const dim3 grid((unsigned)((n + 255) / 256 ? (n + 255) / 256 : 1));
+	ParticleSoA &p = s->pb[s->cur];
+	hipLaunchKernelGGL(k_pack_leavers, grid, dim3(256), 0, s->stream, n, p, tpl, s->slab_lo, s->slab_hi, cnt, (uint32_t *)nullptr,
+	                   (uint32_t *)nullptr, 1);
+	LFA_LAUNCH_CHECK(s);
+	// how many arrive: the neighbours' leave counts
+	LFA_TRY(s->dist->exchange(s, lfa_has_lo(s) ? cnt + 0 : nullptr, lfa_has_lo(s) ? 4 : 0, lfa_has_lo(s) ? cnt + 2 : nullptr,
+	                          lfa_has_lo(s) ? 4 : 0, lfa_has_hi(s) ? cnt + 1 : nullptr, lfa_has_hi(s) ? 4 : 0,
+	                          lfa_has_hi(s) ? cnt + 3 : nullptr, lfa_has_hi(s) ? 4 : 0));
+	uint32_t h[4];
+	LFA_HIP(s, hipMemcpyAsync(h, cnt, 16, hipMemcpyDeviceToHost, s->stream));
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	if (!lfa_has_lo(s)) h[0] = h[2] = 0;  // nothing can leave through a domain wall (positions are clamped into the grid)
+	if (!lfa_has_hi(s)) h[1] = h[3] = 0;
+	for (int w = 0; w < 4; ++w) LFA_TRY(lfa_dist_ensure_xbuf(s, w, (size_t)h[w] * 68));
+	LFA_TRY(lfa_particles_reserve(s, n, n + h[2] + h[3]));
+	ParticleSoA &q = s->pb[s->cur];
+	LFA_HIP(s, hipMemsetAsync(cnt, 0, 8, s->stream));
+	hipLaunchKernelGGL(k_pack_leavers, grid, dim3(256), 0, s->stream, n, q, tpl, s->slab_lo, s->slab_hi, cnt,
+	                   (uint32_t *)s->xbuf[0], (uint32_t *)s->xbuf[1], 0);
+	LFA_LAUNCH_CHECK(s);
+	LFA_TRY(s->dist->exchange(s, s->xbuf[0], (size_t)h[0] * 68, s->xbuf[2], (size_t)h[2] * 68, s->xbuf[1], (size_t)h[1] * 68,
+	                          s->xbuf[3], (size_t)h[3] * 68));
+	size_t at = n;
+	for (int w = 2; w < 4; ++w)
+		if (h[w]) {
+			hipLaunchKernelGGL(k_unpack_arrivals, dim3((h[w] + 255) / 256), dim3(256), 0, s->stream, (size_t)h[w],
+			                   (const uint32_t *)s->xbuf[w], q, at);
+			LFA_LAUNCH_CHECK(s);
+			at += h[w];
+		}
+	// the next binning scans [0, at): leavers carry an invalid key and are dropped there
+	s->np_live = at;
+	if (!s->binned) s->np = at;
+	s->holes = true;
+	return LFA_OK;
+}
+
+/// Position correction needs the particles within one cell across the slab face: the (key, t) of the neighbours' adjacent
+/// tile layers are appended behind the live particles (ghost particles, read-only), with tile_count / tile_start of the
+/// ghost tiles pointing at them. The binned array is ordered by tile, so a tile layer is one contiguous range: no packing.
+int lfa_dist_exchange_ghost_particles(lfa_sim *s) {
+	if (!s->dist) return LFA_OK;
+	const int L = s->g.ntx * s->g.nty;
+	const size_t own_lo = (size_t)s->slab_lo * L, own_hi = (size_t)s->slab_hi * L;
+	// per-tile counts of the boundary layers -> the neighbours' ghost layers (in place)
+	LFA_TRY(lfa_dist_exchange_tile_layers_u32(s, s->tile_count));
+	// my boundary ranges
+	uint32_t hs[4];  // tile_start at own_lo, own_lo+L, own_hi-L, own_hi
+	const size_t marks[4] = {own_lo, own_lo + L < own_hi ? own_lo + L : own_hi, own_hi - L > own_lo ? own_hi - L : own_lo, own_hi};
+	for (int k = 0; k < 4; ++k)
+		LFA_HIP(s, hipMemcpyAsync(&hs[k], s->tile_start + marks[k], 4, hipMemcpyDeviceToHost, s->stream));
+	// ghost totals: sum of the received counts (scan over the ghost layer gives the per-tile starts as well)
+	uint32_t *tot = (uint32_t *)(s->dist_red + 40);
+	size_t n_g[2] = {0, 0};
+	uint32_t hg[2] = {0, 0};
+	if (lfa_has_lo(s)) LFA_TRY(lfa_exclusive_scan_u32(s, s->tile_count + own_lo - L, s->tile_scan + own_lo - L, (size_t)L, tot));
+	if (lfa_has_hi(s)) LFA_TRY(lfa_exclusive_scan_u32(s, s->tile_count + own_hi, s->tile_scan + own_hi, (size_t)L, tot + 1));
+	LFA_HIP(s, hipMemcpyAsync(hg, tot, 8, hipMemcpyDeviceToHost, s->stream));
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	n_g[0] = lfa_has_lo(s) ? hg[0] : 0;
+	n_g[1] = lfa_has_hi(s) ? hg[1] : 0;
+	const size_t n = s->np_live;
+	LFA_TRY(lfa_particles_reserve(s, n, n + n_g[0] + n_g[1]));
+	ParticleSoA &p = s->pb[s->cur];
+	// upper ghosts first: tile_start[own_hi] == n already, so the upper ghost layer continues the owned numbering
+	const size_t at_hi = n, at_lo = n + n_g[1];
+	if (lfa_has_hi(s)) {
+		hipLaunchKernelGGL(k_offset_u32, dim3((L + 255) / 256), dim3(256), 0, s->stream, s->tile_scan + own_hi, s->tile_start + own_hi,
+		                   L, (uint32_t)at_hi);
+		LFA_LAUNCH_CHECK(s);
+	}
+	if (lfa_has_lo(s)) {
+		hipLaunchKernelGGL(k_offset_u32, dim3((L + 255) / 256), dim3(256), 0, s->stream, s->tile_scan + own_lo - L,
+		                   s->tile_start + own_lo - L, L, (uint32_t)at_lo);
+		LFA_LAUNCH_CHECK(s);
+	}
+	const size_t send_lo_at = hs[0], send_lo_n = lfa_has_lo(s) ? hs[1] - hs[0] : 0;
+	const size_t send_hi_at = hs[2], send_hi_n = lfa_has_hi(s) ? hs[3] - hs[2] : 0;
+	uint32_t *arr[4] = {p.key, (uint32_t *)p.t[0], (uint32_t *)p.t[1], (uint32_t *)p.t[2]};
+	for (int a = 0; a < 4; ++a)
+		LFA_TRY(s->dist->exchange(s, arr[a] + send_lo_at, send_lo_n * 4, arr[a] + at_lo, n_g[0] * 4, arr[a] + send_hi_at,
+		                          send_hi_n * 4, arr[a] + at_hi, n_g[1] * 4));
+	s->ghost_at[0] = at_lo;
+	s->ghost_at[1] = at_hi;
+	s->n_ghost_particles = n_g[0] + n_g[1];
+	return LFA_OK;
+}
+
 // ================================================================================================= in-process transport
 struct lfa_hub {
 	int n = 0;

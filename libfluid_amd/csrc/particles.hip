@@ -122,6 +122,7 @@ __global__ void __launch_bounds__(256)
 k_advect_collide(size_t n, ParticleSoA p, GridDims g, const uint8_t *solid, MoveParams mp) {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
+	if (p.key[i] == 0xFFFFFFFFu) return;  // outside this rank's slab (dropped at the next binning)
 	int c[3];
 	cell_of_key(g, p.key[i], c);
 	const int nn[3] = {g.nx, g.ny, g.nz};
@@ -146,18 +147,23 @@ k_advect_collide(size_t n, ParticleSoA p, GridDims g, const uint8_t *solid, Move
 /// Per particle tile: indices of the tile's particles grouped by cell (the `begin` half of the reference's _space_hash,
 /// include/fluid/simulation.h:193-197) - only the position correction needs cell lists.
 __global__ void __launch_bounds__(256)
-k_build_cell_index(const int *ptiles, int n_ptiles, const uint32_t *key, const uint32_t *tile_start, uint32_t *cell_start,
-                   uint32_t *cidx) {
+k_build_cell_index(const int *ptiles, int n_ptiles, const uint32_t *key, const uint32_t *tile_start, const uint32_t *tile_count,
+                   uint32_t *cell_start, uint32_t *cidx, uint32_t *ghost_cell_count, int own_lo, int own_hi) {
 	__shared__ uint32_t cnt[LFA_TILE_CELLS];
 	__shared__ uint32_t wsum[4];
 	for (int slot = blockIdx.x; slot < n_ptiles; slot += gridDim.x) {
 		const int tile = ptiles[slot];
-		const uint32_t b = tile_start[tile], e = tile_start[tile + 1];
+		// ghost tiles (slab decomposition) keep their particles behind the live ones: the range end comes from the count
+		const uint32_t b = tile_start[tile], e = b + tile_count[tile];
 		cnt[threadIdx.x] = 0;
 		cnt[threadIdx.x + 256] = 0;
 		__syncthreads();
 		for (uint32_t i = b + threadIdx.x; i < e; i += 256) atomicAdd(&cnt[key[i] & 511], 1u);
 		__syncthreads();
+		if (tile < own_lo || tile >= own_hi) {  // the binning counted the owned tiles only
+			ghost_cell_count[(size_t)tile * LFA_TILE_CELLS + threadIdx.x] = cnt[threadIdx.x];
+			ghost_cell_count[(size_t)tile * LFA_TILE_CELLS + 256 + threadIdx.x] = cnt[threadIdx.x + 256];
+		}
 		// exclusive scan of the 512 counts: thread t owns cells 2t, 2t+1
 		const uint32_t c0 = cnt[2 * threadIdx.x], c1 = cnt[2 * threadIdx.x + 1];
 		uint32_t incl = c0 + c1;
@@ -432,7 +438,6 @@ static MoveParams move_params(const lfa_sim *s, double dt) {
 
 extern "C" int lfa_advect_collide(lfa_sim *s, double dt) {
 	if (!s) return LFA_E_INVALID;
-	if (s->dist) return lfa_fail(s, LFA_E_UNSUPPORTED, "particle migration between slabs is not implemented: advect on one GPU");
 	LFA_HIP(s, hipSetDevice(s->device));
 	const size_t n = s->binned ? s->np_live : s->np;
 	if (n) {
@@ -440,46 +445,59 @@ extern "C" int lfa_advect_collide(lfa_sim *s, double dt) {
 		                   s->solid, move_params(s, dt));
 		LFA_LAUNCH_CHECK(s);
 	}
+	LFA_TRY(lfa_dist_migrate(s));
 	s->unknown_count_valid = false;
 	return LFA_OK;
 }
 
 extern "C" int lfa_correct_collide(lfa_sim *s, double dt) {
 	if (!s) return LFA_E_INVALID;
-	if (s->dist) return lfa_fail(s, LFA_E_UNSUPPORTED, "particle migration between slabs is not implemented: correct on one GPU");
 	if (!s->binned) return lfa_fail(s, LFA_E_INVALID, "lfa_correct_collide: call lfa_hash_particles first");
 	LFA_HIP(s, hipSetDevice(s->device));
 	const size_t n = s->np_live;
-	if (!n) return LFA_OK;
+	if (!n && !s->dist) return LFA_OK;
 	if (!s->cell_start) {
 		hipError_t e = hipMalloc(&s->cell_start, s->ncp * 4);
 		if (e != hipSuccess) return lfa_fail(s, LFA_E_OOM, "hipMalloc of the per-cell start offsets failed");
 	}
-	const int grid = s->n_ptiles < 16384 ? (s->n_ptiles > 0 ? s->n_ptiles : 1) : 16384;
-	ParticleSoA &cur = s->pb[s->cur], &oth = s->pb[s->cur ^ 1];
-	hipLaunchKernelGGL(k_build_cell_index, dim3(grid), dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, cur.key, s->tile_start,
-	                   s->cell_start, s->rank);
-	LFA_LAUNCH_CHECK(s);
-	// LDS-tiled pass; half tiles whose neighbourhood exceeds the LDS capacity are flagged and redone by the global-gather
-	// kernel (restricted to those particles)
-	uint32_t *ovf = (uint32_t *)s->partials;  // scratch: 2 * n_ptiles bits
-	const size_t ovf_words = ((size_t)CORR_PARTS * s->n_ptiles + 31) / 32 + 1;
-	if (ovf_words * 4 > 16384 * 8) return lfa_fail(s, LFA_E_INVALID, "too many particle tiles for the overflow bitmap");
-	LFA_HIP(s, hipMemsetAsync(ovf, 0, ovf_words * 4, s->stream));
-	{
-		const int work = CORR_PARTS * s->n_ptiles, g2 = work < 65536 ? (work > 0 ? work : 1) : 65536;
-		hipLaunchKernelGGL(k_correct_tiled, dim3(g2), dim3(CORR_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, cur, oth.key, oth.t[0],
-		                   oth.t[1], oth.t[2], s->g, s->solid, s->tile_flag, s->cell_count, s->cell_start, s->rank,
-		                   move_params(s, dt), ovf);
-		LFA_LAUNCH_CHECK(s);
+	const int L = s->g.ntx * s->g.nty;
+	if (s->dist) {
+		// neighbours within one cell across the slab faces: ghost copies of the adjacent tile layers' particles
+		LFA_TRY(lfa_dist_exchange_ghost_particles(s));
+		if (lfa_has_lo(s))
+			LFA_HIP(s, hipMemsetAsync(s->cell_count + (size_t)(s->slab_lo - 1) * L * LFA_TILE_CELLS, 0, (size_t)L * LFA_TILE_CELLS * 4, s->stream));
+		if (lfa_has_hi(s))
+			LFA_HIP(s, hipMemsetAsync(s->cell_count + (size_t)s->slab_hi * L * LFA_TILE_CELLS, 0, (size_t)L * LFA_TILE_CELLS * 4, s->stream));
 	}
-	hipLaunchKernelGGL(k_correct_collide, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, cur, oth.key, oth.t[0],
-	                   oth.t[1], oth.t[2], s->g, s->solid, s->tile_flag, s->cell_count, s->cell_start, s->rank,
-	                   move_params(s, dt), (const uint32_t *)ovf, (const int *)s->tile_pslot, s->p_off);
+	const int n_index = s->dist ? s->n_ptiles_all : s->n_ptiles;
+	const int grid = n_index < 16384 ? (n_index > 0 ? n_index : 1) : 16384;
+	ParticleSoA &cur = s->pb[s->cur], &oth = s->pb[s->cur ^ 1];
+	hipLaunchKernelGGL(k_build_cell_index, dim3(grid), dim3(256), 0, s->stream, s->dist ? s->ptiles_all : s->ptiles, n_index, cur.key,
+	                   s->tile_start, s->tile_count, s->cell_start, s->rank, s->cell_count, s->slab_lo * L, s->slab_hi * L);
 	LFA_LAUNCH_CHECK(s);
-	// every particle read the OLD positions of its neighbours; now publish the new ones
-	LFA_HIP(s, hipMemcpyAsync(cur.key, oth.key, n * 4, hipMemcpyDeviceToDevice, s->stream));
-	for (int d = 0; d < 3; ++d) LFA_HIP(s, hipMemcpyAsync(cur.t[d], oth.t[d], n * 4, hipMemcpyDeviceToDevice, s->stream));
+	if (n) {
+		// LDS-tiled pass; half tiles whose neighbourhood exceeds the LDS capacity are flagged and redone by the global-gather
+		// kernel (restricted to those particles)
+		uint32_t *ovf = (uint32_t *)s->partials;  // scratch: 2 * n_ptiles bits
+		const size_t ovf_words = ((size_t)CORR_PARTS * s->n_ptiles + 31) / 32 + 1;
+		if (ovf_words * 4 > 16384 * 8) return lfa_fail(s, LFA_E_INVALID, "too many particle tiles for the overflow bitmap");
+		LFA_HIP(s, hipMemsetAsync(ovf, 0, ovf_words * 4, s->stream));
+		{
+			const int work = CORR_PARTS * s->n_ptiles, g2 = work < 65536 ? (work > 0 ? work : 1) : 65536;
+			hipLaunchKernelGGL(k_correct_tiled, dim3(g2), dim3(CORR_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, cur, oth.key, oth.t[0],
+			                   oth.t[1], oth.t[2], s->g, s->solid, s->tile_flag, s->cell_count, s->cell_start, s->rank,
+			                   move_params(s, dt), ovf);
+			LFA_LAUNCH_CHECK(s);
+		}
+		hipLaunchKernelGGL(k_correct_collide, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, cur, oth.key, oth.t[0],
+		                   oth.t[1], oth.t[2], s->g, s->solid, s->tile_flag, s->cell_count, s->cell_start, s->rank,
+		                   move_params(s, dt), (const uint32_t *)ovf, (const int *)s->tile_pslot, s->p_off);
+		LFA_LAUNCH_CHECK(s);
+		// every particle read the OLD positions of its neighbours; now publish the new ones
+		LFA_HIP(s, hipMemcpyAsync(cur.key, oth.key, n * 4, hipMemcpyDeviceToDevice, s->stream));
+		for (int d = 0; d < 3; ++d) LFA_HIP(s, hipMemcpyAsync(cur.t[d], oth.t[d], n * 4, hipMemcpyDeviceToDevice, s->stream));
+	}
+	LFA_TRY(lfa_dist_migrate(s));
 	s->unknown_count_valid = false;
 	return LFA_OK;
 }
