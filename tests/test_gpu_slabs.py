@@ -1,6 +1,7 @@
 """GPU tests of the z-slab domain decomposition: N "virtual slabs" (N handles on ONE GPU, one host thread
 each, in-process transport) must reproduce the single-domain result. The RCCL transport differs from the in-process one
 only in how a packed buffer reaches the neighbour; the protocol (what is packed, ghost tiles, reductions) is the same."""
+import os
 import threading
 
 import numpy as np
@@ -172,3 +173,38 @@ def test_virtual_slabs_full_time_step_with_migration(size, block, method, bounds
     assert dpos < 2e-3, dpos
     vel_atol = 1e-3 * 981.0 * util.DT
     util.assert_close(pn["vel"], p1["vel"], 1e-2, "particle velocities after full steps, slabs vs single domain", atol=vel_atol)
+
+
+@pytest.mark.skipif(os.environ.get("LFA_TEST_RCCL") != "1",
+                    reason="loading the 570 MB librccl on a fresh box takes ~4 min; set LFA_TEST_RCCL=1 "
+                           "(last run: profiles/r01_rccl_single_rank.txt)")
+def test_rccl_transport_single_rank():
+    """The RCCL transport (dlopen'ed librccl: unique id, communicator, all-reduces on the handle's stream) with a
+    one-rank communicator: the whole slab code path runs (ghost-free), the result equals the plain single-domain run.
+    Boxes here have one GPU, so the N > 1 protocol is covered by the in-process transport above."""
+    size, block = (16, 16, 32), ((2, 0, 3), (14, 10, 29))
+    kw = dict(precond=lfa.PRECOND_MULTILEVEL, pcg_dtype=lfa.PCG_F64)
+    c1, p1, it1 = run_single(size, block, lfa.APIC, 2, **kw)
+    s = lfa.Sim(size, method=lfa.APIC, blending=0.95, **kw)
+    s.init_rccl_slab(0, 1, lfa.rccl_unique_id(), [0, 4])
+    s.seed_block(*block)
+    its = []
+    for _ in range(2):
+        res, it, rc = s.step_hot(util.DT)
+        assert rc == 0
+        its.append(it)
+    res, it, rc = s.time_step(util.DT)
+    assert rc == 0
+    cells = s.cells()
+    s.close()
+    assert its == it1
+    s1 = lfa.Sim(size, method=lfa.APIC, blending=0.95, **kw)
+    s1.seed_block(*block)
+    for _ in range(2):
+        s1.step_hot(util.DT)
+    s1.time_step(util.DT)
+    c2 = s1.cells()
+    s1.close()
+    assert np.array_equal(cells["type"], c2["type"])
+    util.assert_close(cells["vel"], c2["vel"], 1e-6, "grid velocities, RCCL one-rank slab vs single domain",
+                      atol=1e-7 * 981.0 * util.DT)
