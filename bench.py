@@ -26,13 +26,16 @@ PCG_BYTES = {"spmv_dot": 17, "axpy_max": 28, "mic_apply_dot": 34, "update_s": 12
 
 
 def cpu_baseline(sample, steps):
-    """The oracle (plain-C fp64 restatement of the reference's serial hot path) timed on this box's host cores."""
+    """The reference's own hot path (oracle/_ref/libref.so: src/simulation.cpp + src/pressure_solver.cpp + src/mac_grid.cpp
+    compiled in place, kind "reference") timed on this box's host cores; when that build did not travel, the plain-C
+    restatement (oracle/liboracle.so, kind "port")."""
     import numpy as np  # noqa: F401
     from libfluid_amd import scenes
     from oracle import loader as orc
     cfg = scenes.CONFIGS[sample]
     parts = scenes.seed_block(*cfg["block"])
-    sim = orc.CpuSim(cfg["size"], method=cfg["method"], blending=cfg["blending"])
+    kind = "ref" if orc.have_ref() else "oracle"
+    sim = orc.CpuSim(cfg["size"], method=cfg["method"], blending=cfg["blending"], kind=kind)
     sim.set_particles(parts)
     t0 = time.perf_counter()
     iters = 0
@@ -41,10 +44,13 @@ def cpu_baseline(sample, steps):
         iters += it
     dt = time.perf_counter() - t0
     return {
-        "value": len(parts) * steps / dt, "unit": "particle-steps/s", "cores": 1, "kind": "port",
+        "value": len(parts) * steps / dt, "unit": "particle-steps/s", "cores": 1,
+        "kind": "reference" if kind == "ref" else "port",
         "sample": f"{sample}: {cfg['size'][0]}^3 grid, {len(parts)} particles, {steps} hot-path steps, "
-                  f"{iters} PCG iterations, {dt:.1f} s; serial like the reference's P2G/PCG/G2P (src/simulation.cpp:293-398,"
-                  f" src/pressure_solver.cpp:19-71), gcc -O2",
+                  f"{iters} PCG iterations, {dt:.1f} s; "
+                  + ("the reference's serial _transfer_to_grid / pressure_solver::solve / _transfer_from_grid "
+                     "(src/simulation.cpp:293-398, src/pressure_solver.cpp:19-71), g++ -O2 -DNDEBUG" if kind == "ref" else
+                     "plain-C restatement, serial like the reference's P2G/PCG/G2P, gcc -O2"),
         "pcg_iters_per_s": iters / dt,
     }
 
