@@ -75,6 +75,9 @@ typedef struct lfa_params {
 	int32_t pcg_dtype;            /* LFA_PCG_F32 */
 	int32_t apic_unscaled_kernel; /* 1 = keep the reference quirk simulation.cpp:367-369 (only differs when cell_size != 1;
 	                                 the device path then returns LFA_E_UNSUPPORTED), 0 = divide by cell_size */
+	int32_t pcg_fused;            /* 1 = two launches per PCG iteration (k_pcg_a: search direction + A s, k_pcg_b: AXPYs +
+	                                 MIC(0) sweeps) where the schedule allows it (single domain, tile-local MIC(0));
+	                                 0 = one launch per vector operation. Same arithmetic either way. */
 } lfa_params;
 
 /* -- lifetime ------------------------------------------------------------------------------------------------ */
@@ -215,7 +218,9 @@ enum {
 	LFA_K_G2P = 6,         /* grid -> particles                         algorithmic 60 Np + 12 Nc (APIC) */
 	LFA_K_BIN = 7,         /* tile binning (count + scatter)            algorithmic 2*68 Np + 8 Np bytes */
 	LFA_K_MIC_FINE = 8,    /* the tile-level sweep kernel of LFA_K_MIC_APPLY alone (k_mic_apply) */
-	LFA_K_COARSE = 9       /* the coarse levels of the multilevel preconditioner alone (side stream in the solve) */
+	LFA_K_COARSE = 9,      /* the coarse levels of the multilevel preconditioner alone (side stream in the solve) */
+	LFA_K_PCG_A = 10,      /* fused: s = z + beta s, q = A s, dot(q,s)   algorithmic 12 n + 17 n bytes */
+	LFA_K_PCG_B = 11       /* fused: p += a s, r -= a q, max r, z = M^-1 r, dot(z,r)   algorithmic 28 n + 34 n bytes */
 };
 int lfa_bench_kernel(lfa_sim *s, int which, int reps, double *mean_ms);
 

@@ -46,6 +46,7 @@ class Params(C.Structure):
         ("precond", C.c_int32),
         ("pcg_dtype", C.c_int32),
         ("apic_unscaled_kernel", C.c_int32),
+        ("pcg_fused", C.c_int32),
     ]
 
 
@@ -114,7 +115,7 @@ SIGNATURES = {
     "lfa_dist_get_slab": (_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
 KERNELS = {"spmv_dot": 0, "axpy_max": 1, "mic_apply_dot": 2, "update_s": 3, "p2g_scatter": 4, "p2g_finalize": 5,
-           "g2p": 6, "bin": 7, "mic_fine": 8, "coarse_levels": 9}
+           "g2p": 6, "bin": 7, "mic_fine": 8, "coarse_levels": 9, "pcg_a": 10, "pcg_b": 11}
 
 
 def load_library():

@@ -110,6 +110,8 @@ struct lfa_sim {
 	// pressure system
 	uint8_t *abits = nullptr;
 	void *vp = nullptr, *vr = nullptr, *vz = nullptr, *vs = nullptr, *vpre = nullptr, *vq = nullptr;
+	int *nbr_table = nullptr;  // per particle-tile slot: neighbour tile ids + level-1 indices (k_build_nbr_table)
+	void *vs2 = nullptr;  // second search-direction buffer of the fused iteration (k_pcg_a reads one, writes the other)
 	size_t vec_elem = 0;  // element size the vectors are currently allocated for
 	double *partials = nullptr;  // reduction partials
 	int *pcg_state = nullptr;    // [0] done_iter  [1] nan flag
@@ -123,6 +125,8 @@ struct lfa_sim {
 	float *c_diag = nullptr, *c_w[3] = {nullptr, nullptr, nullptr};
 	uint8_t *c_unk = nullptr;
 	void *c_pre = nullptr, *c_r = nullptr, *c_x = nullptr, *c_r2 = nullptr, *c_x2 = nullptr, *a2inv = nullptr;
+	void *c_as = nullptr;     // level-1 restriction of A s (fused iteration)
+	void *c_r_cur = nullptr;  // overrides c_r as the coarse right-hand side (parity buffer of the fused iteration)
 	int *slot_l1 = nullptr, *l1_tiles = nullptr, *l1_l2 = nullptr;
 	int n_l1tiles = 0, n2 = 0, a2cap = 0;
 	size_t coarse_elem = 0;

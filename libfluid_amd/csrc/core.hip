@@ -141,6 +141,7 @@ extern "C" void lfa_default_params(lfa_params *p) {
 	p->precond = LFA_PRECOND_MULTILEVEL;
 	p->pcg_dtype = LFA_PCG_F32;
 	p->apic_unscaled_kernel = 1;
+	p->pcg_fused = 1;
 }
 
 template <typename T> static int dev_alloc(lfa_sim *s, T **p, size_t count, bool zero) {
@@ -257,7 +258,7 @@ extern "C" void lfa_destroy(lfa_sim *s) {
 	void *ptrs[] = {s->cell_start, s->grid_flag, s->rank, s->tile_count, s->tile_start, s->tile_flag, s->tile_scan, s->ptiles_all, s->dtiles, s->halo_tiles, s->dist_red,
 	                s->xbuf[0], s->xbuf[1], s->xbuf[2], s->xbuf[3],
 	                s->tile_pslot, s->scan_tmp, s->u, s->v, s->w, s->uo, s->vo, s->wo, s->ctype, s->solid,
-	                s->cell_count, s->stage, s->acc, s->abits, s->vp, s->vr, s->vz, s->vs, s->vpre, s->vq,
+	                s->cell_count, s->stage, s->acc, s->abits, s->vp, s->vr, s->vz, s->vs, s->vpre, s->vq, s->vs2, s->c_as, s->nbr_table,
 	                s->partials, s->pcg_state, s->pcg_hist, s->level_tiles, s->io_buf, s->raw_scan, s->c_diag, s->c_w[0],
 	                s->c_w[1], s->c_w[2], s->c_unk, s->c_pre, s->c_r, s->c_x, s->c_r2, s->c_x2, s->a2inv, s->slot_l1,
 	                s->l1_tiles, s->l1_l2};

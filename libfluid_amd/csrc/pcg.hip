@@ -273,6 +273,10 @@ template <typename real> struct CoarseFields {
 	const uint8_t *unk;
 	real *pre, *r, *x;
 	real w1 = (real)1, w2 = (real)1;  // weights of the level-1 / level-2 corrections in the additive preconditioner
+	// fused iteration (k_pcg_b): the restricted residual is r1 = r_prev - alpha * as, with r_prev the exact restriction
+	// of the previous residual and as = P^T A s (tile sums written by k_pcg_a)
+	const real *as = nullptr;
+	real alpha = (real)0;
 };
 
 
@@ -311,6 +315,7 @@ __device__ inline void coarse_block(char *smem, const int *l1_tiles, int n_l1, C
 			U[2][idx] = (uint8_t)c.w[2][base + idx];
 			PRE[idx] = u ? c.pre[base + idx] : (real)0;
 			rr[zz] = u ? c.r[base + idx] : (real)0;
+			if (c.as) rr[zz] = u ? rr[zz] + (-c.alpha) * c.as[base + idx] : (real)0;
 			Q[idx] = rr[zz];
 			PQ[idx] = (real)0;
 			sr += (double)rr[zz];
@@ -835,6 +840,321 @@ k_add_coarse(TileCtx tc, const uint8_t *abits, real *z, const real *coarse_x, co
 	}
 }
 
+
+// ================================================================================================= fused iteration
+// Two launches per PCG iteration instead of five (single domain, tile-local MIC(0) with or without the coarse levels):
+//   k_pcg_a : [stopping rule on the previous residual] s = z + P x_coarse + beta s ; q = A s ; partial dot(q, s)
+//   k_pcg_b : p += alpha s ; r -= alpha q ; signed max r ; z = M^-1 r ; partial dot(z, r)
+// Same arithmetic as k_update_s / k_spmv / k_axpy_max (expression for expression), so the two paths produce the same
+// numbers up to the rounding of the re-associated tile sweeps. What the fusion needs:
+//  * s is double-buffered: a wave of k_pcg_a recomputes the new s on the one-cell halo of its tile from the neighbours'
+//    z and old s, while the neighbours' owners store their new s in the same launch.
+//  * q = A s goes to its own buffer (vq), because z is still read as halo by other waves of k_pcg_a.
+//  * the coarse levels run inside k_pcg_b beside the tile sweeps, i.e. before the new residual exists; their
+//    right-hand side follows from linearity, r1 = P^T r_prev - alpha P^T A s: k_pcg_a writes the tile sums of A s,
+//    k_pcg_b writes the exact tile sums of the new residual for the next iteration (no drift).
+// The sweeps of k_pcg_b are the substitution W = pre q (forward) / z (backward):
+//   W_i = pre_i^2 r_i + b_i (W_{i-x} + W_{i-y} + W_{i-z}),          b_i = scale pre_i^2 [i is fluid]
+//   z_i = W_i + c_i ([fluid] z_{i+x} + [fluid] z_{i+y} + [fluid] z_{i+z}),  c_i = scale pre_i^2
+// (pressure_solver.cpp:301-331 with q_i = W_i / pre_i), in place in one LDS array with zero planes before and behind
+// it and per-lane 0/1 factors for the x/y tile faces: 3 FMAs and 5 LDS operations per cell and sweep.
+#define WAVE_FENCE()                                          \
+	do {                                                       \
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+		__builtin_amdgcn_wave_barrier();                       \
+	} while (0)
+
+template <typename real> struct alignas(2 * sizeof(real)) BCPair { real b, c; };
+#define SWEEP_X_LEN (LFA_TILE_CELLS + 128)
+
+/// X: cell 0 of a SWEEP_X_LEN array whose first and last 64 entries are zero. In: X = pre^2 r. Out: BC[i].c = z_i.
+template <typename real> __device__ inline void fast_tile_sweeps(real *X, BCPair<real> *BC, int lane) {
+	const int lx = lane & 7, ly = lane >> 3, t0 = lx + ly;
+	const real mxm = lx > 0 ? (real)1 : (real)0, mym = ly > 0 ? (real)1 : (real)0;
+	const real mxp = lx < 7 ? (real)1 : (real)0, myp = ly < 7 ? (real)1 : (real)0;
+#pragma clang loop unroll(disable)
+	for (int level = 0; level < 22; ++level) {
+		const int zz = level - t0;
+		if ((unsigned)zz < 8u) {
+			const int idx = zz * 64 + lane;
+			const real sum = fma(mxm, X[idx - 1], fma(mym, X[idx - 8], X[idx - 64]));
+			X[idx] = fma(BC[idx].b, sum, X[idx]);
+		}
+		WAVE_FENCE();
+	}
+#pragma clang loop unroll(disable)
+	for (int level = 21; level >= 0; --level) {
+		const int zz = level - t0;
+		if ((unsigned)zz < 8u) {
+			const int idx = zz * 64 + lane;
+			const real sum = fma(mxp, X[idx + 1], fma(myp, X[idx + 8], X[idx + 64]));
+			const BCPair<real> bc = BC[idx];
+			const real zv = fma(bc.c, sum, X[idx]);
+			BC[idx].c = zv;
+			X[idx] = bc.b != (real)0 ? zv : (real)0;
+		}
+		WAVE_FENCE();
+	}
+}
+
+/// Per particle-tile slot, 16 ints (one 64-B scalar load): [0..5] tile ids of the face neighbours that hold unknowns
+/// (-x,+x,-y,+y,-z,+z; -1 otherwise), [6] own tile id, [8..13] their level-1 indices, [14] own level-1 index.
+#define NBR_STRIDE 16
+__global__ void __launch_bounds__(256)
+k_build_nbr_table(TileCtx tc, const int *slot_l1, int *nbr) {
+	const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+	if (slot >= tc.n_ptiles) return;
+	const int tile = tc.ptiles[slot];
+	int nb[6];
+	face_neighbours(tc, tile, nb);
+	int *o = nbr + (size_t)slot * NBR_STRIDE;
+#pragma unroll
+	for (int k = 0; k < 6; ++k) {
+		o[k] = nb[k];
+		o[8 + k] = (slot_l1 && nb[k] >= 0) ? slot_l1[tc.tile_pslot[nb[k]]] : 0;
+	}
+	o[6] = tile;
+	o[7] = 0;
+	o[14] = slot_l1 ? slot_l1[slot] : 0;
+	o[15] = 0;
+}
+
+template <typename real, bool EMBED>
+__global__ void __launch_bounds__(256)
+k_pcg_b(const int *__restrict__ ptiles, int n_ptiles, const uint8_t *__restrict__ abits, Vecs<real> v,
+        const real *__restrict__ s_cur, real scale, const double *part_sigma_old, int n_sigma, const double *part_zs,
+        int n_zs, double *part_rmax, double *part_sigma_new, const int *state, real *coarse_r_out,
+        const int *__restrict__ slot_l1, CoarseFields<real> cf, CoarseArgs ca) {
+	constexpr int FINE_LDS = PCG_WAVES * (SWEEP_X_LEN + 2 * LFA_TILE_CELLS) * (int)sizeof(real);
+	constexpr int COARSE_LDS = PCG_WAVES * 3 * LFA_TILE_CELLS * ((int)sizeof(real) + 1) + 160 * 8;
+	constexpr int RED_LDS = 256 * 8;  // the scalar reductions use the front of the same block before / after the tiles
+	constexpr int WORK_LDS = EMBED ? (COARSE_LDS > FINE_LDS ? COARSE_LDS : FINE_LDS) : FINE_LDS;
+	__shared__ __attribute__((aligned(16))) char lds_raw[WORK_LDS > RED_LDS ? WORK_LDS : RED_LDS];
+	double *red = (double *)lds_raw;
+	if (state[0] >= 0) return;
+	const double sigma = reduce_partials_sum(part_sigma_old, n_sigma, red);
+	const double zs = reduce_partials_sum(part_zs, n_zs, red);
+	const real alpha = (real)(sigma / zs);
+	const int nblk = EMBED ? (int)gridDim.x - PCG_COARSE_BLOCKS : (int)gridDim.x,
+	          blk = EMBED ? (int)blockIdx.x - PCG_COARSE_BLOCKS : (int)blockIdx.x;
+	if (EMBED && blockIdx.x < PCG_COARSE_BLOCKS) {
+		cf.alpha = alpha;
+		coarse_block<real, PCG_WAVES>(lds_raw, ca.l1_tiles, ca.n_l1, cf, scale, (const real *)ca.a2inv, (real *)ca.x2,
+		                              part_sigma_new + nblk, (int)blockIdx.x, PCG_COARSE_BLOCKS, ca.xchg, ca.ticket);
+		return;
+	}
+	const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+	real *X = (real *)lds_raw + (size_t)wid * SWEEP_X_LEN + 64;
+	BCPair<real> *BC = (BCPair<real> *)((real *)lds_raw + (size_t)PCG_WAVES * SWEEP_X_LEN) + (size_t)wid * LFA_TILE_CELLS;
+	X[lane - 64] = (real)0;
+	X[LFA_TILE_CELLS + lane] = (real)0;
+	double acc = 0.0, m = -INFINITY;
+	bool nan = false;
+	// Software pipeline over the tiles of this wave: the loads of the next tile are issued before the sweeps of the
+	// current one (which only touch LDS), so HBM latency hides behind the 44 dependent hyperplanes.
+	const int stride = nblk * PCG_WAVES;
+	int slot = blk * PCG_WAVES + wid;
+	uint8_t ta[8];
+	real tpre[8], tp[8], ts[8], tr[8], tq[8];
+	size_t base = 0;
+	if (slot < n_ptiles) {
+		base = (size_t)ptiles[slot] * LFA_TILE_CELLS;
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) {
+			const size_t b = base + zz * 64 + lane;
+			ta[zz] = abits[b]; tpre[zz] = v.pre[b]; tp[zz] = v.p[b]; ts[zz] = s_cur[b]; tr[zz] = v.r[b]; tq[zz] = v.q[b];
+		}
+	}
+	while (slot < n_ptiles) {
+		real rn[8];
+		double sr = 0.0;
+		WAVE_FENCE();
+		// entries of non-unknown cells are exact zeros in p, s, r, q and pre, so the arithmetic needs no mask
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) {
+			const size_t b = base + zz * 64 + lane;
+			const bool unk = (ta[zz] & AB_UNKNOWN) != 0;
+			const real pn = tp[zz] + alpha * ts[zz];
+			const real rr = unk ? tr[zz] + (-alpha) * tq[zz] : (real)0;
+			if (unk) {
+				v.p[b] = pn;
+				v.r[b] = rr;
+				nan |= rr != rr;
+				m = (double)rr > m ? (double)rr : m;
+			}
+			sr += (double)rr;
+			rn[zz] = rr;
+			const real d = tpre[zz] * tpre[zz], c = scale * d;
+			X[zz * 64 + lane] = d * rr;
+			BC[zz * 64 + lane] = BCPair<real>{(ta[zz] & AB_FLUID) ? c : (real)0, c};
+		}
+		if (coarse_r_out) {  // exact restriction of the new residual: right-hand side recurrence of the next iteration
+			sr = wave_sum(sr);
+			if (lane == 0) coarse_r_out[slot_l1[slot]] = (real)sr;
+		}
+		const size_t obase = base;
+		slot += stride;
+		if (slot < n_ptiles) {
+			base = (size_t)ptiles[slot] * LFA_TILE_CELLS;
+#pragma unroll
+			for (int zz = 0; zz < 8; ++zz) {
+				const size_t b = base + zz * 64 + lane;
+				ta[zz] = abits[b]; tpre[zz] = v.pre[b]; tp[zz] = v.p[b]; ts[zz] = s_cur[b]; tr[zz] = v.r[b]; tq[zz] = v.q[b];
+			}
+		}
+		WAVE_FENCE();
+		fast_tile_sweeps<real>(X, BC, lane);
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) {
+			const real zv = BC[zz * 64 + lane].c;
+			v.z[obase + zz * 64 + lane] = zv;
+			acc += (double)zv * (double)rn[zz];
+		}
+	}
+	m = wave_max(m);
+	nan = __any(nan);
+	acc = wave_sum(acc);
+	__syncthreads();
+	if (lane == 0) {
+		red[wid] = nan ? NAN : m;
+		red[8 + wid] = acc;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		double r = red[0];
+		for (int i = 1; i < 4; ++i) r = (r != r || red[i] != red[i]) ? NAN : (red[i] > r ? red[i] : r);
+		part_rmax[blk] = r;
+		part_sigma_new[blk] = (red[8] + red[9]) + (red[10] + red[11]);
+	}
+}
+
+template <typename real>
+__global__ void __launch_bounds__(256)
+k_pcg_a(int n_ptiles, const int *__restrict__ nbr, const uint8_t *__restrict__ abits, const real *__restrict__ z,
+        const real *__restrict__ s_old, real *__restrict__ s_new, real *__restrict__ q, real scale,
+        const double *part_sig_new, const double *part_sig_old, int n_sig, int first, const double *part_rmax, int n_rmax,
+        double tol, int iter, int *state, double *hist, double *part_qs, const real *__restrict__ coarse_x,
+        const real *__restrict__ coarse_x2, const int *__restrict__ l1_l2, real *coarse_as) {
+	__shared__ real halo[PCG_WAVES][LFA_HALO_CELLS];
+	__shared__ double lds[256];
+	if (state[0] >= 0) return;
+	if (iter > 0) {
+		// stopping rule of pressure_solver::solve (src/pressure_solver.cpp:54-58) on the residual of iteration iter-1;
+		// every workgroup evaluates it on the same partials, workgroup 0 records it
+		const double rmax = reduce_partials_max(part_rmax, n_rmax, lds);
+		const bool stop = rmax != rmax || rmax < tol;
+		if (blockIdx.x == 0 && threadIdx.x == 0) {
+			hist[iter - 1] = rmax;
+			if (stop) {
+				if (rmax != rmax) state[1] = 1;
+				state[0] = iter;
+			}
+		}
+		if (stop) return;
+	}
+	real beta = (real)0;
+	if (!first) {
+		const double sn = reduce_partials_sum(part_sig_new, n_sig, lds);
+		const double so = reduce_partials_sum(part_sig_old, n_sig, lds);
+		beta = (real)(sn / so);
+	}
+	const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
+	real *h = halo[wid];
+	double acc = 0.0;
+	for (int slot = blockIdx.x * PCG_WAVES + wid; slot < n_ptiles; slot += gridDim.x * PCG_WAVES) {
+		const int *nt = nbr + (size_t)slot * NBR_STRIDE;
+		int nb[6];
+#pragma unroll
+		for (int k = 0; k < 6; ++k) nb[k] = nt[k];
+		const size_t base = (size_t)nt[6] * LFA_TILE_CELLS;
+		// every global load of the tile is issued before the first use: interior, then the six faces
+		// (face lanes = (a, b) over the two in-face axes)
+		const size_t fo[6] = {(size_t)(ly * 64 + lx * 8 + 7), (size_t)(ly * 64 + lx * 8), (size_t)(ly * 64 + 56 + lx),
+		                      (size_t)(ly * 64 + lx), (size_t)(7 * 64 + lane), (size_t)lane};
+		uint8_t ab[8], fab[6];
+		real zi[8], si[8], fz[6], fs[6];
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) {
+			const size_t b = base + zz * 64 + lane;
+			ab[zz] = abits[b];
+			zi[zz] = z[b];
+			si[zz] = first ? (real)0 : s_old[b];
+		}
+#pragma unroll
+		for (int k = 0; k < 6; ++k) {
+			fab[k] = 0; fz[k] = (real)0; fs[k] = (real)0;
+			if (nb[k] >= 0) {
+				const size_t j = (size_t)nb[k] * LFA_TILE_CELLS + fo[k];
+				fab[k] = abits[j];
+				fz[k] = z[j];
+				fs[k] = first ? (real)0 : s_old[j];
+			}
+		}
+		real xc = (real)0, xn[6] = {(real)0, (real)0, (real)0, (real)0, (real)0, (real)0};
+		if (coarse_x) {
+			const int i1 = nt[14];
+			xc = coarse_x[i1] + coarse_x2[l1_l2[i1 >> 9]];
+#pragma unroll
+			for (int k = 0; k < 6; ++k)
+				if (nb[k] >= 0) {
+					const int j1 = nt[8 + k];
+					xn[k] = coarse_x[j1] + coarse_x2[l1_l2[j1 >> 9]];
+				}
+		}
+		WAVE_FENCE();
+		// the new search direction (k_update_s): z + coarse part on the unknowns, + beta s
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) {
+			real zj = zi[zz];
+			if (coarse_x && (ab[zz] & AB_UNKNOWN)) zj += xc;
+			const real sj = first ? zj : zj + beta * si[zz];
+			s_new[base + zz * 64 + lane] = sj;
+			h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)] = sj;
+		}
+		real fv[6];
+#pragma unroll
+		for (int k = 0; k < 6; ++k) {
+			real zj = fz[k];
+			if (coarse_x && (fab[k] & AB_UNKNOWN)) zj += xn[k];
+			fv[k] = first ? zj : zj + beta * fs[k];
+		}
+		h[0 + 10 * (lx + 1) + 100 * (ly + 1)] = fv[0];
+		h[9 + 10 * (lx + 1) + 100 * (ly + 1)] = fv[1];
+		h[(lx + 1) + 10 * 0 + 100 * (ly + 1)] = fv[2];
+		h[(lx + 1) + 10 * 9 + 100 * (ly + 1)] = fv[3];
+		h[(lx + 1) + 10 * (ly + 1) + 100 * 0] = fv[4];
+		h[(lx + 1) + 10 * (ly + 1) + 100 * 9] = fv[5];
+		WAVE_FENCE();
+		double sq = 0.0;
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) {
+			const int i = (lx + 1) + 10 * (ly + 1) + 100 * (zz + 1);
+			const uint8_t a = ab[zz];
+			real out = (real)0;
+			if (a & AB_UNKNOWN) {
+				const real F = (a & AB_FLUID) ? (real)1 : (real)0;
+				const real sc = h[i];
+				real val = (real)(a & 7) * sc;
+				val -= F * h[i - 1];
+				val -= F * h[i - 10];
+				val -= F * h[i - 100];
+				val -= (real)((a >> 3) & 1) * h[i + 1];
+				val -= (real)((a >> 4) & 1) * h[i + 10];
+				val -= (real)((a >> 5) & 1) * h[i + 100];
+				out = scale * val;
+				acc += (double)out * (double)sc;
+				sq += (double)out;
+			}
+			q[base + zz * 64 + lane] = out;
+		}
+		if (coarse_as) {
+			sq = wave_sum(sq);
+			if (lane == 0) coarse_as[nt[14]] = (real)sq;
+		}
+	}
+	block_partial_sum(acc, lds, part_qs);
+}
+
 // ---- boundary helpers: vectors in the reference's unknown order <-> tile-major fields
 template <typename T, typename U>
 __global__ void k_gather_unknowns(GridDims g, size_t nc, const uint32_t *cell_count, const uint32_t *tile_flag,
@@ -871,7 +1191,7 @@ int lfa_pcg_alloc(lfa_sim *s) {
 	const size_t elem = s->prm.pcg_dtype == LFA_PCG_F64 ? 8 : 4;
 	if (s->vp && s->vec_elem == elem) return LFA_OK;
 	LFA_HIP(s, hipStreamSynchronize(s->stream));
-	void **vs[] = {&s->vp, &s->vr, &s->vz, &s->vs, &s->vpre, &s->vq};
+	void **vs[] = {&s->vp, &s->vr, &s->vz, &s->vs, &s->vpre, &s->vq, &s->vs2};
 	for (void **v : vs) {
 		if (*v) LFA_HIP(s, hipFree(*v));
 		*v = nullptr;
@@ -918,8 +1238,8 @@ static bool is_ml(const lfa_sim *s) { return s->prm.precond == LFA_PRECOND_MULTI
 static int sigma_parts(const lfa_sim *s) { return pcg_grid(s->n_ptiles) + (is_ml(s) ? 1 : 0); }
 
 template <typename real> static CoarseFields<real> make_coarse(lfa_sim *s) {
-	CoarseFields<real> cf{s->c_diag, {s->c_w[0], s->c_w[1], s->c_w[2]}, s->c_unk, (real *)s->c_pre, (real *)s->c_r,
-	                      (real *)s->c_x};
+	CoarseFields<real> cf{s->c_diag, {s->c_w[0], s->c_w[1], s->c_w[2]}, s->c_unk, (real *)s->c_pre,
+	                      s->c_r_cur ? (real *)s->c_r_cur : (real *)s->c_r, (real *)s->c_x};
 	if (const char *e = getenv("LFA_COARSE_W1")) cf.w1 = (real)atof(e);  // experiment knobs (tools/pcg_convergence.py)
 	if (const char *e = getenv("LFA_COARSE_W2")) cf.w2 = (real)atof(e);
 	return cf;
@@ -969,7 +1289,7 @@ template <typename real> static int coarse_setup(lfa_sim *s) {
 	if (ncp1 != s->ncp1 || s->coarse_elem != sizeof(real)) {
 		LFA_HIP(s, hipStreamSynchronize(s->stream));
 		void **ptrs[] = {(void **)&s->c_diag, (void **)&s->c_w[0], (void **)&s->c_w[1], (void **)&s->c_w[2],
-		                 (void **)&s->c_unk, &s->c_pre, &s->c_r, &s->c_x, &s->c_r2, &s->c_x2, (void **)&s->slot_l1,
+		                 (void **)&s->c_unk, &s->c_pre, &s->c_r, &s->c_as, &s->c_x, &s->c_r2, &s->c_x2, (void **)&s->slot_l1,
 		                 (void **)&s->l1_tiles, (void **)&s->l1_l2};
 		for (void **p : ptrs) {
 			if (*p) LFA_HIP(s, hipFree(*p));
@@ -979,7 +1299,8 @@ template <typename real> static int coarse_setup(lfa_sim *s) {
 		for (int d = 0; d < 3; ++d) LFA_HIP(s, hipMalloc(&s->c_w[d], ncp1 * 4));
 		LFA_HIP(s, hipMalloc(&s->c_unk, ncp1));
 		LFA_HIP(s, hipMalloc(&s->c_pre, ncp1 * sizeof(real)));
-		LFA_HIP(s, hipMalloc(&s->c_r, ncp1 * sizeof(real)));
+		LFA_HIP(s, hipMalloc(&s->c_r, 2 * ncp1 * sizeof(real)));  // [parity][ncp1], see k_pcg_b
+		LFA_HIP(s, hipMalloc(&s->c_as, ncp1 * sizeof(real)));
 		LFA_HIP(s, hipMalloc(&s->c_x, ncp1 * sizeof(real)));
 		LFA_HIP(s, hipMalloc(&s->c_r2, (size_t)g1.nt * sizeof(real)));
 		LFA_HIP(s, hipMalloc(&s->c_x2, (size_t)g1.nt * sizeof(real)));
@@ -1008,7 +1329,8 @@ template <typename real> static int coarse_setup(lfa_sim *s) {
 	LFA_HIP(s, hipMemsetAsync(s->c_diag, 0, ncp1 * 4, s->stream));
 	for (int d = 0; d < 3; ++d) LFA_HIP(s, hipMemsetAsync(s->c_w[d], 0, ncp1 * 4, s->stream));
 	LFA_HIP(s, hipMemsetAsync(s->c_unk, 0, ncp1, s->stream));
-	LFA_HIP(s, hipMemsetAsync(s->c_r, 0, ncp1 * sizeof(real), s->stream));
+	LFA_HIP(s, hipMemsetAsync(s->c_r, 0, 2 * ncp1 * sizeof(real), s->stream));
+	LFA_HIP(s, hipMemsetAsync(s->c_as, 0, ncp1 * sizeof(real), s->stream));
 	LFA_HIP(s, hipMemsetAsync(s->c_x, 0, ncp1 * sizeof(real), s->stream));
 	LFA_HIP(s, hipMemsetAsync(s->c_pre, 0, ncp1 * sizeof(real), s->stream));
 	TileCtx tc = make_ctx(s);
@@ -1116,6 +1438,12 @@ template <typename real> static int mic_factor(lfa_sim *s) {
 		                   (const int *)nullptr, s->n_ptiles, s->abits, (real *)s->vpre, scale, tau, sigma);
 		LFA_LAUNCH_CHECK(s);
 		if (is_ml(s)) LFA_TRY(coarse_setup<real>(s));
+		if (s->prm.pcg_fused && !s->dist) {
+			if (!s->nbr_table) LFA_HIP(s, hipMalloc(&s->nbr_table, (size_t)s->g.nt * NBR_STRIDE * sizeof(int)));
+			hipLaunchKernelGGL(k_build_nbr_table, dim3((s->n_ptiles + 255) / 256), dim3(256), 0, s->stream, tc,
+			                   is_ml(s) ? (const int *)s->slot_l1 : (const int *)nullptr, s->nbr_table);
+			LFA_LAUNCH_CHECK(s);
+		}
 	}
 	return LFA_OK;
 }
@@ -1235,7 +1563,54 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 	const int chunk = 8;
 	int done = -1, nan = 0, i = 0;
 	int *hstate = (int *)s->h_pinned;
-	while (i < maxit && done < 0) {
+	// fused iteration (k_pcg_a / k_pcg_b): single domain, tile-local MIC(0) with or without the coarse levels
+	const bool fused = s->prm.pcg_fused && !dist && s->prm.precond != LFA_PRECOND_MIC0_EXACT;
+	const bool embed = fused && is_ml(s) && s->n_l1tiles <= 64;
+	real *sbuf[2] = {(real *)s->vs, (real *)s->vs2};
+	real *crbuf[2] = {(real *)s->c_r, is_ml(s) ? (real *)s->c_r + s->ncp1 : (real *)nullptr};
+	while (fused && i < maxit && done < 0) {
+		const int end = std::min(maxit, i + chunk);
+		for (; i < end; ++i) {
+			const int po = i & 1, pn = po ^ 1;
+			hipLaunchKernelGGL(k_pcg_a<real>, dim3(G), dim3(256), 0, s->stream, s->n_ptiles, (const int *)s->nbr_table, s->abits,
+			                   (const real *)v.z, (const real *)sbuf[po], sbuf[pn], v.q, scale, P + (po ? PART_SIG1 : PART_SIG0),
+			                   P + (pn ? PART_SIG1 : PART_SIG0), NS, i == 0 ? 1 : 0, P + PART_RMAX, G, s->prm.tolerance, i,
+			                   s->pcg_state, s->pcg_hist, P + PART_ZS, cx, (const real *)s->c_x2, (const int *)s->l1_l2,
+			                   is_ml(s) ? (real *)s->c_as : (real *)nullptr);
+			LFA_LAUNCH_CHECK(s);
+			CoarseFields<real> cf = is_ml(s) ? make_coarse<real>(s) : CoarseFields<real>{};
+			if (embed) {
+				cf.r = crbuf[po];
+				cf.as = (const real *)s->c_as;
+				CoarseArgs ca{s->l1_tiles, s->n_l1tiles, s->a2inv, s->c_x2, (double *)s->pcg_hist + 6144, (unsigned *)(s->pcg_state + 4)};
+				hipLaunchKernelGGL((k_pcg_b<real, true>), dim3(G + PCG_COARSE_BLOCKS), dim3(256), 0, s->stream,
+				                   (const int *)s->ptiles, s->n_ptiles, s->abits, v, (const real *)sbuf[pn], scale, P + (po ? PART_SIG1 : PART_SIG0), NS, P + PART_ZS, G,
+				                   P + PART_RMAX, P + (pn ? PART_SIG1 : PART_SIG0), s->pcg_state, crbuf[pn],
+				                   (const int *)s->slot_l1, cf, ca);
+				LFA_LAUNCH_CHECK(s);
+			} else {
+				hipLaunchKernelGGL((k_pcg_b<real, false>), dim3(G), dim3(256), 0, s->stream, (const int *)s->ptiles,
+				                   s->n_ptiles, s->abits, v, (const real *)sbuf[pn], scale, P + (po ? PART_SIG1 : PART_SIG0), NS, P + PART_ZS, G,
+				                   P + PART_RMAX, P + (pn ? PART_SIG1 : PART_SIG0), s->pcg_state, crbuf[pn],
+				                   (const int *)s->slot_l1, CoarseFields<real>{}, CoarseArgs{});
+				LFA_LAUNCH_CHECK(s);
+				if (is_ml(s)) {  // more than 64 level-1 blocks: the coarse levels follow as their own launches
+					s->c_r_cur = crbuf[pn];
+					LFA_TRY(coarse_apply<real>(s, P + (pn ? PART_SIG1 : PART_SIG0), s->stream));
+					s->c_r_cur = nullptr;
+				}
+			}
+		}
+		// the residual of the last iteration of the chunk is tested here (k_pcg_a tests the one before it)
+		hipLaunchKernelGGL(k_check_converged, dim3(1), dim3(256), 0, s->stream, P + PART_RMAX, G, s->prm.tolerance, i - 1,
+		                   s->pcg_state, s->pcg_hist);
+		LFA_LAUNCH_CHECK(s);
+		LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 8, hipMemcpyDeviceToHost, s->stream));
+		LFA_HIP(s, hipStreamSynchronize(s->stream));
+		done = hstate[0];
+		nan = hstate[1];
+	}
+	while (!fused && i < maxit && done < 0) {
 		const int end = std::min(maxit, i + chunk);
 		for (; i < end; ++i) {
 			const int po = i & 1, pn = po ^ 1;
@@ -1463,6 +1838,32 @@ template <typename real> static int bench_launch(lfa_sim *s, int which) {
 	case LFA_K_COARSE:
 		if (!is_ml(s)) return lfa_fail(s, LFA_E_INVALID, "no coarse levels with this preconditioner");
 		return coarse_apply<real>(s, P + PART_SIG1, s->stream);
+	case LFA_K_PCG_A:
+		if (!s->nbr_table || !s->prm.pcg_fused) return lfa_fail(s, LFA_E_INVALID, "fused kernels: solve with pcg_fused = 1 first");
+		hipLaunchKernelGGL(k_pcg_a<real>, dim3(G), dim3(256), 0, s->stream, s->n_ptiles, (const int *)s->nbr_table, s->abits,
+		                   (const real *)v.z, (const real *)v.s, (real *)s->vs2, v.q, scale, P + PART_SIG0, P + PART_SIG0, G, 0,
+		                   P + PART_RMAX, G, -1.0, 1, s->pcg_state, s->pcg_hist + 4095, P + PART_ZS,
+		                   is_ml(s) ? (const real *)s->c_x : (const real *)nullptr, (const real *)s->c_x2, (const int *)s->l1_l2,
+		                   is_ml(s) ? (real *)s->c_as : (real *)nullptr);
+		break;
+	case LFA_K_PCG_B: {
+		if (!s->nbr_table || !s->prm.pcg_fused) return lfa_fail(s, LFA_E_INVALID, "fused kernels: solve with pcg_fused = 1 first");
+		const bool embed = is_ml(s) && s->n_l1tiles <= 64;
+		real *cr1 = is_ml(s) ? (real *)s->c_r + s->ncp1 : (real *)nullptr;
+		if (embed) {
+			CoarseFields<real> cf = make_coarse<real>(s);
+			cf.as = (const real *)s->c_as;
+			CoarseArgs ca{s->l1_tiles, s->n_l1tiles, s->a2inv, s->c_x2, (double *)s->pcg_hist + 6144, (unsigned *)(s->pcg_state + 4)};
+			hipLaunchKernelGGL((k_pcg_b<real, true>), dim3(G + PCG_COARSE_BLOCKS), dim3(256), 0, s->stream,
+			                   (const int *)s->ptiles, s->n_ptiles, s->abits, v, (const real *)s->vs2, scale, P + PART_SIG0, G, P + PART_ZS, G, P + PART_RMAX, P + PART_SIG1,
+			                   s->pcg_state, cr1, (const int *)s->slot_l1, cf, ca);
+		} else {
+			hipLaunchKernelGGL((k_pcg_b<real, false>), dim3(G), dim3(256), 0, s->stream, (const int *)s->ptiles, s->n_ptiles,
+			                   s->abits, v, (const real *)s->vs2, scale, P + PART_SIG0, G, P + PART_ZS, G, P + PART_RMAX, P + PART_SIG1, s->pcg_state, cr1,
+			                   (const int *)s->slot_l1, CoarseFields<real>{}, CoarseArgs{});
+		}
+		break;
+	}
 	case LFA_K_UPDATE_S:
 		hipLaunchKernelGGL(k_update_s<real>, dim3(G), dim3(256), 0, s->stream, tc, v, P + PART_SIG0, P + PART_SIG0, G, 0,
 		                   s->pcg_state, s->abits, is_ml(s) ? (const real *)s->c_x : (const real *)nullptr,
@@ -1482,7 +1883,8 @@ extern "C" int lfa_bench_kernel(lfa_sim *s, int which, int reps, double *mean_ms
 		for (auto &e : s->ev) LFA_HIP(s, hipEventCreate(&e));
 		s->ev_created = true;
 	}
-	const bool is_pcg = which <= LFA_K_UPDATE_S || which == LFA_K_MIC_FINE || which == LFA_K_COARSE;
+	const bool is_pcg = which <= LFA_K_UPDATE_S || which == LFA_K_MIC_FINE || which == LFA_K_COARSE ||
+	                    which == LFA_K_PCG_A || which == LFA_K_PCG_B;
 	if (is_pcg) {
 		if (!s->system_valid) return lfa_fail(s, LFA_E_INVALID, "lfa_bench_kernel: no pressure system on the device");
 		int init_state[2] = {-1, 0};  // "still iterating": the kernels early-out once a solve has converged
