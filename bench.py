@@ -22,7 +22,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6.3 TB/s achievable
 
 # algorithmic bytes per unit; n = PCG unknowns, Np particles, Nc cells of the processed tiles
-PCG_BYTES = {"spmv_dot": 17, "axpy_max": 28, "mic_apply_dot": 34, "update_s": 12}
+PCG_BYTES_UNFUSED = {"spmv_dot": 17, "axpy_max": 28, "mic_apply_dot": 34, "update_s": 12}
+# fused iteration (default): k_pcg_a = update_s + spmv_dot, k_pcg_b = axpy_max + mic_apply_dot; same 91 n in total
+PCG_BYTES_FUSED = {"pcg_a": 12 + 17, "pcg_b": 28 + 34}
 
 
 def cpu_baseline(sample, steps):
@@ -71,6 +73,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-full-step", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="one launch per vector operation in the PCG loop (pcg_fused = 0)")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent copies of the domain instead of z-slabs")
     args = ap.parse_args()
 
@@ -107,7 +110,9 @@ def main():
                            "multilevel": lfa.PRECOND_MULTILEVEL}[args.precond],
                   pcg_dtype=lfa.PCG_F64 if args.pcg_dtype == "f64" else lfa.PCG_F32,
                   p2g_variant=lfa.P2G_GLOBAL_ATOMIC if args.p2g == "atomic" else lfa.P2G_LDS_BINNED,
-                  max_iterations=args.max_iterations)
+                  max_iterations=args.max_iterations, pcg_fused=0 if args.unfused else 1)
+    fused = not args.unfused and args.precond != "exact" and (world == 1 or args.replicas)
+    PCG_BYTES = PCG_BYTES_FUSED if fused else PCG_BYTES_UNFUSED
     if world > 1 and not args.replicas:
         # one RCCL communicator per handle: rank 0 creates the id, torch.distributed (RCCL) broadcasts it
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
@@ -173,6 +178,7 @@ def main():
             "unknowns": n_unknowns, "particles_per_gpu": npart,
             "precond": {"tiled": "MIC(0) per 8^3 tile", "exact": "MIC(0) exact (tile hyperplanes)",
                         "multilevel": "MIC(0) per 8^3 tile + tile-aggregate coarse correction"}[args.precond],
+            "pcg_loop": "fused: 2 launches per iteration (k_pcg_a, k_pcg_b)" if fused else "5 launches per iteration",
             "p2g": args.p2g, "pcg_tolerance": 1e-6, "pcg_max_iterations": args.max_iterations,
             "parallelism": parallelism,
         },
@@ -189,12 +195,12 @@ def main():
         # live HIP-event timing of each hot kernel on the handle's stream (mean of 20 launches)
         apic = cfg["method"] == 2
         kernels = {}
-        for name in ("spmv_dot", "axpy_max", "mic_apply_dot", "update_s"):
-            # mic_apply_dot = the launch of the PCG loop: tile sweeps + the embedded coarse-level workgroups
+        for name in PCG_BYTES:
+            # pcg_b / mic_apply_dot = the launch of the PCG loop: tile sweeps + the embedded coarse-level workgroups
             ms = sim.bench_kernel(name, 20)
             b = PCG_BYTES[name] * n_unknowns * (2 if args.pcg_dtype == "f64" else 1)
             kernels[name] = {"ms": ms, "algorithmic_bytes": b, "GBps": b / ms * 1e-6}
-        if args.precond == "multilevel":
+        if args.precond == "multilevel" and not fused:
             kernels["mic_sweeps_without_coarse_levels"] = {"ms": sim.bench_kernel("mic_fine", 20), "algorithmic_bytes": 0,
                                                            "GBps": 0.0}
             kernels["coarse_levels_as_own_launch"] = {"ms": sim.bench_kernel("coarse_levels", 20), "algorithmic_bytes": 0,

@@ -865,6 +865,12 @@ k_add_coarse(TileCtx tc, const uint8_t *abits, real *z, const real *coarse_x, co
 	} while (0)
 
 template <typename real> struct alignas(2 * sizeof(real)) BCPair { real b, c; };
+/// Four consecutive cells of a tile field: one 16-B (fp32) global or LDS access per lane.
+template <typename real> struct alignas(4 * sizeof(real)) V4 {
+	real e[4];
+	__device__ real &operator[](int i) { return e[i]; }
+	__device__ const real &operator[](int i) const { return e[i]; }
+};
 #define SWEEP_X_LEN (LFA_TILE_CELLS + 128)
 
 /// X: cell 0 of a SWEEP_X_LEN array whose first and last 64 entries are zero. In: X = pre^2 r. Out: BC[i].c = z_i.
@@ -897,26 +903,36 @@ template <typename real> __device__ inline void fast_tile_sweeps(real *X, BCPair
 	}
 }
 
-/// Per particle-tile slot, 16 ints (one 64-B scalar load): [0..5] tile ids of the face neighbours that hold unknowns
-/// (-x,+x,-y,+y,-z,+z; -1 otherwise), [6] own tile id, [8..13] their level-1 indices, [14] own level-1 index.
-#define NBR_STRIDE 16
+/// Per particle-tile slot, one 128-B row of ints (scalar loads): [0..5] tile ids of the face neighbours that hold
+/// unknowns (-x,+x,-y,+y,-z,+z; -1 otherwise), [6] own tile id, [7] own level-1 index; [8..13] / [14] index into the
+/// level-1 correction of the neighbours / of the tile itself, [16..21] / [22] the same for the top-level correction, so
+/// that k_pcg_a finds every coarse value with one independent load.
+#define NBR_STRIDE 32
 __global__ void __launch_bounds__(256)
-k_build_nbr_table(TileCtx tc, const int *slot_l1, int *nbr) {
+k_build_nbr_table(TileCtx tc, const int *slot_l1, const int *l1_l2, int *nbr) {
 	const int slot = blockIdx.x * blockDim.x + threadIdx.x;
 	if (slot >= tc.n_ptiles) return;
 	const int tile = tc.ptiles[slot];
 	int nb[6];
 	face_neighbours(tc, tile, nb);
 	int *o = nbr + (size_t)slot * NBR_STRIDE;
+	for (int k = 0; k < NBR_STRIDE; ++k) o[k] = 0;
 #pragma unroll
 	for (int k = 0; k < 6; ++k) {
 		o[k] = nb[k];
-		o[8 + k] = (slot_l1 && nb[k] >= 0) ? slot_l1[tc.tile_pslot[nb[k]]] : 0;
+		if (slot_l1 && nb[k] >= 0) {
+			const int j1 = slot_l1[tc.tile_pslot[nb[k]]];
+			o[8 + k] = j1;
+			o[16 + k] = l1_l2[j1 >> 9];
+		}
 	}
 	o[6] = tile;
-	o[7] = 0;
-	o[14] = slot_l1 ? slot_l1[slot] : 0;
-	o[15] = 0;
+	if (slot_l1) {
+		const int i1 = slot_l1[slot];
+		o[7] = i1;
+		o[14] = i1;
+		o[22] = l1_l2[i1 >> 9];
+	}
 }
 
 template <typename real, bool EMBED>
@@ -952,41 +968,58 @@ k_pcg_b(const int *__restrict__ ptiles, int n_ptiles, const uint8_t *__restrict_
 	bool nan = false;
 	// Software pipeline over the tiles of this wave: the loads of the next tile are issued before the sweeps of the
 	// current one (which only touch LDS), so HBM latency hides behind the 44 dependent hyperplanes.
+	// Global accesses are 16 B per lane: lane l holds cells [256 k + 4 l, 256 k + 4 l + 4), k = 0, 1, of the tile's 512.
 	const int stride = nblk * PCG_WAVES;
 	int slot = blk * PCG_WAVES + wid;
-	uint8_t ta[8];
-	real tpre[8], tp[8], ts[8], tr[8], tq[8];
+	uint32_t ta[2];
+	V4<real> tpre[2], tp[2], ts[2], tr[2], tq[2];
 	size_t base = 0;
-	if (slot < n_ptiles) {
-		base = (size_t)ptiles[slot] * LFA_TILE_CELLS;
+	auto load_tile = [&](int sl) {
+		base = (size_t)ptiles[sl] * LFA_TILE_CELLS;
 #pragma unroll
-		for (int zz = 0; zz < 8; ++zz) {
-			const size_t b = base + zz * 64 + lane;
-			ta[zz] = abits[b]; tpre[zz] = v.pre[b]; tp[zz] = v.p[b]; ts[zz] = s_cur[b]; tr[zz] = v.r[b]; tq[zz] = v.q[b];
+		for (int k = 0; k < 2; ++k) {
+			const size_t b = base + 256 * k + 4 * lane;
+			ta[k] = *(const uint32_t *)(abits + b);
+			tpre[k] = *(const V4<real> *)(v.pre + b);
+			tp[k] = *(const V4<real> *)(v.p + b);
+			ts[k] = *(const V4<real> *)(s_cur + b);
+			tr[k] = *(const V4<real> *)(v.r + b);
+			tq[k] = *(const V4<real> *)(v.q + b);
 		}
-	}
+	};
+	if (slot < n_ptiles) load_tile(slot);
 	while (slot < n_ptiles) {
 		real rn[8];
 		double sr = 0.0;
 		WAVE_FENCE();
-		// entries of non-unknown cells are exact zeros in p, s, r, q and pre, so the arithmetic needs no mask
+		// entries of non-unknown cells are exact zeros in r, q and pre, so only p and r are masked
 #pragma unroll
-		for (int zz = 0; zz < 8; ++zz) {
-			const size_t b = base + zz * 64 + lane;
-			const bool unk = (ta[zz] & AB_UNKNOWN) != 0;
-			const real pn = tp[zz] + alpha * ts[zz];
-			const real rr = unk ? tr[zz] + (-alpha) * tq[zz] : (real)0;
-			if (unk) {
-				v.p[b] = pn;
-				v.r[b] = rr;
+		for (int k = 0; k < 2; ++k) {
+			const size_t b = base + 256 * k + 4 * lane;
+			const int c0 = 256 * k + 4 * lane;
+			V4<real> pn, rv, xv;
+			BCPair<real> bc[4];
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				const uint32_t a = ta[k] >> (8 * j);
+				const bool unk = (a & AB_UNKNOWN) != 0;
+				const real pj = unk ? tp[k][j] + alpha * ts[k][j] : (real)0;
+				const real rr = unk ? tr[k][j] + (-alpha) * tq[k][j] : (real)0;
 				nan |= rr != rr;
-				m = (double)rr > m ? (double)rr : m;
+				if (unk) m = (double)rr > m ? (double)rr : m;
+				sr += (double)rr;
+				rn[4 * k + j] = rr;
+				pn[j] = pj;
+				rv[j] = rr;
+				const real d = tpre[k][j] * tpre[k][j], c = scale * d;
+				xv[j] = d * rr;
+				bc[j] = BCPair<real>{(a & AB_FLUID) ? c : (real)0, c};
 			}
-			sr += (double)rr;
-			rn[zz] = rr;
-			const real d = tpre[zz] * tpre[zz], c = scale * d;
-			X[zz * 64 + lane] = d * rr;
-			BC[zz * 64 + lane] = BCPair<real>{(ta[zz] & AB_FLUID) ? c : (real)0, c};
+			*(V4<real> *)(v.p + b) = pn;
+			*(V4<real> *)(v.r + b) = rv;
+			*(V4<real> *)(X + c0) = xv;
+#pragma unroll
+			for (int j = 0; j < 4; ++j) BC[c0 + j] = bc[j];
 		}
 		if (coarse_r_out) {  // exact restriction of the new residual: right-hand side recurrence of the next iteration
 			sr = wave_sum(sr);
@@ -994,21 +1027,19 @@ k_pcg_b(const int *__restrict__ ptiles, int n_ptiles, const uint8_t *__restrict_
 		}
 		const size_t obase = base;
 		slot += stride;
-		if (slot < n_ptiles) {
-			base = (size_t)ptiles[slot] * LFA_TILE_CELLS;
-#pragma unroll
-			for (int zz = 0; zz < 8; ++zz) {
-				const size_t b = base + zz * 64 + lane;
-				ta[zz] = abits[b]; tpre[zz] = v.pre[b]; tp[zz] = v.p[b]; ts[zz] = s_cur[b]; tr[zz] = v.r[b]; tq[zz] = v.q[b];
-			}
-		}
+		if (slot < n_ptiles) load_tile(slot);
 		WAVE_FENCE();
 		fast_tile_sweeps<real>(X, BC, lane);
 #pragma unroll
-		for (int zz = 0; zz < 8; ++zz) {
-			const real zv = BC[zz * 64 + lane].c;
-			v.z[obase + zz * 64 + lane] = zv;
-			acc += (double)zv * (double)rn[zz];
+		for (int k = 0; k < 2; ++k) {
+			const int c0 = 256 * k + 4 * lane;
+			V4<real> zv;
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				zv[j] = BC[c0 + j].c;
+				acc += (double)zv[j] * (double)rn[4 * k + j];
+			}
+			*(V4<real> *)(v.z + obase + c0) = zv;
 		}
 	}
 	m = wave_max(m);
@@ -1028,13 +1059,14 @@ k_pcg_b(const int *__restrict__ ptiles, int n_ptiles, const uint8_t *__restrict_
 	}
 }
 
-template <typename real>
+template <typename real, bool FIRST, bool COARSE>
 __global__ void __launch_bounds__(256)
 k_pcg_a(int n_ptiles, const int *__restrict__ nbr, const uint8_t *__restrict__ abits, const real *__restrict__ z,
         const real *__restrict__ s_old, real *__restrict__ s_new, real *__restrict__ q, real scale,
-        const double *part_sig_new, const double *part_sig_old, int n_sig, int first, const double *part_rmax, int n_rmax,
-        double tol, int iter, int *state, double *hist, double *part_qs, const real *__restrict__ coarse_x,
-        const real *__restrict__ coarse_x2, const int *__restrict__ l1_l2, real *coarse_as) {
+        const double *part_sig_new, int n_sig_new, const double *part_sig_old, int n_sig_old,
+        const double *part_rmax, int n_rmax, double tol, int iter, int *state, double *hist, double *part_qs,
+        const real *__restrict__ coarse_x,
+        const real *__restrict__ coarse_x2, real *coarse_as) {
 	__shared__ real halo[PCG_WAVES][LFA_HALO_CELLS];
 	__shared__ double lds[256];
 	if (state[0] >= 0) return;
@@ -1053,70 +1085,84 @@ k_pcg_a(int n_ptiles, const int *__restrict__ nbr, const uint8_t *__restrict__ a
 		if (stop) return;
 	}
 	real beta = (real)0;
-	if (!first) {
-		const double sn = reduce_partials_sum(part_sig_new, n_sig, lds);
-		const double so = reduce_partials_sum(part_sig_old, n_sig, lds);
+	if (!FIRST) {
+		const double sn = reduce_partials_sum(part_sig_new, n_sig_new, lds);
+		const double so = reduce_partials_sum(part_sig_old, n_sig_old, lds);
 		beta = (real)(sn / so);
 	}
 	const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
 	real *h = halo[wid];
 	double acc = 0.0;
-	for (int slot = blockIdx.x * PCG_WAVES + wid; slot < n_ptiles; slot += gridDim.x * PCG_WAVES) {
-		const int *nt = nbr + (size_t)slot * NBR_STRIDE;
-		int nb[6];
-#pragma unroll
-		for (int k = 0; k < 6; ++k) nb[k] = nt[k];
-		const size_t base = (size_t)nt[6] * LFA_TILE_CELLS;
-		// every global load of the tile is issued before the first use: interior, then the six faces
-		// (face lanes = (a, b) over the two in-face axes)
-		const size_t fo[6] = {(size_t)(ly * 64 + lx * 8 + 7), (size_t)(ly * 64 + lx * 8), (size_t)(ly * 64 + 56 + lx),
-		                      (size_t)(ly * 64 + lx), (size_t)(7 * 64 + lane), (size_t)lane};
-		uint8_t ab[8], fab[6];
-		real zi[8], si[8], fz[6], fs[6];
+	// XCD-aware slot order: workgroup b runs on XCD b % 8 (observed, speed only), so the workgroups of one XCD take one
+	// contiguous chunk of the (tile-id ordered) slot list and find their y/z face neighbours in their own L2.
+	const int G = (int)gridDim.x, per = G >> 3, rem = G & 7, xcd = (int)blockIdx.x & 7;
+	const int vblk = xcd * per + (xcd < rem ? xcd : rem) + ((int)blockIdx.x >> 3);
+	const int stride = G * PCG_WAVES;
+	// face lanes = (a, b) over the two in-face axes
+	const int fo[6] = {ly * 64 + lx * 8 + 7, ly * 64 + lx * 8, ly * 64 + 56 + lx, ly * 64 + lx, 7 * 64 + lane, lane};
+	// Software pipeline: every global load of the next tile (interior, six faces, coarse values) is in flight while the
+	// current tile is computed.
+	int slot = vblk * PCG_WAVES + wid;
+	uint32_t ab[8], fab[6];  // one register each (see k_pcg_b)
+	real zi[8], si[8], fz[6], fs[6], xc = (real)0, xn[6];
+	size_t base = 0;
+	int l1 = 0;
+	bool fvalid[6];
+	auto load_tile = [&](int sl) {
+		// branch-free: a missing neighbour reads the tile's own cells (masked when consumed), every index comes from the
+		// slot's table row (read as six 16-B scalar loads), so all loads of the tile are independent of each other
+		const int4 *row = (const int4 *)(nbr + (size_t)sl * NBR_STRIDE);
+		const int4 r0 = row[0], r1 = row[1];
+		const int nbk[6] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y};
+		const int own = r1.z;
+		base = (size_t)own * LFA_TILE_CELLS;
+		l1 = r1.w;
 #pragma unroll
 		for (int zz = 0; zz < 8; ++zz) {
 			const size_t b = base + zz * 64 + lane;
 			ab[zz] = abits[b];
 			zi[zz] = z[b];
-			si[zz] = first ? (real)0 : s_old[b];
+			si[zz] = FIRST ? (real)0 : s_old[b];
 		}
 #pragma unroll
 		for (int k = 0; k < 6; ++k) {
-			fab[k] = 0; fz[k] = (real)0; fs[k] = (real)0;
-			if (nb[k] >= 0) {
-				const size_t j = (size_t)nb[k] * LFA_TILE_CELLS + fo[k];
-				fab[k] = abits[j];
-				fz[k] = z[j];
-				fs[k] = first ? (real)0 : s_old[j];
-			}
+			fvalid[k] = nbk[k] >= 0;
+			const size_t j = (size_t)(nbk[k] >= 0 ? nbk[k] : own) * LFA_TILE_CELLS + fo[k];
+			fab[k] = abits[j];
+			fz[k] = z[j];
+			fs[k] = FIRST ? (real)0 : s_old[j];
 		}
-		real xc = (real)0, xn[6] = {(real)0, (real)0, (real)0, (real)0, (real)0, (real)0};
-		if (coarse_x) {
-			const int i1 = nt[14];
-			xc = coarse_x[i1] + coarse_x2[l1_l2[i1 >> 9]];
+		if (COARSE) {
+			const int4 r2 = row[2], r3 = row[3], r4 = row[4], r5 = row[5];
+			const int i1[7] = {r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z}, i2[7] = {r4.x, r4.y, r4.z, r4.w, r5.x, r5.y, r5.z};
 #pragma unroll
-			for (int k = 0; k < 6; ++k)
-				if (nb[k] >= 0) {
-					const int j1 = nt[8 + k];
-					xn[k] = coarse_x[j1] + coarse_x2[l1_l2[j1 >> 9]];
-				}
+			for (int k = 0; k < 6; ++k) xn[k] = coarse_x[i1[k]] + coarse_x2[i2[k]];
+			xc = coarse_x[i1[6]] + coarse_x2[i2[6]];
 		}
+	};
+	if (slot < n_ptiles) load_tile(slot);
+	while (slot < n_ptiles) {
 		WAVE_FENCE();
 		// the new search direction (k_update_s): z + coarse part on the unknowns, + beta s
+		uint32_t ac[8];
+		const size_t obase = base;
+		const int ol1 = l1;
 #pragma unroll
 		for (int zz = 0; zz < 8; ++zz) {
 			real zj = zi[zz];
-			if (coarse_x && (ab[zz] & AB_UNKNOWN)) zj += xc;
-			const real sj = first ? zj : zj + beta * si[zz];
-			s_new[base + zz * 64 + lane] = sj;
+			ac[zz] = ab[zz];
+			if (COARSE && (ab[zz] & AB_UNKNOWN)) zj += xc;
+			const real sj = FIRST ? zj : zj + beta * si[zz];
+			s_new[obase + zz * 64 + lane] = sj;
 			h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)] = sj;
 		}
 		real fv[6];
 #pragma unroll
 		for (int k = 0; k < 6; ++k) {
 			real zj = fz[k];
-			if (coarse_x && (fab[k] & AB_UNKNOWN)) zj += xn[k];
-			fv[k] = first ? zj : zj + beta * fs[k];
+			if (COARSE && (fab[k] & AB_UNKNOWN)) zj += xn[k];
+			fv[k] = FIRST ? zj : zj + beta * fs[k];
+			fv[k] = fvalid[k] ? fv[k] : (real)0;
 		}
 		h[0 + 10 * (lx + 1) + 100 * (ly + 1)] = fv[0];
 		h[9 + 10 * (lx + 1) + 100 * (ly + 1)] = fv[1];
@@ -1124,12 +1170,14 @@ k_pcg_a(int n_ptiles, const int *__restrict__ nbr, const uint8_t *__restrict__ a
 		h[(lx + 1) + 10 * 9 + 100 * (ly + 1)] = fv[3];
 		h[(lx + 1) + 10 * (ly + 1) + 100 * 0] = fv[4];
 		h[(lx + 1) + 10 * (ly + 1) + 100 * 9] = fv[5];
+		slot += stride;
+		if (slot < n_ptiles) load_tile(slot);
 		WAVE_FENCE();
 		double sq = 0.0;
 #pragma unroll
 		for (int zz = 0; zz < 8; ++zz) {
 			const int i = (lx + 1) + 10 * (ly + 1) + 100 * (zz + 1);
-			const uint8_t a = ab[zz];
+			const uint32_t a = ac[zz];
 			real out = (real)0;
 			if (a & AB_UNKNOWN) {
 				const real F = (a & AB_FLUID) ? (real)1 : (real)0;
@@ -1145,11 +1193,11 @@ k_pcg_a(int n_ptiles, const int *__restrict__ nbr, const uint8_t *__restrict__ a
 				acc += (double)out * (double)sc;
 				sq += (double)out;
 			}
-			q[base + zz * 64 + lane] = out;
+			q[obase + zz * 64 + lane] = out;
 		}
-		if (coarse_as) {
+		if (COARSE) {
 			sq = wave_sum(sq);
-			if (lane == 0) coarse_as[nt[14]] = (real)sq;
+			if (lane == 0) coarse_as[ol1] = (real)sq;
 		}
 	}
 	block_partial_sum(acc, lds, part_qs);
@@ -1441,7 +1489,7 @@ template <typename real> static int mic_factor(lfa_sim *s) {
 		if (s->prm.pcg_fused && !s->dist) {
 			if (!s->nbr_table) LFA_HIP(s, hipMalloc(&s->nbr_table, (size_t)s->g.nt * NBR_STRIDE * sizeof(int)));
 			hipLaunchKernelGGL(k_build_nbr_table, dim3((s->n_ptiles + 255) / 256), dim3(256), 0, s->stream, tc,
-			                   is_ml(s) ? (const int *)s->slot_l1 : (const int *)nullptr, s->nbr_table);
+			                   is_ml(s) ? (const int *)s->slot_l1 : (const int *)nullptr, (const int *)s->l1_l2, s->nbr_table);
 			LFA_LAUNCH_CHECK(s);
 		}
 	}
@@ -1512,6 +1560,31 @@ extern "C" int lfa_build_system(lfa_sim *s, double dt) {
 	return s->prm.pcg_dtype == LFA_PCG_F64 ? build_system_t<double>(s, dt) : build_system_t<float>(s, dt);
 }
 
+template <typename real, typename... Args>
+static void launch_pcg_a(bool first, bool coarse, int grid, hipStream_t st, Args... a) {
+	if (first && coarse) hipLaunchKernelGGL((k_pcg_a<real, true, true>), dim3(grid), dim3(256), 0, st, a...);
+	else if (first) hipLaunchKernelGGL((k_pcg_a<real, true, false>), dim3(grid), dim3(256), 0, st, a...);
+	else if (coarse) hipLaunchKernelGGL((k_pcg_a<real, false, true>), dim3(grid), dim3(256), 0, st, a...);
+	else hipLaunchKernelGGL((k_pcg_a<real, false, false>), dim3(grid), dim3(256), 0, st, a...);
+}
+
+/// Launch widths (workgroups) of k_pcg_a / k_pcg_b: both kernels are software pipelines over the tiles of a wave, so the
+/// launch is sized to be resident at once (k_pcg_a: 4 workgroups per CU by registers, k_pcg_b: 5 by LDS) and every wave
+/// streams several tiles. LFA_PCG_GA / LFA_PCG_GB override them for experiments (tools/pcg_grid_sweep.sh).
+static void fused_grids(int G, int &GA, int &GB) {
+	static int n_cu = 0;
+	if (!n_cu) {
+		int dev = 0;
+		hipDeviceProp_t prop;
+		n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+		        prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+	}
+	GA = std::min(G, 4 * n_cu);
+	GB = std::min(G, 5 * n_cu);
+	if (const char *e = getenv("LFA_PCG_GA")) GA = std::max(1, std::min(atoi(e), G));
+	if (const char *e = getenv("LFA_PCG_GB")) GB = std::max(1, std::min(atoi(e), G));
+}
+
 template <typename real> static int solve_t(lfa_sim *s, double dt, double *residual, uint64_t *iterations) {
 	if (s->dist && s->prm.precond == LFA_PRECOND_MIC0_EXACT)
 		return lfa_fail(s, LFA_E_UNSUPPORTED, "the exact (hyperplane) MIC(0) schedule is single-GPU only");
@@ -1568,14 +1641,21 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 	const bool embed = fused && is_ml(s) && s->n_l1tiles <= 64;
 	real *sbuf[2] = {(real *)s->vs, (real *)s->vs2};
 	real *crbuf[2] = {(real *)s->c_r, is_ml(s) ? (real *)s->c_r + s->ncp1 : (real *)nullptr};
+	// launch widths of the two fused kernels (workgroups); each kernel reads the other's per-workgroup partials
+	int GA, GB;
+	fused_grids(G, GA, GB);
+	const int NSB = GB + (is_ml(s) ? 1 : 0);
 	while (fused && i < maxit && done < 0) {
 		const int end = std::min(maxit, i + chunk);
 		for (; i < end; ++i) {
 			const int po = i & 1, pn = po ^ 1;
-			hipLaunchKernelGGL(k_pcg_a<real>, dim3(G), dim3(256), 0, s->stream, s->n_ptiles, (const int *)s->nbr_table, s->abits,
-			                   (const real *)v.z, (const real *)sbuf[po], sbuf[pn], v.q, scale, P + (po ? PART_SIG1 : PART_SIG0),
-			                   P + (pn ? PART_SIG1 : PART_SIG0), NS, i == 0 ? 1 : 0, P + PART_RMAX, G, s->prm.tolerance, i,
-			                   s->pcg_state, s->pcg_hist, P + PART_ZS, cx, (const real *)s->c_x2, (const int *)s->l1_l2,
+			// sigma partials: the application before the loop wrote NS of them, k_pcg_b writes NSB
+			const int n_sig_po = i == 0 ? NS : NSB, n_sig_pn = i <= 1 ? NS : NSB;
+			launch_pcg_a<real>(i == 0, is_ml(s), GA, s->stream, s->n_ptiles, (const int *)s->nbr_table, (const uint8_t *)s->abits,
+			                   (const real *)v.z, (const real *)sbuf[po], sbuf[pn], v.q, scale,
+			                   (const double *)(P + (po ? PART_SIG1 : PART_SIG0)), n_sig_po,
+			                   (const double *)(P + (pn ? PART_SIG1 : PART_SIG0)), n_sig_pn, (const double *)(P + PART_RMAX), GB,
+			                   s->prm.tolerance, i, s->pcg_state, s->pcg_hist, P + PART_ZS, cx, (const real *)s->c_x2,
 			                   is_ml(s) ? (real *)s->c_as : (real *)nullptr);
 			LFA_LAUNCH_CHECK(s);
 			CoarseFields<real> cf = is_ml(s) ? make_coarse<real>(s) : CoarseFields<real>{};
@@ -1583,26 +1663,26 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 				cf.r = crbuf[po];
 				cf.as = (const real *)s->c_as;
 				CoarseArgs ca{s->l1_tiles, s->n_l1tiles, s->a2inv, s->c_x2, (double *)s->pcg_hist + 6144, (unsigned *)(s->pcg_state + 4)};
-				hipLaunchKernelGGL((k_pcg_b<real, true>), dim3(G + PCG_COARSE_BLOCKS), dim3(256), 0, s->stream,
-				                   (const int *)s->ptiles, s->n_ptiles, s->abits, v, (const real *)sbuf[pn], scale, P + (po ? PART_SIG1 : PART_SIG0), NS, P + PART_ZS, G,
-				                   P + PART_RMAX, P + (pn ? PART_SIG1 : PART_SIG0), s->pcg_state, crbuf[pn],
-				                   (const int *)s->slot_l1, cf, ca);
+				hipLaunchKernelGGL((k_pcg_b<real, true>), dim3(GB + PCG_COARSE_BLOCKS), dim3(256), 0, s->stream,
+				                   (const int *)s->ptiles, s->n_ptiles, s->abits, v, (const real *)sbuf[pn], scale,
+				                   P + (po ? PART_SIG1 : PART_SIG0), n_sig_po, P + PART_ZS, GA, P + PART_RMAX,
+				                   P + (pn ? PART_SIG1 : PART_SIG0), s->pcg_state, crbuf[pn], (const int *)s->slot_l1, cf, ca);
 				LFA_LAUNCH_CHECK(s);
 			} else {
-				hipLaunchKernelGGL((k_pcg_b<real, false>), dim3(G), dim3(256), 0, s->stream, (const int *)s->ptiles,
-				                   s->n_ptiles, s->abits, v, (const real *)sbuf[pn], scale, P + (po ? PART_SIG1 : PART_SIG0), NS, P + PART_ZS, G,
-				                   P + PART_RMAX, P + (pn ? PART_SIG1 : PART_SIG0), s->pcg_state, crbuf[pn],
-				                   (const int *)s->slot_l1, CoarseFields<real>{}, CoarseArgs{});
+				hipLaunchKernelGGL((k_pcg_b<real, false>), dim3(GB), dim3(256), 0, s->stream, (const int *)s->ptiles,
+				                   s->n_ptiles, s->abits, v, (const real *)sbuf[pn], scale, P + (po ? PART_SIG1 : PART_SIG0),
+				                   n_sig_po, P + PART_ZS, GA, P + PART_RMAX, P + (pn ? PART_SIG1 : PART_SIG0), s->pcg_state,
+				                   crbuf[pn], (const int *)s->slot_l1, CoarseFields<real>{}, CoarseArgs{});
 				LFA_LAUNCH_CHECK(s);
 				if (is_ml(s)) {  // more than 64 level-1 blocks: the coarse levels follow as their own launches
 					s->c_r_cur = crbuf[pn];
-					LFA_TRY(coarse_apply<real>(s, P + (pn ? PART_SIG1 : PART_SIG0), s->stream));
+					LFA_TRY(coarse_apply<real>(s, P + (pn ? PART_SIG1 : PART_SIG0) + GB - G, s->stream));
 					s->c_r_cur = nullptr;
 				}
 			}
 		}
 		// the residual of the last iteration of the chunk is tested here (k_pcg_a tests the one before it)
-		hipLaunchKernelGGL(k_check_converged, dim3(1), dim3(256), 0, s->stream, P + PART_RMAX, G, s->prm.tolerance, i - 1,
+		hipLaunchKernelGGL(k_check_converged, dim3(1), dim3(256), 0, s->stream, P + PART_RMAX, GB, s->prm.tolerance, i - 1,
 		                   s->pcg_state, s->pcg_hist);
 		LFA_LAUNCH_CHECK(s);
 		LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 8, hipMemcpyDeviceToHost, s->stream));
@@ -1818,6 +1898,8 @@ template <typename real> static int bench_launch(lfa_sim *s, int which) {
 	const int G = pcg_grid(s->n_ptiles);
 	const real scale = (real)s->a_scale;
 	double *P = s->partials;
+	int GA, GB;
+	fused_grids(G, GA, GB);
 	switch (which) {
 	case LFA_K_SPMV_DOT:
 		hipLaunchKernelGGL(k_spmv<real>, dim3(G), dim3(256), 0, s->stream, tc, s->abits, (const real *)v.s, v.z, scale,
@@ -1840,11 +1922,11 @@ template <typename real> static int bench_launch(lfa_sim *s, int which) {
 		return coarse_apply<real>(s, P + PART_SIG1, s->stream);
 	case LFA_K_PCG_A:
 		if (!s->nbr_table || !s->prm.pcg_fused) return lfa_fail(s, LFA_E_INVALID, "fused kernels: solve with pcg_fused = 1 first");
-		hipLaunchKernelGGL(k_pcg_a<real>, dim3(G), dim3(256), 0, s->stream, s->n_ptiles, (const int *)s->nbr_table, s->abits,
-		                   (const real *)v.z, (const real *)v.s, (real *)s->vs2, v.q, scale, P + PART_SIG0, P + PART_SIG0, G, 0,
-		                   P + PART_RMAX, G, -1.0, 1, s->pcg_state, s->pcg_hist + 4095, P + PART_ZS,
-		                   is_ml(s) ? (const real *)s->c_x : (const real *)nullptr, (const real *)s->c_x2, (const int *)s->l1_l2,
-		                   is_ml(s) ? (real *)s->c_as : (real *)nullptr);
+		launch_pcg_a<real>(false, is_ml(s), GA, s->stream, s->n_ptiles, (const int *)s->nbr_table, (const uint8_t *)s->abits,
+		                   (const real *)v.z, (const real *)v.s, (real *)s->vs2, v.q, scale, (const double *)(P + PART_SIG0), G,
+		                   (const double *)(P + PART_SIG0), G, (const double *)(P + PART_RMAX), G, -1.0, 1, s->pcg_state,
+		                   s->pcg_hist + 4095, P + PART_ZS, is_ml(s) ? (const real *)s->c_x : (const real *)nullptr,
+		                   (const real *)s->c_x2, is_ml(s) ? (real *)s->c_as : (real *)nullptr);
 		break;
 	case LFA_K_PCG_B: {
 		if (!s->nbr_table || !s->prm.pcg_fused) return lfa_fail(s, LFA_E_INVALID, "fused kernels: solve with pcg_fused = 1 first");
@@ -1854,11 +1936,11 @@ template <typename real> static int bench_launch(lfa_sim *s, int which) {
 			CoarseFields<real> cf = make_coarse<real>(s);
 			cf.as = (const real *)s->c_as;
 			CoarseArgs ca{s->l1_tiles, s->n_l1tiles, s->a2inv, s->c_x2, (double *)s->pcg_hist + 6144, (unsigned *)(s->pcg_state + 4)};
-			hipLaunchKernelGGL((k_pcg_b<real, true>), dim3(G + PCG_COARSE_BLOCKS), dim3(256), 0, s->stream,
+			hipLaunchKernelGGL((k_pcg_b<real, true>), dim3(GB + PCG_COARSE_BLOCKS), dim3(256), 0, s->stream,
 			                   (const int *)s->ptiles, s->n_ptiles, s->abits, v, (const real *)s->vs2, scale, P + PART_SIG0, G, P + PART_ZS, G, P + PART_RMAX, P + PART_SIG1,
 			                   s->pcg_state, cr1, (const int *)s->slot_l1, cf, ca);
 		} else {
-			hipLaunchKernelGGL((k_pcg_b<real, false>), dim3(G), dim3(256), 0, s->stream, (const int *)s->ptiles, s->n_ptiles,
+			hipLaunchKernelGGL((k_pcg_b<real, false>), dim3(GB), dim3(256), 0, s->stream, (const int *)s->ptiles, s->n_ptiles,
 			                   s->abits, v, (const real *)s->vs2, scale, P + PART_SIG0, G, P + PART_ZS, G, P + PART_RMAX, P + PART_SIG1, s->pcg_state, cr1,
 			                   (const int *)s->slot_l1, CoarseFields<real>{}, CoarseArgs{});
 		}

@@ -1,0 +1,37 @@
+"""Merges the FETCH_SIZE / WRITE_SIZE summaries (tools/pmc_summary.py csv) into profiles/*_pmc_traffic.json.
+
+usage: pmc_traffic.py fetch.csv write.csv out.json "workload text"
+FETCH_SIZE is doubled: gfx950 tallies the 128-B read requests of wide coalesced streams at 64 B
+(/opt/skills/guides/MI355X_MICROARCH.md, section HBM); WRITE_SIZE is taken as reported.
+"""
+import csv
+import json
+import sys
+
+NAMES = {"k_pcg_a<float, false, true>": "pcg_a", "k_pcg_b<float, true>": "pcg_b",
+         "k_pcg_a<float, false, false>": "pcg_a", "k_pcg_b<float, false>": "pcg_b",
+         "k_spmv<float>": "spmv_dot", "k_axpy_max<float>": "axpy_max", "k_mic_apply<float, 0, true>": "mic_apply_dot",
+         "k_update_s<float>": "update_s", "k_p2g_binned<true>": "p2g_scatter", "k_p2g_binned<false>": "p2g_scatter",
+         "k_p2g_finalize<true>": "p2g_finalize", "k_p2g_finalize<false>": "p2g_finalize", "k_g2p<2>": "g2p",
+         "k_g2p<1>": "g2p", "k_g2p<0>": "g2p", "k_tile_scatter": "bin_scatter", "k_correct_tiled": "correct_positions"}
+
+
+def load(path, counter):
+    out = {}
+    for row in csv.DictReader(open(path)):
+        if row["counter"] == counter and row["kernel"] in NAMES:
+            out[NAMES[row["kernel"]]] = float(row["mean_KiB_per_dispatch"]) * 1024.0
+    return out
+
+
+fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+res = {"workload": sys.argv[4],
+       "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py --no-cpu-baseline "
+                 "--no-full-step`; FETCH_SIZE doubled (gfx950 counts 128-B read requests as 64 B, MI355X_MICROARCH.md "
+                 "section HBM)",
+       "hbm_bytes_per_launch": {}}
+for k in sorted(set(fetch) | set(write)):
+    f, w = 2.0 * fetch.get(k, 0.0), write.get(k, 0.0)
+    res["hbm_bytes_per_launch"][k] = {"fetch": f, "write": w, "total": f + w}
+json.dump(res, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(res["hbm_bytes_per_launch"], indent=1))
