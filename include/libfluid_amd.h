@@ -195,6 +195,43 @@ int lfa_dist_init_local(lfa_sim *s, lfa_hub *h, int rank, const int32_t *layer_b
 /* Owned tile layers of this handle ([0, ntz) without a decomposition). */
 int lfa_dist_get_slab(const lfa_sim *s, int32_t *lo, int32_t *hi);
 
+/* -- solid-boundary voxelizer ----------------------------------------------------------------
+ * Replaces fluid::voxelizer (include/fluid/voxelizer.h:14-74, src/voxelizer.cpp:12-136) as the Maya VoxelizerNode
+ * drives it (plugins/maya/nodes/voxelizer_node.cpp:255-343; fluid::obstacle, src/data_structures/obstacle.cpp:9-29, runs
+ * the same sequence). Cell classification is bit-exact (fp64, the reference's operation
+ * order). Host layouts: positions = double[3 nv]; indices = uint32 or uint64 triples (mesh<..., int|size_t, ...>);
+ * voxel types = one byte per cell, x fastest (grid3<cell_type>); cell lists = int32 (x,y,z) triples in grid3::for_each
+ * order, as the plugin passes them on to lfa_set_solid_cells (grid_node.cpp:330-339).
+ *   lfa_voxels_create            : grid3<cell_type>(size, interior) at a given offset  (resize_reposition_grid*)
+ *   lfa_voxels_voxelize_triangles: voxelizer::voxelize_mesh_surface (voxelizer.h:55-63)
+ *   lfa_voxels_mark_exterior     : voxelizer::mark_exterior (voxelizer.cpp:83-124)
+ *   lfa_voxelize_mesh            : get_bounding_box + resize_reposition_grid_constrained + the two above, i.e. the whole
+ *                                  sequence of obstacle.cpp:12-18 / voxelizer_node.cpp:255-268
+ *   lfa_voxels_cells             : ref_grid_size == NULL: voxel-grid coordinates of the selected types ("cells",
+ *                                  voxelizer_node.cpp:285-323); otherwise reference-grid coordinates clipped to the
+ *                                  reference grid ("cells_ref" :325-343). obstacle.cpp:20-28 means the same list
+ *                                  (interior only) but bounds its walk over the voxel grid with a corner in
+ *                                  reference-grid coordinates, which is out of range for positive offsets; that
+ *                                  defect is not reproduced
+ *   lfa_set_solid_from_voxels    : the same selection marked solid in a simulation grid without leaving the device */
+typedef struct lfa_voxels lfa_voxels;
+enum { LFA_VOX_INTERIOR = 0, LFA_VOX_EXTERIOR = 1, LFA_VOX_SURFACE = 2 }; /* voxelizer::cell_type, voxelizer.h:17-21 */
+int lfa_voxels_create(lfa_voxels **out, const uint64_t size[3], const double grid_offset[3], double cell_size, int device);
+void lfa_voxels_destroy(lfa_voxels *v);
+const char *lfa_voxels_last_error(const lfa_voxels *v);
+int lfa_voxels_info(const lfa_voxels *v, int32_t grid_min[3], uint64_t size[3], double grid_offset[3], double *cell_size);
+int lfa_voxels_upload(lfa_voxels *v, const uint8_t *types);
+int lfa_voxels_download(lfa_voxels *v, uint8_t *types);
+int lfa_voxels_voxelize_triangles(lfa_voxels *v, const double *positions, uint64_t n_vertices, const void *indices,
+                                  int index_bytes, uint64_t n_indices);
+int lfa_voxels_mark_exterior(lfa_voxels *v);
+int lfa_voxelize_mesh(lfa_voxels **out, const double *positions, uint64_t n_vertices, const void *indices, int index_bytes,
+                      uint64_t n_indices, double cell_size, const double ref_grid_offset[3], int device);
+int lfa_voxels_count(lfa_voxels *v, int include_interior, int include_surface, const int64_t *ref_grid_size, uint64_t *count);
+int lfa_voxels_cells(lfa_voxels *v, int include_interior, int include_surface, const int64_t *ref_grid_size, int32_t *xyz,
+                     uint64_t capacity, uint64_t *count);
+int lfa_set_solid_from_voxels(lfa_sim *s, lfa_voxels *v, int include_interior, int include_surface);
+
 /* -- measurement --------------------------------------------------------------------------------------------- */
 /* Per-stage device time of the last lfa_step_hot, measured with HIP events on the handle's stream (milliseconds):
  * [0] hash/bin [1] P2G [2] gravity [3] build system [4] PCG loop [5] apply pressure [6] extrapolate [7] G2P

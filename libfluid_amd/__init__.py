@@ -103,6 +103,18 @@ SIGNATURES = {
     "lfa_get_timings": (_int, [_vp, C.POINTER(_dbl * NUM_TIMERS)]),
     "lfa_get_counts": (_int, [_vp, C.POINTER(_u64 * 5)]),
     "lfa_bench_kernel": (_int, [_vp, _int, _int, C.POINTER(_dbl)]),
+    "lfa_voxels_create": (_int, [C.POINTER(_vp), _vp, _vp, _dbl, _int]),
+    "lfa_voxels_destroy": (None, [_vp]),
+    "lfa_voxels_last_error": (C.c_char_p, [_vp]),
+    "lfa_voxels_info": (_int, [_vp, _vp, _vp, _vp, C.POINTER(_dbl)]),
+    "lfa_voxels_upload": (_int, [_vp, _vp]),
+    "lfa_voxels_download": (_int, [_vp, _vp]),
+    "lfa_voxels_voxelize_triangles": (_int, [_vp, _vp, _u64, _vp, _int, _u64]),
+    "lfa_voxels_mark_exterior": (_int, [_vp]),
+    "lfa_voxelize_mesh": (_int, [C.POINTER(_vp), _vp, _u64, _vp, _int, _u64, _dbl, _vp, _int]),
+    "lfa_voxels_count": (_int, [_vp, _int, _int, _vp, C.POINTER(_u64)]),
+    "lfa_voxels_cells": (_int, [_vp, _int, _int, _vp, _vp, _u64, C.POINTER(_u64)]),
+    "lfa_set_solid_from_voxels": (_int, [_vp, _vp, _int, _int]),
     "lfa_advect_collide": (_int, [_vp, _dbl]),
     "lfa_correct_collide": (_int, [_vp, _dbl]),
     "lfa_time_step": (_int, [_vp, _dbl, C.POINTER(_dbl), C.POINTER(_u64)]),
@@ -166,6 +178,95 @@ class LocalHub:
         if self.h:
             self.lib.lfa_dist_local_hub_destroy(self.h)
             self.h = None
+
+
+VOX_INTERIOR, VOX_EXTERIOR, VOX_SURFACE = 0, 1, 2
+
+
+class Voxels:
+    """Device voxel grid of the solid-boundary voxelizer (lfa_voxels): mirrors fluid::voxelizer's call sequence."""
+
+    def __init__(self, handle):
+        self.lib = load_library()
+        self.h = handle
+        gmin, size, off, cs = np.zeros(3, np.int32), np.zeros(3, np.uint64), np.zeros(3, np.float64), _dbl()
+        self._chk(self.lib.lfa_voxels_info(self.h, _ptr(gmin), _ptr(size), _ptr(off), C.byref(cs)))
+        self.grid_min, self.size, self.grid_offset, self.cell_size = gmin, tuple(int(x) for x in size), off, cs.value
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise LibfluidError(rc, self.lib.lfa_voxels_last_error(self.h).decode())
+        return rc
+
+    @classmethod
+    def create(cls, size, grid_offset, cell_size=1.0, device=-1):
+        lib = load_library()
+        h = C.c_void_p()
+        sz, off = np.asarray(size, dtype=np.uint64), np.asarray(grid_offset, dtype=np.float64)
+        rc = lib.lfa_voxels_create(C.byref(h), _ptr(sz), _ptr(off), float(cell_size), int(device))
+        if rc != 0:
+            raise LibfluidError(rc, lib.lfa_last_error(None).decode())
+        return cls(h)
+
+    @classmethod
+    def from_mesh(cls, positions, indices, cell_size=1.0, ref_grid_offset=(0.0, 0.0, 0.0), device=-1):
+        """get_bounding_box + resize_reposition_grid_constrained + voxelize_mesh_surface + mark_exterior."""
+        lib = load_library()
+        pos = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, 3)
+        idx = np.ascontiguousarray(indices)
+        if idx.dtype not in (np.uint32, np.uint64):
+            idx = idx.astype(np.uint64)
+        off = np.asarray(ref_grid_offset, dtype=np.float64)
+        h = C.c_void_p()
+        rc = lib.lfa_voxelize_mesh(C.byref(h), _ptr(pos), pos.shape[0], _ptr(idx), idx.dtype.itemsize, idx.size,
+                                   float(cell_size), _ptr(off), int(device))
+        if rc != 0:
+            raise LibfluidError(rc, lib.lfa_last_error(None).decode())
+        return cls(h)
+
+    def voxelize_triangles(self, positions, indices):
+        pos = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, 3)
+        idx = np.ascontiguousarray(indices)
+        if idx.dtype not in (np.uint32, np.uint64):
+            idx = idx.astype(np.uint64)
+        self._chk(self.lib.lfa_voxels_voxelize_triangles(self.h, _ptr(pos), pos.shape[0], _ptr(idx), idx.dtype.itemsize,
+                                                         idx.size))
+
+    def mark_exterior(self):
+        self._chk(self.lib.lfa_voxels_mark_exterior(self.h))
+
+    def upload(self, types):
+        t = np.ascontiguousarray(types, dtype=np.uint8).reshape(-1)
+        assert t.size == self.size[0] * self.size[1] * self.size[2]
+        self._chk(self.lib.lfa_voxels_upload(self.h, _ptr(t)))
+
+    def types(self):
+        """uint8[nz, ny, nx] (x fastest, like grid3<cell_type>)."""
+        out = np.empty(self.size[0] * self.size[1] * self.size[2], dtype=np.uint8)
+        self._chk(self.lib.lfa_voxels_download(self.h, _ptr(out)))
+        return out.reshape(self.size[2], self.size[1], self.size[0])
+
+    def cells(self, include_interior=True, include_surface=False, ref_grid_size=None):
+        """int32[k,3]: voxel-grid coordinates, or reference-grid coordinates clipped to `ref_grid_size`."""
+        ref = None if ref_grid_size is None else np.asarray(ref_grid_size, dtype=np.int64)
+        refp = None if ref is None else _ptr(ref)
+        n = _u64()
+        self._chk(self.lib.lfa_voxels_count(self.h, int(include_interior), int(include_surface), refp, C.byref(n)))
+        out = np.empty((n.value, 3), dtype=np.int32)
+        self._chk(self.lib.lfa_voxels_cells(self.h, int(include_interior), int(include_surface), refp, _ptr(out), n.value,
+                                            C.byref(n)))
+        return out
+
+    def close(self):
+        if self.h:
+            self.lib.lfa_voxels_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def default_params():
@@ -265,6 +366,10 @@ class Sim:
 
     def clear_solid_cells(self):
         self._chk(self.lib.lfa_clear_solid_cells(self.h))
+
+    def set_solid_from_voxels(self, voxels, include_interior=True, include_surface=False):
+        """Marks the selected voxels of a Voxels grid solid, device to device (lfa_set_solid_from_voxels)."""
+        self._chk(self.lib.lfa_set_solid_from_voxels(self.h, voxels.h, int(include_interior), int(include_surface)))
 
     def upload_cells(self, cells):
         cells = np.ascontiguousarray(cells, dtype=CELL_DTYPE)

@@ -76,3 +76,50 @@ def sphere_solid_cells(size, center, radius):
     d2 = (x + 0.5 - center[0]) ** 2 + (y + 0.5 - center[1]) ** 2 + (z + 0.5 - center[2]) ** 2
     m = d2 < radius * radius
     return np.stack([x[m], y[m], z[m]], axis=1).astype(np.int32)
+
+
+# ---- triangle meshes for the voxelizer: positions float64[nv,3], indices uint64[3 nt] ----------
+def box_mesh(lo, hi):
+    """Axis-aligned box, 12 triangles."""
+    lo, hi = np.asarray(lo, dtype=np.float64), np.asarray(hi, dtype=np.float64)
+    c = np.array([[(lo, hi)[(i >> d) & 1][d] for d in range(3)] for i in range(8)], dtype=np.float64)
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    tri = [t for q in quads for t in ((q[0], q[1], q[2]), (q[0], q[2], q[3]))]
+    return c, np.asarray(tri, dtype=np.uint64).reshape(-1)
+
+
+def icosphere(center, radius, subdivisions=2):
+    """Closed triangulated sphere (subdivided icosahedron)."""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
+         (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6),
+         (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7),
+         (9, 8, 1)]
+    v = [np.asarray(p, dtype=np.float64) / np.linalg.norm(p) for p in v]
+    for _ in range(subdivisions):
+        cache, nf = {}, []
+
+        def mid(a, b):
+            k = (min(a, b), max(a, b))
+            if k not in cache:
+                m = v[a] + v[b]
+                v.append(m / np.linalg.norm(m))
+                cache[k] = len(v) - 1
+            return cache[k]
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    pos = np.asarray(center, dtype=np.float64)[None, :] + radius * np.asarray(v, dtype=np.float64)
+    return pos, np.asarray(f, dtype=np.uint64).reshape(-1)
+
+
+def rotate_mesh(pos, axis, angle, about):
+    """Rigid rotation of mesh vertices (Rodrigues), so triangles cut the grid at generic angles."""
+    a = np.asarray(axis, dtype=np.float64)
+    a = a / np.linalg.norm(a)
+    p = pos - np.asarray(about, dtype=np.float64)[None, :]
+    c, s_ = np.cos(angle), np.sin(angle)
+    r = p * c + np.cross(a[None, :], p) * s_ + a[None, :] * (p @ a)[:, None] * (1.0 - c)
+    return r + np.asarray(about, dtype=np.float64)[None, :]

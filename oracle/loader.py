@@ -29,8 +29,8 @@ PIC, FLIP, APIC = 0, 1, 2
 
 def build(force=False):
     """Compile liboracle.so (always possible: plain C) and oracle/_ref (only where /root/reference exists)."""
-    src = os.path.join(HERE, "oracle.c")
-    if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(HERE, f) for f in ("oracle.c", "voxelizer_oracle.c")]
+    if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", HERE, os.path.join(HERE, "liboracle.so")])
     ref_src = os.path.join(HERE, "ref_harness.cpp")
     if os.path.isdir(os.environ.get("REFERENCE_DIR", "/root/reference")):
@@ -262,3 +262,43 @@ class CpuSim:
         self.extrapolate()
         self.g2p()
         return p, res, it
+
+
+# ---- voxelizer ---------------------------------------------------------------------------------
+def voxelize(positions, indices, cell_size=1.0, ref_grid_offset=(0.0, 0.0, 0.0), kind="oracle"):
+    """Runs get_bounding_box + resize_reposition_grid_constrained + voxelize_mesh_surface + mark_exterior on the oracle
+    (kind='oracle') or the real reference (kind='ref'). Returns (grid_min int32[3], grid_offset float64[3],
+    types uint8[nz, ny, nx])."""
+    L = _get(kind).lib
+    pre = "orc_" if kind == "oracle" else "ref_"
+    pos = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, 3)
+    idx = np.ascontiguousarray(indices, dtype=np.uint64).reshape(-1)
+    off = np.asarray(ref_grid_offset, dtype=np.float64)
+    gmin, size, goff = np.zeros(3, np.int32), np.zeros(3, np.uint64), np.zeros(3, np.float64)
+    grid = getattr(L, pre + "vox_grid")
+    grid.restype, grid.argtypes = None, [_vp, _sz, _dbl, _vp, _vp, _vp, _vp]
+    grid(_ptr(pos), pos.shape[0], float(cell_size), _ptr(off), _ptr(gmin), _ptr(size), _ptr(goff))
+    types = np.zeros(int(size[0] * size[1] * size[2]), dtype=np.uint8)
+    vox = getattr(L, pre + "voxelize")
+    vox.restype, vox.argtypes = None, [_vp, _sz, _vp, _sz, _dbl, _vp, _vp]
+    vox(_ptr(pos), pos.shape[0], _ptr(idx), idx.size, float(cell_size), _ptr(off), _ptr(types))
+    return gmin, goff, types.reshape(int(size[2]), int(size[1]), int(size[0]))
+
+
+def ref_voxel_cells(positions, indices, cell_size, ref_grid_offset, include_interior, include_surface, ref_grid_size=None):
+    """Cell lists of the Maya VoxelizerNode computed with the real reference's voxelizer and grid3::for_each
+    (plugins/maya/nodes/voxelizer_node.cpp:285-343) as int32[k,3]; ref_grid_size=None: voxel-grid coordinates."""
+    L = _get("ref").lib
+    pos = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, 3)
+    idx = np.ascontiguousarray(indices, dtype=np.uint64).reshape(-1)
+    off = np.asarray(ref_grid_offset, dtype=np.float64)
+    rs = None if ref_grid_size is None else np.asarray(ref_grid_size, dtype=np.int64)
+    rsp = None if rs is None else _ptr(rs)
+    fn = L.ref_voxel_cells
+    fn.restype, fn.argtypes = _sz, [_vp, _sz, _vp, _sz, _dbl, _vp, _int, _int, _vp, _vp, _sz]
+    args = (_ptr(pos), pos.shape[0], _ptr(idx), idx.size, float(cell_size), _ptr(off), int(include_interior),
+            int(include_surface), rsp)
+    n = fn(*args, None, 0)
+    out = np.zeros((n, 3), dtype=np.int32)
+    fn(*args, _ptr(out), n)
+    return out

@@ -52,6 +52,10 @@ using arrow_vendored::pcg32;
 #include "src/pressure_solver.cpp"
 #undef private
 #undef protected
+// the reference's voxelizer and its obstacle host
+#include "src/math/intersection.cpp"
+#include "src/voxelizer.cpp"
+#include "src/data_structures/obstacle.cpp"
 
 namespace {
 	using fluid::vec3d;
@@ -272,5 +276,75 @@ extern "C" {
 		};
 		sim.time_step(dt);
 		sim.post_pressure_solve_callback = nullptr;
+	}
+}
+
+// ---- voxelizer (src/voxelizer.cpp, src/data_structures/obstacle.cpp) -------------------------------------------------
+namespace {
+	fluid::obstacle::mesh_t make_mesh(const double *pos, std::size_t nv, const std::uint64_t *idx, std::size_t ni) {
+		fluid::obstacle::mesh_t m;
+		m.positions.resize(nv);
+		for (std::size_t i = 0; i < nv; ++i) m.positions[i] = vec3d(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
+		m.indices.assign(idx, idx + ni);
+		return m;
+	}
+}
+extern "C" {
+	void ref_vox_grid(
+		const double *pos, std::size_t nv, double cs, const double *ref_off, std::int32_t *grid_min, std::uint64_t *size,
+		double *grid_off
+	) {
+		auto m = make_mesh(pos, nv, nullptr, 0);
+		auto [rmin, rmax] = fluid::voxelizer::get_bounding_box(m.positions.begin(), m.positions.end());
+		fluid::voxelizer vox;
+		fluid::vec3i o = vox.resize_reposition_grid_constrained(rmin, rmax, cs, vec3d(ref_off[0], ref_off[1], ref_off[2]));
+		vec3s n = vox.voxels.get_size();
+		grid_min[0] = o.x; grid_min[1] = o.y; grid_min[2] = o.z;
+		size[0] = n.x; size[1] = n.y; size[2] = n.z;
+		grid_off[0] = vox.grid_offset.x; grid_off[1] = vox.grid_offset.y; grid_off[2] = vox.grid_offset.z;
+	}
+	void ref_voxelize(
+		const double *pos, std::size_t nv, const std::uint64_t *idx, std::size_t ni, double cs, const double *ref_off,
+		std::uint8_t *types
+	) {
+		auto m = make_mesh(pos, nv, idx, ni);
+		auto [rmin, rmax] = fluid::voxelizer::get_bounding_box(m.positions.begin(), m.positions.end());
+		fluid::voxelizer vox;
+		vox.resize_reposition_grid_constrained(rmin, rmax, cs, vec3d(ref_off[0], ref_off[1], ref_off[2]));
+		vox.voxelize_mesh_surface(m);
+		vox.mark_exterior();
+		vec3s n = vox.voxels.get_size();
+		for (std::size_t i = 0; i < n.x * n.y * n.z; ++i) types[i] = static_cast<std::uint8_t>(vox.voxels[i]);
+	}
+	/// The cell lists of the Maya VoxelizerNode, gathered with the reference's own grid3::for_each: voxel-grid
+	/// coordinates of the selected types (plugins/maya/nodes/voxelizer_node.cpp:285-323) or, with ref_size != NULL,
+	/// reference-grid coordinates clipped to the reference grid (:325-343). Returns the count, fills at most `cap`
+	/// triples. (fluid::obstacle, src/data_structures/obstacle.cpp:20-28, is not used as the golden source: it passes a
+	/// max corner in reference-grid coordinates to for_each_in_range_unchecked on the voxel grid, which walks out of
+	/// bounds whenever the voxel grid starts at a positive offset; no host of the reference constructs it.)
+	std::size_t ref_voxel_cells(
+		const double *pos, std::size_t nv, const std::uint64_t *idx, std::size_t ni, double cs, const double *ref_off,
+		int include_interior, int include_surface, const std::int64_t *ref_size, std::int32_t *xyz, std::size_t cap
+	) {
+		auto m = make_mesh(pos, nv, idx, ni);
+		auto [rmin, rmax] = fluid::voxelizer::get_bounding_box(m.positions.begin(), m.positions.end());
+		fluid::voxelizer vox;
+		fluid::vec3i o = vox.resize_reposition_grid_constrained(rmin, rmax, cs, vec3d(ref_off[0], ref_off[1], ref_off[2]));
+		vox.voxelize_mesh_surface(m);
+		vox.mark_exterior();
+		std::size_t n = 0;
+		vox.voxels.for_each([&](vec3s p, fluid::voxelizer::cell_type t) {
+			bool take = (t == fluid::voxelizer::cell_type::interior && include_interior) ||
+				(t == fluid::voxelizer::cell_type::surface && include_surface);
+			if (!take) return;
+			std::int64_t c[3] = {static_cast<std::int64_t>(p.x), static_cast<std::int64_t>(p.y), static_cast<std::int64_t>(p.z)};
+			if (ref_size) {
+				c[0] += o.x; c[1] += o.y; c[2] += o.z;
+				for (int d = 0; d < 3; ++d) if (c[d] < 0 || c[d] >= ref_size[d]) return;
+			}
+			if (n < cap) for (int d = 0; d < 3; ++d) xyz[3 * n + d] = static_cast<std::int32_t>(c[d]);
+			++n;
+		});
+		return n;
 	}
 }
