@@ -19,15 +19,9 @@
 #include <utility>
 #include <vector>
 
-#include "simulation.h"
+#include "mesh.h"
 
 namespace fluid_amd {
-	/// fluid::mesh (include/fluid/data_structures/mesh.h:14-54), the members the voxelizer reads.
-	template <typename Position = double, typename Index = std::size_t> struct mesh {
-		std::vector<vec3<Position>> positions;
-		std::vector<Index> indices;
-	};
-
 	class voxelizer {
 	public:
 		enum class cell_type : unsigned char { interior, exterior, surface };  // voxelizer.h:17-21 == LFA_VOX_*

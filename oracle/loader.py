@@ -302,3 +302,39 @@ def ref_voxel_cells(positions, indices, cell_size, ref_grid_offset, include_inte
     out = np.zeros((n, 3), dtype=np.int32)
     fn(*args, _ptr(out), n)
     return out
+
+
+# ---- on-disk formats of the real reference; kind='ref' only -----------------------------------------
+def ref_points_text(points):
+    L = _get("ref").lib
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    L.ref_points_text.restype, L.ref_points_text.argtypes = _sz, [_vp, _sz, _vp, _sz]
+    n = L.ref_points_text(_ptr(pts), pts.shape[0], None, 0)
+    buf = C.create_string_buffer(n)
+    L.ref_points_text(_ptr(pts), pts.shape[0], buf, n)
+    return buf.raw[:n]
+
+
+def ref_points_parse(text, count):
+    L = _get("ref").lib
+    L.ref_points_parse.restype, L.ref_points_parse.argtypes = _sz, [C.c_char_p, _sz, _sz, _vp, _sz]
+    cap = text.count(b"\n") + 2
+    out = np.zeros((cap, 3), dtype=np.float64)
+    n = L.ref_points_parse(text, len(text), int(count), _ptr(out), cap)
+    return out[:n]
+
+
+def ref_mesh_obj(positions, indices, uvs=None, normals=False, reverse=False):
+    """(obj text, normals float64[nv,3] or None) from mesh::save_obj / generate_normals of the real reference."""
+    L = _get("ref").lib
+    pos = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, 3)
+    idx = np.ascontiguousarray(indices, dtype=np.uint64).reshape(-1)
+    uv = None if uvs is None else np.ascontiguousarray(uvs, dtype=np.float64).reshape(-1, 2)
+    nrm = np.zeros_like(pos) if normals else None
+    L.ref_mesh_obj.restype = _sz
+    L.ref_mesh_obj.argtypes = [_vp, _sz, _vp, _sz, _vp, _int, _int, _vp, _sz, _vp]
+    args = (_ptr(pos), pos.shape[0], _ptr(idx), idx.size, None if uv is None else _ptr(uv), int(normals), int(reverse))
+    n = L.ref_mesh_obj(*args, None, 0, None)
+    buf = C.create_string_buffer(n)
+    L.ref_mesh_obj(*args, buf, n, None if nrm is None else _ptr(nrm))
+    return buf.raw[:n], nrm

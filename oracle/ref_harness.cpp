@@ -56,6 +56,9 @@ using arrow_vendored::pcg32;
 #include "src/math/intersection.cpp"
 #include "src/voxelizer.cpp"
 #include "src/data_structures/obstacle.cpp"
+// on-disk formats
+#include "src/data_structures/point_cloud.cpp"
+#include <sstream>
 
 namespace {
 	using fluid::vec3d;
@@ -346,5 +349,45 @@ extern "C" {
 			++n;
 		});
 		return n;
+	}
+}
+
+// ---- formats (include/fluid/data_structures/point_cloud.h, mesh.h) ----------------------------------------------------
+namespace {
+	std::size_t emit(const std::string &s, char *buf, std::size_t cap) {
+		if (buf && cap) std::memcpy(buf, s.data(), std::min(cap, s.size()));
+		return s.size();
+	}
+}
+extern "C" {
+	/// point_cloud::save_to_naive on a default-formatted stream; returns the text length.
+	std::size_t ref_points_text(const double *pos, std::size_t n, char *buf, std::size_t cap) {
+		std::vector<vec3d> pts(n);
+		for (std::size_t i = 0; i < n; ++i) pts[i] = vec3d(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
+		std::ostringstream out;
+		fluid::point_cloud::save_to_naive(out, pts.begin(), pts.end());
+		return emit(out.str(), buf, cap);
+	}
+	/// point_cloud::load_from_naive; returns the number of points read (at most `count`), fills at most `cap` of them.
+	std::size_t ref_points_parse(const char *text, std::size_t len, std::size_t count, double *pos, std::size_t cap) {
+		std::istringstream in(std::string(text, len));
+		std::vector<vec3d> pts = fluid::point_cloud::load_from_naive(in, count);
+		for (std::size_t i = 0; i < pts.size() && i < cap; ++i) { pos[3 * i] = pts[i].x; pos[3 * i + 1] = pts[i].y; pos[3 * i + 2] = pts[i].z; }
+		return pts.size();
+	}
+	/// mesh::save_obj after optional generate_normals / reverse_face_directions; uvs = u,v pairs or NULL.
+	std::size_t ref_mesh_obj(
+		const double *pos, std::size_t nv, const std::uint64_t *idx, std::size_t ni, const double *uvs, int normals, int reverse,
+		char *buf, std::size_t cap, double *normals_out
+	) {
+		auto m = make_mesh(pos, nv, idx, ni);
+		if (uvs) for (std::size_t i = 0; i < nv; ++i) m.uvs.emplace_back(uvs[2 * i], uvs[2 * i + 1]);
+		if (reverse) m.reverse_face_directions();
+		if (normals) m.generate_normals();
+		if (normals && normals_out)
+			for (std::size_t i = 0; i < nv; ++i) { normals_out[3 * i] = m.normals[i].x; normals_out[3 * i + 1] = m.normals[i].y; normals_out[3 * i + 2] = m.normals[i].z; }
+		std::ostringstream out;
+		m.save_obj(out);
+		return emit(out.str(), buf, cap);
 	}
 }
