@@ -232,6 +232,31 @@ int lfa_voxels_cells(lfa_voxels *v, int include_interior, int include_surface, c
                      uint64_t capacity, uint64_t *count);
 int lfa_set_solid_from_voxels(lfa_sim *s, lfa_voxels *v, int include_interior, int include_surface);
 
+/* -- surface mesher ---------------------------------------------------------------------------
+ * Replaces fluid::mesher (include/fluid/mesher.h:14-46, src/mesher.cpp:320-515): implicit surface function sampled from
+ * particle positions + marching cubes with shared vertices. Bit-exact: sampled values, vertex positions, vertex order
+ * and index list equal the reference's (fp64, its summation order and its vertex numbering).
+ * Host layouts: particle positions = double[3 n] (std::vector<vec3d>); values = double per grid point, x fastest,
+ * (size + 1)^3 of them (grid3<double> _surface_function); mesh = double[3 nv] positions + uint64 indices (mesh_t).
+ *   lfa_mesher_create          : mesher::resize(size) + the public fields grid_offset, cell_size, particle_extent,
+ *                                cell_radius (mesher.h:28-32)
+ *   lfa_mesher_sample          : mesher::_sample_surface_function(particles, r) (mesher.cpp:333-376)
+ *   lfa_mesher_marching_cubes  : mesher::_marching_cubes() (mesher.cpp:400-515); the two together = generate_mesh (:325)
+ *   lfa_mesher_upload_values / download_values : the sampled function, for stage-level parity tests */
+typedef struct lfa_mesher lfa_mesher;
+int lfa_mesher_create(lfa_mesher **out, const uint64_t size[3], const double grid_offset[3], double cell_size,
+                      double particle_extent, uint64_t cell_radius, int device);
+void lfa_mesher_destroy(lfa_mesher *m);
+const char *lfa_mesher_last_error(const lfa_mesher *m);
+int lfa_mesher_sample(lfa_mesher *m, const double *positions, uint64_t n, double r);
+/* the same from the particles resident in a simulation handle (upload order, the positions LFA_DL_POSITIONS reports):
+ * what testbed/main.cpp:52-61,101-113 does through a host copy, without the PCIe round trip */
+int lfa_mesher_sample_sim(lfa_mesher *m, lfa_sim *s, double r);
+int lfa_mesher_download_values(lfa_mesher *m, double *values);
+int lfa_mesher_upload_values(lfa_mesher *m, const double *values);
+int lfa_mesher_marching_cubes(lfa_mesher *m, uint64_t *n_vertices, uint64_t *n_indices);
+int lfa_mesher_download_mesh(lfa_mesher *m, double *positions, uint64_t *indices);
+
 /* -- measurement --------------------------------------------------------------------------------------------- */
 /* Per-stage device time of the last lfa_step_hot, measured with HIP events on the handle's stream (milliseconds):
  * [0] hash/bin [1] P2G [2] gravity [3] build system [4] PCG loop [5] apply pressure [6] extrapolate [7] G2P

@@ -115,6 +115,15 @@ SIGNATURES = {
     "lfa_voxels_count": (_int, [_vp, _int, _int, _vp, C.POINTER(_u64)]),
     "lfa_voxels_cells": (_int, [_vp, _int, _int, _vp, _vp, _u64, C.POINTER(_u64)]),
     "lfa_set_solid_from_voxels": (_int, [_vp, _vp, _int, _int]),
+    "lfa_mesher_create": (_int, [C.POINTER(_vp), _vp, _vp, _dbl, _dbl, _u64, _int]),
+    "lfa_mesher_destroy": (None, [_vp]),
+    "lfa_mesher_last_error": (C.c_char_p, [_vp]),
+    "lfa_mesher_sample": (_int, [_vp, _vp, _u64, _dbl]),
+    "lfa_mesher_sample_sim": (_int, [_vp, _vp, _dbl]),
+    "lfa_mesher_download_values": (_int, [_vp, _vp]),
+    "lfa_mesher_upload_values": (_int, [_vp, _vp]),
+    "lfa_mesher_marching_cubes": (_int, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
+    "lfa_mesher_download_mesh": (_int, [_vp, _vp, _vp]),
     "lfa_advect_collide": (_int, [_vp, _dbl]),
     "lfa_correct_collide": (_int, [_vp, _dbl]),
     "lfa_time_step": (_int, [_vp, _dbl, C.POINTER(_dbl), C.POINTER(_u64)]),
@@ -260,6 +269,68 @@ class Voxels:
     def close(self):
         if self.h:
             self.lib.lfa_voxels_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Mesher:
+    """Device surface mesher (lfa_mesher): mirrors fluid::mesher (resize + public fields, generate_mesh)."""
+
+    def __init__(self, size, grid_offset=(0.0, 0.0, 0.0), cell_size=1.0, particle_extent=0.5, cell_radius=2, device=-1):
+        self.lib = load_library()
+        self.size = tuple(int(x) for x in size)
+        sz, off = np.asarray(self.size, dtype=np.uint64), np.asarray(grid_offset, dtype=np.float64)
+        h = C.c_void_p()
+        rc = self.lib.lfa_mesher_create(C.byref(h), _ptr(sz), _ptr(off), float(cell_size), float(particle_extent),
+                                        int(cell_radius), int(device))
+        if rc != 0:
+            raise LibfluidError(rc, self.lib.lfa_last_error(None).decode())
+        self.h = h
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise LibfluidError(rc, self.lib.lfa_mesher_last_error(self.h).decode())
+        return rc
+
+    def sample(self, points, r):
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        self._chk(self.lib.lfa_mesher_sample(self.h, _ptr(pts), pts.shape[0], float(r)))
+
+    def sample_sim(self, sim, r):
+        """Samples from the particles resident in a Sim handle (no host copy)."""
+        self._chk(self.lib.lfa_mesher_sample_sim(self.h, sim.h, float(r)))
+
+    def values(self):
+        """float64[nz+1, ny+1, nx+1]."""
+        out = np.empty((self.size[2] + 1, self.size[1] + 1, self.size[0] + 1), dtype=np.float64)
+        self._chk(self.lib.lfa_mesher_download_values(self.h, _ptr(out)))
+        return out
+
+    def set_values(self, values):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        assert v.size == (self.size[0] + 1) * (self.size[1] + 1) * (self.size[2] + 1)
+        self._chk(self.lib.lfa_mesher_upload_values(self.h, _ptr(v)))
+
+    def marching_cubes(self):
+        """(positions float64[nv,3], indices uint64[ni])"""
+        nv, ni = _u64(), _u64()
+        self._chk(self.lib.lfa_mesher_marching_cubes(self.h, C.byref(nv), C.byref(ni)))
+        pos, idx = np.empty((nv.value, 3), dtype=np.float64), np.empty(ni.value, dtype=np.uint64)
+        self._chk(self.lib.lfa_mesher_download_mesh(self.h, _ptr(pos), _ptr(idx)))
+        return pos, idx
+
+    def generate_mesh(self, points, r):
+        self.sample(points, r)
+        return self.marching_cubes()
+
+    def close(self):
+        if self.h:
+            self.lib.lfa_mesher_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -29,7 +29,7 @@ PIC, FLIP, APIC = 0, 1, 2
 
 def build(force=False):
     """Compile liboracle.so (always possible: plain C) and oracle/_ref (only where /root/reference exists)."""
-    srcs = [os.path.join(HERE, f) for f in ("oracle.c", "voxelizer_oracle.c")]
+    srcs = [os.path.join(HERE, f) for f in ("oracle.c", "voxelizer_oracle.c", "mesher_oracle.c")]
     if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", HERE, os.path.join(HERE, "liboracle.so")])
     ref_src = os.path.join(HERE, "ref_harness.cpp")
@@ -338,3 +338,43 @@ def ref_mesh_obj(positions, indices, uvs=None, normals=False, reverse=False):
     buf = C.create_string_buffer(n)
     L.ref_mesh_obj(*args, buf, n, None if nrm is None else _ptr(nrm))
     return buf.raw[:n], nrm
+
+
+# ---- surface mesher ----------------------------------------------------------------------------
+def _mesher_args(points, size, grid_offset, cell_size, particle_extent, cell_radius, r):
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    sz = np.asarray(size, dtype=np.uint64)
+    off = np.asarray(grid_offset, dtype=np.float64)
+    return pts, sz, off, (_ptr(pts), pts.shape[0], _ptr(sz), _ptr(off), float(cell_size), float(particle_extent),
+                          int(cell_radius), float(r))
+
+
+def mesher_surface(points, size, grid_offset=(0.0, 0.0, 0.0), cell_size=1.0, particle_extent=0.5, cell_radius=2, r=0.5,
+                   kind="oracle"):
+    """mesher::_sample_surface_function: float64[nz+1, ny+1, nx+1] values at the grid points."""
+    L = _get(kind).lib
+    fn = getattr(L, ("orc_" if kind == "oracle" else "ref_") + "mesher_surface")
+    fn.restype, fn.argtypes = None, [_vp, _sz, _vp, _vp, _dbl, _dbl, C.c_uint64, _dbl, _vp]
+    pts, sz, off, args = _mesher_args(points, size, grid_offset, cell_size, particle_extent, cell_radius, r)
+    out = np.zeros((int(sz[2]) + 1, int(sz[1]) + 1, int(sz[0]) + 1), dtype=np.float64)
+    fn(*args, _ptr(out))
+    return out
+
+
+def mesher_mesh(points, size, grid_offset=(0.0, 0.0, 0.0), cell_size=1.0, particle_extent=0.5, cell_radius=2, r=0.5,
+                values=None, kind="oracle"):
+    """mesher::generate_mesh, or mesher::_marching_cubes on given grid-point values. Returns (positions float64[nv,3],
+    indices uint64[ni])."""
+    L = _get(kind).lib
+    fn = getattr(L, ("orc_" if kind == "oracle" else "ref_") + "mesher_mesh")
+    fn.restype = None
+    fn.argtypes = [_vp, _sz, _vp, _vp, _dbl, _dbl, C.c_uint64, _dbl, _vp, _vp, _sz, _vp, _sz, _vp]
+    pts, sz, off, args = _mesher_args(points if points is not None else np.zeros((0, 3)), size, grid_offset, cell_size,
+                                      particle_extent, cell_radius, r)
+    vals = None if values is None else np.ascontiguousarray(values, dtype=np.float64)
+    vp = None if vals is None else _ptr(vals)
+    counts = np.zeros(2, dtype=np.uint64)
+    fn(*args, vp, None, 0, None, 0, _ptr(counts))
+    pos, idx = np.zeros((int(counts[0]), 3), dtype=np.float64), np.zeros(int(counts[1]), dtype=np.uint64)
+    fn(*args, vp, _ptr(pos), pos.shape[0], _ptr(idx), idx.size, _ptr(counts))
+    return pos, idx

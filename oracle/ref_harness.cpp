@@ -56,6 +56,10 @@ using arrow_vendored::pcg32;
 #include "src/math/intersection.cpp"
 #include "src/voxelizer.cpp"
 #include "src/data_structures/obstacle.cpp"
+// surface mesher (private members reached like the solver's)
+#define private public
+#include "src/mesher.cpp"
+#undef private
 // on-disk formats
 #include "src/data_structures/point_cloud.cpp"
 #include <sstream>
@@ -389,5 +393,60 @@ extern "C" {
 		std::ostringstream out;
 		m.save_obj(out);
 		return emit(out.str(), buf, cap);
+	}
+}
+
+// ---- surface mesher (src/mesher.cpp) -------------------------------------------------------------------------------------
+namespace {
+	void setup_mesher(fluid::mesher &m, const std::uint64_t *size, const double *off, double cs, double extent, std::uint64_t radius) {
+		m.resize(vec3s(size[0], size[1], size[2]));
+		m.grid_offset = vec3d(off[0], off[1], off[2]);
+		m.cell_size = cs;
+		m.particle_extent = extent;
+		m.cell_radius = radius;
+	}
+	std::vector<vec3d> to_points(const double *pos, std::size_t n) {
+		std::vector<vec3d> pts(n);
+		for (std::size_t i = 0; i < n; ++i) pts[i] = vec3d(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
+		return pts;
+	}
+}
+extern "C" {
+	/// mesher::_sample_surface_function (src/mesher.cpp:333-376): values at the (size+1)^3 grid points, x fastest.
+	void ref_mesher_surface(
+		const double *pos, std::size_t n, const std::uint64_t *size, const double *off, double cs, double extent,
+		std::uint64_t radius, double r, double *values
+	) {
+		fluid::mesher m;
+		setup_mesher(m, size, off, cs, extent, radius);
+		std::vector<vec3d> pts = to_points(pos, n);
+		m._sample_surface_function(pts, r);
+		std::size_t nv = (size[0] + 1) * (size[1] + 1) * (size[2] + 1);
+		for (std::size_t i = 0; i < nv; ++i) values[i] = m._surface_function[i];
+	}
+	/// mesher::generate_mesh (values == NULL) or mesher::_marching_cubes on given grid-point values (src/mesher.cpp:400-515).
+	/// counts[0..1] = vertices, indices; fills at most cap_v / cap_i of them.
+	void ref_mesher_mesh(
+		const double *pos, std::size_t n, const std::uint64_t *size, const double *off, double cs, double extent,
+		std::uint64_t radius, double r, const double *values, double *vpos, std::size_t cap_v, std::uint64_t *idx,
+		std::size_t cap_i, std::uint64_t *counts
+	) {
+		fluid::mesher m;
+		setup_mesher(m, size, off, cs, extent, radius);
+		fluid::mesher::mesh_t res;
+		if (values) {
+			std::size_t nv = (size[0] + 1) * (size[1] + 1) * (size[2] + 1);
+			for (std::size_t i = 0; i < nv; ++i) m._surface_function[i] = values[i];
+			res = m._marching_cubes();
+		} else {
+			std::vector<vec3d> pts = to_points(pos, n);
+			res = m.generate_mesh(pts, r);
+		}
+		counts[0] = res.positions.size();
+		counts[1] = res.indices.size();
+		for (std::size_t i = 0; i < res.positions.size() && i < cap_v; ++i) {
+			vpos[3 * i] = res.positions[i].x; vpos[3 * i + 1] = res.positions[i].y; vpos[3 * i + 2] = res.positions[i].z;
+		}
+		for (std::size_t i = 0; i < res.indices.size() && i < cap_i; ++i) idx[i] = res.indices[i];
 	}
 }
