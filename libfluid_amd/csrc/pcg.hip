@@ -58,20 +58,35 @@ __device__ inline void face_neighbours(const TileCtx &tc, int tile, int nb[6]) {
 		if (nb[k] >= 0 && tc.tile_pslot[nb[k]] < 0) nb[k] = -1;
 }
 
-/// Sum / max of the per-workgroup partials of the previous kernel, identical in every workgroup.
+/// Sum / max of the per-workgroup partials of the previous kernel, identical in every workgroup (256 threads): strided
+/// private sums, an xor butterfly inside each wave (every lane ends with the wave's total), one exchange through LDS.
 __device__ inline double reduce_partials_sum(const double *part, int n, double *lds) {
 	double a = 0.0;
 	for (int i = threadIdx.x; i < n; i += 256) a += part[i];
-	lds[threadIdx.x] = a;
+	a = wave_sum(a);
+	if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = a;
 	__syncthreads();
-	for (int o = 128; o > 0; o >>= 1) {
-		if ((int)threadIdx.x < o) lds[threadIdx.x] += lds[threadIdx.x + o];
-		__syncthreads();
-	}
-	double r = lds[0];
+	const double r = (lds[0] + lds[1]) + (lds[2] + lds[3]);
 	__syncthreads();
 	return r;
 }
+/// Two sums at once (one LDS exchange).
+__device__ inline void reduce_partials_sum2(const double *pa, int na, const double *pb, int nb, double *lds, double &ra, double &rb) {
+	double a = 0.0, b = 0.0;
+	for (int i = threadIdx.x; i < na; i += 256) a += pa[i];
+	for (int i = threadIdx.x; i < nb; i += 256) b += pb[i];
+	a = wave_sum(a);
+	b = wave_sum(b);
+	if ((threadIdx.x & 63) == 0) {
+		lds[threadIdx.x >> 6] = a;
+		lds[4 + (threadIdx.x >> 6)] = b;
+	}
+	__syncthreads();
+	ra = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+	rb = (lds[4] + lds[5]) + (lds[6] + lds[7]);
+	__syncthreads();
+}
+__device__ inline double nan_max(double x, double y) { return (x != x || y != y) ? NAN : (y > x ? y : x); }
 __device__ inline double reduce_partials_max(const double *part, int n, double *lds) {
 	double a = -INFINITY;
 	bool nan = false;
@@ -80,16 +95,11 @@ __device__ inline double reduce_partials_max(const double *part, int n, double *
 		nan |= x != x;
 		a = x > a ? x : a;
 	}
-	lds[threadIdx.x] = nan ? NAN : a;
+	a = wave_max(a);
+	nan = __any(nan);
+	if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = nan ? NAN : a;
 	__syncthreads();
-	for (int o = 128; o > 0; o >>= 1) {
-		if ((int)threadIdx.x < o) {
-			double x = lds[threadIdx.x], y = lds[threadIdx.x + o];
-			lds[threadIdx.x] = (x != x || y != y) ? NAN : (y > x ? y : x);
-		}
-		__syncthreads();
-	}
-	double r = lds[0];
+	const double r = nan_max(nan_max(lds[0], lds[1]), nan_max(lds[2], lds[3]));
 	__syncthreads();
 	return r;
 }
@@ -948,8 +958,8 @@ k_pcg_b(const int *__restrict__ ptiles, int n_ptiles, const uint8_t *__restrict_
 	__shared__ __attribute__((aligned(16))) char lds_raw[WORK_LDS > RED_LDS ? WORK_LDS : RED_LDS];
 	double *red = (double *)lds_raw;
 	if (state[0] >= 0) return;
-	const double sigma = reduce_partials_sum(part_sigma_old, n_sigma, red);
-	const double zs = reduce_partials_sum(part_zs, n_zs, red);
+	double sigma, zs;
+	reduce_partials_sum2(part_sigma_old, n_sigma, part_zs, n_zs, red, sigma, zs);
 	const real alpha = (real)(sigma / zs);
 	const int nblk = EMBED ? (int)gridDim.x - PCG_COARSE_BLOCKS : (int)gridDim.x,
 	          blk = EMBED ? (int)blockIdx.x - PCG_COARSE_BLOCKS : (int)blockIdx.x;
@@ -1086,8 +1096,8 @@ k_pcg_a(int n_ptiles, const int *__restrict__ nbr, const uint8_t *__restrict__ a
 	}
 	real beta = (real)0;
 	if (!FIRST) {
-		const double sn = reduce_partials_sum(part_sig_new, n_sig_new, lds);
-		const double so = reduce_partials_sum(part_sig_old, n_sig_old, lds);
+		double sn, so;
+		reduce_partials_sum2(part_sig_new, n_sig_new, part_sig_old, n_sig_old, lds, sn, so);
 		beta = (real)(sn / so);
 	}
 	const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
@@ -1568,9 +1578,11 @@ static void launch_pcg_a(bool first, bool coarse, int grid, hipStream_t st, Args
 	else hipLaunchKernelGGL((k_pcg_a<real, false, false>), dim3(grid), dim3(256), 0, st, a...);
 }
 
-/// Launch widths (workgroups) of k_pcg_a / k_pcg_b: both kernels are software pipelines over the tiles of a wave, so the
-/// launch is sized to be resident at once (k_pcg_a: 4 workgroups per CU by registers, k_pcg_b: 5 by LDS) and every wave
-/// streams several tiles. LFA_PCG_GA / LFA_PCG_GB override them for experiments (tools/pcg_grid_sweep.sh).
+/// Launch widths (workgroups) of k_pcg_a / k_pcg_b. k_pcg_a streams: it is sized to be resident at once (4 workgroups per
+/// CU by registers) and every wave pipelines several tiles. k_pcg_b alternates HBM phases with latency-bound sweeps, and
+/// waves that start together stay in lockstep (their phases add up instead of overlapping): twice as many workgroups as
+/// fit, so that the second half starts staggered as the first retires, measured 66 vs 73 us at C4.
+/// LFA_PCG_GA / LFA_PCG_GB override them for experiments (tools/pcg_grid_sweep.sh).
 static void fused_grids(int G, int &GA, int &GB) {
 	static int n_cu = 0;
 	if (!n_cu) {
@@ -1580,7 +1592,7 @@ static void fused_grids(int G, int &GA, int &GB) {
 		        prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
 	}
 	GA = std::min(G, 4 * n_cu);
-	GB = std::min(G, 5 * n_cu);
+	GB = std::min(G, 8 * n_cu);
 	if (const char *e = getenv("LFA_PCG_GA")) GA = std::max(1, std::min(atoi(e), G));
 	if (const char *e = getenv("LFA_PCG_GB")) GB = std::max(1, std::min(atoi(e), G));
 }

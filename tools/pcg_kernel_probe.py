@@ -10,7 +10,9 @@ cfg_name = sys.argv[1] if len(sys.argv) > 1 else "C4"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 cfg = scenes.CONFIGS[cfg_name]
 for fused in (1, 0):
-    sim = lfa.Sim(cfg["size"], method=cfg["method"], blending=cfg["blending"], pcg_fused=fused)
+    precond = {"tiled": lfa.PRECOND_MIC0_TILED, "multilevel": lfa.PRECOND_MULTILEVEL}[os.environ.get("PROBE_PRECOND", "multilevel")]
+    sim = lfa.Sim(cfg["size"], method=cfg["method"], blending=cfg["blending"], pcg_fused=fused, precond=precond,
+                  max_iterations=int(os.environ.get("PROBE_MAXIT", "200")))
     sim.seed_block(*cfg["block"])
     sim.enable_timing(True)
     for _ in range(2):
