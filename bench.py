@@ -111,7 +111,7 @@ def main():
                   pcg_dtype=lfa.PCG_F64 if args.pcg_dtype == "f64" else lfa.PCG_F32,
                   p2g_variant=lfa.P2G_GLOBAL_ATOMIC if args.p2g == "atomic" else lfa.P2G_LDS_BINNED,
                   max_iterations=args.max_iterations, pcg_fused=0 if args.unfused else 1)
-    fused = not args.unfused and args.precond != "exact" and (world == 1 or args.replicas)
+    fused = not args.unfused and args.precond != "exact"
     PCG_BYTES = PCG_BYTES_FUSED if fused else PCG_BYTES_UNFUSED
     if world > 1 and not args.replicas:
         # one RCCL communicator per handle: rank 0 creates the id, torch.distributed (RCCL) broadcasts it

@@ -918,8 +918,11 @@ template <typename real> __device__ inline void fast_tile_sweeps(real *X, BCPair
 /// level-1 correction of the neighbours / of the tile itself, [16..21] / [22] the same for the top-level correction, so
 /// that k_pcg_a finds every coarse value with one independent load.
 #define NBR_STRIDE 32
+/// `p_off`: slot of the first owned tile in tile_pslot's numbering (slabs: ghost tiles come first). A face neighbour on
+/// another rank (ghost tile) is entered as missing: its new search direction does not exist while k_pcg_a runs, the term
+/// is added by k_ghost_face_rows once the boundary slices have been exchanged.
 __global__ void __launch_bounds__(256)
-k_build_nbr_table(TileCtx tc, const int *slot_l1, const int *l1_l2, int *nbr) {
+k_build_nbr_table(TileCtx tc, int p_off, const int *slot_l1, const int *l1_l2, int *nbr) {
 	const int slot = blockIdx.x * blockDim.x + threadIdx.x;
 	if (slot >= tc.n_ptiles) return;
 	const int tile = tc.ptiles[slot];
@@ -929,9 +932,11 @@ k_build_nbr_table(TileCtx tc, const int *slot_l1, const int *l1_l2, int *nbr) {
 	for (int k = 0; k < NBR_STRIDE; ++k) o[k] = 0;
 #pragma unroll
 	for (int k = 0; k < 6; ++k) {
-		o[k] = nb[k];
-		if (slot_l1 && nb[k] >= 0) {
-			const int j1 = slot_l1[tc.tile_pslot[nb[k]]];
+		const int ns = nb[k] >= 0 ? tc.tile_pslot[nb[k]] - p_off : -1;
+		const bool own = ns >= 0 && ns < tc.n_ptiles;
+		o[k] = own ? nb[k] : -1;
+		if (slot_l1 && own) {
+			const int j1 = slot_l1[ns];
 			o[8 + k] = j1;
 			o[16 + k] = l1_l2[j1 >> 9];
 		}
@@ -943,6 +948,58 @@ k_build_nbr_table(TileCtx tc, const int *slot_l1, const int *l1_l2, int *nbr) {
 		o[14] = i1;
 		o[22] = l1_l2[i1 >> 9];
 	}
+}
+
+/// Slabs: rows of q = A s that couple across a slab face. k_pcg_a computed them with the face towards the other rank
+/// empty; once the neighbour's boundary slice of the new s has arrived in the ghost tile, the 64 rows of the slice are
+/// recomputed with k_spmv's expression (so a slab run performs the single-domain arithmetic), and dot(q, s) and the tile
+/// sum of q (coarse right-hand side) are corrected by the difference. One wave per boundary tile and side.
+template <typename real>
+__global__ void __launch_bounds__(256)
+k_ghost_face_rows(TileCtx tc, int n_lo, int hi_slot0, int n_hi, const uint8_t *abits, const real *s, real *q, real scale,
+                  double *part_extra, real *coarse_as, const int *slot_l1, const int *state) {
+	__shared__ double red[4];
+	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
+	double acc = 0.0;
+	if (state[0] < 0) {
+		for (int w = blockIdx.x * PCG_WAVES + wid; w < n_lo + n_hi; w += gridDim.x * PCG_WAVES) {
+			const bool lo = w < n_lo;
+			const int slot = lo ? w : hi_slot0 + (w - n_lo), zs = lo ? 0 : 7;
+			const int tile = tc.ptiles[slot];
+			int nb[6];
+			face_neighbours(tc, tile, nb);
+			const int ghost = lo ? nb[4] : nb[5];
+			if (ghost < 0) continue;  // no fluid across the face (wave-uniform)
+			const size_t base = (size_t)tile * LFA_TILE_CELLS;
+			const int idx = zs * 64 + lane;
+			const uint32_t a = abits[base + idx];
+			double dq = 0.0;
+			if (a & AB_UNKNOWN) {
+				auto at = [&](int t, int i) -> real { return t >= 0 ? s[(size_t)t * LFA_TILE_CELLS + i] : (real)0; };
+				const real F = (a & AB_FLUID) ? (real)1 : (real)0;
+				const real si = s[base + idx];
+				const real sxm = lx > 0 ? s[base + idx - 1] : at(nb[0], idx + 7), sxp = lx < 7 ? s[base + idx + 1] : at(nb[1], idx - 7);
+				const real sym = ly > 0 ? s[base + idx - 8] : at(nb[2], idx + 56), syp = ly < 7 ? s[base + idx + 8] : at(nb[3], idx - 56);
+				const real szm = zs > 0 ? s[base + idx - 64] : at(nb[4], idx + 448), szp = zs < 7 ? s[base + idx + 64] : at(nb[5], idx - 448);
+				real val = (real)(a & 7) * si;
+				val -= F * sxm;
+				val -= F * sym;
+				val -= F * szm;
+				val -= (real)((a >> 3) & 1) * sxp;
+				val -= (real)((a >> 4) & 1) * syp;
+				val -= (real)((a >> 5) & 1) * szp;
+				const real out = scale * val;
+				dq = (double)out - (double)q[base + idx];
+				q[base + idx] = out;
+				acc += dq * (double)si;
+			}
+			if (coarse_as) {
+				dq = wave_sum(dq);
+				if (lane == 0) coarse_as[slot_l1[slot]] = (real)((double)coarse_as[slot_l1[slot]] + dq);
+			}
+		}
+	}
+	block_partial_sum(acc, red, part_extra);
 }
 
 template <typename real, bool EMBED>
@@ -1496,9 +1553,9 @@ template <typename real> static int mic_factor(lfa_sim *s) {
 		                   (const int *)nullptr, s->n_ptiles, s->abits, (real *)s->vpre, scale, tau, sigma);
 		LFA_LAUNCH_CHECK(s);
 		if (is_ml(s)) LFA_TRY(coarse_setup<real>(s));
-		if (s->prm.pcg_fused && !s->dist) {
+		if (s->prm.pcg_fused && s->n_ptiles) {
 			if (!s->nbr_table) LFA_HIP(s, hipMalloc(&s->nbr_table, (size_t)s->g.nt * NBR_STRIDE * sizeof(int)));
-			hipLaunchKernelGGL(k_build_nbr_table, dim3((s->n_ptiles + 255) / 256), dim3(256), 0, s->stream, tc,
+			hipLaunchKernelGGL(k_build_nbr_table, dim3((s->n_ptiles + 255) / 256), dim3(256), 0, s->stream, tc, s->p_off,
 			                   is_ml(s) ? (const int *)s->slot_l1 : (const int *)nullptr, (const int *)s->l1_l2, s->nbr_table);
 			LFA_LAUNCH_CHECK(s);
 		}
@@ -1641,15 +1698,17 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 	// z = M^-1 r ; s = z ; sigma = z.r
 	LFA_TRY(mic_apply<real>(s, P + PART_SIG0));
 	if (dist) LFA_TRY(lfa_dist_allreduce(s, P + PART_SIG0, NS, 3, false));
-	hipLaunchKernelGGL(k_update_s<real>, dim3(G), dim3(256), 0, s->stream, tc, v, sig_src(0), sig_src(0), n_sig, 1,
-	                   s->pcg_state, s->abits, cx, (const int *)s->slot_l1, (const real *)s->c_x2, (const int *)s->l1_l2);
-	LFA_LAUNCH_CHECK(s);
 	const int maxit = (int)s->prm.max_iterations;
 	const int chunk = 8;
 	int done = -1, nan = 0, i = 0;
 	int *hstate = (int *)s->h_pinned;
-	// fused iteration (k_pcg_a / k_pcg_b): single domain, tile-local MIC(0) with or without the coarse levels
-	const bool fused = s->prm.pcg_fused && !dist && s->prm.precond != LFA_PRECOND_MIC0_EXACT;
+	// fused iteration (k_pcg_a / k_pcg_b): tile-local MIC(0) with or without the coarse levels, single domain or slabs
+	const bool fused = s->prm.pcg_fused && s->prm.precond != LFA_PRECOND_MIC0_EXACT && (s->n_ptiles == 0 || s->nbr_table);
+	if (!fused) {
+		hipLaunchKernelGGL(k_update_s<real>, dim3(G), dim3(256), 0, s->stream, tc, v, sig_src(0), sig_src(0), n_sig, 1,
+		                   s->pcg_state, s->abits, cx, (const int *)s->slot_l1, (const real *)s->c_x2, (const int *)s->l1_l2);
+		LFA_LAUNCH_CHECK(s);
+	}
 	const bool embed = fused && is_ml(s) && s->n_l1tiles <= 64;
 	real *sbuf[2] = {(real *)s->vs, (real *)s->vs2};
 	real *crbuf[2] = {(real *)s->c_r, is_ml(s) ? (real *)s->c_r + s->ncp1 : (real *)nullptr};
@@ -1657,45 +1716,71 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 	int GA, GB;
 	fused_grids(G, GA, GB);
 	const int NSB = GB + (is_ml(s) ? 1 : 0);
+	// slabs: boundary tile layers whose rows couple to the neighbour rank (k_ghost_face_rows)
+	const int n_face_lo = dist && lfa_has_lo(s) ? s->n_own_first : 0, n_face_hi = dist && lfa_has_hi(s) ? s->n_own_last : 0;
+	const int g_face_lo = std::min(16, (n_face_lo + PCG_WAVES - 1) / PCG_WAVES), g_face_hi = std::min(16, (n_face_hi + PCG_WAVES - 1) / PCG_WAVES);
 	while (fused && i < maxit && done < 0) {
 		const int end = std::min(maxit, i + chunk);
 		for (; i < end; ++i) {
 			const int po = i & 1, pn = po ^ 1;
-			// sigma partials: the application before the loop wrote NS of them, k_pcg_b writes NSB
-			const int n_sig_po = i == 0 ? NS : NSB, n_sig_pn = i <= 1 ? NS : NSB;
+			// where a kernel finds the scalars of the previous one: per-workgroup partials (the application before the loop
+			// wrote NS sigma partials, k_pcg_b writes NSB), or - with slabs - the all-reduced values
+			const double *sig_po = dist ? red + 3 + po : P + (po ? PART_SIG1 : PART_SIG0), *sig_pn = dist ? red + 3 + pn : P + (pn ? PART_SIG1 : PART_SIG0);
+			const int n_sig_po = dist ? 1 : (i == 0 ? NS : NSB), n_sig_pn = dist ? 1 : (i <= 1 ? NS : NSB);
 			launch_pcg_a<real>(i == 0, is_ml(s), GA, s->stream, s->n_ptiles, (const int *)s->nbr_table, (const uint8_t *)s->abits,
-			                   (const real *)v.z, (const real *)sbuf[po], sbuf[pn], v.q, scale,
-			                   (const double *)(P + (po ? PART_SIG1 : PART_SIG0)), n_sig_po,
-			                   (const double *)(P + (pn ? PART_SIG1 : PART_SIG0)), n_sig_pn, (const double *)(P + PART_RMAX), GB,
-			                   s->prm.tolerance, i, s->pcg_state, s->pcg_hist, P + PART_ZS, cx, (const real *)s->c_x2,
-			                   is_ml(s) ? (real *)s->c_as : (real *)nullptr);
+			                   (const real *)v.z, (const real *)sbuf[po], sbuf[pn], v.q, scale, sig_po, n_sig_po, sig_pn, n_sig_pn,
+			                   (const double *)(dist ? red + 2 : P + PART_RMAX), dist ? 1 : GB, s->prm.tolerance, i, s->pcg_state,
+			                   s->pcg_hist, P + PART_ZS, cx, (const real *)s->c_x2, is_ml(s) ? (real *)s->c_as : (real *)nullptr);
 			LFA_LAUNCH_CHECK(s);
+			if (dist) {
+				// the new search direction across the slab faces, then the rows of q that needed it
+				LFA_TRY(lfa_dist_exchange_slices(s, sbuf[pn], (int)sizeof(real)));
+				real *cas = is_ml(s) ? (real *)s->c_as : (real *)nullptr;
+				if (g_face_lo) {
+					hipLaunchKernelGGL(k_ghost_face_rows<real>, dim3(g_face_lo), dim3(256), 0, s->stream, tc, n_face_lo, 0, 0, s->abits,
+					                   (const real *)sbuf[pn], v.q, scale, P + PART_ZS + GA, cas, (const int *)s->slot_l1, s->pcg_state);
+					LFA_LAUNCH_CHECK(s);
+				}
+				if (g_face_hi) {
+					hipLaunchKernelGGL(k_ghost_face_rows<real>, dim3(g_face_hi), dim3(256), 0, s->stream, tc, 0, s->n_ptiles - n_face_hi,
+					                   n_face_hi, s->abits, (const real *)sbuf[pn], v.q, scale, P + PART_ZS + GA + g_face_lo, cas,
+					                   (const int *)s->slot_l1, s->pcg_state);
+					LFA_LAUNCH_CHECK(s);
+				}
+				LFA_TRY(lfa_dist_allreduce(s, P + PART_ZS, GA + g_face_lo + g_face_hi, 1, false));
+			}
+			const double *zs_src = dist ? red + 1 : P + PART_ZS;
+			const int n_zs_src = dist ? 1 : GA;
+			double *sig_new_part = P + (pn ? PART_SIG1 : PART_SIG0);
 			CoarseFields<real> cf = is_ml(s) ? make_coarse<real>(s) : CoarseFields<real>{};
 			if (embed) {
 				cf.r = crbuf[po];
 				cf.as = (const real *)s->c_as;
 				CoarseArgs ca{s->l1_tiles, s->n_l1tiles, s->a2inv, s->c_x2, (double *)s->pcg_hist + 6144, (unsigned *)(s->pcg_state + 4)};
 				hipLaunchKernelGGL((k_pcg_b<real, true>), dim3(GB + PCG_COARSE_BLOCKS), dim3(256), 0, s->stream,
-				                   (const int *)s->ptiles, s->n_ptiles, s->abits, v, (const real *)sbuf[pn], scale,
-				                   P + (po ? PART_SIG1 : PART_SIG0), n_sig_po, P + PART_ZS, GA, P + PART_RMAX,
-				                   P + (pn ? PART_SIG1 : PART_SIG0), s->pcg_state, crbuf[pn], (const int *)s->slot_l1, cf, ca);
+				                   (const int *)s->ptiles, s->n_ptiles, s->abits, v, (const real *)sbuf[pn], scale, sig_po, n_sig_po,
+				                   zs_src, n_zs_src, P + PART_RMAX, sig_new_part, s->pcg_state, crbuf[pn], (const int *)s->slot_l1, cf, ca);
 				LFA_LAUNCH_CHECK(s);
 			} else {
 				hipLaunchKernelGGL((k_pcg_b<real, false>), dim3(GB), dim3(256), 0, s->stream, (const int *)s->ptiles,
-				                   s->n_ptiles, s->abits, v, (const real *)sbuf[pn], scale, P + (po ? PART_SIG1 : PART_SIG0),
-				                   n_sig_po, P + PART_ZS, GA, P + PART_RMAX, P + (pn ? PART_SIG1 : PART_SIG0), s->pcg_state,
-				                   crbuf[pn], (const int *)s->slot_l1, CoarseFields<real>{}, CoarseArgs{});
+				                   s->n_ptiles, s->abits, v, (const real *)sbuf[pn], scale, sig_po, n_sig_po, zs_src, n_zs_src,
+				                   P + PART_RMAX, sig_new_part, s->pcg_state, crbuf[pn], (const int *)s->slot_l1,
+				                   CoarseFields<real>{}, CoarseArgs{});
 				LFA_LAUNCH_CHECK(s);
 				if (is_ml(s)) {  // more than 64 level-1 blocks: the coarse levels follow as their own launches
 					s->c_r_cur = crbuf[pn];
-					LFA_TRY(coarse_apply<real>(s, P + (pn ? PART_SIG1 : PART_SIG0) + GB - G, s->stream));
+					LFA_TRY(coarse_apply<real>(s, sig_new_part + GB - G, s->stream));
 					s->c_r_cur = nullptr;
 				}
 			}
+			if (dist) {
+				LFA_TRY(lfa_dist_allreduce(s, P + PART_RMAX, GB, 2, true));
+				LFA_TRY(lfa_dist_allreduce(s, sig_new_part, NSB, 3 + pn, false));
+			}
 		}
 		// the residual of the last iteration of the chunk is tested here (k_pcg_a tests the one before it)
-		hipLaunchKernelGGL(k_check_converged, dim3(1), dim3(256), 0, s->stream, P + PART_RMAX, GB, s->prm.tolerance, i - 1,
-		                   s->pcg_state, s->pcg_hist);
+		hipLaunchKernelGGL(k_check_converged, dim3(1), dim3(256), 0, s->stream, dist ? red + 2 : P + PART_RMAX, dist ? 1 : GB,
+		                   s->prm.tolerance, i - 1, s->pcg_state, s->pcg_hist);
 		LFA_LAUNCH_CHECK(s);
 		LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 8, hipMemcpyDeviceToHost, s->stream));
 		LFA_HIP(s, hipStreamSynchronize(s->stream));
