@@ -1014,27 +1014,13 @@ k_pcg_b(const int *__restrict__ ptiles, int n_ptiles, const uint8_t *__restrict_
 	constexpr int WORK_LDS = EMBED ? (COARSE_LDS > FINE_LDS ? COARSE_LDS : FINE_LDS) : FINE_LDS;
 	__shared__ __attribute__((aligned(16))) char lds_raw[WORK_LDS > RED_LDS ? WORK_LDS : RED_LDS];
 	double *red = (double *)lds_raw;
-	if (state[0] >= 0) return;
-	double sigma, zs;
-	reduce_partials_sum2(part_sigma_old, n_sigma, part_zs, n_zs, red, sigma, zs);
-	const real alpha = (real)(sigma / zs);
 	const int nblk = EMBED ? (int)gridDim.x - PCG_COARSE_BLOCKS : (int)gridDim.x,
 	          blk = EMBED ? (int)blockIdx.x - PCG_COARSE_BLOCKS : (int)blockIdx.x;
-	if (EMBED && blockIdx.x < PCG_COARSE_BLOCKS) {
-		cf.alpha = alpha;
-		coarse_block<real, PCG_WAVES>(lds_raw, ca.l1_tiles, ca.n_l1, cf, scale, (const real *)ca.a2inv, (real *)ca.x2,
-		                              part_sigma_new + nblk, (int)blockIdx.x, PCG_COARSE_BLOCKS, ca.xchg, ca.ticket);
-		return;
-	}
+	const bool coarse_wg = EMBED && blockIdx.x < PCG_COARSE_BLOCKS;
 	const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-	real *X = (real *)lds_raw + (size_t)wid * SWEEP_X_LEN + 64;
-	BCPair<real> *BC = (BCPair<real> *)((real *)lds_raw + (size_t)PCG_WAVES * SWEEP_X_LEN) + (size_t)wid * LFA_TILE_CELLS;
-	X[lane - 64] = (real)0;
-	X[LFA_TILE_CELLS + lane] = (real)0;
-	double acc = 0.0, m = -INFINITY;
-	bool nan = false;
 	// Software pipeline over the tiles of this wave: the loads of the next tile are issued before the sweeps of the
-	// current one (which only touch LDS), so HBM latency hides behind the 44 dependent hyperplanes.
+	// current one (which only touch LDS), so HBM latency hides behind the 44 dependent hyperplanes; the loads of the first
+	// tile are issued before the scalars of the previous kernel are reduced.
 	// Global accesses are 16 B per lane: lane l holds cells [256 k + 4 l, 256 k + 4 l + 4), k = 0, 1, of the tile's 512.
 	const int stride = nblk * PCG_WAVES;
 	int slot = blk * PCG_WAVES + wid;
@@ -1054,7 +1040,23 @@ k_pcg_b(const int *__restrict__ ptiles, int n_ptiles, const uint8_t *__restrict_
 			tq[k] = *(const V4<real> *)(v.q + b);
 		}
 	};
-	if (slot < n_ptiles) load_tile(slot);
+	if (!coarse_wg && slot < n_ptiles) load_tile(slot);
+	if (state[0] >= 0) return;
+	double sigma, zs;
+	reduce_partials_sum2(part_sigma_old, n_sigma, part_zs, n_zs, red, sigma, zs);
+	const real alpha = (real)(sigma / zs);
+	if (coarse_wg) {
+		cf.alpha = alpha;
+		coarse_block<real, PCG_WAVES>(lds_raw, ca.l1_tiles, ca.n_l1, cf, scale, (const real *)ca.a2inv, (real *)ca.x2,
+		                              part_sigma_new + nblk, (int)blockIdx.x, PCG_COARSE_BLOCKS, ca.xchg, ca.ticket);
+		return;
+	}
+	real *X = (real *)lds_raw + (size_t)wid * SWEEP_X_LEN + 64;
+	BCPair<real> *BC = (BCPair<real> *)((real *)lds_raw + (size_t)PCG_WAVES * SWEEP_X_LEN) + (size_t)wid * LFA_TILE_CELLS;
+	X[lane - 64] = (real)0;
+	X[LFA_TILE_CELLS + lane] = (real)0;
+	double acc = 0.0, m = -INFINITY;
+	bool nan = false;
 	while (slot < n_ptiles) {
 		real rn[8];
 		double sr = 0.0;
@@ -1136,27 +1138,6 @@ k_pcg_a(int n_ptiles, const int *__restrict__ nbr, const uint8_t *__restrict__ a
         const real *__restrict__ coarse_x2, real *coarse_as) {
 	__shared__ real halo[PCG_WAVES][LFA_HALO_CELLS];
 	__shared__ double lds[256];
-	if (state[0] >= 0) return;
-	if (iter > 0) {
-		// stopping rule of pressure_solver::solve (src/pressure_solver.cpp:54-58) on the residual of iteration iter-1;
-		// every workgroup evaluates it on the same partials, workgroup 0 records it
-		const double rmax = reduce_partials_max(part_rmax, n_rmax, lds);
-		const bool stop = rmax != rmax || rmax < tol;
-		if (blockIdx.x == 0 && threadIdx.x == 0) {
-			hist[iter - 1] = rmax;
-			if (stop) {
-				if (rmax != rmax) state[1] = 1;
-				state[0] = iter;
-			}
-		}
-		if (stop) return;
-	}
-	real beta = (real)0;
-	if (!FIRST) {
-		double sn, so;
-		reduce_partials_sum2(part_sig_new, n_sig_new, part_sig_old, n_sig_old, lds, sn, so);
-		beta = (real)(sn / so);
-	}
 	const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
 	real *h = halo[wid];
 	double acc = 0.0;
@@ -1207,7 +1188,28 @@ k_pcg_a(int n_ptiles, const int *__restrict__ nbr, const uint8_t *__restrict__ a
 			xc = coarse_x[i1[6]] + coarse_x2[i2[6]];
 		}
 	};
-	if (slot < n_ptiles) load_tile(slot);
+	if (slot < n_ptiles) load_tile(slot);  // in flight while the scalars of the previous kernel are reduced
+	if (state[0] >= 0) return;
+	if (iter > 0) {
+		// stopping rule of pressure_solver::solve (src/pressure_solver.cpp:54-58) on the residual of iteration iter-1;
+		// every workgroup evaluates it on the same partials, workgroup 0 records it
+		const double rmax = reduce_partials_max(part_rmax, n_rmax, lds);
+		const bool stop = rmax != rmax || rmax < tol;
+		if (blockIdx.x == 0 && threadIdx.x == 0) {
+			hist[iter - 1] = rmax;
+			if (stop) {
+				if (rmax != rmax) state[1] = 1;
+				state[0] = iter;
+			}
+		}
+		if (stop) return;
+	}
+	real beta = (real)0;
+	if (!FIRST) {
+		double sn, so;
+		reduce_partials_sum2(part_sig_new, n_sig_new, part_sig_old, n_sig_old, lds, sn, so);
+		beta = (real)(sn / so);
+	}
 	while (slot < n_ptiles) {
 		WAVE_FENCE();
 		// the new search direction (k_update_s): z + coarse part on the unknowns, + beta s
