@@ -25,6 +25,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 PCG_BYTES_UNFUSED = {"spmv_dot": 17, "axpy_max": 28, "mic_apply_dot": 34, "update_s": 12}
 # fused iteration (default): k_pcg_a = update_s + spmv_dot, k_pcg_b = axpy_max + mic_apply_dot; same 91 n in total
 PCG_BYTES_FUSED = {"pcg_a": 12 + 17, "pcg_b": 28 + 34}
+# multigrid iteration (default on one GPU): search direction + A s, AXPYs + finest-level pre-smoothing, finest-level residual
+# + restriction, coarser levels (latency bound: no byte figure), finest-level prolongation + post-smoothing + dot.
+# Bytes per unknown = the minimal traffic of each pass with SURVEY 8(d)'s conventions (fp32 vector 4, A byte 1, dot 8, max 4).
+PCG_BYTES_MG = {"pcg_a": 12 + 17, "mg_axpy_presmooth": 28 + 5, "mg_down0": 9.5, "mg_coarse": 0, "mg_up0": 21}
 
 
 def cpu_baseline(sample, steps):
@@ -64,7 +68,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default=None, help="C2 | C3 | C4 | C5 (default: C4 at 1 GPU, see DESIGN.md)")
     ap.add_argument("--dt", type=float, default=0.033, help="min(3*cfl, 0.033) of simulation::time_step() at rest")
-    ap.add_argument("--precond", default="multilevel", choices=["multilevel", "tiled", "exact"])
+    ap.add_argument("--precond", default=None, choices=["multigrid", "multilevel", "tiled", "exact"],
+                    help="default: multigrid on one GPU, multilevel with z-slabs (the V-cycle is single-domain)")
     ap.add_argument("--pcg-dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--p2g", default="binned", choices=["binned", "atomic"])
     ap.add_argument("--max-iterations", type=int, default=200, help="PCG iteration cap (pressure_solver.h:42)")
@@ -78,6 +83,8 @@ def main():
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
+    if args.precond is None:
+        args.precond = "multigrid" if (int(os.environ.get("WORLD_SIZE", "1")) == 1 or args.replicas) else "multilevel"
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
@@ -107,12 +114,12 @@ def main():
         bhi[2] *= world
     sim = lfa.Sim(size, method=cfg["method"], blending=cfg["blending"], device=local_rank,
                   precond={"exact": lfa.PRECOND_MIC0_EXACT, "tiled": lfa.PRECOND_MIC0_TILED,
-                           "multilevel": lfa.PRECOND_MULTILEVEL}[args.precond],
+                           "multilevel": lfa.PRECOND_MULTILEVEL, "multigrid": lfa.PRECOND_MULTIGRID}[args.precond],
                   pcg_dtype=lfa.PCG_F64 if args.pcg_dtype == "f64" else lfa.PCG_F32,
                   p2g_variant=lfa.P2G_GLOBAL_ATOMIC if args.p2g == "atomic" else lfa.P2G_LDS_BINNED,
                   max_iterations=args.max_iterations, pcg_fused=0 if args.unfused else 1)
     fused = not args.unfused and args.precond != "exact"
-    PCG_BYTES = PCG_BYTES_FUSED if fused else PCG_BYTES_UNFUSED
+    PCG_BYTES = PCG_BYTES_MG if args.precond == "multigrid" else (PCG_BYTES_FUSED if fused else PCG_BYTES_UNFUSED)
     if world > 1 and not args.replicas:
         # one RCCL communicator per handle: rank 0 creates the id, torch.distributed (RCCL) broadcasts it
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
@@ -177,8 +184,10 @@ def main():
                         f"hot path only (bin+P2G+gravity+PCG+apply+extrapolate+G2P)",
             "unknowns": n_unknowns, "particles_per_gpu": npart,
             "precond": {"tiled": "MIC(0) per 8^3 tile", "exact": "MIC(0) exact (tile hyperplanes)",
-                        "multilevel": "MIC(0) per 8^3 tile + tile-aggregate coarse correction"}[args.precond],
-            "pcg_loop": "fused: 2 launches per iteration (k_pcg_a, k_pcg_b)" if fused else "5 launches per iteration",
+                        "multilevel": "MIC(0) per 8^3 tile + tile-aggregate coarse correction",
+                        "multigrid": "geometric multigrid V(1,1), red-black Gauss-Seidel per tile"}[args.precond],
+            "pcg_loop": ("k_pcg_a + AXPYs/pre-smoothing + V-cycle (k_mg_*) per iteration" if args.precond == "multigrid" else
+                         "fused: 2 launches per iteration (k_pcg_a, k_pcg_b)" if fused else "5 launches per iteration"),
             "p2g": args.p2g, "pcg_tolerance": 1e-6, "pcg_max_iterations": args.max_iterations,
             "parallelism": parallelism,
         },
@@ -198,7 +207,7 @@ def main():
         for name in PCG_BYTES:
             # pcg_b / mic_apply_dot = the launch of the PCG loop: tile sweeps + the embedded coarse-level workgroups
             ms = sim.bench_kernel(name, 20)
-            b = PCG_BYTES[name] * n_unknowns * (2 if args.pcg_dtype == "f64" else 1)
+            b = int(PCG_BYTES[name] * n_unknowns * (2 if args.pcg_dtype == "f64" else 1))
             kernels[name] = {"ms": ms, "algorithmic_bytes": b, "GBps": b / ms * 1e-6}
         if args.precond == "multilevel" and not fused:
             kernels["mic_sweeps_without_coarse_levels"] = {"ms": sim.bench_kernel("mic_fine", 20), "algorithmic_bytes": 0,
@@ -212,7 +221,8 @@ def main():
         # 296-335); cells outside the processed tiles are implicit here (background value), a legitimate saving
         ncell_all = cfg["size"][0] * cfg["size"][1] * cfg["size"][2]  # per GPU
         fin_bytes = (26 if cfg["method"] == 1 else 14) * ncell_all
-        for name, b in (("g2p", g2p_bytes), ("p2g_finalize", fin_bytes), ("p2g_scatter", p2g_bytes)):
+        bin_bytes = (2 * 68 + 8) * npart  # 2 x state bytes + keys
+        for name, b in (("g2p", g2p_bytes), ("p2g_finalize", fin_bytes), ("p2g_scatter", p2g_bytes), ("bin", bin_bytes)):
             ms = sim.bench_kernel(name, 10)
             kernels[name] = {"ms": ms, "algorithmic_bytes": b, "GBps": b / ms * 1e-6}
         out["kernels"] = kernels
@@ -224,7 +234,7 @@ def main():
         # HBM traffic of that kernel from the PMC passes committed under profiles/ (same command, same workload)
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_c4_pmc_traffic.json")
-        if cfg_name == "C4" and args.precond == "multilevel" and args.pcg_dtype == "f32" and os.path.exists(pmc):
+        if cfg_name == "C4" and args.precond in ("multilevel", "multigrid") and args.pcg_dtype == "f32" and os.path.exists(pmc):
             traffic = json.load(open(pmc))["hbm_bytes_per_launch"].get(dom, {}).get("total")
         out["roofline"] = {
             "bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -233,7 +243,8 @@ def main():
             "share_of_step_ms": share[dom],
         }
         pcg_iter_ms = sum(kernels[k]["ms"] for k in PCG_BYTES)
-        pcg_bytes = 91 * n_unknowns * (2 if args.pcg_dtype == "f64" else 1)
+        # the reference's iteration is 91 n bytes; the V-cycle iteration is priced by its own passes
+        pcg_bytes = (sum(PCG_BYTES.values()) if args.precond == "multigrid" else 91) * n_unknowns * (2 if args.pcg_dtype == "f64" else 1)
         out["roofline_groups"] = {
             "pcg_iteration": {"ms": pcg_iter_ms, "algorithmic_bytes": pcg_bytes, "GBps": pcg_bytes / pcg_iter_ms * 1e-6,
                               "frac": pcg_bytes / pcg_iter_ms * 1e-6 / HBM_PEAK_GBS},

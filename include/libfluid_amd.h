@@ -51,7 +51,13 @@ enum { LFA_PRECOND_MIC0_TILED = 0, LFA_PRECOND_MIC0_EXACT = 1,
        /* MULTILEVEL = TILED + additive coarse-space correction: one piecewise-constant unknown per 8^3 tile (Galerkin
         * operator, block MIC(0) again on 8^3 blocks of tiles) and a dense solve of the 64^3-cell aggregates on top.
         * Restores mesh-independent-ish convergence at one launch per level. */
-       LFA_PRECOND_MULTILEVEL = 2 };
+       LFA_PRECOND_MULTILEVEL = 2,
+       /* MULTIGRID = geometric multigrid V-cycle (levels of 2x coarser cells down to one tile, rediscretised operators,
+        * red-black Gauss-Seidel inside tiles / Jacobi across tile faces, piecewise-constant transfers): the work per
+        * iteration stays O(unknowns) and the iteration count barely grows with the grid (about 20 at 512^3 where MIC(0)
+        * needs 180). Single domain only: a handle with a slab decomposition uses MULTILEVEL instead. Same converged
+        * pressure, same stopping rule. The default. */
+       LFA_PRECOND_MULTIGRID = 3 };
 /* arithmetic type of the PCG vectors */
 enum { LFA_PCG_F32 = 0, LFA_PCG_F64 = 1 };
 
@@ -71,7 +77,7 @@ typedef struct lfa_params {
 	double tau, sigma, tolerance; /* 0.97, 0.25, 1e-6 */
 	uint64_t max_iterations;      /* 200 */
 	int32_t p2g_variant;          /* LFA_P2G_LDS_BINNED */
-	int32_t precond;              /* LFA_PRECOND_MULTILEVEL */
+	int32_t precond;              /* LFA_PRECOND_MULTIGRID (LFA_PRECOND_MULTILEVEL with slabs) */
 	int32_t pcg_dtype;            /* LFA_PCG_F32 */
 	int32_t apic_unscaled_kernel; /* 1 = keep the reference quirk simulation.cpp:367-369 (only differs when cell_size != 1;
 	                                 the device path then returns LFA_E_UNSUPPORTED), 0 = divide by cell_size */
@@ -282,7 +288,12 @@ enum {
 	LFA_K_MIC_FINE = 8,    /* the tile-level sweep kernel of LFA_K_MIC_APPLY alone (k_mic_apply) */
 	LFA_K_COARSE = 9,      /* the coarse levels of the multilevel preconditioner alone (side stream in the solve) */
 	LFA_K_PCG_A = 10,      /* fused: s = z + beta s, q = A s, dot(q,s)   algorithmic 12 n + 17 n bytes */
-	LFA_K_PCG_B = 11       /* fused: p += a s, r -= a q, max r, z = M^-1 r, dot(z,r)   algorithmic 28 n + 34 n bytes */
+	LFA_K_PCG_B = 11,      /* fused: p += a s, r -= a q, max r, z = M^-1 r, dot(z,r)   algorithmic 28 n + 34 n bytes */
+	/* LFA_PRECOND_MULTIGRID: the parts of one iteration besides LFA_K_PCG_A */
+	LFA_K_MG_AXPY_PRESMOOTH = 12, /* p += a s, r -= a q, max r + red-black pre-smoothing of the finest level  28 n + 5 n */
+	LFA_K_MG_DOWN0 = 13,          /* finest level: residual + restriction                                     9.5 n */
+	LFA_K_MG_COARSE = 14,         /* all coarser levels: down, single-workgroup tail, up (latency bound)          */
+	LFA_K_MG_UP0 = 15             /* finest level: prolongation + post-smoothing + dot(z, r)                   21 n */
 };
 int lfa_bench_kernel(lfa_sim *s, int which, int reps, double *mean_ms);
 

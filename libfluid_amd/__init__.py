@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(HERE, "libfluid_amd.so")
 
 PIC, FLIP_BLEND, APIC = 0, 1, 2
 P2G_LDS_BINNED, P2G_GLOBAL_ATOMIC = 0, 1
-PRECOND_MIC0_TILED, PRECOND_MIC0_EXACT, PRECOND_MULTILEVEL = 0, 1, 2
+PRECOND_MIC0_TILED, PRECOND_MIC0_EXACT, PRECOND_MULTILEVEL, PRECOND_MULTIGRID = 0, 1, 2, 3
 PCG_F32, PCG_F64 = 0, 1
 OK, W_PCG_NOT_CONVERGED = 0, 1
 NUM_TIMERS = 10
@@ -136,7 +136,8 @@ SIGNATURES = {
     "lfa_dist_get_slab": (_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
 KERNELS = {"spmv_dot": 0, "axpy_max": 1, "mic_apply_dot": 2, "update_s": 3, "p2g_scatter": 4, "p2g_finalize": 5,
-           "g2p": 6, "bin": 7, "mic_fine": 8, "coarse_levels": 9, "pcg_a": 10, "pcg_b": 11}
+           "g2p": 6, "bin": 7, "mic_fine": 8, "coarse_levels": 9, "pcg_a": 10, "pcg_b": 11,
+           "mg_axpy_presmooth": 12, "mg_down0": 13, "mg_coarse": 14, "mg_up0": 15}
 
 
 def load_library():

@@ -110,6 +110,7 @@ struct lfa_sim {
 	// pressure system
 	uint8_t *abits = nullptr;
 	void *vp = nullptr, *vr = nullptr, *vz = nullptr, *vs = nullptr, *vpre = nullptr, *vq = nullptr;
+	struct lfa_mg *mg = nullptr;  // multigrid hierarchy (mg.hip)
 	int *nbr_table = nullptr;  // per particle-tile slot: neighbour tile ids + level-1 indices (k_build_nbr_table)
 	void *vs2 = nullptr;  // second search-direction buffer of the fused iteration (k_pcg_a reads one, writes the other)
 	size_t vec_elem = 0;  // element size the vectors are currently allocated for

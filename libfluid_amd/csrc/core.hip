@@ -6,6 +6,8 @@
 #include <string.h>
 
 #include "common.h"
+#include "pcg.h"
+#include "pcg.h"
 
 static thread_local std::string g_create_error;
 
@@ -138,7 +140,7 @@ extern "C" void lfa_default_params(lfa_params *p) {
 	p->tolerance = 1e-6;
 	p->max_iterations = 200;
 	p->p2g_variant = LFA_P2G_LDS_BINNED;
-	p->precond = LFA_PRECOND_MULTILEVEL;
+	p->precond = LFA_PRECOND_MULTIGRID;
 	p->pcg_dtype = LFA_PCG_F32;
 	p->apic_unscaled_kernel = 1;
 	p->pcg_fused = 1;
@@ -267,6 +269,7 @@ extern "C" void lfa_destroy(lfa_sim *s) {
 	if (s->h_pinned) (void)hipHostFree(s->h_pinned);
 	if (s->dist) delete s->dist;
 	s->dist = nullptr;
+	lfa_mg_free(s);
 	if (s->ev_created)
 		for (auto &e : s->ev) (void)hipEventDestroy(e);
 	if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
@@ -290,8 +293,9 @@ extern "C" int lfa_set_params(lfa_sim *s, const lfa_params *p) {
 		                "APIC with the reference's unscaled kernel (simulation.cpp:367-369) is only implemented for "
 		                "cell_size == 1; set apic_unscaled_kernel = 0");
 	if (p->pcg_dtype != s->prm.pcg_dtype || p->precond != s->prm.precond) s->system_valid = false;
-	if (p->precond < 0 || p->precond > 2) return lfa_fail(s, LFA_E_INVALID, "bad precond");
+	if (p->precond < 0 || p->precond > LFA_PRECOND_MULTIGRID) return lfa_fail(s, LFA_E_INVALID, "bad precond");
 	s->prm = *p;
+	if (s->dist && s->prm.precond == LFA_PRECOND_MULTIGRID) s->prm.precond = LFA_PRECOND_MULTILEVEL;  // single-domain only
 	return LFA_OK;
 }
 extern "C" int lfa_get_params(const lfa_sim *s, lfa_params *p) {

@@ -541,6 +541,7 @@ int attach(lfa_sim *s, lfa_dist *d, const int32_t *bounds) {
 	}
 	if (s->dist) delete s->dist;
 	s->dist = d;
+	if (s->prm.precond == LFA_PRECOND_MULTIGRID) s->prm.precond = LFA_PRECOND_MULTILEVEL;  // multigrid is single-domain
 	s->slab_lo = lo;
 	s->slab_hi = hi;
 	s->binned = false;

@@ -1,0 +1,705 @@
+// libfluid_amd/csrc/mg.hip -- geometric multigrid V-cycle as the preconditioner of the pressure PCG
+// (LFA_PRECOND_MULTIGRID). Not in the reference (its preconditioner is MIC(0), src/pressure_solver.cpp:244-332): the
+// converged pressure is the same (the stopping rule of pressure_solver.cpp:54 is unchanged), the iteration count drops
+// from ~180 (MIC(0), C4) to ~20 because the work per iteration no longer depends on how far information has to travel.
+//
+// Hierarchy: level l has cells of 2^l fine cells, stored tile-major exactly like the fine grid (8^3 tiles of that
+// level's cells), so every level runs the same wave-per-tile kernels. A fine tile is one octant of its parent tile.
+//   types     : a coarse cell is AIR if any child is air, else FLUID if any child is an unknown, else SOLID
+//               (McAdams, Sifakis, Teran 2010: the Dirichlet surface moves inwards, never outwards)
+//   operator  : the 7-point operator rediscretised on those types, in the fine level's encoding (one A byte per cell:
+//               non-solid neighbour count + "positive neighbour is fluid" bits), UNSCALED (the factor dt/(rho h^2) of
+//               pressure_solver.cpp:22 is applied once, to the result)
+//   transfers : piecewise constant; restriction = sum of the 8 children, halved (the Galerkin operator of piecewise
+//               constant interpolation is twice as stiff as the rediscretised one)
+//   smoother  : red-black Gauss-Seidel inside a tile, Jacobi across tile faces ("hybrid"); one sweep red->black on
+//               the way down from a zero guess (which makes it tile-local: no halo), one sweep black->red on the way up.
+//               The two are adjoint, so the V-cycle is a symmetric positive definite operator (tested).
+// Launches per V-cycle and level: k_mg_presmooth, k_mg_residual_restrict on the way down, k_mg_prolong_postsmooth on the
+// way up; the coarsest level (one tile) is solved by many sweeps inside one wave.
+#include "pcg.h"
+
+#include <math.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <unordered_map>
+#include <vector>
+
+#define MG_MAX_LEVELS 12
+#define MG_NBR_STRIDE 8  // per slot: six face-neighbour tile ids (-1: inactive) + own tile id + pad
+
+struct lfa_mg_level {
+	GridDims g{};          // cells of this level
+	size_t ncp = 0;        // padded cells
+	int n_tiles = 0;       // active tiles (hold unknowns or children that do)
+	int *tiles = nullptr;  // device, ascending tile id
+	int *nbr = nullptr;    // device, MG_NBR_STRIDE ints per slot
+	uint8_t *ctype = nullptr;  // device, whole padded grid: 0 air, 1 fluid, 2 solid   (levels >= 1)
+	uint8_t *abits = nullptr;  // device, whole padded grid                            (levels >= 1; level 0: s->abits)
+	// device, whole padded grid: right-hand side, pre-smoothed iterate, final iterate (the up-kernel reads the ring of x while
+	// neighbouring waves store y)                                                     (levels >= 1; level 0: vr, vq, vz)
+	void *b = nullptr, *x = nullptr, *y = nullptr;
+	size_t cap_tiles = 0;
+};
+struct lfa_mg {
+	int n_levels = 0;
+	lfa_mg_level lv[MG_MAX_LEVELS];
+	size_t elem = 0;
+};
+
+namespace {
+#define MG_FENCE()                                             \
+	do {                                                       \
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+		__builtin_amdgcn_wave_barrier();                       \
+	} while (0)
+
+enum { MT_AIR = 0, MT_FLUID = 1, MT_SOLID = 2 };
+
+// ------------------------------------------------------------------------------------------------ set-up kernels
+/// Level-0 cell type for the coarsening rule, from the simulation's own arrays (cell_type_at / is_unknown_at of
+/// grid_ops.hip): tiles that hold particles have explicit types, every other cell is solid or air by the solid mask.
+__device__ inline int fine_type(const uint32_t *tile_flag, const uint32_t *cell_count, const uint8_t *ctype, const uint8_t *solid,
+                                uint32_t b) {
+	if (!tile_flag[b >> 9]) return solid[b] ? MT_SOLID : MT_AIR;
+	if (cell_count[b] > 0) return MT_FLUID;  // an unknown (also a solid cell that holds particles)
+	return (ctype[b] & 7) == CT_SOLID ? MT_SOLID : MT_AIR;
+}
+
+/// Types of level 1 from the fine grid, one thread per coarse cell of the whole padded coarse grid.
+__global__ void k_mg_types_from_fine(GridDims gf, GridDims gc, size_t ncp_c, const uint32_t *tile_flag, const uint32_t *cell_count,
+                                     const uint8_t *ctype, const uint8_t *solid, uint8_t *out) {
+	const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= ncp_c) return;
+	const int tile = (int)(c >> 9), l = (int)(c & 511);
+	int tx, ty, tz;
+	tile_coords(gc, tile, tx, ty, tz);
+	const int X = tx * 8 + (l & 7), Y = ty * 8 + ((l >> 3) & 7), Z = tz * 8 + (l >> 6);
+	bool any_air = false, any_fluid = false;
+	for (int k = 0; k < 8; ++k) {
+		const int x = 2 * X + (k & 1), y = 2 * Y + ((k >> 1) & 1), z = 2 * Z + (k >> 2);
+		int t = MT_SOLID;  // outside the grid: a wall (mac_grid.cpp:26-31)
+		if (in_grid(gf, x, y, z)) t = fine_type(tile_flag, cell_count, ctype, solid, blocked_index(gf, x, y, z));
+		any_air |= t == MT_AIR;
+		any_fluid |= t == MT_FLUID;
+	}
+	out[c] = (uint8_t)(!in_grid(gc, X, Y, Z) ? MT_SOLID : (any_air ? MT_AIR : (any_fluid ? MT_FLUID : MT_SOLID)));
+}
+/// Types of level l + 1 from level l.
+__global__ void k_mg_types_coarsen(GridDims gf, GridDims gc, size_t ncp_c, const uint8_t *tf, uint8_t *out) {
+	const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= ncp_c) return;
+	const int tile = (int)(c >> 9), l = (int)(c & 511);
+	int tx, ty, tz;
+	tile_coords(gc, tile, tx, ty, tz);
+	const int X = tx * 8 + (l & 7), Y = ty * 8 + ((l >> 3) & 7), Z = tz * 8 + (l >> 6);
+	bool any_air = false, any_fluid = false;
+	for (int k = 0; k < 8; ++k) {
+		const int x = 2 * X + (k & 1), y = 2 * Y + ((k >> 1) & 1), z = 2 * Z + (k >> 2);
+		const int t = in_grid(gf, x, y, z) ? tf[blocked_index(gf, x, y, z)] : MT_SOLID;
+		any_air |= t == MT_AIR;
+		any_fluid |= t == MT_FLUID;
+	}
+	out[c] = (uint8_t)(!in_grid(gc, X, Y, Z) ? MT_SOLID : (any_air ? MT_AIR : (any_fluid ? MT_FLUID : MT_SOLID)));
+}
+/// A bytes of a coarse level from its types (the encoding of k_abits, grid_ops.hip), for the active tiles.
+__global__ void __launch_bounds__(256) k_mg_abits(const int *tiles, int n_tiles, GridDims g, const uint8_t *t, uint8_t *abits) {
+	for (int slot = blockIdx.x; slot < n_tiles; slot += gridDim.x) {
+		const int tile = tiles[slot];
+		int tx, ty, tz;
+		tile_coords(g, tile, tx, ty, tz);
+		for (int l = threadIdx.x; l < 512; l += 256) {
+			const int x = tx * 8 + (l & 7), y = ty * 8 + ((l >> 3) & 7), z = tz * 8 + (l >> 6);
+			const size_t b = (size_t)tile * 512 + l;
+			uint8_t a = 0;
+			if (t[b] == MT_FLUID) {
+				auto ty_at = [&](int xx, int yy, int zz) -> int { return in_grid(g, xx, yy, zz) ? t[blocked_index(g, xx, yy, zz)] : MT_SOLID; };
+				const int xp = ty_at(x + 1, y, z), yp = ty_at(x, y + 1, z), zp = ty_at(x, y, z + 1);
+				const int ns = (xp != MT_SOLID) + (yp != MT_SOLID) + (zp != MT_SOLID) + (ty_at(x - 1, y, z) != MT_SOLID) +
+				               (ty_at(x, y - 1, z) != MT_SOLID) + (ty_at(x, y, z - 1) != MT_SOLID);
+				a = (uint8_t)(ns | ((xp == MT_FLUID) << 3) | ((yp == MT_FLUID) << 4) | ((zp == MT_FLUID) << 5) | AB_UNKNOWN | AB_FLUID);
+			}
+			abits[b] = a;
+		}
+	}
+}
+__global__ void k_mg_zero_tiles(const int *tiles, int n_tiles, void *field, int elem) {
+	const int slot = blockIdx.x;
+	if (slot >= n_tiles) return;
+	uint32_t *p = (uint32_t *)((char *)field + (size_t)tiles[slot] * 512 * elem);
+	for (int i = threadIdx.x; i < 512 * elem / 4; i += 256) p[i] = 0u;
+}
+
+// ------------------------------------------------------------------------------------------------ V-cycle kernels
+/// What a kernel needs to know about one level.
+template <typename real> struct MgLv {
+	const int *tiles, *nbr;
+	int n_tiles;
+	GridDims g;
+	const uint8_t *abits;
+	real *b, *x, *y;
+};
+
+/// 1 / (number of non-solid neighbours), 1..6: a table lookup by selects instead of an IEEE division in the smoother.
+template <typename real> __device__ inline real rcp_diag(uint32_t n) {
+	return n == 6 ? (real)(1.0 / 6.0) : n == 5 ? (real)0.2 : n == 4 ? (real)0.25 : n == 3 ? (real)(1.0 / 3.0) : n == 2 ? (real)0.5 : (real)1;
+}
+
+/// One colour of the Gauss-Seidel update on the column of a lane: x_i = (b_i + sum of coupled neighbours) / diag_i.
+/// `h` is the 10^3 halo block of the wave (current values, ring = values of the neighbour tiles or 0).
+template <typename real>
+__device__ inline void gs_colour(real *h, const uint32_t (&ab)[8], const real (&bb)[8], int lx, int ly, int colour) {
+#pragma unroll
+	for (int zz = 0; zz < 8; ++zz) {
+		if (((lx + ly + zz) & 1) != colour) continue;
+		const uint32_t a = ab[zz];
+		if (!(a & AB_UNKNOWN) || !(a & 7)) continue;
+		const int i = (lx + 1) + 10 * (ly + 1) + 100 * (zz + 1);
+		const real F = (a & AB_FLUID) ? (real)1 : (real)0;
+		real sum = bb[zz];
+		sum += F * h[i - 1];
+		sum += F * h[i - 10];
+		sum += F * h[i - 100];
+		sum += (real)((a >> 3) & 1) * h[i + 1];
+		sum += (real)((a >> 4) & 1) * h[i + 10];
+		sum += (real)((a >> 5) & 1) * h[i + 100];
+		h[i] = sum * rcp_diag<real>(a & 7);
+	}
+}
+
+/// Down, one tile: x = one red->black sweep on A x = b from x = 0 (`h`: ring already zero). With a zero guess the values
+/// across the tile faces do not enter, so the tile is smoothed on its own. Returns nothing; the column ends in `h`.
+template <typename real>
+__device__ inline void presmooth_column(real *h, const uint32_t (&ab)[8], const real (&bb)[8], int lx, int ly) {
+	MG_FENCE();
+#pragma unroll
+	for (int zz = 0; zz < 8; ++zz) h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)] = (real)0;
+	MG_FENCE();
+	gs_colour<real>(h, ab, bb, lx, ly, 0);
+	MG_FENCE();
+	gs_colour<real>(h, ab, bb, lx, ly, 1);
+	MG_FENCE();
+}
+template <typename real> __device__ inline void presmooth_tile(const MgLv<real> &L, int slot, real *h, int lane) {
+	const int lx = lane & 7, ly = lane >> 3;
+	const size_t base = (size_t)L.tiles[slot] * 512;
+	uint32_t ab[8];
+	real bb[8];
+#pragma unroll
+	for (int zz = 0; zz < 8; ++zz) {
+		ab[zz] = L.abits[base + zz * 64 + lane];
+		bb[zz] = L.b[base + zz * 64 + lane];
+	}
+	presmooth_column<real>(h, ab, bb, lx, ly);
+#pragma unroll
+	for (int zz = 0; zz < 8; ++zz) L.x[base + zz * 64 + lane] = h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)];
+}
+
+/// Halo block of a tile-major vector (k_spmv's layout): interior + the six faces of the neighbour tiles (0 if inactive).
+template <typename real> __device__ inline void load_halo(real *h, const real *v, size_t base, const int *nb, int lane, int lx, int ly) {
+#pragma unroll
+	for (int zz = 0; zz < 8; ++zz) h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)] = v[base + zz * 64 + lane];
+	h[0 + 10 * (lx + 1) + 100 * (ly + 1)] = nb[0] >= 0 ? v[(size_t)nb[0] * 512 + ly * 64 + lx * 8 + 7] : (real)0;
+	h[9 + 10 * (lx + 1) + 100 * (ly + 1)] = nb[1] >= 0 ? v[(size_t)nb[1] * 512 + ly * 64 + lx * 8 + 0] : (real)0;
+	h[(lx + 1) + 10 * 0 + 100 * (ly + 1)] = nb[2] >= 0 ? v[(size_t)nb[2] * 512 + ly * 64 + 7 * 8 + lx] : (real)0;
+	h[(lx + 1) + 10 * 9 + 100 * (ly + 1)] = nb[3] >= 0 ? v[(size_t)nb[3] * 512 + ly * 64 + 0 * 8 + lx] : (real)0;
+	h[(lx + 1) + 10 * (ly + 1) + 100 * 0] = nb[4] >= 0 ? v[(size_t)nb[4] * 512 + 7 * 64 + lane] : (real)0;
+	h[(lx + 1) + 10 * (ly + 1) + 100 * 9] = nb[5] >= 0 ? v[(size_t)nb[5] * 512 + 0 * 64 + lane] : (real)0;
+}
+
+/// Down, one tile: residual r = b - A x of the level and its restriction to the next: half the sum over the 8 children.
+template <typename real>
+__device__ inline void residual_restrict_tile(const MgLv<real> &L, const GridDims &gc, real *b_coarse, int slot, real *h, int lane) {
+	const int lx = lane & 7, ly = lane >> 3;
+	const int *nt = L.nbr + (size_t)slot * MG_NBR_STRIDE;
+	const int nb[6] = {nt[0], nt[1], nt[2], nt[3], nt[4], nt[5]}, tile = nt[6];
+	const size_t base = (size_t)tile * 512;
+	MG_FENCE();
+	load_halo<real>(h, L.x, base, nb, lane, lx, ly);
+	MG_FENCE();
+	real pair[4];
+#pragma unroll
+	for (int zz = 0; zz < 8; ++zz) {
+		const int i = (lx + 1) + 10 * (ly + 1) + 100 * (zz + 1);
+		const uint32_t a = L.abits[base + zz * 64 + lane];
+		real r = (real)0;
+		if (a & AB_UNKNOWN) {
+			const real F = (a & AB_FLUID) ? (real)1 : (real)0;
+			real val = (real)(a & 7) * h[i];
+			val -= F * h[i - 1];
+			val -= F * h[i - 10];
+			val -= F * h[i - 100];
+			val -= (real)((a >> 3) & 1) * h[i + 1];
+			val -= (real)((a >> 4) & 1) * h[i + 10];
+			val -= (real)((a >> 5) & 1) * h[i + 100];
+			r = L.b[base + zz * 64 + lane] - val;
+		}
+		if (zz & 1) pair[zz >> 1] += r;
+		else pair[zz >> 1] = r;
+	}
+	int tx, ty, tz;
+	tile_coords(L.g, tile, tx, ty, tz);
+	const int ptile = (tx >> 1) + gc.ntx * ((ty >> 1) + gc.nty * (tz >> 1));
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		real t = pair[j];
+		t += __shfl_xor(t, 1, 64);
+		t += __shfl_xor(t, 8, 64);
+		if (!(lx & 1) && !(ly & 1))
+			b_coarse[(size_t)ptile * 512 + ((tz & 1) * 4 + j) * 64 + ((ty & 1) * 4 + (ly >> 1)) * 8 + (tx & 1) * 4 + (lx >> 1)] = (real)0.5 * t;
+	}
+}
+
+/// Up, one tile: x += P e (piecewise constant prolongation of the next level's solution), then one black->red sweep with
+/// the corrected values of the neighbour tiles on the ring; the column ends in `h`, `bb` returns the right-hand side.
+template <typename real>
+__device__ inline void prolong_postsmooth_tile(const MgLv<real> &L, const GridDims &gc, const real *e, int slot, real *h, int lane,
+                                               real (&bb)[8]) {
+	const int lx = lane & 7, ly = lane >> 3;
+	const int *nt = L.nbr + (size_t)slot * MG_NBR_STRIDE;
+	const int nb[6] = {nt[0], nt[1], nt[2], nt[3], nt[4], nt[5]}, tile = nt[6];
+	const size_t base = (size_t)tile * 512;
+	int tx, ty, tz;
+	tile_coords(L.g, tile, tx, ty, tz);
+	// correction of a cell given by its coordinates on this level (any tile): value of its parent cell
+	auto corr = [&](int X, int Y, int Z) -> real { return e ? e[blocked_index(gc, X >> 1, Y >> 1, Z >> 1)] : (real)0; };
+	uint32_t ab[8];
+	MG_FENCE();
+#pragma unroll
+	for (int zz = 0; zz < 8; ++zz) {
+		ab[zz] = L.abits[base + zz * 64 + lane];
+		bb[zz] = L.b[base + zz * 64 + lane];
+		real v = L.x[base + zz * 64 + lane];
+		if (ab[zz] & AB_UNKNOWN) v += corr(tx * 8 + lx, ty * 8 + ly, tz * 8 + zz);
+		h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)] = v;
+	}
+	// ring: face lanes = (a, b) over the two in-face axes; a ring cell is corrected like its own tile corrects it
+	auto ring = [&](int nbk, int cell, int X, int Y, int Z) -> real {
+		if (nbk < 0) return (real)0;
+		const size_t j = (size_t)nbk * 512 + cell;
+		real v = L.x[j];
+		if (L.abits[j] & AB_UNKNOWN) v += corr(X, Y, Z);
+		return v;
+	};
+	h[0 + 10 * (lx + 1) + 100 * (ly + 1)] = ring(nb[0], ly * 64 + lx * 8 + 7, tx * 8 - 1, ty * 8 + lx, tz * 8 + ly);
+	h[9 + 10 * (lx + 1) + 100 * (ly + 1)] = ring(nb[1], ly * 64 + lx * 8 + 0, tx * 8 + 8, ty * 8 + lx, tz * 8 + ly);
+	h[(lx + 1) + 10 * 0 + 100 * (ly + 1)] = ring(nb[2], ly * 64 + 7 * 8 + lx, tx * 8 + lx, ty * 8 - 1, tz * 8 + ly);
+	h[(lx + 1) + 10 * 9 + 100 * (ly + 1)] = ring(nb[3], ly * 64 + 0 * 8 + lx, tx * 8 + lx, ty * 8 + 8, tz * 8 + ly);
+	h[(lx + 1) + 10 * (ly + 1) + 100 * 0] = ring(nb[4], 7 * 64 + lane, tx * 8 + lx, ty * 8 + ly, tz * 8 - 1);
+	h[(lx + 1) + 10 * (ly + 1) + 100 * 9] = ring(nb[5], 0 * 64 + lane, tx * 8 + lx, ty * 8 + ly, tz * 8 + 8);
+	MG_FENCE();
+	gs_colour<real>(h, ab, bb, lx, ly, 1);
+	MG_FENCE();
+	gs_colour<real>(h, ab, bb, lx, ly, 0);
+	MG_FENCE();
+}
+
+/// Coarsest level (a single tile), one wave: NSW red->black sweeps followed by NSW black->red sweeps from zero -- a
+/// symmetric operator that is as good as exact for the few unknowns left. `h`: ring already zero.
+template <typename real> __device__ inline void coarsest_tile(const MgLv<real> &L, int nsw, real *h, int lane) {
+	const int lx = lane & 7, ly = lane >> 3;
+	const size_t base = (size_t)L.tiles[0] * 512;
+	uint32_t ab[8];
+	real bb[8];
+	MG_FENCE();
+#pragma unroll
+	for (int zz = 0; zz < 8; ++zz) {
+		ab[zz] = L.abits[base + zz * 64 + lane];
+		bb[zz] = L.b[base + zz * 64 + lane];
+		h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)] = (real)0;
+	}
+	MG_FENCE();
+	for (int k = 0; k < 2 * nsw; ++k) {
+		const int first = k < nsw ? 0 : 1;
+		gs_colour<real>(h, ab, bb, lx, ly, first);
+		MG_FENCE();
+		gs_colour<real>(h, ab, bb, lx, ly, first ^ 1);
+		MG_FENCE();
+	}
+#pragma unroll
+	for (int zz = 0; zz < 8; ++zz) L.y[base + zz * 64 + lane] = h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)];
+}
+
+template <typename real>
+__global__ void __launch_bounds__(256) k_mg_presmooth(MgLv<real> L, const int *state) {
+	__shared__ real halo[PCG_WAVES][LFA_HALO_CELLS];
+	if (state[0] >= 0) return;
+	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	real *h = halo[wid];
+	for (int i = lane; i < LFA_HALO_CELLS; i += 64) h[i] = (real)0;  // the ring stays zero
+	for (int slot = blockIdx.x * PCG_WAVES + wid; slot < L.n_tiles; slot += gridDim.x * PCG_WAVES) presmooth_tile<real>(L, slot, h, lane);
+}
+
+/// The AXPYs of the iteration (k_axpy_max) fused with the pre-smoothing of the finest level: p += alpha s, r -= alpha q,
+/// signed max r, then x0 = red->black sweep on the new residual, tile by tile (x0 overwrites q: same tile, same wave).
+template <typename real>
+__global__ void __launch_bounds__(256)
+k_mg_axpy_presmooth(const int *tiles, int n_tiles, const uint8_t *abits, real *p, const real *sdir, real *r, real *q_x,
+                    const double *part_sigma, int n_sigma, const double *part_qs, int n_qs, double *part_rmax, const int *state) {
+	__shared__ real halo[PCG_WAVES][LFA_HALO_CELLS];
+	__shared__ double lds[16];
+	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
+	double m = -INFINITY;
+	bool nan = false;
+	if (state[0] < 0) {
+		double a = 0.0, b = 0.0;
+		for (int i = threadIdx.x; i < n_sigma; i += 256) a += part_sigma[i];
+		for (int i = threadIdx.x; i < n_qs; i += 256) b += part_qs[i];
+		a = wave_sum(a);
+		b = wave_sum(b);
+		if (lane == 0) { lds[wid] = a; lds[4 + wid] = b; }
+		__syncthreads();
+		const real alpha = (real)(((lds[0] + lds[1]) + (lds[2] + lds[3])) / ((lds[4] + lds[5]) + (lds[6] + lds[7])));
+		__syncthreads();
+		real *h = halo[wid];
+		for (int i = lane; i < LFA_HALO_CELLS; i += 64) h[i] = (real)0;
+		for (int slot = blockIdx.x * PCG_WAVES + wid; slot < n_tiles; slot += gridDim.x * PCG_WAVES) {
+			const size_t base = (size_t)tiles[slot] * 512;
+			uint32_t ab[8];
+			real bb[8];
+#pragma unroll
+			for (int zz = 0; zz < 8; ++zz) {
+				const size_t c = base + zz * 64 + lane;
+				ab[zz] = abits[c];
+				const real pv = p[c], sv = sdir[c], rv = r[c], qv = q_x[c];
+				real rn = (real)0;
+				if (ab[zz] & AB_UNKNOWN) {
+					p[c] = pv + alpha * sv;
+					rn = rv + (-alpha) * qv;
+					r[c] = rn;
+					nan |= rn != rn;
+					m = (double)rn > m ? (double)rn : m;
+				}
+				bb[zz] = rn;
+			}
+			presmooth_column<real>(h, ab, bb, lx, ly);
+#pragma unroll
+			for (int zz = 0; zz < 8; ++zz) q_x[base + zz * 64 + lane] = h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)];
+		}
+	}
+	m = wave_max(m);
+	nan = __any(nan);
+	__syncthreads();
+	if (lane == 0) lds[8 + wid] = nan ? NAN : m;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		double v = lds[8];
+		for (int i = 1; i < 4; ++i) v = (v != v || lds[8 + i] != lds[8 + i]) ? NAN : (lds[8 + i] > v ? lds[8 + i] : v);
+		part_rmax[blockIdx.x] = v;
+	}
+}
+
+template <typename real>
+__global__ void __launch_bounds__(256) k_mg_residual_restrict(MgLv<real> L, GridDims gc, real *b_coarse, const int *state) {
+	__shared__ real halo[PCG_WAVES][LFA_HALO_CELLS];
+	if (state[0] >= 0) return;
+	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	for (int slot = blockIdx.x * PCG_WAVES + wid; slot < L.n_tiles; slot += gridDim.x * PCG_WAVES)
+		residual_restrict_tile<real>(L, gc, b_coarse, slot, halo[wid], lane);
+}
+
+/// LEVEL0: the result is scaled by 1/scale and dot(z, r) is formed.
+template <typename real, bool LEVEL0>
+__global__ void __launch_bounds__(256)
+k_mg_prolong_postsmooth(MgLv<real> L, GridDims gc, const real *e, real inv_scale, double *part_sigma, const int *state) {
+	__shared__ real halo[PCG_WAVES][LFA_HALO_CELLS];
+	__shared__ double red[4];
+	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
+	real *h = halo[wid];
+	double acc = 0.0;
+	if (state[0] < 0) {
+		for (int slot = blockIdx.x * PCG_WAVES + wid; slot < L.n_tiles; slot += gridDim.x * PCG_WAVES) {
+			real bb[8];
+			prolong_postsmooth_tile<real>(L, gc, e, slot, h, lane, bb);
+			const size_t base = (size_t)L.tiles[slot] * 512;
+#pragma unroll
+			for (int zz = 0; zz < 8; ++zz) {
+				const real v = h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)];
+				if (LEVEL0) {
+					const real zv = v * inv_scale;
+					L.y[base + zz * 64 + lane] = zv;
+					acc += (double)zv * (double)bb[zz];
+				} else {
+					L.y[base + zz * 64 + lane] = v;
+				}
+			}
+		}
+	}
+	if (LEVEL0) {
+		acc = wave_sum(acc);
+		if (lane == 0) red[wid] = acc;
+		__syncthreads();
+		if (threadIdx.x == 0) part_sigma[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+	}
+}
+
+/// The small levels in ONE workgroup of 16 waves: down from level `first` to the single-tile level, the coarsest solve,
+/// and up again to `first`, with a workgroup barrier between the phases (their data sits in L2).
+#define MG_TAIL_WAVES 16
+template <typename real> struct MgTail {
+	MgLv<real> lv[MG_MAX_LEVELS];
+	int first, last, nsw;
+};
+template <typename real>
+__global__ void __launch_bounds__(MG_TAIL_WAVES * 64) k_mg_tail(MgTail<real> T, const int *state) {
+	__shared__ real halo[MG_TAIL_WAVES][LFA_HALO_CELLS];
+	if (state[0] >= 0) return;
+	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
+	real *h = halo[wid];
+	for (int l = T.first; l < T.last; ++l) {
+		const MgLv<real> &L = T.lv[l];
+		for (int i = lane; i < LFA_HALO_CELLS; i += 64) h[i] = (real)0;
+		for (int slot = wid; slot < L.n_tiles; slot += MG_TAIL_WAVES) presmooth_tile<real>(L, slot, h, lane);
+		__syncthreads();
+		for (int slot = wid; slot < L.n_tiles; slot += MG_TAIL_WAVES) residual_restrict_tile<real>(L, T.lv[l + 1].g, T.lv[l + 1].b, slot, h, lane);
+		__syncthreads();
+	}
+	if (wid == 0) {
+		for (int i = lane; i < LFA_HALO_CELLS; i += 64) h[i] = (real)0;
+		coarsest_tile<real>(T.lv[T.last], T.nsw, h, lane);
+	}
+	__syncthreads();
+	for (int l = T.last - 1; l >= T.first; --l) {
+		const MgLv<real> &L = T.lv[l];
+		for (int slot = wid; slot < L.n_tiles; slot += MG_TAIL_WAVES) {
+			real bb[8];
+			prolong_postsmooth_tile<real>(L, T.lv[l + 1].g, T.lv[l + 1].y, slot, h, lane, bb);
+			const size_t base = (size_t)L.tiles[slot] * 512;
+#pragma unroll
+			for (int zz = 0; zz < 8; ++zz) L.y[base + zz * 64 + lane] = h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)];
+		}
+		__syncthreads();
+	}
+}
+
+int mg_grid(int n_tiles) { return pcg_grid(n_tiles); }
+}  // namespace
+
+// ================================================================================================= host side
+void lfa_mg_free(lfa_sim *s) {
+	if (!s->mg) return;
+	for (auto &L : s->mg->lv) {
+		void *ptrs[] = {L.tiles, L.nbr, L.ctype, L.abits, L.x, L.b, L.y};
+		for (void *p : ptrs)
+			if (p) (void)hipFree(p);
+	}
+	delete s->mg;
+	s->mg = nullptr;
+}
+
+/// Builds the hierarchy for the current unknown set (after lfa_build_rhs: A bytes and types of the step are on the device).
+template <typename real> static int mg_setup_t(lfa_sim *s) {
+	if (!s->mg) s->mg = new lfa_mg();
+	lfa_mg &M = *s->mg;
+	// level grids: halve until one tile holds the whole level
+	std::vector<GridDims> gs{s->g};
+	while ((gs.back().nx > 8 || gs.back().ny > 8 || gs.back().nz > 8) && (int)gs.size() < MG_MAX_LEVELS) {
+		GridDims c, f = gs.back();
+		c.nx = (f.nx + 1) / 2; c.ny = (f.ny + 1) / 2; c.nz = (f.nz + 1) / 2;
+		c.ntx = (c.nx + 7) / 8; c.nty = (c.ny + 7) / 8; c.ntz = (c.nz + 7) / 8;
+		c.nt = c.ntx * c.nty * c.ntz;
+		gs.push_back(c);
+	}
+	const int nl = (int)gs.size();
+	const bool realloc_all = M.n_levels != nl || M.elem != sizeof(real) || (nl > 1 && (M.lv[1].g.nx != gs[1].nx || M.lv[1].g.ny != gs[1].ny || M.lv[1].g.nz != gs[1].nz));
+	if (realloc_all) {
+		LFA_HIP(s, hipStreamSynchronize(s->stream));
+		for (auto &L : M.lv) {
+			void *ptrs[] = {L.tiles, L.nbr, L.ctype, L.abits, L.x, L.b, L.y};
+			for (void *p : ptrs)
+				if (p) LFA_HIP(s, hipFree(p));
+			L = lfa_mg_level();
+		}
+		M.n_levels = nl;
+		M.elem = sizeof(real);
+		for (int l = 0; l < nl; ++l) {
+			lfa_mg_level &L = M.lv[l];
+			L.g = gs[l];
+			L.ncp = (size_t)gs[l].nt * 512;
+			if (l == 0) continue;
+			LFA_HIP(s, hipMalloc(&L.ctype, L.ncp));
+			LFA_HIP(s, hipMalloc(&L.abits, L.ncp));
+			LFA_HIP(s, hipMalloc(&L.x, L.ncp * sizeof(real)));
+			LFA_HIP(s, hipMalloc(&L.b, L.ncp * sizeof(real)));
+			LFA_HIP(s, hipMalloc(&L.y, L.ncp * sizeof(real)));
+		}
+	}
+	// active tiles per level on the host: a tile is active if one of its child tiles is
+	std::vector<int> tiles(s->n_ptiles);
+	LFA_HIP(s, hipMemcpyAsync(tiles.data(), s->ptiles, (size_t)s->n_ptiles * 4, hipMemcpyDeviceToHost, s->stream));
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	std::vector<std::vector<int>> act(nl);
+	act[0] = tiles;
+	for (int l = 1; l < nl; ++l) {
+		const GridDims &f = gs[l - 1], &c = gs[l];
+		std::vector<int> &o = act[l];
+		o.reserve(act[l - 1].size() / 4 + 8);
+		for (int t : act[l - 1]) {
+			int tx, ty, tz;
+			tile_coords(f, t, tx, ty, tz);
+			o.push_back((tx >> 1) + c.ntx * ((ty >> 1) + c.nty * (tz >> 1)));
+		}
+		std::sort(o.begin(), o.end());
+		o.erase(std::unique(o.begin(), o.end()), o.end());
+	}
+	for (int l = 0; l < nl; ++l) {
+		lfa_mg_level &L = M.lv[l];
+		const GridDims &g = gs[l];
+		const std::vector<int> &a = act[l];
+		L.n_tiles = (int)a.size();
+		if (a.size() > L.cap_tiles) {
+			if (L.tiles) LFA_HIP(s, hipFree(L.tiles));
+			if (L.nbr) LFA_HIP(s, hipFree(L.nbr));
+			L.tiles = L.nbr = nullptr;
+			L.cap_tiles = a.size() + a.size() / 4 + 16;
+			LFA_HIP(s, hipMalloc(&L.tiles, L.cap_tiles * 4));
+			LFA_HIP(s, hipMalloc(&L.nbr, L.cap_tiles * MG_NBR_STRIDE * 4));
+		}
+		if (a.empty()) continue;
+		std::unordered_map<int, int> slot;
+		slot.reserve(a.size() * 2);
+		for (size_t i = 0; i < a.size(); ++i) slot[a[i]] = (int)i;
+		std::vector<int> nbr(a.size() * MG_NBR_STRIDE, 0);
+		const int sy = g.ntx, sz = g.ntx * g.nty;
+		for (size_t i = 0; i < a.size(); ++i) {
+			int tx, ty, tz;
+			tile_coords(g, a[i], tx, ty, tz);
+			const int cand[6] = {tx > 0 ? a[i] - 1 : -1,           tx + 1 < g.ntx ? a[i] + 1 : -1, ty > 0 ? a[i] - sy : -1,
+			                     ty + 1 < g.nty ? a[i] + sy : -1, tz > 0 ? a[i] - sz : -1,          tz + 1 < g.ntz ? a[i] + sz : -1};
+			for (int k = 0; k < 6; ++k) nbr[i * MG_NBR_STRIDE + k] = (cand[k] >= 0 && slot.count(cand[k])) ? cand[k] : -1;
+			nbr[i * MG_NBR_STRIDE + 6] = a[i];
+		}
+		LFA_HIP(s, hipMemcpyAsync(L.tiles, a.data(), a.size() * 4, hipMemcpyHostToDevice, s->stream));
+		LFA_HIP(s, hipMemcpyAsync(L.nbr, nbr.data(), nbr.size() * 4, hipMemcpyHostToDevice, s->stream));
+		LFA_HIP(s, hipStreamSynchronize(s->stream));  // the host vectors go out of scope
+	}
+	// types and operators of the coarse levels
+	for (int l = 1; l < nl; ++l) {
+		lfa_mg_level &L = M.lv[l];
+		const unsigned grid = (unsigned)((L.ncp + 255) / 256);
+		if (l == 1)
+			hipLaunchKernelGGL(k_mg_types_from_fine, dim3(grid), dim3(256), 0, s->stream, gs[0], gs[1], L.ncp, (const uint32_t *)s->tile_flag,
+			                   (const uint32_t *)s->cell_count, (const uint8_t *)s->ctype, (const uint8_t *)s->solid, L.ctype);
+		else
+			hipLaunchKernelGGL(k_mg_types_coarsen, dim3(grid), dim3(256), 0, s->stream, gs[l - 1], gs[l], L.ncp,
+			                   (const uint8_t *)M.lv[l - 1].ctype, L.ctype);
+		LFA_LAUNCH_CHECK(s);
+		// vectors of levels >= 1 are read where no tile of this solve writes (parents of ring cells): start from zero
+		LFA_HIP(s, hipMemsetAsync(L.x, 0, L.ncp * sizeof(real), s->stream));
+		LFA_HIP(s, hipMemsetAsync(L.b, 0, L.ncp * sizeof(real), s->stream));
+		LFA_HIP(s, hipMemsetAsync(L.y, 0, L.ncp * sizeof(real), s->stream));
+		LFA_HIP(s, hipMemsetAsync(L.abits, 0, L.ncp, s->stream));
+		if (L.n_tiles) {
+			hipLaunchKernelGGL(k_mg_abits, dim3(std::min(L.n_tiles, 4096)), dim3(256), 0, s->stream, (const int *)L.tiles, L.n_tiles, gs[l],
+			                   (const uint8_t *)L.ctype, L.abits);
+			LFA_LAUNCH_CHECK(s);
+		}
+	}
+	return LFA_OK;
+}
+
+int lfa_mg_setup(lfa_sim *s) {
+	return s->prm.pcg_dtype == LFA_PCG_F64 ? mg_setup_t<double>(s) : mg_setup_t<float>(s);
+}
+
+/// z = V(r) / scale and the partial sums of dot(z, r) (pcg_grid(n_ptiles) of them) into part_sigma.
+/// Level 0 uses the solver's own vectors: b = r (vr), pre-smoothed iterate in vq (free between the AXPYs and the next
+/// A s), result in vz. `level0_presmoothed`: vq already holds the pre-smoothed iterate (k_mg_axpy_presmooth).
+#define MG_TAIL_TILES 64  // levels with at most this many tiles run inside k_mg_tail
+#define MG_COARSEST_SWEEPS 4
+enum { MG_PART_PRE0 = 1, MG_PART_DOWN0 = 2, MG_PART_COARSE = 4, MG_PART_UP0 = 8, MG_PART_ALL = 15 };
+template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, bool level0_presmoothed, int parts = MG_PART_ALL) {
+	lfa_mg &M = *s->mg;
+	const int nl = M.n_levels, last = nl - 1;  // every level down to the single-tile one has active tiles
+	auto lvl = [&](int l) {
+		const lfa_mg_level &L = M.lv[l];
+		return MgLv<real>{L.tiles, L.nbr, L.n_tiles, L.g, l == 0 ? (const uint8_t *)s->abits : (const uint8_t *)L.abits,
+		                  l == 0 ? (real *)s->vr : (real *)L.b, l == 0 ? (real *)s->vq : (real *)L.x, l == 0 ? (real *)s->vz : (real *)L.y};
+	};
+	const real inv_scale = (real)(1.0 / s->a_scale);
+	const int *st = (const int *)s->pcg_state;
+	if (last == 0) {  // a single level: the two sweeps alone
+		const MgLv<real> L = lvl(0);
+		if (!level0_presmoothed) hipLaunchKernelGGL(k_mg_presmooth<real>, dim3(1), dim3(256), 0, s->stream, L, st);
+		hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true>), dim3(1), dim3(256), 0, s->stream, L, L.g, (const real *)nullptr,
+		                   inv_scale, part_sigma, st);
+		LFA_LAUNCH_CHECK(s);
+		return LFA_OK;
+	}
+	int tail = last;  // first level handled by the single-workgroup tail
+	while (tail > 1 && M.lv[tail - 1].n_tiles <= MG_TAIL_TILES) --tail;
+	for (int l = 0; l < tail; ++l) {
+		const MgLv<real> L = lvl(l);
+		const int G = mg_grid(L.n_tiles);
+		if (!(l == 0 && level0_presmoothed) && (parts & (l == 0 ? MG_PART_PRE0 : MG_PART_COARSE)))
+			hipLaunchKernelGGL(k_mg_presmooth<real>, dim3(G), dim3(256), 0, s->stream, L, st);
+		if (parts & (l == 0 ? MG_PART_DOWN0 : MG_PART_COARSE))
+			hipLaunchKernelGGL(k_mg_residual_restrict<real>, dim3(G), dim3(256), 0, s->stream, L, M.lv[l + 1].g, (real *)M.lv[l + 1].b, st);
+		LFA_LAUNCH_CHECK(s);
+	}
+	if (parts & MG_PART_COARSE) {
+		MgTail<real> T;
+		for (int l = tail; l <= last; ++l) T.lv[l] = lvl(l);
+		T.first = tail;
+		T.last = last;
+		T.nsw = MG_COARSEST_SWEEPS;
+		if (const char *e = getenv("LFA_MG_NSW")) T.nsw = std::max(1, atoi(e));
+		hipLaunchKernelGGL(k_mg_tail<real>, dim3(1), dim3(MG_TAIL_WAVES * 64), 0, s->stream, T, st);
+		LFA_LAUNCH_CHECK(s);
+	}
+	for (int l = tail - 1; l >= 0; --l) {
+		const MgLv<real> L = lvl(l);
+		const int G = mg_grid(L.n_tiles);
+		if (!(parts & (l == 0 ? MG_PART_UP0 : MG_PART_COARSE))) continue;
+		if (l == 0)
+			hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true>), dim3(G), dim3(256), 0, s->stream, L, M.lv[1].g,
+			                   (const real *)M.lv[1].y, inv_scale, part_sigma, st);
+		else
+			hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, false>), dim3(G), dim3(256), 0, s->stream, L, M.lv[l + 1].g,
+			                   (const real *)M.lv[l + 1].y, (real)1, (double *)nullptr, st);
+		LFA_LAUNCH_CHECK(s);
+	}
+	return LFA_OK;
+}
+
+int lfa_mg_apply(lfa_sim *s, double *part_sigma) {
+	return s->prm.pcg_dtype == LFA_PCG_F64 ? mg_apply_t<double>(s, part_sigma, false) : mg_apply_t<float>(s, part_sigma, false);
+}
+
+/// One PCG iteration's AXPYs + V-cycle: p += alpha s, r -= alpha q (alpha = sigma / (q.s) from the partials), signed max r
+/// into part_rmax, z = V(r) / scale, partials of dot(z, r) into part_sigma_new. `sdir` = current search direction.
+template <typename real>
+static int mg_axpy_apply_t(lfa_sim *s, const void *sdir, const double *part_sigma, int n_sigma, const double *part_qs, int n_qs,
+                           double *part_rmax, double *part_sigma_new) {
+	const int G = mg_grid(s->n_ptiles);
+	hipLaunchKernelGGL(k_mg_axpy_presmooth<real>, dim3(G), dim3(256), 0, s->stream, (const int *)s->ptiles, s->n_ptiles,
+	                   (const uint8_t *)s->abits, (real *)s->vp, (const real *)sdir, (real *)s->vr, (real *)s->vq, part_sigma, n_sigma,
+	                   part_qs, n_qs, part_rmax, (const int *)s->pcg_state);
+	LFA_LAUNCH_CHECK(s);
+	return mg_apply_t<real>(s, part_sigma_new, true);
+}
+int lfa_mg_axpy_apply(lfa_sim *s, const void *sdir, const double *part_sigma, int n_sigma, const double *part_qs, int n_qs,
+                      double *part_rmax, double *part_sigma_new) {
+	return s->prm.pcg_dtype == LFA_PCG_F64
+	           ? mg_axpy_apply_t<double>(s, sdir, part_sigma, n_sigma, part_qs, n_qs, part_rmax, part_sigma_new)
+	           : mg_axpy_apply_t<float>(s, sdir, part_sigma, n_sigma, part_qs, n_qs, part_rmax, part_sigma_new);
+}
+
+/// For lfa_bench_kernel: one part of an iteration on the state left by the last solve. 0: AXPYs + level-0 pre-smoothing,
+/// 1: level-0 residual + restriction, 2: all coarser levels (down, single-workgroup tail, up), 3: level-0 prolongation +
+/// post-smoothing + dot.
+int lfa_mg_bench_part(lfa_sim *s, int part) {
+	if (!s->mg || !s->mg->n_levels || !s->n_ptiles) return lfa_fail(s, LFA_E_INVALID, "multigrid bench: solve with LFA_PRECOND_MULTIGRID first");
+	const bool f64 = s->prm.pcg_dtype == LFA_PCG_F64;
+	double *P = s->partials;
+	const int G = mg_grid(s->n_ptiles);
+	if (part == 0) {
+		if (f64) hipLaunchKernelGGL(k_mg_axpy_presmooth<double>, dim3(G), dim3(256), 0, s->stream, (const int *)s->ptiles, s->n_ptiles, (const uint8_t *)s->abits, (double *)s->vp, (const double *)s->vs, (double *)s->vr, (double *)s->vq, P + PART_SIG0, G, P + PART_ZS, G, P + PART_RMAX, (const int *)s->pcg_state);
+		else hipLaunchKernelGGL(k_mg_axpy_presmooth<float>, dim3(G), dim3(256), 0, s->stream, (const int *)s->ptiles, s->n_ptiles, (const uint8_t *)s->abits, (float *)s->vp, (const float *)s->vs, (float *)s->vr, (float *)s->vq, P + PART_SIG0, G, P + PART_ZS, G, P + PART_RMAX, (const int *)s->pcg_state);
+		LFA_LAUNCH_CHECK(s);
+		return LFA_OK;
+	}
+	const int parts = part == 1 ? MG_PART_DOWN0 : (part == 2 ? MG_PART_COARSE : MG_PART_UP0);
+	return f64 ? mg_apply_t<double>(s, P + PART_SIG1, true, parts) : mg_apply_t<float>(s, P + PART_SIG1, true, parts);
+}

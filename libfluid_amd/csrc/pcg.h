@@ -19,3 +19,12 @@ static inline int pcg_grid(int n_ptiles) {
 int lfa_build_rhs(lfa_sim *s, double dt);
 int lfa_p2g_run(lfa_sim *s, bool fuse_gravity, double dt);
 int lfa_dist_refresh_grid(lfa_sim *s, bool with_topology);
+
+// multigrid preconditioner (mg.hip)
+int lfa_mg_setup(lfa_sim *s);                       // hierarchy for the current unknown set (after lfa_build_rhs)
+int lfa_mg_apply(lfa_sim *s, double *part_sigma);   // vz = V(vr) / scale (vq is scratch), partials of dot(z, r)
+// the AXPYs of a PCG iteration fused with the pre-smoothing of the finest level, then the rest of the V-cycle
+int lfa_mg_axpy_apply(lfa_sim *s, const void *sdir, const double *part_sigma, int n_sigma, const double *part_qs, int n_qs,
+                      double *part_rmax, double *part_sigma_new);
+int lfa_mg_bench_part(lfa_sim *s, int part);
+void lfa_mg_free(lfa_sim *s);

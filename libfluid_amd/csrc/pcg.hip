@@ -1351,6 +1351,7 @@ static int build_levels(lfa_sim *s) {
 
 // ---- multilevel preconditioner: host-side set-up -----------------------------------------------------------
 static bool is_ml(const lfa_sim *s) { return s->prm.precond == LFA_PRECOND_MULTILEVEL; }
+static bool is_mg(const lfa_sim *s) { return s->prm.precond == LFA_PRECOND_MULTIGRID; }
 /// number of partial sums the consumers of sigma add up: one per workgroup (+1 for the coarse part of z.r)
 static int sigma_parts(const lfa_sim *s) { return pcg_grid(s->n_ptiles) + (is_ml(s) ? 1 : 0); }
 
@@ -1551,11 +1552,15 @@ template <typename real> static int mic_factor(lfa_sim *s) {
 			LFA_LAUNCH_CHECK(s);
 		}
 	} else {
-		hipLaunchKernelGGL((k_mic_factor<real, false>), dim3(pcg_grid(s->n_ptiles)), dim3(256), 0, s->stream, tc,
-		                   (const int *)nullptr, s->n_ptiles, s->abits, (real *)s->vpre, scale, tau, sigma);
-		LFA_LAUNCH_CHECK(s);
+		if (is_mg(s)) {
+			LFA_TRY(lfa_mg_setup(s));  // no factorisation: the smoother needs the A bytes only
+		} else {
+			hipLaunchKernelGGL((k_mic_factor<real, false>), dim3(pcg_grid(s->n_ptiles)), dim3(256), 0, s->stream, tc,
+			                   (const int *)nullptr, s->n_ptiles, s->abits, (real *)s->vpre, scale, tau, sigma);
+			LFA_LAUNCH_CHECK(s);
+		}
 		if (is_ml(s)) LFA_TRY(coarse_setup<real>(s));
-		if (s->prm.pcg_fused && s->n_ptiles) {
+		if ((s->prm.pcg_fused || is_mg(s)) && s->n_ptiles) {
 			if (!s->nbr_table) LFA_HIP(s, hipMalloc(&s->nbr_table, (size_t)s->g.nt * NBR_STRIDE * sizeof(int)));
 			hipLaunchKernelGGL(k_build_nbr_table, dim3((s->n_ptiles + 255) / 256), dim3(256), 0, s->stream, tc, s->p_off,
 			                   is_ml(s) ? (const int *)s->slot_l1 : (const int *)nullptr, (const int *)s->l1_l2, s->nbr_table);
@@ -1568,6 +1573,7 @@ template <typename real> static int mic_factor(lfa_sim *s) {
 /// z = M^-1 r and partial dot(z, r) into part_sigma. `r1_ready`: the restricted residual was already written (by
 /// k_axpy_max), so the coarse levels are forked onto the side stream and overlap the fine sweep.
 template <typename real> static int mic_apply(lfa_sim *s, double *part_sigma, bool r1_ready = false) {
+	if (is_mg(s)) return lfa_mg_apply(s, part_sigma);
 	TileCtx tc = make_ctx(s);
 	Vecs<real> v = make_vecs<real>(s);
 	const real scale = (real)s->a_scale;
@@ -1659,6 +1665,8 @@ static void fused_grids(int G, int &GA, int &GB) {
 template <typename real> static int solve_t(lfa_sim *s, double dt, double *residual, uint64_t *iterations) {
 	if (s->dist && s->prm.precond == LFA_PRECOND_MIC0_EXACT)
 		return lfa_fail(s, LFA_E_UNSUPPORTED, "the exact (hyperplane) MIC(0) schedule is single-GPU only");
+	if (s->dist && is_mg(s))
+		return lfa_fail(s, LFA_E_UNSUPPORTED, "the multigrid preconditioner is single-GPU only (use LFA_PRECOND_MULTILEVEL with slabs)");
 	LFA_TRY(build_system_t<real>(s, dt));
 	if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[18], s->stream));
 	s->last_residual = 0.0;
@@ -1704,9 +1712,31 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 	const int chunk = 8;
 	int done = -1, nan = 0, i = 0;
 	int *hstate = (int *)s->h_pinned;
+	// multigrid: k_pcg_a (search direction + A s), the AXPYs, then the V-cycle (mg.hip) on the new residual
+	real *sbuf_mg[2] = {(real *)s->vs, (real *)s->vs2};
+	while (is_mg(s) && i < maxit && done < 0) {
+		const int end = std::min(maxit, i + chunk);
+		for (; i < end; ++i) {
+			const int po = i & 1, pn = po ^ 1;
+			const double *sig_po = P + (po ? PART_SIG1 : PART_SIG0), *sig_pn = P + (pn ? PART_SIG1 : PART_SIG0);
+			launch_pcg_a<real>(i == 0, false, G, s->stream, s->n_ptiles, (const int *)s->nbr_table, (const uint8_t *)s->abits,
+			                   (const real *)v.z, (const real *)sbuf_mg[po], sbuf_mg[pn], v.q, scale, sig_po, G, sig_pn, G,
+			                   (const double *)(P + PART_RMAX), G, s->prm.tolerance, i, s->pcg_state, s->pcg_hist, P + PART_ZS,
+			                   (const real *)nullptr, (const real *)nullptr, (real *)nullptr);
+			LFA_LAUNCH_CHECK(s);
+			LFA_TRY(lfa_mg_axpy_apply(s, sbuf_mg[pn], sig_po, G, P + PART_ZS, G, P + PART_RMAX, P + (pn ? PART_SIG1 : PART_SIG0)));
+		}
+		hipLaunchKernelGGL(k_check_converged, dim3(1), dim3(256), 0, s->stream, P + PART_RMAX, G, s->prm.tolerance, i - 1,
+		                   s->pcg_state, s->pcg_hist);
+		LFA_LAUNCH_CHECK(s);
+		LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 8, hipMemcpyDeviceToHost, s->stream));
+		LFA_HIP(s, hipStreamSynchronize(s->stream));
+		done = hstate[0];
+		nan = hstate[1];
+	}
 	// fused iteration (k_pcg_a / k_pcg_b): tile-local MIC(0) with or without the coarse levels, single domain or slabs
-	const bool fused = s->prm.pcg_fused && s->prm.precond != LFA_PRECOND_MIC0_EXACT && (s->n_ptiles == 0 || s->nbr_table);
-	if (!fused) {
+	const bool fused = !is_mg(s) && s->prm.pcg_fused && s->prm.precond != LFA_PRECOND_MIC0_EXACT && (s->n_ptiles == 0 || s->nbr_table);
+	if (!fused && !is_mg(s)) {
 		hipLaunchKernelGGL(k_update_s<real>, dim3(G), dim3(256), 0, s->stream, tc, v, sig_src(0), sig_src(0), n_sig, 1,
 		                   s->pcg_state, s->abits, cx, (const int *)s->slot_l1, (const real *)s->c_x2, (const int *)s->l1_l2);
 		LFA_LAUNCH_CHECK(s);
@@ -1789,7 +1819,7 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 		done = hstate[0];
 		nan = hstate[1];
 	}
-	while (!fused && i < maxit && done < 0) {
+	while (!fused && !is_mg(s) && i < maxit && done < 0) {
 		const int end = std::min(maxit, i + chunk);
 		for (; i < end; ++i) {
 			const int po = i & 1, pn = po ^ 1;
@@ -2020,10 +2050,10 @@ template <typename real> static int bench_launch(lfa_sim *s, int which) {
 		if (!is_ml(s)) return lfa_fail(s, LFA_E_INVALID, "no coarse levels with this preconditioner");
 		return coarse_apply<real>(s, P + PART_SIG1, s->stream);
 	case LFA_K_PCG_A:
-		if (!s->nbr_table || !s->prm.pcg_fused) return lfa_fail(s, LFA_E_INVALID, "fused kernels: solve with pcg_fused = 1 first");
-		launch_pcg_a<real>(false, is_ml(s), GA, s->stream, s->n_ptiles, (const int *)s->nbr_table, (const uint8_t *)s->abits,
+		if (!s->nbr_table || !(s->prm.pcg_fused || is_mg(s))) return lfa_fail(s, LFA_E_INVALID, "fused kernels: solve with pcg_fused = 1 first");
+		launch_pcg_a<real>(false, is_ml(s), is_mg(s) ? G : GA, s->stream, s->n_ptiles, (const int *)s->nbr_table, (const uint8_t *)s->abits,
 		                   (const real *)v.z, (const real *)v.s, (real *)s->vs2, v.q, scale, (const double *)(P + PART_SIG0), G,
-		                   (const double *)(P + PART_SIG0), G, (const double *)(P + PART_RMAX), G, -1.0, 1, s->pcg_state,
+		                   (const double *)(P + PART_SIG0), G, (const double *)(P + PART_RMAX), G, -HUGE_VAL, 1, s->pcg_state,
 		                   s->pcg_hist + 4095, P + PART_ZS, is_ml(s) ? (const real *)s->c_x : (const real *)nullptr,
 		                   (const real *)s->c_x2, is_ml(s) ? (real *)s->c_as : (real *)nullptr);
 		break;
@@ -2045,6 +2075,10 @@ template <typename real> static int bench_launch(lfa_sim *s, int which) {
 		}
 		break;
 	}
+	case LFA_K_MG_AXPY_PRESMOOTH: return lfa_mg_bench_part(s, 0);
+	case LFA_K_MG_DOWN0: return lfa_mg_bench_part(s, 1);
+	case LFA_K_MG_COARSE: return lfa_mg_bench_part(s, 2);
+	case LFA_K_MG_UP0: return lfa_mg_bench_part(s, 3);
 	case LFA_K_UPDATE_S:
 		hipLaunchKernelGGL(k_update_s<real>, dim3(G), dim3(256), 0, s->stream, tc, v, P + PART_SIG0, P + PART_SIG0, G, 0,
 		                   s->pcg_state, s->abits, is_ml(s) ? (const real *)s->c_x : (const real *)nullptr,
@@ -2065,7 +2099,7 @@ extern "C" int lfa_bench_kernel(lfa_sim *s, int which, int reps, double *mean_ms
 		s->ev_created = true;
 	}
 	const bool is_pcg = which <= LFA_K_UPDATE_S || which == LFA_K_MIC_FINE || which == LFA_K_COARSE ||
-	                    which == LFA_K_PCG_A || which == LFA_K_PCG_B;
+	                    which == LFA_K_PCG_A || which == LFA_K_PCG_B || (which >= LFA_K_MG_AXPY_PRESMOOTH && which <= LFA_K_MG_UP0);
 	if (is_pcg) {
 		if (!s->system_valid) return lfa_fail(s, LFA_E_INVALID, "lfa_bench_kernel: no pressure system on the device");
 		int init_state[2] = {-1, 0};  // "still iterating": the kernels early-out once a solve has converged

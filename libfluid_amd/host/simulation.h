@@ -236,7 +236,7 @@ namespace fluid_amd {
 		// -- device-path selectors (not in the reference) and status
 		int device = -1;                            ///< HIP device (-1: current); takes effect at resize()
 		bool device_resident_steps = true;          ///< run whole steps on the device when no source/callback needs the host
-		int p2g_variant = LFA_P2G_LDS_BINNED, precond = LFA_PRECOND_MULTILEVEL, pcg_dtype = LFA_PCG_F32;
+		int p2g_variant = LFA_P2G_LDS_BINNED, precond = LFA_PRECOND_MULTIGRID, pcg_dtype = LFA_PCG_F32;
 		double pcg_tau = 0.97, pcg_sigma = 0.25, pcg_tolerance = 1e-6;   ///< pressure_solver.h:39-41
 		std::size_t pcg_max_iterations = 200;                             ///< pressure_solver.h:42
 		int last_status() const { return _status; }

@@ -108,7 +108,7 @@ def test_pcg_exact_schedule_matches_reference_iterations(name):
 
 
 @pytest.mark.parametrize("dtype", [lfa.PCG_F32, lfa.PCG_F64])
-@pytest.mark.parametrize("precond", [lfa.PRECOND_MIC0_TILED, lfa.PRECOND_MIC0_EXACT, lfa.PRECOND_MULTILEVEL])
+@pytest.mark.parametrize("precond", [lfa.PRECOND_MIC0_TILED, lfa.PRECOND_MIC0_EXACT, lfa.PRECOND_MULTILEVEL, lfa.PRECOND_MULTIGRID])
 @pytest.mark.parametrize("name", ["apic16_solid", "flip16", "pic_ragged", "apic_tank"])
 def test_pcg_pressure_within_tolerance(name, precond, dtype):
     c, parts, solid, s = make_gpu(name, precond=precond, pcg_dtype=dtype)
@@ -147,7 +147,7 @@ def test_apply_pressure_extrapolate_g2p(name):
 
 
 @pytest.mark.parametrize("precond,dtype", [(lfa.PRECOND_MIC0_EXACT, lfa.PCG_F64), (lfa.PRECOND_MIC0_TILED, lfa.PCG_F32),
-                                           (lfa.PRECOND_MULTILEVEL, lfa.PCG_F32)])
+                                           (lfa.PRECOND_MULTILEVEL, lfa.PCG_F32), (lfa.PRECOND_MULTIGRID, lfa.PCG_F32)])
 @pytest.mark.parametrize("name", sorted(util.CASES))
 def test_two_hot_steps_end_to_end(name, precond, dtype):
     """Two full passes of the hot path, staged exactly like the golden run, against the reference's final state."""
@@ -221,6 +221,47 @@ def test_multilevel_preconditioner_is_symmetric_and_cuts_iterations(dtype):
     _, _, it_tiled, _ = s.solve(util.DT)
     assert it_ml <= it_tiled
     s.close()
+
+
+@pytest.mark.parametrize("dtype", [lfa.PCG_F32, lfa.PCG_F64])
+@pytest.mark.parametrize("name", ["apic_ragged", "apic16_solid", "apic_tank"])
+def test_multigrid_preconditioner_is_symmetric_positive_definite(name, dtype):
+    """The V-cycle (down: red->black from zero, up: black->red) must be a symmetric positive definite operator."""
+    c, parts, solid, s = make_gpu(name, precond=lfa.PRECOND_MULTIGRID, pcg_dtype=dtype)
+    g = util.load_golden(name)
+    s.hash()
+    s.upload_cells(cells_from(g["grav_vel0"], g["p2g_type0"]))
+    s.build_system(util.DT)
+    n = len(g["b0"])
+    rng = np.random.default_rng(11)
+    x, y = rng.normal(size=n), rng.normal(size=n)
+    mx, my = s.apply_precon(x), s.apply_precon(y)
+    assert abs(y @ mx - x @ my) <= (2e-5 if dtype == lfa.PCG_F32 else 1e-11) * (abs(y @ mx) + np.linalg.norm(x) * np.linalg.norm(my))
+    assert x @ mx > 0 and y @ my > 0
+    p, res, it, rc = s.solve(util.DT)
+    assert rc == 0 and res < 1e-6
+    util.assert_close(p, g["p0"], P_REL, "pressure (multigrid)")
+    s.close()
+
+
+def test_multigrid_iteration_count_barely_grows_with_the_grid():
+    """Dam-break blocks of 16^3 ... 64^3 cells at rest: MIC(0) per tile needs several times the iterations when the block
+    doubles twice, the V-cycle a handful more; both converge to the same pressure."""
+    its, pres = {}, {}
+    for n in (16, 32, 64):
+        for precond in (lfa.PRECOND_MULTIGRID, lfa.PRECOND_MIC0_TILED):
+            s = lfa.Sim((2 * n,) * 3, precond=precond, max_iterations=1000)
+            s.seed_block((0, 0, 0), (n, n, n))
+            res, it, rc = s.step_hot(0.01)
+            assert rc == 0
+            its[(n, precond)] = it
+            pres[(n, precond)] = s.pressure()
+            s.close()
+        util.assert_close(pres[(n, lfa.PRECOND_MULTIGRID)], pres[(n, lfa.PRECOND_MIC0_TILED)], P_REL, "pressure")
+    mg = [its[(n, lfa.PRECOND_MULTIGRID)] for n in (16, 32, 64)]
+    tiled = [its[(n, lfa.PRECOND_MIC0_TILED)] for n in (16, 32, 64)]
+    assert max(mg) <= 30 and mg[2] <= mg[0] + 10, (mg, tiled)
+    assert tiled[2] >= 2 * mg[2], (mg, tiled)
 
 
 def test_seed_block_matches_numpy_generator():
