@@ -235,7 +235,12 @@ def main():
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_c4_pmc_traffic.json")
         if cfg_name == "C4" and args.precond in ("multilevel", "multigrid") and args.pcg_dtype == "f32" and os.path.exists(pmc):
-            traffic = json.load(open(pmc))["hbm_bytes_per_launch"].get(dom, {}).get("total")
+            per_launch = json.load(open(pmc))["hbm_bytes_per_launch"]
+            if dom == "bin":  # the binning stage = count + scatter + per-cell histogram launches
+                parts = [per_launch.get(k, {}).get("total") for k in ("bin_count", "bin_scatter", "bin_cells")]
+                traffic = sum(parts) if all(v is not None for v in parts) else None
+            else:
+                traffic = per_launch.get(dom, {}).get("total")
         out["roofline"] = {
             "bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic,

@@ -23,7 +23,6 @@
 #include <stdlib.h>
 
 #include <algorithm>
-#include <unordered_map>
 #include <vector>
 
 #define MG_MAX_LEVELS 12
@@ -46,6 +45,7 @@ struct lfa_mg {
 	int n_levels = 0;
 	lfa_mg_level lv[MG_MAX_LEVELS];
 	size_t elem = 0;
+	std::vector<int> host_tiles;  // particle tiles the tile lists / neighbour tables on the device were built for
 };
 
 namespace {
@@ -529,50 +529,55 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 	std::vector<int> tiles(s->n_ptiles);
 	LFA_HIP(s, hipMemcpyAsync(tiles.data(), s->ptiles, (size_t)s->n_ptiles * 4, hipMemcpyDeviceToHost, s->stream));
 	LFA_HIP(s, hipStreamSynchronize(s->stream));
-	std::vector<std::vector<int>> act(nl);
-	act[0] = tiles;
-	for (int l = 1; l < nl; ++l) {
-		const GridDims &f = gs[l - 1], &c = gs[l];
-		std::vector<int> &o = act[l];
-		o.reserve(act[l - 1].size() / 4 + 8);
-		for (int t : act[l - 1]) {
-			int tx, ty, tz;
-			tile_coords(f, t, tx, ty, tz);
-			o.push_back((tx >> 1) + c.ntx * ((ty >> 1) + c.nty * (tz >> 1)));
+	// The tile structure changes far less often than its contents: when the particle tiles are the ones of the last solve, the
+	// lists and neighbour tables on the device are kept (and no vector can hold values of a tile that has left the set).
+	const bool same_tiles = !realloc_all && tiles == M.host_tiles;
+	if (!same_tiles) {
+		std::vector<std::vector<int>> act(nl);
+		act[0] = tiles;
+		for (int l = 1; l < nl; ++l) {
+			const GridDims &f = gs[l - 1], &c = gs[l];
+			std::vector<int> &o = act[l];
+			o.reserve(act[l - 1].size() / 4 + 8);
+			for (int t : act[l - 1]) {
+				int tx, ty, tz;
+				tile_coords(f, t, tx, ty, tz);
+				o.push_back((tx >> 1) + c.ntx * ((ty >> 1) + c.nty * (tz >> 1)));
+			}
+			std::sort(o.begin(), o.end());
+			o.erase(std::unique(o.begin(), o.end()), o.end());
 		}
-		std::sort(o.begin(), o.end());
-		o.erase(std::unique(o.begin(), o.end()), o.end());
-	}
-	for (int l = 0; l < nl; ++l) {
-		lfa_mg_level &L = M.lv[l];
-		const GridDims &g = gs[l];
-		const std::vector<int> &a = act[l];
-		L.n_tiles = (int)a.size();
-		if (a.size() > L.cap_tiles) {
-			if (L.tiles) LFA_HIP(s, hipFree(L.tiles));
-			if (L.nbr) LFA_HIP(s, hipFree(L.nbr));
-			L.tiles = L.nbr = nullptr;
-			L.cap_tiles = a.size() + a.size() / 4 + 16;
-			LFA_HIP(s, hipMalloc(&L.tiles, L.cap_tiles * 4));
-			LFA_HIP(s, hipMalloc(&L.nbr, L.cap_tiles * MG_NBR_STRIDE * 4));
+		for (int l = 0; l < nl; ++l) {
+			lfa_mg_level &L = M.lv[l];
+			const GridDims &g = gs[l];
+			const std::vector<int> &a = act[l];
+			L.n_tiles = (int)a.size();
+			if (a.size() > L.cap_tiles) {
+				if (L.tiles) LFA_HIP(s, hipFree(L.tiles));
+				if (L.nbr) LFA_HIP(s, hipFree(L.nbr));
+				L.tiles = L.nbr = nullptr;
+				L.cap_tiles = a.size() + a.size() / 4 + 16;
+				LFA_HIP(s, hipMalloc(&L.tiles, L.cap_tiles * 4));
+				LFA_HIP(s, hipMalloc(&L.nbr, L.cap_tiles * MG_NBR_STRIDE * 4));
+			}
+			if (a.empty()) continue;
+			// neighbour tiles by binary search in the sorted list
+			std::vector<int> nbr(a.size() * MG_NBR_STRIDE, 0);
+			const int sy = g.ntx, sz = g.ntx * g.nty;
+			for (size_t i = 0; i < a.size(); ++i) {
+				int tx, ty, tz;
+				tile_coords(g, a[i], tx, ty, tz);
+				const int cand[6] = {tx > 0 ? a[i] - 1 : -1,           tx + 1 < g.ntx ? a[i] + 1 : -1, ty > 0 ? a[i] - sy : -1,
+				                     ty + 1 < g.nty ? a[i] + sy : -1, tz > 0 ? a[i] - sz : -1,          tz + 1 < g.ntz ? a[i] + sz : -1};
+				for (int k = 0; k < 6; ++k)
+					nbr[i * MG_NBR_STRIDE + k] = (cand[k] >= 0 && std::binary_search(a.begin(), a.end(), cand[k])) ? cand[k] : -1;
+				nbr[i * MG_NBR_STRIDE + 6] = a[i];
+			}
+			LFA_HIP(s, hipMemcpyAsync(L.tiles, a.data(), a.size() * 4, hipMemcpyHostToDevice, s->stream));
+			LFA_HIP(s, hipMemcpyAsync(L.nbr, nbr.data(), nbr.size() * 4, hipMemcpyHostToDevice, s->stream));
+			LFA_HIP(s, hipStreamSynchronize(s->stream));  // the host vectors go out of scope
 		}
-		if (a.empty()) continue;
-		std::unordered_map<int, int> slot;
-		slot.reserve(a.size() * 2);
-		for (size_t i = 0; i < a.size(); ++i) slot[a[i]] = (int)i;
-		std::vector<int> nbr(a.size() * MG_NBR_STRIDE, 0);
-		const int sy = g.ntx, sz = g.ntx * g.nty;
-		for (size_t i = 0; i < a.size(); ++i) {
-			int tx, ty, tz;
-			tile_coords(g, a[i], tx, ty, tz);
-			const int cand[6] = {tx > 0 ? a[i] - 1 : -1,           tx + 1 < g.ntx ? a[i] + 1 : -1, ty > 0 ? a[i] - sy : -1,
-			                     ty + 1 < g.nty ? a[i] + sy : -1, tz > 0 ? a[i] - sz : -1,          tz + 1 < g.ntz ? a[i] + sz : -1};
-			for (int k = 0; k < 6; ++k) nbr[i * MG_NBR_STRIDE + k] = (cand[k] >= 0 && slot.count(cand[k])) ? cand[k] : -1;
-			nbr[i * MG_NBR_STRIDE + 6] = a[i];
-		}
-		LFA_HIP(s, hipMemcpyAsync(L.tiles, a.data(), a.size() * 4, hipMemcpyHostToDevice, s->stream));
-		LFA_HIP(s, hipMemcpyAsync(L.nbr, nbr.data(), nbr.size() * 4, hipMemcpyHostToDevice, s->stream));
-		LFA_HIP(s, hipStreamSynchronize(s->stream));  // the host vectors go out of scope
+		M.host_tiles = tiles;
 	}
 	// types and operators of the coarse levels
 	for (int l = 1; l < nl; ++l) {
@@ -585,11 +590,14 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 			hipLaunchKernelGGL(k_mg_types_coarsen, dim3(grid), dim3(256), 0, s->stream, gs[l - 1], gs[l], L.ncp,
 			                   (const uint8_t *)M.lv[l - 1].ctype, L.ctype);
 		LFA_LAUNCH_CHECK(s);
-		// vectors of levels >= 1 are read where no tile of this solve writes (parents of ring cells): start from zero
-		LFA_HIP(s, hipMemsetAsync(L.x, 0, L.ncp * sizeof(real), s->stream));
-		LFA_HIP(s, hipMemsetAsync(L.b, 0, L.ncp * sizeof(real), s->stream));
-		LFA_HIP(s, hipMemsetAsync(L.y, 0, L.ncp * sizeof(real), s->stream));
-		LFA_HIP(s, hipMemsetAsync(L.abits, 0, L.ncp, s->stream));
+		// vectors of levels >= 1 are read where no tile of this solve writes (parents of ring cells): they must be zero there.
+		// Tiles of the current set are rewritten by every V-cycle, so clearing is only needed when the set has changed.
+		if (!same_tiles) {
+			LFA_HIP(s, hipMemsetAsync(L.x, 0, L.ncp * sizeof(real), s->stream));
+			LFA_HIP(s, hipMemsetAsync(L.b, 0, L.ncp * sizeof(real), s->stream));
+			LFA_HIP(s, hipMemsetAsync(L.y, 0, L.ncp * sizeof(real), s->stream));
+			LFA_HIP(s, hipMemsetAsync(L.abits, 0, L.ncp, s->stream));
+		}
 		if (L.n_tiles) {
 			hipLaunchKernelGGL(k_mg_abits, dim3(std::min(L.n_tiles, 4096)), dim3(256), 0, s->stream, (const int *)L.tiles, L.n_tiles, gs[l],
 			                   (const uint8_t *)L.ctype, L.abits);
