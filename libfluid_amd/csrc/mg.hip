@@ -12,9 +12,10 @@
 //               pressure_solver.cpp:22 is applied once, to the result)
 //   transfers : piecewise constant; restriction = sum of the 8 children, halved (the Galerkin operator of piecewise
 //               constant interpolation is twice as stiff as the rediscretised one)
-//   smoother  : red-black Gauss-Seidel inside a tile, Jacobi across tile faces ("hybrid"); one sweep red->black on
-//               the way down from a zero guess (which makes it tile-local: no halo), one sweep black->red on the way up.
-//               The two are adjoint, so the V-cycle is a symmetric positive definite operator (tested).
+//   smoother  : red-black Gauss-Seidel inside a tile, Jacobi across tile faces ("hybrid"); MG_INNER_SWEEPS sweeps
+//               red->black on the way down from a zero guess (which makes them tile-local: no halo), as many black->red
+//               on the way up with the ring values frozen. The two are adjoint, so the V-cycle is a symmetric positive
+//               definite operator (tested).
 // Launches per V-cycle and level: k_mg_presmooth, k_mg_residual_restrict on the way down, k_mg_prolong_postsmooth on the
 // way up; the coarsest level (one tile) is solved by many sweeps inside one wave.
 #include "pcg.h"
@@ -27,6 +28,9 @@
 
 #define MG_MAX_LEVELS 12
 #define MG_NBR_STRIDE 8  // per slot: six face-neighbour tile ids (-1: inactive) + own tile id + pad
+// Sweeps per smoothing step. The values across the tile faces stay frozen during a step, so the extra sweep only touches LDS:
+// no HBM traffic, and a third fewer iterations (C4: 31 -> 19; a third sweep gains little).
+#define MG_INNER_SWEEPS 2
 
 struct lfa_mg_level {
 	GridDims g{};          // cells of this level
@@ -171,17 +175,19 @@ __device__ inline void gs_colour(real *h, const uint32_t (&ab)[8], const real (&
 /// Down, one tile: x = one red->black sweep on A x = b from x = 0 (`h`: ring already zero). With a zero guess the values
 /// across the tile faces do not enter, so the tile is smoothed on its own. Returns nothing; the column ends in `h`.
 template <typename real>
-__device__ inline void presmooth_column(real *h, const uint32_t (&ab)[8], const real (&bb)[8], int lx, int ly) {
+__device__ inline void presmooth_column(real *h, const uint32_t (&ab)[8], const real (&bb)[8], int lx, int ly, int inner) {
 	MG_FENCE();
 #pragma unroll
 	for (int zz = 0; zz < 8; ++zz) h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)] = (real)0;
 	MG_FENCE();
-	gs_colour<real>(h, ab, bb, lx, ly, 0);
-	MG_FENCE();
-	gs_colour<real>(h, ab, bb, lx, ly, 1);
-	MG_FENCE();
+	for (int it = 0; it < inner; ++it) {
+		gs_colour<real>(h, ab, bb, lx, ly, 0);
+		MG_FENCE();
+		gs_colour<real>(h, ab, bb, lx, ly, 1);
+		MG_FENCE();
+	}
 }
-template <typename real> __device__ inline void presmooth_tile(const MgLv<real> &L, int slot, real *h, int lane) {
+template <typename real> __device__ inline void presmooth_tile(const MgLv<real> &L, int slot, real *h, int lane, int inner) {
 	const int lx = lane & 7, ly = lane >> 3;
 	const size_t base = (size_t)L.tiles[slot] * 512;
 	uint32_t ab[8];
@@ -191,7 +197,7 @@ template <typename real> __device__ inline void presmooth_tile(const MgLv<real> 
 		ab[zz] = L.abits[base + zz * 64 + lane];
 		bb[zz] = L.b[base + zz * 64 + lane];
 	}
-	presmooth_column<real>(h, ab, bb, lx, ly);
+	presmooth_column<real>(h, ab, bb, lx, ly, inner);
 #pragma unroll
 	for (int zz = 0; zz < 8; ++zz) L.x[base + zz * 64 + lane] = h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)];
 }
@@ -255,7 +261,7 @@ __device__ inline void residual_restrict_tile(const MgLv<real> &L, const GridDim
 /// the corrected values of the neighbour tiles on the ring; the column ends in `h`, `bb` returns the right-hand side.
 template <typename real>
 __device__ inline void prolong_postsmooth_tile(const MgLv<real> &L, const GridDims &gc, const real *e, int slot, real *h, int lane,
-                                               real (&bb)[8]) {
+                                               real (&bb)[8], int inner) {
 	const int lx = lane & 7, ly = lane >> 3;
 	const int *nt = L.nbr + (size_t)slot * MG_NBR_STRIDE;
 	const int nb[6] = {nt[0], nt[1], nt[2], nt[3], nt[4], nt[5]}, tile = nt[6];
@@ -289,10 +295,12 @@ __device__ inline void prolong_postsmooth_tile(const MgLv<real> &L, const GridDi
 	h[(lx + 1) + 10 * (ly + 1) + 100 * 0] = ring(nb[4], 7 * 64 + lane, tx * 8 + lx, ty * 8 + ly, tz * 8 - 1);
 	h[(lx + 1) + 10 * (ly + 1) + 100 * 9] = ring(nb[5], 0 * 64 + lane, tx * 8 + lx, ty * 8 + ly, tz * 8 + 8);
 	MG_FENCE();
-	gs_colour<real>(h, ab, bb, lx, ly, 1);
-	MG_FENCE();
-	gs_colour<real>(h, ab, bb, lx, ly, 0);
-	MG_FENCE();
+	for (int it = 0; it < inner; ++it) {
+		gs_colour<real>(h, ab, bb, lx, ly, 1);
+		MG_FENCE();
+		gs_colour<real>(h, ab, bb, lx, ly, 0);
+		MG_FENCE();
+	}
 }
 
 /// Coarsest level (a single tile), one wave: NSW red->black sweeps followed by NSW black->red sweeps from zero -- a
@@ -328,7 +336,7 @@ __global__ void __launch_bounds__(256) k_mg_presmooth(MgLv<real> L, const int *s
 	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	real *h = halo[wid];
 	for (int i = lane; i < LFA_HALO_CELLS; i += 64) h[i] = (real)0;  // the ring stays zero
-	for (int slot = blockIdx.x * PCG_WAVES + wid; slot < L.n_tiles; slot += gridDim.x * PCG_WAVES) presmooth_tile<real>(L, slot, h, lane);
+	for (int slot = blockIdx.x * PCG_WAVES + wid; slot < L.n_tiles; slot += gridDim.x * PCG_WAVES) presmooth_tile<real>(L, slot, h, lane, MG_INNER_SWEEPS);
 }
 
 /// The AXPYs of the iteration (k_axpy_max) fused with the pre-smoothing of the finest level: p += alpha s, r -= alpha q,
@@ -373,7 +381,7 @@ k_mg_axpy_presmooth(const int *tiles, int n_tiles, const uint8_t *abits, real *p
 				}
 				bb[zz] = rn;
 			}
-			presmooth_column<real>(h, ab, bb, lx, ly);
+			presmooth_column<real>(h, ab, bb, lx, ly, MG_INNER_SWEEPS);
 #pragma unroll
 			for (int zz = 0; zz < 8; ++zz) q_x[base + zz * 64 + lane] = h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)];
 		}
@@ -411,7 +419,7 @@ k_mg_prolong_postsmooth(MgLv<real> L, GridDims gc, const real *e, real inv_scale
 	if (state[0] < 0) {
 		for (int slot = blockIdx.x * PCG_WAVES + wid; slot < L.n_tiles; slot += gridDim.x * PCG_WAVES) {
 			real bb[8];
-			prolong_postsmooth_tile<real>(L, gc, e, slot, h, lane, bb);
+			prolong_postsmooth_tile<real>(L, gc, e, slot, h, lane, bb, MG_INNER_SWEEPS);
 			const size_t base = (size_t)L.tiles[slot] * 512;
 #pragma unroll
 			for (int zz = 0; zz < 8; ++zz) {
@@ -439,7 +447,7 @@ k_mg_prolong_postsmooth(MgLv<real> L, GridDims gc, const real *e, real inv_scale
 #define MG_TAIL_WAVES 16
 template <typename real> struct MgTail {
 	MgLv<real> lv[MG_MAX_LEVELS];
-	int first, last, nsw;
+	int first, last, nsw, inner;
 };
 template <typename real>
 __global__ void __launch_bounds__(MG_TAIL_WAVES * 64) k_mg_tail(MgTail<real> T, const int *state) {
@@ -450,7 +458,7 @@ __global__ void __launch_bounds__(MG_TAIL_WAVES * 64) k_mg_tail(MgTail<real> T, 
 	for (int l = T.first; l < T.last; ++l) {
 		const MgLv<real> &L = T.lv[l];
 		for (int i = lane; i < LFA_HALO_CELLS; i += 64) h[i] = (real)0;
-		for (int slot = wid; slot < L.n_tiles; slot += MG_TAIL_WAVES) presmooth_tile<real>(L, slot, h, lane);
+		for (int slot = wid; slot < L.n_tiles; slot += MG_TAIL_WAVES) presmooth_tile<real>(L, slot, h, lane, T.inner);
 		__syncthreads();
 		for (int slot = wid; slot < L.n_tiles; slot += MG_TAIL_WAVES) residual_restrict_tile<real>(L, T.lv[l + 1].g, T.lv[l + 1].b, slot, h, lane);
 		__syncthreads();
@@ -464,7 +472,7 @@ __global__ void __launch_bounds__(MG_TAIL_WAVES * 64) k_mg_tail(MgTail<real> T, 
 		const MgLv<real> &L = T.lv[l];
 		for (int slot = wid; slot < L.n_tiles; slot += MG_TAIL_WAVES) {
 			real bb[8];
-			prolong_postsmooth_tile<real>(L, T.lv[l + 1].g, T.lv[l + 1].y, slot, h, lane, bb);
+			prolong_postsmooth_tile<real>(L, T.lv[l + 1].g, T.lv[l + 1].y, slot, h, lane, bb, T.inner);
 			const size_t base = (size_t)L.tiles[slot] * 512;
 #pragma unroll
 			for (int zz = 0; zz < 8; ++zz) L.y[base + zz * 64 + lane] = h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)];
@@ -652,6 +660,8 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		T.first = tail;
 		T.last = last;
 		T.nsw = MG_COARSEST_SWEEPS;
+		T.inner = MG_INNER_SWEEPS;  // measured at C4: 19 iterations; 1 sweep on the tail levels: 22
+		if (const char *e = getenv("LFA_MG_TAIL_INNER")) T.inner = std::max(1, atoi(e));
 		if (const char *e = getenv("LFA_MG_NSW")) T.nsw = std::max(1, atoi(e));
 		hipLaunchKernelGGL(k_mg_tail<real>, dim3(1), dim3(MG_TAIL_WAVES * 64), 0, s->stream, T, st);
 		LFA_LAUNCH_CHECK(s);
