@@ -150,18 +150,33 @@ template <typename real> __device__ inline real rcp_diag(uint32_t n) {
 	return n == 6 ? (real)(1.0 / 6.0) : n == 5 ? (real)0.2 : n == 4 ? (real)0.25 : n == 3 ? (real)(1.0 / 3.0) : n == 2 ? (real)0.5 : (real)1;
 }
 
+/// pick ? b : a on the bit patterns (exact, and immune to being rewritten into an indexed load).
+__device__ inline float bit_select(float a, float b, int pick) {
+	const uint32_t x = __builtin_bit_cast(uint32_t, a), y = __builtin_bit_cast(uint32_t, b);
+	return __builtin_bit_cast(float, x ^ ((x ^ y) & (0u - (uint32_t)pick)));
+}
+__device__ inline double bit_select(double a, double b, int pick) {
+	const uint64_t x = __builtin_bit_cast(uint64_t, a), y = __builtin_bit_cast(uint64_t, b);
+	return __builtin_bit_cast(double, x ^ ((x ^ y) & (0ull - (uint64_t)pick)));
+}
+
 /// One colour of the Gauss-Seidel update on the column of a lane: x_i = (b_i + sum of coupled neighbours) / diag_i.
 /// `h` is the 10^3 halo block of the wave (current values, ring = values of the neighbour tiles or 0).
 template <typename real>
 __device__ inline void gs_colour(real *h, const uint32_t (&ab)[8], const real (&bb)[8], int lx, int ly, int colour) {
+	// the cells of one colour in the column of lane (x, y) are z = 2 j + z0, z0 = (x + y + colour) & 1: four updates with every
+	// lane active (looping over z and skipping the other colour would idle half the wave)
+	const int z0 = (lx + ly + colour) & 1;
+	const uint32_t zmask = 0u - (uint32_t)z0;
 #pragma unroll
-	for (int zz = 0; zz < 8; ++zz) {
-		if (((lx + ly + zz) & 1) != colour) continue;
-		const uint32_t a = ab[zz];
+	for (int j = 0; j < 4; ++j) {
+		// (a select written as arithmetic: `z0 ? ab[2j+1] : ab[2j]` is turned into a dynamically indexed load from scratch)
+		const uint32_t a = ab[2 * j] ^ ((ab[2 * j] ^ ab[2 * j + 1]) & zmask);
+		const real bv = bit_select(bb[2 * j], bb[2 * j + 1], z0);
 		if (!(a & AB_UNKNOWN) || !(a & 7)) continue;
-		const int i = (lx + 1) + 10 * (ly + 1) + 100 * (zz + 1);
+		const int i = (lx + 1) + 10 * (ly + 1) + 100 * (2 * j + z0 + 1);
 		const real F = (a & AB_FLUID) ? (real)1 : (real)0;
-		real sum = bb[zz];
+		real sum = bv;
 		sum += F * h[i - 1];
 		sum += F * h[i - 10];
 		sum += F * h[i - 100];
@@ -362,28 +377,44 @@ k_mg_axpy_presmooth(const int *tiles, int n_tiles, const uint8_t *abits, real *p
 		__syncthreads();
 		real *h = halo[wid];
 		for (int i = lane; i < LFA_HALO_CELLS; i += 64) h[i] = (real)0;
-		for (int slot = blockIdx.x * PCG_WAVES + wid; slot < n_tiles; slot += gridDim.x * PCG_WAVES) {
-			const size_t base = (size_t)tiles[slot] * 512;
-			uint32_t ab[8];
-			real bb[8];
+		// software pipeline: the loads of the wave's next tile are in flight during the sweeps of the current one
+		const int stride = gridDim.x * PCG_WAVES;
+		int slot = blockIdx.x * PCG_WAVES + wid;
+		uint32_t tab[8];
+		real tp[8], ts[8], tr[8], tq[8];
+		size_t base = 0;
+		auto load_tile = [&](int sl) {
+			base = (size_t)tiles[sl] * 512;
 #pragma unroll
 			for (int zz = 0; zz < 8; ++zz) {
 				const size_t c = base + zz * 64 + lane;
-				ab[zz] = abits[c];
-				const real pv = p[c], sv = sdir[c], rv = r[c], qv = q_x[c];
+				tab[zz] = abits[c]; tp[zz] = p[c]; ts[zz] = sdir[c]; tr[zz] = r[c]; tq[zz] = q_x[c];
+			}
+		};
+		if (slot < n_tiles) load_tile(slot);
+		while (slot < n_tiles) {
+			uint32_t ab[8];
+			real bb[8];
+			const size_t obase = base;
+#pragma unroll
+			for (int zz = 0; zz < 8; ++zz) {
+				const size_t c = obase + zz * 64 + lane;
+				ab[zz] = tab[zz];
 				real rn = (real)0;
 				if (ab[zz] & AB_UNKNOWN) {
-					p[c] = pv + alpha * sv;
-					rn = rv + (-alpha) * qv;
+					p[c] = tp[zz] + alpha * ts[zz];
+					rn = tr[zz] + (-alpha) * tq[zz];
 					r[c] = rn;
 					nan |= rn != rn;
 					m = (double)rn > m ? (double)rn : m;
 				}
 				bb[zz] = rn;
 			}
+			slot += stride;
+			if (slot < n_tiles) load_tile(slot);
 			presmooth_column<real>(h, ab, bb, lx, ly, MG_INNER_SWEEPS);
 #pragma unroll
-			for (int zz = 0; zz < 8; ++zz) q_x[base + zz * 64 + lane] = h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)];
+			for (int zz = 0; zz < 8; ++zz) q_x[obase + zz * 64 + lane] = h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)];
 		}
 	}
 	m = wave_max(m);
@@ -622,7 +653,7 @@ int lfa_mg_setup(lfa_sim *s) {
 /// z = V(r) / scale and the partial sums of dot(z, r) (pcg_grid(n_ptiles) of them) into part_sigma.
 /// Level 0 uses the solver's own vectors: b = r (vr), pre-smoothed iterate in vq (free between the AXPYs and the next
 /// A s), result in vz. `level0_presmoothed`: vq already holds the pre-smoothed iterate (k_mg_axpy_presmooth).
-#define MG_TAIL_TILES 64  // levels with at most this many tiles run inside k_mg_tail
+#define MG_TAIL_TILES 8  // levels with at most this many tiles run inside k_mg_tail (measured at C4: 8 -> 128 us, 64 -> 150 us)
 #define MG_COARSEST_SWEEPS 4
 enum { MG_PART_PRE0 = 1, MG_PART_DOWN0 = 2, MG_PART_COARSE = 4, MG_PART_UP0 = 8, MG_PART_ALL = 15 };
 template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, bool level0_presmoothed, int parts = MG_PART_ALL) {
@@ -643,8 +674,9 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		LFA_LAUNCH_CHECK(s);
 		return LFA_OK;
 	}
-	int tail = last;  // first level handled by the single-workgroup tail
-	while (tail > 1 && M.lv[tail - 1].n_tiles <= MG_TAIL_TILES) --tail;
+	int tail = last, tail_tiles = MG_TAIL_TILES;  // first level handled by the single-workgroup tail
+	if (const char *e = getenv("LFA_MG_TAIL_TILES")) tail_tiles = atoi(e);
+	while (tail > 1 && M.lv[tail - 1].n_tiles <= tail_tiles) --tail;
 	for (int l = 0; l < tail; ++l) {
 		const MgLv<real> L = lvl(l);
 		const int G = mg_grid(L.n_tiles);
