@@ -79,6 +79,10 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-full-step", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="one launch per vector operation in the PCG loop (pcg_fused = 0)")
+    ap.add_argument("--obstacle", action="store_true", help="BASELINE configs[4]: voxelize a sphere mesh on the device "
+                    "(lfa_voxelize_mesh) and mark it solid before the steps")
+    ap.add_argument("--mesh", action="store_true", help="BASELINE configs[4]: extract the surface mesh from the resident particles "
+                    "after the timed steps (lfa_mesher_sample_sim + marching cubes), timed separately")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent copies of the domain instead of z-slabs")
     args = ap.parse_args()
 
@@ -132,6 +136,20 @@ def main():
         parallelism = f"{world} z-slabs (tile layers {bounds}), RCCL send/recv halos + scalar all-reduces over xGMI"
     elif world > 1:
         parallelism = f"{world} independent replicas (--replicas)"
+    extras = {}
+    if args.obstacle:
+        # a sphere in the dry part of the tank, in the path of the collapsing column (the classic dam break with an obstacle),
+        # voxelized on the device and marked solid without leaving it. It must not overlap the seeded block: particles deep
+        # inside a solid give rows without a diagonal, which the reference's MIC(0) turns into 1/sqrt(0) as well.
+        rad = 0.16 * min(bhi[0] - blo[0], bhi[1] - blo[1], cfg["block"][1][2] - blo[2])
+        ctr = [min(bhi[0] + 2.0 * rad, size[0] - 1.5 * rad), blo[1] + 1.2 * rad, 0.5 * (blo[2] + cfg["block"][1][2])]
+        mpos, midx = scenes.icosphere(ctr, rad, 5)
+        t0 = time.perf_counter()
+        vox = lfa.Voxels.from_mesh(mpos, midx, 1.0, (0.0, 0.0, 0.0), device=local_rank)
+        sim.set_solid_from_voxels(vox, True, True)
+        extras["voxelizer"] = {"triangles": int(len(midx) // 3), "voxel_grid": list(vox.size), "ms_mesh_to_solid_cells": 1e3 * (time.perf_counter() - t0),
+                               "solid_cells": int(len(vox.cells(True, True, size)))}
+        vox.close()
     sim.seed_block(blo, bhi)
     sim.enable_timing(True)
 
@@ -274,6 +292,17 @@ def main():
                                  "pcg_iterations_per_step": fs_iters / n_fs, "stage_ms": sim.step_timings(),
                                  "note": "device resident: advect+collide, bin, P2G, PCG, apply, correct+collide, "
                                          "extrapolate, bin, G2P"}
+    if args.mesh and world == 1:
+        m = lfa.Mesher(size, (0.0, 0.0, 0.0), 1.0, 1.0, 2, device=local_rank)  # mesher settings of testbed/main.cpp:101-107 at cell size 1
+        t0 = time.perf_counter()
+        m.sample_sim(sim, 0.5)
+        t1 = time.perf_counter()
+        mpos, midx = m.marching_cubes()
+        t2 = time.perf_counter()
+        extras["mesher"] = {"grid_points": (size[0] + 1) * (size[1] + 1) * (size[2] + 1), "sample_ms": 1e3 * (t1 - t0),
+                            "marching_cubes_ms_incl_download": 1e3 * (t2 - t1), "vertices": int(len(mpos)), "triangles": int(len(midx) // 3)}
+        m.close()
+    out.update(extras)
     sim.close()
 
     if rank == 0:

@@ -67,8 +67,10 @@ enum { MT_AIR = 0, MT_FLUID = 1, MT_SOLID = 2 };
 __device__ inline int fine_type(const uint32_t *tile_flag, const uint32_t *cell_count, const uint8_t *ctype, const uint8_t *solid,
                                 uint32_t b) {
 	if (!tile_flag[b >> 9]) return solid[b] ? MT_SOLID : MT_AIR;
-	if (cell_count[b] > 0) return MT_FLUID;  // an unknown (also a solid cell that holds particles)
-	return (ctype[b] & 7) == CT_SOLID ? MT_SOLID : MT_AIR;
+	// a solid cell that holds particles is an unknown on the finest level (src/simulation.cpp:83-94) but takes no pressure
+	// from its lower neighbours and gives none to them: for the coarse levels it is a wall
+	if ((ctype[b] & 7) == CT_SOLID) return MT_SOLID;
+	return cell_count[b] > 0 ? MT_FLUID : MT_AIR;
 }
 
 /// Types of level 1 from the fine grid, one thread per coarse cell of the whole padded coarse grid.
