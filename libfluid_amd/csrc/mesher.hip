@@ -156,7 +156,9 @@ __global__ void k_scatter_particles(MeshGrid g, const double *pos, size_t np, co
 	if (c != 0xFFFFFFFFu) order[cell_start[c] + atomicAdd(&cell_fill[c], 1u)] = (uint32_t)i;
 }
 /// The scatter leaves a cell's particles in arbitrary order; the reference visits them newest first, so each group is put
-/// in ascending input order (and read backwards). Groups are a handful of particles: insertion sort, one thread per cell.
+/// in DESCENDING input order. Cells are x fastest, so the cells [x0, x1) of one row of a neighbourhood are one contiguous
+/// run of `order` that already is in the reference's visiting order (cells ascending, newest first inside a cell).
+/// Groups are a handful of particles: insertion sort, one thread per cell.
 __global__ void k_sort_groups(const uint32_t *cell_start, size_t ncell, uint32_t *order) {
 	const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= ncell) return;
@@ -164,7 +166,7 @@ __global__ void k_sort_groups(const uint32_t *cell_start, size_t ncell, uint32_t
 	for (uint32_t i = b + 1; i < e; ++i) {
 		const uint32_t v = order[i];
 		uint32_t j = i;
-		while (j > b && order[j - 1] > v) {
+		while (j > b && order[j - 1] < v) {
 			order[j] = order[j - 1];
 			--j;
 		}
@@ -188,12 +190,12 @@ k_sample_surface(MeshGrid g, const double *pos, const uint32_t *cell_start, cons
 	const double e2 = g.extent * g.extent;
 	double tw = 0.0, tr = 0.0, tx = 0.0, ty = 0.0, tz = 0.0;
 	bool has = false;
+	if (x0 < x1)
 	for (uint64_t cz = z0; cz < z1; ++cz)
-		for (uint64_t cy = y0; cy < y1; ++cy)
-			for (uint64_t cx = x0; cx < x1; ++cx) {
-				const size_t cell = (size_t)(cx + g.nx * (cy + g.ny * cz));
-				const uint32_t b = cell_start[cell];
-				for (uint32_t k = cell_start[cell + 1]; k-- > b;) {
+		for (uint64_t cy = y0; cy < y1; ++cy) {
+				const size_t row = (size_t)(g.nx * (cy + g.ny * cz));
+				const uint32_t e = cell_start[row + x1];
+				for (uint32_t k = cell_start[row + x0]; k < e; ++k) {
 					const double *p = pos + 3 * (size_t)order[k];
 					const double qx = p[0], qy = p[1], qz = p[2];
 					has = true;
