@@ -450,19 +450,88 @@ k_mg_prolong_postsmooth(MgLv<real> L, GridDims gc, const real *e, real inv_scale
 	real *h = halo[wid];
 	double acc = 0.0;
 	if (state[0] < 0) {
-		for (int slot = blockIdx.x * PCG_WAVES + wid; slot < L.n_tiles; slot += gridDim.x * PCG_WAVES) {
+		// The body of prolong_postsmooth_tile as a software pipeline: every load of the wave's next tile (column, ring, the
+		// parents' corrections) is in flight while the current tile is swept in LDS.
+		const int stride = gridDim.x * PCG_WAVES;
+		int slot = blockIdx.x * PCG_WAVES + wid;
+		uint32_t tab[8], rab[6];
+		real tb[8], tx[8], tc[4], rx[6], rc[6];
+		bool rv[6];
+		size_t base = 0;
+		auto load_tile = [&](int sl) {
+			const int *nt = L.nbr + (size_t)sl * MG_NBR_STRIDE;
+			const int tile = nt[6];
+			base = (size_t)tile * 512;
+			int tx_, ty_, tz_;
+			tile_coords(L.g, tile, tx_, ty_, tz_);
+			auto corr = [&](int X, int Y, int Z) -> real { return e ? e[blocked_index(gc, X >> 1, Y >> 1, Z >> 1)] : (real)0; };
+#pragma unroll
+			for (int zz = 0; zz < 8; ++zz) {
+				tab[zz] = L.abits[base + zz * 64 + lane];
+				tb[zz] = L.b[base + zz * 64 + lane];
+				tx[zz] = L.x[base + zz * 64 + lane];
+			}
+#pragma unroll
+			for (int j = 0; j < 4; ++j) tc[j] = corr(tx_ * 8 + lx, ty_ * 8 + ly, tz_ * 8 + 2 * j);
+			// ring: face lanes = (a, b) over the two in-face axes; a missing neighbour reads the tile's own cell (masked later)
+			const int cell[6] = {ly * 64 + lx * 8 + 7, ly * 64 + lx * 8, ly * 64 + 56 + lx, ly * 64 + lx, 7 * 64 + lane, lane};
+			const int RX[6] = {tx_ * 8 - 1, tx_ * 8 + 8, tx_ * 8 + lx, tx_ * 8 + lx, tx_ * 8 + lx, tx_ * 8 + lx};
+			const int RY[6] = {ty_ * 8 + lx, ty_ * 8 + lx, ty_ * 8 - 1, ty_ * 8 + 8, ty_ * 8 + ly, ty_ * 8 + ly};
+			const int RZ[6] = {tz_ * 8 + ly, tz_ * 8 + ly, tz_ * 8 + ly, tz_ * 8 + ly, tz_ * 8 - 1, tz_ * 8 + 8};
+#pragma unroll
+			for (int k = 0; k < 6; ++k) {
+				rv[k] = nt[k] >= 0;
+				const size_t j = (size_t)(rv[k] ? nt[k] : tile) * 512 + cell[k];
+				rab[k] = L.abits[j];
+				rx[k] = L.x[j];
+				rc[k] = rv[k] ? corr(RX[k], RY[k], RZ[k]) : (real)0;
+			}
+		};
+		if (slot < L.n_tiles) load_tile(slot);
+		while (slot < L.n_tiles) {
+			uint32_t ab[8];
 			real bb[8];
-			prolong_postsmooth_tile<real>(L, gc, e, slot, h, lane, bb, MG_INNER_SWEEPS);
-			const size_t base = (size_t)L.tiles[slot] * 512;
+			const size_t obase = base;
+			MG_FENCE();
+#pragma unroll
+			for (int zz = 0; zz < 8; ++zz) {
+				ab[zz] = tab[zz];
+				bb[zz] = tb[zz];
+				real v = tx[zz];
+				if (ab[zz] & AB_UNKNOWN) v += tc[zz >> 1];
+				h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)] = v;
+			}
+			real fv[6];
+#pragma unroll
+			for (int k = 0; k < 6; ++k) {
+				real v = rx[k];
+				if (rab[k] & AB_UNKNOWN) v += rc[k];
+				fv[k] = rv[k] ? v : (real)0;
+			}
+			h[0 + 10 * (lx + 1) + 100 * (ly + 1)] = fv[0];
+			h[9 + 10 * (lx + 1) + 100 * (ly + 1)] = fv[1];
+			h[(lx + 1) + 10 * 0 + 100 * (ly + 1)] = fv[2];
+			h[(lx + 1) + 10 * 9 + 100 * (ly + 1)] = fv[3];
+			h[(lx + 1) + 10 * (ly + 1) + 100 * 0] = fv[4];
+			h[(lx + 1) + 10 * (ly + 1) + 100 * 9] = fv[5];
+			slot += stride;
+			if (slot < L.n_tiles) load_tile(slot);
+			MG_FENCE();
+			for (int it = 0; it < MG_INNER_SWEEPS; ++it) {
+				gs_colour<real>(h, ab, bb, lx, ly, 1);
+				MG_FENCE();
+				gs_colour<real>(h, ab, bb, lx, ly, 0);
+				MG_FENCE();
+			}
 #pragma unroll
 			for (int zz = 0; zz < 8; ++zz) {
 				const real v = h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)];
 				if (LEVEL0) {
 					const real zv = v * inv_scale;
-					L.y[base + zz * 64 + lane] = zv;
+					L.y[obase + zz * 64 + lane] = zv;
 					acc += (double)zv * (double)bb[zz];
 				} else {
-					L.y[base + zz * 64 + lane] = v;
+					L.y[obase + zz * 64 + lane] = v;
 				}
 			}
 		}

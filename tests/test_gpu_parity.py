@@ -244,6 +244,25 @@ def test_multigrid_preconditioner_is_symmetric_positive_definite(name, dtype):
     s.close()
 
 
+@pytest.mark.parametrize("size,block", [((8, 8, 8), ((0, 0, 0), (5, 4, 6))), ((7, 5, 3), ((1, 0, 0), (6, 3, 3))),
+                                        ((40, 9, 24), ((3, 0, 2), (37, 6, 20)))])
+def test_multigrid_on_grids_of_one_or_few_tiles(size, block):
+    """A grid that fits one tile has a single level (the two smoothing sweeps alone); a flat one has levels that stop
+    coarsening in one direction. Same pressure as the reference's schedule."""
+    parts = util.scenes.seed_block(*block)
+    rng = np.random.default_rng(3)
+    parts["vel"] = rng.normal(size=(len(parts), 3)) * 2.0
+    ps = {}
+    for precond in (lfa.PRECOND_MIC0_EXACT, lfa.PRECOND_MULTIGRID):
+        s = lfa.Sim(size, precond=precond, pcg_dtype=lfa.PCG_F64)
+        s.upload_particles(parts)
+        res, it, rc = s.step_hot(util.DT)
+        assert rc == 0 and res < 1e-6
+        ps[precond] = s.pressure()
+        s.close()
+    util.assert_close(ps[lfa.PRECOND_MULTIGRID], ps[lfa.PRECOND_MIC0_EXACT], 1e-6, "pressure")
+
+
 def test_multigrid_iteration_count_barely_grows_with_the_grid():
     """Dam-break blocks of 16^3 ... 64^3 cells at rest: MIC(0) per tile needs several times the iterations when the block
     doubles twice, the V-cycle a handful more; both converge to the same pressure."""
