@@ -1665,8 +1665,6 @@ static void fused_grids(int G, int &GA, int &GB) {
 template <typename real> static int solve_t(lfa_sim *s, double dt, double *residual, uint64_t *iterations) {
 	if (s->dist && s->prm.precond == LFA_PRECOND_MIC0_EXACT)
 		return lfa_fail(s, LFA_E_UNSUPPORTED, "the exact (hyperplane) MIC(0) schedule is single-GPU only");
-	if (s->dist && is_mg(s))
-		return lfa_fail(s, LFA_E_UNSUPPORTED, "the multigrid preconditioner is single-GPU only (use LFA_PRECOND_MULTILEVEL with slabs)");
 	LFA_TRY(build_system_t<real>(s, dt));
 	if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[18], s->stream));
 	s->last_residual = 0.0;
@@ -1712,31 +1710,10 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 	const int chunk = 8;
 	int done = -1, nan = 0, i = 0;
 	int *hstate = (int *)s->h_pinned;
-	// multigrid: k_pcg_a (search direction + A s), the AXPYs, then the V-cycle (mg.hip) on the new residual
-	real *sbuf_mg[2] = {(real *)s->vs, (real *)s->vs2};
-	while (is_mg(s) && i < maxit && done < 0) {
-		const int end = std::min(maxit, i + chunk);
-		for (; i < end; ++i) {
-			const int po = i & 1, pn = po ^ 1;
-			const double *sig_po = P + (po ? PART_SIG1 : PART_SIG0), *sig_pn = P + (pn ? PART_SIG1 : PART_SIG0);
-			launch_pcg_a<real>(i == 0, false, G, s->stream, s->n_ptiles, (const int *)s->nbr_table, (const uint8_t *)s->abits,
-			                   (const real *)v.z, (const real *)sbuf_mg[po], sbuf_mg[pn], v.q, scale, sig_po, G, sig_pn, G,
-			                   (const double *)(P + PART_RMAX), G, s->prm.tolerance, i, s->pcg_state, s->pcg_hist, P + PART_ZS,
-			                   (const real *)nullptr, (const real *)nullptr, (real *)nullptr);
-			LFA_LAUNCH_CHECK(s);
-			LFA_TRY(lfa_mg_axpy_apply(s, sbuf_mg[pn], sig_po, G, P + PART_ZS, G, P + PART_RMAX, P + (pn ? PART_SIG1 : PART_SIG0)));
-		}
-		hipLaunchKernelGGL(k_check_converged, dim3(1), dim3(256), 0, s->stream, P + PART_RMAX, G, s->prm.tolerance, i - 1,
-		                   s->pcg_state, s->pcg_hist);
-		LFA_LAUNCH_CHECK(s);
-		LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 8, hipMemcpyDeviceToHost, s->stream));
-		LFA_HIP(s, hipStreamSynchronize(s->stream));
-		done = hstate[0];
-		nan = hstate[1];
-	}
 	// fused iteration (k_pcg_a / k_pcg_b): tile-local MIC(0) with or without the coarse levels, single domain or slabs
-	const bool fused = !is_mg(s) && s->prm.pcg_fused && s->prm.precond != LFA_PRECOND_MIC0_EXACT && (s->n_ptiles == 0 || s->nbr_table);
-	if (!fused && !is_mg(s)) {
+	// (with the multigrid preconditioner the second kernel is the AXPY/pre-smoothing kernel followed by the V-cycle, mg.hip)
+	const bool fused = (is_mg(s) || s->prm.pcg_fused) && s->prm.precond != LFA_PRECOND_MIC0_EXACT && (s->n_ptiles == 0 || s->nbr_table);
+	if (!fused) {
 		hipLaunchKernelGGL(k_update_s<real>, dim3(G), dim3(256), 0, s->stream, tc, v, sig_src(0), sig_src(0), n_sig, 1,
 		                   s->pcg_state, s->abits, cx, (const int *)s->slot_l1, (const real *)s->c_x2, (const int *)s->l1_l2);
 		LFA_LAUNCH_CHECK(s);
@@ -1747,6 +1724,7 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 	// launch widths of the two fused kernels (workgroups); each kernel reads the other's per-workgroup partials
 	int GA, GB;
 	fused_grids(G, GA, GB);
+	if (is_mg(s)) GB = G;  // the V-cycle kernels write pcg_grid(n_ptiles) partials
 	const int NSB = GB + (is_ml(s) ? 1 : 0);
 	// slabs: boundary tile layers whose rows couple to the neighbour rank (k_ghost_face_rows)
 	const int n_face_lo = dist && lfa_has_lo(s) ? s->n_own_first : 0, n_face_hi = dist && lfa_has_hi(s) ? s->n_own_last : 0;
@@ -1785,7 +1763,9 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 			const int n_zs_src = dist ? 1 : GA;
 			double *sig_new_part = P + (pn ? PART_SIG1 : PART_SIG0);
 			CoarseFields<real> cf = is_ml(s) ? make_coarse<real>(s) : CoarseFields<real>{};
-			if (embed) {
+			if (is_mg(s)) {
+				LFA_TRY(lfa_mg_axpy_apply(s, sbuf[pn], sig_po, n_sig_po, zs_src, n_zs_src, P + PART_RMAX, sig_new_part));
+			} else if (embed) {
 				cf.r = crbuf[po];
 				cf.as = (const real *)s->c_as;
 				CoarseArgs ca{s->l1_tiles, s->n_l1tiles, s->a2inv, s->c_x2, (double *)s->pcg_hist + 6144, (unsigned *)(s->pcg_state + 4)};
@@ -1819,7 +1799,7 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 		done = hstate[0];
 		nan = hstate[1];
 	}
-	while (!fused && !is_mg(s) && i < maxit && done < 0) {
+	while (!fused && i < maxit && done < 0) {
 		const int end = std::min(maxit, i + chunk);
 		for (; i < end; ++i) {
 			const int po = i & 1, pn = po ^ 1;
