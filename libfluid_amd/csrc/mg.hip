@@ -130,13 +130,6 @@ __global__ void __launch_bounds__(256) k_mg_abits(const int *tiles, int n_tiles,
 		}
 	}
 }
-__global__ void k_mg_zero_tiles(const int *tiles, int n_tiles, void *field, int elem) {
-	const int slot = blockIdx.x;
-	if (slot >= n_tiles) return;
-	uint32_t *p = (uint32_t *)((char *)field + (size_t)tiles[slot] * 512 * elem);
-	for (int i = threadIdx.x; i < 512 * elem / 4; i += 256) p[i] = 0u;
-}
-
 // ------------------------------------------------------------------------------------------------ V-cycle kernels
 /// What a kernel needs to know about one level.
 template <typename real> struct MgLv {
