@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--config", default=None, help="C2 | C3 | C4 | C5 (default: C4 at 1 GPU, see DESIGN.md)")
     ap.add_argument("--dt", type=float, default=0.033, help="min(3*cfl, 0.033) of simulation::time_step() at rest")
     ap.add_argument("--precond", default=None, choices=["multigrid", "multilevel", "tiled", "exact"],
-                    help="default: multigrid on one GPU, multilevel with z-slabs (the V-cycle is single-domain)")
+                    help="default: multigrid (on z-slabs: finest 4 levels distributed, coarser ones replicated)")
     ap.add_argument("--pcg-dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--p2g", default="binned", choices=["binned", "atomic"])
     ap.add_argument("--max-iterations", type=int, default=200, help="PCG iteration cap (pressure_solver.h:42)")
@@ -88,7 +88,7 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     if args.precond is None:
-        args.precond = "multigrid" if (int(os.environ.get("WORLD_SIZE", "1")) == 1 or args.replicas) else "multilevel"
+        args.precond = "multigrid"
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:

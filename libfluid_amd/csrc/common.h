@@ -71,6 +71,7 @@ struct lfa_sim {
 	// [slab_lo, slab_hi) and mirrors one ghost tile layer on each side. dist == nullptr: single domain.
 	struct lfa_dist *dist = nullptr;
 	int slab_lo = 0, slab_hi = 0;           // owned tile layers (z)
+	int slab_align = 0;                     // every interior slab bound is a multiple of 2^slab_align tile layers
 	int *ptiles_all = nullptr;              // ghost-lo | owned | ghost-hi particle tiles, ascending tile id
 	int p_off = 0, n_ptiles_all = 0;        // ptiles == ptiles_all + p_off
 	int n_own_first = 0, n_own_last = 0;    // owned particle tiles in the first / last owned layer
@@ -220,15 +221,21 @@ struct lfa_dist {
 	virtual int exchange(lfa_sim *s, const void *send_lo, size_t n_send_lo, void *recv_lo, size_t n_recv_lo,
 	                     const void *send_hi, size_t n_send_hi, void *recv_hi, size_t n_recv_hi) = 0;
 	virtual int allreduce(lfa_sim *s, double *dev, int count, bool is_max) = 0;
+	/// in-place all-reduce of a device array: dtype LFA_RED_U8 / F32 / F64, sum or max
+	virtual int allreduce_buf(lfa_sim *s, void *dev, size_t count, int dtype, bool is_max) = 0;
 	virtual ~lfa_dist() {}
 };
+enum { LFA_RED_U8 = 0, LFA_RED_F32 = 1, LFA_RED_F64 = 2 };
 inline bool lfa_has_lo(const lfa_sim *s) { return s->dist && s->dist->rank > 0; }
 inline bool lfa_has_hi(const lfa_sim *s) { return s->dist && s->dist->rank + 1 < s->dist->nranks; }
 int lfa_dist_exchange_tile_layers_u32(lfa_sim *s, uint32_t *per_tile);  // own boundary layers -> neighbours' ghost layers
 int lfa_dist_build_halo_lists(lfa_sim *s);
 int lfa_dist_exchange_fields(lfa_sim *s, int nfields, void *const *fields, const int *elem_bytes);
 int lfa_dist_exchange_p2g_planes(lfa_sim *s, float *stage_all);
-int lfa_dist_exchange_slices(lfa_sim *s, void *vec, int elem_bytes);
+int lfa_dist_exchange_slices(lfa_sim *s, void *vec, int elem_bytes);  // elem_bytes 1, 4 or 8
+/// The same for a whole tile layer of a tile-major array with `tiles_per_layer` tiles per layer (multigrid levels): slice 0 of
+/// layer lo_layer goes down, slice 7 of layer hi_layer - 1 goes up; they land in layers lo_layer - 1 and hi_layer.
+int lfa_dist_exchange_layer_slices(lfa_sim *s, void *vec, int elem_bytes, int tiles_per_layer, int lo_layer, int hi_layer);
 int lfa_dist_allreduce(lfa_sim *s, const double *partials, int n, int slot, bool is_max);  // result in dist_red[slot]
 int lfa_dist_ensure_xbuf(lfa_sim *s, int which, size_t bytes);
 int lfa_dist_migrate(lfa_sim *s);

@@ -295,7 +295,6 @@ extern "C" int lfa_set_params(lfa_sim *s, const lfa_params *p) {
 	if (p->pcg_dtype != s->prm.pcg_dtype || p->precond != s->prm.precond) s->system_valid = false;
 	if (p->precond < 0 || p->precond > LFA_PRECOND_MULTIGRID) return lfa_fail(s, LFA_E_INVALID, "bad precond");
 	s->prm = *p;
-	if (s->dist && s->prm.precond == LFA_PRECOND_MULTIGRID) s->prm.precond = LFA_PRECOND_MULTILEVEL;  // single-domain only
 	return LFA_OK;
 }
 extern "C" int lfa_get_params(const lfa_sim *s, lfa_params *p) {

@@ -9,6 +9,8 @@
 //                  before the system build, before extrapolation and before G2P
 //   PCG          : one z-slice (64 values per particle tile) of the search vector per iteration, of the pressure once;
 //                  the two dot products and the signed max as scalar all-reduces
+//   multigrid    : per distributed level one z-slice of the pre-smoothed and of the post-smoothed iterate (whole boundary
+//                  tile layer on levels >= 1); one sum all-reduce of the first replicated level's right-hand side (mg.hip)
 // Every rank indexes the GLOBAL grid, so a ghost tile is simply a tile id whose data arrives by message; kernels are the
 // single-GPU kernels, run over the owned tile lists.
 //
@@ -20,9 +22,11 @@
 #include <string.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <vector>
 
 #include "common.h"
 
@@ -65,18 +69,28 @@ __global__ void __launch_bounds__(128) k_planes_copy(float *stage_all, int slot0
 	}
 }
 
-/// One z-slice (64 elements) of a tile-major vector for a run of particle tiles.
+/// One z-slice (64 elements, `slice_words` 32-bit words) of a tile-major vector for a run of particle tiles.
 template <bool PACK>
 __global__ void __launch_bounds__(64) k_slices_copy(const int *ptiles_all, int slot0, int n, int zz, uint32_t *vec,
-                                                   int words_per_elem, uint32_t *buf) {
+                                                   int slice_words, uint32_t *buf) {
 	const int k = blockIdx.x;
 	if (k >= n) return;
-	uint32_t *g = vec + ((size_t)ptiles_all[slot0 + k] * LFA_TILE_CELLS + (size_t)zz * 64) * words_per_elem;
-	uint32_t *b = buf + (size_t)k * 64 * words_per_elem;
-	for (int i = threadIdx.x; i < 64 * words_per_elem; i += 64) {
+	uint32_t *g = vec + ((size_t)ptiles_all[slot0 + k] * 8 + (size_t)zz) * slice_words;
+	uint32_t *b = buf + (size_t)k * slice_words;
+	for (int i = threadIdx.x; i < slice_words; i += 64) {
 		if (PACK) b[i] = g[i];
 		else g[i] = b[i];
 	}
+}
+/// The same for the consecutive tiles tile0 .. tile0 + n - 1 (a whole tile layer).
+template <bool PACK>
+__global__ void __launch_bounds__(256) k_layer_slices_copy(int tile0, int n, int zz, uint32_t *vec, int slice_words, uint32_t *buf) {
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= (size_t)n * slice_words) return;
+	const size_t k = i / slice_words, w = i % slice_words;
+	uint32_t *g = vec + ((size_t)(tile0 + k) * 8 + (size_t)zz) * slice_words + w;
+	if (PACK) buf[i] = *g;
+	else *g = buf[i];
 }
 
 __global__ void __launch_bounds__(256) k_reduce_partials(const double *part, int n, double *out, int is_max) {
@@ -190,7 +204,7 @@ int lfa_dist_exchange_p2g_planes(lfa_sim *s, float *stage_all) {
 /// ghost-hi tiles), slice z=7 of the last owned layer goes up (slice 7 of the upper rank's ghost-lo tiles).
 int lfa_dist_exchange_slices(lfa_sim *s, void *vec, int elem_bytes) {
 	if (!s->dist) return LFA_OK;
-	const int wpe = elem_bytes / 4;
+	const int wpe = 16 * elem_bytes;  // 32-bit words per slice
 	const size_t sb = (size_t)64 * elem_bytes;
 	const int n_send[2] = {lfa_has_lo(s) ? s->n_own_first : 0, lfa_has_hi(s) ? s->n_own_last : 0};
 	const int n_recv[2] = {s->n_ghost_lo, s->n_ghost_hi};
@@ -214,6 +228,33 @@ int lfa_dist_exchange_slices(lfa_sim *s, void *vec, int elem_bytes) {
 			                   n_recv[w], recv_z[w], (uint32_t *)vec, wpe, (uint32_t *)s->xbuf[2 + w]);
 			LFA_LAUNCH_CHECK(s);
 		}
+	return LFA_OK;
+}
+
+int lfa_dist_exchange_layer_slices(lfa_sim *s, void *vec, int elem_bytes, int tiles_per_layer, int lo_layer, int hi_layer) {
+	if (!s->dist) return LFA_OK;
+	const int sw = 16 * elem_bytes, L = tiles_per_layer;
+	const size_t sb = (size_t)64 * elem_bytes * L;
+	const bool on[2] = {lfa_has_lo(s), lfa_has_hi(s)};
+	const int send_tile0[2] = {lo_layer * L, (hi_layer - 1) * L}, recv_tile0[2] = {(lo_layer - 1) * L, hi_layer * L};
+	const int send_z[2] = {0, 7}, recv_z[2] = {7, 0};
+	const unsigned grid = (unsigned)(((size_t)L * sw + 255) / 256);
+	for (int w = 0; w < 2; ++w) {
+		if (!on[w]) continue;
+		LFA_TRY(lfa_dist_ensure_xbuf(s, w, sb));
+		LFA_TRY(lfa_dist_ensure_xbuf(s, 2 + w, sb));
+		hipLaunchKernelGGL(k_layer_slices_copy<true>, dim3(grid), dim3(256), 0, s->stream, send_tile0[w], L, send_z[w], (uint32_t *)vec,
+		                   sw, (uint32_t *)s->xbuf[w]);
+		LFA_LAUNCH_CHECK(s);
+	}
+	LFA_TRY(s->dist->exchange(s, s->xbuf[0], on[0] ? sb : 0, s->xbuf[2], on[0] ? sb : 0, s->xbuf[1], on[1] ? sb : 0, s->xbuf[3],
+	                          on[1] ? sb : 0));
+	for (int w = 0; w < 2; ++w) {
+		if (!on[w]) continue;
+		hipLaunchKernelGGL(k_layer_slices_copy<false>, dim3(grid), dim3(256), 0, s->stream, recv_tile0[w], L, recv_z[w], (uint32_t *)vec,
+		                   sw, (uint32_t *)s->xbuf[2 + w]);
+		LFA_LAUNCH_CHECK(s);
+	}
 	return LFA_OK;
 }
 
@@ -397,6 +438,7 @@ struct lfa_hub {
 		const void *lo = nullptr, *hi = nullptr;
 		size_t n_lo = 0, n_hi = 0;
 		double val = 0.0;
+		std::vector<uint8_t> buf;  // array all-reduce: this rank's contribution, staged on the host
 	};
 	std::vector<Mail> mail;
 	bool failed = false;
@@ -471,6 +513,36 @@ struct LocalDist : lfa_dist {
 		LFA_HIP(s, hipStreamSynchronize(s->stream));
 		return LFA_OK;
 	}
+	int allreduce_buf(lfa_sim *s, void *dev, size_t count, int dtype, bool is_max) override {
+		const size_t es = dtype == LFA_RED_U8 ? 1 : (dtype == LFA_RED_F32 ? 4 : 8), bytes = count * es;
+		std::vector<uint8_t> &mine = hub->mail[rank].buf;
+		mine.resize(bytes);
+		LFA_HIP(s, hipMemcpyAsync(mine.data(), dev, bytes, hipMemcpyDeviceToHost, s->stream));
+		LFA_HIP(s, hipStreamSynchronize(s->stream));
+		if (!hub->barrier()) return lfa_fail(s, LFA_E_HIP, "slab all-reduce: a peer rank failed or timed out");
+		std::vector<uint8_t> out(hub->mail[0].buf);  // fixed rank order: every rank computes the identical array
+		bool ok = out.size() == bytes;
+		for (int r = 1; r < nranks && ok; ++r) {
+			const std::vector<uint8_t> &o = hub->mail[r].buf;
+			if (o.size() != bytes) { ok = false; break; }
+			if (dtype == LFA_RED_U8) {
+				for (size_t i = 0; i < count; ++i) out[i] = is_max ? std::max(out[i], o[i]) : (uint8_t)(out[i] + o[i]);
+			} else if (dtype == LFA_RED_F32) {
+				float *a = (float *)out.data();
+				const float *b = (const float *)o.data();
+				for (size_t i = 0; i < count; ++i) a[i] = is_max ? std::max(a[i], b[i]) : a[i] + b[i];
+			} else {
+				double *a = (double *)out.data();
+				const double *b = (const double *)o.data();
+				for (size_t i = 0; i < count; ++i) a[i] = is_max ? std::max(a[i], b[i]) : a[i] + b[i];
+			}
+		}
+		if (!ok) hub->fail();
+		if (!hub->barrier() || !ok) return lfa_fail(s, LFA_E_HIP, "slab all-reduce: size mismatch or a peer rank failed");
+		LFA_HIP(s, hipMemcpyAsync(dev, out.data(), bytes, hipMemcpyHostToDevice, s->stream));
+		LFA_HIP(s, hipStreamSynchronize(s->stream));
+		return LFA_OK;
+	}
 };
 
 // ================================================================================================= RCCL transport
@@ -531,6 +603,11 @@ struct RcclDist : lfa_dist {
 		NCCL_TRY(s, g_rccl.AllReduce(dev, dev, (size_t)count, ncclFloat64, is_max ? ncclMax : ncclSum, comm, s->stream));
 		return LFA_OK;
 	}
+	int allreduce_buf(lfa_sim *s, void *dev, size_t count, int dtype, bool is_max) override {
+		const ncclDataType_t t = dtype == LFA_RED_U8 ? ncclUint8 : (dtype == LFA_RED_F32 ? ncclFloat32 : ncclFloat64);
+		NCCL_TRY(s, g_rccl.AllReduce(dev, dev, count, t, is_max ? ncclMax : ncclSum, comm, s->stream));
+		return LFA_OK;
+	}
 };
 
 int attach(lfa_sim *s, lfa_dist *d, const int32_t *bounds) {
@@ -541,9 +618,9 @@ int attach(lfa_sim *s, lfa_dist *d, const int32_t *bounds) {
 	}
 	if (s->dist) delete s->dist;
 	s->dist = d;
-	// the multigrid hierarchy is single-domain (a rank-local one, tried with Dirichlet and with Neumann slab faces, needs
-	// 49 / 66 iterations on 2 / 4 C2 slabs against 15 on one): slabs use the MIC(0)-based multilevel preconditioner
-	if (s->prm.precond == LFA_PRECOND_MULTIGRID) s->prm.precond = LFA_PRECOND_MULTILEVEL;
+	// the multigrid levels whose tile layers do not straddle a slab face stay distributed (mg.hip)
+	s->slab_align = 30;
+	for (int r = 1; r < d->nranks; ++r) s->slab_align = std::min(s->slab_align, __builtin_ctz((unsigned)bounds[r]));
 	s->slab_lo = lo;
 	s->slab_hi = hi;
 	s->binned = false;

@@ -18,8 +18,12 @@
 //               definite operator (tested).
 // Launches per V-cycle and level: k_mg_presmooth, k_mg_residual_restrict on the way down, k_mg_prolong_postsmooth on the
 // way up; the coarsest level (one tile) is solved by many sweeps inside one wave.
+// Slabs (dist.hip): the finest levels are distributed like the fine grid (own tiles, one slice per slab face exchanged where
+// a stencil crosses it), the coarser ones are replicated through one sum all-reduce of the restricted residual -- the same
+// V-cycle as on a single domain, so the iteration count does not depend on the decomposition (see lfa_mg::n_dist).
 #include "pcg.h"
 
+#include <limits.h>
 #include <math.h>
 #include <stdlib.h>
 
@@ -38,19 +42,28 @@ struct lfa_mg_level {
 	int n_tiles = 0;       // active tiles (hold unknowns or children that do)
 	int *tiles = nullptr;  // device, ascending tile id
 	int *nbr = nullptr;    // device, MG_NBR_STRIDE ints per slot
-	uint8_t *ctype = nullptr;  // device, whole padded grid: 0 air, 1 fluid, 2 solid   (levels >= 1)
+	uint8_t *ctype = nullptr;  // device, whole padded grid: MT_SOLID / MT_FLUID / MT_AIR (levels >= 1)
 	uint8_t *abits = nullptr;  // device, whole padded grid                            (levels >= 1; level 0: s->abits)
 	// device, whole padded grid: right-hand side, pre-smoothed iterate, final iterate (the up-kernel reads the ring of x while
 	// neighbouring waves store y)                                                     (levels >= 1; level 0: vr, vq, vz)
 	void *b = nullptr, *x = nullptr, *y = nullptr;
 	size_t cap_tiles = 0;
+	int lo_layer = 0, hi_layer = 0;  // owned tile layers of this level (slabs: distributed levels only)
 };
 struct lfa_mg {
 	int n_levels = 0;
 	lfa_mg_level lv[MG_MAX_LEVELS];
 	size_t elem = 0;
 	std::vector<int> host_tiles;  // particle tiles the tile lists / neighbour tables on the device were built for
+	// Slabs: levels 0 .. n_dist - 1 are distributed like the fine grid (every rank runs its own tiles, one slice per slab face
+	// and level is exchanged); the levels from n_dist on are small and replicated: every rank holds the whole level, the
+	// restricted residual is combined by a sum all-reduce and each rank runs the identical remaining V-cycle.
+	int n_dist = 0;
+	std::vector<int> host_top;    // active tiles of level n_dist (all ranks') the replicated lists were built for
 };
+// A level stays distributed while no tile layer straddles a slab face, and its ghost types follow from the one fine ghost tile
+// layer a rank mirrors (8 cells = one slice of level 3).
+#define MG_DIST_MAX 4
 
 namespace {
 #define MG_FENCE()                                             \
@@ -59,7 +72,8 @@ namespace {
 		__builtin_amdgcn_wave_barrier();                       \
 	} while (0)
 
-enum { MT_AIR = 0, MT_FLUID = 1, MT_SOLID = 2 };
+// ordered so that the coarsening rule is a maximum (slabs combine the types of a replicated level by a max all-reduce)
+enum { MT_SOLID = 0, MT_FLUID = 1, MT_AIR = 2 };
 
 // ------------------------------------------------------------------------------------------------ set-up kernels
 /// Level-0 cell type for the coarsening rule, from the simulation's own arrays (cell_type_at / is_unknown_at of
@@ -73,11 +87,13 @@ __device__ inline int fine_type(const uint32_t *tile_flag, const uint32_t *cell_
 	return cell_count[b] > 0 ? MT_FLUID : MT_AIR;
 }
 
-/// Types of level 1 from the fine grid, one thread per coarse cell of the whole padded coarse grid.
-__global__ void k_mg_types_from_fine(GridDims gf, GridDims gc, size_t ncp_c, const uint32_t *tile_flag, const uint32_t *cell_count,
-                                     const uint8_t *ctype, const uint8_t *solid, uint8_t *out) {
-	const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= ncp_c) return;
+/// Types of level 1 from the fine grid, one thread per coarse cell c0 .. c0 + count - 1 of the padded coarse grid. Children
+/// with z outside [zlo, zhi) (fine cells) count as walls: the neutral element of the rule (slabs, replicated level).
+__global__ void k_mg_types_from_fine(GridDims gf, GridDims gc, size_t c0, size_t count, int zlo, int zhi, const uint32_t *tile_flag,
+                                     const uint32_t *cell_count, const uint8_t *ctype, const uint8_t *solid, uint8_t *out) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= count) return;
+	const size_t c = c0 + i;
 	const int tile = (int)(c >> 9), l = (int)(c & 511);
 	int tx, ty, tz;
 	tile_coords(gc, tile, tx, ty, tz);
@@ -86,16 +102,17 @@ __global__ void k_mg_types_from_fine(GridDims gf, GridDims gc, size_t ncp_c, con
 	for (int k = 0; k < 8; ++k) {
 		const int x = 2 * X + (k & 1), y = 2 * Y + ((k >> 1) & 1), z = 2 * Z + (k >> 2);
 		int t = MT_SOLID;  // outside the grid: a wall (mac_grid.cpp:26-31)
-		if (in_grid(gf, x, y, z)) t = fine_type(tile_flag, cell_count, ctype, solid, blocked_index(gf, x, y, z));
+		if (in_grid(gf, x, y, z) && z >= zlo && z < zhi) t = fine_type(tile_flag, cell_count, ctype, solid, blocked_index(gf, x, y, z));
 		any_air |= t == MT_AIR;
 		any_fluid |= t == MT_FLUID;
 	}
 	out[c] = (uint8_t)(!in_grid(gc, X, Y, Z) ? MT_SOLID : (any_air ? MT_AIR : (any_fluid ? MT_FLUID : MT_SOLID)));
 }
 /// Types of level l + 1 from level l.
-__global__ void k_mg_types_coarsen(GridDims gf, GridDims gc, size_t ncp_c, const uint8_t *tf, uint8_t *out) {
-	const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= ncp_c) return;
+__global__ void k_mg_types_coarsen(GridDims gf, GridDims gc, size_t c0, size_t count, int zlo, int zhi, const uint8_t *tf, uint8_t *out) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= count) return;
+	const size_t c = c0 + i;
 	const int tile = (int)(c >> 9), l = (int)(c & 511);
 	int tx, ty, tz;
 	tile_coords(gc, tile, tx, ty, tz);
@@ -103,7 +120,7 @@ __global__ void k_mg_types_coarsen(GridDims gf, GridDims gc, size_t ncp_c, const
 	bool any_air = false, any_fluid = false;
 	for (int k = 0; k < 8; ++k) {
 		const int x = 2 * X + (k & 1), y = 2 * Y + ((k >> 1) & 1), z = 2 * Z + (k >> 2);
-		const int t = in_grid(gf, x, y, z) ? tf[blocked_index(gf, x, y, z)] : MT_SOLID;
+		const int t = (in_grid(gf, x, y, z) && z >= zlo && z < zhi) ? tf[blocked_index(gf, x, y, z)] : MT_SOLID;
 		any_air |= t == MT_AIR;
 		any_fluid |= t == MT_FLUID;
 	}
@@ -577,6 +594,9 @@ __global__ void __launch_bounds__(MG_TAIL_WAVES * 64) k_mg_tail(MgTail<real> T, 
 }
 
 int mg_grid(int n_tiles) { return pcg_grid(n_tiles); }
+/// Slab mode of the hierarchy. A one-rank communicator needs none of it; LFA_MG_DIST_SINGLE=1 runs it anyway (tests: the array
+/// all-reduces then go through the real transport).
+bool mg_dist(const lfa_sim *s) { return s->dist && (s->dist->nranks > 1 || getenv("LFA_MG_DIST_SINGLE")); }
 }  // namespace
 
 // ================================================================================================= host side
@@ -605,7 +625,11 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 		gs.push_back(c);
 	}
 	const int nl = (int)gs.size();
-	const bool realloc_all = M.n_levels != nl || M.elem != sizeof(real) || (nl > 1 && (M.lv[1].g.nx != gs[1].nx || M.lv[1].g.ny != gs[1].ny || M.lv[1].g.nz != gs[1].nz));
+	const bool dist = mg_dist(s);
+	const int D = dist ? std::min({MG_DIST_MAX, s->slab_align + 1, nl - 1}) : 0;
+	if (dist && D < 1) return lfa_fail(s, LFA_E_INVALID, "multigrid on slabs needs at least two levels");
+	const bool realloc_all = M.n_levels != nl || M.elem != sizeof(real) || M.n_dist != D ||
+	                         (nl > 1 && (M.lv[1].g.nx != gs[1].nx || M.lv[1].g.ny != gs[1].ny || M.lv[1].g.nz != gs[1].nz));
 	if (realloc_all) {
 		LFA_HIP(s, hipStreamSynchronize(s->stream));
 		for (auto &L : M.lv) {
@@ -616,6 +640,9 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 		}
 		M.n_levels = nl;
 		M.elem = sizeof(real);
+		M.n_dist = D;
+		M.host_tiles.clear();
+		M.host_top.clear();
 		for (int l = 0; l < nl; ++l) {
 			lfa_mg_level &L = M.lv[l];
 			L.g = gs[l];
@@ -626,30 +653,69 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 			LFA_HIP(s, hipMalloc(&L.x, L.ncp * sizeof(real)));
 			LFA_HIP(s, hipMalloc(&L.b, L.ncp * sizeof(real)));
 			LFA_HIP(s, hipMalloc(&L.y, L.ncp * sizeof(real)));
+			LFA_HIP(s, hipMemsetAsync(L.ctype, MT_SOLID, L.ncp, s->stream));
 		}
 	}
+	for (int l = 0; l < nl; ++l) {
+		M.lv[l].lo_layer = dist ? s->slab_lo >> l : 0;
+		M.lv[l].hi_layer = (!dist || s->slab_hi == s->g.ntz) ? gs[l].ntz : s->slab_hi >> l;
+	}
+	// the part of a level's arrays this rank touches: its own tile layers and one ghost layer per side (distributed levels)
+	auto layer_range = [&](int l, int &t0, int &t1) {
+		const lfa_mg_level &L = M.lv[l];
+		const int per = gs[l].ntx * gs[l].nty;
+		if (dist && l < D) {
+			t0 = std::max(L.lo_layer - 1, 0) * per;
+			t1 = std::min(L.hi_layer + 1, gs[l].ntz) * per;
+		} else {
+			t0 = 0;
+			t1 = gs[l].nt;
+		}
+	};
 	// active tiles per level on the host: a tile is active if one of its child tiles is
-	std::vector<int> tiles(s->n_ptiles);
-	LFA_HIP(s, hipMemcpyAsync(tiles.data(), s->ptiles, (size_t)s->n_ptiles * 4, hipMemcpyDeviceToHost, s->stream));
+	const int n_all = dist ? s->n_ptiles_all : s->n_ptiles;
+	std::vector<int> tiles(n_all);  // slabs: with the neighbours' particle tiles of the adjacent layers (ascending ids all the same)
+	LFA_HIP(s, hipMemcpyAsync(tiles.data(), dist ? s->ptiles_all : s->ptiles, (size_t)n_all * 4, hipMemcpyDeviceToHost, s->stream));
 	LFA_HIP(s, hipStreamSynchronize(s->stream));
 	// The tile structure changes far less often than its contents: when the particle tiles are the ones of the last solve, the
 	// lists and neighbour tables on the device are kept (and no vector can hold values of a tile that has left the set).
-	const bool same_tiles = !realloc_all && tiles == M.host_tiles;
-	if (!same_tiles) {
-		std::vector<std::vector<int>> act(nl);
-		act[0] = tiles;
-		for (int l = 1; l < nl; ++l) {
-			const GridDims &f = gs[l - 1], &c = gs[l];
-			std::vector<int> &o = act[l];
-			o.reserve(act[l - 1].size() / 4 + 8);
-			for (int t : act[l - 1]) {
-				int tx, ty, tz;
-				tile_coords(f, t, tx, ty, tz);
-				o.push_back((tx >> 1) + c.ntx * ((ty >> 1) + c.nty * (tz >> 1)));
-			}
-			std::sort(o.begin(), o.end());
-			o.erase(std::unique(o.begin(), o.end()), o.end());
+	bool same_tiles = !realloc_all && tiles == M.host_tiles;
+	std::vector<std::vector<int>> act(nl);
+	auto parents = [&](int l) {  // active tiles of level l from those of level l - 1
+		const GridDims &f = gs[l - 1], &c = gs[l];
+		std::vector<int> &o = act[l];
+		o.clear();
+		o.reserve(act[l - 1].size() / 4 + 8);
+		for (int t : act[l - 1]) {
+			int tx, ty, tz;
+			tile_coords(f, t, tx, ty, tz);
+			o.push_back((tx >> 1) + c.ntx * ((ty >> 1) + c.nty * (tz >> 1)));
 		}
+		std::sort(o.begin(), o.end());
+		o.erase(std::unique(o.begin(), o.end()), o.end());
+	};
+	if (dist || !same_tiles) {
+		if (dist) act[0].assign(tiles.begin() + s->p_off, tiles.begin() + s->p_off + s->n_ptiles);
+		else act[0] = tiles;
+		for (int l = 1; l < nl; ++l) {
+			parents(l);
+			if (dist && l == D) {
+				// the first replicated level: union of every rank's active tiles (one flag byte per tile, max all-reduce)
+				std::vector<uint8_t> flag((size_t)gs[l].nt, 0);
+				for (int t : act[l]) flag[t] = 1;
+				LFA_TRY(lfa_dist_ensure_xbuf(s, 0, flag.size()));
+				LFA_HIP(s, hipMemcpyAsync(s->xbuf[0], flag.data(), flag.size(), hipMemcpyHostToDevice, s->stream));
+				LFA_TRY(s->dist->allreduce_buf(s, s->xbuf[0], flag.size(), LFA_RED_U8, true));
+				LFA_HIP(s, hipMemcpyAsync(flag.data(), s->xbuf[0], flag.size(), hipMemcpyDeviceToHost, s->stream));
+				LFA_HIP(s, hipStreamSynchronize(s->stream));
+				act[l].clear();
+				for (int t = 0; t < gs[l].nt; ++t)
+					if (flag[t]) act[l].push_back(t);
+				same_tiles = same_tiles && act[l] == M.host_top;
+			}
+		}
+	}
+	if (!same_tiles) {
 		for (int l = 0; l < nl; ++l) {
 			lfa_mg_level &L = M.lv[l];
 			const GridDims &g = gs[l];
@@ -664,7 +730,9 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 				LFA_HIP(s, hipMalloc(&L.nbr, L.cap_tiles * MG_NBR_STRIDE * 4));
 			}
 			if (a.empty()) continue;
-			// neighbour tiles by binary search in the sorted list
+			// neighbour tiles by binary search in the sorted list. Across a slab face of a distributed level the neighbour belongs
+			// to another rank: on the finest level it is active if it is one of that rank's particle tiles, on the others it always
+			// counts as active (its slice arrives with the layer exchange; an inactive tile holds zeros and no unknowns)
 			std::vector<int> nbr(a.size() * MG_NBR_STRIDE, 0);
 			const int sy = g.ntx, sz = g.ntx * g.nty;
 			for (size_t i = 0; i < a.size(); ++i) {
@@ -672,8 +740,15 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 				tile_coords(g, a[i], tx, ty, tz);
 				const int cand[6] = {tx > 0 ? a[i] - 1 : -1,           tx + 1 < g.ntx ? a[i] + 1 : -1, ty > 0 ? a[i] - sy : -1,
 				                     ty + 1 < g.nty ? a[i] + sy : -1, tz > 0 ? a[i] - sz : -1,          tz + 1 < g.ntz ? a[i] + sz : -1};
-				for (int k = 0; k < 6; ++k)
-					nbr[i * MG_NBR_STRIDE + k] = (cand[k] >= 0 && std::binary_search(a.begin(), a.end(), cand[k])) ? cand[k] : -1;
+				for (int k = 0; k < 6; ++k) {
+					int v = -1;
+					const int nz = tz + (k == 4 ? -1 : (k == 5 ? 1 : 0));
+					if (cand[k] < 0) v = -1;
+					else if (dist && l < D && (nz < L.lo_layer || nz >= L.hi_layer))
+						v = (l > 0 || std::binary_search(tiles.begin(), tiles.end(), cand[k])) ? cand[k] : -1;
+					else v = std::binary_search(a.begin(), a.end(), cand[k]) ? cand[k] : -1;
+					nbr[i * MG_NBR_STRIDE + k] = v;
+				}
 				nbr[i * MG_NBR_STRIDE + 6] = a[i];
 			}
 			LFA_HIP(s, hipMemcpyAsync(L.tiles, a.data(), a.size() * 4, hipMemcpyHostToDevice, s->stream));
@@ -681,31 +756,55 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 			LFA_HIP(s, hipStreamSynchronize(s->stream));  // the host vectors go out of scope
 		}
 		M.host_tiles = tiles;
+		if (dist) M.host_top = act[D];
 	}
 	// types and operators of the coarse levels
 	for (int l = 1; l < nl; ++l) {
 		lfa_mg_level &L = M.lv[l];
-		const unsigned grid = (unsigned)((L.ncp + 255) / 256);
+		int t0, t1, zlo = 0, zhi = INT_MAX;
+		layer_range(l, t0, t1);
+		if (dist && l == D) {
+			// the rank's share of the first replicated level: children outside its own layers count as walls (the neutral type),
+			// the shares are combined by a max all-reduce (air > fluid > wall = the coarsening rule)
+			const lfa_mg_level &F = M.lv[l - 1];
+			const int per = gs[l].ntx * gs[l].nty;
+			LFA_HIP(s, hipMemsetAsync(L.ctype, MT_SOLID, L.ncp, s->stream));
+			t0 = (F.lo_layer >> 1) * per;
+			t1 = std::min((F.hi_layer + 1) >> 1, gs[l].ntz) * per;
+			zlo = F.lo_layer * 8;
+			zhi = F.hi_layer * 8;
+		}
+		const size_t c0 = (size_t)t0 * 512, count = (size_t)(t1 - t0) * 512;
+		const unsigned grid = (unsigned)((count + 255) / 256);
 		if (l == 1)
-			hipLaunchKernelGGL(k_mg_types_from_fine, dim3(grid), dim3(256), 0, s->stream, gs[0], gs[1], L.ncp, (const uint32_t *)s->tile_flag,
-			                   (const uint32_t *)s->cell_count, (const uint8_t *)s->ctype, (const uint8_t *)s->solid, L.ctype);
+			hipLaunchKernelGGL(k_mg_types_from_fine, dim3(grid), dim3(256), 0, s->stream, gs[0], gs[1], c0, count, zlo, zhi,
+			                   (const uint32_t *)s->tile_flag, (const uint32_t *)s->cell_count, (const uint8_t *)s->ctype,
+			                   (const uint8_t *)s->solid, L.ctype);
 		else
-			hipLaunchKernelGGL(k_mg_types_coarsen, dim3(grid), dim3(256), 0, s->stream, gs[l - 1], gs[l], L.ncp,
+			hipLaunchKernelGGL(k_mg_types_coarsen, dim3(grid), dim3(256), 0, s->stream, gs[l - 1], gs[l], c0, count, zlo, zhi,
 			                   (const uint8_t *)M.lv[l - 1].ctype, L.ctype);
 		LFA_LAUNCH_CHECK(s);
+		if (dist && l == D) LFA_TRY(s->dist->allreduce_buf(s, L.ctype, L.ncp, LFA_RED_U8, true));
 		// vectors of levels >= 1 are read where no tile of this solve writes (parents of ring cells): they must be zero there.
 		// Tiles of the current set are rewritten by every V-cycle, so clearing is only needed when the set has changed.
 		if (!same_tiles) {
-			LFA_HIP(s, hipMemsetAsync(L.x, 0, L.ncp * sizeof(real), s->stream));
-			LFA_HIP(s, hipMemsetAsync(L.b, 0, L.ncp * sizeof(real), s->stream));
-			LFA_HIP(s, hipMemsetAsync(L.y, 0, L.ncp * sizeof(real), s->stream));
-			LFA_HIP(s, hipMemsetAsync(L.abits, 0, L.ncp, s->stream));
+			layer_range(l, t0, t1);
+			const size_t o = (size_t)t0 * 512, n = (size_t)(t1 - t0) * 512;
+			LFA_HIP(s, hipMemsetAsync((real *)L.x + o, 0, n * sizeof(real), s->stream));
+			LFA_HIP(s, hipMemsetAsync((real *)L.b + o, 0, n * sizeof(real), s->stream));
+			LFA_HIP(s, hipMemsetAsync((real *)L.y + o, 0, n * sizeof(real), s->stream));
+			LFA_HIP(s, hipMemsetAsync(L.abits + o, 0, n, s->stream));
 		}
 		if (L.n_tiles) {
 			hipLaunchKernelGGL(k_mg_abits, dim3(std::min(L.n_tiles, 4096)), dim3(256), 0, s->stream, (const int *)L.tiles, L.n_tiles, gs[l],
 			                   (const uint8_t *)L.ctype, L.abits);
 			LFA_LAUNCH_CHECK(s);
 		}
+	}
+	// slabs: which cells across a slab face are unknowns (the up-sweep corrects ring values of unknowns only)
+	for (int l = 0; dist && l < D; ++l) {
+		if (l == 0) LFA_TRY(lfa_dist_exchange_slices(s, s->abits, 1));
+		else LFA_TRY(lfa_dist_exchange_layer_slices(s, M.lv[l].abits, 1, gs[l].ntx * gs[l].nty, M.lv[l].lo_layer, M.lv[l].hi_layer));
 	}
 	return LFA_OK;
 }
@@ -741,14 +840,29 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 	int tail = last, tail_tiles = MG_TAIL_TILES;  // first level handled by the single-workgroup tail
 	if (const char *e = getenv("LFA_MG_TAIL_TILES")) tail_tiles = atoi(e);
 	while (tail > 1 && M.lv[tail - 1].n_tiles <= tail_tiles) --tail;
+	// slabs: levels < D run on the rank's own tiles with one slice per slab face exchanged where a stencil crosses it;
+	// levels >= D are replicated (identical work on every rank), so the tail workgroup may only hold replicated levels
+	const int D = mg_dist(s) ? M.n_dist : 0;
+	tail = std::max(tail, D);
+	auto exchange_level = [&](int l, void *vec) -> int {
+		if (l == 0) return lfa_dist_exchange_slices(s, vec, (int)sizeof(real));
+		return lfa_dist_exchange_layer_slices(s, vec, (int)sizeof(real), M.lv[l].g.ntx * M.lv[l].g.nty, M.lv[l].lo_layer, M.lv[l].hi_layer);
+	};
 	for (int l = 0; l < tail; ++l) {
 		const MgLv<real> L = lvl(l);
 		const int G = mg_grid(L.n_tiles);
 		if (!(l == 0 && level0_presmoothed) && (parts & (l == 0 ? MG_PART_PRE0 : MG_PART_COARSE)))
 			hipLaunchKernelGGL(k_mg_presmooth<real>, dim3(G), dim3(256), 0, s->stream, L, st);
+		if (l < D) {
+			LFA_TRY(exchange_level(l, L.x));  // the residual needs the pre-smoothed iterate across the slab faces
+			// the first replicated level collects the restricted residual of every rank: zero where this rank has no children
+			if (l + 1 == D) LFA_HIP(s, hipMemsetAsync(M.lv[D].b, 0, M.lv[D].ncp * sizeof(real), s->stream));
+		}
 		if (parts & (l == 0 ? MG_PART_DOWN0 : MG_PART_COARSE))
 			hipLaunchKernelGGL(k_mg_residual_restrict<real>, dim3(G), dim3(256), 0, s->stream, L, M.lv[l + 1].g, (real *)M.lv[l + 1].b, st);
 		LFA_LAUNCH_CHECK(s);
+		if (l < D && l + 1 == D)
+			LFA_TRY(s->dist->allreduce_buf(s, M.lv[D].b, M.lv[D].ncp, sizeof(real) == 4 ? LFA_RED_F32 : LFA_RED_F64, false));
 	}
 	if (parts & MG_PART_COARSE) {
 		MgTail<real> T;
@@ -773,6 +887,8 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 			hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, false>), dim3(G), dim3(256), 0, s->stream, L, M.lv[l + 1].g,
 			                   (const real *)M.lv[l + 1].y, (real)1, (double *)nullptr, st);
 		LFA_LAUNCH_CHECK(s);
+		// the finer level corrects its ring cells across a slab face with this level's result there
+		if (l >= 1 && l < D) LFA_TRY(exchange_level(l, L.y));
 	}
 	return LFA_OK;
 }

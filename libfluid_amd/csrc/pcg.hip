@@ -1623,7 +1623,7 @@ template <typename real> static int mic_apply(lfa_sim *s, double *part_sigma, bo
 
 template <typename real> static int build_system_t(lfa_sim *s, double dt) {
 	LFA_TRY(lfa_build_rhs(s, dt));
-	if (s->n_ptiles) LFA_TRY(mic_factor<real>(s));
+	if (s->n_ptiles || (s->dist && is_mg(s))) LFA_TRY(mic_factor<real>(s));  // the multigrid set-up has collectives: every rank takes part
 	s->system_valid = true;
 	return LFA_OK;
 }

@@ -106,6 +106,40 @@ def test_virtual_slabs_match_single_domain(size, block, method, bounds, precond)
         assert itn[0] == it1
 
 
+MG_CASES = [
+    # size, block, method, bounds -> distributed levels (common alignment of the interior bounds)
+    ((16, 16, 32), ((2, 0, 3), (14, 10, 29)), lfa.APIC, [0, 2, 4]),                 # aligned to 2 layers: levels 0-1 distributed
+    ((16, 16, 32), ((2, 0, 3), (14, 10, 29)), lfa.FLIP_BLEND, [0, 1, 3, 4]),        # odd bounds: only level 0 distributed
+    ((24, 16, 40), ((0, 0, 0), (24, 8, 40)), lfa.APIC, [0, 1, 2, 3, 5]),            # 4 slabs, ragged z
+    ((16, 16, 32), ((2, 0, 3), (14, 10, 13)), lfa.PIC, [0, 2, 4]),                  # fluid only in the lower slab
+    ((32, 32, 128), ((0, 0, 0), (32, 12, 128)), lfa.APIC, [0, 8, 16]),              # aligned to 8 layers: levels 0-3 distributed
+    ((32, 32, 128), ((4, 0, 10), (30, 20, 100)), lfa.APIC, [0, 4, 8, 12, 16]),      # 4 slabs, levels 0-2 distributed
+    ((40, 24, 96), ((0, 0, 0), (40, 10, 50)), lfa.PIC, [0, 4, 12]),                 # unequal slabs, free surface ends inside a slab
+]
+
+
+@pytest.mark.parametrize("dtype", [lfa.PCG_F32, lfa.PCG_F64])
+@pytest.mark.parametrize("size,block,method,bounds", MG_CASES)
+def test_virtual_slabs_multigrid_matches_single_domain(size, block, method, bounds, dtype):
+    """The multigrid preconditioner on slabs is the single-domain V-cycle: distributed levels exchange one slice per slab
+    face, the coarse levels are replicated through a sum all-reduce of the restricted residual (exact: every cell has one
+    contributing rank). So the iteration counts are those of the single domain and the results agree to rounding."""
+    solid = util.scenes.sphere_solid_cells(size, (size[0] / 2, 3, size[2] / 2), 2.6)
+    solid = solid[(solid[:, 0] < block[0][0]) | (solid[:, 0] >= block[1][0]) | (solid[:, 1] >= block[1][1])]
+    kw = dict(precond=lfa.PRECOND_MULTIGRID, pcg_dtype=dtype)
+    c1, p1, it1 = run_single(size, block, method, 2, solid=solid, **kw)
+    cn, pn, itn = run_slabs(size, block, method, 2, bounds, solid=solid, **kw)
+    assert len(pn) == len(p1)
+    assert all(it == itn[0] for it in itn), "ranks must agree on the iteration count"
+    assert np.array_equal(cn["type"], c1["type"])
+    # dot products are summed in another order on slabs: allow one iteration of difference at the stopping threshold
+    assert all(abs(a - b) <= 1 for a, b in zip(itn[0], it1)), (itn[0], it1)
+    vel_atol = 1e-5 * 981.0 * util.DT
+    util.assert_close(cn["vel"], c1["vel"], 1e-4, "grid velocities, slabs vs single domain", atol=vel_atol)
+    i1, i2 = util.order_by_position(p1), util.order_by_position(pn)
+    util.assert_close(pn["vel"][i2], p1["vel"][i1], 1e-4, "particle velocities, slabs vs single domain", atol=vel_atol)
+
+
 def run_time_steps(size, block, method, steps, bounds=None, solid=None, **kw):
     """Full device-resident time_step (advect, collide, hot path, position correction); with `bounds` on virtual slabs.
     Returns particles ordered by global id and, for slabs, the per-rank particle counts before / after."""
@@ -178,12 +212,17 @@ def test_virtual_slabs_full_time_step_with_migration(size, block, method, bounds
 @pytest.mark.skipif(os.environ.get("LFA_TEST_RCCL") != "1",
                     reason="loading the 570 MB librccl on a fresh box takes ~4 min; set LFA_TEST_RCCL=1 "
                            "(last run: profiles/r01_rccl_single_rank.txt)")
-def test_rccl_transport_single_rank():
+@pytest.mark.parametrize("precond,dtype", [(lfa.PRECOND_MULTILEVEL, lfa.PCG_F64), (lfa.PRECOND_MULTIGRID, lfa.PCG_F32),
+                                           (lfa.PRECOND_MULTIGRID, lfa.PCG_F64)])
+def test_rccl_transport_single_rank(precond, dtype, monkeypatch):
     """The RCCL transport (dlopen'ed librccl: unique id, communicator, all-reduces on the handle's stream) with a
     one-rank communicator: the whole slab code path runs (ghost-free), the result equals the plain single-domain run.
+    With the multigrid preconditioner the slab mode of the hierarchy is forced (LFA_MG_DIST_SINGLE), so the byte-max and
+    float/double-sum array all-reduces of its replicated levels go through ncclAllReduce.
     Boxes here have one GPU, so the N > 1 protocol is covered by the in-process transport above."""
+    monkeypatch.setenv("LFA_MG_DIST_SINGLE", "1")
     size, block = (16, 16, 32), ((2, 0, 3), (14, 10, 29))
-    kw = dict(precond=lfa.PRECOND_MULTILEVEL, pcg_dtype=lfa.PCG_F64)
+    kw = dict(precond=precond, pcg_dtype=dtype)
     c1, p1, it1 = run_single(size, block, lfa.APIC, 2, **kw)
     s = lfa.Sim(size, method=lfa.APIC, blending=0.95, **kw)
     s.init_rccl_slab(0, 1, lfa.rccl_unique_id(), [0, 4])
