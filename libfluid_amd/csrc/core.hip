@@ -696,26 +696,60 @@ extern "C" int lfa_upload_cells(lfa_sim *s, const void *aos32) {
 }
 
 // =============================================================================================== binning (a2)
-/// Pass 1: particles per tile + rank of each particle inside its tile. One atomic per (wave, distinct tile):
-/// particles arrive tile-coherent (they were binned last step and move < 1 tile), so a wave sees 1-3 distinct tiles.
-__global__ void k_tile_count(const uint32_t *key, size_t n, uint32_t *tile_count, uint32_t *rank) {
-	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	bool live = i < n && key[i] != 0xFFFFFFFFu;
-	uint32_t tile = live ? key[i] >> 9 : 0xFFFFFFFFu;
+/// Pass 1: particles per tile + rank of each particle inside its tile. A wave takes TC_CHUNKS x 64 consecutive particles and
+/// issues one atomic per distinct tile among them: particles arrive tile-coherent (they were binned last step and move < 1
+/// tile), so that is 1-3 atomics per 256 particles, and a wave's particles of one tile get consecutive ranks in input order
+/// (the scatter then writes runs of up to 1 KB per field). One particle per lane spent its time waiting for the returning
+/// atomic (0.54 ms at C4; 4 chunks: see DESIGN.md).
+#define TC_CHUNKS 8
+__global__ void __launch_bounds__(256) k_tile_count(const uint32_t *key, size_t n, uint32_t *tile_count, uint32_t *rank) {
 	const int lane = threadIdx.x & 63;
-	uint32_t my_rank = 0;
-	unsigned long long todo = __ballot(live);
-	while (todo) {
-		int leader = __ffsll((long long)todo) - 1;
-		uint32_t t = __shfl(tile, leader, 64);
-		unsigned long long same = __ballot(live && tile == t) & todo;
-		uint32_t base = 0;
-		if (lane == leader) base = atomicAdd(&tile_count[t], (uint32_t)__popcll(same));
-		base = __shfl(base, leader, 64);
-		if (live && tile == t) my_rank = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-		todo &= ~same;
+	const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const size_t i0 = wave * (64 * TC_CHUNKS) + lane;
+	const unsigned long long lt = (1ull << lane) - 1ull;
+	uint32_t tile[TC_CHUNKS], my_rank[TC_CHUNKS];
+	unsigned long long todo[TC_CHUNKS];
+#pragma unroll
+	for (int c = 0; c < TC_CHUNKS; ++c) {
+		const size_t i = i0 + 64 * c;
+		const uint32_t k = i < n ? key[i] : 0xFFFFFFFFu;
+		tile[c] = k != 0xFFFFFFFFu ? k >> 9 : 0xFFFFFFFFu;
+		todo[c] = __ballot(k != 0xFFFFFFFFu);
+		my_rank[c] = 0;
 	}
-	if (live) rank[i] = my_rank;
+	for (;;) {
+		// the first pending particle (chunk-major) names the tile of this round
+		uint32_t t = 0xFFFFFFFFu;
+		bool found = false;
+#pragma unroll
+		for (int c = 0; c < TC_CHUNKS; ++c)
+			if (!found && todo[c]) {
+				t = __shfl(tile[c], __ffsll((long long)todo[c]) - 1, 64);
+				found = true;
+			}
+		if (!found) break;
+		unsigned long long same[TC_CHUNKS];
+		uint32_t total = 0;
+#pragma unroll
+		for (int c = 0; c < TC_CHUNKS; ++c) {
+			same[c] = __ballot(tile[c] == t) & todo[c];
+			total += (uint32_t)__popcll(same[c]);
+		}
+		uint32_t base = 0;
+		if (lane == 0) base = atomicAdd(&tile_count[t], total);
+		base = __shfl(base, 0, 64);
+#pragma unroll
+		for (int c = 0; c < TC_CHUNKS; ++c) {
+			if ((same[c] >> lane) & 1ull) my_rank[c] = base + (uint32_t)__popcll(same[c] & lt);
+			base += (uint32_t)__popcll(same[c]);
+			todo[c] &= ~same[c];
+		}
+	}
+#pragma unroll
+	for (int c = 0; c < TC_CHUNKS; ++c) {
+		const size_t i = i0 + 64 * c;
+		if (tile[c] != 0xFFFFFFFFu) rank[i] = my_rank[c];
+	}
 }
 
 __global__ void k_tile_flags(const uint32_t *tile_count, uint32_t *flag, int nt) {
@@ -836,7 +870,7 @@ extern "C" int lfa_hash_particles(lfa_sim *s) {
 
 	LFA_HIP(s, hipMemsetAsync(s->tile_count, 0, (size_t)(nt + 1) * 4, s->stream));
 	if (n) {
-		hipLaunchKernelGGL(k_tile_count, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, src.key, n,
+		hipLaunchKernelGGL(k_tile_count, dim3((unsigned)((n + 256 * TC_CHUNKS - 1) / (256 * TC_CHUNKS))), dim3(256), 0, s->stream, src.key, n,
 		                   s->tile_count, s->rank);
 		LFA_LAUNCH_CHECK(s);
 	}
