@@ -38,6 +38,8 @@
 // Over-relaxation of the Gauss-Seidel update (red-black SOR as the smoother; forward and backward sweeps stay adjoint).
 // Measured iterations at C2 / C3 / C4: 1.0: 15 / 18 / 19, 1.08: 14 / 16 / 17, 1.15: - / 15 / 16, 1.2: 13 / 15 / 16, 1.3: - / 17 / 17, 1.5: - / 29 / 31.
 #define MG_OMEGA 1.15
+// Also measured (C4 / C3, with omega 1.15 = 16 / 15 iterations): 3 sweeps per step on the levels below the finest: 15 / 14 but
+// 8 % more time per iteration; restriction factor 0.4 / 0.45 / 0.6 instead of 0.5: 19 / 16 / 23 iterations at C4.
 
 struct lfa_mg_level {
 	GridDims g{};          // cells of this level
