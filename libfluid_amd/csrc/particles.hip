@@ -380,32 +380,65 @@ k_correct_tiled(const int *ptiles, int n_ptiles, ParticleSoA p, uint32_t *out_ke
 			const uint32_t j = __float_as_uint(sp.w);
 			const float tme[3] = {sp.x, sp.y, sp.z};  // exact fraction (the staged copy is block-relative)
 			const int c[3] = {cx, cy, cz};
+			// Every particle of a cell walks the same 3 x 3 x 3 cells, whole: the (up to 8) lanes of a cell then read the same LDS
+			// word at the same time. Skipping, per particle, the neighbour cells whose nearest face is beyond the kernel radius
+			// made the lanes of a cell read different words: the wave ran the longest trip count anyway and the LDS reads
+			// conflicted 3x (7.1 ms of pair tests at C4). Partners within the radius (0.71 cells) always lie in these cells, also
+			// for a particle stored with t == 1 (the reference visits c .. c + 2 for it, :13-15); all others contribute exactly 0.
 			int lo[3], hi[3];
-			const float re = rsqrtf((float)mp.inv_re2);  // kernel radius in cells: pairs further apart contribute exactly 0
 #pragma unroll
 			for (int d = 0; d < 3; ++d) {
-				const int ci = c[d] + (tme[d] >= 1.0f ? 1 : 0);  // unclamped index of compute_cell_index (:13-15)
-				const float tc = tme[d] >= 1.0f ? 0.0f : tme[d];
-				// the reference visits ci-1..ci+1; a neighbour cell whose nearest face is >= re away cannot hold a partner
-				lo[d] = (ci - 1 < 0 || tc >= re) ? ci : ci - 1;
-				hi[d] = (ci + 1 > nn[d] - 1 || 1.0f - tc >= re) ? ci : ci + 1;
-				if (lo[d] > nn[d] - 1) lo[d] = nn[d] - 1;
-				if (hi[d] > nn[d] - 1) hi[d] = nn[d] - 1;
+				lo[d] = c[d] - 1 < 0 ? 0 : c[d] - 1;
+				hi[d] = c[d] + 1 > nn[d] - 1 ? nn[d] - 1 : c[d] + 1;
 			}
 			float sx = 0.f, sy = 0.f, sz = 0.f;
+			float __attribute__((ext_vector_type(2))) s2x = 0.f, s2y = 0.f, s2z = 0.f;
 			const float inv_re2 = (float)mp.inv_re2;
 			for (int zz = lo[2]; zz <= hi[2]; ++zz)
 				for (int yy = lo[1]; yy <= hi[1]; ++yy) {
 					// the x-run of up to three cells is contiguous in the halo block: one LDS range
 					const int hrow = (lo[0] - ox) + 10 * (yy - oy) + 100 * (zz - oz);
 					const uint32_t b = off[hrow], e = off[hrow + (hi[0] - lo[0]) + 1];
+					// The pair test is what this kernel spends its time on, and it is VALU bound (PMC: 86 % VALU busy, 21 VALU
+					// instructions per candidate; a wave64 instruction issues over four cycles): two candidates per instruction
+					// with the packed fp32 operations (v_pk_add/mul/fma_f32), explicit FMAs, the self-pair left to the rare branch.
+					typedef float f2 __attribute__((ext_vector_type(2)));
+					auto pair2 = [&](uint32_t q, f2 qx, f2 qy, f2 qz) {
+						const f2 dx = mx - qx, dy = my - qy, dz = mz - qz;
+						const f2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+						const f2 kl = __builtin_elementwise_fma(-d2, (f2)inv_re2, (f2)1.0f);
+						if (kl.x > 0.0f || kl.y > 0.0f) {  // ~1 pair in 10 is inside the kernel radius
+							if (d2.x < 1e-12f || d2.y < 1e-12f) {
+								// coincident (or the particle itself): the reference adds a random unit-box vector (:584-587)
+#pragma unroll
+								for (int k = 0; k < 2; ++k) {
+									const float d2k = k ? d2.y : d2.x, klk = k ? kl.y : kl.x;
+									if (!(klk > 0.0f)) continue;
+									if (d2k < 1e-12f) {
+										if (q + k != me) { sx += hash_unit(me, q + k, 0); sy += hash_unit(me, q + k, 1); sz += hash_unit(me, q + k, 2); }
+									} else {
+										const float f = klk * klk * klk * rsqrtf(d2k);
+										sx += f * (k ? dx.y : dx.x); sy += f * (k ? dy.y : dy.x); sz += f * (k ? dz.y : dz.x);
+									}
+								}
+							} else {
+								const f2 klp = __builtin_elementwise_max(kl, (f2)0.0f);
+								f2 f = klp * klp * klp;
+								f.x *= rsqrtf(d2.x);
+								f.y *= rsqrtf(d2.y);
+								s2x = __builtin_elementwise_fma(f, dx, s2x);
+								s2y = __builtin_elementwise_fma(f, dy, s2y);
+								s2z = __builtin_elementwise_fma(f, dz, s2z);
+							}
+						}
+					};
 					auto pair = [&](uint32_t q, float qx, float qy, float qz) {
 						const float dx = mx - qx, dy = my - qy, dz = mz - qz;
-						const float d2 = dx * dx + dy * dy + dz * dz;
-						const float kl = 1.0f - d2 * inv_re2;
-						if (kl > 0.0f && q != me) {  // ~1 pair in 10 is inside the kernel radius
-							if (d2 < 1e-12f) {  // coincident: the reference adds a random unit-box vector (:584-587)
-								sx += hash_unit(me, q, 0); sy += hash_unit(me, q, 1); sz += hash_unit(me, q, 2);
+						const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+						const float kl = __builtin_fmaf(-d2, inv_re2, 1.0f);
+						if (kl > 0.0f) {
+							if (d2 < 1e-12f) {
+								if (q != me) { sx += hash_unit(me, q, 0); sy += hash_unit(me, q, 1); sz += hash_unit(me, q, 2); }
 							} else {
 								const float f = kl * kl * kl * rsqrtf(d2);
 								sx += f * dx; sy += f * dy; sz += f * dz;
@@ -418,10 +451,14 @@ k_correct_tiled(const int *ptiles, int n_ptiles, ParticleSoA p, uint32_t *out_ke
 						const float x0 = px[q], x1 = px[q + 1], x2 = px[q + 2], x3 = px[q + 3];
 						const float y0 = py[q], y1 = py[q + 1], y2 = py[q + 2], y3 = py[q + 3];
 						const float z0 = pz[q], z1 = pz[q + 1], z2 = pz[q + 2], z3 = pz[q + 3];
-						pair(q, x0, y0, z0); pair(q + 1, x1, y1, z1); pair(q + 2, x2, y2, z2); pair(q + 3, x3, y3, z3);
+						pair2(q, f2{x0, x1}, f2{y0, y1}, f2{z0, z1});
+						pair2(q + 2, f2{x2, x3}, f2{y2, y3}, f2{z2, z3});
 					}
 					for (; q < e; ++q) pair(q, px[q], py[q], pz[q]);
 				}
+			sx += s2x.x + s2x.y;
+			sy += s2y.x + s2y.y;
+			sz += s2z.x + s2z.y;
 			const double spring[3] = {(double)sx, (double)sy, (double)sz};
 			double from[3], to[3];
 #pragma unroll
