@@ -405,3 +405,44 @@ def test_properties_at_scale():
     t.solve(util.DT); t.apply_pressure(util.DT)
     util.assert_close(t.cells()["vel"], a, 1e-4, "binned vs atomic P2G at 128^3")
     t.close()
+
+
+def test_properties_at_full_size():
+    """BASELINE config 4 sizes (512^3 grid, 67 M particles, 8.4 M unknowns): no oracle run is affordable there, so
+    size-independent properties (what moves between host and device stays small: ids, unknown lists, pressures).
+    - a wall-to-wall tank 32 cells deep (the same particle and unknown counts as C4) is hydrostatic: p = rho |g| depth
+    - the projected field is divergence free
+    - the C4 dam break: binning is a permutation of the particle ids, the multigrid PCG converges in a few iterations,
+      and a second step from the updated particles works on the same unknown count."""
+    n = 512
+    s = lfa.Sim((n, n, n), pcg_dtype=lfa.PCG_F32)
+    s.seed_block((0, 0, 0), (n, 32, n))
+    assert s.counts()["particles"] == 67108864
+    s.hash(); s.p2g(); s.add_gravity(util.DT)
+    s.build_system(util.DT)
+    b0 = np.abs(s.b()).max()
+    p, res, it, rc = s.solve(util.DT)
+    assert rc == 0 and it <= 30, (rc, it)
+    fc = s.fluid_cells().astype(np.int64)
+    assert len(fc) == 8388608
+    y = (fc // n) % n
+    util.assert_close(p, 981.0 * (32 - y), P_REL, "hydrostatic pressure at 512^3")
+    s.apply_pressure(util.DT)
+    s.build_system(util.DT)
+    assert np.abs(s.b()).max() < 1e-3 * b0  # fp32 pressure: divergence floor ~1e-4 |b| (see test_properties_at_scale)
+    s.close()
+
+    cfg = util.scenes.CONFIGS["C4"]
+    s = lfa.Sim(cfg["size"], method=cfg["method"], blending=cfg["blending"])
+    s.seed_block(*cfg["block"])
+    its = []
+    for _ in range(2):
+        res, it, rc = s.step_hot(0.033)
+        assert rc == 0 and res < 1e-6
+        its.append(it)
+    assert max(its) <= 25, its
+    c = s.counts()
+    assert c["particles"] == 67108864 and c["unknowns"] == 8388608
+    ids = np.sort(s.particle_ids())
+    assert ids[0] == 0 and ids[-1] == len(ids) - 1 and np.all(np.diff(ids) == 1), "binning must permute the particles"
+    s.close()
