@@ -1667,6 +1667,10 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 		return lfa_fail(s, LFA_E_UNSUPPORTED, "the exact (hyperplane) MIC(0) schedule is single-GPU only");
 	LFA_TRY(build_system_t<real>(s, dt));
 	if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[18], s->stream));
+	// The host polls the solver state between chunks of iterations; iterations launched after convergence are no-ops but
+	// still cost their launches (~40 us each). The count barely changes from step to step, so the first chunk is as long
+	// as the previous solve, the following ones short. (Identical on every rank of a slab run: the scalars are all-reduced.)
+	const int first_chunk = s->last_iters > 0 ? (int)std::min<uint64_t>(s->last_iters, 64) : 8;
 	s->last_residual = 0.0;
 	s->last_iters = 0;
 	if (residual) *residual = 0.0;
@@ -1707,7 +1711,7 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 	LFA_TRY(mic_apply<real>(s, P + PART_SIG0));
 	if (dist) LFA_TRY(lfa_dist_allreduce(s, P + PART_SIG0, NS, 3, false));
 	const int maxit = (int)s->prm.max_iterations;
-	const int chunk = 8;
+	const int chunk = 4;
 	int done = -1, nan = 0, i = 0;
 	int *hstate = (int *)s->h_pinned;
 	// fused iteration (k_pcg_a / k_pcg_b): tile-local MIC(0) with or without the coarse levels, single domain or slabs
@@ -1730,7 +1734,7 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 	const int n_face_lo = dist && lfa_has_lo(s) ? s->n_own_first : 0, n_face_hi = dist && lfa_has_hi(s) ? s->n_own_last : 0;
 	const int g_face_lo = std::min(16, (n_face_lo + PCG_WAVES - 1) / PCG_WAVES), g_face_hi = std::min(16, (n_face_hi + PCG_WAVES - 1) / PCG_WAVES);
 	while (fused && i < maxit && done < 0) {
-		const int end = std::min(maxit, i + chunk);
+		const int end = std::min(maxit, i + (i == 0 ? first_chunk : chunk));
 		for (; i < end; ++i) {
 			const int po = i & 1, pn = po ^ 1;
 			// where a kernel finds the scalars of the previous one: per-workgroup partials (the application before the loop
@@ -1800,7 +1804,7 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 		nan = hstate[1];
 	}
 	while (!fused && i < maxit && done < 0) {
-		const int end = std::min(maxit, i + chunk);
+		const int end = std::min(maxit, i + (i == 0 ? first_chunk : chunk));
 		for (; i < end; ++i) {
 			const int po = i & 1, pn = po ^ 1;
 			double *sig_new_part = P + (pn ? PART_SIG1 : PART_SIG0);
