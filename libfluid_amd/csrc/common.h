@@ -137,6 +137,7 @@ struct lfa_sim {
 	bool system_valid = false, unknown_count_valid = false;
 	double last_residual = 0.0;
 	uint64_t last_iters = 0;
+	unsigned solid_epoch = 1;               // bumped whenever the solid mask changes (caches keyed on it: mg.hip)
 
 	// boundary scratch
 	void *io_buf = nullptr;

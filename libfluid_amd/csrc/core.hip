@@ -589,6 +589,7 @@ __global__ void k_set_solid(const int32_t *xyz, size_t k, uint8_t *solid, uint8_
 
 extern "C" int lfa_set_solid_cells(lfa_sim *s, const int32_t *xyz, uint64_t k) {
 	if (!s || (!xyz && k)) return LFA_E_INVALID;
+	++s->solid_epoch;
 	if (k == 0) return LFA_OK;
 	LFA_HIP(s, hipSetDevice(s->device));
 	LFA_TRY(lfa_ensure_io(s, k * 12));
@@ -603,6 +604,7 @@ extern "C" int lfa_set_solid_cells(lfa_sim *s, const int32_t *xyz, uint64_t k) {
 
 extern "C" int lfa_clear_solid_cells(lfa_sim *s) {
 	if (!s) return LFA_E_INVALID;
+	++s->solid_epoch;
 	LFA_HIP(s, hipSetDevice(s->device));
 	hipLaunchKernelGGL(k_init_ctype, dim3((unsigned)((s->ncp + 255) / 256)), dim3(256), 0, s->stream, s->ctype, s->solid,
 	                   s->g, s->ncp);
@@ -681,6 +683,7 @@ __global__ void k_import_cells(const CellAos *in, GridDims g, size_t nc, float *
 
 extern "C" int lfa_upload_cells(lfa_sim *s, const void *aos32) {
 	if (!s || !aos32) return LFA_E_INVALID;
+	++s->solid_epoch;
 	LFA_HIP(s, hipSetDevice(s->device));
 	LFA_TRY(lfa_ensure_io(s, s->nc * 32));
 	LFA_HIP(s, hipMemcpyAsync(s->io_buf, aos32, s->nc * 32, hipMemcpyHostToDevice, s->stream));

@@ -572,6 +572,7 @@ extern "C" int lfa_voxelize_mesh(lfa_voxels **out, const double *positions, uint
 
 extern "C" int lfa_set_solid_from_voxels(lfa_sim *s, lfa_voxels *v, int include_interior, int include_surface) {
 	if (!s || !v) return LFA_E_INVALID;
+	++s->solid_epoch;
 	if (s->device != v->device) return lfa_fail(s, LFA_E_INVALID, "lfa_set_solid_from_voxels: handles live on different devices");
 	if (v->nc == 0) return LFA_OK;
 	LFA_HIP(s, hipSetDevice(s->device));
