@@ -238,6 +238,8 @@ int lfa_dist_exchange_slices(lfa_sim *s, void *vec, int elem_bytes);  // elem_by
 /// layer lo_layer goes down, slice 7 of layer hi_layer - 1 goes up; they land in layers lo_layer - 1 and hi_layer.
 int lfa_dist_exchange_layer_slices(lfa_sim *s, void *vec, int elem_bytes, int tiles_per_layer, int lo_layer, int hi_layer);
 int lfa_dist_allreduce(lfa_sim *s, const double *partials, int n, int slot, bool is_max);  // result in dist_red[slot]
+double *lfa_dist_gather_buf(lfa_sim *s, int parity);  // [max per rank | sum per rank] of the last lfa_dist_gather_pair
+int lfa_dist_gather_pair(lfa_sim *s, const double *pmax, int n_max, const double *psum, int n_sum, int parity);
 int lfa_dist_ensure_xbuf(lfa_sim *s, int which, size_t bytes);
 int lfa_dist_migrate(lfa_sim *s);
 int lfa_dist_exchange_ghost_particles(lfa_sim *s);

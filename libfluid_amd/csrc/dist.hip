@@ -113,6 +113,37 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const double *part, int
 	}
 	if (threadIdx.x == 0) *out = lds[0];
 }
+/// out[0 .. 2 n) = 0 except out[rank] = max of the first list and out[n + rank] = sum of the second (the fixed-order
+/// reductions of k_reduce_partials): a SUM all-reduce of `out` then leaves every rank's pair on every rank (an all-gather
+/// that is exact in any order), and the consumers reduce n values instead of their per-workgroup partials.
+__global__ void __launch_bounds__(256) k_gather_pair(const double *pmax, int n_max, const double *psum, int n_sum, double *out, int n, int rank) {
+	__shared__ double lds[2][256];
+	double a = -INFINITY, b = 0.0;
+	bool nan_a = false, nan_b = false;
+	for (int i = threadIdx.x; i < n_max; i += 256) {
+		const double x = pmax[i];
+		nan_a |= x != x;
+		a = x > a ? x : a;
+	}
+	for (int i = threadIdx.x; i < n_sum; i += 256) {
+		const double x = psum[i];
+		nan_b |= x != x;
+		b += x;
+	}
+	lds[0][threadIdx.x] = nan_a ? NAN : a;
+	lds[1][threadIdx.x] = nan_b ? NAN : b;
+	__syncthreads();
+	for (int o = 128; o > 0; o >>= 1) {
+		if ((int)threadIdx.x < o) {
+			const double x = lds[0][threadIdx.x], y = lds[0][threadIdx.x + o];
+			lds[0][threadIdx.x] = (x != x || y != y) ? NAN : (y > x ? y : x);
+			const double u = lds[1][threadIdx.x], w = lds[1][threadIdx.x + o];
+			lds[1][threadIdx.x] = (u != u || w != w) ? NAN : u + w;
+		}
+		__syncthreads();
+	}
+	for (int i = threadIdx.x; i < 2 * n; i += 256) out[i] = i == rank ? lds[0][0] : (i == n + rank ? lds[1][0] : 0.0);
+}
 }  // namespace
 
 int lfa_dist_ensure_xbuf(lfa_sim *s, int which, size_t bytes) {
@@ -265,6 +296,18 @@ int lfa_dist_allreduce(lfa_sim *s, const double *partials, int n, int slot, bool
 	return s->dist->allreduce(s, s->dist_red + slot, 1, is_max);
 }
 
+
+/// The signed max of `pmax` and the sum of `psum` of every rank in ONE collective: afterwards lfa_dist_gather_buf(s, parity)
+/// holds [max of rank 0 .. n-1 | sum of rank 0 .. n-1] on every rank.
+double *lfa_dist_gather_buf(lfa_sim *s, int parity) { return s->dist_red + 64 + (size_t)parity * 2 * s->dist->nranks; }
+int lfa_dist_gather_pair(lfa_sim *s, const double *pmax, int n_max, const double *psum, int n_sum, int parity) {
+	const int n = s->dist->nranks;
+	if (n > 32) return lfa_fail(s, LFA_E_UNSUPPORTED, "more than 32 slabs");
+	double *out = lfa_dist_gather_buf(s, parity);
+	hipLaunchKernelGGL(k_gather_pair, dim3(1), dim3(256), 0, s->stream, pmax, n_max, psum, n_sum, out, n, s->dist->rank);
+	LFA_LAUNCH_CHECK(s);
+	return s->dist->allreduce_buf(s, out, (size_t)2 * n, LFA_RED_F64, false);
+}
 
 // ================================================================================================= particle migration
 namespace {
@@ -626,7 +669,7 @@ int attach(lfa_sim *s, lfa_dist *d, const int32_t *bounds) {
 	s->binned = false;
 	s->grid_valid = false;
 	s->system_valid = false;
-	if (!s->dist_red) LFA_HIP(s, hipMalloc(&s->dist_red, 64 * 8));
+	if (!s->dist_red) LFA_HIP(s, hipMalloc(&s->dist_red, (64 + 4 * 32) * 8));  // scalars | 2 gather buffers of 2 x nranks
 	if (!s->halo_tiles) LFA_HIP(s, hipMalloc(&s->halo_tiles, (size_t)4 * s->g.ntx * s->g.nty * 4));
 	return LFA_OK;
 }

@@ -1739,11 +1739,17 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 			const int po = i & 1, pn = po ^ 1;
 			// where a kernel finds the scalars of the previous one: per-workgroup partials (the application before the loop
 			// wrote NS sigma partials, k_pcg_b writes NSB), or - with slabs - the all-reduced values
-			const double *sig_po = dist ? red + 3 + po : P + (po ? PART_SIG1 : PART_SIG0), *sig_pn = dist ? red + 3 + pn : P + (pn ? PART_SIG1 : PART_SIG0);
-			const int n_sig_po = dist ? 1 : (i == 0 ? NS : NSB), n_sig_pn = dist ? 1 : (i <= 1 ? NS : NSB);
+			// slabs: sigma_k (k >= 1) and the signed max of the residual it belongs to arrive together, one value per rank
+			// (lfa_dist_gather_pair, parity k & 1); sigma_0 of the application before the loop is the all-reduced scalar
+			const int nr = dist ? s->dist->nranks : 0;
+			const double *sig_po = !dist ? P + (po ? PART_SIG1 : PART_SIG0) : (i == 0 ? red + 3 : lfa_dist_gather_buf(s, po) + nr);
+			const double *sig_pn = !dist ? P + (pn ? PART_SIG1 : PART_SIG0) : (i <= 1 ? red + 3 : lfa_dist_gather_buf(s, pn) + nr);
+			const int n_sig_po = dist ? (i == 0 ? 1 : nr) : (i == 0 ? NS : NSB), n_sig_pn = dist ? (i <= 1 ? 1 : nr) : (i <= 1 ? NS : NSB);
+			const double *rmax_prev = !dist ? P + PART_RMAX : (i == 0 ? red + 2 : lfa_dist_gather_buf(s, po));
+			const int n_rmax_prev = dist ? (i == 0 ? 1 : nr) : GB;
 			launch_pcg_a<real>(i == 0, is_ml(s), GA, s->stream, s->n_ptiles, (const int *)s->nbr_table, (const uint8_t *)s->abits,
 			                   (const real *)v.z, (const real *)sbuf[po], sbuf[pn], v.q, scale, sig_po, n_sig_po, sig_pn, n_sig_pn,
-			                   (const double *)(dist ? red + 2 : P + PART_RMAX), dist ? 1 : GB, s->prm.tolerance, i, s->pcg_state,
+			                   rmax_prev, n_rmax_prev, s->prm.tolerance, i, s->pcg_state,
 			                   s->pcg_hist, P + PART_ZS, cx, (const real *)s->c_x2, is_ml(s) ? (real *)s->c_as : (real *)nullptr);
 			LFA_LAUNCH_CHECK(s);
 			if (dist) {
@@ -1789,13 +1795,11 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 					s->c_r_cur = nullptr;
 				}
 			}
-			if (dist) {
-				LFA_TRY(lfa_dist_allreduce(s, P + PART_RMAX, GB, 2, true));
-				LFA_TRY(lfa_dist_allreduce(s, sig_new_part, NSB, 3 + pn, false));
-			}
+			if (dist) LFA_TRY(lfa_dist_gather_pair(s, P + PART_RMAX, GB, sig_new_part, NSB, pn));  // one collective for both
 		}
 		// the residual of the last iteration of the chunk is tested here (k_pcg_a tests the one before it)
-		hipLaunchKernelGGL(k_check_converged, dim3(1), dim3(256), 0, s->stream, dist ? red + 2 : P + PART_RMAX, dist ? 1 : GB,
+		hipLaunchKernelGGL(k_check_converged, dim3(1), dim3(256), 0, s->stream,
+		                   dist ? (const double *)lfa_dist_gather_buf(s, i & 1) : P + PART_RMAX, dist ? s->dist->nranks : GB,
 		                   s->prm.tolerance, i - 1, s->pcg_state, s->pcg_hist);
 		LFA_LAUNCH_CHECK(s);
 		LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 8, hipMemcpyDeviceToHost, s->stream));
