@@ -69,28 +69,37 @@ __global__ void __launch_bounds__(128) k_planes_copy(float *stage_all, int slot0
 	}
 }
 
-/// One z-slice (64 elements, `slice_words` 32-bit words) of a tile-major vector for a run of particle tiles.
+/// One z-slice (64 elements, `slice_words` 32-bit words) of a tile-major vector for a run of particle tiles; both slab
+/// faces in one launch (blockIdx.y = face: the packs / unpacks of a halo exchange are launch-latency bound).
+struct SliceRun {
+	int slot0[2], n[2], zz[2];
+	uint32_t *buf[2];
+};
 template <bool PACK>
-__global__ void __launch_bounds__(64) k_slices_copy(const int *ptiles_all, int slot0, int n, int zz, uint32_t *vec,
-                                                   int slice_words, uint32_t *buf) {
-	const int k = blockIdx.x;
-	if (k >= n) return;
-	uint32_t *g = vec + ((size_t)ptiles_all[slot0 + k] * 8 + (size_t)zz) * slice_words;
-	uint32_t *b = buf + (size_t)k * slice_words;
+__global__ void __launch_bounds__(64) k_slices_copy(const int *ptiles_all, SliceRun r, uint32_t *vec, int slice_words) {
+	const int w = blockIdx.y, k = blockIdx.x;
+	if (k >= r.n[w]) return;
+	uint32_t *g = vec + ((size_t)ptiles_all[r.slot0[w] + k] * 8 + (size_t)r.zz[w]) * slice_words;
+	uint32_t *b = r.buf[w] + (size_t)k * slice_words;
 	for (int i = threadIdx.x; i < slice_words; i += 64) {
 		if (PACK) b[i] = g[i];
 		else g[i] = b[i];
 	}
 }
 /// The same for the consecutive tiles tile0 .. tile0 + n - 1 (a whole tile layer).
+struct LayerRun {
+	int tile0[2], n[2], zz[2];
+	uint32_t *buf[2];
+};
 template <bool PACK>
-__global__ void __launch_bounds__(256) k_layer_slices_copy(int tile0, int n, int zz, uint32_t *vec, int slice_words, uint32_t *buf) {
+__global__ void __launch_bounds__(256) k_layer_slices_copy(LayerRun r, uint32_t *vec, int slice_words) {
+	const int w = blockIdx.y;
 	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-	if (i >= (size_t)n * slice_words) return;
-	const size_t k = i / slice_words, w = i % slice_words;
-	uint32_t *g = vec + ((size_t)(tile0 + k) * 8 + (size_t)zz) * slice_words + w;
-	if (PACK) buf[i] = *g;
-	else *g = buf[i];
+	if (i >= (size_t)r.n[w] * slice_words) return;
+	const size_t k = i / slice_words, o = i % slice_words;
+	uint32_t *g = vec + ((size_t)(r.tile0[w] + k) * 8 + (size_t)r.zz[w]) * slice_words + o;
+	if (PACK) r.buf[w][i] = *g;
+	else *g = r.buf[w][i];
 }
 
 __global__ void __launch_bounds__(256) k_reduce_partials(const double *part, int n, double *out, int is_max) {
@@ -239,26 +248,25 @@ int lfa_dist_exchange_slices(lfa_sim *s, void *vec, int elem_bytes) {
 	const size_t sb = (size_t)64 * elem_bytes;
 	const int n_send[2] = {lfa_has_lo(s) ? s->n_own_first : 0, lfa_has_hi(s) ? s->n_own_last : 0};
 	const int n_recv[2] = {s->n_ghost_lo, s->n_ghost_hi};
-	const int send_slot0[2] = {s->p_off, s->p_off + s->n_ptiles - s->n_own_last};
-	const int recv_slot0[2] = {0, s->p_off + s->n_ptiles};
-	const int send_z[2] = {0, 7}, recv_z[2] = {7, 0};
 	for (int w = 0; w < 2; ++w) {
 		LFA_TRY(lfa_dist_ensure_xbuf(s, w, (size_t)n_send[w] * sb));
 		LFA_TRY(lfa_dist_ensure_xbuf(s, 2 + w, (size_t)n_recv[w] * sb));
-		if (n_send[w]) {
-			hipLaunchKernelGGL(k_slices_copy<true>, dim3(n_send[w]), dim3(64), 0, s->stream, s->ptiles_all, send_slot0[w],
-			                   n_send[w], send_z[w], (uint32_t *)vec, wpe, (uint32_t *)s->xbuf[w]);
-			LFA_LAUNCH_CHECK(s);
-		}
+	}
+	const SliceRun out{{s->p_off, s->p_off + s->n_ptiles - s->n_own_last}, {n_send[0], n_send[1]}, {0, 7},
+	                   {(uint32_t *)s->xbuf[0], (uint32_t *)s->xbuf[1]}};
+	const SliceRun in{{0, s->p_off + s->n_ptiles}, {n_recv[0], n_recv[1]}, {7, 0}, {(uint32_t *)s->xbuf[2], (uint32_t *)s->xbuf[3]}};
+	if (n_send[0] || n_send[1]) {
+		hipLaunchKernelGGL(k_slices_copy<true>, dim3(std::max(n_send[0], n_send[1]), 2), dim3(64), 0, s->stream, s->ptiles_all, out,
+		                   (uint32_t *)vec, wpe);
+		LFA_LAUNCH_CHECK(s);
 	}
 	LFA_TRY(s->dist->exchange(s, s->xbuf[0], n_send[0] * sb, s->xbuf[2], n_recv[0] * sb, s->xbuf[1], n_send[1] * sb,
 	                          s->xbuf[3], n_recv[1] * sb));
-	for (int w = 0; w < 2; ++w)
-		if (n_recv[w]) {
-			hipLaunchKernelGGL(k_slices_copy<false>, dim3(n_recv[w]), dim3(64), 0, s->stream, s->ptiles_all, recv_slot0[w],
-			                   n_recv[w], recv_z[w], (uint32_t *)vec, wpe, (uint32_t *)s->xbuf[2 + w]);
-			LFA_LAUNCH_CHECK(s);
-		}
+	if (n_recv[0] || n_recv[1]) {
+		hipLaunchKernelGGL(k_slices_copy<false>, dim3(std::max(n_recv[0], n_recv[1]), 2), dim3(64), 0, s->stream, s->ptiles_all, in,
+		                   (uint32_t *)vec, wpe);
+		LFA_LAUNCH_CHECK(s);
+	}
 	return LFA_OK;
 }
 
@@ -267,25 +275,23 @@ int lfa_dist_exchange_layer_slices(lfa_sim *s, void *vec, int elem_bytes, int ti
 	const int sw = 16 * elem_bytes, L = tiles_per_layer;
 	const size_t sb = (size_t)64 * elem_bytes * L;
 	const bool on[2] = {lfa_has_lo(s), lfa_has_hi(s)};
-	const int send_tile0[2] = {lo_layer * L, (hi_layer - 1) * L}, recv_tile0[2] = {(lo_layer - 1) * L, hi_layer * L};
-	const int send_z[2] = {0, 7}, recv_z[2] = {7, 0};
-	const unsigned grid = (unsigned)(((size_t)L * sw + 255) / 256);
-	for (int w = 0; w < 2; ++w) {
-		if (!on[w]) continue;
-		LFA_TRY(lfa_dist_ensure_xbuf(s, w, sb));
-		LFA_TRY(lfa_dist_ensure_xbuf(s, 2 + w, sb));
-		hipLaunchKernelGGL(k_layer_slices_copy<true>, dim3(grid), dim3(256), 0, s->stream, send_tile0[w], L, send_z[w], (uint32_t *)vec,
-		                   sw, (uint32_t *)s->xbuf[w]);
-		LFA_LAUNCH_CHECK(s);
-	}
+	if (!on[0] && !on[1]) return LFA_OK;
+	for (int w = 0; w < 2; ++w)
+		if (on[w]) {
+			LFA_TRY(lfa_dist_ensure_xbuf(s, w, sb));
+			LFA_TRY(lfa_dist_ensure_xbuf(s, 2 + w, sb));
+		}
+	const LayerRun out{{lo_layer * L, (hi_layer - 1) * L}, {on[0] ? L : 0, on[1] ? L : 0}, {0, 7},
+	                   {(uint32_t *)s->xbuf[0], (uint32_t *)s->xbuf[1]}};
+	const LayerRun in{{(lo_layer - 1) * L, hi_layer * L}, {on[0] ? L : 0, on[1] ? L : 0}, {7, 0},
+	                  {(uint32_t *)s->xbuf[2], (uint32_t *)s->xbuf[3]}};
+	const dim3 grid((unsigned)(((size_t)L * sw + 255) / 256), 2);
+	hipLaunchKernelGGL(k_layer_slices_copy<true>, grid, dim3(256), 0, s->stream, out, (uint32_t *)vec, sw);
+	LFA_LAUNCH_CHECK(s);
 	LFA_TRY(s->dist->exchange(s, s->xbuf[0], on[0] ? sb : 0, s->xbuf[2], on[0] ? sb : 0, s->xbuf[1], on[1] ? sb : 0, s->xbuf[3],
 	                          on[1] ? sb : 0));
-	for (int w = 0; w < 2; ++w) {
-		if (!on[w]) continue;
-		hipLaunchKernelGGL(k_layer_slices_copy<false>, dim3(grid), dim3(256), 0, s->stream, recv_tile0[w], L, recv_z[w], (uint32_t *)vec,
-		                   sw, (uint32_t *)s->xbuf[2 + w]);
-		LFA_LAUNCH_CHECK(s);
-	}
+	hipLaunchKernelGGL(k_layer_slices_copy<false>, grid, dim3(256), 0, s->stream, in, (uint32_t *)vec, sw);
+	LFA_LAUNCH_CHECK(s);
 	return LFA_OK;
 }
 
