@@ -35,6 +35,7 @@ struct lfa_mesher {
 	uint32_t *cell_fill = nullptr;   // ncell
 	uint32_t *order = nullptr;     // particle indices grouped by cell
 	double *pos = nullptr;         // uploaded particle positions
+	double *spos = nullptr;        // the same in the visiting order of `order` (contiguous per cell run)
 	size_t pcap = 0;
 	uint32_t *vcount = nullptr, *icount = nullptr;  // per cell (+1): vertices created / indices emitted -> offsets
 	uint16_t *created = nullptr;
@@ -174,10 +175,21 @@ __global__ void k_sort_groups(const uint32_t *cell_start, size_t ncell, uint32_t
 	}
 }
 
+/// Positions in visiting order: the sampling loop then streams a row of cells instead of chasing order[k] -> pos (two
+/// dependent, uncoalesced loads per particle visit; 134 M particles on 270 M points: 258 -> see DESIGN.md).
+__global__ void k_gather_positions(const double *pos, const uint32_t *order, const uint32_t *cell_start, size_t ncell, double *spos) {
+	const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= cell_start[ncell]) return;
+	const double *p = pos + 3 * (size_t)order[k];
+	spos[3 * k] = p[0];
+	spos[3 * k + 1] = p[1];
+	spos[3 * k + 2] = p[2];
+}
+
 // ------------------------------------------------------------------------------------------------ surface function
 /// mesher::_sample_surface_function (src/mesher.cpp:342-375), one thread per grid point.
 __global__ void __launch_bounds__(256)
-k_sample_surface(MeshGrid g, const double *pos, const uint32_t *cell_start, const uint32_t *order, double r, double *values) {
+k_sample_surface(MeshGrid g, const double *spos, const uint32_t *cell_start, double r, double *values) {
 	const uint64_t px = g.nx + 1, py = g.ny + 1, pz = g.nz + 1;
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= px * py * pz) return;
@@ -196,7 +208,7 @@ k_sample_surface(MeshGrid g, const double *pos, const uint32_t *cell_start, cons
 				const size_t row = (size_t)(g.nx * (cy + g.ny * cz));
 				const uint32_t e = cell_start[row + x1];
 				for (uint32_t k = cell_start[row + x0]; k < e; ++k) {
-					const double *p = pos + 3 * (size_t)order[k];
+					const double *p = spos + 3 * (size_t)k;
 					const double qx = p[0], qy = p[1], qz = p[2];
 					has = true;
 					const double dx = qx - gx, dy = qy - gy, dz = qz - gz;
@@ -405,7 +417,7 @@ extern "C" void lfa_mesher_destroy(lfa_mesher *m) {
 	if (!m) return;
 	(void)hipSetDevice(m->device);
 	if (m->stream) (void)hipStreamSynchronize(m->stream);
-	void *ptrs[] = {m->values, m->cell_start, m->cell_fill, m->order, m->pos, m->vcount, m->icount, m->created, m->occ, m->blk,
+	void *ptrs[] = {m->values, m->cell_start, m->cell_fill, m->order, m->pos, m->spos, m->vcount, m->icount, m->created, m->occ, m->blk,
 	                m->vpos, m->vidx};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
@@ -431,9 +443,11 @@ static int sample_device_positions(lfa_mesher *m, const double *dpos, uint64_t n
 		                   (const uint32_t *)m->cell_start, m->cell_fill, m->order);
 		hipLaunchKernelGGL(k_sort_groups, dim3((unsigned)((m->ncell + 255) / 256)), dim3(256), 0, m->stream,
 		                   (const uint32_t *)m->cell_start, m->ncell, m->order);
+		hipLaunchKernelGGL(k_gather_positions, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, dpos,
+		                   (const uint32_t *)m->order, (const uint32_t *)m->cell_start, m->ncell, m->spos);
 	}
-	hipLaunchKernelGGL(k_sample_surface, dim3((unsigned)((m->npts + 255) / 256)), dim3(256), 0, m->stream, g, dpos,
-	                   (const uint32_t *)m->cell_start, (const uint32_t *)m->order, r, m->values);
+	hipLaunchKernelGGL(k_sample_surface, dim3((unsigned)((m->npts + 255) / 256)), dim3(256), 0, m->stream, g, (const double *)m->spos,
+	                   (const uint32_t *)m->cell_start, r, m->values);
 	MSH_HIP(m, hipGetLastError());
 	m->have_mesh = false;
 	return LFA_OK;
@@ -446,10 +460,13 @@ extern "C" int lfa_mesher_sample(lfa_mesher *m, const double *positions, uint64_
 	if (n > m->pcap) {
 		if (m->pos) MSH_HIP(m, hipFree(m->pos));
 		if (m->order) MSH_HIP(m, hipFree(m->order));
+		if (m->spos) MSH_HIP(m, hipFree(m->spos));
 		m->pos = nullptr;
 		m->order = nullptr;
+		m->spos = nullptr;
 		m->pcap = 0;
 		MSH_HIP(m, hipMalloc(&m->pos, (size_t)n * 24));
+		MSH_HIP(m, hipMalloc(&m->spos, (size_t)n * 24));
 		MSH_HIP(m, hipMalloc(&m->order, (size_t)n * 4));
 		m->pcap = n;
 	}
@@ -486,10 +503,13 @@ extern "C" int lfa_mesher_sample_sim(lfa_mesher *m, lfa_sim *s, double r) {
 	if (n > m->pcap) {
 		if (m->pos) MSH_HIP(m, hipFree(m->pos));
 		if (m->order) MSH_HIP(m, hipFree(m->order));
+		if (m->spos) MSH_HIP(m, hipFree(m->spos));
 		m->pos = nullptr;
 		m->order = nullptr;
+		m->spos = nullptr;
 		m->pcap = 0;
 		MSH_HIP(m, hipMalloc(&m->pos, n * 24));
+		MSH_HIP(m, hipMalloc(&m->spos, n * 24));
 		MSH_HIP(m, hipMalloc(&m->order, n * 4));
 		m->pcap = n;
 	}
