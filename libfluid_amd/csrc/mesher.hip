@@ -36,6 +36,8 @@ struct lfa_mesher {
 	uint32_t *order = nullptr;     // particle indices grouped by cell
 	double *pos = nullptr;         // uploaded particle positions
 	double *spos = nullptr;        // the same in the visiting order of `order` (contiguous per cell run)
+	uint8_t *blk_flag = nullptr;   // per 8^3 block of cells: holds a particle (lets grid points in empty space skip the row walk)
+	size_t n_blk_flag = 0;
 	size_t pcap = 0;
 	uint32_t *vcount = nullptr, *icount = nullptr;  // per cell (+1): vertices created / indices emitted -> offsets
 	uint16_t *created = nullptr;
@@ -143,11 +145,14 @@ __device__ inline uint32_t particle_cell(const MeshGrid &g, const double *p) {
 		return (uint32_t)((uint64_t)ix + g.nx * ((uint64_t)iy + g.ny * (uint64_t)iz));
 	return 0xFFFFFFFFu;
 }
-__global__ void k_count_particles(MeshGrid g, const double *pos, size_t np, uint32_t *cell_count) {
+__global__ void k_count_particles(MeshGrid g, const double *pos, size_t np, uint32_t *cell_count, uint8_t *blk_flag) {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= np) return;
 	const uint32_t c = particle_cell(g, pos + 3 * i);
-	if (c != 0xFFFFFFFFu) atomicAdd(&cell_count[c], 1u);
+	if (c == 0xFFFFFFFFu) return;
+	atomicAdd(&cell_count[c], 1u);
+	const uint64_t x = c % g.nx, y = (c / g.nx) % g.ny, z = c / (g.nx * g.ny);
+	blk_flag[(x >> 3) + ((g.nx + 7) >> 3) * ((y >> 3) + ((g.ny + 7) >> 3) * (z >> 3))] = 1;
 }
 __global__ void k_scatter_particles(MeshGrid g, const double *pos, size_t np, const uint32_t *cell_start, uint32_t *cell_fill,
                                     uint32_t *order) {
@@ -189,7 +194,7 @@ __global__ void k_gather_positions(const double *pos, const uint32_t *order, con
 // ------------------------------------------------------------------------------------------------ surface function
 /// mesher::_sample_surface_function (src/mesher.cpp:342-375), one thread per grid point.
 __global__ void __launch_bounds__(256)
-k_sample_surface(MeshGrid g, const double *spos, const uint32_t *cell_start, double r, double *values) {
+k_sample_surface(MeshGrid g, const double *spos, const uint32_t *cell_start, const uint8_t *blk_flag, double r, double *values) {
 	const uint64_t px = g.nx + 1, py = g.ny + 1, pz = g.nz + 1;
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= px * py * pz) return;
@@ -202,7 +207,16 @@ k_sample_surface(MeshGrid g, const double *spos, const uint32_t *cell_start, dou
 	const double e2 = g.extent * g.extent;
 	double tw = 0.0, tr = 0.0, tx = 0.0, ty = 0.0, tz = 0.0;
 	bool has = false;
-	if (x0 < x1)
+	// most grid points of a scene sit in empty space: a look at the (at most 2 x 2 x 2, radius <= 8) blocks of cells the
+	// neighbourhood overlaps replaces two cell_start loads per row
+	bool maybe = false;
+	if (x0 < x1 && y0 < y1 && z0 < z1) {
+		const uint64_t bnx = (g.nx + 7) >> 3, bny = (g.ny + 7) >> 3;
+		for (uint64_t bz = z0 >> 3; bz <= (z1 - 1) >> 3; ++bz)
+			for (uint64_t by = y0 >> 3; by <= (y1 - 1) >> 3; ++by)
+				for (uint64_t bx = x0 >> 3; bx <= (x1 - 1) >> 3; ++bx) maybe |= blk_flag[bx + bnx * (by + bny * bz)] != 0;
+	}
+	if (maybe)
 	for (uint64_t cz = z0; cz < z1; ++cz)
 		for (uint64_t cy = y0; cy < y1; ++cy) {
 				const size_t row = (size_t)(g.nx * (cy + g.ny * cz));
@@ -417,7 +431,7 @@ extern "C" void lfa_mesher_destroy(lfa_mesher *m) {
 	if (!m) return;
 	(void)hipSetDevice(m->device);
 	if (m->stream) (void)hipStreamSynchronize(m->stream);
-	void *ptrs[] = {m->values, m->cell_start, m->cell_fill, m->order, m->pos, m->spos, m->vcount, m->icount, m->created, m->occ, m->blk,
+	void *ptrs[] = {m->values, m->cell_start, m->cell_fill, m->order, m->pos, m->spos, m->blk_flag, m->vcount, m->icount, m->created, m->occ, m->blk,
 	                m->vpos, m->vidx};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
@@ -431,9 +445,17 @@ static int sample_device_positions(lfa_mesher *m, const double *dpos, uint64_t n
 	const MeshGrid g = make_grid(m);
 	MSH_HIP(m, hipMemsetAsync(m->cell_start, 0, (m->ncell + 1) * 4, m->stream));
 	MSH_HIP(m, hipMemsetAsync(m->cell_fill, 0, m->ncell * 4, m->stream));
+	const size_t nbf = (size_t)((m->n[0] + 7) >> 3) * ((m->n[1] + 7) >> 3) * ((m->n[2] + 7) >> 3);
+	if (nbf > m->n_blk_flag) {
+		if (m->blk_flag) MSH_HIP(m, hipFree(m->blk_flag));
+		m->blk_flag = nullptr;
+		MSH_HIP(m, hipMalloc(&m->blk_flag, nbf));
+		m->n_blk_flag = nbf;
+	}
+	MSH_HIP(m, hipMemsetAsync(m->blk_flag, 0, nbf, m->stream));
 	if (n) {
 		hipLaunchKernelGGL(k_count_particles, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, g, dpos, (size_t)n,
-		                   m->cell_start);
+		                   m->cell_start, m->blk_flag);
 		MSH_HIP(m, hipGetLastError());
 	}
 	int rc = scan_u32(m, m->cell_start, m->cell_start, m->ncell);
@@ -447,7 +469,7 @@ static int sample_device_positions(lfa_mesher *m, const double *dpos, uint64_t n
 		                   (const uint32_t *)m->order, (const uint32_t *)m->cell_start, m->ncell, m->spos);
 	}
 	hipLaunchKernelGGL(k_sample_surface, dim3((unsigned)((m->npts + 255) / 256)), dim3(256), 0, m->stream, g, (const double *)m->spos,
-	                   (const uint32_t *)m->cell_start, r, m->values);
+	                   (const uint32_t *)m->cell_start, (const uint8_t *)m->blk_flag, r, m->values);
 	MSH_HIP(m, hipGetLastError());
 	m->have_mesh = false;
 	return LFA_OK;
