@@ -203,11 +203,12 @@ __device__ inline float hash_unit(uint32_t a, uint32_t b, uint32_t k) {
 }
 
 /// _correct_positions (pairwise springs over the 27-cell neighbourhood, all from the OLD positions) fused with the
-/// _detect_collisions that follows it. Reads (key, t) of `p`, writes the new ones to `out`.
+/// _detect_collisions that follows it. Reads (key, t) of its own particle from `p` and the neighbours from the cell-ordered
+/// records `spos` (k_build_cell_index), so `out` may be `p` itself.
 __global__ void __launch_bounds__(256)
 k_correct_collide(size_t n, ParticleSoA p, uint32_t *out_key, float *out_tx, float *out_ty, float *out_tz, GridDims g,
                   const uint8_t *solid, const uint32_t *tile_flag, const uint32_t *cell_count, const uint32_t *cell_start,
-                  const uint32_t *cidx, MoveParams mp, const uint32_t *only_flagged, const int *tile_pslot, int p_off) {
+                  const float4 *spos, MoveParams mp, const uint32_t *only_flagged, const int *tile_pslot, int p_off) {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	const uint32_t key_i = p.key[i];
@@ -239,9 +240,10 @@ k_correct_collide(size_t n, ParticleSoA p, uint32_t *out_key, float *out_tx, flo
 				const uint32_t st = cell_start[b];
 				const float ox = (float)(c[0] - xx) + t[0], oy = (float)(c[1] - yy) + t[1], oz = (float)(c[2] - zz) + t[2];
 				for (uint32_t k = 0; k < cnt; ++k) {
-					const uint32_t j = cidx[st + k];
+					const float4 sp = spos[st + k];  // the neighbours' OLD positions (the outputs go back in place)
+					const uint32_t j = __float_as_uint(sp.w);
 					if (j == (uint32_t)i) continue;
-					const float dx = ox - p.t[0][j], dy = oy - p.t[1][j], dz = oz - p.t[2][j];
+					const float dx = ox - sp.x, dy = oy - sp.y, dz = oz - sp.z;
 					const float d2 = dx * dx + dy * dy + dz * dz;  // grid units^2
 					if (d2 < 1e-12f) {
 						// coincident pair: the reference adds a random unit-box vector (:584-587, std::random_device)
@@ -541,18 +543,17 @@ extern "C" int lfa_correct_collide(lfa_sim *s, double dt) {
 		LFA_HIP(s, hipMemsetAsync(ovf, 0, ovf_words * 4, s->stream));
 		{
 			const int work = CORR_PARTS * s->n_ptiles, g2 = work < 65536 ? (work > 0 ? work : 1) : 65536;
-			hipLaunchKernelGGL(k_correct_tiled, dim3(g2), dim3(CORR_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, cur, oth.key, oth.t[0],
-			                   oth.t[1], oth.t[2], s->g, s->solid, s->tile_flag, s->cell_count, s->cell_start, (const float4 *)spos,
+			// every neighbour position comes from the cell-ordered records built above (the OLD positions), so the new ones
+			// are written in place
+			hipLaunchKernelGGL(k_correct_tiled, dim3(g2), dim3(CORR_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, cur, cur.key, cur.t[0],
+			                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_flag, s->cell_count, s->cell_start, (const float4 *)spos,
 			                   move_params(s, dt), ovf);
 			LFA_LAUNCH_CHECK(s);
 		}
-		hipLaunchKernelGGL(k_correct_collide, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, cur, oth.key, oth.t[0],
-		                   oth.t[1], oth.t[2], s->g, s->solid, s->tile_flag, s->cell_count, s->cell_start, s->rank,
+		hipLaunchKernelGGL(k_correct_collide, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, cur, cur.key, cur.t[0],
+		                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_flag, s->cell_count, s->cell_start, (const float4 *)spos,
 		                   move_params(s, dt), (const uint32_t *)ovf, (const int *)s->tile_pslot, s->p_off);
 		LFA_LAUNCH_CHECK(s);
-		// every particle read the OLD positions of its neighbours; now publish the new ones
-		LFA_HIP(s, hipMemcpyAsync(cur.key, oth.key, n * 4, hipMemcpyDeviceToDevice, s->stream));
-		for (int d = 0; d < 3; ++d) LFA_HIP(s, hipMemcpyAsync(cur.t[d], oth.t[d], n * 4, hipMemcpyDeviceToDevice, s->stream));
 	}
 	LFA_TRY(lfa_dist_migrate(s));
 	s->unknown_count_valid = false;
