@@ -185,8 +185,11 @@ int lfa_get_step_timings(lfa_sim *s, double ms[3]);
  * One handle per GPU/process, every handle created with the GLOBAL grid size. Rank r owns the tile layers
  * [bounds[r], bounds[r+1]) (a tile layer = 8 cells in z) and the particles inside them; one ghost tile layer on each side
  * is refreshed by nearest-neighbour exchanges (tile flags, P2G boundary planes, u/v/w/type halos, one z-slice of the PCG
- * search vector per iteration) and three scalar all-reduces per PCG iteration. The reference has no distributed mode;
- * this replaces nothing in it.
+ * search vector per iteration) and two scalar collectives per PCG iteration. The multigrid preconditioner runs the same
+ * V-cycle as on a single domain: its finest levels (while no tile layer straddles a slab face: pick layer_bounds that are
+ * multiples of 8 tile layers to keep four levels distributed) exchange one z-slice per face and smoothing step, the
+ * coarser levels are replicated through one sum all-reduce of the restricted residual per V-cycle. The reference has no
+ * distributed mode; this replaces nothing in it.
  *   lfa_dist_unique_id  : rank 0 fills a 128-byte RCCL id, the caller broadcasts it (e.g. torch.distributed)
  *   lfa_dist_init_rccl  : ncclCommInitRank on this handle's device; send/recv to z+-1 and all-reduce run on the
  *                         handle's stream over xGMI
