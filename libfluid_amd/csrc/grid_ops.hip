@@ -243,20 +243,91 @@ struct G2PParams {
 	              // divisions per particle made the kernel VALU-bound), identical for power-of-two cell sizes
 };
 
+/// The transfer of one particle (PIC :447-461, FLIP blend :463-505, APIC + _calculate_c_vector :507-546).
+/// corner(b0, b1, b2) names the sample cell particle cell + (b0, b1, b2); fetch(field, comp, corner, k) = clamped staggered
+/// sample of field (0-2: u v w, 3-5: FLIP's old grid) at that cell + ((k & 1), (k >> 1) & 1, k >> 2).
+template <int METHOD, typename Corner, typename Fetch>
+__device__ inline void g2p_particle(const ParticleSoA &p, uint32_t i, const G2PParams &gp, Corner &&corner, Fetch &&fetch) {
+	const float t[3] = {p.t[0][i], p.t[1][i], p.t[2][i]};
+	float vnew[3], vold[3];
+	float cvec[9];
+#pragma unroll
+	for (int comp = 0; comp < 3; ++comp) {
+		// (b, f) per axis exactly as in the P2G scatter: own axis -> (idx-1, t), other axes -> (d-1, tmid)
+		int b[3];
+		float f[3];
+#pragma unroll
+		for (int a = 0; a < 3; ++a) {
+			if (a == comp) {
+				b[a] = t[a] >= 1.0f ? 0 : -1;
+				f[a] = t[a] >= 1.0f ? 0.0f : t[a];
+			} else {
+				b[a] = t[a] < 0.5f ? -1 : 0;
+				f[a] = t[a] < 0.5f ? t[a] + 0.5f : t[a] - 0.5f;
+			}
+		}
+		const auto base = corner(b[0], b[1], b[2]);
+		float s[8];
+#pragma unroll
+		for (int k = 0; k < 8; ++k) s[k] = fetch(comp, comp, base, k);
+		// trilerp nesting of include/fluid/misc.h:24-36: x innermost, then y, then z
+		vnew[comp] = lerp_ref(lerp_ref(lerp_ref(s[0], s[1], f[0]), lerp_ref(s[2], s[3], f[0]), f[1]),
+		                      lerp_ref(lerp_ref(s[4], s[5], f[0]), lerp_ref(s[6], s[7], f[0]), f[1]), f[2]);
+		if (METHOD == LFA_FLIP_BLEND) {
+			float o[8];
+#pragma unroll
+			for (int k = 0; k < 8; ++k) o[k] = fetch(3 + comp, comp, base, k);
+			vold[comp] = lerp_ref(lerp_ref(lerp_ref(o[0], o[1], f[0]), lerp_ref(o[2], o[3], f[0]), f[1]),
+			                      lerp_ref(lerp_ref(o[4], o[5], f[0]), lerp_ref(o[6], o[7], f[0]), f[1]), f[2]);
+		}
+		if (METHOD == LFA_APIC) {
+			// _calculate_c_vector: sum_k grad_kernel(f - corner_k) * s_k, _grad_kernel sign rule d > 0 ? -1 : +1
+			float cx = 0.f, cy = 0.f, cz = 0.f;
+#pragma unroll
+			for (int k = 0; k < 8; ++k) {
+				const float px = f[0] - (float)(k & 1), py = f[1] - (float)((k >> 1) & 1), pz = f[2] - (float)(k >> 2);
+				const float sx = px > 0.f ? -1.f : 1.f, sy = py > 0.f ? -1.f : 1.f, sz = pz > 0.f ? -1.f : 1.f;
+				const float ax = 1.f - fabsf(px), ay = 1.f - fabsf(py), az = 1.f - fabsf(pz);
+				cx = cx + (sx * ay * az * gp.inv_h) * s[k];
+				cy = cy + (ax * sy * az * gp.inv_h) * s[k];
+				cz = cz + (ax * ay * sz * gp.inv_h) * s[k];
+			}
+			cvec[3 * comp] = cx; cvec[3 * comp + 1] = cy; cvec[3 * comp + 2] = cz;
+		}
+	}
+	if (METHOD == LFA_FLIP_BLEND) {
+#pragma unroll
+		for (int k = 0; k < 3; ++k) p.v[k][i] = vnew[k] + (p.v[k][i] - vold[k]) * gp.blend;
+	} else {
+#pragma unroll
+		for (int k = 0; k < 3; ++k) p.v[k][i] = vnew[k];
+	}
+	if (METHOD == LFA_APIC) {
+#pragma unroll
+		for (int k = 0; k < 9; ++k) p.c[k][i] = cvec[k];
+	}
+}
+
 /// One workgroup per particle tile: stage u,v,w (and FLIP's old grid) of the tile + 1-cell ring in LDS with the
 /// clamping rule applied, then every particle of the tile gathers its 3x8 samples from LDS.
-/// PIC :447-461, FLIP blend :463-505, APIC + _calculate_c_vector :507-546.
-template <int METHOD>
+/// STALE: the particles still sit in the order of the last binning but have moved since (position correction): those
+/// whose cell has left the tile are appended to `leavers` for k_g2p_leavers instead (a second binning of all particles
+/// for the sake of the 1-3 % that crossed a tile face cost 2.1 ms of the 30 ms full step at C4).
+#define G2P_LV_CAP 1024
+template <int METHOD, bool STALE>
 __global__ void __launch_bounds__(256)
 k_g2p(const int *ptiles, int n_ptiles, GridDims g, ParticleSoA p, const uint32_t *tile_start, const float *u,
-      const float *v, const float *w, const float *uo, const float *vo, const float *wo, G2PParams gp) {
+      const float *v, const float *w, const float *uo, const float *vo, const float *wo, G2PParams gp, uint32_t *leavers,
+      uint32_t *n_leavers) {
 	constexpr int NF = METHOD == LFA_FLIP_BLEND ? 6 : 3;
 	__shared__ float lds[NF * LFA_HALO_CELLS];
+	__shared__ uint32_t lv[STALE ? G2P_LV_CAP : 1], lv_n, lv_base;
 	for (int slot = blockIdx.x; slot < n_ptiles; slot += gridDim.x) {
 		const int tile = ptiles[slot];
 		int tx, ty, tz;
 		tile_coords(g, tile, tx, ty, tz);
 		__syncthreads();
+		if (STALE && threadIdx.x == 0) lv_n = 0;
 		for (int i = threadIdx.x; i < LFA_HALO_CELLS; i += 256) {
 			const int hx = i % 10, hy = (i / 10) % 10, hz = i / 100;
 			const int x = tx * 8 + hx - 1, y = ty * 8 + hy - 1, z = tz * 8 + hz - 1;
@@ -272,69 +343,46 @@ k_g2p(const int *ptiles, int n_ptiles, GridDims g, ParticleSoA p, const uint32_t
 		__syncthreads();
 		const uint32_t beg = tile_start[tile], end = tile_start[tile + 1];
 		for (uint32_t i = beg + threadIdx.x; i < end; i += 256) {
-			const int l = (int)(p.key[i] & 511);
-			const int lc[3] = {l & 7, (l >> 3) & 7, l >> 6};
-			const float t[3] = {p.t[0][i], p.t[1][i], p.t[2][i]};
-			float vnew[3], vold[3];
-			float cvec[9];
-#pragma unroll
-			for (int comp = 0; comp < 3; ++comp) {
-				// (b, f) per axis exactly as in the P2G scatter: own axis -> (idx-1, t), other axes -> (d-1, tmid)
-				int b[3];
-				float f[3];
-#pragma unroll
-				for (int a = 0; a < 3; ++a) {
-					if (a == comp) {
-						b[a] = t[a] >= 1.0f ? 0 : -1;
-						f[a] = t[a] >= 1.0f ? 0.0f : t[a];
-					} else {
-						b[a] = t[a] < 0.5f ? -1 : 0;
-						f[a] = t[a] < 0.5f ? t[a] + 0.5f : t[a] - 0.5f;
-					}
-				}
-				const int base = (lc[0] + 1 + b[0]) + 10 * (lc[1] + 1 + b[1]) + 100 * (lc[2] + 1 + b[2]);
-				float s[8];
-#pragma unroll
-				for (int k = 0; k < 8; ++k)
-					s[k] = lds[comp * LFA_HALO_CELLS + base + (k & 1) + 10 * ((k >> 1) & 1) + 100 * (k >> 2)];
-				// trilerp nesting of include/fluid/misc.h:24-36: x innermost, then y, then z
-				vnew[comp] = lerp_ref(lerp_ref(lerp_ref(s[0], s[1], f[0]), lerp_ref(s[2], s[3], f[0]), f[1]),
-				                      lerp_ref(lerp_ref(s[4], s[5], f[0]), lerp_ref(s[6], s[7], f[0]), f[1]), f[2]);
-				if (METHOD == LFA_FLIP_BLEND) {
-					float o[8];
-#pragma unroll
-					for (int k = 0; k < 8; ++k)
-						o[k] = lds[(3 + comp) * LFA_HALO_CELLS + base + (k & 1) + 10 * ((k >> 1) & 1) + 100 * (k >> 2)];
-					vold[comp] = lerp_ref(lerp_ref(lerp_ref(o[0], o[1], f[0]), lerp_ref(o[2], o[3], f[0]), f[1]),
-					                      lerp_ref(lerp_ref(o[4], o[5], f[0]), lerp_ref(o[6], o[7], f[0]), f[1]), f[2]);
-				}
-				if (METHOD == LFA_APIC) {
-					// _calculate_c_vector: sum_k grad_kernel(f - corner_k) * s_k, _grad_kernel sign rule d > 0 ? -1 : +1
-					float cx = 0.f, cy = 0.f, cz = 0.f;
-#pragma unroll
-					for (int k = 0; k < 8; ++k) {
-						const float px = f[0] - (float)(k & 1), py = f[1] - (float)((k >> 1) & 1), pz = f[2] - (float)(k >> 2);
-						const float sx = px > 0.f ? -1.f : 1.f, sy = py > 0.f ? -1.f : 1.f, sz = pz > 0.f ? -1.f : 1.f;
-						const float ax = 1.f - fabsf(px), ay = 1.f - fabsf(py), az = 1.f - fabsf(pz);
-						cx = cx + (sx * ay * az * gp.inv_h) * s[k];
-						cy = cy + (ax * sy * az * gp.inv_h) * s[k];
-						cz = cz + (ax * ay * sz * gp.inv_h) * s[k];
-					}
-					cvec[3 * comp] = cx; cvec[3 * comp + 1] = cy; cvec[3 * comp + 2] = cz;
-				}
+			const uint32_t key = p.key[i];
+			if (STALE && (int)(key >> 9) != tile) {
+				const uint32_t at = atomicAdd(&lv_n, 1u);
+				if (at < G2P_LV_CAP) lv[at] = i;
+				else leavers[atomicAdd(n_leavers, 1u)] = i;  // more than the LDS list holds: straight to the global list
+				continue;
 			}
-			if (METHOD == LFA_FLIP_BLEND) {
-#pragma unroll
-				for (int k = 0; k < 3; ++k) p.v[k][i] = vnew[k] + (p.v[k][i] - vold[k]) * gp.blend;
-			} else {
-#pragma unroll
-				for (int k = 0; k < 3; ++k) p.v[k][i] = vnew[k];
-			}
-			if (METHOD == LFA_APIC) {
-#pragma unroll
-				for (int k = 0; k < 9; ++k) p.c[k][i] = cvec[k];
-			}
+			const int l = (int)(key & 511);
+			const int cell = ((l & 7) + 1) + 10 * (((l >> 3) & 7) + 1) + 100 * ((l >> 6) + 1);
+			g2p_particle<METHOD>(
+			    p, i, gp, [&](int b0, int b1, int b2) { return cell + b0 + 10 * b1 + 100 * b2; },
+			    [&](int field, int, int base, int k) { return lds[field * LFA_HALO_CELLS + base + (k & 1) + 10 * ((k >> 1) & 1) + 100 * (k >> 2)]; });
 		}
+		if (STALE) {  // one global atomic per tile
+			__syncthreads();
+			const uint32_t n = lv_n < G2P_LV_CAP ? lv_n : G2P_LV_CAP;
+			if (threadIdx.x == 0 && n) lv_base = atomicAdd(n_leavers, n);
+			__syncthreads();
+			for (uint32_t k = threadIdx.x; k < n; k += 256) leavers[lv_base + k] = lv[k];
+		}
+	}
+}
+
+/// The particles k_g2p<.., STALE> set aside: the same transfer with the samples gathered from the grid in global memory.
+template <int METHOD>
+__global__ void __launch_bounds__(256)
+k_g2p_leavers(GridDims g, ParticleSoA p, const float *u, const float *v, const float *w, const float *uo, const float *vo,
+              const float *wo, G2PParams gp, const uint32_t *leavers, const uint32_t *n_leavers) {
+	const uint32_t n = *n_leavers;
+	for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
+		const uint32_t i = leavers[k], key = p.key[i];
+		if (key == 0xFFFFFFFFu) continue;
+		const int tile = (int)(key >> 9), l = (int)(key & 511);
+		int tx, ty, tz;
+		tile_coords(g, tile, tx, ty, tz);
+		const int cx = tx * 8 + (l & 7), cy = ty * 8 + ((l >> 3) & 7), cz = tz * 8 + (l >> 6);
+		const float *F[6] = {u, v, w, uo, vo, wo};
+		g2p_particle<METHOD>(
+		    p, i, gp, [&](int b0, int b1, int b2) { return make_int3(cx + b0, cy + b1, cz + b2); },
+		    [&](int field, int comp, int3 c, int k) { return clamped_sample(g, F[field], comp, c.x + (k & 1), c.y + ((k >> 1) & 1), c.z + (k >> 2)); });
 	}
 }
 }  // namespace
@@ -437,7 +485,8 @@ extern "C" int lfa_extrapolate(lfa_sim *s) {
 	return LFA_OK;
 }
 
-extern "C" int lfa_g2p(lfa_sim *s) {
+/// stale: the particles have moved since the last binning but keep its order (lfa_time_step after the position correction)
+static int g2p_run(lfa_sim *s, bool stale) {
 	if (!s) return LFA_E_INVALID;
 	if (!s->binned) return lfa_fail(s, LFA_E_INVALID, "lfa_g2p: call lfa_hash_particles first");
 	LFA_HIP(s, hipSetDevice(s->device));
@@ -449,23 +498,30 @@ extern "C" int lfa_g2p(lfa_sim *s) {
 	gp.inv_h = (float)(1.0 / s->prm.cell_size);
 	dim3 grid(grid_blocks(s->n_ptiles));
 	const ParticleSoA &p = s->pb[s->cur];
+	if (s->prm.simulation_method == LFA_FLIP_BLEND && !s->uo) return lfa_fail(s, LFA_E_INVALID, "lfa_g2p: FLIP needs the old grid written by lfa_p2g");
+	// leaver list: the binning's rank array is free between two binnings; its counter sits behind the PCG state words
+	uint32_t *leavers = s->rank, *n_leavers = (uint32_t *)(s->pcg_state + 6);
+	if (stale) LFA_HIP(s, hipMemsetAsync(n_leavers, 0, 4, s->stream));
+	// (the STALE instantiation serves both cases: it allocates 62 VGPRs where the plain one gets 129 - 8 instead of 3 waves
+	// per SIMD; on freshly binned particles it finds no leavers)
+#define G2P_LAUNCH(M)                                                                                                        \
+	do {                                                                                                                     \
+		hipLaunchKernelGGL((k_g2p<M, true>), grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, s->g, p, s->tile_start,   \
+		                   s->u, s->v, s->w, s->uo, s->vo, s->wo, gp, leavers, n_leavers);                                   \
+		if (stale)                                                                                                           \
+			hipLaunchKernelGGL(k_g2p_leavers<M>, dim3(512), dim3(256), 0, s->stream, s->g, p, s->u, s->v, s->w, s->uo, s->vo, \
+			                   s->wo, gp, (const uint32_t *)leavers, (const uint32_t *)n_leavers);                           \
+	} while (0)
 	switch (s->prm.simulation_method) {
-	case LFA_PIC:
-		hipLaunchKernelGGL(k_g2p<LFA_PIC>, grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, s->g, p, s->tile_start,
-		                   s->u, s->v, s->w, s->uo, s->vo, s->wo, gp);
-		break;
-	case LFA_FLIP_BLEND:
-		if (!s->uo) return lfa_fail(s, LFA_E_INVALID, "lfa_g2p: FLIP needs the old grid written by lfa_p2g");
-		hipLaunchKernelGGL(k_g2p<LFA_FLIP_BLEND>, grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, s->g, p,
-		                   s->tile_start, s->u, s->v, s->w, s->uo, s->vo, s->wo, gp);
-		break;
-	default:
-		hipLaunchKernelGGL(k_g2p<LFA_APIC>, grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, s->g, p, s->tile_start,
-		                   s->u, s->v, s->w, s->uo, s->vo, s->wo, gp);
-		break;
+	case LFA_PIC: G2P_LAUNCH(LFA_PIC); break;
+	case LFA_FLIP_BLEND: G2P_LAUNCH(LFA_FLIP_BLEND); break;
+	default: G2P_LAUNCH(LFA_APIC); break;
 	}
+#undef G2P_LAUNCH
 	LFA_LAUNCH_CHECK(s);
 	return LFA_OK;
 }
+extern "C" int lfa_g2p(lfa_sim *s) { return g2p_run(s, false); }
+int lfa_g2p_stale(lfa_sim *s) { return g2p_run(s, true); }
 
 int lfa_g2p_bench(lfa_sim *s) { return lfa_g2p(s); }

@@ -562,6 +562,7 @@ extern "C" int lfa_correct_collide(lfa_sim *s, double dt) {
 
 /// Device-resident simulation::time_step(dt) (src/simulation.cpp:43-125) without fluid sources and host callbacks:
 /// advect+collide, hash, P2G, gravity, pressure solve, pressure gradient, correct+collide, extrapolate, hash, G2P.
+int lfa_g2p_stale(lfa_sim *s);  // grid_ops.hip
 extern "C" int lfa_time_step(lfa_sim *s, double dt, double *residual, uint64_t *iterations) {
 	if (!s) return LFA_E_INVALID;
 	LFA_HIP(s, hipSetDevice(s->device));
@@ -580,9 +581,15 @@ extern "C" int lfa_time_step(lfa_sim *s, double dt, double *residual, uint64_t *
 	LFA_TRY(lfa_correct_collide(s, dt));
 	if (tm) LFA_HIP(s, hipEventRecord(s->ev[13], s->stream));
 	LFA_TRY(lfa_extrapolate(s));  // the valid set is the one of the P2G-time hash, like the reference (:119)
-	// the G2P gathers per tile: re-bin the corrected positions first (the grid keeps the tile set of the P2G)
-	LFA_TRY(lfa_hash_particles(s));
-	LFA_TRY(lfa_g2p(s));
+	// The G2P gathers per tile. Single domain: the particles keep the order of the P2G-time binning and the few whose
+	// corrected position left their tile take the global-gather path (lfa_g2p_stale); like after lfa_advect_collide the
+	// order is stale afterwards and the next step re-bins. Slabs: re-bin first (arrivals from the neighbour ranks).
+	if (s->dist) {
+		LFA_TRY(lfa_hash_particles(s));
+		LFA_TRY(lfa_g2p(s));
+	} else {
+		LFA_TRY(lfa_g2p_stale(s));
+	}
 	if (tm) {
 		LFA_HIP(s, hipEventRecord(s->ev[14], s->stream));
 		LFA_HIP(s, hipEventSynchronize(s->ev[14]));
