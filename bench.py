@@ -291,7 +291,7 @@ def main():
         out["full_time_step"] = {"steps": n_fs, "ms_per_step": 1e3 * fs_s / n_fs, "particle_steps_per_sec": npart * n_fs / fs_s,
                                  "pcg_iterations_per_step": fs_iters / n_fs, "stage_ms": sim.step_timings(),
                                  "note": "device resident: advect+collide, bin, P2G, PCG, apply, correct+collide, "
-                                         "extrapolate, bin, G2P"}
+                                         "extrapolate, G2P (P2G-time order; particles that left their tile: gather kernel)"}
     if args.mesh and world == 1:
         m = lfa.Mesher(size, (0.0, 0.0, 0.0), 1.0, 1.0, 2, device=local_rank)  # mesher settings of testbed/main.cpp:101-107 at cell size 1
         t0 = time.perf_counter()
