@@ -313,7 +313,7 @@ __device__ inline void g2p_particle(const ParticleSoA &p, uint32_t i, const G2PP
 /// STALE: the particles still sit in the order of the last binning but have moved since (position correction): those
 /// whose cell has left the tile are appended to `leavers` for k_g2p_leavers instead (a second binning of all particles
 /// for the sake of the 1-3 % that crossed a tile face cost 2.1 ms of the 30 ms full step at C4).
-#define G2P_LV_CAP 1024
+#define G2P_LV_CAP 256
 template <int METHOD, bool STALE>
 __global__ void __launch_bounds__(256)
 k_g2p(const int *ptiles, int n_ptiles, GridDims g, ParticleSoA p, const uint32_t *tile_start, const float *u,
