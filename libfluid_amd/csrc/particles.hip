@@ -208,10 +208,13 @@ __device__ inline float hash_unit(uint32_t a, uint32_t b, uint32_t k) {
 __global__ void __launch_bounds__(256)
 k_correct_collide(size_t n, ParticleSoA p, uint32_t *out_key, float *out_tx, float *out_ty, float *out_tz, GridDims g,
                   const uint8_t *solid, const uint32_t *tile_flag, const uint32_t *cell_count, const uint32_t *cell_start,
-                  const float4 *spos, MoveParams mp, const uint32_t *only_flagged, const int *tile_pslot, int p_off) {
+                  const float4 *spos, MoveParams mp, const uint32_t *only_flagged, const int *tile_pslot, int p_off,
+                  const uint32_t *key_before) {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	const uint32_t key_i = p.key[i];
+	// the key BEFORE the correction: k_correct_tiled has already rewritten, in place, the keys of the particles it moved
+	// (a particle of a flagged half tile still has its old key and position)
+	const uint32_t key_i = key_before ? key_before[i] : p.key[i];
 	if (only_flagged) {  // fallback pass: only particles of the half tiles the LDS-tiled kernel could not hold
 		const int work = CORR_PARTS * (tile_pslot[key_i >> 9] - p_off) + (int)(((key_i >> 6) & 7) / CORR_ZT);
 		if (!((only_flagged[work >> 5] >> (work & 31)) & 1u)) return;
@@ -544,7 +547,8 @@ extern "C" int lfa_correct_collide(lfa_sim *s, double dt) {
 		{
 			const int work = CORR_PARTS * s->n_ptiles, g2 = work < 65536 ? (work > 0 ? work : 1) : 65536;
 			// every neighbour position comes from the cell-ordered records built above (the OLD positions), so the new ones
-			// are written in place
+			// are written in place; the fallback pass below selects its particles by their old keys
+			LFA_HIP(s, hipMemcpyAsync(oth.key, cur.key, n * 4, hipMemcpyDeviceToDevice, s->stream));
 			hipLaunchKernelGGL(k_correct_tiled, dim3(g2), dim3(CORR_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, cur, cur.key, cur.t[0],
 			                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_flag, s->cell_count, s->cell_start, (const float4 *)spos,
 			                   move_params(s, dt), ovf);
@@ -552,7 +556,7 @@ extern "C" int lfa_correct_collide(lfa_sim *s, double dt) {
 		}
 		hipLaunchKernelGGL(k_correct_collide, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, cur, cur.key, cur.t[0],
 		                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_flag, s->cell_count, s->cell_start, (const float4 *)spos,
-		                   move_params(s, dt), (const uint32_t *)ovf, (const int *)s->tile_pslot, s->p_off);
+		                   move_params(s, dt), (const uint32_t *)ovf, (const int *)s->tile_pslot, s->p_off, (const uint32_t *)oth.key);
 		LFA_LAUNCH_CHECK(s);
 	}
 	LFA_TRY(lfa_dist_migrate(s));

@@ -119,3 +119,33 @@ def test_device_time_step_matches_reference(precond, dtype):
     util.assert_close(out["pos"], g["pos"], 1e-6, "positions after 3 device time steps", atol=3e-4)
     util.assert_close(out["vel"], g["vel"], 3e-4, "velocities after 3 device time steps")
     s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dense", ["all", "half"])
+def test_position_correction_fallback_for_crowded_tiles(dense):
+    """Half tiles whose 10 x 10 x 6-cell neighbourhood holds more particles than the LDS of the tiled kernel are redone by
+    the global-gather kernel (24 particles per cell here: every half tile, or - "half" - only those of the lower part of
+    the block, so that both kernels run in one call and the second one has to pick its particles by their keys from
+    BEFORE the first one moved the others in place). Checked against the oracle's _correct_positions + collisions."""
+    size, lo, hi = (24, 24, 24), (2, 2, 2), (18, 16, 18)
+    parts = [util.scenes.seed_block(lo, hi, seed=util.scenes.SEED + 7 * k) for k in range(3 if dense == "all" else 1)]
+    if dense == "half":
+        parts += [util.scenes.seed_block(lo, (hi[0], 8, hi[2]), seed=util.scenes.SEED + 7 * k) for k in (1, 2)]
+    parts = np.concatenate(parts)
+    parts["cx"][:, 0] = np.arange(len(parts))  # ids, like fullstep_inputs (by_id reads them back)
+    cpu = orc.CpuSim(size, method=orc.PIC)
+    cpu.set_particles(parts)
+    cpu.hash()
+    cpu.L.correct_positions(cpu.h, DT_CORR)
+    cpu.L.detect_collisions(cpu.h)
+    want = by_id(cpu.particles())["pos"].copy()
+    cpu.close()
+    s = lfa.Sim(size, method=lfa.PIC)
+    s.upload_particles(parts)
+    s.hash()
+    s.correct_collide(DT_CORR)
+    out = s.download_particles(into=parts.copy(), write_positions=True)
+    s.close()
+    assert np.abs(out["pos"] - parts["pos"]).max() > 1e-2  # the correction did move particles
+    assert np.abs(out["pos"] - want).max() < 5e-5
