@@ -521,7 +521,10 @@ static int g2p_run(lfa_sim *s, bool stale) {
 	LFA_LAUNCH_CHECK(s);
 	return LFA_OK;
 }
-extern "C" int lfa_g2p(lfa_sim *s) { return g2p_run(s, false); }
+/// (the public entry point takes the leaver path too: it costs a 4-byte memset and an empty launch on freshly binned
+/// particles, and makes the call valid after lfa_correct_collide / lfa_advect_collide without a second binning as long as
+/// the grid still covers the particles' new cells)
+extern "C" int lfa_g2p(lfa_sim *s) { return g2p_run(s, true); }
 int lfa_g2p_stale(lfa_sim *s) { return g2p_run(s, true); }
 
 int lfa_g2p_bench(lfa_sim *s) { return lfa_g2p(s); }

@@ -149,3 +149,36 @@ def test_position_correction_fallback_for_crowded_tiles(dense):
     s.close()
     assert np.abs(out["pos"] - parts["pos"]).max() > 1e-2  # the correction did move particles
     assert np.abs(out["pos"] - want).max() < 5e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", [lfa.PIC, lfa.FLIP_BLEND, lfa.APIC])
+def test_g2p_on_the_order_of_the_last_binning_equals_g2p_after_rebinning(method):
+    """lfa_time_step bins once per step: after the position correction the G2P runs on the P2G-time order, and the
+    particles whose cell has left their tile take the global-gather kernel. Same stages with and without a second
+    binning before the G2P: the same velocities and C vectors per particle (same samples, same arithmetic)."""
+    c, parts, solid = fullstep_inputs()
+    outs = []
+    for rebin in (True, False):
+        s = lfa.Sim(c["size"], method=method, blending=0.9)
+        s.set_solid_cells(solid)
+        s.upload_particles(parts)
+        s.hash(); s.p2g(); s.add_gravity(c["dt"])
+        s.solve(c["dt"]); s.apply_pressure(c["dt"])
+        s.correct_collide(DT_CORR)  # moves particles by up to a cell: some leave their tile
+        s.extrapolate()
+        if rebin:
+            s.hash()
+        s.g2p()
+        outs.append(s.download_particles(into=parts.copy(), write_positions=True))  # upload order
+        s.close()
+    a, b = outs
+    moved_tile = (np.floor(a["pos"] / 8) != np.floor(parts["pos"] / 8)).any(axis=1).sum()
+    assert moved_tile > 50, "the scene is meant to push particles across tile faces"
+    # (the correction's spring sums run in the order of an LDS atomic counter, so two runs agree to fp32 rounding only;
+    # a particle that missed its transfer would keep its old velocity: O(1) off)
+    assert np.abs(a["pos"] - b["pos"]).max() < 1e-5
+    for f in ("vel", "cx", "cy", "cz") if method == lfa.APIC else ("vel",):
+        scale = np.abs(a[f]).max()
+        assert np.abs(a[f] - b[f]).max() < 2e-4 * scale, f
+    assert np.abs(a["vel"] - parts["vel"]).max() > 1e-2 * np.abs(a["vel"]).max()  # the transfer did change velocities
