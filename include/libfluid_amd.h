@@ -155,8 +155,9 @@ int lfa_apply_pressure(lfa_sim *s, double dt);
 /* a18: simulation::_extrapolate_velocities (src/simulation.cpp:685-754). */
 int lfa_extrapolate(lfa_sim *s);
 /* a19-a20: simulation::_transfer_from_grid (src/simulation.cpp:548-560). Works on the particle order of the last
- * lfa_hash_particles: particles that lfa_correct_collide / lfa_advect_collide have since moved out of their tile are
- * transferred by a gather kernel, so no second binning is needed before it (lfa_time_step relies on this). */
+ * lfa_hash_particles: particles that lfa_correct_collide has since moved out of their tile are transferred by a gather
+ * kernel (the new cell must still lie in the processed tiles, i.e. within a tile of the P2G-time particles), so no second
+ * binning is needed before it (lfa_time_step relies on this). */
 int lfa_g2p(lfa_sim *s);
 /* a21: simulation::cfl (src/simulation.cpp:199-205); +inf when every velocity is zero. */
 int lfa_cfl(lfa_sim *s, double *out);

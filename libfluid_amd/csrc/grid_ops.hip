@@ -522,8 +522,8 @@ static int g2p_run(lfa_sim *s, bool stale) {
 	return LFA_OK;
 }
 /// (the public entry point takes the leaver path too: it costs a 4-byte memset and an empty launch on freshly binned
-/// particles, and makes the call valid after lfa_correct_collide / lfa_advect_collide without a second binning as long as
-/// the grid still covers the particles' new cells)
+/// particles, and makes the call valid after lfa_correct_collide without a second binning as long as the processed tiles
+/// still cover the particles' new cells)
 extern "C" int lfa_g2p(lfa_sim *s) { return g2p_run(s, true); }
 int lfa_g2p_stale(lfa_sim *s) { return g2p_run(s, true); }
 
