@@ -292,6 +292,15 @@ __device__ inline void residual_restrict_tile(const MgLv<real> &L, const GridDim
 	const int *nt = L.nbr + (size_t)slot * MG_NBR_STRIDE;
 	const int nb[6] = {nt[0], nt[1], nt[2], nt[3], nt[4], nt[5]}, tile = nt[6];
 	const size_t base = (size_t)tile * 512;
+	// A bytes and right-hand side of the whole column up front, unconditionally (b is 0 where the cell is no unknown): a load
+	// inside the per-cell branch costs one HBM round trip per z
+	uint32_t ab[8];
+	real bb[8];
+#pragma unroll
+	for (int zz = 0; zz < 8; ++zz) {
+		ab[zz] = L.abits[base + zz * 64 + lane];
+		bb[zz] = L.b[base + zz * 64 + lane];
+	}
 	MG_FENCE();
 	load_halo<real>(h, L.x, base, nb, lane, lx, ly);
 	MG_FENCE();
@@ -299,7 +308,7 @@ __device__ inline void residual_restrict_tile(const MgLv<real> &L, const GridDim
 #pragma unroll
 	for (int zz = 0; zz < 8; ++zz) {
 		const int i = (lx + 1) + 10 * (ly + 1) + 100 * (zz + 1);
-		const uint32_t a = L.abits[base + zz * 64 + lane];
+		const uint32_t a = ab[zz];
 		real r = (real)0;
 		if (a & AB_UNKNOWN) {
 			const real F = (a & AB_FLUID) ? (real)1 : (real)0;
@@ -310,7 +319,7 @@ __device__ inline void residual_restrict_tile(const MgLv<real> &L, const GridDim
 			val -= (real)((a >> 3) & 1) * h[i + 1];
 			val -= (real)((a >> 4) & 1) * h[i + 10];
 			val -= (real)((a >> 5) & 1) * h[i + 100];
-			r = L.b[base + zz * 64 + lane] - val;
+			r = bb[zz] - val;
 		}
 		if (zz & 1) pair[zz >> 1] += r;
 		else pair[zz >> 1] = r;
