@@ -137,6 +137,12 @@ struct lfa_sim {
 	bool system_valid = false, unknown_count_valid = false;
 	double last_residual = 0.0;
 	uint64_t last_iters = 0;
+	// Deferred half of the binning (single domain, APIC): lfa_hash_particles moves key, t, id (20 of the 68 bytes) and records
+	// where each particle came from; v and C stay in the other buffer until the P2G has read them through that index -
+	// the G2P then writes the new v, C straight into the binned order. Anything else that reads v or C calls
+	// lfa_particles_materialize first.
+	uint32_t *vc_src = nullptr;             // index in pb[cur ^ 1] of the particle now at i (valid while vc_pending)
+	bool vc_pending = false;
 	unsigned solid_epoch = 1;               // bumped whenever the solid mask changes (caches keyed on it: mg.hip)
 
 	// boundary scratch
@@ -211,6 +217,7 @@ int lfa_exclusive_scan_u32(lfa_sim *s, const uint32_t *in, uint32_t *out, size_t
 
 // stage entry points implemented per file
 int lfa_particles_alloc(lfa_sim *s, size_t n);
+int lfa_particles_materialize(lfa_sim *s);  // completes a deferred binning (no-op otherwise)
 int lfa_ensure_io(lfa_sim *s, size_t bytes);
 int lfa_pcg_alloc(lfa_sim *s);
 int lfa_number_unknowns(lfa_sim *s);

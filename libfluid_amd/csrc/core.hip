@@ -257,7 +257,7 @@ extern "C" void lfa_destroy(lfa_sim *s) {
 	if (s->stream2) (void)hipStreamSynchronize(s->stream2);
 	free_soa(s->pb[0]);
 	free_soa(s->pb[1]);
-	void *ptrs[] = {s->cell_start, s->grid_flag, s->rank, s->tile_count, s->tile_start, s->tile_flag, s->tile_scan, s->ptiles_all, s->dtiles, s->halo_tiles, s->dist_red,
+	void *ptrs[] = {s->cell_start, s->grid_flag, s->rank, s->vc_src, s->tile_count, s->tile_start, s->tile_flag, s->tile_scan, s->ptiles_all, s->dtiles, s->halo_tiles, s->dist_red,
 	                s->xbuf[0], s->xbuf[1], s->xbuf[2], s->xbuf[3],
 	                s->tile_pslot, s->scan_tmp, s->u, s->v, s->w, s->uo, s->vo, s->wo, s->ctype, s->solid,
 	                s->cell_count, s->stage, s->acc, s->abits, s->vp, s->vr, s->vz, s->vs, s->vpre, s->vq, s->vs2, s->c_as, s->nbr_table,
@@ -293,6 +293,7 @@ extern "C" int lfa_set_params(lfa_sim *s, const lfa_params *p) {
 		                "APIC with the reference's unscaled kernel (simulation.cpp:367-369) is only implemented for "
 		                "cell_size == 1; set apic_unscaled_kernel = 0");
 	if (p->pcg_dtype != s->prm.pcg_dtype || p->precond != s->prm.precond) s->system_valid = false;
+	if (p->simulation_method != s->prm.simulation_method) LFA_TRY(lfa_particles_materialize(s));  // only APIC defers v, C
 	if (p->precond < 0 || p->precond > LFA_PRECOND_MULTIGRID) return lfa_fail(s, LFA_E_INVALID, "bad precond");
 	s->prm = *p;
 	return LFA_OK;
@@ -341,12 +342,17 @@ int lfa_particles_alloc(lfa_sim *s, size_t n) {
 	if (s->rank) LFA_HIP(s, hipFree(s->rank));
 	s->rank = nullptr;
 	LFA_HIP(s, hipMalloc(&s->rank, cap * 4));
+	if (s->vc_src) LFA_HIP(s, hipFree(s->vc_src));
+	s->vc_src = nullptr;
+	LFA_HIP(s, hipMalloc(&s->vc_src, cap * 4));
+	s->vc_pending = false;
 	s->pcap = cap;
 	return LFA_OK;
 }
 
 /// Grows the particle arrays to hold n_total particles, keeping the first n_keep of the current buffer.
 int lfa_particles_reserve(lfa_sim *s, size_t n_keep, size_t n_total) {
+	LFA_TRY(lfa_particles_materialize(s));
 	if (n_total <= s->pcap) return LFA_OK;
 	LFA_HIP(s, hipStreamSynchronize(s->stream));
 	const size_t cap = ((n_total + n_total / 8) + 1023) & ~(size_t)1023, old_cap = s->pcap;
@@ -417,6 +423,7 @@ __global__ void k_ingest(const double *aos, size_t n, ParticleSoA p, GridDims g,
 
 extern "C" int lfa_upload_particles(lfa_sim *s, const void *aos152, uint64_t n) {
 	if (!s || (!aos152 && n)) return LFA_E_INVALID;
+	s->vc_pending = false;  // the particle set is replaced
 	if (!(s->prm.cell_size > 0.0)) return lfa_fail(s, LFA_E_INVALID, "set cell_size (lfa_set_params) before uploading");
 	if (n >= ((uint64_t)1 << 32)) return lfa_fail(s, LFA_E_INVALID, "more than 2^32 particles");
 	LFA_HIP(s, hipSetDevice(s->device));
@@ -466,6 +473,7 @@ __global__ void k_export(double *aos, size_t n, ParticleSoA p, GridDims g, Inges
 
 extern "C" int lfa_download_particles(lfa_sim *s, void *aos152, uint64_t n, int flags) {
 	if (!s || (!aos152 && n)) return LFA_E_INVALID;
+	LFA_TRY(lfa_particles_materialize(s));
 	if (n != s->np) return lfa_fail(s, LFA_E_INVALID, "download of %llu particles but %zu are resident",
 	                                (unsigned long long)n, s->np);
 	if (n == 0) return LFA_OK;
@@ -541,6 +549,7 @@ __global__ void k_seed_block(size_t n, size_t first, ParticleSoA p, GridDims g, 
 
 extern "C" int lfa_seed_block(lfa_sim *s, const int64_t lo[3], const int64_t hi[3], uint64_t seed) {
 	if (!s || !lo || !hi) return LFA_E_INVALID;
+	LFA_TRY(lfa_particles_materialize(s));
 	if (!(s->prm.cell_size > 0.0)) return lfa_fail(s, LFA_E_INVALID, "set cell_size before seeding");
 	const int nn[3] = {s->g.nx, s->g.ny, s->g.nz};
 	for (int a = 0; a < 3; ++a)
@@ -784,8 +793,11 @@ __global__ void k_dilate(const int *ptiles, int n_ptiles, uint32_t *flag, GridDi
 /// Pass 2: move every particle to its tile's segment. With `shuffle` the slot inside the segment is a multiplicative
 /// permutation of the rank, which separates particles of one cell (uploads arrive cell-sorted; neighbouring lanes
 /// hitting one cell would serialise the LDS atomics of the P2G scatter).
+/// LIGHT: only key, t, id move (20 of the 68 bytes); from[d] records the source index, v and C follow through it
+/// (k_p2g_*, k_g2p FLIP, k_gather_vc) - see lfa_sim::vc_pending.
+template <bool LIGHT>
 __global__ void k_tile_scatter(size_t n, ParticleSoA src, ParticleSoA dst, const uint32_t *rank,
-                               const uint32_t *tile_start, const uint32_t *tile_count, int shuffle) {
+                               const uint32_t *tile_start, const uint32_t *tile_count, int shuffle, uint32_t *from) {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	uint32_t key = src.key[i], tile = key >> 9, r = rank[i];
@@ -797,13 +809,26 @@ __global__ void k_tile_scatter(size_t n, ParticleSoA src, ParticleSoA dst, const
 	size_t d = (size_t)tile_start[tile] + r;
 	dst.key[d] = key;
 #pragma unroll
-	for (int k = 0; k < 3; ++k) {
-		dst.t[k][d] = src.t[k][i];
-		dst.v[k][d] = src.v[k][i];
-	}
-#pragma unroll
-	for (int k = 0; k < 9; ++k) dst.c[k][d] = src.c[k][i];
+	for (int k = 0; k < 3; ++k) dst.t[k][d] = src.t[k][i];
 	dst.id[d] = src.id[i];
+	if (LIGHT) {
+		from[d] = (uint32_t)i;
+	} else {
+#pragma unroll
+		for (int k = 0; k < 3; ++k) dst.v[k][d] = src.v[k][i];
+#pragma unroll
+		for (int k = 0; k < 9; ++k) dst.c[k][d] = src.c[k][i];
+	}
+}
+/// The deferred half: v, C of the particle now at d from where it was before the binning.
+__global__ void k_gather_vc(size_t n, ParticleSoA old, ParticleSoA cur, const uint32_t *from) {
+	size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (d >= n) return;
+	const uint32_t i = from[d];
+#pragma unroll
+	for (int k = 0; k < 3; ++k) cur.v[k][d] = old.v[k][i];
+#pragma unroll
+	for (int k = 0; k < 9; ++k) cur.c[k][d] = old.c[k][i];
 }
 
 /// Particles per cell for every processed tile (the `count` half of _space_hash, src/simulation.cpp:266-291);
@@ -860,9 +885,22 @@ static int compact_tiles(lfa_sim *s, const uint32_t *flag, int lo, int hi, int *
 	return LFA_OK;
 }
 
+int lfa_particles_materialize(lfa_sim *s) {
+	if (!s->vc_pending) return LFA_OK;
+	s->vc_pending = false;
+	LFA_HIP(s, hipSetDevice(s->device));
+	const size_t n = s->np_live;
+	if (!n) return LFA_OK;
+	hipLaunchKernelGGL(k_gather_vc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, s->pb[s->cur ^ 1], s->pb[s->cur],
+	                   (const uint32_t *)s->vc_src);
+	LFA_LAUNCH_CHECK(s);
+	return LFA_OK;
+}
+
 extern "C" int lfa_hash_particles(lfa_sim *s) {
 	if (!s) return LFA_E_INVALID;
 	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_particles_materialize(s));  // a binning on top of a deferred one: complete that first
 	const GridDims &g = s->g;
 	const int nt = g.nt, L = g.ntx * g.nty;
 	const size_t n = s->binned ? s->np_live : s->np;
@@ -932,10 +970,20 @@ extern "C" int lfa_hash_particles(lfa_sim *s) {
 	if (s->dist) LFA_TRY(lfa_dist_build_halo_lists(s));
 
 	if (n) {
-		hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, src, dst,
-		                   s->rank, s->tile_start, s->tile_count, s->binned ? 0 : 1);
+		// single domain: v and C (48 of the 68 bytes) stay behind and are read through vc_src by the P2G; the G2P writes the
+		// new ones in the new order (slabs: the migration and ghost exchanges want whole records)
+		// APIC only: PIC and FLIP carry C through the step unchanged (the reference's G2P does not touch it), so there it has
+		// to travel with the particle
+		const bool light = !s->dist && s->prm.simulation_method == LFA_APIC && !getenv("LFA_FULL_SCATTER");
+		if (light)
+			hipLaunchKernelGGL(k_tile_scatter<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, src, dst,
+			                   s->rank, s->tile_start, s->tile_count, s->binned ? 0 : 1, s->vc_src);
+		else
+			hipLaunchKernelGGL(k_tile_scatter<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, src, dst,
+			                   s->rank, s->tile_start, s->tile_count, s->binned ? 0 : 1, (uint32_t *)nullptr);
 		LFA_LAUNCH_CHECK(s);
 		s->cur ^= 1;
+		s->vc_pending = light;
 	}
 	if (s->n_dtiles) {
 		int grid = s->n_dtiles < 8192 ? s->n_dtiles : 8192;
@@ -1061,6 +1109,7 @@ __global__ void __launch_bounds__(256) k_max_speed2(size_t n, const float *vx, c
 
 extern "C" int lfa_cfl(lfa_sim *s, double *out) {
 	if (!s || !out) return LFA_E_INVALID;
+	LFA_TRY(lfa_particles_materialize(s));
 	LFA_HIP(s, hipSetDevice(s->device));
 	double m = 0.0;
 	if (s->np_live) {

@@ -246,8 +246,10 @@ struct G2PParams {
 /// The transfer of one particle (PIC :447-461, FLIP blend :463-505, APIC + _calculate_c_vector :507-546).
 /// corner(b0, b1, b2) names the sample cell particle cell + (b0, b1, b2); fetch(field, comp, corner, k) = clamped staggered
 /// sample of field (0-2: u v w, 3-5: FLIP's old grid) at that cell + ((k & 1), (k >> 1) & 1, k >> 2).
+/// `pold`, `j`: where FLIP finds the particle's velocity from before the step (a deferred binning leaves it in the other buffer).
 template <int METHOD, typename Corner, typename Fetch>
-__device__ inline void g2p_particle(const ParticleSoA &p, uint32_t i, const G2PParams &gp, Corner &&corner, Fetch &&fetch) {
+__device__ inline void g2p_particle(const ParticleSoA &p, uint32_t i, const ParticleSoA &pold, uint32_t j, const G2PParams &gp,
+                                    Corner &&corner, Fetch &&fetch) {
 	const float t[3] = {p.t[0][i], p.t[1][i], p.t[2][i]};
 	float vnew[3], vold[3];
 	float cvec[9];
@@ -297,7 +299,7 @@ __device__ inline void g2p_particle(const ParticleSoA &p, uint32_t i, const G2PP
 	}
 	if (METHOD == LFA_FLIP_BLEND) {
 #pragma unroll
-		for (int k = 0; k < 3; ++k) p.v[k][i] = vnew[k] + (p.v[k][i] - vold[k]) * gp.blend;
+		for (int k = 0; k < 3; ++k) p.v[k][i] = vnew[k] + (pold.v[k][j] - vold[k]) * gp.blend;
 	} else {
 #pragma unroll
 		for (int k = 0; k < 3; ++k) p.v[k][i] = vnew[k];
@@ -318,7 +320,7 @@ template <int METHOD, bool STALE>
 __global__ void __launch_bounds__(256)
 k_g2p(const int *ptiles, int n_ptiles, GridDims g, ParticleSoA p, const uint32_t *tile_start, const float *u,
       const float *v, const float *w, const float *uo, const float *vo, const float *wo, G2PParams gp, uint32_t *leavers,
-      uint32_t *n_leavers) {
+      uint32_t *n_leavers, ParticleSoA pold, const uint32_t *from) {
 	constexpr int NF = METHOD == LFA_FLIP_BLEND ? 6 : 3;
 	__shared__ float lds[NF * LFA_HALO_CELLS];
 	__shared__ uint32_t lv[STALE ? G2P_LV_CAP : 1], lv_n, lv_base;
@@ -353,7 +355,8 @@ k_g2p(const int *ptiles, int n_ptiles, GridDims g, ParticleSoA p, const uint32_t
 			const int l = (int)(key & 511);
 			const int cell = ((l & 7) + 1) + 10 * (((l >> 3) & 7) + 1) + 100 * ((l >> 6) + 1);
 			g2p_particle<METHOD>(
-			    p, i, gp, [&](int b0, int b1, int b2) { return cell + b0 + 10 * b1 + 100 * b2; },
+			    p, i, pold, (METHOD == LFA_FLIP_BLEND && from) ? from[i] : i, gp,
+			    [&](int b0, int b1, int b2) { return cell + b0 + 10 * b1 + 100 * b2; },
 			    [&](int field, int, int base, int k) { return lds[field * LFA_HALO_CELLS + base + (k & 1) + 10 * ((k >> 1) & 1) + 100 * (k >> 2)]; });
 		}
 		if (STALE) {  // one global atomic per tile
@@ -370,7 +373,7 @@ k_g2p(const int *ptiles, int n_ptiles, GridDims g, ParticleSoA p, const uint32_t
 template <int METHOD>
 __global__ void __launch_bounds__(256)
 k_g2p_leavers(GridDims g, ParticleSoA p, const float *u, const float *v, const float *w, const float *uo, const float *vo,
-              const float *wo, G2PParams gp, const uint32_t *leavers, const uint32_t *n_leavers) {
+              const float *wo, G2PParams gp, const uint32_t *leavers, const uint32_t *n_leavers, ParticleSoA pold, const uint32_t *from) {
 	const uint32_t n = *n_leavers;
 	for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
 		const uint32_t i = leavers[k], key = p.key[i];
@@ -381,7 +384,8 @@ k_g2p_leavers(GridDims g, ParticleSoA p, const float *u, const float *v, const f
 		const int cx = tx * 8 + (l & 7), cy = ty * 8 + ((l >> 3) & 7), cz = tz * 8 + (l >> 6);
 		const float *F[6] = {u, v, w, uo, vo, wo};
 		g2p_particle<METHOD>(
-		    p, i, gp, [&](int b0, int b1, int b2) { return make_int3(cx + b0, cy + b1, cz + b2); },
+		    p, i, pold, (METHOD == LFA_FLIP_BLEND && from) ? from[i] : i, gp,
+		    [&](int b0, int b1, int b2) { return make_int3(cx + b0, cy + b1, cz + b2); },
 		    [&](int field, int comp, int3 c, int k) { return clamped_sample(g, F[field], comp, c.x + (k & 1), c.y + ((k >> 1) & 1), c.z + (k >> 2)); });
 	}
 }
@@ -491,7 +495,10 @@ static int g2p_run(lfa_sim *s, bool stale) {
 	if (!s->binned) return lfa_fail(s, LFA_E_INVALID, "lfa_g2p: call lfa_hash_particles first");
 	LFA_HIP(s, hipSetDevice(s->device));
 	LFA_TRY(lfa_dist_refresh_grid(s, false));  // extrapolated velocities of the neighbour's adjacent layer
-	if (!s->n_ptiles) return LFA_OK;
+	if (!s->n_ptiles) {
+		s->vc_pending = false;
+		return LFA_OK;
+	}
 	G2PParams gp;
 	gp.method = s->prm.simulation_method;
 	gp.blend = (float)s->prm.blending_factor;
@@ -501,16 +508,20 @@ static int g2p_run(lfa_sim *s, bool stale) {
 	if (s->prm.simulation_method == LFA_FLIP_BLEND && !s->uo) return lfa_fail(s, LFA_E_INVALID, "lfa_g2p: FLIP needs the old grid written by lfa_p2g");
 	// leaver list: the binning's rank array is free between two binnings; its counter sits behind the PCG state words
 	uint32_t *leavers = s->rank, *n_leavers = (uint32_t *)(s->pcg_state + 6);
+	// a deferred binning (lfa_sim::vc_pending): FLIP's old velocity still sits in the other buffer; PIC and APIC overwrite
+	// v, C without reading them. Either way the transfer completes the particle records in the binned order.
+	const ParticleSoA &pold = s->vc_pending ? s->pb[s->cur ^ 1] : s->pb[s->cur];
+	const uint32_t *from = s->vc_pending ? (const uint32_t *)s->vc_src : (const uint32_t *)nullptr;
 	if (stale) LFA_HIP(s, hipMemsetAsync(n_leavers, 0, 4, s->stream));
 	// (the STALE instantiation serves both cases: it allocates 62 VGPRs where the plain one gets 129 - 8 instead of 3 waves
 	// per SIMD; on freshly binned particles it finds no leavers)
 #define G2P_LAUNCH(M)                                                                                                        \
 	do {                                                                                                                     \
 		hipLaunchKernelGGL((k_g2p<M, true>), grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, s->g, p, s->tile_start,   \
-		                   s->u, s->v, s->w, s->uo, s->vo, s->wo, gp, leavers, n_leavers);                                   \
+		                   s->u, s->v, s->w, s->uo, s->vo, s->wo, gp, leavers, n_leavers, pold, from);                       \
 		if (stale)                                                                                                           \
 			hipLaunchKernelGGL(k_g2p_leavers<M>, dim3(512), dim3(256), 0, s->stream, s->g, p, s->u, s->v, s->w, s->uo, s->vo, \
-			                   s->wo, gp, (const uint32_t *)leavers, (const uint32_t *)n_leavers);                           \
+			                   s->wo, gp, (const uint32_t *)leavers, (const uint32_t *)n_leavers, pold, from);               \
 	} while (0)
 	switch (s->prm.simulation_method) {
 	case LFA_PIC: G2P_LAUNCH(LFA_PIC); break;
@@ -519,6 +530,7 @@ static int g2p_run(lfa_sim *s, bool stale) {
 	}
 #undef G2P_LAUNCH
 	LFA_LAUNCH_CHECK(s);
+	s->vc_pending = false;
 	return LFA_OK;
 }
 /// (the public entry point takes the leaver path too: it costs a 4-byte memset and an empty launch on freshly binned

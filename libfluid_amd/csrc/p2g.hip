@@ -89,22 +89,26 @@ struct ParticleRegs {
 	uint32_t key;
 	float t[3], v[3], c[9];
 };
-template <bool APIC> __device__ inline void load_particle(const ParticleSoA &p, uint32_t i, ParticleRegs &r) {
+/// key, t from `p` at i; v, C from `pvc` at j (a deferred binning leaves them in the other buffer: j = vc_src[i], else
+/// pvc == p and j == i).
+template <bool APIC>
+__device__ inline void load_particle(const ParticleSoA &p, const ParticleSoA &pvc, uint32_t i, uint32_t j, ParticleRegs &r) {
 	r.key = p.key[i];
 #pragma unroll
 	for (int k = 0; k < 3; ++k) {
 		r.t[k] = p.t[k][i];
-		r.v[k] = p.v[k][i];
+		r.v[k] = pvc.v[k][j];
 	}
 	if (APIC) {
 #pragma unroll
-		for (int k = 0; k < 9; ++k) r.c[k] = p.c[k][i];
+		for (int k = 0; k < 9; ++k) r.c[k] = pvc.c[k][j];
 	}
 }
 
 template <bool APIC>
 __global__ void __launch_bounds__(256)
-k_p2g_binned(const int *ptiles, int n_ptiles, ParticleSoA p, const uint32_t *tile_start, float *stage, float hworld) {
+k_p2g_binned(const int *ptiles, int n_ptiles, ParticleSoA p, ParticleSoA pvc, const uint32_t *from, const uint32_t *tile_start,
+             float *stage, float hworld) {
 	__shared__ unsigned long long acc[6 * LFA_HALO_CELLS];  // 48 KB: [comp][wv | w][10x10x10]
 	for (int slot = blockIdx.x; slot < n_ptiles; slot += gridDim.x) {
 		const int tile = ptiles[slot];
@@ -112,12 +116,16 @@ k_p2g_binned(const int *ptiles, int n_ptiles, ParticleSoA p, const uint32_t *til
 		__syncthreads();
 		const uint32_t beg = tile_start[tile], end = tile_start[tile + 1];
 		// software pipeline: the loads of the next particle are in flight while the current one is scattered
+		// (with a deferred binning the index of the particle after next is loaded one round ahead of its v, C)
 		ParticleRegs cur, nxt;
 		uint32_t i = beg + threadIdx.x;
-		if (i < end) load_particle<APIC>(p, i, cur);
+		uint32_t jn = i + 256 < end ? (from ? from[i + 256] : i + 256) : 0u;
+		if (i < end) load_particle<APIC>(p, pvc, i, from ? from[i] : i, cur);
 		for (; i < end; i += 256) {
 			const uint32_t in = i + 256;
-			if (in < end) load_particle<APIC>(p, in, nxt);
+			const uint32_t jnn = in + 256 < end ? (from ? from[in + 256] : in + 256) : 0u;
+			if (in < end) load_particle<APIC>(p, pvc, in, jn, nxt);
+			jn = jnn;
 			const int l = (int)(cur.key & 511);
 			scatter_particle<APIC>(l & 7, (l >> 3) & 7, l >> 6, cur.t, cur.v, cur.c, hworld,
 			                       [&](int comp, int hx, int hy, int hz, float wv, float wgt) {
@@ -289,8 +297,11 @@ int lfa_p2g_run(lfa_sim *s, bool fuse_gravity, double dt) {
 		LFA_HIP(s, hipMemsetAsync(s->wo, 0, s->ncp * 4, s->stream));
 	}
 	const float hworld = (float)s->prm.cell_size;
-	const ParticleSoA &p = s->pb[s->cur];
 	const bool binned = s->prm.p2g_variant == LFA_P2G_LDS_BINNED;
+	if (!binned) LFA_TRY(lfa_particles_materialize(s));  // the global-atomic variant reads v, C in place
+	// a deferred binning: v, C come from the other buffer through vc_src
+	const ParticleSoA &p = s->pb[s->cur], &pvc = s->vc_pending ? s->pb[s->cur ^ 1] : s->pb[s->cur];
+	const uint32_t *from = s->vc_pending ? (const uint32_t *)s->vc_src : (const uint32_t *)nullptr;
 	if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[16], s->stream));
 	if (binned) {
 		if ((size_t)s->n_ptiles_all > s->stage_tiles) {
@@ -304,10 +315,10 @@ int lfa_p2g_run(lfa_sim *s, bool fuse_gravity, double dt) {
 		if (s->n_ptiles) {
 			dim3 grid(grid_blocks(s->n_ptiles));
 			if (apic)
-				hipLaunchKernelGGL(k_p2g_binned<true>, grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, p,
+				hipLaunchKernelGGL(k_p2g_binned<true>, grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, p, pvc, from,
 				                   s->tile_start, s->stage + (size_t)s->p_off * 6 * LFA_HALO_CELLS, hworld);
 			else
-				hipLaunchKernelGGL(k_p2g_binned<false>, grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, p,
+				hipLaunchKernelGGL(k_p2g_binned<false>, grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, p, pvc, from,
 				                   s->tile_start, s->stage + (size_t)s->p_off * 6 * LFA_HALO_CELLS, hworld);
 			LFA_LAUNCH_CHECK(s);
 		}
@@ -381,7 +392,9 @@ extern "C" int lfa_add_gravity(lfa_sim *s, double dt) {
 
 /// One launch of the P2G scatter kernel / finalize kernel / binning pass on the current state (lfa_bench_kernel).
 int lfa_p2g_bench(lfa_sim *s, int which) {
-	const ParticleSoA &p = s->pb[s->cur];
+	if (which == LFA_K_P2G_SCATTER && s->prm.p2g_variant != LFA_P2G_LDS_BINNED) LFA_TRY(lfa_particles_materialize(s));
+	const ParticleSoA &p = s->pb[s->cur], &pvc = s->vc_pending ? s->pb[s->cur ^ 1] : s->pb[s->cur];
+	const uint32_t *from = s->vc_pending ? (const uint32_t *)s->vc_src : (const uint32_t *)nullptr;
 	const bool apic = s->prm.simulation_method == LFA_APIC;
 	const float hworld = (float)s->prm.cell_size;
 	if (which == LFA_K_P2G_SCATTER) {
@@ -390,10 +403,10 @@ int lfa_p2g_bench(lfa_sim *s, int which) {
 			dim3 grid(grid_blocks(s->n_ptiles));
 			float *own = s->stage + (size_t)s->p_off * 6 * LFA_HALO_CELLS;
 			if (apic)
-				hipLaunchKernelGGL(k_p2g_binned<true>, grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, p,
+				hipLaunchKernelGGL(k_p2g_binned<true>, grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, p, pvc, from,
 				                   s->tile_start, own, hworld);
 			else
-				hipLaunchKernelGGL(k_p2g_binned<false>, grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, p,
+				hipLaunchKernelGGL(k_p2g_binned<false>, grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, p, pvc, from,
 				                   s->tile_start, own, hworld);
 		} else {
 			if (!s->acc) return lfa_fail(s, LFA_E_INVALID, "no accumulators");

@@ -498,6 +498,7 @@ static MoveParams move_params(const lfa_sim *s, double dt) {
 extern "C" int lfa_advect_collide(lfa_sim *s, double dt) {
 	if (!s) return LFA_E_INVALID;
 	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_particles_materialize(s));  // reads v
 	const size_t n = s->binned ? s->np_live : s->np;
 	if (n) {
 		hipLaunchKernelGGL(k_advect_collide, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, s->pb[s->cur], s->g,
@@ -531,8 +532,9 @@ extern "C" int lfa_correct_collide(lfa_sim *s, double dt) {
 	const int n_index = s->dist ? s->n_ptiles_all : s->n_ptiles;
 	const int grid = n_index < 16384 ? (n_index > 0 ? n_index : 1) : 16384;
 	ParticleSoA &cur = s->pb[s->cur], &oth = s->pb[s->cur ^ 1];
-	// cell-ordered positions: scratch in the other particle buffer (its v / c arrays are free between two binnings)
-	float4 *spos = (float4 *)oth.v[0];
+	// cell-ordered positions: scratch in the v / c arrays that are free right now - the other buffer's, or with a deferred
+	// binning (the other buffer still holds the v, C the G2P may want) this buffer's own, which the G2P is yet to fill
+	float4 *spos = (float4 *)(s->vc_pending ? cur.v[0] : oth.v[0]);
 	hipLaunchKernelGGL(k_build_cell_index, dim3(grid), dim3(256), 0, s->stream, s->dist ? s->ptiles_all : s->ptiles, n_index, cur.key,
 	                   cur.t[0], cur.t[1], cur.t[2], s->tile_start, s->tile_count, s->cell_start, s->rank, spos, s->cell_count,
 	                   s->slab_lo * L, s->slab_hi * L);
