@@ -182,3 +182,34 @@ def test_g2p_on_the_order_of_the_last_binning_equals_g2p_after_rebinning(method)
         scale = np.abs(a[f]).max()
         assert np.abs(a[f] - b[f]).max() < 2e-4 * scale, f
     assert np.abs(a["vel"] - parts["vel"]).max() > 1e-2 * np.abs(a["vel"]).max()  # the transfer did change velocities
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seq", ["hash", "hash,hash", "hash,p2g", "hash,p2g,hash", "hash,correct", "hash,advect,hash",
+                                 "hash,p2g,correct,hash,p2g", "hash,cfl"])
+def test_deferred_binning_never_loses_velocities(seq):
+    """With APIC the binning moves key, t and id only; v and C follow lazily (the P2G reads them through the source index,
+    the G2P rewrites them). Whatever is called in between, a download returns every particle's own v and C."""
+    c, parts, solid = fullstep_inputs()
+    parts = parts.copy()
+    rng = np.random.default_rng(11)
+    for f in ("cx", "cy", "cz"):
+        parts[f] = rng.normal(size=(len(parts), 3))
+    s = lfa.Sim(c["size"], method=lfa.APIC)
+    s.set_solid_cells(solid)
+    s.upload_particles(parts)
+    for op in seq.split(","):
+        if op == "hash":
+            s.hash()
+        elif op == "p2g":
+            s.p2g()
+        elif op == "correct":
+            s.correct_collide(1e-3)
+        elif op == "advect":
+            s.advect_collide(1e-3)
+        elif op == "cfl":
+            s.cfl()
+    out = s.download_particles(into=parts.copy())  # velocities and C only; upload order
+    s.close()
+    for f in ("vel", "cx", "cy", "cz"):
+        assert np.array_equal(out[f].astype(np.float32), parts[f].astype(np.float32)), (seq, f)
