@@ -137,7 +137,7 @@ struct lfa_sim {
 	bool system_valid = false, unknown_count_valid = false;
 	double last_residual = 0.0;
 	uint64_t last_iters = 0;
-	// Deferred half of the binning (single domain, APIC): lfa_hash_particles moves key, t, id (20 of the 68 bytes) and records
+	// Deferred half of the binning (APIC): lfa_hash_particles moves key, t, id (20 of the 68 bytes) and records
 	// where each particle came from; v and C stay in the other buffer until the P2G has read them through that index -
 	// the G2P then writes the new v, C straight into the binned order. Anything else that reads v or C calls
 	// lfa_particles_materialize first.

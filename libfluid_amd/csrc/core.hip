@@ -970,11 +970,11 @@ extern "C" int lfa_hash_particles(lfa_sim *s) {
 	if (s->dist) LFA_TRY(lfa_dist_build_halo_lists(s));
 
 	if (n) {
-		// single domain: v and C (48 of the 68 bytes) stay behind and are read through vc_src by the P2G; the G2P writes the
-		// new ones in the new order (slabs: the migration and ghost exchanges want whole records)
+		// v and C (48 of the 68 bytes) stay behind and are read through vc_src by the P2G; the G2P writes the new ones in the
+		// new order (the slab migration, which packs whole records, completes the move first)
 		// APIC only: PIC and FLIP carry C through the step unchanged (the reference's G2P does not touch it), so there it has
 		// to travel with the particle
-		const bool light = !s->dist && s->prm.simulation_method == LFA_APIC && !getenv("LFA_FULL_SCATTER");
+		const bool light = s->prm.simulation_method == LFA_APIC && !getenv("LFA_FULL_SCATTER");
 		if (light)
 			hipLaunchKernelGGL(k_tile_scatter<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, src, dst,
 			                   s->rank, s->tile_start, s->tile_count, s->binned ? 0 : 1, s->vc_src);

@@ -383,6 +383,7 @@ int lfa_particles_reserve(lfa_sim *s, size_t n_keep, size_t n_total);  // core.h
 /// neighbour ranks and take theirs. Moves of more than one slab per step are not handled (CFL bounds a step to 3 cells).
 int lfa_dist_migrate(lfa_sim *s) {
 	if (!s->dist) return LFA_OK;
+	LFA_TRY(lfa_particles_materialize(s));  // leavers travel as whole records
 	const size_t n = s->binned ? s->np_live : s->np;
 	uint32_t *cnt = (uint32_t *)(s->dist_red + 32);  // [0,1] leaving lo/hi, [2,3] arriving from lo/hi
 	LFA_HIP(s, hipMemsetAsync(cnt, 0, 16, s->stream));
