@@ -144,14 +144,16 @@ k_advect_collide(size_t n, ParticleSoA p, GridDims g, const uint8_t *solid, Move
 	for (int d = 0; d < 3; ++d) p.t[d][i] = nt[d];
 }
 
+#define CIDX_STAGE 4608  // records staged in LDS per tile (72 KB: two workgroups per CU); 8 per cell fill 4096
 /// Per particle tile: indices of the tile's particles grouped by cell (the `begin` half of the reference's _space_hash,
 /// include/fluid/simulation.h:193-197) - only the position correction needs cell lists.
 __global__ void __launch_bounds__(256)
 k_build_cell_index(const int *ptiles, int n_ptiles, const uint32_t *key, const float *t0, const float *t1, const float *t2,
-                   const uint32_t *tile_start, const uint32_t *tile_count, uint32_t *cell_start, uint32_t *cidx, float4 *spos,
+                   const uint32_t *tile_start, const uint32_t *tile_count, uint32_t *cell_start, float4 *spos,
                    uint32_t *ghost_cell_count, int own_lo, int own_hi) {
 	__shared__ uint32_t cnt[LFA_TILE_CELLS];
 	__shared__ uint32_t wsum[4];
+	__shared__ float4 stage[CIDX_STAGE];
 	for (int slot = blockIdx.x; slot < n_ptiles; slot += gridDim.x) {
 		const int tile = ptiles[slot];
 		// ghost tiles (slab decomposition) keep their particles behind the live ones: the range end comes from the count
@@ -187,11 +189,18 @@ k_build_cell_index(const int *ptiles, int n_ptiles, const uint32_t *key, const f
 		__syncthreads();
 		// besides the index list, the in-cell positions in the same cell order (+ the particle index): the tiled correction
 		// stages whole cell runs from it with contiguous reads (gathering t[d][cidx[..]] cost 16x its bytes: 7 of 13 ms at C4)
+		// The records are put in place in LDS and written out as one contiguous run (scattered 16-B stores straight to HBM made
+		// this kernel 1.7 ms at C4); a tile with more particles than the staging area holds writes them directly.
+		const bool staged = e - b <= CIDX_STAGE;
 		for (uint32_t i = b + threadIdx.x; i < e; i += 256) {
 			const uint32_t at = atomicAdd(&cnt[key[i] & 511], 1u);
-			cidx[at] = i;
-			spos[at] = make_float4(t0[i], t1[i], t2[i], __uint_as_float(i));
+			const float4 rec = make_float4(t0[i], t1[i], t2[i], __uint_as_float(i));
+			if (staged) stage[at - b] = rec;
+			else spos[at] = rec;
 		}
+		__syncthreads();
+		if (staged)
+			for (uint32_t k = threadIdx.x; k < e - b; k += 256) spos[b + k] = stage[k];
 		__syncthreads();
 	}
 }
@@ -536,7 +545,7 @@ extern "C" int lfa_correct_collide(lfa_sim *s, double dt) {
 	// binning (the other buffer still holds the v, C the G2P may want) this buffer's own, which the G2P is yet to fill
 	float4 *spos = (float4 *)(s->vc_pending ? cur.v[0] : oth.v[0]);
 	hipLaunchKernelGGL(k_build_cell_index, dim3(grid), dim3(256), 0, s->stream, s->dist ? s->ptiles_all : s->ptiles, n_index, cur.key,
-	                   cur.t[0], cur.t[1], cur.t[2], s->tile_start, s->tile_count, s->cell_start, s->rank, spos, s->cell_count,
+	                   cur.t[0], cur.t[1], cur.t[2], s->tile_start, s->tile_count, s->cell_start, spos, s->cell_count,
 	                   s->slab_lo * L, s->slab_hi * L);
 	LFA_LAUNCH_CHECK(s);
 	if (n) {
