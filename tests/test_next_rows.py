@@ -213,3 +213,33 @@ def test_deferred_binning_never_loses_velocities(seq):
     s.close()
     for f in ("vel", "cx", "cy", "cz"):
         assert np.array_equal(out[f].astype(np.float32), parts[f].astype(np.float32)), (seq, f)
+
+
+@pytest.mark.gpu
+def test_deferred_binning_is_bitwise_the_full_scatter(monkeypatch):
+    """Five hot steps with the deferred binning (key, t, id move; v, C through the source index) and
+    with LFA_FULL_SCATTER=1 (whole records move): the P2G sums are order-independent fixed point and everything else is
+    per particle, so velocities, C and pressures agree bit for bit."""
+    c, parts, solid = fullstep_inputs()
+    outs = []
+    for full in (False, True):
+        if full:
+            monkeypatch.setenv("LFA_FULL_SCATTER", "1")
+        else:
+            monkeypatch.delenv("LFA_FULL_SCATTER", raising=False)
+        s = lfa.Sim(c["size"], method=lfa.APIC, precond=lfa.PRECOND_MIC0_TILED, pcg_dtype=lfa.PCG_F64)
+        s.set_solid_cells(solid)
+        s.upload_particles(parts)
+        its = []
+        for _ in range(5):
+            res, it, rc = s.step_hot(c["dt"])
+            assert rc == 0
+            its.append(it)
+        p = s.pressure().copy()
+        outs.append((s.download_particles(into=parts.copy()), p, its))
+        s.close()
+    (a, pa, ia), (b, pb, ib) = outs
+    assert ia == ib
+    assert np.array_equal(pa, pb)
+    for f in ("vel", "cx", "cy", "cz"):
+        assert np.array_equal(a[f], b[f]), f
