@@ -613,14 +613,141 @@ k_mg_prolong_postsmooth(MgLv<real> L, GridDims gc, const real *e, real inv_scale
 template <typename real> struct MgTail {
 	MgLv<real> lv[MG_MAX_LEVELS];
 	int first, last, nsw, inner;
+	int chain;  // first level of the trailing run of single-tile levels handled by single_tile_chain (== last: none but the coarsest)
 };
+#define MG_CHAIN_MAX 4
+/// The trailing levels that consist of ONE active tile each (the last two at every BASELINE size), down and up inside one
+/// wave: a single tile has no active neighbours, so nothing but its own column and its parent is ever needed - right-hand
+/// sides, iterates and results stay in LDS instead of making a global-memory round trip and a workgroup barrier per phase
+/// (the same operations in the same order as presmooth_tile / residual_restrict_tile / coarsest_tile /
+/// prolong_postsmooth_tile: bit-identical results). `h`: all zero on entry (the ring stays zero throughout).
+template <typename real>
+__device__ inline void single_tile_chain(const MgTail<real> &T, real *h, int lane, real (*cb)[LFA_HALO_CELLS], real (*cx)[LFA_HALO_CELLS],
+                                         real (*cy)[LFA_HALO_CELLS], uint8_t *cab_) {
+	uint8_t (*cab)[512] = (uint8_t (*)[512])cab_;
+	static_assert(1 + 3 * MG_CHAIN_MAX < MG_TAIL_WAVES && MG_CHAIN_MAX * 512 <= LFA_HALO_CELLS * (int)sizeof(real), "chain arrays must fit the idle halo blocks");
+	const int lx = lane & 7, ly = lane >> 3, s1 = T.chain, n = T.last - s1 + 1;
+	// A bytes of every chain level, right-hand side of the first one
+	for (int k = 0; k < n; ++k) {
+		const MgLv<real> &L = T.lv[s1 + k];
+		const size_t base = (size_t)L.tiles[0] * 512;
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) {
+			cab[k][zz * 64 + lane] = L.abits[base + zz * 64 + lane];
+			cb[k][zz * 64 + lane] = k == 0 ? L.b[base + zz * 64 + lane] : (real)0;
+		}
+	}
+	MG_FENCE();
+	for (int k = 0; k + 1 < n; ++k) {  // down
+		const MgLv<real> &L = T.lv[s1 + k];
+		uint32_t ab[8];
+		real bb[8];
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) {
+			ab[zz] = cab[k][zz * 64 + lane];
+			bb[zz] = cb[k][zz * 64 + lane];
+		}
+		presmooth_column<real>(h, ab, bb, lx, ly, T.inner);
+		real pair[4];
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) {
+			const int i = (lx + 1) + 10 * (ly + 1) + 100 * (zz + 1);
+			cx[k][zz * 64 + lane] = h[i];
+			const uint32_t a = ab[zz];
+			real r = (real)0;
+			if (a & AB_UNKNOWN) {
+				const real F = (a & AB_FLUID) ? (real)1 : (real)0;
+				real val = (real)(a & 7) * h[i];
+				val -= F * h[i - 1];
+				val -= F * h[i - 10];
+				val -= F * h[i - 100];
+				val -= (real)((a >> 3) & 1) * h[i + 1];
+				val -= (real)((a >> 4) & 1) * h[i + 10];
+				val -= (real)((a >> 5) & 1) * h[i + 100];
+				r = bb[zz] - val;
+			}
+			if (zz & 1) pair[zz >> 1] += r;
+			else pair[zz >> 1] = r;
+		}
+		int tx, ty, tz;
+		tile_coords(L.g, L.tiles[0], tx, ty, tz);
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			real t = pair[j];
+			t += __shfl_xor(t, 1, 64);
+			t += __shfl_xor(t, 8, 64);
+			if (!(lx & 1) && !(ly & 1))
+				cb[k + 1][((tz & 1) * 4 + j) * 64 + ((ty & 1) * 4 + (ly >> 1)) * 8 + (tx & 1) * 4 + (lx >> 1)] = (real)0.5 * t;
+		}
+		MG_FENCE();
+	}
+	{  // coarsest level: nsw sweeps red->black, nsw black->red from zero
+		const int k = n - 1;
+		uint32_t ab[8];
+		real bb[8];
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) {
+			ab[zz] = cab[k][zz * 64 + lane];
+			bb[zz] = cb[k][zz * 64 + lane];
+			h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)] = (real)0;
+		}
+		MG_FENCE();
+		for (int q = 0; q < 2 * T.nsw; ++q) {
+			const int fc = q < T.nsw ? 0 : 1;
+			gs_colour<real>(h, ab, bb, lx, ly, fc);
+			MG_FENCE();
+			gs_colour<real>(h, ab, bb, lx, ly, fc ^ 1);
+			MG_FENCE();
+		}
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) cy[k][zz * 64 + lane] = h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)];
+		if (n == 1) {
+			const size_t base = (size_t)T.lv[T.last].tiles[0] * 512;
+#pragma unroll
+			for (int zz = 0; zz < 8; ++zz) T.lv[T.last].y[base + zz * 64 + lane] = cy[k][zz * 64 + lane];
+		}
+		MG_FENCE();
+	}
+	for (int k = n - 2; k >= 0; --k) {  // up
+		const MgLv<real> &L = T.lv[s1 + k];
+		int tx, ty, tz;
+		tile_coords(L.g, L.tiles[0], tx, ty, tz);
+		uint32_t ab[8];
+		real bb[8];
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) {
+			ab[zz] = cab[k][zz * 64 + lane];
+			bb[zz] = cb[k][zz * 64 + lane];
+			real v = cx[k][zz * 64 + lane];
+			// the parent cell of (tx*8+lx, ty*8+ly, tz*8+zz) inside the single tile of the next level
+			const int X = (tx * 8 + lx) >> 1, Y = (ty * 8 + ly) >> 1, Z = (tz * 8 + zz) >> 1;
+			if (ab[zz] & AB_UNKNOWN) v += cy[k + 1][(X & 7) | ((Y & 7) << 3) | ((Z & 7) << 6)];
+			h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)] = v;
+		}
+		MG_FENCE();
+		for (int it = 0; it < T.inner; ++it) {
+			gs_colour<real>(h, ab, bb, lx, ly, 1);
+			MG_FENCE();
+			gs_colour<real>(h, ab, bb, lx, ly, 0);
+			MG_FENCE();
+		}
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) cy[k][zz * 64 + lane] = h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)];
+		if (k == 0) {  // the level above (several tiles, in global memory) reads this result
+			const size_t base = (size_t)L.tiles[0] * 512;
+#pragma unroll
+			for (int zz = 0; zz < 8; ++zz) L.y[base + zz * 64 + lane] = cy[0][zz * 64 + lane];
+		}
+		MG_FENCE();
+	}
+}
 template <typename real>
 __global__ void __launch_bounds__(MG_TAIL_WAVES * 64) k_mg_tail(MgTail<real> T, const int *state) {
 	__shared__ real halo[MG_TAIL_WAVES][LFA_HALO_CELLS];
 	if (state[0] >= 0) return;
 	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
 	real *h = halo[wid];
-	for (int l = T.first; l < T.last; ++l) {
+	for (int l = T.first; l < T.chain; ++l) {
 		const MgLv<real> &L = T.lv[l];
 		for (int i = lane; i < LFA_HALO_CELLS; i += 64) h[i] = (real)0;
 		for (int slot = wid; slot < L.n_tiles; slot += MG_TAIL_WAVES) presmooth_tile<real>(L, slot, h, lane, T.inner);
@@ -630,10 +757,13 @@ __global__ void __launch_bounds__(MG_TAIL_WAVES * 64) k_mg_tail(MgTail<real> T, 
 	}
 	if (wid == 0) {
 		for (int i = lane; i < LFA_HALO_CELLS; i += 64) h[i] = (real)0;
-		coarsest_tile<real>(T.lv[T.last], T.nsw, h, lane);
+		MG_FENCE();
+		// (its level arrays live in the halo blocks of the waves that wait at the barrier below: 512 of their 1000 entries each)
+		single_tile_chain<real>(T, h, lane, &halo[1], &halo[1 + MG_CHAIN_MAX], &halo[1 + 2 * MG_CHAIN_MAX],
+		                        (uint8_t *)&halo[1 + 3 * MG_CHAIN_MAX][0]);
 	}
 	__syncthreads();
-	for (int l = T.last - 1; l >= T.first; --l) {
+	for (int l = T.chain - 1; l >= T.first; --l) {
 		const MgLv<real> &L = T.lv[l];
 		for (int slot = wid; slot < L.n_tiles; slot += MG_TAIL_WAVES) {
 			real bb[8];
@@ -932,6 +1062,10 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		for (int l = tail; l <= last; ++l) T.lv[l] = lvl(l);
 		T.first = tail;
 		T.last = last;
+		// the trailing run of single-tile levels (at most MG_CHAIN_MAX of them) stays inside one wave
+		T.chain = last;
+		if (!getenv("LFA_MG_NO_CHAIN"))
+			while (T.chain > tail && last - (T.chain - 1) + 1 <= MG_CHAIN_MAX && M.lv[T.chain - 1].n_tiles == 1) --T.chain;
 		T.nsw = MG_COARSEST_SWEEPS;
 		T.inner = MG_INNER_SWEEPS;  // measured at C4: 19 iterations; 1 sweep on the tail levels: 22
 		if (const char *e = getenv("LFA_MG_TAIL_INNER")) T.inner = std::max(1, atoi(e));

@@ -446,3 +446,28 @@ def test_properties_at_full_size():
     ids = np.sort(s.particle_ids())
     assert ids[0] == 0 and ids[-1] == len(ids) - 1 and np.all(np.diff(ids) == 1), "binning must permute the particles"
     s.close()
+
+
+@pytest.mark.parametrize("dtype", [lfa.PCG_F32, lfa.PCG_F64])
+def test_multigrid_single_tile_chain_is_bitwise_the_level_by_level_tail(dtype, monkeypatch):
+    """The last levels of the hierarchy hold one active tile each; the tail workgroup runs them down and up inside one wave
+    out of LDS (single_tile_chain). Same operations in the same order as the level-by-level code (LFA_MG_NO_CHAIN=1):
+    identical iteration counts and bit-identical pressures."""
+    size, block = (64, 48, 72), ((0, 0, 0), (30, 26, 40))
+    res = []
+    for no_chain in (False, True):
+        if no_chain:
+            monkeypatch.setenv("LFA_MG_NO_CHAIN", "1")
+        else:
+            monkeypatch.delenv("LFA_MG_NO_CHAIN", raising=False)
+        s = lfa.Sim(size, precond=lfa.PRECOND_MULTIGRID, pcg_dtype=dtype)
+        s.seed_block(*block)
+        its = []
+        for _ in range(2):
+            r, it, rc = s.step_hot(util.DT)
+            assert rc == 0
+            its.append(it)
+        res.append((its, s.pressure().copy()))
+        s.close()
+    assert res[0][0] == res[1][0]
+    assert np.array_equal(res[0][1], res[1][1])
