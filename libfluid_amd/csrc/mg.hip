@@ -616,129 +616,129 @@ template <typename real> struct MgTail {
 	int chain;  // first level of the trailing run of single-tile levels handled by single_tile_chain (== last: none but the coarsest)
 };
 #define MG_CHAIN_MAX 4
-/// The trailing levels that consist of ONE active tile each (the last two at every BASELINE size), down and up inside one
-/// wave: a single tile has no active neighbours, so nothing but its own column and its parent is ever needed - right-hand
-/// sides, iterates and results stay in LDS instead of making a global-memory round trip and a workgroup barrier per phase
-/// (the same operations in the same order as presmooth_tile / residual_restrict_tile / coarsest_tile /
-/// prolong_postsmooth_tile: bit-identical results). `h`: all zero on entry (the ring stays zero throughout).
+/// gs_colour for ONE cell (halo index i): the same expression, term by term.
+template <typename real> __device__ inline void gs_cell(real *H, uint32_t a, real bv, int i) {
+	if (!(a & AB_UNKNOWN) || !(a & 7)) return;
+	const real F = (a & AB_FLUID) ? (real)1 : (real)0;
+	real sum = bv;
+	sum += F * H[i - 1];
+	sum += F * H[i - 10];
+	sum += F * H[i - 100];
+	sum += (real)((a >> 3) & 1) * H[i + 1];
+	sum += (real)((a >> 4) & 1) * H[i + 10];
+	sum += (real)((a >> 5) & 1) * H[i + 100];
+	H[i] = H[i] + (real)MG_OMEGA * (sum * rcp_diag<real>(a & 7) - H[i]);
+}
+/// The trailing levels that consist of ONE active tile each (the last two at every BASELINE size), down and up with the
+/// whole workgroup on one tile: a thread per cell (512) for the cell-wise phases, a thread per cell of one colour (256)
+/// for the Gauss-Seidel half sweeps, a workgroup barrier between them; right-hand sides, iterates and results stay in LDS.
+/// A single tile has no active neighbours, so the ring of the halo block stays zero. One wave doing all of this alone
+/// (4 cells per lane and colour, 24 dependent half sweeps per V-cycle) spent 22 of the tail's 35 us on instruction latency
+/// (s_memtime stamps). Same operations in the same order as presmooth_tile / residual_restrict_tile / coarsest_tile /
+/// prolong_postsmooth_tile: bit-identical results (tested against LFA_MG_NO_CHAIN=1).
 template <typename real>
-__device__ inline void single_tile_chain(const MgTail<real> &T, real *h, int lane, real (*cb)[LFA_HALO_CELLS], real (*cx)[LFA_HALO_CELLS],
-                                         real (*cy)[LFA_HALO_CELLS], uint8_t *cab_) {
+__device__ inline void single_tile_chain(const MgTail<real> &T, real *H, real (*cb)[LFA_HALO_CELLS], real (*cx)[LFA_HALO_CELLS],
+                                         real (*cy)[LFA_HALO_CELLS], real *R, uint8_t *cab_) {
 	uint8_t (*cab)[512] = (uint8_t (*)[512])cab_;
-	static_assert(1 + 3 * MG_CHAIN_MAX < MG_TAIL_WAVES && MG_CHAIN_MAX * 512 <= LFA_HALO_CELLS * (int)sizeof(real), "chain arrays must fit the idle halo blocks");
-	const int lx = lane & 7, ly = lane >> 3, s1 = T.chain, n = T.last - s1 + 1;
-	// A bytes of every chain level, right-hand side of the first one
-	for (int k = 0; k < n; ++k) {
-		const MgLv<real> &L = T.lv[s1 + k];
-		const size_t base = (size_t)L.tiles[0] * 512;
-#pragma unroll
-		for (int zz = 0; zz < 8; ++zz) {
-			cab[k][zz * 64 + lane] = L.abits[base + zz * 64 + lane];
-			cb[k][zz * 64 + lane] = k == 0 ? L.b[base + zz * 64 + lane] : (real)0;
+	static_assert(3 + 3 * MG_CHAIN_MAX <= MG_TAIL_WAVES && MG_CHAIN_MAX * 512 <= LFA_HALO_CELLS * (int)sizeof(real), "chain arrays must fit the halo blocks");
+	const int t = threadIdx.x, s1 = T.chain, n = T.last - s1 + 1;
+	const bool cellwise = t < 512, colourwise = t < 256;
+	// cell of a thread in the cell-wise phases, and its halo index
+	const int cell = t & 511, px = cell & 7, py = (cell >> 3) & 7, pz = cell >> 6;
+	const int hi = (px + 1) + 10 * (py + 1) + 100 * (pz + 1);
+	// cell of a thread in a half sweep of colour c: column (qx, qy), z = 2 j + ((qx + qy + c) & 1)
+	const int qx = t & 7, qy = (t >> 3) & 7, qj = (t >> 6) & 3;
+	auto half_sweep = [&](int k, int colour) {
+		if (colourwise) {
+			const int z = 2 * qj + ((qx + qy + colour) & 1), c = qx + 8 * qy + 64 * z;
+			gs_cell<real>(H, cab[k][c], cb[k][c], (qx + 1) + 10 * (qy + 1) + 100 * (z + 1));
 		}
-	}
-	MG_FENCE();
+		__syncthreads();
+	};
+	for (int i = t; i < LFA_HALO_CELLS; i += MG_TAIL_WAVES * 64) H[i] = (real)0;
+	if (cellwise)
+		for (int k = 0; k < n; ++k) {
+			const MgLv<real> &L = T.lv[s1 + k];
+			const size_t base = (size_t)L.tiles[0] * 512;
+			cab[k][cell] = L.abits[base + cell];
+			cb[k][cell] = k == 0 ? L.b[base + cell] : (real)0;
+		}
+	__syncthreads();
 	for (int k = 0; k + 1 < n; ++k) {  // down
 		const MgLv<real> &L = T.lv[s1 + k];
-		uint32_t ab[8];
-		real bb[8];
-#pragma unroll
-		for (int zz = 0; zz < 8; ++zz) {
-			ab[zz] = cab[k][zz * 64 + lane];
-			bb[zz] = cb[k][zz * 64 + lane];
+		if (cellwise) H[hi] = (real)0;
+		__syncthreads();
+		for (int it = 0; it < T.inner; ++it) {
+			half_sweep(k, 0);
+			half_sweep(k, 1);
 		}
-		presmooth_column<real>(h, ab, bb, lx, ly, T.inner);
-		real pair[4];
-#pragma unroll
-		for (int zz = 0; zz < 8; ++zz) {
-			const int i = (lx + 1) + 10 * (ly + 1) + 100 * (zz + 1);
-			cx[k][zz * 64 + lane] = h[i];
-			const uint32_t a = ab[zz];
+		if (cellwise) {
+			cx[k][cell] = H[hi];
+			const uint32_t a = cab[k][cell];
 			real r = (real)0;
 			if (a & AB_UNKNOWN) {
 				const real F = (a & AB_FLUID) ? (real)1 : (real)0;
-				real val = (real)(a & 7) * h[i];
-				val -= F * h[i - 1];
-				val -= F * h[i - 10];
-				val -= F * h[i - 100];
-				val -= (real)((a >> 3) & 1) * h[i + 1];
-				val -= (real)((a >> 4) & 1) * h[i + 10];
-				val -= (real)((a >> 5) & 1) * h[i + 100];
-				r = bb[zz] - val;
+				real val = (real)(a & 7) * H[hi];
+				val -= F * H[hi - 1];
+				val -= F * H[hi - 10];
+				val -= F * H[hi - 100];
+				val -= (real)((a >> 3) & 1) * H[hi + 1];
+				val -= (real)((a >> 4) & 1) * H[hi + 10];
+				val -= (real)((a >> 5) & 1) * H[hi + 100];
+				r = cb[k][cell] - val;
 			}
-			if (zz & 1) pair[zz >> 1] += r;
-			else pair[zz >> 1] = r;
+			R[cell] = r;
 		}
-		int tx, ty, tz;
-		tile_coords(L.g, L.tiles[0], tx, ty, tz);
-#pragma unroll
-		for (int j = 0; j < 4; ++j) {
-			real t = pair[j];
-			t += __shfl_xor(t, 1, 64);
-			t += __shfl_xor(t, 8, 64);
-			if (!(lx & 1) && !(ly & 1))
-				cb[k + 1][((tz & 1) * 4 + j) * 64 + ((ty & 1) * 4 + (ly >> 1)) * 8 + (tx & 1) * 4 + (lx >> 1)] = (real)0.5 * t;
+		__syncthreads();
+		if (t < 64) {  // one coarse cell each: its 8 children in the order of the pair sums and the two shuffle steps
+			const int X = t & 3, Y = (t >> 2) & 3, Z = t >> 4;
+			auto pair = [&](int x, int y) { real p = R[x + 8 * y + 64 * (2 * Z)]; p += R[x + 8 * y + 64 * (2 * Z + 1)]; return p; };
+			real v = pair(2 * X, 2 * Y);
+			v += pair(2 * X + 1, 2 * Y);
+			real w = pair(2 * X, 2 * Y + 1);
+			w += pair(2 * X + 1, 2 * Y + 1);
+			v += w;
+			int tx, ty, tz;
+			tile_coords(L.g, L.tiles[0], tx, ty, tz);
+			cb[k + 1][((tz & 1) * 4 + Z) * 64 + ((ty & 1) * 4 + Y) * 8 + (tx & 1) * 4 + X] = (real)0.5 * v;
 		}
-		MG_FENCE();
+		__syncthreads();
 	}
 	{  // coarsest level: nsw sweeps red->black, nsw black->red from zero
 		const int k = n - 1;
-		uint32_t ab[8];
-		real bb[8];
-#pragma unroll
-		for (int zz = 0; zz < 8; ++zz) {
-			ab[zz] = cab[k][zz * 64 + lane];
-			bb[zz] = cb[k][zz * 64 + lane];
-			h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)] = (real)0;
-		}
-		MG_FENCE();
+		if (cellwise) H[hi] = (real)0;
+		__syncthreads();
 		for (int q = 0; q < 2 * T.nsw; ++q) {
 			const int fc = q < T.nsw ? 0 : 1;
-			gs_colour<real>(h, ab, bb, lx, ly, fc);
-			MG_FENCE();
-			gs_colour<real>(h, ab, bb, lx, ly, fc ^ 1);
-			MG_FENCE();
+			half_sweep(k, fc);
+			half_sweep(k, fc ^ 1);
 		}
-#pragma unroll
-		for (int zz = 0; zz < 8; ++zz) cy[k][zz * 64 + lane] = h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)];
-		if (n == 1) {
-			const size_t base = (size_t)T.lv[T.last].tiles[0] * 512;
-#pragma unroll
-			for (int zz = 0; zz < 8; ++zz) T.lv[T.last].y[base + zz * 64 + lane] = cy[k][zz * 64 + lane];
+		if (cellwise) {
+			cy[k][cell] = H[hi];
+			if (n == 1) T.lv[T.last].y[(size_t)T.lv[T.last].tiles[0] * 512 + cell] = H[hi];
 		}
-		MG_FENCE();
+		__syncthreads();
 	}
 	for (int k = n - 2; k >= 0; --k) {  // up
 		const MgLv<real> &L = T.lv[s1 + k];
-		int tx, ty, tz;
-		tile_coords(L.g, L.tiles[0], tx, ty, tz);
-		uint32_t ab[8];
-		real bb[8];
-#pragma unroll
-		for (int zz = 0; zz < 8; ++zz) {
-			ab[zz] = cab[k][zz * 64 + lane];
-			bb[zz] = cb[k][zz * 64 + lane];
-			real v = cx[k][zz * 64 + lane];
-			// the parent cell of (tx*8+lx, ty*8+ly, tz*8+zz) inside the single tile of the next level
-			const int X = (tx * 8 + lx) >> 1, Y = (ty * 8 + ly) >> 1, Z = (tz * 8 + zz) >> 1;
-			if (ab[zz] & AB_UNKNOWN) v += cy[k + 1][(X & 7) | ((Y & 7) << 3) | ((Z & 7) << 6)];
-			h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)] = v;
+		if (cellwise) {
+			int tx, ty, tz;
+			tile_coords(L.g, L.tiles[0], tx, ty, tz);
+			real v = cx[k][cell];
+			const int X = (tx * 8 + px) >> 1, Y = (ty * 8 + py) >> 1, Z = (tz * 8 + pz) >> 1;  // parent cell in the next level's tile
+			if (cab[k][cell] & AB_UNKNOWN) v += cy[k + 1][(X & 7) | ((Y & 7) << 3) | ((Z & 7) << 6)];
+			H[hi] = v;
 		}
-		MG_FENCE();
+		__syncthreads();
 		for (int it = 0; it < T.inner; ++it) {
-			gs_colour<real>(h, ab, bb, lx, ly, 1);
-			MG_FENCE();
-			gs_colour<real>(h, ab, bb, lx, ly, 0);
-			MG_FENCE();
+			half_sweep(k, 1);
+			half_sweep(k, 0);
 		}
-#pragma unroll
-		for (int zz = 0; zz < 8; ++zz) cy[k][zz * 64 + lane] = h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)];
-		if (k == 0) {  // the level above (several tiles, in global memory) reads this result
-			const size_t base = (size_t)L.tiles[0] * 512;
-#pragma unroll
-			for (int zz = 0; zz < 8; ++zz) L.y[base + zz * 64 + lane] = cy[0][zz * 64 + lane];
+		if (cellwise) {
+			cy[k][cell] = H[hi];
+			if (k == 0) L.y[(size_t)L.tiles[0] * 512 + cell] = H[hi];  // the level above (several tiles, global memory) reads this
 		}
-		MG_FENCE();
+		__syncthreads();
 	}
 }
 template <typename real>
@@ -755,14 +755,8 @@ __global__ void __launch_bounds__(MG_TAIL_WAVES * 64) k_mg_tail(MgTail<real> T, 
 		for (int slot = wid; slot < L.n_tiles; slot += MG_TAIL_WAVES) residual_restrict_tile<real>(L, T.lv[l + 1].g, T.lv[l + 1].b, slot, h, lane);
 		__syncthreads();
 	}
-	if (wid == 0) {
-		for (int i = lane; i < LFA_HALO_CELLS; i += 64) h[i] = (real)0;
-		MG_FENCE();
-		// (its level arrays live in the halo blocks of the waves that wait at the barrier below: 512 of their 1000 entries each)
-		single_tile_chain<real>(T, h, lane, &halo[1], &halo[1 + MG_CHAIN_MAX], &halo[1 + 2 * MG_CHAIN_MAX],
-		                        (uint8_t *)&halo[1 + 3 * MG_CHAIN_MAX][0]);
-	}
-	__syncthreads();
+	// (the chain's level arrays live in the halo blocks of the waves: 512 of their 1000 entries each)
+	single_tile_chain<real>(T, halo[0], &halo[3], &halo[3 + MG_CHAIN_MAX], &halo[3 + 2 * MG_CHAIN_MAX], halo[1], (uint8_t *)&halo[2][0]);
 	for (int l = T.chain - 1; l >= T.first; --l) {
 		const MgLv<real> &L = T.lv[l];
 		for (int slot = wid; slot < L.n_tiles; slot += MG_TAIL_WAVES) {
