@@ -609,7 +609,7 @@ k_mg_prolong_postsmooth(MgLv<real> L, GridDims gc, const real *e, real inv_scale
 
 /// The small levels in ONE workgroup of 16 waves: down from level `first` to the single-tile level, the coarsest solve,
 /// and up again to `first`, with a workgroup barrier between the phases (their data sits in L2).
-#define MG_TAIL_WAVES 16
+#define MG_TAIL_WAVES 8  // = MG_TAIL_TILES: a level of the tail never has more tiles than that, and barriers get cheaper
 template <typename real> struct MgTail {
 	MgLv<real> lv[MG_MAX_LEVELS];
 	int first, last, nsw, inner;
@@ -637,10 +637,9 @@ template <typename real> __device__ inline void gs_cell(real *H, uint32_t a, rea
 /// (s_memtime stamps). Same operations in the same order as presmooth_tile / residual_restrict_tile / coarsest_tile /
 /// prolong_postsmooth_tile: bit-identical results (tested against LFA_MG_NO_CHAIN=1).
 template <typename real>
-__device__ inline void single_tile_chain(const MgTail<real> &T, real *H, real (*cb)[LFA_HALO_CELLS], real (*cx)[LFA_HALO_CELLS],
-                                         real (*cy)[LFA_HALO_CELLS], real *R, uint8_t *cab_) {
+__device__ inline void single_tile_chain(const MgTail<real> &T, real *H, real (*cb)[512], real (*cx)[512], real (*cy)[512], real *R,
+                                         uint8_t *cab_) {
 	uint8_t (*cab)[512] = (uint8_t (*)[512])cab_;
-	static_assert(3 + 3 * MG_CHAIN_MAX <= MG_TAIL_WAVES && MG_CHAIN_MAX * 512 <= LFA_HALO_CELLS * (int)sizeof(real), "chain arrays must fit the halo blocks");
 	const int t = threadIdx.x, s1 = T.chain, n = T.last - s1 + 1;
 	const bool cellwise = t < 512, colourwise = t < 256;
 	// cell of a thread in the cell-wise phases, and its halo index
@@ -744,6 +743,8 @@ __device__ inline void single_tile_chain(const MgTail<real> &T, real *H, real (*
 template <typename real>
 __global__ void __launch_bounds__(MG_TAIL_WAVES * 64) k_mg_tail(MgTail<real> T, const int *state) {
 	__shared__ real halo[MG_TAIL_WAVES][LFA_HALO_CELLS];
+	__shared__ real cb[MG_CHAIN_MAX][512], cx[MG_CHAIN_MAX][512], cy[MG_CHAIN_MAX][512];  // level arrays of the single-tile chain
+	__shared__ uint8_t cab[MG_CHAIN_MAX][512];
 	if (state[0] >= 0) return;
 	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
 	real *h = halo[wid];
@@ -755,8 +756,7 @@ __global__ void __launch_bounds__(MG_TAIL_WAVES * 64) k_mg_tail(MgTail<real> T, 
 		for (int slot = wid; slot < L.n_tiles; slot += MG_TAIL_WAVES) residual_restrict_tile<real>(L, T.lv[l + 1].g, T.lv[l + 1].b, slot, h, lane);
 		__syncthreads();
 	}
-	// (the chain's level arrays live in the halo blocks of the waves: 512 of their 1000 entries each)
-	single_tile_chain<real>(T, halo[0], &halo[3], &halo[3 + MG_CHAIN_MAX], &halo[3 + 2 * MG_CHAIN_MAX], halo[1], (uint8_t *)&halo[2][0]);
+	single_tile_chain<real>(T, halo[0], cb, cx, cy, halo[1], &cab[0][0]);
 	for (int l = T.chain - 1; l >= T.first; --l) {
 		const MgLv<real> &L = T.lv[l];
 		for (int slot = wid; slot < L.n_tiles; slot += MG_TAIL_WAVES) {
