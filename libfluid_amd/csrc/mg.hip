@@ -607,15 +607,6 @@ k_mg_prolong_postsmooth(MgLv<real> L, GridDims gc, const real *e, real inv_scale
 	}
 }
 
-/// The small levels in ONE workgroup of 16 waves: down from level `first` to the single-tile level, the coarsest solve,
-/// and up again to `first`, with a workgroup barrier between the phases (their data sits in L2).
-#define MG_TAIL_WAVES 8  // = MG_TAIL_TILES: a level of the tail never has more tiles than that, and barriers get cheaper
-template <typename real> struct MgTail {
-	MgLv<real> lv[MG_MAX_LEVELS];
-	int first, last, nsw, inner;
-	int chain;  // first level of the trailing run of single-tile levels handled by single_tile_chain (== last: none but the coarsest)
-};
-#define MG_CHAIN_MAX 4
 /// gs_colour for ONE cell (halo index i): the same expression, term by term.
 template <typename real> __device__ inline void gs_cell(real *H, uint32_t a, real bv, int i) {
 	if (!(a & AB_UNKNOWN) || !(a & 7)) return;
@@ -629,6 +620,168 @@ template <typename real> __device__ inline void gs_cell(real *H, uint32_t a, rea
 	sum += (real)((a >> 5) & 1) * H[i + 100];
 	H[i] = H[i] + (real)MG_OMEGA * (sum * rcp_diag<real>(a & 7) - H[i]);
 }
+// ------------------------------------------------------------------------------------------------ cell-parallel variants
+// The levels below the finest hold 1/8, 1/64, ... of the tiles: with one wave per tile (4 cells per lane and colour) a
+// kernel of theirs is a handful of waves, each alone on its SIMD, waiting out the latency of ~140 dependent instructions per
+// half sweep (s_memtime: 2300 cycles). Here a WORKGROUP takes a tile: a thread per cell of a colour in the half sweeps, two
+// cells per thread elsewhere, a barrier between the steps. Same operations in the same order per cell: bit-identical to
+// k_mg_presmooth / k_mg_residual_restrict / k_mg_prolong_postsmooth (LFA_MG_NO_CP=1 selects those; tested).
+template <typename real> struct CpTile {
+	real H[LFA_HALO_CELLS];
+	real bb[512];
+	uint8_t ab[512];
+};
+template <typename real> __device__ inline void cp_half_sweep(CpTile<real> &S, int colour) {
+	const int t = threadIdx.x, qx = t & 7, qy = (t >> 3) & 7, z = 2 * (t >> 6) + ((qx + qy + colour) & 1), c = qx + 8 * qy + 64 * z;
+	gs_cell<real>(S.H, S.ab[c], S.bb[c], (qx + 1) + 10 * (qy + 1) + 100 * (z + 1));
+	__syncthreads();
+}
+__device__ inline int cp_hi(int cell) { return ((cell & 7) + 1) + 10 * (((cell >> 3) & 7) + 1) + 100 * ((cell >> 6) + 1); }
+
+template <typename real>
+__global__ void __launch_bounds__(256) k_mg_presmooth_cp(MgLv<real> L, int inner, const int *state) {
+	__shared__ CpTile<real> S;
+	if (state[0] >= 0) return;
+	const int t = threadIdx.x;
+	for (int slot = blockIdx.x; slot < L.n_tiles; slot += gridDim.x) {
+		const size_t base = (size_t)L.tiles[slot] * 512;
+		for (int c = t; c < 512; c += 256) {
+			S.ab[c] = L.abits[base + c];
+			S.bb[c] = L.b[base + c];
+		}
+		for (int i = t; i < LFA_HALO_CELLS; i += 256) S.H[i] = (real)0;
+		__syncthreads();
+		for (int it = 0; it < inner; ++it) {
+			cp_half_sweep<real>(S, 0);
+			cp_half_sweep<real>(S, 1);
+		}
+		for (int c = t; c < 512; c += 256) L.x[base + c] = S.H[cp_hi(c)];
+		__syncthreads();
+	}
+}
+
+/// Ring cell r (0..383) of a tile: face f = r >> 6, in-face lane (a, b) = (r & 7, (r >> 3) & 7) as in load_halo.
+__device__ inline void cp_ring(int r, int &f, int &hidx, int &ncell, int &dx, int &dy, int &dz) {
+	f = r >> 6;
+	const int lane = r & 63, a = lane & 7, b = lane >> 3;
+	switch (f) {
+	case 0: hidx = 0 + 10 * (a + 1) + 100 * (b + 1); ncell = b * 64 + a * 8 + 7; dx = -1; dy = a; dz = b; break;
+	case 1: hidx = 9 + 10 * (a + 1) + 100 * (b + 1); ncell = b * 64 + a * 8; dx = 8; dy = a; dz = b; break;
+	case 2: hidx = (a + 1) + 100 * (b + 1); ncell = b * 64 + 56 + a; dx = a; dy = -1; dz = b; break;
+	case 3: hidx = (a + 1) + 90 + 100 * (b + 1); ncell = b * 64 + a; dx = a; dy = 8; dz = b; break;
+	case 4: hidx = (a + 1) + 10 * (b + 1); ncell = 448 + lane; dx = a; dy = b; dz = -1; break;
+	default: hidx = (a + 1) + 10 * (b + 1) + 900; ncell = lane; dx = a; dy = b; dz = 8; break;
+	}
+}
+
+template <typename real>
+__global__ void __launch_bounds__(256) k_mg_residual_restrict_cp(MgLv<real> L, GridDims gc, real *b_coarse, const int *state) {
+	__shared__ CpTile<real> S;
+	__shared__ real R[512];
+	if (state[0] >= 0) return;
+	const int t = threadIdx.x;
+	for (int slot = blockIdx.x; slot < L.n_tiles; slot += gridDim.x) {
+		const int *nt = L.nbr + (size_t)slot * MG_NBR_STRIDE;
+		const int tile = nt[6];
+		const size_t base = (size_t)tile * 512;
+		for (int c = t; c < 512; c += 256) {
+			S.ab[c] = L.abits[base + c];
+			S.bb[c] = L.b[base + c];
+			S.H[cp_hi(c)] = L.x[base + c];
+		}
+		for (int r = t; r < 384; r += 256) {
+			int f, hidx, ncell, dx, dy, dz;
+			cp_ring(r, f, hidx, ncell, dx, dy, dz);
+			const int nb = nt[f];
+			S.H[hidx] = nb >= 0 ? L.x[(size_t)nb * 512 + ncell] : (real)0;
+		}
+		__syncthreads();
+		for (int c = t; c < 512; c += 256) {
+			const int i = cp_hi(c);
+			const uint32_t a = S.ab[c];
+			real r = (real)0;
+			if (a & AB_UNKNOWN) {
+				const real F = (a & AB_FLUID) ? (real)1 : (real)0;
+				real val = (real)(a & 7) * S.H[i];
+				val -= F * S.H[i - 1];
+				val -= F * S.H[i - 10];
+				val -= F * S.H[i - 100];
+				val -= (real)((a >> 3) & 1) * S.H[i + 1];
+				val -= (real)((a >> 4) & 1) * S.H[i + 10];
+				val -= (real)((a >> 5) & 1) * S.H[i + 100];
+				r = S.bb[c] - val;
+			}
+			R[c] = r;
+		}
+		__syncthreads();
+		if (t < 64) {  // one coarse cell each: its 8 children in the order of the pair sums and the two shuffle steps
+			const int X = t & 3, Y = (t >> 2) & 3, Z = t >> 4;
+			auto pair = [&](int x, int y) { real p = R[x + 8 * y + 64 * (2 * Z)]; p += R[x + 8 * y + 64 * (2 * Z + 1)]; return p; };
+			real v = pair(2 * X, 2 * Y);
+			v += pair(2 * X + 1, 2 * Y);
+			real w = pair(2 * X, 2 * Y + 1);
+			w += pair(2 * X + 1, 2 * Y + 1);
+			v += w;
+			int tx, ty, tz;
+			tile_coords(L.g, tile, tx, ty, tz);
+			const int ptile = (tx >> 1) + gc.ntx * ((ty >> 1) + gc.nty * (tz >> 1));
+			b_coarse[(size_t)ptile * 512 + ((tz & 1) * 4 + Z) * 64 + ((ty & 1) * 4 + Y) * 8 + (tx & 1) * 4 + X] = (real)0.5 * v;
+		}
+		__syncthreads();
+	}
+}
+
+template <typename real>
+__global__ void __launch_bounds__(256) k_mg_prolong_postsmooth_cp(MgLv<real> L, GridDims gc, const real *e, int inner, const int *state) {
+	__shared__ CpTile<real> S;
+	if (state[0] >= 0) return;
+	const int t = threadIdx.x;
+	for (int slot = blockIdx.x; slot < L.n_tiles; slot += gridDim.x) {
+		const int *nt = L.nbr + (size_t)slot * MG_NBR_STRIDE;
+		const int tile = nt[6];
+		const size_t base = (size_t)tile * 512;
+		int tx, ty, tz;
+		tile_coords(L.g, tile, tx, ty, tz);
+		auto corr = [&](int X, int Y, int Z) -> real { return e[blocked_index(gc, X >> 1, Y >> 1, Z >> 1)]; };
+		for (int c = t; c < 512; c += 256) {
+			const uint8_t a = L.abits[base + c];
+			S.ab[c] = a;
+			S.bb[c] = L.b[base + c];
+			real v = L.x[base + c];
+			if (a & AB_UNKNOWN) v += corr(tx * 8 + (c & 7), ty * 8 + ((c >> 3) & 7), tz * 8 + (c >> 6));
+			S.H[cp_hi(c)] = v;
+		}
+		for (int r = t; r < 384; r += 256) {
+			int f, hidx, ncell, dx, dy, dz;
+			cp_ring(r, f, hidx, ncell, dx, dy, dz);
+			const int nb = nt[f];
+			real v = (real)0;
+			if (nb >= 0) {
+				const size_t j = (size_t)nb * 512 + ncell;
+				v = L.x[j];
+				if (L.abits[j] & AB_UNKNOWN) v += corr(tx * 8 + dx, ty * 8 + dy, tz * 8 + dz);
+			}
+			S.H[hidx] = v;
+		}
+		__syncthreads();
+		for (int it = 0; it < inner; ++it) {
+			cp_half_sweep<real>(S, 1);
+			cp_half_sweep<real>(S, 0);
+		}
+		for (int c = t; c < 512; c += 256) L.y[base + c] = S.H[cp_hi(c)];
+		__syncthreads();
+	}
+}
+
+/// The small levels in ONE workgroup of 16 waves: down from level `first` to the single-tile level, the coarsest solve,
+/// and up again to `first`, with a workgroup barrier between the phases (their data sits in L2).
+#define MG_TAIL_WAVES 8  // = MG_TAIL_TILES: a level of the tail never has more tiles than that, and barriers get cheaper
+template <typename real> struct MgTail {
+	MgLv<real> lv[MG_MAX_LEVELS];
+	int first, last, nsw, inner;
+	int chain;  // first level of the trailing run of single-tile levels handled by single_tile_chain (== last: none but the coarsest)
+};
+#define MG_CHAIN_MAX 4
 /// The trailing levels that consist of ONE active tile each (the last two at every BASELINE size), down and up with the
 /// whole workgroup on one tile: a thread per cell (512) for the cell-wise phases, a thread per cell of one colour (256)
 /// for the Gauss-Seidel half sweeps, a workgroup barrier between them; right-hand sides, iterates and results stay in LDS.
@@ -1031,6 +1184,10 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 	// levels >= D are replicated (identical work on every rank), so the tail workgroup may only hold replicated levels
 	const int D = mg_dist(s) ? M.n_dist : 0;
 	tail = std::max(tail, D);
+	// cell-parallel kernels for levels of up to 1024 tiles (C4: levels 2 and 3; level 1 with 2048 tiles fills the chip with a
+	// wave per tile: 8.58 ms per step against 8.75 with cell-parallel kernels on every coarse level, 8.79 with none)
+	int cp_max = 1024;
+	if (const char *e = getenv("LFA_MG_CP_MAX_TILES")) cp_max = atoi(e);
 	auto exchange_level = [&](int l, void *vec) -> int {
 		if (l == 0) return lfa_dist_exchange_slices(s, vec, (int)sizeof(real));
 		return lfa_dist_exchange_layer_slices(s, vec, (int)sizeof(real), M.lv[l].g.ntx * M.lv[l].g.nty, M.lv[l].lo_layer, M.lv[l].hi_layer);
@@ -1038,15 +1195,21 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 	for (int l = 0; l < tail; ++l) {
 		const MgLv<real> L = lvl(l);
 		const int G = mg_grid(L.n_tiles);
-		if (!(l == 0 && level0_presmoothed) && (parts & (l == 0 ? MG_PART_PRE0 : MG_PART_COARSE)))
-			hipLaunchKernelGGL(k_mg_presmooth<real>, dim3(G), dim3(256), 0, s->stream, L, st);
+		const bool cp = l >= 1 && !getenv("LFA_MG_NO_CP") && L.n_tiles <= cp_max;  // a workgroup per tile on the coarser levels (see k_mg_*_cp)
+		const int Gcp = std::max(1, std::min(L.n_tiles, 8192));  // (a slab rank may hold no tile of a level)
+		if (!(l == 0 && level0_presmoothed) && (parts & (l == 0 ? MG_PART_PRE0 : MG_PART_COARSE))) {
+			if (cp) hipLaunchKernelGGL(k_mg_presmooth_cp<real>, dim3(Gcp), dim3(256), 0, s->stream, L, MG_INNER_SWEEPS, st);
+			else hipLaunchKernelGGL(k_mg_presmooth<real>, dim3(G), dim3(256), 0, s->stream, L, st);
+		}
 		if (l < D) {
 			LFA_TRY(exchange_level(l, L.x));  // the residual needs the pre-smoothed iterate across the slab faces
 			// the first replicated level collects the restricted residual of every rank: zero where this rank has no children
 			if (l + 1 == D) LFA_HIP(s, hipMemsetAsync(M.lv[D].b, 0, M.lv[D].ncp * sizeof(real), s->stream));
 		}
-		if (parts & (l == 0 ? MG_PART_DOWN0 : MG_PART_COARSE))
-			hipLaunchKernelGGL(k_mg_residual_restrict<real>, dim3(G), dim3(256), 0, s->stream, L, M.lv[l + 1].g, (real *)M.lv[l + 1].b, st);
+		if (parts & (l == 0 ? MG_PART_DOWN0 : MG_PART_COARSE)) {
+			if (cp) hipLaunchKernelGGL(k_mg_residual_restrict_cp<real>, dim3(Gcp), dim3(256), 0, s->stream, L, M.lv[l + 1].g, (real *)M.lv[l + 1].b, st);
+			else hipLaunchKernelGGL(k_mg_residual_restrict<real>, dim3(G), dim3(256), 0, s->stream, L, M.lv[l + 1].g, (real *)M.lv[l + 1].b, st);
+		}
 		LFA_LAUNCH_CHECK(s);
 		if (l < D && l + 1 == D)
 			LFA_TRY(s->dist->allreduce_buf(s, M.lv[D].b, M.lv[D].ncp, sizeof(real) == 4 ? LFA_RED_F32 : LFA_RED_F64, false));
@@ -1074,6 +1237,9 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		if (l == 0)
 			hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true>), dim3(G), dim3(256), 0, s->stream, L, M.lv[1].g,
 			                   (const real *)M.lv[1].y, inv_scale, part_sigma, st);
+		else if (!getenv("LFA_MG_NO_CP") && L.n_tiles <= cp_max)
+			hipLaunchKernelGGL(k_mg_prolong_postsmooth_cp<real>, dim3(std::max(1, std::min(L.n_tiles, 8192))), dim3(256), 0, s->stream, L, M.lv[l + 1].g,
+			                   (const real *)M.lv[l + 1].y, MG_INNER_SWEEPS, st);
 		else
 			hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, false>), dim3(G), dim3(256), 0, s->stream, L, M.lv[l + 1].g,
 			                   (const real *)M.lv[l + 1].y, (real)1, (double *)nullptr, st);

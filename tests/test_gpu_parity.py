@@ -449,17 +449,20 @@ def test_properties_at_full_size():
 
 
 @pytest.mark.parametrize("dtype", [lfa.PCG_F32, lfa.PCG_F64])
-def test_multigrid_single_tile_chain_is_bitwise_the_level_by_level_tail(dtype, monkeypatch):
-    """The last levels of the hierarchy hold one active tile each; the tail workgroup runs them down and up inside one wave
-    out of LDS (single_tile_chain). Same operations in the same order as the level-by-level code (LFA_MG_NO_CHAIN=1):
-    identical iteration counts and bit-identical pressures."""
-    size, block = (64, 48, 72), ((0, 0, 0), (30, 26, 40))
+@pytest.mark.parametrize("switch", ["LFA_MG_NO_CHAIN", "LFA_MG_NO_CP"])
+def test_multigrid_cell_parallel_variants_are_bitwise_the_wave_per_tile_code(dtype, switch, monkeypatch):
+    """The coarse levels of the V-cycle are run by cell-parallel code (a workgroup per tile: k_mg_*_cp; the trailing
+    single-tile levels inside the tail workgroup: single_tile_chain). Same operations in the same order per cell as the
+    wave-per-tile kernels (selected by LFA_MG_NO_CP=1 / LFA_MG_NO_CHAIN=1): identical iteration counts, bit-identical
+    pressures. The grid is ragged and large enough for three levels of several tiles with neighbours on every side."""
+    size, block = (136, 72, 104), ((0, 0, 0), (90, 50, 70))
     res = []
     for no_chain in (False, True):
+        monkeypatch.setenv("LFA_MG_CP_MAX_TILES", "1000000")  # cell-parallel kernels on every coarse level
         if no_chain:
-            monkeypatch.setenv("LFA_MG_NO_CHAIN", "1")
+            monkeypatch.setenv(switch, "1")
         else:
-            monkeypatch.delenv("LFA_MG_NO_CHAIN", raising=False)
+            monkeypatch.delenv(switch, raising=False)
         s = lfa.Sim(size, precond=lfa.PRECOND_MULTIGRID, pcg_dtype=dtype)
         s.seed_block(*block)
         its = []
