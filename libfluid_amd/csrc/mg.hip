@@ -775,7 +775,7 @@ __global__ void __launch_bounds__(256) k_mg_prolong_postsmooth_cp(MgLv<real> L, 
 
 /// The small levels in ONE workgroup of 16 waves: down from level `first` to the single-tile level, the coarsest solve,
 /// and up again to `first`, with a workgroup barrier between the phases (their data sits in L2).
-#define MG_TAIL_WAVES 8  // = MG_TAIL_TILES: a level of the tail never has more tiles than that, and barriers get cheaper
+#define MG_TAIL_WAVES 8  // 512 threads: a thread per cell in the single-tile chain; tail levels of several tiles take a wave per tile
 template <typename real> struct MgTail {
 	MgLv<real> lv[MG_MAX_LEVELS];
 	int first, last, nsw, inner;
@@ -1156,7 +1156,8 @@ int lfa_mg_setup(lfa_sim *s) {
 /// z = V(r) / scale and the partial sums of dot(z, r) (pcg_grid(n_ptiles) of them) into part_sigma.
 /// Level 0 uses the solver's own vectors: b = r (vr), pre-smoothed iterate in vq (free between the AXPYs and the next
 /// A s), result in vz. `level0_presmoothed`: vq already holds the pre-smoothed iterate (k_mg_axpy_presmooth).
-#define MG_TAIL_TILES 8  // levels with at most this many tiles run inside k_mg_tail (measured at C4: 8 -> 128 us, 64 -> 150 us)
+#define MG_TAIL_TILES 1  // levels with at most this many tiles run inside k_mg_tail: with the cell-parallel kernels for the small
+                         // levels only the single-tile ones are worth keeping there (C2 / C4: 1.52 / 8.63 ms per step, 8: 1.55 / 8.69)
 #define MG_COARSEST_SWEEPS 4
 enum { MG_PART_PRE0 = 1, MG_PART_DOWN0 = 2, MG_PART_COARSE = 4, MG_PART_UP0 = 8, MG_PART_ALL = 15 };
 template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, bool level0_presmoothed, int parts = MG_PART_ALL) {
