@@ -293,7 +293,7 @@ extern "C" int lfa_set_params(lfa_sim *s, const lfa_params *p) {
 		                "APIC with the reference's unscaled kernel (simulation.cpp:367-369) is only implemented for "
 		                "cell_size == 1; set apic_unscaled_kernel = 0");
 	if (p->pcg_dtype != s->prm.pcg_dtype || p->precond != s->prm.precond) s->system_valid = false;
-	if (p->simulation_method != s->prm.simulation_method) LFA_TRY(lfa_particles_materialize(s));  // only APIC defers v, C
+	if (p->simulation_method != s->prm.simulation_method) LFA_TRY(lfa_particles_materialize(s));  // what is deferred depends on it
 	if (p->precond < 0 || p->precond > LFA_PRECOND_MULTIGRID) return lfa_fail(s, LFA_E_INVALID, "bad precond");
 	s->prm = *p;
 	return LFA_OK;
@@ -793,9 +793,10 @@ __global__ void k_dilate(const int *ptiles, int n_ptiles, uint32_t *flag, GridDi
 /// Pass 2: move every particle to its tile's segment. With `shuffle` the slot inside the segment is a multiplicative
 /// permutation of the rank, which separates particles of one cell (uploads arrive cell-sorted; neighbouring lanes
 /// hitting one cell would serialise the LDS atomics of the P2G scatter).
-/// LIGHT: only key, t, id move (20 of the 68 bytes); from[d] records the source index, v and C follow through it
-/// (k_p2g_*, k_g2p FLIP, k_gather_vc) - see lfa_sim::vc_pending.
-template <bool LIGHT>
+/// DEFER 1 (APIC): only key, t, id move (20 of the 68 bytes); from[d] records the source index, v and C follow through it
+/// (k_p2g_*, k_g2p FLIP, k_gather_vc) - see lfa_sim::vc_pending. DEFER 2 (PIC, FLIP): v alone stays behind - their G2P
+/// never writes C, so C has to travel with the particle. DEFER 0: the whole record moves.
+template <int DEFER>
 __global__ void k_tile_scatter(size_t n, ParticleSoA src, ParticleSoA dst, const uint32_t *rank,
                                const uint32_t *tile_start, const uint32_t *tile_count, int shuffle, uint32_t *from) {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -811,24 +812,27 @@ __global__ void k_tile_scatter(size_t n, ParticleSoA src, ParticleSoA dst, const
 #pragma unroll
 	for (int k = 0; k < 3; ++k) dst.t[k][d] = src.t[k][i];
 	dst.id[d] = src.id[i];
-	if (LIGHT) {
-		from[d] = (uint32_t)i;
-	} else {
+	if (DEFER) from[d] = (uint32_t)i;
+	if (DEFER == 0) {
 #pragma unroll
 		for (int k = 0; k < 3; ++k) dst.v[k][d] = src.v[k][i];
+	}
+	if (DEFER != 1) {
 #pragma unroll
 		for (int k = 0; k < 9; ++k) dst.c[k][d] = src.c[k][i];
 	}
 }
 /// The deferred half: v, C of the particle now at d from where it was before the binning.
-__global__ void k_gather_vc(size_t n, ParticleSoA old, ParticleSoA cur, const uint32_t *from) {
+__global__ void k_gather_vc(size_t n, ParticleSoA old, ParticleSoA cur, const uint32_t *from, int with_c) {
 	size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (d >= n) return;
 	const uint32_t i = from[d];
 #pragma unroll
 	for (int k = 0; k < 3; ++k) cur.v[k][d] = old.v[k][i];
+	if (with_c) {
 #pragma unroll
-	for (int k = 0; k < 9; ++k) cur.c[k][d] = old.c[k][i];
+		for (int k = 0; k < 9; ++k) cur.c[k][d] = old.c[k][i];
+	}
 }
 
 /// Particles per cell for every processed tile (the `count` half of _space_hash, src/simulation.cpp:266-291);
@@ -892,7 +896,7 @@ int lfa_particles_materialize(lfa_sim *s) {
 	const size_t n = s->np_live;
 	if (!n) return LFA_OK;
 	hipLaunchKernelGGL(k_gather_vc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, s->pb[s->cur ^ 1], s->pb[s->cur],
-	                   (const uint32_t *)s->vc_src);
+	                   (const uint32_t *)s->vc_src, s->vc_with_c ? 1 : 0);
 	LFA_LAUNCH_CHECK(s);
 	return LFA_OK;
 }
@@ -972,18 +976,23 @@ extern "C" int lfa_hash_particles(lfa_sim *s) {
 	if (n) {
 		// v and C (48 of the 68 bytes) stay behind and are read through vc_src by the P2G; the G2P writes the new ones in the
 		// new order (the slab migration, which packs whole records, completes the move first)
-		// APIC only: PIC and FLIP carry C through the step unchanged (the reference's G2P does not touch it), so there it has
-		// to travel with the particle
-		const bool light = s->prm.simulation_method == LFA_APIC && !getenv("LFA_FULL_SCATTER");
-		if (light)
-			hipLaunchKernelGGL(k_tile_scatter<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, src, dst,
-			                   s->rank, s->tile_start, s->tile_count, s->binned ? 0 : 1, s->vc_src);
+		// PIC and FLIP carry C through the step unchanged (the reference's G2P does not touch it), so there C travels with the
+		// particle and only v stays behind
+		const int defer = getenv("LFA_FULL_SCATTER") ? 0 : (s->prm.simulation_method == LFA_APIC ? 1 : 2);
+		const dim3 sgrid((unsigned)((n + 255) / 256));
+		if (defer == 1)
+			hipLaunchKernelGGL(k_tile_scatter<1>, sgrid, dim3(256), 0, s->stream, n, src, dst, s->rank, s->tile_start, s->tile_count,
+			                   s->binned ? 0 : 1, s->vc_src);
+		else if (defer == 2)
+			hipLaunchKernelGGL(k_tile_scatter<2>, sgrid, dim3(256), 0, s->stream, n, src, dst, s->rank, s->tile_start, s->tile_count,
+			                   s->binned ? 0 : 1, s->vc_src);
 		else
-			hipLaunchKernelGGL(k_tile_scatter<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, src, dst,
-			                   s->rank, s->tile_start, s->tile_count, s->binned ? 0 : 1, (uint32_t *)nullptr);
+			hipLaunchKernelGGL(k_tile_scatter<0>, sgrid, dim3(256), 0, s->stream, n, src, dst, s->rank, s->tile_start, s->tile_count,
+			                   s->binned ? 0 : 1, (uint32_t *)nullptr);
 		LFA_LAUNCH_CHECK(s);
 		s->cur ^= 1;
-		s->vc_pending = light;
+		s->vc_pending = defer != 0;
+		s->vc_with_c = defer == 1;
 	}
 	if (s->n_dtiles) {
 		int grid = s->n_dtiles < 8192 ? s->n_dtiles : 8192;

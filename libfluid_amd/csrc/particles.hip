@@ -541,9 +541,10 @@ extern "C" int lfa_correct_collide(lfa_sim *s, double dt) {
 	const int n_index = s->dist ? s->n_ptiles_all : s->n_ptiles;
 	const int grid = n_index < 16384 ? (n_index > 0 ? n_index : 1) : 16384;
 	ParticleSoA &cur = s->pb[s->cur], &oth = s->pb[s->cur ^ 1];
-	// cell-ordered positions: scratch in the v / c arrays that are free right now - the other buffer's, or with a deferred
-	// binning (the other buffer still holds the v, C the G2P may want) this buffer's own, which the G2P is yet to fill
-	float4 *spos = (float4 *)(s->vc_pending ? cur.v[0] : oth.v[0]);
+	// cell-ordered positions: scratch in four consecutive v / c arrays that are free right now - the other buffer's v.. ; with a
+	// deferred binning, where the other buffer still holds the v (and for APIC the C) that the P2G / G2P read: this buffer's
+	// own v.. (APIC: the G2P is yet to fill them) or the other buffer's c[0..3] (PIC / FLIP: its C has moved here already)
+	float4 *spos = (float4 *)(!s->vc_pending ? oth.v[0] : (s->vc_with_c ? cur.v[0] : oth.c[0]));
 	hipLaunchKernelGGL(k_build_cell_index, dim3(grid), dim3(256), 0, s->stream, s->dist ? s->ptiles_all : s->ptiles, n_index, cur.key,
 	                   cur.t[0], cur.t[1], cur.t[2], s->tile_start, s->tile_count, s->cell_start, spos, s->cell_count,
 	                   s->slab_lo * L, s->slab_hi * L);

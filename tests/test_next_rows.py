@@ -185,17 +185,18 @@ def test_g2p_on_the_order_of_the_last_binning_equals_g2p_after_rebinning(method)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("method", [lfa.APIC, lfa.FLIP_BLEND, lfa.PIC])
 @pytest.mark.parametrize("seq", ["hash", "hash,hash", "hash,p2g", "hash,p2g,hash", "hash,correct", "hash,advect,hash",
                                  "hash,p2g,correct,hash,p2g", "hash,cfl"])
-def test_deferred_binning_never_loses_velocities(seq):
-    """With APIC the binning moves key, t and id only; v and C follow lazily (the P2G reads them through the source index,
-    the G2P rewrites them). Whatever is called in between, a download returns every particle's own v and C."""
+def test_deferred_binning_never_loses_velocities(seq, method):
+    """The binning moves key, t and id (PIC / FLIP: and C); v (APIC: and C) follow lazily - the P2G reads them through the
+    source index, the G2P rewrites them. Whatever is called in between, a download returns every particle's own v and C."""
     c, parts, solid = fullstep_inputs()
     parts = parts.copy()
     rng = np.random.default_rng(11)
     for f in ("cx", "cy", "cz"):
         parts[f] = rng.normal(size=(len(parts), 3))
-    s = lfa.Sim(c["size"], method=lfa.APIC)
+    s = lfa.Sim(c["size"], method=method, blending=0.9)
     s.set_solid_cells(solid)
     s.upload_particles(parts)
     for op in seq.split(","):
@@ -216,7 +217,8 @@ def test_deferred_binning_never_loses_velocities(seq):
 
 
 @pytest.mark.gpu
-def test_deferred_binning_is_bitwise_the_full_scatter(monkeypatch):
+@pytest.mark.parametrize("method", [lfa.APIC, lfa.FLIP_BLEND, lfa.PIC])
+def test_deferred_binning_is_bitwise_the_full_scatter(method, monkeypatch):
     """Five hot steps with the deferred binning (key, t, id move; v, C through the source index) and
     with LFA_FULL_SCATTER=1 (whole records move): the P2G sums are order-independent fixed point and everything else is
     per particle, so velocities, C and pressures agree bit for bit."""
@@ -227,7 +229,7 @@ def test_deferred_binning_is_bitwise_the_full_scatter(monkeypatch):
             monkeypatch.setenv("LFA_FULL_SCATTER", "1")
         else:
             monkeypatch.delenv("LFA_FULL_SCATTER", raising=False)
-        s = lfa.Sim(c["size"], method=lfa.APIC, precond=lfa.PRECOND_MIC0_TILED, pcg_dtype=lfa.PCG_F64)
+        s = lfa.Sim(c["size"], method=method, blending=0.9, precond=lfa.PRECOND_MIC0_TILED, pcg_dtype=lfa.PCG_F64)
         s.set_solid_cells(solid)
         s.upload_particles(parts)
         its = []
