@@ -55,8 +55,8 @@ enum { LFA_PRECOND_MIC0_TILED = 0, LFA_PRECOND_MIC0_EXACT = 1,
        /* MULTIGRID = geometric multigrid V-cycle (levels of 2x coarser cells down to one tile, rediscretised operators,
         * red-black Gauss-Seidel inside tiles / Jacobi across tile faces, piecewise-constant transfers): the work per
         * iteration stays O(unknowns) and the iteration count barely grows with the grid (about 20 at 512^3 where MIC(0)
-        * needs 180). Single domain only: a handle with a slab decomposition uses MULTILEVEL instead. Same converged
-        * pressure, same stopping rule. The default. */
+        * needs 180). Runs on a slab decomposition too (finest levels distributed, coarser ones replicated, see the slab
+        * section below). Same converged pressure, same stopping rule. The default. */
        LFA_PRECOND_MULTIGRID = 3 };
 /* arithmetic type of the PCG vectors */
 enum { LFA_PCG_F32 = 0, LFA_PCG_F64 = 1 };
@@ -77,10 +77,12 @@ typedef struct lfa_params {
 	double tau, sigma, tolerance; /* 0.97, 0.25, 1e-6 */
 	uint64_t max_iterations;      /* 200 */
 	int32_t p2g_variant;          /* LFA_P2G_LDS_BINNED */
-	int32_t precond;              /* LFA_PRECOND_MULTIGRID (LFA_PRECOND_MULTILEVEL with slabs) */
+	int32_t precond;              /* LFA_PRECOND_MULTIGRID (single domain and slabs) */
 	int32_t pcg_dtype;            /* LFA_PCG_F32 */
-	int32_t apic_unscaled_kernel; /* 1 = keep the reference quirk simulation.cpp:367-369 (only differs when cell_size != 1;
-	                                 the device path then returns LFA_E_UNSUPPORTED), 0 = divide by cell_size */
+	int32_t apic_unscaled_kernel; /* 1 (default) = keep the reference quirk simulation.cpp:367-369: the APIC P2G hat is
+	                                 evaluated on world-space distances (only differs when cell_size != 1: narrower hat for
+	                                 cell_size > 1, wider - truncated by the 27-cell gather - for cell_size < 1);
+	                                 0 = divide by cell_size like the PIC transfer does */
 	int32_t pcg_fused;            /* 1 = two launches per PCG iteration (k_pcg_a: search direction + A s, k_pcg_b: AXPYs +
 	                                 MIC(0) sweeps) where the schedule allows it (single domain, tile-local MIC(0));
 	                                 0 = one launch per vector operation. Same arithmetic either way. */

@@ -7,7 +7,6 @@
 
 #include "common.h"
 #include "pcg.h"
-#include "pcg.h"
 
 static thread_local std::string g_create_error;
 
@@ -288,13 +287,14 @@ extern "C" int lfa_set_params(lfa_sim *s, const lfa_params *p) {
 	if (p->velocity_extrapolation_iterations > 8)
 		return lfa_fail(s, LFA_E_UNSUPPORTED, "velocity_extrapolation_iterations > 8 exceeds the 1-tile dilation");
 	if (p->max_iterations > 4000) return lfa_fail(s, LFA_E_INVALID, "max_iterations > 4000");
-	if (p->simulation_method == LFA_APIC && p->apic_unscaled_kernel && p->cell_size != 1.0)
-		return lfa_fail(s, LFA_E_UNSUPPORTED,
-		                "APIC with the reference's unscaled kernel (simulation.cpp:367-369) is only implemented for "
-		                "cell_size == 1; set apic_unscaled_kernel = 0");
-	if (p->pcg_dtype != s->prm.pcg_dtype || p->precond != s->prm.precond) s->system_valid = false;
+	// every selector is validated before anything is invalidated
+	if (p->precond < 0 || p->precond > LFA_PRECOND_MULTIGRID) return lfa_fail(s, LFA_E_INVALID, "bad precond %d", p->precond);
+	if (p->pcg_dtype != LFA_PCG_F32 && p->pcg_dtype != LFA_PCG_F64) return lfa_fail(s, LFA_E_INVALID, "bad pcg_dtype %d", p->pcg_dtype);
+	if (p->p2g_variant != LFA_P2G_LDS_BINNED && p->p2g_variant != LFA_P2G_GLOBAL_ATOMIC)
+		return lfa_fail(s, LFA_E_INVALID, "bad p2g_variant %d", p->p2g_variant);
+	if (!(p->density > 0.0)) return lfa_fail(s, LFA_E_INVALID, "density must be > 0 (got %g)", p->density);
 	if (p->simulation_method != s->prm.simulation_method) LFA_TRY(lfa_particles_materialize(s));  // what is deferred depends on it
-	if (p->precond < 0 || p->precond > LFA_PRECOND_MULTIGRID) return lfa_fail(s, LFA_E_INVALID, "bad precond");
+	if (p->pcg_dtype != s->prm.pcg_dtype || p->precond != s->prm.precond) s->system_valid = false;
 	s->prm = *p;
 	return LFA_OK;
 }

@@ -10,9 +10,9 @@
 //
 // Two variants (BASELINE config 2):
 //   LDS-binned   one workgroup per particle tile accumulates (sum w v, sum w) for its 10x10x10 halo block in LDS
-//                (ds_add_f32), streams the tile's particles once, coalesced, and stores the block to a per-tile
-//                staging slab; the finalize kernel adds the up to 8 overlapping slabs per cell in a fixed order.
-//                No global atomics.
+//                (64-bit fixed point, ds_add_u64: order independent), streams the tile's particles once, coalesced, and
+//                stores the block to a per-tile staging slab; the finalize kernel adds the up to 8 overlapping slabs per
+//                cell in a fixed order. No global atomics.
 //   global-atomic one thread per particle, 48 global_atomic_add_f32 into dense accumulators.
 // Finalize = normalise (weight > 1e-6 else 0, :324/:383), cell typing (:329-334), APIC boundary-face zeroing
 // (_remove_boundary_velocities :428-445), FLIP's old-grid copy (:340-344) and, inside lfa_step_hot, gravity (:72-78).
@@ -35,9 +35,40 @@ __device__ inline void axis_bf(float t, bool own, int &b, float &f) {
 
 /// Accumulates one particle into a 10x10x10 block of (sum_wv, sum_w) pairs per component.
 /// acc layout: [comp][2][1000], halo cell index = hx + 10 hy + 100 hz.
-template <bool APIC, typename AddFn>
+/// QUIRK (APIC only): the reference evaluates the APIC hat on world-space distances, _kernel(p - face) WITHOUT the division
+/// by cell_size that PIC has (src/simulation.cpp:367-369 vs :313-315). For cell_size == 1 both are the same 2x2x2 stencil;
+/// otherwise the 1-D weight towards the face of cell (particle cell + o) is max(0, 1 - h |d|) with d the distance in cells,
+/// o = -1, 0, +1 being exactly the cells whose 27-neighbourhood gather (simulation.h:212-223) visits the particle:
+/// h > 1 narrows the hat inside the 2x2x2 set, h < 1 widens it to (up to) all 3x3x3 cells, truncated there by the gather.
+template <bool APIC, bool QUIRK, typename AddFn>
 __device__ inline void scatter_particle(int lx, int ly, int lz, const float t[3], const float v[3], const float c[9],
                                         float hworld, AddFn add) {
+	if (QUIRK) {
+#pragma unroll
+		for (int comp = 0; comp < 3; ++comp) {
+			float w1[3][3], a1[3][3];  // [axis][o + 1]
+			const float *cc = c + 3 * comp;
+#pragma unroll
+			for (int a = 0; a < 3; ++a)
+#pragma unroll
+				for (int o = -1; o <= 1; ++o) {
+					const float d = t[a] - (float)o - (a == comp ? 1.0f : 0.5f);  // (p - face)_a in cells
+					w1[a][o + 1] = fmaxf(0.0f, 1.0f - hworld * fabsf(d));
+					a1[a][o + 1] = -hworld * cc[a] * d;  // c_comp[a] * (face - p)_a, :371-375
+				}
+			for (int k = 0; k < 3; ++k)
+				for (int j = 0; j < 3; ++j)
+#pragma unroll
+					for (int i = 0; i < 3; ++i) {
+						const float wgt = (w1[0][i] * w1[1][j]) * w1[2][k];
+						if (wgt > 0.0f) {
+							const float val = v[comp] + ((a1[0][i] + a1[1][j]) + a1[2][k]);
+							add(comp, lx + i, ly + j, lz + k, wgt * val, wgt);
+						}
+					}
+		}
+		return;
+	}
 #pragma unroll
 	for (int comp = 0; comp < 3; ++comp) {
 		int b[3];
@@ -74,14 +105,19 @@ __device__ inline void scatter_particle(int lx, int ly, int lz, const float t[3]
 // Accumulation primitive. Measured on MI355X (tools/lds_atomic_bench.hip, lane-ops/clk/CU, random addresses):
 //   ds_add_f32 0.33 | ds_add_f64 2.3 | ds_add_u64 4.3 | ds_add_u32 6.7 | ds_write_b32 7.2
 // i.e. the fp32 LDS atomic is ~20x slower than the 64-bit integer one on gfx950. The tile therefore accumulates in
-// 64-bit FIXED POINT (2^-30 units): integer adds are associative, so the per-tile sums are also bit-reproducible
-// whatever order the lanes arrive in. |sum| < 2^21 (velocity * weight in cells/s), resolution 9.3e-10.
-#define P2G_FIX_SCALE 1073741824.0      /* 2^30 */
-#define P2G_FIX_INV (1.0 / 1073741824.0)
+// 64-bit FIXED POINT: integer adds are associative, so the per-tile sums are also bit-reproducible whatever order the
+// lanes arrive in. Units: sum w in 2^-40 (a contribution is <= 1, a sum < 2^10), sum w v in 2^-36 (|w v| < 2^15 per
+// contribution - the range of the magic-constant conversion below -, |sum| < 2^27). The velocity of a face is
+// sum wv / sum w down to sum w = 1e-6 (src/simulation.cpp:324,383), so its error is |v| * err(sum w) / sum w: with the
+// 2^-30 units of round 1 a face that only sees the far corner of one hat (sum w ~ 1e-5: routine with the narrow
+// un-scaled APIC hat at cell_size > 1) was off by 1e-4 of |v|; now 2^-41 n / 1e-6 < 4e-6 even at the threshold.
+#define P2G_FIX_SCALE_W 1099511627776.0   /* 2^40 */
+#define P2G_FIX_SCALE_V 68719476736.0     /* 2^36 */
 /// float -> fixed via the 1.5*2^52 magic constant: two f64 ops and one 64-bit subtract (no f32->i64 convert on CDNA).
-__device__ inline unsigned long long to_fixed(float x) {
+/// Valid for |x * scale| < 2^51.
+__device__ inline unsigned long long to_fixed(float x, double scale) {
 	const double magic = 6755399441055744.0;  // 1.5 * 2^52
-	double d = fma((double)x, P2G_FIX_SCALE, magic);
+	double d = fma((double)x, scale, magic);
 	return (unsigned long long)(__double_as_longlong(d) - __double_as_longlong(magic));
 }
 
@@ -105,7 +141,7 @@ __device__ inline void load_particle(const ParticleSoA &p, const ParticleSoA &pv
 	}
 }
 
-template <bool APIC>
+template <bool APIC, bool QUIRK>
 __global__ void __launch_bounds__(256)
 k_p2g_binned(const int *ptiles, int n_ptiles, ParticleSoA p, ParticleSoA pvc, const uint32_t *from, const uint32_t *tile_start,
              float *stage, float hworld) {
@@ -127,18 +163,18 @@ k_p2g_binned(const int *ptiles, int n_ptiles, ParticleSoA p, ParticleSoA pvc, co
 			if (in < end) load_particle<APIC>(p, pvc, in, jn, nxt);
 			jn = jnn;
 			const int l = (int)(cur.key & 511);
-			scatter_particle<APIC>(l & 7, (l >> 3) & 7, l >> 6, cur.t, cur.v, cur.c, hworld,
+			scatter_particle<APIC, QUIRK>(l & 7, (l >> 3) & 7, l >> 6, cur.t, cur.v, cur.c, hworld,
 			                       [&](int comp, int hx, int hy, int hz, float wv, float wgt) {
 				                       unsigned long long *a = acc + comp * 2 * LFA_HALO_CELLS + hx + 10 * hy + 100 * hz;
-				                       atomicAdd(a, to_fixed(wv));
-				                       atomicAdd(a + LFA_HALO_CELLS, to_fixed(wgt));
+				                       atomicAdd(a, to_fixed(wv, P2G_FIX_SCALE_V));
+				                       atomicAdd(a + LFA_HALO_CELLS, to_fixed(wgt, P2G_FIX_SCALE_W));
 			                       });
 			cur = nxt;
 		}
 		__syncthreads();
 		float *out = stage + (size_t)slot * 6 * LFA_HALO_CELLS;
 		for (int k = threadIdx.x; k < 6 * LFA_HALO_CELLS; k += 256)
-			out[k] = (float)((double)(long long)acc[k] * P2G_FIX_INV);
+			out[k] = (float)((double)(long long)acc[k] * (((k / LFA_HALO_CELLS) & 1) ? 1.0 / P2G_FIX_SCALE_W : 1.0 / P2G_FIX_SCALE_V));
 		__syncthreads();
 	}
 }
@@ -154,7 +190,7 @@ __global__ void k_zero_acc(const int *dtiles, int n_dtiles, float *acc, size_t n
 	}
 }
 
-template <bool APIC>
+template <bool APIC, bool QUIRK>
 __global__ void __launch_bounds__(256)
 k_p2g_atomic(size_t n, ParticleSoA p, float *acc, size_t ncp, GridDims g, float hworld) {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -172,7 +208,7 @@ k_p2g_atomic(size_t n, ParticleSoA p, float *acc, size_t ncp, GridDims g, float 
 		for (int k = 0; k < 9; ++k) c[k] = p.c[k][i];
 	}
 	// local coords 0 here: hx = 1 + b + i  => cell offset = hx - 1
-	scatter_particle<APIC>(0, 0, 0, t, v, c, hworld, [&](int comp, int hx, int hy, int hz, float wv, float wgt) {
+	scatter_particle<APIC, QUIRK>(0, 0, 0, t, v, c, hworld, [&](int comp, int hx, int hy, int hz, float wv, float wgt) {
 		int x = cx + hx - 1, y = cy + hy - 1, z = cz + hz - 1;
 		if (!in_grid(g, x, y, z)) return;
 		size_t b = blocked_index(g, x, y, z);
@@ -283,11 +319,40 @@ k_add_gravity(const int *dtiles, int n_dtiles, GridDims g, float *u, float *v, f
 
 static int grid_blocks(int n) { return n < 16384 ? (n > 0 ? n : 1) : 16384; }
 
+/// 0 = PIC / FLIP, 1 = APIC, 2 = APIC with the reference's unscaled hat at cell_size != 1 (scatter_particle's QUIRK)
+static int scatter_mode(const lfa_sim *s) {
+	if (s->prm.simulation_method != LFA_APIC) return 0;
+	return (s->prm.apic_unscaled_kernel && s->prm.cell_size != 1.0) ? 2 : 1;
+}
+static void launch_binned(lfa_sim *s, const ParticleSoA &p, const ParticleSoA &pvc, const uint32_t *from, float *stage_own) {
+	const dim3 grid(grid_blocks(s->n_ptiles));
+	const float hworld = (float)s->prm.cell_size;
+#define LB(A, Q)                                                                                                             \
+	hipLaunchKernelGGL((k_p2g_binned<A, Q>), grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, p, pvc, from, s->tile_start, \
+	                   stage_own, hworld)
+	switch (scatter_mode(s)) {
+	case 0: LB(false, false); break;
+	case 1: LB(true, false); break;
+	default: LB(true, true); break;
+	}
+#undef LB
+}
+static void launch_atomic(lfa_sim *s, const ParticleSoA &p) {
+	const dim3 grid((unsigned)((s->np_live + 255) / 256));
+	const float hworld = (float)s->prm.cell_size;
+#define LA(A, Q) hipLaunchKernelGGL((k_p2g_atomic<A, Q>), grid, dim3(256), 0, s->stream, s->np_live, p, s->acc, s->ncp, s->g, hworld)
+	switch (scatter_mode(s)) {
+	case 0: LA(false, false); break;
+	case 1: LA(true, false); break;
+	default: LA(true, true); break;
+	}
+#undef LA
+}
+
 int lfa_p2g_run(lfa_sim *s, bool fuse_gravity, double dt) {
 	if (!s->binned) return lfa_fail(s, LFA_E_INVALID, "lfa_p2g: call lfa_hash_particles first");
 	LFA_HIP(s, hipSetDevice(s->device));
 	const int method = s->prm.simulation_method;
-	const bool apic = method == LFA_APIC;
 	if (method == LFA_FLIP_BLEND && !s->uo) {
 		LFA_HIP(s, hipMalloc(&s->uo, s->ncp * 4));
 		LFA_HIP(s, hipMalloc(&s->vo, s->ncp * 4));
@@ -296,7 +361,6 @@ int lfa_p2g_run(lfa_sim *s, bool fuse_gravity, double dt) {
 		LFA_HIP(s, hipMemsetAsync(s->vo, 0, s->ncp * 4, s->stream));
 		LFA_HIP(s, hipMemsetAsync(s->wo, 0, s->ncp * 4, s->stream));
 	}
-	const float hworld = (float)s->prm.cell_size;
 	const bool binned = s->prm.p2g_variant == LFA_P2G_LDS_BINNED;
 	if (!binned) LFA_TRY(lfa_particles_materialize(s));  // the global-atomic variant reads v, C in place
 	// a deferred binning: v, C come from the other buffer through vc_src
@@ -313,13 +377,7 @@ int lfa_p2g_run(lfa_sim *s, bool fuse_gravity, double dt) {
 			s->stage_tiles = want;
 		}
 		if (s->n_ptiles) {
-			dim3 grid(grid_blocks(s->n_ptiles));
-			if (apic)
-				hipLaunchKernelGGL(k_p2g_binned<true>, grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, p, pvc, from,
-				                   s->tile_start, s->stage + (size_t)s->p_off * 6 * LFA_HALO_CELLS, hworld);
-			else
-				hipLaunchKernelGGL(k_p2g_binned<false>, grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, p, pvc, from,
-				                   s->tile_start, s->stage + (size_t)s->p_off * 6 * LFA_HALO_CELLS, hworld);
+			launch_binned(s, p, pvc, from, s->stage + (size_t)s->p_off * 6 * LFA_HALO_CELLS);
 			LFA_LAUNCH_CHECK(s);
 		}
 		// particles within one cell of a slab face also contribute to the neighbour rank's faces
@@ -336,13 +394,7 @@ int lfa_p2g_run(lfa_sim *s, bool fuse_gravity, double dt) {
 			LFA_LAUNCH_CHECK(s);
 		}
 		if (s->np_live) {
-			dim3 grid((unsigned)((s->np_live + 255) / 256));
-			if (apic)
-				hipLaunchKernelGGL(k_p2g_atomic<true>, grid, dim3(256), 0, s->stream, s->np_live, p, s->acc, s->ncp, s->g,
-				                   hworld);
-			else
-				hipLaunchKernelGGL(k_p2g_atomic<false>, grid, dim3(256), 0, s->stream, s->np_live, p, s->acc, s->ncp, s->g,
-				                   hworld);
+			launch_atomic(s, p);
 			LFA_LAUNCH_CHECK(s);
 		}
 	}
@@ -395,26 +447,13 @@ int lfa_p2g_bench(lfa_sim *s, int which) {
 	if (which == LFA_K_P2G_SCATTER && s->prm.p2g_variant != LFA_P2G_LDS_BINNED) LFA_TRY(lfa_particles_materialize(s));
 	const ParticleSoA &p = s->pb[s->cur], &pvc = s->vc_pending ? s->pb[s->cur ^ 1] : s->pb[s->cur];
 	const uint32_t *from = s->vc_pending ? (const uint32_t *)s->vc_src : (const uint32_t *)nullptr;
-	const bool apic = s->prm.simulation_method == LFA_APIC;
-	const float hworld = (float)s->prm.cell_size;
 	if (which == LFA_K_P2G_SCATTER) {
 		if (s->prm.p2g_variant == LFA_P2G_LDS_BINNED) {
 			if (!s->stage || (size_t)s->n_ptiles_all > s->stage_tiles) return lfa_fail(s, LFA_E_INVALID, "no staging slabs");
-			dim3 grid(grid_blocks(s->n_ptiles));
-			float *own = s->stage + (size_t)s->p_off * 6 * LFA_HALO_CELLS;
-			if (apic)
-				hipLaunchKernelGGL(k_p2g_binned<true>, grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, p, pvc, from,
-				                   s->tile_start, own, hworld);
-			else
-				hipLaunchKernelGGL(k_p2g_binned<false>, grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, p, pvc, from,
-				                   s->tile_start, own, hworld);
+			launch_binned(s, p, pvc, from, s->stage + (size_t)s->p_off * 6 * LFA_HALO_CELLS);
 		} else {
 			if (!s->acc) return lfa_fail(s, LFA_E_INVALID, "no accumulators");
-			dim3 grid((unsigned)((s->np_live + 255) / 256));
-			if (apic)
-				hipLaunchKernelGGL(k_p2g_atomic<true>, grid, dim3(256), 0, s->stream, s->np_live, p, s->acc, s->ncp, s->g, hworld);
-			else
-				hipLaunchKernelGGL(k_p2g_atomic<false>, grid, dim3(256), 0, s->stream, s->np_live, p, s->acc, s->ncp, s->g, hworld);
+			launch_atomic(s, p);
 		}
 		LFA_LAUNCH_CHECK(s);
 		return LFA_OK;

@@ -52,10 +52,15 @@ if __name__ == "__main__":
     orc.build()
     if not orc.have_ref():
         sys.exit("oracle/_ref/libref.so is not built: /root/reference is needed to generate the golden vectors")
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]
     for name in util.CASES:
+        if only and name not in only:
+            continue
         rec = util.staged_cpu_run(name, "ref")
         np.savez_compressed(util.golden_path(name), **rec)
         print(name, {k: int(rec[k]) for k in rec if k.startswith("iters")},
               os.path.getsize(util.golden_path(name)) // 1024, "KiB")
-    make_fullstep()
-    make_next_stages()
+    if not only or "fullstep_flip" in only:
+        make_fullstep()
+    if not only or "next_stages" in only:
+        make_next_stages()

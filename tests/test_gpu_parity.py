@@ -25,7 +25,8 @@ VEL_ATOL = 1e-5 * 981.0 * util.DT
 
 def make_gpu(name, **extra):
     c, parts, solid = util.make_case(name)
-    s = lfa.Sim(c["size"], method=c["method"], blending=c["blend"], **extra)
+    h, off, rho = util.case_params(c)
+    s = lfa.Sim(c["size"], cell_size=h, offset=off, density=rho, method=c["method"], blending=c["blend"], **extra)
     if solid is not None:
         s.set_solid_cells(solid)
     s.upload_particles(parts)
@@ -51,7 +52,7 @@ def test_keys_counts_and_fluid_cells_bit_exact(name):
     assert np.array_equal(out["pos"], parts["pos"])
     # positions reconstructed from the device's (cell, fraction) representation: fp32 fraction of a cell
     rec = s.download_particles()
-    assert np.abs(rec["pos"] - parts["pos"]).max() <= 2.0 ** -23
+    assert np.abs(rec["pos"] - parts["pos"]).max() <= 2.0 ** -23 * util.case_params(c)[0] + 1e-13
     s.close()
 
 
@@ -73,7 +74,7 @@ def test_p2g_and_gravity(name, variant):
 
 
 @pytest.mark.parametrize("dtype", [lfa.PCG_F32, lfa.PCG_F64])
-@pytest.mark.parametrize("name", ["apic16", "apic16_solid", "pic_ragged", "apic_tank"])
+@pytest.mark.parametrize("name", ["apic16", "apic16_solid", "pic_ragged", "apic_tank", "pic_h05", "flip_h17", "apic_h05", "apic_h17"])
 def test_system_matrix_rhs_and_exact_mic(name, dtype):
     """A bits bit-exact; b, MIC(0) factor, M^-1 probe and A probe against the reference on the reference's own grid."""
     c, parts, solid, s = make_gpu(name, precond=lfa.PRECOND_MIC0_EXACT, pcg_dtype=dtype)
@@ -109,7 +110,7 @@ def test_pcg_exact_schedule_matches_reference_iterations(name):
 
 @pytest.mark.parametrize("dtype", [lfa.PCG_F32, lfa.PCG_F64])
 @pytest.mark.parametrize("precond", [lfa.PRECOND_MIC0_TILED, lfa.PRECOND_MIC0_EXACT, lfa.PRECOND_MULTILEVEL, lfa.PRECOND_MULTIGRID])
-@pytest.mark.parametrize("name", ["apic16_solid", "flip16", "pic_ragged", "apic_tank"])
+@pytest.mark.parametrize("name", ["apic16_solid", "flip16", "pic_ragged", "apic_tank", "pic_h05", "flip_h17", "apic_h05", "apic_h17"])
 def test_pcg_pressure_within_tolerance(name, precond, dtype):
     c, parts, solid, s = make_gpu(name, precond=precond, pcg_dtype=dtype)
     g = util.load_golden(name)
@@ -135,14 +136,19 @@ def test_apply_pressure_extrapolate_g2p(name):
     s.upload_cells(cells_from(g["apply_vel0"], g["p2g_type0"]))
     s.extrapolate()
     util.assert_close(s.cells()["vel"], g["extrap_vel0"], VEL_REL, "after extrapolation")
-    if c["method"] != util.FLIP:  # FLIP needs the old grid of its own P2G: covered by the end-to-end test
-        s.upload_cells(cells_from(g["extrap_vel0"], g["p2g_type0"]))
-        s.g2p()
-        out = s.download_particles(into=parts.copy())
-        util.assert_close(out["vel"], g["g2p_vel0"], VEL_REL, "particle velocity after G2P")
-        if c["method"] == util.APIC:
-            cc = np.concatenate([out["cx"], out["cy"], out["cz"]], axis=1)
-            util.assert_close(cc, g["g2p_c0"], 5e-5, "APIC C after G2P")
+    if c["method"] == util.FLIP:
+        # FLIP's blend reads the old grid its own P2G left on the device (src/simulation.cpp:340-344,463-505): run that P2G,
+        # then replace the live grid by the reference's extrapolated one - the G2P stage alone against the reference's
+        s.hash()
+        s.p2g()
+        util.assert_close(s.old_cells()["vel"], g["old_vel0"], VEL_REL, "flip old grid")
+    s.upload_cells(cells_from(g["extrap_vel0"], g["p2g_type0"]))
+    s.g2p()
+    out = s.download_particles(into=parts.copy())
+    util.assert_close(out["vel"], g["g2p_vel0"], VEL_REL * (2 if c["method"] == util.FLIP else 1), "particle velocity after G2P")
+    if c["method"] == util.APIC:
+        cc = np.concatenate([out["cx"], out["cy"], out["cz"]], axis=1)
+        util.assert_close(cc, g["g2p_c0"], 5e-5, "APIC C after G2P")
     s.close()
 
 
@@ -171,19 +177,18 @@ def test_two_hot_steps_end_to_end(name, precond, dtype):
         util.assert_close(out["vel"], g[f"g2p_vel{st}"], 1e-4, f"particle velocity step {st}", atol=VEL_ATOL)
         util.assert_close(np.concatenate([out["cx"], out["cy"], out["cz"]], axis=1), g[f"g2p_c{st}"], 2e-4,
                           f"particle C step {st}", atol=VEL_ATOL)
-        vmax_ref = 1.0 / float(g[f"cfl{st}"])  # cell_size = 1: cfl = 1 / max|v|
-        assert abs(1.0 / s.cfl() - vmax_ref) <= 1e-4 * vmax_ref + VEL_ATOL
+        hh = util.case_params(c)[0]
+        vmax_ref = hh / float(g[f"cfl{st}"])  # cfl = cell_size / max|v| (src/simulation.cpp:199-205)
+        assert abs(hh / s.cfl() - vmax_ref) <= 1e-4 * vmax_ref + VEL_ATOL
     s.close()
 
 
-@pytest.mark.parametrize("name", ["apic16_solid", "flip16", "apic_ragged"])
+@pytest.mark.parametrize("name", ["apic16_solid", "flip16", "apic_ragged", "pic_h05", "flip_h17", "apic_h05", "apic_h17"])
 def test_step_hot_equals_staged_calls_and_oracle(name):
     """lfa_step_hot (fused gravity, no intermediate downloads) against the oracle's hot_step on the same inputs."""
     from oracle import loader as orc
     c, parts, solid, s = make_gpu(name, precond=lfa.PRECOND_MIC0_EXACT, pcg_dtype=lfa.PCG_F64)
-    o = orc.CpuSim(c["size"], method=c["method"], blending=c["blend"])
-    if solid is not None:
-        o.set_solid_cells(solid)
+    o = util.cpu_sim(c, "oracle", solid)
     o.set_particles(parts)
     for st in range(2):
         res, it, rc = s.step_hot(util.DT)

@@ -12,6 +12,15 @@ __global__ void __launch_bounds__(256) k(const uint32_t *idx, float *out, int it
 	__syncthreads();
 	uint32_t a = PATTERN == 0 ? threadIdx.x : idx[blockIdx.x * 256 + threadIdx.x];  // 0: conflict free, 1: random
 	if (PATTERN == 2) a = threadIdx.x / 8;  // 8 lanes per address
+	if (PATTERN == 3) {  // monotone in the lane with random gaps of 1-2 (k-th particles of consecutive occupied cells)
+		uint32_t g = 1 + (idx[blockIdx.x * 256 + threadIdx.x] & 1), incl = g;
+		for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(incl, o, 64); if ((threadIdx.x & 63) >= o) incl += t; }
+		a = incl + 100 * (threadIdx.x >> 6);
+	}
+	if (PATTERN == 4) {  // halo index of the cells of an 8 x 8 slab of a tile, each shifted by a random (0|-1, 0|-10, 0|-100)
+		const uint32_t r = idx[blockIdx.x * 256 + threadIdx.x], l = threadIdx.x & 63;
+		a = 111 + (l & 7) + 10 * (l >> 3) + 100 * (threadIdx.x >> 6) - (r & 1) - 10 * ((r >> 1) & 1) - 100 * ((r >> 2) & 1);
+	}
 	float v = 1.0f + threadIdx.x;
 	for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -59,6 +68,11 @@ int main() {
 	run<1, 2>("ds_add_u32 8 lanes/addr", idx, out);
 	run<2, 0>("ds_add_u64 conflict-free", idx, out);
 	run<2, 1>("ds_add_u64 random", idx, out);
+	run<2, 2>("ds_add_u64 8 lanes/addr", idx, out);
+	run<2, 3>("ds_add_u64 monotone+gaps", idx, out);
+	run<2, 4>("ds_add_u64 slab cells +-1", idx, out);
+	run<1, 3>("ds_add_u32 monotone+gaps", idx, out);
+	run<1, 4>("ds_add_u32 slab cells +-1", idx, out);
 	run<3, 0>("ds_add_f64 conflict-free", idx, out);
 	run<3, 1>("ds_add_f64 random", idx, out);
 	run<4, 0>("ds_write_b32 conflict-free", idx, out);
