@@ -1,10 +1,14 @@
 #!/usr/bin/env python3
-"""bench.py -- particle-steps/s (+ PCG iterations/s) of the MI355X hot path on BASELINE.json's synthetic dam break.
+"""bench.py -- particle-steps/s (+ PCG iterations/s) of the MI355X-native libfluid step on BASELINE.json's synthetic dam break.
 
-A "step" is one device-resident pass of the hot path over the resident particle set (lfa_step_hot):
-    tile binning -> P2G -> gravity -> pressure system + MIC(0)-PCG -> pressure gradient -> extrapolation -> G2P
-(reference: src/simulation.cpp:62-66,72-78,83-104,119-121). The stages of simulation::time_step outside SURVEY.md
-section 8(a) (advect / collide / position correction, 8(f) "next" rows) are not part of the timed region.
+A "step" is one device-resident simulation::time_step(dt) (reference: src/simulation.cpp:43-125; SURVEY.md 8(d) metric (1)):
+    dt = min(cfl_number * cfl(), 0.033)   (simulation::time_step(), :127-129 -- the max-|v| reduction is inside the timed step)
+    advect+collide -> binning -> P2G -> gravity -> pressure system + PCG -> pressure gradient -> position correction+collide
+    -> extrapolation -> G2P
+over the particles resident in HBM. The timed region starts on a dam that is already breaking: at least 20 untimed steps
+(`--warmup`, topped up by a pre-roll when the caller asks for fewer) precede it, so that particles cross cells and tiles, the
+binning permutes, the deferred v/C gather fires and the multigrid tile lists are rebuilt as in a production run. The hot path
+alone (lfa_step_hot: the rows of SURVEY 8(a)) is reported beside it under "hot_path".
 
 Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches one rank per GPU with
 torch.distributed.run. W untimed steps, then exactly K timed steps bracketed by barrier + device synchronise, MAX over
@@ -13,29 +17,31 @@ ranks, rank 0 prints ONE JSON line.
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6.3 TB/s achievable
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); the measured ceiling is reported beside it
+MIN_LEAD_IN = 20       # untimed steps before the timed region (warm-up + pre-roll)
 
-# algorithmic bytes per unit; n = PCG unknowns, Np particles, Nc cells of the processed tiles
+# algorithmic bytes per unit; n = PCG unknowns, Np particles, Nc cells
 PCG_BYTES_UNFUSED = {"spmv_dot": 17, "axpy_max": 28, "mic_apply_dot": 34, "update_s": 12}
-# fused iteration (default): k_pcg_a = update_s + spmv_dot, k_pcg_b = axpy_max + mic_apply_dot; same 91 n in total
+# fused iteration: k_pcg_a = update_s + spmv_dot, k_pcg_b = axpy_max + mic_apply_dot; same 91 n in total
 PCG_BYTES_FUSED = {"pcg_a": 12 + 17, "pcg_b": 28 + 34}
-# multigrid iteration (default on one GPU): search direction + A s, AXPYs + finest-level pre-smoothing, finest-level residual
+# multigrid iteration (default): search direction + A s, AXPYs + finest-level pre-smoothing, finest-level residual
 # + restriction, coarser levels (latency bound: no byte figure), finest-level prolongation + post-smoothing + dot.
-# Bytes per unknown = the minimal traffic of each pass with SURVEY 8(d)'s conventions (fp32 vector 4, A byte 1, dot 8, max 4).
 PCG_BYTES_MG = {"pcg_a": 12 + 17, "mg_axpy_presmooth": 28 + 5, "mg_down0": 9.5, "mg_coarse": 0, "mg_up0": 21}
 
 
-def cpu_baseline(sample, steps):
+def cpu_baseline(sample, steps, lfa):
     """The reference's own hot path (oracle/_ref/libref.so: src/simulation.cpp + src/pressure_solver.cpp + src/mac_grid.cpp
     compiled in place, kind "reference") timed on this box's host cores; when that build did not travel, the plain-C
-    restatement (oracle/liboracle.so, kind "port")."""
-    import numpy as np  # noqa: F401
+    restatement (oracle/liboracle.so, kind "port"). The pressures it computes are compared with the device's on the same
+    particles (the oracle is the checker here, never the thing measured on the GPU side)."""
+    import numpy as np
     from libfluid_amd import scenes
     from oracle import loader as orc
     cfg = scenes.CONFIGS[sample]
@@ -44,12 +50,15 @@ def cpu_baseline(sample, steps):
     sim = orc.CpuSim(cfg["size"], method=cfg["method"], blending=cfg["blending"], kind=kind)
     sim.set_particles(parts)
     t0 = time.perf_counter()
-    iters = 0
-    for _ in range(steps):
-        _, _, it = sim.hot_step(0.033)
+    iters, its, p_first = 0, [], None
+    for k in range(steps):
+        p, _, it = sim.hot_step(0.033)
+        if k == 0:
+            p_first = p.copy()
         iters += it
+        its.append(int(it))
     dt = time.perf_counter() - t0
-    return {
+    out = {
         "value": len(parts) * steps / dt, "unit": "particle-steps/s", "cores": 1,
         "kind": "reference" if kind == "ref" else "port",
         "sample": f"{sample}: {cfg['size'][0]}^3 grid, {len(parts)} particles, {steps} hot-path steps, "
@@ -57,19 +66,34 @@ def cpu_baseline(sample, steps):
                   + ("the reference's serial _transfer_to_grid / pressure_solver::solve / _transfer_from_grid "
                      "(src/simulation.cpp:293-398, src/pressure_solver.cpp:19-71), g++ -O2 -DNDEBUG" if kind == "ref" else
                      "plain-C restatement, serial like the reference's P2G/PCG/G2P, gcc -O2"),
-        "pcg_iters_per_s": iters / dt,
+        "pcg_iters_per_s": iters / dt, "pcg_iterations": its,
     }
+    # the same first step on the device: exact MIC(0) schedule / fp64 vectors (iteration count) and the default configuration
+    check = {}
+    for tag, extra in (("exact_f64", dict(precond=lfa.PRECOND_MIC0_EXACT, pcg_dtype=lfa.PCG_F64)), ("default", {})):
+        g = lfa.Sim(cfg["size"], method=cfg["method"], blending=cfg["blending"], **extra)
+        g.upload_particles(parts)
+        _, it, _ = g.step_hot(0.033)
+        pg = g.pressure()
+        check[tag] = {"iterations": int(it), "pressure_max_rel_err": float(np.abs(pg - p_first).max() / np.abs(p_first).max())}
+        g.close()
+    out["device_vs_cpu_first_step"] = check
+    sim.close()
+    return out
+
+
+def med(xs):
+    return statistics.median(xs) if xs else 0.0
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default=None, help="C2 | C3 | C4 | C5 (default: C4 at 1 GPU, see DESIGN.md)")
-    ap.add_argument("--dt", type=float, default=0.033, help="min(3*cfl, 0.033) of simulation::time_step() at rest")
-    ap.add_argument("--precond", default=None, choices=["multigrid", "multilevel", "tiled", "exact"],
-                    help="default: multigrid (on z-slabs: finest 4 levels distributed, coarser ones replicated)")
+    ap.add_argument("--dt-max", type=float, default=0.033, help="cap of simulation::time_step(): dt = min(3 cfl, 0.033)")
+    ap.add_argument("--precond", default="multigrid", choices=["multigrid", "multilevel", "tiled", "exact"])
     ap.add_argument("--pcg-dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--p2g", default="binned", choices=["binned", "atomic"])
     ap.add_argument("--max-iterations", type=int, default=200, help="PCG iteration cap (pressure_solver.h:42)")
@@ -77,18 +101,19 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--no-full-step", action="store_true")
+    ap.add_argument("--no-hot-path", action="store_true")
+    ap.add_argument("--hot-steps", type=int, default=10)
     ap.add_argument("--unfused", action="store_true", help="one launch per vector operation in the PCG loop (pcg_fused = 0)")
     ap.add_argument("--obstacle", action="store_true", help="BASELINE configs[4]: voxelize a sphere mesh on the device "
                     "(lfa_voxelize_mesh) and mark it solid before the steps")
     ap.add_argument("--mesh", action="store_true", help="BASELINE configs[4]: extract the surface mesh from the resident particles "
                     "after the timed steps (lfa_mesher_sample_sim + marching cubes), timed separately")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent copies of the domain instead of z-slabs")
+    ap.add_argument("--strong", action="store_true", help="N > 1: the FIXED BASELINE domain (configs[3]/[4]) split into N z-slabs "
+                    "instead of a domain that grows with N")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
-    if args.precond is None:
-        args.precond = "multigrid"
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
@@ -111,9 +136,10 @@ def main():
     cfg = dict(scenes.CONFIGS[cfg_name])
     size, (blo, bhi) = list(cfg["size"]), [list(x) for x in cfg["block"]]
     parallelism = "1 GPU"
-    if world > 1 and not args.replicas:
+    slabs = world > 1 and not args.replicas
+    if slabs and not args.strong:
         # weak scaling: the domain and the dam-break block grow along z with the number of GPUs, every rank owns a slab
-        # as large as the single-GPU workload (BASELINE configs[3]/[4] decompose along z the same way)
+        # as large as the single-GPU workload
         size[2] *= world
         bhi[2] *= world
     sim = lfa.Sim(size, method=cfg["method"], blending=cfg["blending"], device=local_rank,
@@ -124,7 +150,7 @@ def main():
                   max_iterations=args.max_iterations, pcg_fused=0 if args.unfused else 1)
     fused = not args.unfused and args.precond != "exact"
     PCG_BYTES = PCG_BYTES_MG if args.precond == "multigrid" else (PCG_BYTES_FUSED if fused else PCG_BYTES_UNFUSED)
-    if world > 1 and not args.replicas:
+    if slabs:
         # one RCCL communicator per handle: rank 0 creates the id, torch.distributed (RCCL) broadcasts it
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
@@ -133,21 +159,22 @@ def main():
         ntz = (size[2] + 7) // 8
         bounds = lfa.balanced_layer_bounds(ntz, world, blo[2] // 8, (bhi[2] + 7) // 8)
         sim.init_rccl_slab(rank, world, uid.cpu().numpy().tobytes(), bounds)
-        parallelism = f"{world} z-slabs (tile layers {bounds}), RCCL send/recv halos + scalar all-reduces over xGMI"
+        parallelism = (f"{world} z-slabs (tile layers {bounds}), {'strong' if args.strong else 'weak'} scaling, "
+                       "RCCL send/recv halos + scalar all-reduces + particle migration over xGMI")
     elif world > 1:
         parallelism = f"{world} independent replicas (--replicas)"
     extras = {}
     if args.obstacle:
-        # a sphere in the dry part of the tank, in the path of the collapsing column (the classic dam break with an obstacle),
-        # voxelized on the device and marked solid without leaving it. It must not overlap the seeded block: particles deep
-        # inside a solid give rows without a diagonal, which the reference's MIC(0) turns into 1/sqrt(0) as well.
+        # a sphere in the dry part of the tank, in the path of the collapsing column, voxelized on the device and marked solid
+        # without leaving it (it must not overlap the seeded block: particles deep inside a solid give rows without a diagonal)
         rad = 0.16 * min(bhi[0] - blo[0], bhi[1] - blo[1], cfg["block"][1][2] - blo[2])
         ctr = [min(bhi[0] + 2.0 * rad, size[0] - 1.5 * rad), blo[1] + 1.2 * rad, 0.5 * (blo[2] + cfg["block"][1][2])]
         mpos, midx = scenes.icosphere(ctr, rad, 5)
         t0 = time.perf_counter()
         vox = lfa.Voxels.from_mesh(mpos, midx, 1.0, (0.0, 0.0, 0.0), device=local_rank)
         sim.set_solid_from_voxels(vox, True, True)
-        extras["voxelizer"] = {"triangles": int(len(midx) // 3), "voxel_grid": list(vox.size), "ms_mesh_to_solid_cells": 1e3 * (time.perf_counter() - t0),
+        extras["voxelizer"] = {"triangles": int(len(midx) // 3), "voxel_grid": list(vox.size),
+                               "ms_mesh_to_solid_cells": 1e3 * (time.perf_counter() - t0),
                                "solid_cells": int(len(vox.cells(True, True, size)))}
         vox.close()
     sim.seed_block(blo, bhi)
@@ -159,18 +186,34 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    iters_total, not_converged = 0, 0
-    for _ in range(args.warmup):
-        sim.step_hot(args.dt)
+    def global_cfl():
+        """simulation::cfl over the whole domain: each rank reduces its own particles, the minimum over ranks is the CFL step."""
+        c = sim.cfl()
+        if slabs:
+            t = torch.tensor([c], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            c = float(t.item())
+        return c
+
+    def one_step():
+        dt = min(3.0 * global_cfl(), args.dt_max)
+        res, it, rc = sim.time_step(dt)
+        return dt, it, rc
+
+    preroll = max(0, MIN_LEAD_IN - args.warmup)
+    t_sim = 0.0
+    for _ in range(preroll + args.warmup):
+        dt, _, _ = one_step()
+        t_sim += dt
     barrier()
     t0 = time.perf_counter()
-    stage_ms = {}
+    iters_total, not_converged, per_step, dts = 0, 0, [], []
     for _ in range(args.steps):
-        res, it, rc = sim.step_hot(args.dt)
+        dt, it, rc = one_step()
         iters_total += it
+        dts.append(dt)
         not_converged += int(rc == lfa.W_PCG_NOT_CONVERGED)
-        for k, v in sim.timings().items():
-            stage_ms[k] = stage_ms.get(k, 0.0) + v
+        per_step.append(sim.step_timings())
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -180,32 +223,34 @@ def main():
 
     counts = sim.counts()
     npart, n_unknowns = counts["particles"], counts["unknowns"]
-    ncell_proc = counts["processed_tiles"] * 512
     npart_total = npart
     if dist is not None:
         t = torch.tensor([float(npart)], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         npart_total = int(t.item())
     value = npart_total * args.steps / elapsed
-    stage_ms = {k: v / args.steps for k, v in stage_ms.items()}
-    pcg_s = stage_ms["pcg_loop"] * 1e-3 * args.steps
+    names = [k for k in per_step[0] if k not in ("pcg_iterations",)]
+    stage_med = {k: med([s[k] for s in per_step]) for k in names}
+    stage_p95 = {k: sorted(s[k] for s in per_step)[min(len(per_step) - 1, int(0.95 * len(per_step)))] for k in names}
+    pcg_s = sum(s["pcg_loop"] for s in per_step) * 1e-3
 
     out = {
         "metric": "particle_steps_per_sec", "value": value, "unit": "particle-steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if (slabs and args.strong) else "weak", "vs_baseline": None,
         "dtype": "f32" if args.pcg_dtype == "f32" else "f32 particles/grid, f64 PCG vectors", "data": "synthetic",
         "config": {
             "workload": f"{cfg_name}: {size[0]}x{size[1]}x{size[2]} MAC grid, dam-break block "
                         f"{tuple(blo)}-{tuple(bhi)} cells, {npart_total} particles, "
-                        f"{['PIC', 'FLIP', 'APIC'][cfg['method']]} blend {cfg['blending']}, dt {args.dt}, "
-                        f"hot path only (bin+P2G+gravity+PCG+apply+extrapolate+G2P)",
+                        f"{['PIC', 'FLIP', 'APIC'][cfg['method']]} blend {cfg['blending']}, full simulation::time_step "
+                        f"(cfl + advect/collide + bin + P2G + gravity + PCG + apply + correct/collide + extrapolate + G2P), "
+                        f"dt = min(3 cfl, {args.dt_max}), timed from step {preroll + args.warmup} of the dam break "
+                        f"(t = {t_sim:.3f} s .. {t_sim + sum(dts):.3f} s)",
+            "preroll_steps": preroll, "dt_mean": sum(dts) / len(dts),
             "unknowns": n_unknowns, "particles_per_gpu": npart,
             "precond": {"tiled": "MIC(0) per 8^3 tile", "exact": "MIC(0) exact (tile hyperplanes)",
                         "multilevel": "MIC(0) per 8^3 tile + tile-aggregate coarse correction",
                         "multigrid": "geometric multigrid V(1,1), red-black Gauss-Seidel per tile"}[args.precond],
-            "pcg_loop": ("k_pcg_a + AXPYs/pre-smoothing + V-cycle (k_mg_*) per iteration" if args.precond == "multigrid" else
-                         "fused: 2 launches per iteration (k_pcg_a, k_pcg_b)" if fused else "5 launches per iteration"),
             "p2g": args.p2g, "pcg_tolerance": 1e-6, "pcg_max_iterations": args.max_iterations,
             "parallelism": parallelism,
         },
@@ -214,84 +259,98 @@ def main():
             "iters_per_sec": iters_total / pcg_s if pcg_s > 0 else None,
             "unknown_iters_per_sec": n_unknowns * iters_total / pcg_s if pcg_s > 0 else None,
             "steps_hitting_max_iterations": not_converged,
+            "note": "iterations of the preconditioner named in config.precond; the reference-comparable MIC(0) figure is "
+                    "`--precond multilevel` (same iteration counts as the reference's MIC(0)-PCG within a few per cent)",
         },
-        "stage_ms": stage_ms,
+        "stage_ms_median": stage_med, "stage_ms_p95": stage_p95,
     }
 
     if rank == 0 and world == 1 and not args.no_kernel_timing:
-        # live HIP-event timing of each hot kernel on the handle's stream (mean of 20 launches)
         apic = cfg["method"] == 2
+        flip = cfg["method"] == 1
+        ncell_all = cfg["size"][0] * cfg["size"][1] * cfg["size"][2]
+        ncell_proc = counts["processed_tiles"] * 512
+        it_per_step = iters_total / max(args.steps, 1)
+        # ---- measured HBM ceiling of this device ("report both")
+        copy_gbs, read_gbs = sim.bench_stream(1 << 30, 10)
+        out["hbm_ceiling_measured"] = {"device_copy_GBps": copy_gbs, "read_only_GBps": read_gbs, "spec_peak_GBps": HBM_PEAK_GBS,
+                                       "how": "lfa_bench_stream: float4 grid-stride kernels over 1 GiB, mean of 10 launches"}
+        # ---- in-step kernels / kernel groups: MEDIAN device time inside the timed steps (HIP events on the handle's stream)
+        # algorithmic bytes: SURVEY 8(d). P2G scatter 60 Np (APIC) / 24 Np; PCG iteration 91 n (92.5 n for the V-cycle's own
+        # passes); G2P 60 Np + 12 Nc (APIC), 36 Np + 24 Nc (FLIP), 24 Np + 12 Nc (PIC); binning: the bytes the deferred scheme
+        # moves (key, t, id both ways + source index = 44 Np, + 2 x 36 Np for PIC/FLIP whose C travels with the particle);
+        # position correction: positions in and out, 24 Np (the reference's OMP loop reads and writes vec3d positions,
+        # src/simulation.cpp:562-610; pair interactions are arithmetic, not traffic)
+        pcg_iter_bytes = (sum(PCG_BYTES.values()) if args.precond == "multigrid" else 91) * n_unknowns * (2 if args.pcg_dtype == "f64" else 1)
+        in_step = {
+            "p2g_scatter_kernel": ((60 if apic else 24) * npart, 1.0),
+            "pcg_iteration_mean": (pcg_iter_bytes, it_per_step),
+            "g2p": ((60 if apic else (36 if flip else 24)) * npart + (24 if flip else 12) * ncell_proc, 1.0),
+            "bin": ((44 if apic else 116) * npart, 1.0),
+            "correct_tiled_kernel": (24 * npart, 1.0),
+            "advect_collide": (32 * npart, 1.0),
+        }
+        kern = {}
+        for k, (b, mult) in in_step.items():
+            ms = stage_med[k]
+            if ms > 0:
+                kern[k] = {"ms_median": ms, "ms_p95": stage_p95[k], "algorithmic_bytes": int(b), "GBps": b / ms * 1e-6,
+                           "frac": b / ms * 1e-6 / HBM_PEAK_GBS, "share_of_step_ms": ms * mult}
+        out["in_step_kernels"] = kern
+        dom = max(kern, key=lambda k: kern[k]["share_of_step_ms"])
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r02_c4_pmc_traffic.json")
+        pmc_names = {"p2g_scatter_kernel": "p2g_scatter", "correct_tiled_kernel": "correct_tiled", "g2p": "g2p",
+                     "advect_collide": "advect_collide"}
+        if cfg_name == "C4" and args.pcg_dtype == "f32" and os.path.exists(pmc) and dom in pmc_names:
+            traffic = json.load(open(pmc))["hbm_bytes_per_launch"].get(pmc_names[dom], {}).get("total")
+        out["roofline"] = {
+            "bound": "hbm", "kernel": dom, "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": kern[dom]["frac"], "traffic": traffic, "algorithmic_bytes": kern[dom]["algorithmic_bytes"],
+            "ms": kern[dom]["ms_median"], "share_of_step_ms": kern[dom]["share_of_step_ms"],
+            "note": "dominant = largest share of the median full step; duration = in-step median over the timed steps",
+        }
+        p2g_b = (60 if apic else 24) * npart + (26 if flip else 14) * ncell_all
+        p2g_pcg_ms = stage_med["p2g"] + stage_med["pcg_loop"]
+        p2g_pcg_b = p2g_b + pcg_iter_bytes * it_per_step
+        out["roofline_groups"] = {
+            "p2g": {"ms": stage_med["p2g"], "algorithmic_bytes": int(p2g_b), "GBps": p2g_b / stage_med["p2g"] * 1e-6,
+                    "frac": p2g_b / stage_med["p2g"] * 1e-6 / HBM_PEAK_GBS},
+            "pcg_iteration": {"ms": stage_med["pcg_iteration_mean"], "algorithmic_bytes": int(pcg_iter_bytes),
+                              "GBps": kern["pcg_iteration_mean"]["GBps"], "frac": kern["pcg_iteration_mean"]["frac"]},
+            "p2g_plus_pcg": {"ms": p2g_pcg_ms, "algorithmic_bytes": int(p2g_pcg_b), "GBps": p2g_pcg_b / p2g_pcg_ms * 1e-6,
+                             "frac": p2g_pcg_b / p2g_pcg_ms * 1e-6 / HBM_PEAK_GBS,
+                             "note": "the north star's target group (>= 0.40): in-step medians, 60 Np + 14 Nc + 91(92.5) n x iterations"},
+        }
+        # ---- isolated kernels, back to back on the state of the last step (lfa_bench_kernel): the PCG loop's launches
         kernels = {}
         for name in PCG_BYTES:
-            # pcg_b / mic_apply_dot = the launch of the PCG loop: tile sweeps + the embedded coarse-level workgroups
             ms = sim.bench_kernel(name, 20)
             b = int(PCG_BYTES[name] * n_unknowns * (2 if args.pcg_dtype == "f64" else 1))
             kernels[name] = {"ms": ms, "algorithmic_bytes": b, "GBps": b / ms * 1e-6}
-        if args.precond == "multilevel" and not fused:
-            kernels["mic_sweeps_without_coarse_levels"] = {"ms": sim.bench_kernel("mic_fine", 20), "algorithmic_bytes": 0,
-                                                           "GBps": 0.0}
-            kernels["coarse_levels_as_own_launch"] = {"ms": sim.bench_kernel("coarse_levels", 20), "algorithmic_bytes": 0,
-                                                      "GBps": 0.0}
-        p2g_bytes = (60 if apic else 24) * npart
-        g2p_bytes = (60 if apic else (36 if cfg["method"] == 1 else 24)) * npart + \
-            (24 if cfg["method"] == 1 else 12) * ncell_proc
-        # P2G = 60 Np + 14 Nc with Nc = ALL cells (the reference writes every cell, src/simulation.cpp:
-        # 296-335); cells outside the processed tiles are implicit here (background value), a legitimate saving
-        ncell_all = cfg["size"][0] * cfg["size"][1] * cfg["size"][2]  # per GPU
-        fin_bytes = (26 if cfg["method"] == 1 else 14) * ncell_all
-        bin_bytes = (2 * 68 + 8) * npart  # 2 x state bytes + keys
-        for name, b in (("g2p", g2p_bytes), ("p2g_finalize", fin_bytes), ("p2g_scatter", p2g_bytes), ("bin", bin_bytes)):
-            ms = sim.bench_kernel(name, 10)
-            kernels[name] = {"ms": ms, "algorithmic_bytes": b, "GBps": b / ms * 1e-6}
-        out["kernels"] = kernels
-        # dominant kernel = largest share of the step: iterations x per-iteration kernel time vs the one-shot kernels
-        it_per_step = iters_total / max(args.steps, 1)
-        share = {k: v["ms"] * (it_per_step if k in PCG_BYTES else 1.0) for k, v in kernels.items()
-                 if v["algorithmic_bytes"]}
-        dom = max(share, key=share.get)
-        # HBM traffic of that kernel from the PMC passes committed under profiles/ (same command, same workload)
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_c4_pmc_traffic.json")
-        if cfg_name == "C4" and args.precond in ("multilevel", "multigrid") and args.pcg_dtype == "f32" and os.path.exists(pmc):
-            per_launch = json.load(open(pmc))["hbm_bytes_per_launch"]
-            if dom == "bin":  # the binning stage = count + scatter + per-cell histogram launches
-                parts = [per_launch.get(k, {}).get("total") for k in ("bin_count", "bin_scatter", "bin_cells")]
-                traffic = sum(parts) if all(v is not None for v in parts) else None
-            else:
-                traffic = per_launch.get(dom, {}).get("total")
-        out["roofline"] = {
-            "bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
-            "algorithmic_bytes": kernels[dom]["algorithmic_bytes"], "ms": kernels[dom]["ms"],
-            "share_of_step_ms": share[dom],
-        }
-        pcg_iter_ms = sum(kernels[k]["ms"] for k in PCG_BYTES)
-        # the reference's iteration is 91 n bytes; the V-cycle iteration is priced by its own passes
-        pcg_bytes = (sum(PCG_BYTES.values()) if args.precond == "multigrid" else 91) * n_unknowns * (2 if args.pcg_dtype == "f64" else 1)
-        out["roofline_groups"] = {
-            "pcg_iteration": {"ms": pcg_iter_ms, "algorithmic_bytes": pcg_bytes, "GBps": pcg_bytes / pcg_iter_ms * 1e-6,
-                              "frac": pcg_bytes / pcg_iter_ms * 1e-6 / HBM_PEAK_GBS},
-            "p2g": {"ms": kernels["p2g_scatter"]["ms"] + kernels["p2g_finalize"]["ms"],
-                    "algorithmic_bytes": p2g_bytes + fin_bytes,
-                    "GBps": (p2g_bytes + fin_bytes) / (kernels["p2g_scatter"]["ms"] + kernels["p2g_finalize"]["ms"]) * 1e-6,
-                    "frac": (p2g_bytes + fin_bytes) / (kernels["p2g_scatter"]["ms"] + kernels["p2g_finalize"]["ms"])
-                    * 1e-6 / HBM_PEAK_GBS},
-        }
-    if world == 1 and not args.no_full_step:
-        # beyond the headline: the device-resident simulation::time_step(dt) (hot path + advect/collide/correct, SURVEY 8f
-        # rank 1), dt = min(cfl_number * cfl, 0.033) like simulation::time_step() (src/simulation.cpp:127-129)
-        fs_ms, fs_iters, n_fs = 0.0, 0, 3
-        t1 = time.perf_counter()
-        for _ in range(n_fs):
-            dt_fs = min(3.0 * sim.cfl(), 0.033)
-            _, it, _ = sim.time_step(dt_fs)
-            fs_iters += it
+        out["kernels_isolated"] = kernels
+
+    if world == 1 and not args.no_hot_path:
+        # secondary figure: the hot path alone (no advection / correction) on the state the dam has reached
+        hot_ms, hot_it = [], 0
+        stage = {}
+        for _ in range(2):
+            sim.step_hot(args.dt_max)
         sim.synchronize()
-        fs_s = time.perf_counter() - t1
-        out["full_time_step"] = {"steps": n_fs, "ms_per_step": 1e3 * fs_s / n_fs, "particle_steps_per_sec": npart * n_fs / fs_s,
-                                 "pcg_iterations_per_step": fs_iters / n_fs, "stage_ms": sim.step_timings(),
-                                 "note": "device resident: advect+collide, bin, P2G, PCG, apply, correct+collide, "
-                                         "extrapolate, G2P (P2G-time order; particles that left their tile: gather kernel)"}
+        t1 = time.perf_counter()
+        for _ in range(args.hot_steps):
+            _, it, _ = sim.step_hot(args.dt_max)
+            hot_it += it
+            for k, v in sim.timings().items():
+                stage.setdefault(k, []).append(v)
+        sim.synchronize()
+        hs = time.perf_counter() - t1
+        out["hot_path"] = {"steps": args.hot_steps, "ms_per_step": 1e3 * hs / args.hot_steps,
+                           "particle_steps_per_sec": npart * args.hot_steps / hs,
+                           "pcg_iterations_per_step": hot_it / args.hot_steps,
+                           "stage_ms_median": {k: med(v) for k, v in stage.items()},
+                           "note": "lfa_step_hot on the state reached by the timed steps: bin + P2G + gravity + PCG + apply + "
+                                   "extrapolate + G2P without advection (round 1's headline)"}
     if args.mesh and world == 1:
         m = lfa.Mesher(size, (0.0, 0.0, 0.0), 1.0, 1.0, 2, device=local_rank)  # mesher settings of testbed/main.cpp:101-107 at cell size 1
         t0 = time.perf_counter()
@@ -307,7 +366,7 @@ def main():
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_steps, lfa)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -183,8 +183,14 @@ int lfa_step_hot(lfa_sim *s, double dt, double *residual, uint64_t *iterations);
 int lfa_advect_collide(lfa_sim *s, double dt);
 int lfa_correct_collide(lfa_sim *s, double dt);
 int lfa_time_step(lfa_sim *s, double dt, double *residual, uint64_t *iterations);
-/* device time of the last lfa_time_step in ms (timing enabled): [0] advect+collide [1] correct+collide [2] whole step */
-int lfa_get_step_timings(lfa_sim *s, double ms[3]);
+/* Device time of the stages of the last lfa_time_step in milliseconds (timing enabled), HIP events on the handle's stream:
+ * [0] advect+collide  [1] binning  [2] P2G (scatter + finalize + gravity)  [3] P2G scatter kernel alone
+ * [4] pressure system + preconditioner set-up  [5] PCG loop  [6] pressure gradient  [7] cell index of the position
+ * correction (k_build_cell_index)  [8] LDS-tiled correction kernel alone  [9] correct+collide as a whole (7 + 8 + fallback)
+ * [10] extrapolation  [11] G2P  [12] whole step  [13] PCG iterations of the step (a count, not a time)
+ * [14] mean PCG iteration ([5] / [13])  [15] reserved */
+#define LFA_NUM_STEP_TIMERS 16
+int lfa_get_step_timings(lfa_sim *s, double ms[LFA_NUM_STEP_TIMERS]);
 
 /* -- multi-GPU: z-slab domain decomposition ---------------------------------------------------------
  * One handle per GPU/process, every handle created with the GLOBAL grid size. Rank r owns the tile layers
@@ -304,6 +310,9 @@ enum {
 	LFA_K_MG_UP0 = 15             /* finest level: prolongation + post-smoothing + dot(z, r)                   21 n */
 };
 int lfa_bench_kernel(lfa_sim *s, int which, int reps, double *mean_ms);
+/* Measured HBM ceilings of this device beside the 8 TB/s spec peak (SURVEY.md 8d "report both"): a float4 grid-stride device
+ * copy of `bytes` (read + write counted) and a read-only pass over the same buffer, GB/s, mean of `reps` launches. */
+int lfa_bench_stream(lfa_sim *s, uint64_t bytes, int reps, double *copy_gbs, double *read_gbs);
 
 #ifdef __cplusplus
 }

@@ -21,6 +21,10 @@ PRECOND_MIC0_TILED, PRECOND_MIC0_EXACT, PRECOND_MULTILEVEL, PRECOND_MULTIGRID = 
 PCG_F32, PCG_F64 = 0, 1
 OK, W_PCG_NOT_CONVERGED = 0, 1
 NUM_TIMERS = 10
+NUM_STEP_TIMERS = 16
+STEP_TIMER_NAMES = ["advect_collide", "bin", "p2g", "p2g_scatter_kernel", "build_system", "pcg_loop", "apply_pressure",
+                    "correct_cell_index", "correct_tiled_kernel", "correct_collide", "extrapolate", "g2p", "time_step",
+                    "pcg_iterations", "pcg_iteration_mean", "reserved"]
 TIMER_NAMES = ["bin", "p2g", "gravity", "build_system", "pcg_loop", "apply_pressure", "extrapolate", "g2p",
                "p2g_scatter_kernel", "pcg_iteration_mean"]
 
@@ -103,6 +107,7 @@ SIGNATURES = {
     "lfa_get_timings": (_int, [_vp, C.POINTER(_dbl * NUM_TIMERS)]),
     "lfa_get_counts": (_int, [_vp, C.POINTER(_u64 * 5)]),
     "lfa_bench_kernel": (_int, [_vp, _int, _int, C.POINTER(_dbl)]),
+    "lfa_bench_stream": (_int, [_vp, _u64, _int, C.POINTER(_dbl), C.POINTER(_dbl)]),
     "lfa_voxels_create": (_int, [C.POINTER(_vp), _vp, _vp, _dbl, _int]),
     "lfa_voxels_destroy": (None, [_vp]),
     "lfa_voxels_last_error": (C.c_char_p, [_vp]),
@@ -127,7 +132,7 @@ SIGNATURES = {
     "lfa_advect_collide": (_int, [_vp, _dbl]),
     "lfa_correct_collide": (_int, [_vp, _dbl]),
     "lfa_time_step": (_int, [_vp, _dbl, C.POINTER(_dbl), C.POINTER(_u64)]),
-    "lfa_get_step_timings": (_int, [_vp, C.POINTER(_dbl * 3)]),
+    "lfa_get_step_timings": (_int, [_vp, C.POINTER(_dbl * NUM_STEP_TIMERS)]),
     "lfa_dist_unique_id": (_int, [_vp]),
     "lfa_dist_init_rccl": (_int, [_vp, _int, _int, _vp, _vp]),
     "lfa_dist_local_hub_create": (_vp, [_int]),
@@ -560,9 +565,9 @@ class Sim:
         return res.value, it.value, rc
 
     def step_timings(self):
-        arr = (C.c_double * 3)()
+        arr = (C.c_double * NUM_STEP_TIMERS)()
         self._chk(self.lib.lfa_get_step_timings(self.h, C.byref(arr)))
-        return dict(zip(["advect_collide", "correct_collide", "time_step"], list(arr)))
+        return dict(zip(STEP_TIMER_NAMES[:15], list(arr)[:15]))
 
     # -- z-slab decomposition ------------------------------------------------------------------------------
     def init_local_slab(self, hub, rank, layer_bounds):
@@ -592,6 +597,12 @@ class Sim:
         out = C.c_double(0.0)
         self._chk(self.lib.lfa_bench_kernel(self.h, KERNELS[name], int(reps), C.byref(out)))
         return out.value
+
+    def bench_stream(self, nbytes=1 << 30, reps=10):
+        """(device-copy GB/s, read-only GB/s) measured on this device."""
+        c, r = C.c_double(0.0), C.c_double(0.0)
+        self._chk(self.lib.lfa_bench_stream(self.h, int(nbytes), int(reps), C.byref(c), C.byref(r)))
+        return c.value, r.value
 
     def counts(self):
         arr = (C.c_uint64 * 5)()

@@ -153,10 +153,10 @@ struct lfa_sim {
 
 	// timing
 	bool timing = false;
-	hipEvent_t ev[24];
+	hipEvent_t ev[48];  // 0-9, 16-18: lfa_step_hot; 20-21: lfa_bench_kernel; 24-..: lfa_time_step (LFA_ST_* boundaries)
 	bool ev_created = false;
 	double ms[LFA_NUM_TIMERS] = {0};
-	double ms_next[3] = {0, 0, 0};  // advect+collide, correct+collide, whole lfa_time_step
+	double ms_next[LFA_NUM_STEP_TIMERS] = {0};  // lfa_get_step_timings
 };
 
 // ---------------------------------------------------------------------------------------------------- error handling

@@ -1136,6 +1136,56 @@ extern "C" int lfa_cfl(lfa_sim *s, double *out) {
 	return LFA_OK;
 }
 
+// =============================================================================================== measured HBM ceiling
+__global__ void __launch_bounds__(256) k_stream_copy(const float4 *in, float4 *out, size_t n) {
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = in[i];
+}
+__global__ void __launch_bounds__(256) k_stream_read(const float4 *in, float *sink, size_t n) {
+	float acc = 0.f;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+		const float4 v = in[i];
+		acc += (v.x + v.y) + (v.z + v.w);
+	}
+	if (acc == 123.456f) sink[0] = acc;  // never true for the zero-filled buffer: keeps the loads alive
+}
+
+extern "C" int lfa_bench_stream(lfa_sim *s, uint64_t bytes, int reps, double *copy_gbs, double *read_gbs) {
+	if (!s || reps < 1 || bytes < (1u << 20)) return LFA_E_INVALID;
+	LFA_HIP(s, hipSetDevice(s->device));
+	const size_t n = (size_t)bytes / 16;
+	float4 *a = nullptr, *b = nullptr;
+	if (hipMalloc((void **)&a, n * 16) != hipSuccess || hipMalloc((void **)&b, n * 16) != hipSuccess) {
+		if (a) (void)hipFree(a);
+		return lfa_fail(s, LFA_E_OOM, "lfa_bench_stream: hipMalloc of 2 x %llu bytes failed", (unsigned long long)bytes);
+	}
+	hipEvent_t e0, e1;
+	LFA_HIP(s, hipEventCreate(&e0));
+	LFA_HIP(s, hipEventCreate(&e1));
+	LFA_HIP(s, hipMemsetAsync(a, 0, n * 16, s->stream));
+	LFA_HIP(s, hipMemsetAsync(b, 0, n * 16, s->stream));
+	const dim3 grid(256 * 16);  // 16 workgroups per CU, grid-stride
+	float ms = 0.f;
+	for (int pass = 0; pass < 2; ++pass) {
+		for (int r = -1; r < reps; ++r) {  // r == -1: warm-up
+			if (r == 0) LFA_HIP(s, hipEventRecord(e0, s->stream));
+			if (pass == 0) hipLaunchKernelGGL(k_stream_copy, grid, dim3(256), 0, s->stream, (const float4 *)a, b, n);
+			else hipLaunchKernelGGL(k_stream_read, grid, dim3(256), 0, s->stream, (const float4 *)a, (float *)b, n);
+		}
+		LFA_LAUNCH_CHECK(s);
+		LFA_HIP(s, hipEventRecord(e1, s->stream));
+		LFA_HIP(s, hipEventSynchronize(e1));
+		LFA_HIP(s, hipEventElapsedTime(&ms, e0, e1));
+		const double gbs = (double)(n * 16) * reps * (pass == 0 ? 2.0 : 1.0) / ((double)ms * 1e-3) * 1e-9;
+		if (pass == 0 && copy_gbs) *copy_gbs = gbs;
+		if (pass == 1 && read_gbs) *read_gbs = gbs;
+	}
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
+	(void)hipFree(a);
+	(void)hipFree(b);
+	return LFA_OK;
+}
+
 // =============================================================================================== timing / counts
 extern "C" int lfa_enable_timing(lfa_sim *s, int on) {
 	if (!s) return LFA_E_INVALID;

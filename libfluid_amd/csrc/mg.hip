@@ -58,6 +58,7 @@ struct lfa_mg_level {
 	void *b = nullptr, *x = nullptr, *y = nullptr;
 	size_t cap_tiles = 0;
 	int lo_layer = 0, hi_layer = 0;  // owned tile layers of this level (slabs: distributed levels only)
+	uint32_t *flag = nullptr, *prev_flag = nullptr;  // device, per tile of the level: active now / at the last set-up (single domain)
 };
 struct lfa_mg {
 	int n_levels = 0;
@@ -71,6 +72,7 @@ struct lfa_mg {
 	std::vector<int> host_top;    // active tiles of level n_dist (all ranks') the replicated lists were built for
 	uint8_t *l1_dirty = nullptr;  // device, per level-1 tile: a child tile was flagged at the last set-up (k_mg_types_from_fine_dirty)
 	unsigned solid_epoch = 0;     // solid mask the level-1 types were computed for
+	uint32_t *counts = nullptr;   // device, active tiles per level (single-domain set-up, read back once)
 };
 // A level stays distributed while no tile layer straddles a slab face, and its ghost types follow from the one fine ghost tile
 // layer a rank mirrors (8 cells = one slice of level 3).
@@ -191,6 +193,57 @@ __global__ void __launch_bounds__(256) k_mg_abits(const int *tiles, int n_tiles,
 		}
 	}
 }
+// ---- single domain: active-tile lists and neighbour tables of every level without a host round trip per level
+/// flag0[t] = tile t holds particles (slot table of the binning)
+__global__ void k_mg_flag_level0(const int *tile_pslot, uint32_t *flag, int nt) {
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t < nt) flag[t] = tile_pslot[t] >= 0 ? 1u : 0u;
+}
+/// a tile is active if one of its (up to 8) child tiles is
+__global__ void k_mg_flag_parents(GridDims gf, GridDims gc, const uint32_t *ff, uint32_t *fc) {
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= gc.nt) return;
+	int tx, ty, tz;
+	tile_coords(gc, t, tx, ty, tz);
+	uint32_t any = 0;
+	for (int k = 0; k < 8; ++k) {
+		const int cx = 2 * tx + (k & 1), cy = 2 * ty + ((k >> 1) & 1), cz = 2 * tz + (k >> 2);
+		if (cx < gf.ntx && cy < gf.nty && cz < gf.ntz) any |= ff[cx + gf.ntx * (cy + gf.nty * cz)];
+	}
+	fc[t] = any ? 1u : 0u;
+}
+__global__ void k_mg_compact(const uint32_t *flag, const uint32_t *scan, int *list, int nt) {
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t < nt && flag[t]) list[scan[t]] = t;
+}
+/// six face neighbours (tile id, -1: inactive or outside) + own id per slot
+__global__ void k_mg_build_nbr(const int *tiles, int n_tiles, GridDims g, const uint32_t *flag, int *nbr) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_tiles) return;
+	const int t = tiles[i], sy = g.ntx, sz = g.ntx * g.nty;
+	int tx, ty, tz;
+	tile_coords(g, t, tx, ty, tz);
+	const int cand[6] = {tx > 0 ? t - 1 : -1, tx + 1 < g.ntx ? t + 1 : -1, ty > 0 ? t - sy : -1,
+	                     ty + 1 < g.nty ? t + sy : -1, tz > 0 ? t - sz : -1, tz + 1 < g.ntz ? t + sz : -1};
+#pragma unroll
+	for (int k = 0; k < 6; ++k) nbr[i * MG_NBR_STRIDE + k] = (cand[k] >= 0 && flag[cand[k]]) ? cand[k] : -1;
+	nbr[i * MG_NBR_STRIDE + 6] = t;
+	nbr[i * MG_NBR_STRIDE + 7] = 0;
+}
+/// Vectors of levels >= 1 are read where no tile of this solve writes (parents of ring cells): a tile that has left the active
+/// set must not leave values behind. One workgroup per tile that was active at the last set-up and is not now.
+template <typename real>
+__global__ void __launch_bounds__(256)
+k_mg_clear_departed(const uint32_t *prev, const uint32_t *cur, int nt, real *x, real *b, real *y, uint8_t *abits) {
+	for (int t = blockIdx.x; t < nt; t += gridDim.x) {
+		if (!prev[t] || cur[t]) continue;
+		for (int l = threadIdx.x; l < 512; l += 256) {
+			const size_t c = (size_t)t * 512 + l;
+			x[c] = (real)0; b[c] = (real)0; y[c] = (real)0; abits[c] = 0;
+		}
+	}
+}
+
 // ------------------------------------------------------------------------------------------------ V-cycle kernels
 /// What a kernel needs to know about one level.
 template <typename real> struct MgLv {
@@ -933,11 +986,12 @@ bool mg_dist(const lfa_sim *s) { return s->dist && (s->dist->nranks > 1 || geten
 void lfa_mg_free(lfa_sim *s) {
 	if (!s->mg) return;
 	for (auto &L : s->mg->lv) {
-		void *ptrs[] = {L.tiles, L.nbr, L.ctype, L.abits, L.x, L.b, L.y};
+		void *ptrs[] = {L.tiles, L.nbr, L.ctype, L.abits, L.x, L.b, L.y, L.flag, L.prev_flag};
 		for (void *p : ptrs)
 			if (p) (void)hipFree(p);
 	}
 	if (s->mg->l1_dirty) (void)hipFree(s->mg->l1_dirty);
+	if (s->mg->counts) (void)hipFree(s->mg->counts);
 	delete s->mg;
 	s->mg = nullptr;
 }
@@ -964,7 +1018,7 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 	if (realloc_all) {
 		LFA_HIP(s, hipStreamSynchronize(s->stream));
 		for (auto &L : M.lv) {
-			void *ptrs[] = {L.tiles, L.nbr, L.ctype, L.abits, L.x, L.b, L.y};
+			void *ptrs[] = {L.tiles, L.nbr, L.ctype, L.abits, L.x, L.b, L.y, L.flag, L.prev_flag};
 			for (void *p : ptrs)
 				if (p) LFA_HIP(s, hipFree(p));
 			L = lfa_mg_level();
@@ -978,10 +1032,20 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 		M.l1_dirty = nullptr;
 		M.solid_epoch = 0;  // forces a full pass
 		if (nl > 1) LFA_HIP(s, hipMalloc(&M.l1_dirty, (size_t)gs[1].nt));
+		if (!M.counts) LFA_HIP(s, hipMalloc(&M.counts, MG_MAX_LEVELS * 4));
 		for (int l = 0; l < nl; ++l) {
 			lfa_mg_level &L = M.lv[l];
 			L.g = gs[l];
 			L.ncp = (size_t)gs[l].nt * 512;
+			if (!dist) {
+				// single domain: tile lists and neighbour tables are built on the device (mg_device_lists); sized for every tile
+				LFA_HIP(s, hipMalloc(&L.flag, (size_t)(gs[l].nt + 1) * 4));
+				LFA_HIP(s, hipMalloc(&L.prev_flag, (size_t)(gs[l].nt + 1) * 4));
+				LFA_HIP(s, hipMemsetAsync(L.prev_flag, 0, (size_t)(gs[l].nt + 1) * 4, s->stream));
+				LFA_HIP(s, hipMalloc(&L.tiles, (size_t)gs[l].nt * 4));
+				LFA_HIP(s, hipMalloc(&L.nbr, (size_t)gs[l].nt * MG_NBR_STRIDE * 4));
+				L.cap_tiles = (size_t)gs[l].nt;
+			}
 			if (l == 0) continue;
 			LFA_HIP(s, hipMalloc(&L.ctype, L.ncp));
 			LFA_HIP(s, hipMalloc(&L.abits, L.ncp));
@@ -989,6 +1053,12 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 			LFA_HIP(s, hipMalloc(&L.b, L.ncp * sizeof(real)));
 			LFA_HIP(s, hipMalloc(&L.y, L.ncp * sizeof(real)));
 			LFA_HIP(s, hipMemsetAsync(L.ctype, MT_SOLID, L.ncp, s->stream));
+			if (!dist) {  // the device path clears only what a departed tile leaves behind
+				LFA_HIP(s, hipMemsetAsync(L.x, 0, L.ncp * sizeof(real), s->stream));
+				LFA_HIP(s, hipMemsetAsync(L.b, 0, L.ncp * sizeof(real), s->stream));
+				LFA_HIP(s, hipMemsetAsync(L.y, 0, L.ncp * sizeof(real), s->stream));
+				LFA_HIP(s, hipMemsetAsync(L.abits, 0, L.ncp, s->stream));
+			}
 		}
 	}
 	for (int l = 0; l < nl; ++l) {
@@ -1007,91 +1077,138 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 			t1 = gs[l].nt;
 		}
 	};
-	// active tiles per level on the host: a tile is active if one of its child tiles is
-	const int n_all = dist ? s->n_ptiles_all : s->n_ptiles;
-	std::vector<int> tiles(n_all);  // slabs: with the neighbours' particle tiles of the adjacent layers (ascending ids all the same)
-	LFA_HIP(s, hipMemcpyAsync(tiles.data(), dist ? s->ptiles_all : s->ptiles, (size_t)n_all * 4, hipMemcpyDeviceToHost, s->stream));
-	LFA_HIP(s, hipStreamSynchronize(s->stream));
-	// The tile structure changes far less often than its contents: when the particle tiles are the ones of the last solve, the
-	// lists and neighbour tables on the device are kept (and no vector can hold values of a tile that has left the set).
-	bool same_tiles = !realloc_all && tiles == M.host_tiles;
-	std::vector<std::vector<int>> act(nl);
-	auto parents = [&](int l) {  // active tiles of level l from those of level l - 1
-		const GridDims &f = gs[l - 1], &c = gs[l];
-		std::vector<int> &o = act[l];
-		o.clear();
-		o.reserve(act[l - 1].size() / 4 + 8);
-		for (int t : act[l - 1]) {
-			int tx, ty, tz;
-			tile_coords(f, t, tx, ty, tz);
-			o.push_back((tx >> 1) + c.ntx * ((ty >> 1) + c.nty * (tz >> 1)));
-		}
-		std::sort(o.begin(), o.end());
-		o.erase(std::unique(o.begin(), o.end()), o.end());
-	};
-	if (dist || !same_tiles) {
-		if (dist) act[0].assign(tiles.begin() + s->p_off, tiles.begin() + s->p_off + s->n_ptiles);
-		else act[0] = tiles;
-		for (int l = 1; l < nl; ++l) {
-			parents(l);
-			if (dist && l == D) {
-				// the first replicated level: union of every rank's active tiles (one flag byte per tile, max all-reduce)
-				std::vector<uint8_t> flag((size_t)gs[l].nt, 0);
-				for (int t : act[l]) flag[t] = 1;
-				LFA_TRY(lfa_dist_ensure_xbuf(s, 0, flag.size()));
-				LFA_HIP(s, hipMemcpyAsync(s->xbuf[0], flag.data(), flag.size(), hipMemcpyHostToDevice, s->stream));
-				LFA_TRY(s->dist->allreduce_buf(s, s->xbuf[0], flag.size(), LFA_RED_U8, true));
-				LFA_HIP(s, hipMemcpyAsync(flag.data(), s->xbuf[0], flag.size(), hipMemcpyDeviceToHost, s->stream));
-				LFA_HIP(s, hipStreamSynchronize(s->stream));
-				act[l].clear();
-				for (int t = 0; t < gs[l].nt; ++t)
-					if (flag[t]) act[l].push_back(t);
-				same_tiles = same_tiles && act[l] == M.host_top;
-			}
-		}
-	}
-	if (!same_tiles) {
+	bool same_tiles = false;
+	if (!dist) {
+		// ---- single domain: flags -> scan -> compact per level on the device, ONE read-back of the counts, then the neighbour
+		// tables. (The host version below - download of the particle tiles, sorted parent lists, binary-searched neighbours,
+		// an upload per level - cost 2.8 ms per step at C4 once the dam moves and the tile set changes every step.)
+		hipLaunchKernelGGL(k_mg_flag_level0, dim3((gs[0].nt + 255) / 256), dim3(256), 0, s->stream, (const int *)s->tile_pslot,
+		                   M.lv[0].flag, gs[0].nt);
+		for (int l = 1; l < nl; ++l)
+			hipLaunchKernelGGL(k_mg_flag_parents, dim3((gs[l].nt + 255) / 256), dim3(256), 0, s->stream, gs[l - 1], gs[l],
+			                   (const uint32_t *)M.lv[l - 1].flag, M.lv[l].flag);
+		LFA_LAUNCH_CHECK(s);
 		for (int l = 0; l < nl; ++l) {
 			lfa_mg_level &L = M.lv[l];
-			const GridDims &g = gs[l];
-			const std::vector<int> &a = act[l];
-			L.n_tiles = (int)a.size();
-			if (a.size() > L.cap_tiles) {
-				if (L.tiles) LFA_HIP(s, hipFree(L.tiles));
-				if (L.nbr) LFA_HIP(s, hipFree(L.nbr));
-				L.tiles = L.nbr = nullptr;
-				L.cap_tiles = a.size() + a.size() / 4 + 16;
-				LFA_HIP(s, hipMalloc(&L.tiles, L.cap_tiles * 4));
-				LFA_HIP(s, hipMalloc(&L.nbr, L.cap_tiles * MG_NBR_STRIDE * 4));
+			if (l == 0) {  // the binning's own list
+				LFA_HIP(s, hipMemcpyAsync(L.tiles, s->ptiles, (size_t)s->n_ptiles * 4, hipMemcpyDeviceToDevice, s->stream));
+				continue;
 			}
-			if (a.empty()) continue;
-			// neighbour tiles by binary search in the sorted list. Across a slab face of a distributed level the neighbour belongs
-			// to another rank: on the finest level it is active if it is one of that rank's particle tiles, on the others it always
-			// counts as active (its slice arrives with the layer exchange; an inactive tile holds zeros and no unknowns)
-			std::vector<int> nbr(a.size() * MG_NBR_STRIDE, 0);
-			const int sy = g.ntx, sz = g.ntx * g.nty;
-			for (size_t i = 0; i < a.size(); ++i) {
-				int tx, ty, tz;
-				tile_coords(g, a[i], tx, ty, tz);
-				const int cand[6] = {tx > 0 ? a[i] - 1 : -1,           tx + 1 < g.ntx ? a[i] + 1 : -1, ty > 0 ? a[i] - sy : -1,
-				                     ty + 1 < g.nty ? a[i] + sy : -1, tz > 0 ? a[i] - sz : -1,          tz + 1 < g.ntz ? a[i] + sz : -1};
-				for (int k = 0; k < 6; ++k) {
-					int v = -1;
-					const int nz = tz + (k == 4 ? -1 : (k == 5 ? 1 : 0));
-					if (cand[k] < 0) v = -1;
-					else if (dist && l < D && (nz < L.lo_layer || nz >= L.hi_layer))
-						v = (l > 0 || std::binary_search(tiles.begin(), tiles.end(), cand[k])) ? cand[k] : -1;
-					else v = std::binary_search(a.begin(), a.end(), cand[k]) ? cand[k] : -1;
-					nbr[i * MG_NBR_STRIDE + k] = v;
-				}
-				nbr[i * MG_NBR_STRIDE + 6] = a[i];
-			}
-			LFA_HIP(s, hipMemcpyAsync(L.tiles, a.data(), a.size() * 4, hipMemcpyHostToDevice, s->stream));
-			LFA_HIP(s, hipMemcpyAsync(L.nbr, nbr.data(), nbr.size() * 4, hipMemcpyHostToDevice, s->stream));
-			LFA_HIP(s, hipStreamSynchronize(s->stream));  // the host vectors go out of scope
+			LFA_TRY(lfa_exclusive_scan_u32(s, L.flag, s->tile_scan, (size_t)gs[l].nt, M.counts + l));  // gs[l].nt <= nt / 8
+			hipLaunchKernelGGL(k_mg_compact, dim3((gs[l].nt + 255) / 256), dim3(256), 0, s->stream, (const uint32_t *)L.flag,
+			                   (const uint32_t *)s->tile_scan, L.tiles, gs[l].nt);
+			LFA_LAUNCH_CHECK(s);
 		}
-		M.host_tiles = tiles;
-		if (dist) M.host_top = act[D];
+		uint32_t *hc = s->h_pinned + 64;
+		if (nl > 1) {
+			LFA_HIP(s, hipMemcpyAsync(hc, M.counts, (size_t)nl * 4, hipMemcpyDeviceToHost, s->stream));
+			LFA_HIP(s, hipStreamSynchronize(s->stream));
+		}
+		for (int l = 0; l < nl; ++l) {
+			lfa_mg_level &L = M.lv[l];
+			L.n_tiles = l == 0 ? s->n_ptiles : (int)hc[l];
+			if (L.n_tiles) {
+				hipLaunchKernelGGL(k_mg_build_nbr, dim3((L.n_tiles + 255) / 256), dim3(256), 0, s->stream, (const int *)L.tiles, L.n_tiles,
+				                   gs[l], (const uint32_t *)L.flag, L.nbr);
+				LFA_LAUNCH_CHECK(s);
+			}
+			if (l >= 1) {
+				hipLaunchKernelGGL(k_mg_clear_departed<real>, dim3(std::min(gs[l].nt, 4096)), dim3(256), 0, s->stream,
+				                   (const uint32_t *)L.prev_flag, (const uint32_t *)L.flag, gs[l].nt, (real *)L.x, (real *)L.b, (real *)L.y,
+				                   L.abits);
+				LFA_LAUNCH_CHECK(s);
+			}
+			std::swap(L.flag, L.prev_flag);  // prev_flag = this set-up's set; flag is rewritten by the next one
+		}
+		same_tiles = true;  // nothing left for the host path / the whole-array clears below
+	}
+	// active tiles per level on the host: a tile is active if one of its child tiles is
+	if (dist) {
+		const int n_all = dist ? s->n_ptiles_all : s->n_ptiles;
+		std::vector<int> tiles(n_all);  // slabs: with the neighbours' particle tiles of the adjacent layers (ascending ids all the same)
+		LFA_HIP(s, hipMemcpyAsync(tiles.data(), dist ? s->ptiles_all : s->ptiles, (size_t)n_all * 4, hipMemcpyDeviceToHost, s->stream));
+		LFA_HIP(s, hipStreamSynchronize(s->stream));
+		// The tile structure changes far less often than its contents: when the particle tiles are the ones of the last solve, the
+		// lists and neighbour tables on the device are kept (and no vector can hold values of a tile that has left the set).
+		same_tiles = !realloc_all && tiles == M.host_tiles;
+		std::vector<std::vector<int>> act(nl);
+		auto parents = [&](int l) {  // active tiles of level l from those of level l - 1
+			const GridDims &f = gs[l - 1], &c = gs[l];
+			std::vector<int> &o = act[l];
+			o.clear();
+			o.reserve(act[l - 1].size() / 4 + 8);
+			for (int t : act[l - 1]) {
+				int tx, ty, tz;
+				tile_coords(f, t, tx, ty, tz);
+				o.push_back((tx >> 1) + c.ntx * ((ty >> 1) + c.nty * (tz >> 1)));
+			}
+			std::sort(o.begin(), o.end());
+			o.erase(std::unique(o.begin(), o.end()), o.end());
+		};
+		if (dist || !same_tiles) {
+			if (dist) act[0].assign(tiles.begin() + s->p_off, tiles.begin() + s->p_off + s->n_ptiles);
+			else act[0] = tiles;
+			for (int l = 1; l < nl; ++l) {
+				parents(l);
+				if (dist && l == D) {
+					// the first replicated level: union of every rank's active tiles (one flag byte per tile, max all-reduce)
+					std::vector<uint8_t> flag((size_t)gs[l].nt, 0);
+					for (int t : act[l]) flag[t] = 1;
+					LFA_TRY(lfa_dist_ensure_xbuf(s, 0, flag.size()));
+					LFA_HIP(s, hipMemcpyAsync(s->xbuf[0], flag.data(), flag.size(), hipMemcpyHostToDevice, s->stream));
+					LFA_TRY(s->dist->allreduce_buf(s, s->xbuf[0], flag.size(), LFA_RED_U8, true));
+					LFA_HIP(s, hipMemcpyAsync(flag.data(), s->xbuf[0], flag.size(), hipMemcpyDeviceToHost, s->stream));
+					LFA_HIP(s, hipStreamSynchronize(s->stream));
+					act[l].clear();
+					for (int t = 0; t < gs[l].nt; ++t)
+						if (flag[t]) act[l].push_back(t);
+					same_tiles = same_tiles && act[l] == M.host_top;
+				}
+			}
+		}
+		if (!same_tiles) {
+			for (int l = 0; l < nl; ++l) {
+				lfa_mg_level &L = M.lv[l];
+				const GridDims &g = gs[l];
+				const std::vector<int> &a = act[l];
+				L.n_tiles = (int)a.size();
+				if (a.size() > L.cap_tiles) {
+					if (L.tiles) LFA_HIP(s, hipFree(L.tiles));
+					if (L.nbr) LFA_HIP(s, hipFree(L.nbr));
+					L.tiles = L.nbr = nullptr;
+					L.cap_tiles = a.size() + a.size() / 4 + 16;
+					LFA_HIP(s, hipMalloc(&L.tiles, L.cap_tiles * 4));
+					LFA_HIP(s, hipMalloc(&L.nbr, L.cap_tiles * MG_NBR_STRIDE * 4));
+				}
+				if (a.empty()) continue;
+				// neighbour tiles by binary search in the sorted list. Across a slab face of a distributed level the neighbour belongs
+				// to another rank: on the finest level it is active if it is one of that rank's particle tiles, on the others it always
+				// counts as active (its slice arrives with the layer exchange; an inactive tile holds zeros and no unknowns)
+				std::vector<int> nbr(a.size() * MG_NBR_STRIDE, 0);
+				const int sy = g.ntx, sz = g.ntx * g.nty;
+				for (size_t i = 0; i < a.size(); ++i) {
+					int tx, ty, tz;
+					tile_coords(g, a[i], tx, ty, tz);
+					const int cand[6] = {tx > 0 ? a[i] - 1 : -1,           tx + 1 < g.ntx ? a[i] + 1 : -1, ty > 0 ? a[i] - sy : -1,
+					                     ty + 1 < g.nty ? a[i] + sy : -1, tz > 0 ? a[i] - sz : -1,          tz + 1 < g.ntz ? a[i] + sz : -1};
+					for (int k = 0; k < 6; ++k) {
+						int v = -1;
+						const int nz = tz + (k == 4 ? -1 : (k == 5 ? 1 : 0));
+						if (cand[k] < 0) v = -1;
+						else if (dist && l < D && (nz < L.lo_layer || nz >= L.hi_layer))
+							v = (l > 0 || std::binary_search(tiles.begin(), tiles.end(), cand[k])) ? cand[k] : -1;
+						else v = std::binary_search(a.begin(), a.end(), cand[k]) ? cand[k] : -1;
+						nbr[i * MG_NBR_STRIDE + k] = v;
+					}
+					nbr[i * MG_NBR_STRIDE + 6] = a[i];
+				}
+				LFA_HIP(s, hipMemcpyAsync(L.tiles, a.data(), a.size() * 4, hipMemcpyHostToDevice, s->stream));
+				LFA_HIP(s, hipMemcpyAsync(L.nbr, nbr.data(), nbr.size() * 4, hipMemcpyHostToDevice, s->stream));
+				LFA_HIP(s, hipStreamSynchronize(s->stream));  // the host vectors go out of scope
+			}
+			M.host_tiles = tiles;
+			if (dist) M.host_top = act[D];
+		}
 	}
 	// types and operators of the coarse levels
 	for (int l = 1; l < nl; ++l) {

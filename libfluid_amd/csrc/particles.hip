@@ -394,6 +394,14 @@ k_correct_tiled(const int *ptiles, int n_ptiles, ParticleSoA p, uint32_t *out_ke
 			const uint32_t j = __float_as_uint(sp.w);
 			const float tme[3] = {sp.x, sp.y, sp.z};  // exact fraction (the staged copy is block-relative)
 			const int c[3] = {cx, cy, cz};
+			// (Round 2, measured at C4 on a moving dam, 9.2 ms for this kernel: (a) per-particle pruning of cells and x-runs by
+			// their box distance - 92 instead of 216 candidates - with the nine runs of a lane flattened into one loop so that
+			// lanes do not wait for each other's runs: 62 ms, the divergent loop control costs more than the pairs it saves;
+			// (b) branch-free pairs (force computed unconditionally, kl clamped at 0, d^2 floored at 1e-12, coincidences detected
+			// by a side sum): 11.8 ms - PMC SQ_INSTS_VALU 6.5e9 against 4.1e9 for the branch: the lanes of a wave walk the same
+			// RELATIVE cell at the same time, and for the 20 corner and edge cells of the 27 no lane of the wave has a partner
+			// most of the time, so the branch does skip the force for the whole wave. The kernel is VALU bound either way: 74 % /
+			// 89 % of the SIMD cycles issue VALU instructions.)
 			// Every particle of a cell walks the same 3 x 3 x 3 cells, whole: the (up to 8) lanes of a cell then read the same LDS
 			// word at the same time. Skipping, per particle, the neighbour cells whose nearest face is beyond the kernel radius
 			// made the lanes of a cell read different words: the wave ran the longest trip count anyway and the LDS reads
@@ -545,6 +553,7 @@ extern "C" int lfa_correct_collide(lfa_sim *s, double dt) {
 	// deferred binning, where the other buffer still holds the v (and for APIC the C) that the P2G / G2P read: this buffer's
 	// own v.. (APIC: the G2P is yet to fill them) or the other buffer's c[0..3] (PIC / FLIP: its C has moved here already)
 	float4 *spos = (float4 *)(!s->vc_pending ? oth.v[0] : (s->vc_with_c ? cur.v[0] : oth.c[0]));
+	if (s->timing && n) LFA_HIP(s, hipEventRecord(s->ev[40], s->stream));
 	hipLaunchKernelGGL(k_build_cell_index, dim3(grid), dim3(256), 0, s->stream, s->dist ? s->ptiles_all : s->ptiles, n_index, cur.key,
 	                   cur.t[0], cur.t[1], cur.t[2], s->tile_start, s->tile_count, s->cell_start, spos, s->cell_count,
 	                   s->slab_lo * L, s->slab_hi * L);
@@ -561,10 +570,12 @@ extern "C" int lfa_correct_collide(lfa_sim *s, double dt) {
 			// every neighbour position comes from the cell-ordered records built above (the OLD positions), so the new ones
 			// are written in place; the fallback pass below selects its particles by their old keys
 			LFA_HIP(s, hipMemcpyAsync(oth.key, cur.key, n * 4, hipMemcpyDeviceToDevice, s->stream));
+			if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[41], s->stream));
 			hipLaunchKernelGGL(k_correct_tiled, dim3(g2), dim3(CORR_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, cur, cur.key, cur.t[0],
 			                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_flag, s->cell_count, s->cell_start, (const float4 *)spos,
 			                   move_params(s, dt), ovf);
 			LFA_LAUNCH_CHECK(s);
+			if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[42], s->stream));
 		}
 		hipLaunchKernelGGL(k_correct_collide, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, cur, cur.key, cur.t[0],
 		                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_flag, s->cell_count, s->cell_start, (const float4 *)spos,
@@ -583,20 +594,30 @@ extern "C" int lfa_time_step(lfa_sim *s, double dt, double *residual, uint64_t *
 	if (!s) return LFA_E_INVALID;
 	LFA_HIP(s, hipSetDevice(s->device));
 	const bool tm = s->timing;
-	if (tm) LFA_HIP(s, hipEventRecord(s->ev[10], s->stream));
+	// stage boundaries: ev[24 + k]
+	enum { B_START = 24, B_ADVECT, B_BIN, B_P2G, B_SOLVE, B_APPLY, B_CORRECT, B_EXTRAP, B_G2P };
+	auto rec = [&](int id) -> int {
+		if (tm) LFA_HIP(s, hipEventRecord(s->ev[id], s->stream));
+		return LFA_OK;
+	};
+	LFA_TRY(rec(B_START));
 	LFA_TRY(lfa_advect_collide(s, dt));
-	if (tm) LFA_HIP(s, hipEventRecord(s->ev[11], s->stream));
+	LFA_TRY(rec(B_ADVECT));
 	LFA_TRY(lfa_hash_particles(s));
+	LFA_TRY(rec(B_BIN));
 	LFA_TRY(lfa_p2g_run(s, true, dt));
+	LFA_TRY(rec(B_P2G));
 	double res = 0.0;
 	uint64_t it = 0;
 	int rc = lfa_pcg_solve(s, dt, &res, &it);
 	if (rc < 0) return rc;
+	LFA_TRY(rec(B_SOLVE));
 	LFA_TRY(lfa_apply_pressure(s, dt));
-	if (tm) LFA_HIP(s, hipEventRecord(s->ev[12], s->stream));
+	LFA_TRY(rec(B_APPLY));
 	LFA_TRY(lfa_correct_collide(s, dt));
-	if (tm) LFA_HIP(s, hipEventRecord(s->ev[13], s->stream));
+	LFA_TRY(rec(B_CORRECT));
 	LFA_TRY(lfa_extrapolate(s));  // the valid set is the one of the P2G-time hash, like the reference (:119)
+	LFA_TRY(rec(B_EXTRAP));
 	// The G2P gathers per tile. Single domain: the particles keep the order of the P2G-time binning and the few whose
 	// corrected position left their tile take the global-gather path (lfa_g2p_stale); like after lfa_advect_collide the
 	// order is stale afterwards and the next step re-bins. Slabs: re-bin first (arrivals from the neighbour ranks).
@@ -607,20 +628,49 @@ extern "C" int lfa_time_step(lfa_sim *s, double dt, double *residual, uint64_t *
 		LFA_TRY(lfa_g2p_stale(s));
 	}
 	if (tm) {
-		LFA_HIP(s, hipEventRecord(s->ev[14], s->stream));
-		LFA_HIP(s, hipEventSynchronize(s->ev[14]));
-		float ms = 0.f;
-		LFA_HIP(s, hipEventElapsedTime(&ms, s->ev[10], s->ev[11])); s->ms_next[0] = ms;  // advect + collide
-		LFA_HIP(s, hipEventElapsedTime(&ms, s->ev[12], s->ev[13])); s->ms_next[1] = ms;  // correct + collide
-		LFA_HIP(s, hipEventElapsedTime(&ms, s->ev[10], s->ev[14])); s->ms_next[2] = ms;  // whole step
+		LFA_TRY(rec(B_G2P));
+		LFA_HIP(s, hipEventSynchronize(s->ev[B_G2P]));
+		auto span = [&](int a, int b, double &out) -> int {
+			float ms = 0.f;
+			LFA_HIP(s, hipEventElapsedTime(&ms, s->ev[a], s->ev[b]));
+			out = ms;
+			return LFA_OK;
+		};
+		double *m = s->ms_next;
+		const bool solved = it || s->n_ptiles;  // ev[18] (end of the system build) is recorded inside a non-trivial solve
+		LFA_TRY(span(B_START, B_ADVECT, m[0]));
+		LFA_TRY(span(B_ADVECT, B_BIN, m[1]));
+		LFA_TRY(span(B_BIN, B_P2G, m[2]));
+		LFA_TRY(span(16, 17, m[3]));
+		if (solved) {
+			LFA_TRY(span(B_P2G, 18, m[4]));
+			LFA_TRY(span(18, B_SOLVE, m[5]));
+		} else {
+			LFA_TRY(span(B_P2G, B_SOLVE, m[4]));
+			m[5] = 0.0;
+		}
+		LFA_TRY(span(B_SOLVE, B_APPLY, m[6]));
+		if (s->np_live) {
+			LFA_TRY(span(40, 41, m[7]));
+			LFA_TRY(span(41, 42, m[8]));
+		} else {
+			m[7] = m[8] = 0.0;
+		}
+		LFA_TRY(span(B_APPLY, B_CORRECT, m[9]));
+		LFA_TRY(span(B_CORRECT, B_EXTRAP, m[10]));
+		LFA_TRY(span(B_EXTRAP, B_G2P, m[11]));
+		LFA_TRY(span(B_START, B_G2P, m[12]));
+		m[13] = (double)it;
+		m[14] = it ? m[5] / (double)it : 0.0;
+		m[15] = 0.0;
 	}
 	if (residual) *residual = res;
 	if (iterations) *iterations = it;
 	return rc;
 }
 
-extern "C" int lfa_get_step_timings(lfa_sim *s, double ms[3]) {
+extern "C" int lfa_get_step_timings(lfa_sim *s, double ms[LFA_NUM_STEP_TIMERS]) {
 	if (!s || !ms) return LFA_E_INVALID;
-	for (int k = 0; k < 3; ++k) ms[k] = s->ms_next[k];
+	for (int k = 0; k < LFA_NUM_STEP_TIMERS; ++k) ms[k] = s->ms_next[k];
 	return LFA_OK;
 }
