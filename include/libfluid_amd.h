@@ -170,16 +170,34 @@ int lfa_cfl(lfa_sim *s, double *out);
 int lfa_step_hot(lfa_sim *s, double dt, double *residual, uint64_t *iterations);
 
 /* -- the per-step particle stages around the hot path, device resident ----------------------------
- * lfa_advect_collide : simulation::_advect_particles (src/simulation.cpp:226-249, without fluid sources) fused with the
+ * lfa_advect_collide : simulation::_advect_particles (src/simulation.cpp:226-249, with the sources' velocity coercion) fused with the
  *                      _detect_collisions that follows it (:612-683, grid::march_cells grid.h:140-209; from = old position)
  * lfa_correct_collide: simulation::_correct_positions (:562-610) fused with the _detect_collisions after it (:114-117);
  *                      needs lfa_hash_particles of the current positions
  * lfa_time_step      : simulation::time_step(dt) (:43-125) entirely on the device: advect+collide, hash, P2G, gravity,
- *                      pressure solve, pressure gradient, correct+collide, extrapolate, hash, G2P. No sources, no callbacks
+ *                      pressure solve, pressure gradient, correct+collide, extrapolate, hash, G2P; sources included, no callbacks
  *                      (the host class falls back to stage calls when it needs them).
  * With a slab decomposition both move stages end with the particle migration: particles whose cell left the owned tile
  * layers are packed (68 B records) and handed to the neighbour rank, arrivals are appended; lfa_correct_collide first
  * fetches ghost copies (key + fraction) of the neighbours' adjacent tile layers, so pairs across a slab face interact. */
+/* Fluid sources: simulation::sources (include/fluid/simulation.h:179; include/fluid/data_structures/source.h:12-22) as the
+ * hosts fill them (testbed/main.cpp:141-165, plugins/maya/nodes/grid_node.cpp:295-303: flat int[3k] cell triples).
+ *   lfa_clear_sources / lfa_add_source : replace the list (sources keep their order: a later coercing source wins a cell, a
+ *                        later seeding source tops a cell up beyond an earlier one's target, exactly as the sequential
+ *                        loops of src/simulation.cpp:227-238 and :756-765 do)
+ *   lfa_update_sources : simulation::_update_sources (:756-765) + the hash_particles that follows it (:64): every cell of an
+ *                        active source is topped up to target_density_cubic_root^3 particles (seed_cell, :136-151: uniformly
+ *                        random positions inside the cell, the source's velocity, C = 0), counted by the last
+ *                        lfa_hash_particles. The positions come from a counter-based generator - the reference draws from
+ *                        its pcg32 member in an unspecified argument order, so parity is the particle count
+ *                        per cell and every non-random field. New particles get the next ids (download order).
+ * lfa_advect_collide applies the velocity coercion of _advect_particles (:227-238: velocity = the source's, C = 0 for every
+ * particle inside a cell of an active coercing source) before it moves the particles; lfa_time_step runs the seeding
+ * between its two binnings when a source is active. Not available with a slab decomposition. */
+int lfa_clear_sources(lfa_sim *s);
+int lfa_add_source(lfa_sim *s, const int32_t *xyz, uint64_t k, const double velocity[3], uint64_t target_density_cubic_root,
+                   int active, int coerce_velocity);
+int lfa_update_sources(lfa_sim *s, uint64_t *n_seeded);
 int lfa_advect_collide(lfa_sim *s, double dt);
 int lfa_correct_collide(lfa_sim *s, double dt);
 int lfa_time_step(lfa_sim *s, double dt, double *residual, uint64_t *iterations);

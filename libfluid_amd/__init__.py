@@ -129,6 +129,9 @@ SIGNATURES = {
     "lfa_mesher_upload_values": (_int, [_vp, _vp]),
     "lfa_mesher_marching_cubes": (_int, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "lfa_mesher_download_mesh": (_int, [_vp, _vp, _vp]),
+    "lfa_clear_sources": (_int, [_vp]),
+    "lfa_add_source": (_int, [_vp, _vp, _u64, _vp, _u64, _int, _int]),
+    "lfa_update_sources": (_int, [_vp, C.POINTER(_u64)]),
     "lfa_advect_collide": (_int, [_vp, _dbl]),
     "lfa_correct_collide": (_int, [_vp, _dbl]),
     "lfa_time_step": (_int, [_vp, _dbl, C.POINTER(_dbl), C.POINTER(_u64)]),
@@ -552,6 +555,22 @@ class Sim:
         return res.value, it.value, rc
 
     # -- particle stages around the hot path, full step ---------------------------------------------------
+    def clear_sources(self):
+        self._chk(self.lib.lfa_clear_sources(self.h))
+
+    def add_source(self, cells, velocity=(0.0, 0.0, 0.0), density_cubic_root=2, active=True, coerce_velocity=False):
+        """fluid::source (data_structures/source.h:12-22): cells as int32[k,3]."""
+        xyz = np.ascontiguousarray(cells, dtype=np.int32).reshape(-1, 3)
+        vel = np.asarray(velocity, dtype=np.float64)
+        self._chk(self.lib.lfa_add_source(self.h, _ptr(xyz), xyz.shape[0], _ptr(vel), int(density_cubic_root), int(active),
+                                          int(coerce_velocity)))
+
+    def update_sources(self):
+        """_update_sources + hash_particles (src/simulation.cpp:63-64); returns the number of particles created."""
+        n = C.c_uint64(0)
+        self._chk(self.lib.lfa_update_sources(self.h, C.byref(n)))
+        return n.value
+
     def advect_collide(self, dt):
         self._chk(self.lib.lfa_advect_collide(self.h, float(dt)))
 

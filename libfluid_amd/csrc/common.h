@@ -146,6 +146,30 @@ struct lfa_sim {
 	bool vc_with_c = false;                 // C is deferred as well (APIC); PIC / FLIP move C with the particle and defer v only
 	unsigned solid_epoch = 1;               // bumped whenever the solid mask changes (caches keyed on it: mg.hip)
 
+	// fluid sources (particles.hip): the host-side list as handed in, and its flattened device form (rebuilt when it changes)
+	struct SourceHost {
+		std::vector<int32_t> xyz;
+		double vel[3];
+		uint64_t root;
+		bool active, coerce;
+		bool operator==(const SourceHost &o) const {
+			return xyz == o.xyz && vel[0] == o.vel[0] && vel[1] == o.vel[1] && vel[2] == o.vel[2] && root == o.root &&
+			       active == o.active && coerce == o.coerce;
+		}
+	};
+	std::vector<SourceHost> sources, sources_built;
+	bool sources_valid = false;       // the device arrays below describe `sources`
+	uint32_t *src_cell = nullptr;     // [n_src_entries] blocked cell index of a seeding entry
+	uint32_t *src_lo = nullptr;       // count the entry tops up FROM: 0xFFFFFFFF = the binning's, else the previous entry's target
+	uint32_t *src_target = nullptr;   // target_density_cubic_root^3
+	uint32_t *src_of = nullptr;       // source index of the entry
+	uint32_t *src_need = nullptr;     // scratch: particles to create per entry, then their exclusive scan
+	float *src_vel = nullptr;         // [n sources][3]
+	size_t n_src_entries = 0, src_cap = 0;
+	uint8_t *coerce_map = nullptr;    // [ncp] 1 + index of the LAST active coercing source that lists the cell, 0: none
+	bool any_coerce = false;
+	uint64_t source_epoch = 0;        // counter of seeding calls: part of the counter-based generator's key
+
 	// boundary scratch
 	void *io_buf = nullptr;
 	size_t io_cap = 0;
@@ -252,3 +276,4 @@ int lfa_dist_ensure_xbuf(lfa_sim *s, int which, size_t bytes);
 int lfa_dist_migrate(lfa_sim *s);
 int lfa_dist_exchange_ghost_particles(lfa_sim *s);
 int lfa_particles_reserve(lfa_sim *s, size_t n_keep, size_t n_total);
+int lfa_sources_sync(lfa_sim *s);  // flattens `sources` to the device arrays if they changed (particles.hip)

@@ -8,6 +8,9 @@
 // the reference's (position - grid_offset) / cell_size.
 #include <math.h>
 
+#include <algorithm>
+#include <utility>
+
 #include "common.h"
 #include "pcg.h"
 
@@ -118,19 +121,37 @@ struct MoveParams {
 };
 
 /// _advect_particles (x += v dt, clamp to [skin, n - skin]) fused with _detect_collisions (from = the old position).
+/// COERCE: the velocity coercion of the fluid sources first (src/simulation.cpp:227-238): a particle inside a cell of an active
+/// coercing source takes the source's velocity and C = 0 (the cell is the particle's current one: the reference hashes at the
+/// start of the step, :49).
+template <bool COERCE>
 __global__ void __launch_bounds__(256)
-k_advect_collide(size_t n, ParticleSoA p, GridDims g, const uint8_t *solid, MoveParams mp) {
+k_advect_collide(size_t n, ParticleSoA p, GridDims g, const uint8_t *solid, MoveParams mp, const uint8_t *coerce_map,
+                 const float *src_vel) {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	if (p.key[i] == 0xFFFFFFFFu) return;  // outside this rank's slab (dropped at the next binning)
 	int c[3];
 	cell_of_key(g, p.key[i], c);
 	const int nn[3] = {g.nx, g.ny, g.nz};
+	float vel[3] = {p.v[0][i], p.v[1][i], p.v[2][i]};
+	if (COERCE) {
+		const uint32_t src = coerce_map[p.key[i]];
+		if (src) {
+#pragma unroll
+			for (int d = 0; d < 3; ++d) {
+				vel[d] = src_vel[3 * (src - 1) + d];
+				p.v[d][i] = vel[d];
+			}
+#pragma unroll
+			for (int k = 0; k < 9; ++k) p.c[k][i] = 0.0f;
+		}
+	}
 	double from[3], to[3];
 #pragma unroll
 	for (int d = 0; d < 3; ++d) {
 		from[d] = (double)c[d] + (double)p.t[d][i];
-		double x = from[d] + (double)p.v[d][i] * mp.dt_over_h;
+		double x = from[d] + (double)vel[d] * mp.dt_over_h;
 		const double lo = mp.skin, hi = (double)nn[d] - mp.skin;
 		to[d] = x < lo ? lo : (hi < x ? hi : x);
 	}
@@ -512,14 +533,214 @@ static MoveParams move_params(const lfa_sim *s, double dt) {
 	return mp;
 }
 
+
+// ===================================================================================================== fluid sources
+namespace {
+__global__ void k_mark_coerce(const uint32_t *cell, const uint32_t *src1, size_t n, uint8_t *map) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) map[cell[i]] = (uint8_t)src1[i];
+}
+/// seed_cell's `for (; num < target; ++num)` (src/simulation.cpp:144): particles an entry has to create, given the count of
+/// the last binning and what earlier entries of the same cell have already topped it up to.
+__global__ void k_source_need(const uint32_t *cell, const uint32_t *lo, const uint32_t *target, size_t n, const uint32_t *cell_count,
+                              const uint32_t *tile_flag, uint32_t *need) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t b = cell[i];
+	// first entry of the cell: the binning's count; later entries: the target the previous entry left in the hash (:150)
+	const uint32_t have = lo[i] != 0xFFFFFFFFu ? lo[i] : (tile_flag[b >> 9] ? cell_count[b] : 0u);
+	need[i] = target[i] > have ? target[i] - have : 0u;
+}
+__device__ inline uint64_t mix64(uint64_t x) {
+	x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+	x ^= x >> 27; x *= 0x94D049BB133111EBull;
+	x ^= x >> 31;
+	return x;
+}
+/// One workgroup-strided thread per seeding entry: position = cell + U[0,1)^3 (seed_cell :141-147), velocity = the source's.
+__global__ void k_source_seed(const uint32_t *cell, const uint32_t *src_of, const uint32_t *need, const uint32_t *off, size_t n,
+                              const float *src_vel, ParticleSoA p, size_t base, uint64_t seed) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t cnt = need[i], b = cell[i];
+	const float *vel = src_vel + 3 * src_of[i];
+	for (uint32_t j = 0; j < cnt; ++j) {
+		const size_t d = base + off[i] + j;
+		p.key[d] = b;
+#pragma unroll
+		for (int a = 0; a < 3; ++a) {
+			const uint64_t r = mix64(seed + ((uint64_t)b * 4096ull + (uint64_t)j * 3ull + (uint64_t)a + 1ull) * 0x9E3779B97F4A7C15ull);
+			float t = (float)(r >> 40) * (1.0f / 16777216.0f);  // 24 random bits: [0, 1)
+			p.t[a][d] = t;
+			p.v[a][d] = vel[a];
+		}
+#pragma unroll
+		for (int k = 0; k < 9; ++k) p.c[k][d] = 0.0f;
+		p.id[d] = (uint32_t)d;
+	}
+}
+}  // namespace
+
+extern "C" int lfa_clear_sources(lfa_sim *s) {
+	if (!s) return LFA_E_INVALID;
+	s->sources.clear();
+	s->sources_valid = false;
+	return LFA_OK;
+}
+
+extern "C" int lfa_add_source(lfa_sim *s, const int32_t *xyz, uint64_t k, const double velocity[3], uint64_t root, int active,
+                              int coerce_velocity) {
+	if (!s || (!xyz && k) || !velocity) return LFA_E_INVALID;
+	if (s->sources.size() >= 254) return lfa_fail(s, LFA_E_UNSUPPORTED, "more than 254 fluid sources");
+	if (root > 16) return lfa_fail(s, LFA_E_INVALID, "target_density_cubic_root %llu: more than 4096 particles per cell", (unsigned long long)root);
+	for (uint64_t i = 0; i < k; ++i)
+		if (!in_grid(s->g, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]))
+			return lfa_fail(s, LFA_E_INVALID, "source cell (%d, %d, %d) outside the grid", xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+	lfa_sim::SourceHost h;
+	h.xyz.assign(xyz, xyz + 3 * k);
+	for (int d = 0; d < 3; ++d) h.vel[d] = velocity[d];
+	h.root = root;
+	h.active = active != 0;
+	h.coerce = coerce_velocity != 0;
+	s->sources.push_back(std::move(h));
+	s->sources_valid = false;
+	return LFA_OK;
+}
+
+/// Flattens the source list for the kernels. Seeding entries keep the reference's sequential semantics: seed_cell ends with
+/// `_space_hash(cell).count = target` UNCONDITIONALLY (src/simulation.cpp:150), so the first entry of a cell tops it up from the
+/// count of the binning, and every later entry of the same cell from the previous entry's target (a static difference; an
+/// entry whose target does not exceed it creates nothing and is dropped). Coercion: the last active coercing source of a cell wins.
+int lfa_sources_sync(lfa_sim *s) {
+	if (s->sources_valid) return LFA_OK;
+	if (s->sources == s->sources_built && (s->sources.empty() || s->src_vel)) {  // the host re-sent the same list
+		s->sources_valid = true;
+		return LFA_OK;
+	}
+	if (s->dist && !s->sources.empty()) return lfa_fail(s, LFA_E_UNSUPPORTED, "fluid sources with a slab decomposition");
+	LFA_HIP(s, hipSetDevice(s->device));
+	std::vector<uint32_t> cell, lo, target, of, ccell, csrc;
+	std::vector<float> vel;
+	{
+		std::vector<std::pair<uint32_t, uint32_t>> seen;  // (cell, target of its latest entry), kept sorted by cell
+		std::vector<std::pair<uint32_t, uint32_t>> coerce;  // (cell, source + 1), last one wins
+		for (size_t si = 0; si < s->sources.size(); ++si) {
+			const auto &h = s->sources[si];
+			for (int d = 0; d < 3; ++d) vel.push_back((float)h.vel[d]);
+			if (!h.active) continue;
+			const uint32_t tgt = (uint32_t)(h.root * h.root * h.root);
+			for (size_t i = 0; i + 2 < h.xyz.size(); i += 3) {
+				const uint32_t b = blocked_index(s->g, h.xyz[i], h.xyz[i + 1], h.xyz[i + 2]);
+				auto it = std::lower_bound(seen.begin(), seen.end(), std::make_pair(b, 0u),
+				                           [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &c) { return a.first < c.first; });
+				if (it != seen.end() && it->first == b) {
+					const uint32_t prev = it->second;
+					it->second = tgt;
+					if (tgt > prev) {
+						cell.push_back(b); lo.push_back(prev); target.push_back(tgt); of.push_back((uint32_t)si);
+					}
+				} else {
+					seen.insert(it, std::make_pair(b, tgt));
+					cell.push_back(b); lo.push_back(0xFFFFFFFFu); target.push_back(tgt); of.push_back((uint32_t)si);
+				}
+				if (h.coerce) coerce.push_back(std::make_pair(b, (uint32_t)si + 1));
+			}
+		}
+		std::stable_sort(coerce.begin(), coerce.end(), [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &c) { return a.first < c.first; });
+		for (size_t i = 0; i < coerce.size(); ++i)
+			if (i + 1 == coerce.size() || coerce[i + 1].first != coerce[i].first) { ccell.push_back(coerce[i].first); csrc.push_back(coerce[i].second); }
+	}
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	const size_t n = cell.size(), need = std::max(n, ccell.size());
+	if (need > s->src_cap) {
+		void *old[] = {s->src_cell, s->src_lo, s->src_target, s->src_of, s->src_need};
+		for (void *q : old)
+			if (q) LFA_HIP(s, hipFree(q));
+		s->src_cap = need + need / 2 + 64;
+		LFA_HIP(s, hipMalloc(&s->src_cell, s->src_cap * 4));
+		LFA_HIP(s, hipMalloc(&s->src_lo, s->src_cap * 4));
+		LFA_HIP(s, hipMalloc(&s->src_target, s->src_cap * 4));
+		LFA_HIP(s, hipMalloc(&s->src_of, s->src_cap * 4));
+		LFA_HIP(s, hipMalloc(&s->src_need, 2 * (s->src_cap + 1) * 4));  // counts | their exclusive scan
+	}
+	if (s->src_vel) LFA_HIP(s, hipFree(s->src_vel));
+	s->src_vel = nullptr;
+	LFA_HIP(s, hipMalloc(&s->src_vel, (vel.size() + 3) * 4));
+	if (!vel.empty()) LFA_HIP(s, hipMemcpy(s->src_vel, vel.data(), vel.size() * 4, hipMemcpyHostToDevice));
+	// coercion map first (it borrows the entry arrays), then the seeding entries
+	const bool had_coerce = s->any_coerce;
+	s->any_coerce = !ccell.empty();
+	if (s->any_coerce || had_coerce) {
+		if (!s->coerce_map) LFA_HIP(s, hipMalloc(&s->coerce_map, s->ncp));
+		LFA_HIP(s, hipMemsetAsync(s->coerce_map, 0, s->ncp, s->stream));
+		if (s->any_coerce) {
+			LFA_HIP(s, hipMemcpyAsync(s->src_cell, ccell.data(), ccell.size() * 4, hipMemcpyHostToDevice, s->stream));
+			LFA_HIP(s, hipMemcpyAsync(s->src_of, csrc.data(), csrc.size() * 4, hipMemcpyHostToDevice, s->stream));
+			hipLaunchKernelGGL(k_mark_coerce, dim3((unsigned)((ccell.size() + 255) / 256)), dim3(256), 0, s->stream,
+			                   (const uint32_t *)s->src_cell, (const uint32_t *)s->src_of, ccell.size(), s->coerce_map);
+			LFA_LAUNCH_CHECK(s);
+		}
+		LFA_HIP(s, hipStreamSynchronize(s->stream));
+	}
+	if (n) {
+		LFA_HIP(s, hipMemcpy(s->src_cell, cell.data(), n * 4, hipMemcpyHostToDevice));
+		LFA_HIP(s, hipMemcpy(s->src_lo, lo.data(), n * 4, hipMemcpyHostToDevice));
+		LFA_HIP(s, hipMemcpy(s->src_target, target.data(), n * 4, hipMemcpyHostToDevice));
+		LFA_HIP(s, hipMemcpy(s->src_of, of.data(), n * 4, hipMemcpyHostToDevice));
+	}
+	s->n_src_entries = n;
+	s->sources_built = s->sources;
+	s->sources_valid = true;
+	return LFA_OK;
+}
+
+extern "C" int lfa_update_sources(lfa_sim *s, uint64_t *n_seeded) {
+	if (!s) return LFA_E_INVALID;
+	if (n_seeded) *n_seeded = 0;
+	if (!s->binned) return lfa_fail(s, LFA_E_INVALID, "lfa_update_sources: call lfa_hash_particles first");
+	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_sources_sync(s));
+	const size_t n = s->n_src_entries;
+	if (!n) return LFA_OK;
+	hipLaunchKernelGGL(k_source_need, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, (const uint32_t *)s->src_cell,
+	                   (const uint32_t *)s->src_lo, (const uint32_t *)s->src_target, n, (const uint32_t *)s->cell_count,
+	                   (const uint32_t *)s->tile_flag, s->src_need);
+	LFA_LAUNCH_CHECK(s);
+	// exclusive scan into the second half of the scratch; the total is read back (the host has to size the particle arrays)
+	uint32_t *off = s->src_need + s->src_cap + 1;
+	LFA_TRY(lfa_exclusive_scan_u32(s, s->src_need, off, n, off + n));
+	LFA_HIP(s, hipMemcpyAsync(s->h_pinned + 96, off + n, 4, hipMemcpyDeviceToHost, s->stream));
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	const size_t total = s->h_pinned[96];
+	if (!total) return LFA_OK;  // every source cell is full: the binning stands
+	if (s->np_live + total >= ((size_t)1 << 32)) return lfa_fail(s, LFA_E_INVALID, "more than 2^32 particles");
+	const size_t base = s->np_live;
+	LFA_TRY(lfa_particles_reserve(s, base, base + total));  // completes a deferred binning, keeps the live records
+	++s->source_epoch;
+	hipLaunchKernelGGL(k_source_seed, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, (const uint32_t *)s->src_cell,
+	                   (const uint32_t *)s->src_of, (const uint32_t *)s->src_need, (const uint32_t *)off, n, (const float *)s->src_vel,
+	                   s->pb[s->cur], base, 0x5EED50ull + s->source_epoch * 0x632BE59BD9B4E019ull);
+	LFA_LAUNCH_CHECK(s);
+	s->np_live = base + total;
+	s->np = s->np_live;
+	if (n_seeded) *n_seeded = total;
+	return lfa_hash_particles(s);  // the reference re-hashes after seeding (src/simulation.cpp:64)
+}
+
 extern "C" int lfa_advect_collide(lfa_sim *s, double dt) {
 	if (!s) return LFA_E_INVALID;
 	LFA_HIP(s, hipSetDevice(s->device));
 	LFA_TRY(lfa_particles_materialize(s));  // reads v
 	const size_t n = s->binned ? s->np_live : s->np;
+	LFA_TRY(lfa_sources_sync(s));
 	if (n) {
-		hipLaunchKernelGGL(k_advect_collide, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, s->pb[s->cur], s->g,
-		                   s->solid, move_params(s, dt));
+		const dim3 grid((unsigned)((n + 255) / 256));
+		if (s->any_coerce)
+			hipLaunchKernelGGL(k_advect_collide<true>, grid, dim3(256), 0, s->stream, n, s->pb[s->cur], s->g, s->solid, move_params(s, dt),
+			                   (const uint8_t *)s->coerce_map, (const float *)s->src_vel);
+		else
+			hipLaunchKernelGGL(k_advect_collide<false>, grid, dim3(256), 0, s->stream, n, s->pb[s->cur], s->g, s->solid, move_params(s, dt),
+			                   (const uint8_t *)nullptr, (const float *)nullptr);
 		LFA_LAUNCH_CHECK(s);
 	}
 	LFA_TRY(lfa_dist_migrate(s));
@@ -604,6 +825,7 @@ extern "C" int lfa_time_step(lfa_sim *s, double dt, double *residual, uint64_t *
 	LFA_TRY(lfa_advect_collide(s, dt));
 	LFA_TRY(rec(B_ADVECT));
 	LFA_TRY(lfa_hash_particles(s));
+	if (!s->sources.empty()) LFA_TRY(lfa_update_sources(s, nullptr));  // _update_sources + hash_particles (:63-64)
 	LFA_TRY(rec(B_BIN));
 	LFA_TRY(lfa_p2g_run(s, true, dt));
 	LFA_TRY(rec(B_P2G));

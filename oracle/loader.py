@@ -93,6 +93,10 @@ class _Lib:
             "detect_collisions": (None, [_vp]),
             "correct_positions": (None, [_vp, _dbl]),
             "time_step": (None, [_vp, _dbl, _vp, _vp]),
+            "clear_sources": (None, [_vp]),
+            "add_source": (None, [_vp, _vp, _sz, _vp, _sz, _int, _int]),
+            "update_sources": (None, [_vp]),
+            "update": (_sz, [_vp, _dbl, _vp, _sz]),
         }.items():
             fn = getattr(self.lib, prefix + name, None)
             if fn is not None:
@@ -243,6 +247,25 @@ class CpuSim:
 
     def cfl(self):
         return self.L.cfl(self.h)
+
+    # -- fluid sources, update() -------------------------------------------------------------------------------
+    def clear_sources(self):
+        self.L.clear_sources(self.h)
+
+    def add_source(self, cells, velocity=(0.0, 0.0, 0.0), density_cubic_root=2, active=True, coerce_velocity=False):
+        xyz = np.ascontiguousarray(cells, dtype=np.int32).reshape(-1, 3)
+        vel = np.asarray(velocity, dtype=np.float64)
+        self.L.add_source(self.h, _ptr(xyz), xyz.shape[0], _ptr(vel), int(density_cubic_root), int(active), int(coerce_velocity))
+
+    def update_sources(self):
+        """_update_sources + hash_particles (src/simulation.cpp:63-64)."""
+        self.L.update_sources(self.h)
+
+    def update(self, dt, cap=4096):
+        """simulation::update(dt): returns the lengths of the CFL sub-steps taken."""
+        dts = np.zeros(cap, dtype=np.float64)
+        n = self.L.update(self.h, float(dt), _ptr(dts), cap)
+        return dts[:min(n, cap)]
 
     def hot_step(self, dt):
         """hash -> p2g -> gravity -> solve -> apply -> extrapolate -> g2p; returns (p, residual, iters)."""

@@ -57,6 +57,11 @@ typedef struct {
 	uint8_t *abits;
 	double a_scale, *precon;
 	size_t nsys;
+
+	/* fluid sources (include/fluid/data_structures/source.h:12-22; simulation.h:179 `sources`) */
+	struct orc_source { int *xyz; size_t k; double vel[3]; size_t root; int active, coerce; } *src;
+	size_t nsrc;
+	uint64_t rng; /* seeding draws: splitmix64 state (the reference draws from its pcg32 member, simulation.h:177) */
 } orc_ctx;
 
 static size_t ncells(const orc_ctx *c) { return c->n[0] * c->n[1] * c->n[2]; }
@@ -84,7 +89,9 @@ void *orc_create(size_t nx, size_t ny, size_t nz, double h, const double *off, c
 void orc_destroy(void *h) {
 	orc_ctx *c = (orc_ctx *)h;
 	free(c->p); free(c->ptmp); free(c->grid); free(c->old_grid); free(c->hbegin); free(c->hcount);
-	free(c->fluid_raw); free(c->cell_to_unknown); free(c->fc); free(c->abits); free(c->precon); free(c);
+	free(c->fluid_raw); free(c->cell_to_unknown); free(c->fc); free(c->abits); free(c->precon);
+	for (size_t i = 0; i < c->nsrc; ++i) free(c->src[i].xyz);
+	free(c->src); free(c);
 }
 void orc_set_extrapolation_iterations(void *h, size_t n) { ((orc_ctx *)h)->extrap_iters = n; }
 void orc_set_pcg_params(void *h, double tau, double sigma, double tol, size_t maxit) {
@@ -669,9 +676,81 @@ void orc_hot_step(void *hh, double dt, double *p_out, double *residual, uint64_t
  * rest of this file: test infrastructure, pinned against oracle/_ref (tests/test_oracle.py).
  * ================================================================================================================= */
 
-/* simulation::_advect_particles src/simulation.cpp:226-249 (without fluid sources: no velocity coercion). */
+/* fluid sources: simulation::sources (include/fluid/simulation.h:179), data_structures/source.h:12-22. */
+void orc_clear_sources(void *hh) {
+	orc_ctx *c = (orc_ctx *)hh;
+	for (size_t i = 0; i < c->nsrc; ++i) free(c->src[i].xyz);
+	free(c->src);
+	c->src = NULL;
+	c->nsrc = 0;
+}
+void orc_add_source(void *hh, const int *xyz, size_t k, const double *vel, size_t root, int active, int coerce) {
+	orc_ctx *c = (orc_ctx *)hh;
+	c->src = (struct orc_source *)realloc(c->src, (c->nsrc + 1) * sizeof *c->src);
+	struct orc_source *s = &c->src[c->nsrc++];
+	s->xyz = (int *)malloc((k ? k : 1) * 12);
+	memcpy(s->xyz, xyz, k * 12);
+	s->k = k; s->root = root; s->active = active; s->coerce = coerce;
+	memcpy(s->vel, vel, 24);
+}
+static double orc_draw(orc_ctx *c) { /* U[0,1): splitmix64 */
+	uint64_t x = (c->rng += 0x9E3779B97F4A7C15ull);
+	x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+	return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+}
+/* simulation::seed_cell src/simulation.cpp:136-151: tops the cell up to density^3 particles at uniformly random positions
+ * inside it, velocity = the source's; the cell's count in the space hash becomes the target. The positions are random by
+ * design (the reference draws from pcg32 in an unspecified argument order): parity = counts and velocities. */
+static void orc_seed_cell(orc_ctx *c, size_t x, size_t y, size_t z, const double *vel, size_t dens) {
+	const size_t r = raw_of(c, x, y, z), target = dens * dens * dens;
+	size_t num = c->hcount[r];
+	for (; num < target; ++num) {
+		if (c->np == c->pcap) {
+			c->pcap = c->pcap ? 2 * c->pcap : 1024;
+			c->p = (orc_particle *)realloc(c->p, c->pcap * sizeof(orc_particle));
+			c->ptmp = (orc_particle *)realloc(c->ptmp, c->pcap * sizeof(orc_particle));
+		}
+		orc_particle *p = &c->p[c->np++];
+		memset(p, 0, sizeof *p);
+		const size_t cell[3] = {x, y, z};
+		for (int d = 0; d < 3; ++d) {
+			p->pos[d] = c->off[d] + (double)cell[d] * c->h + orc_draw(c) * c->h;
+			p->old_pos[d] = p->pos[d];
+			p->vel[d] = vel[d];
+		}
+		p->raw = r;
+	}
+	c->hcount[r] = target; /* unconditional, :150: a cell that held MORE than the target is recorded as holding the target, so a
+	                        * later source with a larger target tops it up from there (not from its real count) */
+}
+/* simulation::_update_sources src/simulation.cpp:756-765, followed by the hash_particles of time_step (:64). */
+void orc_update_sources(void *hh) {
+	orc_ctx *c = (orc_ctx *)hh;
+	for (size_t i = 0; i < c->nsrc; ++i) {
+		const struct orc_source *s = &c->src[i];
+		if (!s->active) continue;
+		for (size_t k = 0; k < s->k; ++k)
+			orc_seed_cell(c, (size_t)s->xyz[3 * k], (size_t)s->xyz[3 * k + 1], (size_t)s->xyz[3 * k + 2], s->vel, s->root);
+	}
+	orc_hash(c);
+}
+
+/* simulation::_advect_particles src/simulation.cpp:226-249: velocity coercion inside the cells of active coercing
+ * sources (by the space hash of the step's first hash), then x += v dt clamped to the skin. */
 void orc_advect(void *hh, double dt) {
 	orc_ctx *c = (orc_ctx *)hh;
+	for (size_t i = 0; i < c->nsrc; ++i) {
+		const struct orc_source *s = &c->src[i];
+		if (!s->active || !s->coerce) continue;
+		for (size_t k = 0; k < s->k; ++k) {
+			const size_t r = raw_of(c, (size_t)s->xyz[3 * k], (size_t)s->xyz[3 * k + 1], (size_t)s->xyz[3 * k + 2]);
+			orc_particle *q = c->p + c->hbegin[r];
+			for (uint64_t j = 0; j < c->hcount[r]; ++j, ++q) {
+				memcpy(q->vel, s->vel, 24);
+				memset(q->cx, 0, 72); /* cx = cy = cz = 0, :234 */
+			}
+		}
+	}
 	double lo[3], hi[3];
 	for (int d = 0; d < 3; ++d) {
 		lo[d] = c->off[d] + c->skin;
@@ -804,13 +883,14 @@ void orc_correct_positions(void *hh, double dt) {
 	free(moved);
 }
 
-/* simulation::time_step(dt) src/simulation.cpp:43-125 without sources and callbacks. */
+/* simulation::time_step(dt) src/simulation.cpp:43-125 without callbacks. */
 void orc_time_step(void *hh, double dt, double *residual, uint64_t *iters) {
 	orc_ctx *c = (orc_ctx *)hh;
 	orc_hash(c);
 	orc_advect(c, dt);
 	orc_detect_collisions(c);
 	orc_hash(c);
+	if (c->nsrc) orc_update_sources(c);
 	orc_p2g(c);
 	orc_add_gravity(c, dt);
 	double *p = (double *)malloc((c->nfluid ? c->nfluid : 1) * 8), res;
@@ -824,4 +904,20 @@ void orc_time_step(void *hh, double dt, double *residual, uint64_t *iters) {
 	if (residual) *residual = res;
 	if (iters) *iters = it;
 	free(p);
+}
+
+/* simulation::update(dt) src/simulation.cpp:31-41: CFL sub-stepping; returns the number of time steps, their lengths in dts. */
+size_t orc_update(void *hh, double dt, double *dts, size_t cap) {
+	orc_ctx *c = (orc_ctx *)hh;
+	size_t n = 0;
+	for (;;) {
+		const double ts = 3.0 * orc_cfl(c); /* cfl_number = 3, include/fluid/simulation.h:182 */
+		const double step = ts > dt ? dt : ts;
+		if (dts && n < cap) dts[n] = step;
+		++n;
+		orc_time_step(c, step, NULL, NULL);
+		if (ts > dt) break;
+		dt -= ts;
+	}
+	return n;
 }

@@ -269,6 +269,42 @@ extern "C" {
 	void ref_correct_positions(void *h, double dt) {
 		static_cast<ref_ctx*>(h)->sim._correct_positions(dt);
 	}
+	/// Fluid sources (include/fluid/data_structures/source.h:12-22), appended to simulation::sources (simulation.h:179).
+	void ref_clear_sources(void *h) {
+		static_cast<ref_ctx*>(h)->sim.sources.clear();
+	}
+	void ref_add_source(void *h, const int *xyz, std::size_t k, const double *vel, std::size_t root, int active, int coerce) {
+		auto src = std::make_unique<fluid::source>();
+		for (std::size_t i = 0; i < k; ++i) {
+			src->cells.emplace_back(vec3s(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]));
+		}
+		src->velocity = vec3d(vel[0], vel[1], vel[2]);
+		src->target_density_cubic_root = root;
+		src->active = active != 0;
+		src->coerce_velocity = coerce != 0;
+		static_cast<ref_ctx*>(h)->sim.sources.emplace_back(std::move(src));
+	}
+	/// simulation::_update_sources + the hash_particles that follows it in time_step (src/simulation.cpp:63-64,756-765).
+	void ref_update_sources(void *h) {
+		auto &sim = static_cast<ref_ctx*>(h)->sim;
+		sim._update_sources();
+		sim.hash_particles();
+	}
+	/// simulation::update(dt) (src/simulation.cpp:31-41): CFL sub-stepping. Returns the number of time steps taken and
+	/// writes up to `cap` of their lengths to `dts` (pre_time_step_callback, include/fluid/simulation.h:153).
+	std::size_t ref_update(void *h, double dt, double *dts, std::size_t cap) {
+		auto &sim = static_cast<ref_ctx*>(h)->sim;
+		std::size_t n = 0;
+		sim.pre_time_step_callback = [&](double step) {
+			if (dts && n < cap) {
+				dts[n] = step;
+			}
+			++n;
+		};
+		sim.update(dt);
+		sim.pre_time_step_callback = nullptr;
+		return n;
+	}
 	/// Full simulation::time_step(dt) (src/simulation.cpp:43-125); pressure/residual/iters of the step are
 	/// captured through post_pressure_solve_callback (include/fluid/simulation.h:166).
 	void ref_time_step(void *h, double dt, double *residual, std::uint64_t *iters) {
