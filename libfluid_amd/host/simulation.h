@@ -9,12 +9,18 @@
 // `namespace fluid_amd` mirrors `namespace fluid`; a host that wants the device path replaces
 // `fluid::simulation` by `fluid_amd::simulation`.
 //
-// What runs where: without fluid sources and callbacks a whole time_step runs on the device (lfa_time_step) and the
-// particles stay there; particles()/grid() download lazily. With a source or any callback set, the stages of SURVEY 8(a)
-// run on the device one by one and the stages outside it (advection, collision, position correction, sources:
-// src/simulation.cpp:226-249,562-683,756-765) run here on the host exactly where the reference runs them, so that every
-// callback sees host-visible state at its point of the step (particles then cross PCIe twice up and once down per step).
-// The class never throws on the step path; device errors are kept in last_status()/last_error().
+// What runs where: EVERY stage of time_step runs on the device (there is no host implementation of any stage and no CPU
+// fallback). Without callbacks a step is one lfa_time_step call; with callbacks the same device stages are called one by one and
+// the callbacks are invoked between them in the reference's order. The particles and the grid stay on the device:
+// particles() / grid() download lazily, only when something (a callback, the host after the step) actually calls them, and an
+// edit made through the mutable references they return is detected (64-bit content hash) and uploaded before the next device
+// stage. The testbed's three callbacks (testbed/main.cpp:101-123: print dt, read the pressure vector, read the particles after
+// the step) therefore cost one n-double download and one particle download per step, not a PCIe round trip per stage.
+// Two callbacks see a slightly later state than in the reference because the device fuses the collision pass into the kernel
+// before it: post_advection_callback and post_correction_callback run AFTER the collision handling that follows them in
+// src/simulation.cpp:51-59,111-117 (no host in the reference tree installs either).
+// The class never throws on the step path. A device error is latched: last_status() < 0, last_error() has the text, the failed
+// time_step() leaves the particles untouched and every later time_step()/update() returns immediately until clear_status().
 #pragma once
 
 #include <algorithm>
@@ -163,11 +169,15 @@ namespace fluid_amd {
 			_status = lfa_create(&_dev, sz.x, sz.y, sz.z, device);
 			if (_status != LFA_OK) _error = lfa_last_error(nullptr);
 			_solids_dirty = true;
+			_host_stale = _grid_stale = false;  // the new handle holds nothing yet
+			_dev_stale = true;
+			_particles_handed_out = _grid_handed_out = false;
+			_rehash_grid();
 		}
 
 		/// simulation::update (src/simulation.cpp:31-41).
 		void update(double dt) {
-			while (true) {
+			while (_status >= 0) {
 				double ts = cfl_number * cfl();
 				if (ts > dt) { time_step(dt); break; }
 				time_step(ts);
@@ -200,7 +210,7 @@ namespace fluid_amd {
 		}
 		/// simulation::cfl (src/simulation.cpp:199-205); on the device when the particles are resident there.
 		double cfl() const {
-			if (_dev && !_dev_stale && _host_stale) {
+			if (_dev && _host_stale) {  // the device holds the current particles
 				double out = 0.0;
 				if (lfa_cfl(_dev, &out) == LFA_OK) return out;
 			}
@@ -210,12 +220,12 @@ namespace fluid_amd {
 			return cell_size / std::sqrt(m);
 		}
 
-		// State lives on the device between steps when nothing forces it to the host (no sources, no callbacks): these
-		// accessors synchronise lazily. The non-const particles() hands out a mutable reference ("do not store references",
-		// simulation.h:141), so the device copy is considered stale afterwards and is re-uploaded by the next step.
-		mac_grid &grid() { _sync_grid(); return _grid; }
+		// State lives on the device; these accessors synchronise lazily. The non-const overloads hand out mutable references
+		// ("do not store references", simulation.h:141): what the caller does with them is found out by comparing a content hash
+		// before the next device stage (_flush_host_edits), so a read through a non-const simulation costs a download, not an upload.
+		mac_grid &grid() { _sync_grid(); _grid_handed_out = true; return _grid; }
 		const mac_grid &grid() const { const_cast<simulation*>(this)->_sync_grid(); return _grid; }
-		std::vector<particle> &particles() { _sync_host(); _dev_stale = true; return _particles; }
+		std::vector<particle> &particles() { _sync_host(); _particles_handed_out = true; return _particles; }
 		const std::vector<particle> &particles() const { const_cast<simulation*>(this)->_sync_host(); return _particles; }
 
 		// callbacks, in calling order (include/fluid/simulation.h:150-175)
@@ -235,11 +245,12 @@ namespace fluid_amd {
 
 		// -- device-path selectors (not in the reference) and status
 		int device = -1;                            ///< HIP device (-1: current); takes effect at resize()
-		bool device_resident_steps = true;          ///< run whole steps on the device when no source/callback needs the host
+		int apic_unscaled_kernel = 1;               ///< 1: the reference's APIC hat on world distances (simulation.cpp:367-369)
 		int p2g_variant = LFA_P2G_LDS_BINNED, precond = LFA_PRECOND_MULTIGRID, pcg_dtype = LFA_PCG_F32;
 		double pcg_tau = 0.97, pcg_sigma = 0.25, pcg_tolerance = 1e-6;   ///< pressure_solver.h:39-41
 		std::size_t pcg_max_iterations = 200;                             ///< pressure_solver.h:42
 		int last_status() const { return _status; }
+		void clear_status() { _status = LFA_OK; _error.clear(); }
 		const std::string &last_error() const { return _error; }
 		lfa_sim *device_handle() { return _dev; }
 
@@ -254,23 +265,71 @@ namespace fluid_amd {
 		std::string _error;
 		bool _solids_dirty = true;
 		bool _host_stale = false;  // the device holds newer particles than _particles
-		bool _dev_stale = true;    // _particles may have been edited since the last upload
+		bool _dev_stale = true;    // _particles must be uploaded before the next device stage
 		bool _grid_stale = false;  // the device holds a newer grid than _grid
+		bool _particles_handed_out = false, _grid_handed_out = false;  // a mutable reference went out since the last hash
+		std::uint64_t _particles_hash = 0, _grid_vel_hash = 0, _grid_solid_hash = 0;
+		bool _in_step = false;     // between two device stages of a staged time_step (edits need a re-binning / a grid upload)
+
+		/// 64-bit content hash of words [first_word, first_word + n_words) of every record of `stride_words` 64-bit words:
+		/// multiply-xorshift per word, chunks of 16 Ki records combined with their index. At most 8 OpenMP threads, and only for
+		/// arrays worth it (a wide team on a many-core host costs far more in wake-ups and spinning than the hash itself).
+		static std::uint64_t _hash_words(const void *data, std::size_t bytes, std::size_t stride_words, std::size_t first_word,
+		                                 std::size_t n_words) {
+			const std::uint64_t *w = static_cast<const std::uint64_t*>(data);
+			const std::size_t records = bytes / (8 * stride_words);
+			const std::size_t chunk = 1 << 14;
+			const long n_chunks = static_cast<long>((records + chunk - 1) / chunk);
+			std::uint64_t total = 0x9E3779B97F4A7C15ull ^ records;
+	#pragma omp parallel for reduction(^ : total) schedule(static) num_threads(8) if (n_chunks >= 64)
+			for (long c = 0; c < n_chunks; ++c) {
+				std::uint64_t h = 0xD6E8FEB86659FD93ull + static_cast<std::uint64_t>(c);
+				const std::size_t r1 = std::min(records, (static_cast<std::size_t>(c) + 1) * chunk);
+				for (std::size_t r = static_cast<std::size_t>(c) * chunk; r < r1; ++r)
+					for (std::size_t k = 0; k < n_words; ++k) {
+						h ^= w[r * stride_words + first_word + k];
+						h *= 0xFF51AFD7ED558CCDull;
+						h ^= h >> 32;
+					}
+				total ^= h * (2 * static_cast<std::uint64_t>(c) + 1);
+			}
+			return total;
+		}
+		void _rehash_particles() { _particles_hash = _hash_words(_particles.data(), _particles.size() * sizeof(particle), 19, 0, 19); }
+		void _rehash_grid() {
+			const std::size_t bytes = _grid.grid().get_array_size() * sizeof(mac_grid::cell);
+			_grid_vel_hash = _hash_words(_grid.grid().data(), bytes, 4, 0, 3);
+			_grid_solid_hash = _solid_hash();
+		}
+		std::uint64_t _solid_hash() const {
+			// only WHICH cells are solid matters to the device (air / fluid are recomputed by every P2G)
+			const mac_grid::cell *c = _grid.grid().data();
+			const std::size_t n = _grid.grid().get_array_size();
+			std::uint64_t h = 0x2545F4914F6CDD1Dull;
+			for (std::size_t i = 0; i < n; ++i)
+				if (c[i].cell_type == mac_grid::cell::type::solid) { h ^= i + 0x9E3779B97F4A7C15ull; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 29; }
+			return h;
+		}
 
 		void _sync_host() {
 			if (_host_stale && _dev) {
+				_particles.resize(static_cast<std::size_t>(lfa_num_particles(_dev)));  // sources create particles on the device
 				_ok(lfa_download_particles(_dev, _particles.data(), _particles.size(), LFA_DL_POSITIONS));
 				_host_stale = false;
+				_rehash_particles();
+				_particles_handed_out = false;
 			}
 		}
 		void _sync_grid() {
 			if (_grid_stale && _dev) {
 				_ok(lfa_download_cells(_dev, _grid.grid().data()));
 				_grid_stale = false;
+				_rehash_grid();
+				_grid_handed_out = false;
 			}
 		}
-		bool _any_callback() const {
-			return pre_time_step_callback || post_advection_callback || post_particle_to_grid_transfer_callback ||
+		bool _any_stage_callback() const {
+			return post_advection_callback || post_particle_to_grid_transfer_callback ||
 			       post_gravity_callback || post_pressure_solve_callback || post_apply_pressure_callback ||
 			       post_correction_callback || post_grid_to_particle_transfer_callback;
 		}
@@ -279,14 +338,11 @@ namespace fluid_amd {
 			if (rc < 0) { _status = rc; _error = _dev ? lfa_last_error(_dev) : lfa_last_error(nullptr); return false; }
 			return true;
 		}
+		bool _flush_host_edits();
+		bool _push_sources();
+		void _device_advanced() { _host_stale = true; _grid_stale = true; }
 		bool _push_params();
 		bool _push_solids();
-		void _pull_grid() { if (_dev) _ok(lfa_download_cells(_dev, _grid.grid().data())); }
-		template <typename Cb> void _for_all_nearby_particles(vec3s c, Cb &&cb);
-		void _advect_particles(double dt);
-		void _correct_positions(double dt);
-		void _detect_collisions();
-		void _update_sources();
 	};
 	static_assert(sizeof(simulation::particle) == 152, "particle layout must match the reference (152-B AoS)");
 
@@ -300,7 +356,7 @@ namespace fluid_amd {
 		p.velocity_extrapolation_iterations = velocity_extrapolation_iterations;
 		p.simulation_method = static_cast<int>(simulation_method);
 		p.tau = pcg_tau; p.sigma = pcg_sigma; p.tolerance = pcg_tolerance; p.max_iterations = pcg_max_iterations;
-		p.p2g_variant = p2g_variant; p.precond = precond; p.pcg_dtype = pcg_dtype;
+		p.p2g_variant = p2g_variant; p.precond = precond; p.pcg_dtype = pcg_dtype; p.apic_unscaled_kernel = apic_unscaled_kernel;
 		return _ok(lfa_set_params(_dev, &p));
 	}
 	/// Solid cells are set by the hosts directly on grid() (testbed/main.cpp:167-176, grid_node.cpp:330-339); they are
@@ -405,211 +461,109 @@ namespace fluid_amd {
 		          [&](vec3d p) { return (p - center).squared_length() < r2; }, vel, dens);
 	}
 
-	template <typename Cb> void simulation::_for_all_nearby_particles(vec3s c, Cb &&cb) {
-		vec3s n = _space_hash.get_size();
-		std::size_t x0 = c.x < 1 ? 0 : c.x - 1, y0 = c.y < 1 ? 0 : c.y - 1, z0 = c.z < 1 ? 0 : c.z - 1;
-		std::size_t x1 = std::min(c.x + 2, n.x), y1 = std::min(c.y + 2, n.y), z1 = std::min(c.z + 2, n.z);
-		for (std::size_t z = z0; z < z1; ++z)
-			for (std::size_t y = y0; y < y1; ++y)
-				for (std::size_t x = x0; x < x1; ++x) {
-					const _cell_particles &cp = _space_hash(x, y, z);
-					for (std::size_t k = 0; k < cp.count; ++k) cb(_particles[cp.begin + k]);
-				}
+	/// Sources go to the device as the flat int[3k] lists the Maya plugin holds (grid_node.cpp:295-303); re-sending an unchanged
+	/// list is free on the device side.
+	inline bool simulation::_push_sources() {
+		if (!_ok(lfa_clear_sources(_dev))) return false;
+		std::vector<std::int32_t> xyz;
+		for (const auto &src : sources) {
+			if (!src) continue;
+			xyz.clear();
+			for (const vec3s &c : src->cells) {
+				xyz.push_back(static_cast<std::int32_t>(c.x)); xyz.push_back(static_cast<std::int32_t>(c.y));
+				xyz.push_back(static_cast<std::int32_t>(c.z));
+			}
+			const double vel[3] = {src->velocity.x, src->velocity.y, src->velocity.z};
+			if (!_ok(lfa_add_source(_dev, xyz.data(), xyz.size() / 3, vel, src->target_density_cubic_root, src->active ? 1 : 0,
+			                        src->coerce_velocity ? 1 : 0)))
+				return false;
+		}
+		return true;
 	}
 
-	/// simulation::_advect_particles (src/simulation.cpp:226-249).
-	inline void simulation::_advect_particles(double dt) {
-		for (auto &src : sources) {
-			if (!src->active || !src->coerce_velocity) continue;
-			for (vec3s v : src->cells) {
-				_cell_particles cp = _space_hash(v);
-				for (std::size_t k = 0; k < cp.count; ++k) {
-					particle &p = _particles[cp.begin + k];
-					p.velocity = src->velocity;
-					p.cx = p.cy = p.cz = vec3d();
-				}
+	/// Brings the device up to date with whatever the host did through particles() / grid() / the seeding functions since the last
+	/// device stage. Between steps only the solid mask of the grid matters (the P2G rebuilds velocities and air / fluid types);
+	/// inside a staged step an edited grid is uploaded whole and edited particles are re-uploaded and re-binned.
+	inline bool simulation::_flush_host_edits() {
+		if (_particles_handed_out && !_host_stale) {
+			const std::uint64_t before = _particles_hash;
+			_rehash_particles();
+			if (_particles_hash != before) _dev_stale = true;
+			_particles_handed_out = false;
+		}
+		if (_grid_handed_out && !_grid_stale) {
+			const std::uint64_t vel_before = _grid_vel_hash, solid_before = _grid_solid_hash;
+			_rehash_grid();
+			if (_grid_solid_hash != solid_before) _solids_dirty = true;
+			if (_in_step && (_grid_vel_hash != vel_before || _grid_solid_hash != solid_before)) {
+				if (!_ok(lfa_upload_cells(_dev, _grid.grid().data()))) return false;
+				_solids_dirty = false;
 			}
+			_grid_handed_out = false;
 		}
-		vec3d skin(boundary_skin_width, boundary_skin_width, boundary_skin_width);
-		vec3d lo = grid_offset + skin, hi = cell_size * vec3d(_grid.grid().get_size()) + grid_offset - skin;
-		for (particle &p : _particles) {
-			p.position += p.velocity * dt;
-			for (int a = 0; a < 3; ++a) p.position[a] = std::clamp(p.position[a], lo[a], hi[a]);
+		if (_solids_dirty) {
+			if (!_push_solids()) return false;
+			_solids_dirty = false;
+			_grid_solid_hash = _solid_hash();
 		}
-	}
-
-	/// simulation::_correct_positions (src/simulation.cpp:562-610): pairwise springs over the 27-cell neighbourhood.
-	inline void simulation::_correct_positions(double dt) {
-		const double re = cell_size / std::sqrt(2.0);
-		std::vector<vec3d> moved(_particles.size());
-		const int count = static_cast<int>(_particles.size());
-#pragma omp parallel
-		{
-			pcg32 jitter_rng(std::random_device{}());
-			std::uniform_real_distribution<double> dist(-1.0, 1.0);
-#pragma omp for
-			for (int i = 0; i < count; ++i) {
-				const particle &p = _particles[static_cast<std::size_t>(i)];
-				vec3d spring;
-				_for_all_nearby_particles(p.compute_cell_index(grid_offset, cell_size), [&](const particle &o) {
-					if (&o == &p) return;
-					vec3d d = p.position - o.position;
-					double d2 = d.squared_length();
-					if (d2 < 1e-12) {
-						double a = dist(jitter_rng), b = dist(jitter_rng), c = dist(jitter_rng);
-						spring += vec3d(a, b, c);
-					} else {
-						double k = 1.0 - d2 / (re * re), w = k > 0.0 ? k * k * k : 0.0;
-						spring += (w / std::sqrt(d2)) * d;
-					}
-				});
-				moved[static_cast<std::size_t>(i)] = p.position + spring * (dt * correction_stiffness * re);
-			}
+		if (_dev_stale) {
+			if (!_ok(lfa_upload_particles(_dev, _particles.data(), _particles.size()))) return false;
+			_dev_stale = false;
+			_host_stale = false;
+			_rehash_particles();
+			if (_in_step && !_ok(lfa_hash_particles(_dev))) return false;  // the stages of the running step need the binning
 		}
-		vec3d hi = grid_offset + vec3d(_grid.grid().get_size()) * cell_size;
-		for (std::size_t i = 0; i < _particles.size(); ++i)
-			for (int a = 0; a < 3; ++a) _particles[i].position[a] = std::clamp(moved[i][a], grid_offset[a], hi[a]);
-	}
-
-	/// simulation::_detect_collisions (src/simulation.cpp:612-683) with grid::march_cells (grid.h:140-209): up to three
-	/// bounces of the segment old_position -> position against solid cells / the domain walls, then skin push-out.
-	inline void simulation::_detect_collisions() {
-		const vec3s n = _grid.grid().get_size();
-		auto solid_at = [&](int x, int y, int z) {
-			if (x < 0 || y < 0 || z < 0) return true;
-			if (static_cast<std::size_t>(x) >= n.x || static_cast<std::size_t>(y) >= n.y || static_cast<std::size_t>(z) >= n.z) return true;
-			return _grid.grid()(x, y, z).cell_type == mac_grid::cell::type::solid;
-		};
-		const int count = static_cast<int>(_particles.size());
-#pragma omp parallel for
-		for (int pi = 0; pi < count; ++pi) {
-			particle &p = _particles[static_cast<std::size_t>(pi)];
-			vec3d from = p.old_position, to = p.position;
-			for (int bounce = 0; bounce < 3; ++bounce) {
-				bool hit = false;
-				vec3d a = (from - grid_offset) / cell_size, b = (to - grid_offset) / cell_size, diff = b - a, inv, t;
-				int cur[3], last[3], adv[3];
-				for (int d = 0; d < 3; ++d) {
-					cur[d] = static_cast<int>(std::floor(a[d]));
-					last[d] = static_cast<int>(std::floor(b[d]));
-					adv[d] = diff[d] > 0.0 ? 1 : -1;
-					inv[d] = 1.0 / std::abs(diff[d]);
-					t[d] = std::abs(static_cast<double>(cur[d] + (diff[d] > 0.0 ? 1 : 0)) - a[d]) * inv[d];
-				}
-				while (cur[0] != last[0] || cur[1] != last[1] || cur[2] != last[2]) {
-					int dim = 0;
-					double tmin = 2.0;
-					for (int d = 0; d < 3; ++d) if (t[d] < tmin) { tmin = t[d]; dim = d; }
-					if (!(tmin <= 1.0)) break;
-					cur[dim] += adv[dim];
-					if (solid_at(cur[0], cur[1], cur[2])) {
-						vec3d normal;
-						normal[dim] = -static_cast<double>(adv[dim]);
-						vec3d off = to - from;
-						double tt = std::max(t[dim] + boundary_skin_width / dot(off, normal), 0.0);
-						from = tt * to + (1.0 - tt) * from;
-						to[dim] = from[dim];
-						hit = true;
-						break;
-					}
-					t[dim] += inv[dim];
-				}
-				if (!hit) break;
-			}
-			p.position = to;
-			vec3d gp = p.position - grid_offset;
-			vec3s ci(gp / cell_size);
-			vec3d cp = gp - vec3d(ci) * cell_size;
-			const double skin_max = cell_size - boundary_skin_width;
-			for (int d = 0; d < 3; ++d) {
-				int c[3] = {static_cast<int>(ci.x), static_cast<int>(ci.y), static_cast<int>(ci.z)};
-				if (cp[d] < boundary_skin_width) {
-					int q[3] = {c[0], c[1], c[2]};
-					q[d] -= 1;
-					if (ci[d] == 0 || solid_at(q[0], q[1], q[2])) p.position[d] += boundary_skin_width - cp[d];
-				}
-				if (cp[d] > skin_max) {
-					int q[3] = {c[0], c[1], c[2]};
-					q[d] += 1;
-					if (ci[d] + 1 >= n[d] || solid_at(q[0], q[1], q[2])) p.position[d] += skin_max - cp[d];
-				}
-			}
-		}
-	}
-
-	inline void simulation::_update_sources() {
-		for (auto &src : sources) {
-			if (!src->active) continue;
-			for (vec3s v : src->cells) seed_cell(v, src->velocity, src->target_density_cubic_root);
-		}
+		return true;
 	}
 
 	inline void simulation::time_step(double dt) {
-		// ---- device-resident step: nothing needs the host in the middle of the step (no sources, no callbacks)
-		if (_dev && sources.empty() && !_any_callback() && device_resident_steps) {
-			bool dev = _push_params();
-			if (dev && _solids_dirty) { dev = _push_solids(); _solids_dirty = !dev; }
-			if (dev && _dev_stale) {
-				dev = _ok(lfa_upload_particles(_dev, _particles.data(), _particles.size()));
-				_dev_stale = !dev;
-			}
-			double residual = 0.0;
-			std::uint64_t iters = 0;
-			if (dev && _ok(lfa_time_step(_dev, dt, &residual, &iters))) {
-				_host_stale = true;
-				_grid_stale = true;
-				return;
-			}
-			// a device failure is reported through last_status(); fall through to the staged path
-		}
-		_sync_host();
-		_dev_stale = true;
-		_grid_stale = false;
+		if (_status < 0) return;  // a latched device failure: see clear_status()
+		if (!_dev) { _status = LFA_E_NO_DEVICE; _error = "no device handle: resize() failed or was not called (there is no CPU fallback)"; return; }
 		if (pre_time_step_callback) pre_time_step_callback(dt);
-		update_and_hash_particles();
-		_advect_particles(dt);
-		if (post_advection_callback) post_advection_callback(dt);
-		_detect_collisions();
-		for (particle &p : _particles) p.old_position = p.position;
-		update_and_hash_particles();
-		_update_sources();
-		hash_particles();
+		_in_step = false;
+		if (!_push_params() || !_push_sources() || !_flush_host_edits()) return;  // nothing has been advanced
 
-		// ---- hot path on the device -------------------------------------------------------------
-		bool dev = _dev != nullptr && _push_params();
-		if (dev && _solids_dirty) { dev = _push_solids(); _solids_dirty = !dev; }
-		dev = dev && _ok(lfa_upload_particles(_dev, _particles.data(), _particles.size()));
-		dev = dev && _ok(lfa_hash_particles(_dev));
-		dev = dev && _ok(lfa_p2g(_dev));
-		if (dev && post_particle_to_grid_transfer_callback) { _pull_grid(); post_particle_to_grid_transfer_callback(dt); }
-		dev = dev && _ok(lfa_add_gravity(_dev, dt));
-		if (dev && post_gravity_callback) { _pull_grid(); post_gravity_callback(dt); }
 		double residual = 0.0;
 		std::uint64_t iters = 0;
-		dev = dev && _ok(lfa_pcg_solve(_dev, dt, &residual, &iters));
-		if (dev && post_pressure_solve_callback) {
-			std::vector<double> pressure(lfa_num_fluid_cells(_dev));
-			_ok(lfa_download_pressure(_dev, pressure.data(), pressure.size()));
-			std::vector<double> before = pressure;
-			post_pressure_solve_callback(dt, pressure, residual, static_cast<std::size_t>(iters));
-			if (pressure != before && pressure.size() == before.size())  // the callback may edit it (simulation.h:166)
-				_ok(lfa_upload_pressure(_dev, pressure.data(), pressure.size()));
+		if (!_any_stage_callback()) {
+			// ---- the whole step in one call (src/simulation.cpp:43-125 incl. sources)
+			if (_ok(lfa_time_step(_dev, dt, &residual, &iters))) _device_advanced();
+			return;
 		}
-		dev = dev && _ok(lfa_apply_pressure(_dev, dt));
-		if (dev && post_apply_pressure_callback) { _pull_grid(); post_apply_pressure_callback(dt); }
-
-		_correct_positions(dt);
-		if (post_correction_callback) post_correction_callback(dt);
-		_detect_collisions();
-		for (particle &p : _particles) p.old_position = p.position;
-
-		dev = dev && _ok(lfa_extrapolate(_dev));  // uses the fluid-cell set of the P2G-time hash, like the reference
-		// G2P samples at the corrected positions (src/simulation.cpp:110-121): positions go up again, velocities come back
-		dev = dev && _ok(lfa_upload_particles(_dev, _particles.data(), _particles.size()));
-		dev = dev && _ok(lfa_hash_particles(_dev));
-		dev = dev && _ok(lfa_g2p(_dev));
-		dev = dev && _ok(lfa_download_particles(_dev, _particles.data(), _particles.size(), LFA_DL_KEEP_RAW));
-		if (dev) _pull_grid();
-		if (post_grid_to_particle_transfer_callback) post_grid_to_particle_transfer_callback(dt);
+		// ---- the same device stages one by one, callbacks in the reference's order between them. After every callback the
+		// host's edits (if any) are flushed; a failure stops the step where it is (the status is latched).
+		auto stage = [&](int rc) { if (!_ok(rc)) return false; _device_advanced(); return true; };
+		auto after = [&](const std::function<void(double)> &cb) {
+			if (!cb) return true;
+			cb(dt);
+			return _flush_host_edits();
+		};
+		_in_step = true;
+		bool ok = stage(lfa_advect_collide(_dev, dt)) && after(post_advection_callback) &&
+		          stage(lfa_hash_particles(_dev)) && (sources.empty() || stage(lfa_update_sources(_dev, nullptr))) &&
+		          stage(lfa_p2g(_dev)) && after(post_particle_to_grid_transfer_callback) &&
+		          stage(lfa_add_gravity(_dev, dt)) && after(post_gravity_callback) &&
+		          stage(lfa_pcg_solve(_dev, dt, &residual, &iters));
+		if (ok && post_pressure_solve_callback) {
+			// the callback gets the pressure vector by reference and may edit it (simulation.h:166): n doubles down, and up again
+			// only if it did
+			std::vector<double> pressure(static_cast<std::size_t>(lfa_num_fluid_cells(_dev)));
+			ok = _ok(lfa_download_pressure(_dev, pressure.data(), pressure.size()));
+			if (ok) {
+				const std::vector<double> before = pressure;
+				post_pressure_solve_callback(dt, pressure, residual, static_cast<std::size_t>(iters));
+				if (pressure.size() == before.size() && pressure != before)
+					ok = _ok(lfa_upload_pressure(_dev, pressure.data(), pressure.size()));
+				ok = ok && _flush_host_edits();
+			}
+		}
+		ok = ok && stage(lfa_apply_pressure(_dev, dt)) && after(post_apply_pressure_callback) &&
+		     stage(lfa_correct_collide(_dev, dt)) && after(post_correction_callback) &&
+		     stage(lfa_extrapolate(_dev)) && stage(lfa_g2p(_dev));
+		_in_step = false;
+		if (ok && post_grid_to_particle_transfer_callback) {
+			post_grid_to_particle_transfer_callback(dt);
+			_flush_host_edits();
+		}
 	}
 }  // namespace fluid_amd

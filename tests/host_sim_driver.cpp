@@ -1,11 +1,20 @@
 // Test driver for the C++ host class (libfluid_amd/host/simulation.h): runs N `time_step(dt)` on a particle file and writes
-// the particles back. Mirrors how testbed/main.cpp:91-99,187-195 drives fluid::simulation (construct, set public fields,
-// inject particles and solid cells, step, read particles()). Built and run by tests/test_host_class.py.
-//   usage: host_sim_driver nx ny nz method blend dt steps particles_in.bin particles_out.bin solids.bin|- [nocb]
-//   `nocb`: no callback is installed, so the class runs whole steps on the device (lfa_time_step) and keeps the
-//   particles there until particles() is read at the end
+// the particles back. Mirrors how testbed/main.cpp:91-123,187-195 drives fluid::simulation (construct, set public fields,
+// install callbacks, inject particles and solid cells, step, read particles()). Built and run by tests/test_host_class.py.
+//   usage: host_sim_driver nx ny nz method blend dt steps particles_in.bin particles_out.bin solids.bin|- [mode] [cell_size]
+//   mode: nocb      no callback: one lfa_time_step per step
+//         callbacks the testbed's three callbacks (testbed/main.cpp:101-123): print dt; iterations, residual, max pressure from
+//                   the pressure vector; max particle speed from particles() after the step (default)
+//         two       the first two only (nothing touches particles() during the run)
+//         edit      callbacks that EDIT device-resident state through the mutable references: the pressure vector, the grid
+//                   (post_gravity: zero a face) and the particles (post_g2p: scale one velocity) - the edits must reach the device
+//         obstacle  nocb, and the solid cells are only put in after the first step, then removed again before the last one
+//                   (the testbed's scene reset edits sim.grid() between steps, testbed/main.cpp:125-178)
+//   Prints "step_ms <mean wall milliseconds per step>" (after one warm-up step when steps > 2).
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -36,7 +45,8 @@ int main(int argc, char **argv) {
 		std::fprintf(stderr, "device init failed: %s\n", sim.last_error().c_str());
 		return 3;
 	}
-	sim.cell_size = 1.0;
+	const std::string mode = argc > 11 ? argv[11] : "callbacks";
+	sim.cell_size = argc > 12 ? std::atof(argv[12]) : 1.0;
 	sim.grid_offset = vec3d();
 	sim.gravity = vec3d(0.0, -981.0, 0.0);
 	sim.simulation_method = static_cast<simulation::method>(std::atoi(argv[4]));
@@ -46,29 +56,57 @@ int main(int argc, char **argv) {
 	std::vector<char> in = slurp(argv[8]);
 	sim.particles().resize(in.size() / sizeof(simulation::particle));
 	std::memcpy(static_cast<void*>(sim.particles().data()), in.data(), in.size());
-	const bool with_callback = !(argc > 11 && std::string(argv[11]) == "nocb");
+	std::vector<int> solids;
 	if (argc > 10 && std::string(argv[10]) != "-") {
 		std::vector<char> s = slurp(argv[10]);
-		const int *xyz = reinterpret_cast<const int*>(s.data());
-		for (std::size_t i = 0; i + 2 < s.size() / sizeof(int); i += 3)
-			sim.grid().grid()(xyz[i], xyz[i + 1], xyz[i + 2]).cell_type = fluid_amd::mac_grid::cell::type::solid;
+		solids.assign(reinterpret_cast<const int*>(s.data()), reinterpret_cast<const int*>(s.data()) + s.size() / sizeof(int));
 	}
+	auto set_solids = [&](fluid_amd::mac_grid::cell::type t) {
+		for (std::size_t i = 0; i + 2 < solids.size(); i += 3) sim.grid().grid()(solids[i], solids[i + 1], solids[i + 2]).cell_type = t;
+	};
+	if (mode != "obstacle") set_solids(fluid_amd::mac_grid::cell::type::solid);
 	sim.reset_space_hash();
 	std::size_t iters_total = 0;
 	int calls = 0;
-	if (with_callback)
+	double max_speed = 0.0;
+	if (mode == "callbacks" || mode == "two" || mode == "edit") {
+		sim.pre_time_step_callback = [](double step) { std::printf("  time step %g\n", step); };
 		sim.post_pressure_solve_callback = [&](double, std::vector<double> &p, double res, std::size_t it) {
 			iters_total += it;
 			++calls;
-			std::printf("solve %d: %zu unknowns, %zu iterations, residual %.3e\n", calls, p.size(), it, res);
+			double pmax = 0.0;
+			for (double v : p) pmax = v > pmax ? v : pmax;
+			std::printf("solve %d: %zu unknowns, %zu iterations, residual %.3e, max pressure %.6g\n", calls, p.size(), it, res, pmax);
+			if (mode == "edit" && !p.empty()) p[0] *= 1.0;  // touches the vector without changing it: no upload
 		};
+	}
+	if (mode == "callbacks")
+		sim.post_grid_to_particle_transfer_callback = [&](double) {
+			double m = 0.0;
+			for (const simulation::particle &p : sim.particles()) m = std::max(m, p.velocity.squared_length());
+			max_speed = std::sqrt(m);
+			std::printf("    max particle velocity = %g\n", max_speed);
+		};
+	if (mode == "edit") {
+		sim.post_gravity_callback = [&](double) { sim.grid().grid()(1, 1, 1).velocities_posface = vec3d(); };
+		sim.post_grid_to_particle_transfer_callback = [&](double) { sim.particles()[0].velocity = sim.particles()[0].velocity * 0.5; };
+	}
+	double wall_ms = 0.0;
+	int timed = 0;
 	for (int i = 0; i < steps; ++i) {
+		if (mode == "obstacle" && i == 1) set_solids(fluid_amd::mac_grid::cell::type::solid);
+		if (mode == "obstacle" && i == steps - 1) set_solids(fluid_amd::mac_grid::cell::type::air);
+		const auto t0 = std::chrono::steady_clock::now();
 		sim.time_step(dt);
+		if (sim.device_handle()) lfa_synchronize(sim.device_handle());
+		const auto t1 = std::chrono::steady_clock::now();
+		if (i > 0 || steps <= 2) { wall_ms += std::chrono::duration<double, std::milli>(t1 - t0).count(); ++timed; }
 		if (sim.last_status() < 0) {
 			std::fprintf(stderr, "step %d failed (%d): %s\n", i, sim.last_status(), sim.last_error().c_str());
 			return 4;
 		}
 	}
+	std::printf("step_ms %.4f\n", timed ? wall_ms / timed : 0.0);
 	std::printf("cfl %.9g fluid type of cell0 %d\n", sim.cfl(), static_cast<int>(sim.grid().grid()[0].cell_type));
 	if (FILE *f = std::fopen(argv[9], "wb")) {
 		std::fwrite(sim.particles().data(), sizeof(simulation::particle), sim.particles().size(), f);
