@@ -521,6 +521,325 @@ k_correct_tiled(const int *ptiles, int n_ptiles, ParticleSoA p, uint32_t *out_ke
 	}
 }
 
+
+// ------------------------------------------------------------------------------------------------ fine-cell variant
+// The pair tests of k_correct_tiled are VALU bound and cannot get cheaper per pair (PMC: 74 % of the SIMD cycles issue VALU,
+// ~13 instructions per candidate with packed fp32), so the lever is the number of candidates: the 27 CELLS around a particle
+// hold 216 of them for 12 partners, because a cell (1) is wider than the kernel radius re = 0.7071 cells needs. Here the halo
+// block is re-sorted, in LDS, by FINE cells of 0.72 cells: the 27 fine cells around a particle hold 27 x 8 x 0.72^3 = 81
+// candidates. Lanes are own particles in fine-cell order, so the lanes of a fine cell still walk the same ranges together
+// (broadcast LDS reads, shared trip counts) - the property per-particle pruning of cells loses (see k_correct_tiled).
+#define FINE_S 0.72f
+#define FINE_INV_S (1.0f / 0.72f)
+#define FINE_R 0.7072f                          // particles farther than this from the own region cannot be partners
+#define FINE_NX 14                              // ceil(10 / 0.72)
+#define FINE_NZ (((CORR_ZT + 2) * 100 + 71) / 72)  // ceil((CORR_ZT + 2) / 0.72)
+#define FINE_N (FINE_NX * FINE_NX * FINE_NZ)
+#define FINE_CAP 4608                           // staged particles (the needed region holds 3840 at 8 per cell)
+#define FINE_PER_THREAD ((FINE_N + CORR_THREADS - 1) / CORR_THREADS)
+#define FINE_RAW_PER_THREAD 11                  // particles of the whole 10 x 10 x (CORR_ZT + 2) block per thread: 5632 in all
+
+__global__ void __launch_bounds__(CORR_THREADS, 4)
+k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx, float *out_ty, float *out_tz, GridDims g,
+               const uint8_t *solid, const uint32_t *tile_flag, const uint32_t *cell_count, const uint32_t *cell_start,
+               const float4 *spos, MoveParams mp, uint32_t *overflow_tiles) {
+	__shared__ float px[FINE_CAP], py[FINE_CAP], pz[FINE_CAP];
+	__shared__ uint16_t hk[FINE_CAP];            // (halo cell << 6 | index in the cell) of the staged particle
+	__shared__ uint32_t fcnt[FINE_N];            // per fine cell: count, then running cursor; afterwards the own list (u16)
+	__shared__ uint16_t foff[FINE_N + 1];        // first staged slot of every fine cell
+	__shared__ uint32_t gstart[CORR_HCELLS];
+	__shared__ uint16_t ccnt[CORR_HCELLS];
+	__shared__ uint32_t wsum[CORR_THREADS / 64], n_bad;
+	uint16_t *own = (uint16_t *)fcnt;            // FINE_N * 2 >= CORR_OWN entries
+	static_assert(FINE_N * 2 >= CORR_OWN, "own list does not fit the cursor array");
+	const int nn[3] = {g.nx, g.ny, g.nz};
+	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+	auto fine_of = [](float x, float y, float z) -> int {
+		int fx = (int)(x * FINE_INV_S), fy = (int)(y * FINE_INV_S), fz = (int)(z * FINE_INV_S);
+		fx = fx < FINE_NX - 1 ? fx : FINE_NX - 1; fy = fy < FINE_NX - 1 ? fy : FINE_NX - 1; fz = fz < FINE_NZ - 1 ? fz : FINE_NZ - 1;
+		return fx + FINE_NX * (fy + FINE_NX * fz);
+	};
+	for (int work = blockIdx.x; work < CORR_PARTS * n_ptiles; work += gridDim.x) {
+		const int tile = ptiles[work / CORR_PARTS], half = work % CORR_PARTS;
+		int tx, ty, tz;
+		tile_coords(g, tile, tx, ty, tz);
+		const int ox = tx * 8 - 1, oy = ty * 8 - 1, oz = tz * 8 + CORR_ZT * half - 1;  // origin of the halo block
+		__syncthreads();
+		// ---- the halo cells: where their particles sit in the cell-ordered records
+		for (int h = threadIdx.x; h < CORR_HCELLS; h += CORR_THREADS) {
+			uint32_t cnt = 0, st = 0;
+			const int x = ox + h % 10, y = oy + (h / 10) % 10, z = oz + h / 100;
+			if (in_grid(g, x, y, z)) {
+				const uint32_t b = blocked_index(g, x, y, z);
+				if (tile_flag[b >> 9]) {
+					cnt = cell_count[b];
+					st = cnt ? cell_start[b] : 0;
+				}
+			}
+			gstart[h] = st;
+			ccnt[h] = (uint16_t)(cnt < 65535u ? cnt : 65535u);
+		}
+		for (int f = threadIdx.x; f < FINE_N; f += CORR_THREADS) fcnt[f] = 0;
+		if (threadIdx.x == 0) n_bad = 0;
+		__syncthreads();
+		// ---- the raw particle list of the halo block: (cell, index) of its r-th particle, so that the loads below can be spread
+		// evenly over the threads and issued together. (A loop per cell - a thread walking its cell's records one after the
+		// other - waited for a dependent HBM/L2 round trip per particle: the staging was a third of the kernel.)
+		uint16_t *rawhk = (uint16_t *)px;  // consumed before px is written
+		static_assert(sizeof(float) * FINE_CAP >= 2 * FINE_RAW_PER_THREAD * CORR_THREADS, "raw list does not fit");
+		uint32_t craw = 0;
+		{
+			// exclusive scan of the cell counts (thread t owns cells CORR_CPT t .. CORR_CPT t + CORR_CPT - 1)
+			uint32_t c3[CORR_CPT], sum0 = 0;
+#pragma unroll
+			for (int k = 0; k < CORR_CPT; ++k) {
+				const int h = CORR_CPT * threadIdx.x + k;
+				c3[k] = h < CORR_HCELLS ? ccnt[h] : 0u;
+				if (c3[k] > 63) atomicAdd(&n_bad, 1u);  // does not fit the (cell, index) packing: the fallback kernel takes the block
+				sum0 += c3[k];
+			}
+			uint32_t inc0 = sum0;
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) {
+				uint32_t t = __shfl_up(inc0, o, 64);
+				if (lane >= o) inc0 += t;
+			}
+			if (lane == 63) wsum[wid] = inc0;
+			__syncthreads();
+			uint32_t woff0 = 0;
+			for (int w = 0; w < CORR_THREADS / 64; ++w) {
+				if (w < wid) woff0 += wsum[w];
+				craw += wsum[w];
+			}
+			__syncthreads();  // wsum is reused below
+			if (craw > FINE_RAW_PER_THREAD * CORR_THREADS || n_bad) {  // uniform
+				if (threadIdx.x == 0) atomicOr(&overflow_tiles[work >> 5], 1u << (work & 31));
+				continue;
+			}
+			uint32_t r = woff0 + inc0 - sum0;
+#pragma unroll
+			for (int k = 0; k < CORR_CPT; ++k) {
+				const int h = CORR_CPT * threadIdx.x + k;
+				for (uint32_t i = 0; i < c3[k]; ++i) rawhk[r++] = (uint16_t)((h << 6) | i);
+			}
+		}
+		__syncthreads();
+		// ---- pass 1 over the records: fine-cell histogram of the particles that can be partners of an own particle. The loads of a
+		// thread are independent and issued in batches; only the packed (fine cell, cell, index) word of each survives to pass 2
+		// (keeping the positions in registers across the scan took 163 VGPRs: one workgroup per CU instead of two).
+		const float zhi = (float)(1 + CORR_ZT) + FINE_R;
+		uint32_t rinfo[FINE_RAW_PER_THREAD];  // fine cell << 16 | (cell << 6 | index); 0xFFFFFFFF: not staged
+		auto staged_pos = [&](uint32_t e, const float4 &sp, float &x, float &y, float &z) -> bool {
+			const int h = (int)(e >> 6);
+			// in-cell fractions are kept below 1 (a particle ON the max face is stored with t == 1): it stays in its cell's box
+			x = (float)(h % 10) + fminf(sp.x, 0.99999994f);
+			y = (float)((h / 10) % 10) + fminf(sp.y, 0.99999994f);
+			z = (float)(h / 100) + fminf(sp.z, 0.99999994f);
+			return x >= 1.0f - FINE_R && x < 9.0f + FINE_R && y >= 1.0f - FINE_R && y < 9.0f + FINE_R && z >= 1.0f - FINE_R && z < zhi;
+		};
+#pragma unroll
+		for (int i = 0; i < FINE_RAW_PER_THREAD; ++i) {
+			const uint32_t r = threadIdx.x + CORR_THREADS * i;
+			rinfo[i] = 0xFFFFFFFFu;
+			if (r < craw) {
+				const uint32_t e = rawhk[r];
+				float x, y, z;
+				if (staged_pos(e, spos[gstart[e >> 6] + (e & 63u)], x, y, z)) {
+					const uint32_t f = (uint32_t)fine_of(x, y, z);
+					rinfo[i] = (f << 16) | e;
+					atomicAdd(&fcnt[f], 1u);
+				}
+			}
+		}
+		__syncthreads();
+		// ---- exclusive scan over the fine cells
+		uint32_t c4[FINE_PER_THREAD], sum = 0;
+#pragma unroll
+		for (int k = 0; k < FINE_PER_THREAD; ++k) {
+			const int f = FINE_PER_THREAD * threadIdx.x + k;
+			c4[k] = f < FINE_N ? fcnt[f] : 0u;
+			sum += c4[k];
+		}
+		uint32_t incl = sum;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			uint32_t t = __shfl_up(incl, o, 64);
+			if (lane >= o) incl += t;
+		}
+		if (lane == 63) wsum[wid] = incl;
+		__syncthreads();
+		uint32_t woff = 0, total = 0;
+		for (int w = 0; w < CORR_THREADS / 64; ++w) {
+			if (w < wid) woff += wsum[w];
+			total += wsum[w];
+		}
+		if (total > FINE_CAP) {  // uniform
+			if (threadIdx.x == 0) atomicOr(&overflow_tiles[work >> 5], 1u << (work & 31));
+			continue;
+		}
+		uint32_t ex = woff + incl - sum;
+#pragma unroll
+		for (int k = 0; k < FINE_PER_THREAD; ++k) {
+			const int f = FINE_PER_THREAD * threadIdx.x + k;
+			if (f < FINE_N) {
+				foff[f] = (uint16_t)ex;
+				fcnt[f] = ex;  // cursor
+			}
+			ex += c4[k];
+		}
+		if (threadIdx.x == 0) foff[FINE_N] = (uint16_t)total;
+		__syncthreads();  // (the raw list in px has been consumed by every thread)
+		// ---- pass 2: scatter into fine-cell order (the records come from L2 this time)
+#pragma unroll
+		for (int i = 0; i < FINE_RAW_PER_THREAD; ++i)
+			if (rinfo[i] != 0xFFFFFFFFu) {
+				const uint32_t e = rinfo[i] & 0xFFFFu;
+				float x, y, z;
+				staged_pos(e, spos[gstart[e >> 6] + (e & 63u)], x, y, z);
+				const uint32_t slot = atomicAdd(&fcnt[rinfo[i] >> 16], 1u);
+				px[slot] = x; py[slot] = y; pz[slot] = z;
+				hk[slot] = (uint16_t)e;
+			}
+		__syncthreads();
+		// ---- own particles (those of the 8 x 8 x CORR_ZT interior cells) in slot order = fine-cell order
+		constexpr int SPT = (FINE_CAP + CORR_THREADS - 1) / CORR_THREADS;  // slots per thread
+		auto is_own = [&](uint32_t slot) -> bool {
+			const int h = hk[slot] >> 6, hx = h % 10, hy = (h / 10) % 10, hz = h / 100;
+			return hx >= 1 && hx <= 8 && hy >= 1 && hy <= 8 && hz >= 1 && hz <= CORR_ZT;
+		};
+		uint32_t mine = 0;
+		for (int k = 0; k < SPT; ++k) {
+			const uint32_t slot = SPT * threadIdx.x + k;
+			if (slot < total && is_own(slot)) ++mine;
+		}
+		incl = mine;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			uint32_t t = __shfl_up(incl, o, 64);
+			if (lane >= o) incl += t;
+		}
+		if (lane == 63) wsum[wid] = incl;
+		__syncthreads();  // (also: every cursor read of pass 2 is done before `own` overwrites the array)
+		woff = 0;
+		uint32_t own_total = 0;
+		for (int w = 0; w < CORR_THREADS / 64; ++w) {
+			if (w < wid) woff += wsum[w];
+			own_total += wsum[w];
+		}
+		if (own_total > CORR_OWN) {  // uniform
+			if (threadIdx.x == 0) atomicOr(&overflow_tiles[work >> 5], 1u << (work & 31));
+			continue;
+		}
+		uint32_t at = woff + incl - mine;
+		for (int k = 0; k < SPT; ++k) {
+			const uint32_t slot = SPT * threadIdx.x + k;
+			if (slot < total && is_own(slot)) own[at++] = (uint16_t)slot;
+		}
+		__syncthreads();
+		// ---- one thread per own particle
+		for (uint32_t w = threadIdx.x; w < own_total; w += CORR_THREADS) {
+			const uint32_t me = own[w];
+			const float mx = px[me], my = py[me], mz = pz[me];
+			const int hc = hk[me] >> 6;
+			const float4 sp = spos[gstart[hc] + (hk[me] & 63u)];
+			const uint32_t j = __float_as_uint(sp.w);
+			const float tme[3] = {sp.x, sp.y, sp.z};  // exact fraction (the staged copy is block-relative)
+			const int c[3] = {ox + hc % 10, oy + (hc / 10) % 10, oz + hc / 100};
+			int fx = (int)(mx * FINE_INV_S), fy = (int)(my * FINE_INV_S), fz = (int)(mz * FINE_INV_S);
+			fx = fx < FINE_NX - 1 ? fx : FINE_NX - 1; fy = fy < FINE_NX - 1 ? fy : FINE_NX - 1; fz = fz < FINE_NZ - 1 ? fz : FINE_NZ - 1;
+			const int xa = fx > 0 ? fx - 1 : 0, xb = fx + 1 < FINE_NX ? fx + 1 : FINE_NX - 1;
+			float sx = 0.f, sy = 0.f, sz = 0.f;
+			typedef float f2 __attribute__((ext_vector_type(2)));
+			f2 s2x = 0.f, s2y = 0.f, s2z = 0.f;
+			const float inv_re2 = (float)mp.inv_re2;
+			auto pair2 = [&](uint32_t q, f2 qx, f2 qy, f2 qz) {
+				const f2 dx = mx - qx, dy = my - qy, dz = mz - qz;
+				const f2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+				const f2 kl = __builtin_elementwise_fma(-d2, (f2)inv_re2, (f2)1.0f);
+				if (kl.x > 0.0f || kl.y > 0.0f) {
+					if (d2.x < 1e-12f || d2.y < 1e-12f) {
+						// coincident (or the particle itself): the reference adds a random unit-box vector (:584-587)
+#pragma unroll
+						for (int k = 0; k < 2; ++k) {
+							const float d2k = k ? d2.y : d2.x, klk = k ? kl.y : kl.x;
+							if (!(klk > 0.0f)) continue;
+							if (d2k < 1e-12f) {
+								if (q + k != me) { sx += hash_unit(j, q + k, 0); sy += hash_unit(j, q + k, 1); sz += hash_unit(j, q + k, 2); }
+							} else {
+								const float f = klk * klk * klk * rsqrtf(d2k);
+								sx += f * (k ? dx.y : dx.x); sy += f * (k ? dy.y : dy.x); sz += f * (k ? dz.y : dz.x);
+							}
+						}
+					} else {
+						const f2 klp = __builtin_elementwise_max(kl, (f2)0.0f);
+						f2 f = klp * klp * klp;
+						f.x *= rsqrtf(d2.x);
+						f.y *= rsqrtf(d2.y);
+						s2x = __builtin_elementwise_fma(f, dx, s2x);
+						s2y = __builtin_elementwise_fma(f, dy, s2y);
+						s2z = __builtin_elementwise_fma(f, dz, s2z);
+					}
+				}
+			};
+			auto pair = [&](uint32_t q, float qx, float qy, float qz) {
+				const float dx = mx - qx, dy = my - qy, dz = mz - qz;
+				const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+				const float kl = __builtin_fmaf(-d2, inv_re2, 1.0f);
+				if (kl > 0.0f) {
+					if (d2 < 1e-12f) {
+						if (q != me) { sx += hash_unit(j, q, 0); sy += hash_unit(j, q, 1); sz += hash_unit(j, q, 2); }
+					} else {
+						const float f = kl * kl * kl * rsqrtf(d2);
+						sx += f * dx; sy += f * dy; sz += f * dz;
+					}
+				}
+			};
+			for (int dz = -1; dz <= 1; ++dz) {
+				const int zz = fz + dz;
+				if (zz < 0 || zz >= FINE_NZ) continue;
+				for (int dy = -1; dy <= 1; ++dy) {
+					const int yy = fy + dy;
+					if (yy < 0 || yy >= FINE_NX) continue;
+					const int row = FINE_NX * (yy + FINE_NX * zz);
+					const uint32_t b = foff[row + xa], e = foff[row + xb + 1];
+					uint32_t q = b;
+					for (; q + 4 <= e; q += 4) {
+						const float x0 = px[q], x1 = px[q + 1], x2 = px[q + 2], x3 = px[q + 3];
+						const float y0 = py[q], y1 = py[q + 1], y2 = py[q + 2], y3 = py[q + 3];
+						const float z0 = pz[q], z1 = pz[q + 1], z2 = pz[q + 2], z3 = pz[q + 3];
+						pair2(q, f2{x0, x1}, f2{y0, y1}, f2{z0, z1});
+						pair2(q + 2, f2{x2, x3}, f2{y2, y3}, f2{z2, z3});
+					}
+					// tail of 1-3: pairs again (an odd one out is paired with a far-away dummy): at most two evaluations instead of three
+					if (q + 2 <= e) {
+						pair2(q, f2{px[q], px[q + 1]}, f2{py[q], py[q + 1]}, f2{pz[q], pz[q + 1]});
+						q += 2;
+					}
+					if (q < e) pair2(q, f2{px[q], 1e6f}, f2{py[q], 1e6f}, f2{pz[q], 1e6f});
+				}
+			}
+			sx += s2x.x + s2x.y;
+			sy += s2y.x + s2y.y;
+			sz += s2z.x + s2z.y;
+			const double spring[3] = {(double)sx, (double)sy, (double)sz};
+			double from[3], to[3];
+#pragma unroll
+			for (int d = 0; d < 3; ++d) {
+				from[d] = (double)c[d] + (double)tme[d];
+				double x = from[d] + spring[d] * mp.corr;
+				to[d] = x < 0.0 ? 0.0 : ((double)nn[d] < x ? (double)nn[d] : x);
+			}
+			collide(g, solid, from, to, mp.skin);
+			int nc[3];
+			float nt[3];
+#pragma unroll
+			for (int d = 0; d < 3; ++d) split_position(to[d], nn[d], nc[d], nt[d]);
+			out_key[j] = blocked_index(g, nc[0], nc[1], nc[2]);
+			out_tx[j] = nt[0]; out_ty[j] = nt[1]; out_tz[j] = nt[2];
+		}
+	}
+}
+
 }  // namespace
 
 static MoveParams move_params(const lfa_sim *s, double dt) {
@@ -792,9 +1111,14 @@ extern "C" int lfa_correct_collide(lfa_sim *s, double dt) {
 			// are written in place; the fallback pass below selects its particles by their old keys
 			LFA_HIP(s, hipMemcpyAsync(oth.key, cur.key, n * 4, hipMemcpyDeviceToDevice, s->stream));
 			if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[41], s->stream));
-			hipLaunchKernelGGL(k_correct_tiled, dim3(g2), dim3(CORR_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, cur, cur.key, cur.t[0],
-			                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_flag, s->cell_count, s->cell_start, (const float4 *)spos,
-			                   move_params(s, dt), ovf);
+			if (getenv("LFA_CORR_COARSE"))  // round 1's walk over the 27 cells (A/B runs)
+				hipLaunchKernelGGL(k_correct_tiled, dim3(g2), dim3(CORR_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, cur, cur.key, cur.t[0],
+				                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_flag, s->cell_count, s->cell_start, (const float4 *)spos,
+				                   move_params(s, dt), ovf);
+			else
+				hipLaunchKernelGGL(k_correct_fine, dim3(g2), dim3(CORR_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, cur.key, cur.t[0],
+				                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_flag, s->cell_count, s->cell_start, (const float4 *)spos,
+				                   move_params(s, dt), ovf);
 			LFA_LAUNCH_CHECK(s);
 			if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[42], s->stream));
 		}
