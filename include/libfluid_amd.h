@@ -86,6 +86,11 @@ typedef struct lfa_params {
 	int32_t pcg_fused;            /* 1 = two launches per PCG iteration (k_pcg_a: search direction + A s, k_pcg_b: AXPYs +
 	                                 MIC(0) sweeps) where the schedule allows it (single domain, tile-local MIC(0));
 	                                 0 = one launch per vector operation. Same arithmetic either way. */
+	int32_t pcg_warm_start;       /* 0 (default) = every solve starts from p = 0 like the reference (src/pressure_solver.cpp:36).
+	                                 1 = the PCG starts from the pressure of the previous solve where a tile was solved then
+	                                 (r = b - A p): same system, same stopping rule, fewer iterations when consecutive steps
+	                                 resemble each other (a settling pool; in the violent phase of the C4 dam break 16 -> 15).
+	                                 Never with LFA_PRECOND_MIC0_EXACT (the reference-parity schedule) or slabs. */
 } lfa_params;
 
 /* -- lifetime ------------------------------------------------------------------------------------------------ */

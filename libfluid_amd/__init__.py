@@ -51,6 +51,7 @@ class Params(C.Structure):
         ("pcg_dtype", C.c_int32),
         ("apic_unscaled_kernel", C.c_int32),
         ("pcg_fused", C.c_int32),
+        ("pcg_warm_start", C.c_int32),
     ]
 
 

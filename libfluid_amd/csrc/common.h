@@ -137,6 +137,11 @@ struct lfa_sim {
 	bool system_valid = false, unknown_count_valid = false;
 	double last_residual = 0.0;
 	uint64_t last_iters = 0;
+	// warm start of the PCG (lfa_params.pcg_warm_start)
+	uint32_t *tile_epoch = nullptr;   // [nt] solve counter of the last solve a tile took part in
+	uint32_t solve_epoch = 0;         // counter of system builds
+	uint32_t pressure_epoch = 0;      // solve the pressure in vp belongs to (0: none / replaced by an upload)
+	bool warm_started = false;        // the system just built starts from the previous pressure: r = b - A p is still due
 	// Deferred half of the binning (APIC): lfa_hash_particles moves key, t, id (20 of the 68 bytes) and records
 	// where each particle came from; v and C stay in the other buffer until the P2G has read them through that index -
 	// the G2P then writes the new v, C straight into the binned order. Anything else that reads v or C calls

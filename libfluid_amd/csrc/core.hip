@@ -143,6 +143,7 @@ extern "C" void lfa_default_params(lfa_params *p) {
 	p->pcg_dtype = LFA_PCG_F32;
 	p->apic_unscaled_kernel = 1;
 	p->pcg_fused = 1;
+	p->pcg_warm_start = 0;
 }
 
 template <typename T> static int dev_alloc(lfa_sim *s, T **p, size_t count, bool zero) {
@@ -256,7 +257,7 @@ extern "C" void lfa_destroy(lfa_sim *s) {
 	if (s->stream2) (void)hipStreamSynchronize(s->stream2);
 	free_soa(s->pb[0]);
 	free_soa(s->pb[1]);
-	void *ptrs[] = {s->src_cell, s->src_lo, s->src_target, s->src_of, s->src_need, s->src_vel, s->coerce_map, s->cell_start, s->grid_flag, s->rank, s->vc_src, s->tile_count, s->tile_start, s->tile_flag, s->tile_scan, s->ptiles_all, s->dtiles, s->halo_tiles, s->dist_red,
+	void *ptrs[] = {s->tile_epoch, s->src_cell, s->src_lo, s->src_target, s->src_of, s->src_need, s->src_vel, s->coerce_map, s->cell_start, s->grid_flag, s->rank, s->vc_src, s->tile_count, s->tile_start, s->tile_flag, s->tile_scan, s->ptiles_all, s->dtiles, s->halo_tiles, s->dist_red,
 	                s->xbuf[0], s->xbuf[1], s->xbuf[2], s->xbuf[3],
 	                s->tile_pslot, s->scan_tmp, s->u, s->v, s->w, s->uo, s->vo, s->wo, s->ctype, s->solid,
 	                s->cell_count, s->stage, s->acc, s->abits, s->vp, s->vr, s->vz, s->vs, s->vpre, s->vq, s->vs2, s->c_as, s->nbr_table,
@@ -980,15 +981,16 @@ extern "C" int lfa_hash_particles(lfa_sim *s) {
 		// particle and only v stays behind
 		const int defer = getenv("LFA_FULL_SCATTER") ? 0 : (s->prm.simulation_method == LFA_APIC ? 1 : 2);
 		const dim3 sgrid((unsigned)((n + 255) / 256));
+		const int shuffle = (!s->binned || getenv("LFA_BIN_SHUFFLE")) ? 1 : 0;
 		if (defer == 1)
 			hipLaunchKernelGGL(k_tile_scatter<1>, sgrid, dim3(256), 0, s->stream, n, src, dst, s->rank, s->tile_start, s->tile_count,
-			                   s->binned ? 0 : 1, s->vc_src);
+			                   shuffle, s->vc_src);
 		else if (defer == 2)
 			hipLaunchKernelGGL(k_tile_scatter<2>, sgrid, dim3(256), 0, s->stream, n, src, dst, s->rank, s->tile_start, s->tile_count,
-			                   s->binned ? 0 : 1, s->vc_src);
+			                   shuffle, s->vc_src);
 		else
 			hipLaunchKernelGGL(k_tile_scatter<0>, sgrid, dim3(256), 0, s->stream, n, src, dst, s->rank, s->tile_start, s->tile_count,
-			                   s->binned ? 0 : 1, (uint32_t *)nullptr);
+			                   shuffle, (uint32_t *)nullptr);
 		LFA_LAUNCH_CHECK(s);
 		s->cur ^= 1;
 		s->vc_pending = defer != 0;

@@ -62,20 +62,26 @@ __global__ void __launch_bounds__(256) k_abits(const int *ptiles, int n_ptiles, 
 template <typename real>
 __global__ void __launch_bounds__(256)
 k_rhs(const int *ptiles, int n_ptiles, GridView gv, const float *u, const float *v, const float *w, real *r, real *p,
-      float inv_h, double *part_b2) {
+      float inv_h, double *part_b2, uint32_t *tile_epoch, uint32_t keep_epoch, uint32_t new_epoch) {
 	__shared__ double lds[4];
 	double acc = 0.0;
 	for (int slot = blockIdx.x; slot < n_ptiles; slot += gridDim.x) {
 		const int tile = ptiles[slot];
 		int tx, ty, tz;
 		tile_coords(gv.g, tile, tx, ty, tz);
+		// warm start (lfa_params.pcg_warm_start): the pressure of the previous solve is the initial guess where the tile was
+		// solved then (a tile that has been out of the set holds pressures of some older step: dropped)
+		const bool keep = keep_epoch != 0 && tile_epoch[tile] == keep_epoch;
+		__syncthreads();
+		if (threadIdx.x == 0 && tile_epoch) tile_epoch[tile] = new_epoch;
 #pragma unroll
 		for (int half = 0; half < 2; ++half) {
 			const int l = threadIdx.x + 256 * half;
 			const int x = tx * 8 + (l & 7), y = ty * 8 + ((l >> 3) & 7), z = tz * 8 + (l >> 6);
 			const size_t b = (size_t)tile * LFA_TILE_CELLS + l;
-			real out = (real)0;
+			real out = (real)0, guess = (real)0;
 			if (in_grid(gv.g, x, y, z) && gv.cell_count[b] > 0) {
+				if (keep) guess = p[b];
 				const float vx = u[b], vy = v[b], vz = w[b];
 				float val = -(vx + vy + vz);
 				if (x > 0) {
@@ -103,7 +109,7 @@ k_rhs(const int *ptiles, int n_ptiles, GridView gv, const float *u, const float 
 				acc += (double)out * (double)out;
 			}
 			r[b] = out;
-			p[b] = (real)0;
+			p[b] = guess;
 		}
 	}
 	acc = wave_sum(acc);
@@ -429,12 +435,23 @@ int lfa_build_rhs(lfa_sim *s, double dt) {
 	LFA_LAUNCH_CHECK(s);
 	const int G = pcg_grid(s->n_ptiles);
 	const float inv_h = (float)(1.0 / s->prm.cell_size);
+	// warm start: only for the solver's own preconditioners (the exact MIC(0) schedule is the reference-parity path and keeps
+	// the reference's zero guess, src/pressure_solver.cpp:36), only from the pressure of the immediately preceding solve
+	if (!s->tile_epoch) {
+		LFA_HIP(s, hipMalloc(&s->tile_epoch, (size_t)s->g.nt * 4));
+		LFA_HIP(s, hipMemsetAsync(s->tile_epoch, 0, (size_t)s->g.nt * 4, s->stream));
+	}
+	s->warm_started = s->prm.pcg_warm_start && s->prm.precond != LFA_PRECOND_MIC0_EXACT && !s->dist && s->pressure_epoch == s->solve_epoch &&
+	                  s->solve_epoch != 0;
+	const uint32_t keep_epoch = s->warm_started ? s->solve_epoch : 0u;
+	++s->solve_epoch;
+	if (s->solve_epoch == 0) s->solve_epoch = 1;
 	if (s->prm.pcg_dtype == LFA_PCG_F64)
 		hipLaunchKernelGGL(k_rhs<double>, dim3(G), dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, gv, s->u, s->v, s->w,
-		                   (double *)s->vr, (double *)s->vp, inv_h, s->partials + PART_B2);
+		                   (double *)s->vr, (double *)s->vp, inv_h, s->partials + PART_B2, s->tile_epoch, keep_epoch, s->solve_epoch);
 	else
 		hipLaunchKernelGGL(k_rhs<float>, dim3(G), dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, gv, s->u, s->v, s->w,
-		                   (float *)s->vr, (float *)s->vp, inv_h, s->partials + PART_B2);
+		                   (float *)s->vr, (float *)s->vp, inv_h, s->partials + PART_B2, s->tile_epoch, keep_epoch, s->solve_epoch);
 	LFA_LAUNCH_CHECK(s);
 	return LFA_OK;
 }

@@ -42,7 +42,7 @@ __device__ inline void axis_bf(float t, bool own, int &b, float &f) {
 /// h > 1 narrows the hat inside the 2x2x2 set, h < 1 widens it to (up to) all 3x3x3 cells, truncated there by the gather.
 template <bool APIC, bool QUIRK, typename AddFn>
 __device__ inline void scatter_particle(int lx, int ly, int lz, const float t[3], const float v[3], const float c[9],
-                                        float hworld, AddFn add) {
+                                        float hworld, int rot, AddFn add) {
 	if (QUIRK) {
 #pragma unroll
 		for (int comp = 0; comp < 3; ++comp) {
@@ -88,16 +88,16 @@ __device__ inline void scatter_particle(int lx, int ly, int lz, const float t[3]
 				az[i] = -hworld * cc[2] * (f[2] - (float)i);
 			}
 		}
+		// The eight nodes are visited starting from node `rot` (0: in order). The LDS-binned kernel passes the lane number:
+		// consecutive particles of one cell - neighbouring lanes once the flow has made the order inside a tile spatially
+		// coherent - then add to eight DIFFERENT nodes at the same time instead of queueing up on one LDS word.
 #pragma unroll
-		for (int k = 0; k < 2; ++k)
-#pragma unroll
-			for (int j = 0; j < 2; ++j)
-#pragma unroll
-				for (int i = 0; i < 2; ++i) {
-					float wgt = (wx[i] * wy[j]) * wz[k];  // product order of _kernel, src/simulation.cpp:209-212
-					float val = APIC ? v[comp] + ((ax[i] + ay[j]) + az[k]) : v[comp];
-					add(comp, hx0 + i, hy0 + j, hz0 + k, wgt * val, wgt);
-				}
+		for (int n = 0; n < 8; ++n) {
+			const int m = (n + rot) & 7, i = m & 1, j = (m >> 1) & 1, k = m >> 2;
+			const float wgt = ((i ? wx[1] : wx[0]) * (j ? wy[1] : wy[0])) * (k ? wz[1] : wz[0]);  // product order of _kernel, :209-212
+			const float val = APIC ? v[comp] + (((i ? ax[1] : ax[0]) + (j ? ay[1] : ay[0])) + (k ? az[1] : az[0])) : v[comp];
+			add(comp, hx0 + i, hy0 + j, hz0 + k, wgt * val, wgt);
+		}
 	}
 }
 
@@ -163,7 +163,7 @@ k_p2g_binned(const int *ptiles, int n_ptiles, ParticleSoA p, ParticleSoA pvc, co
 			if (in < end) load_particle<APIC>(p, pvc, in, jn, nxt);
 			jn = jnn;
 			const int l = (int)(cur.key & 511);
-			scatter_particle<APIC, QUIRK>(l & 7, (l >> 3) & 7, l >> 6, cur.t, cur.v, cur.c, hworld,
+			scatter_particle<APIC, QUIRK>(l & 7, (l >> 3) & 7, l >> 6, cur.t, cur.v, cur.c, hworld, (int)(threadIdx.x & 7),
 			                       [&](int comp, int hx, int hy, int hz, float wv, float wgt) {
 				                       unsigned long long *a = acc + comp * 2 * LFA_HALO_CELLS + hx + 10 * hy + 100 * hz;
 				                       atomicAdd(a, to_fixed(wv, P2G_FIX_SCALE_V));
@@ -208,7 +208,7 @@ k_p2g_atomic(size_t n, ParticleSoA p, float *acc, size_t ncp, GridDims g, float 
 		for (int k = 0; k < 9; ++k) c[k] = p.c[k][i];
 	}
 	// local coords 0 here: hx = 1 + b + i  => cell offset = hx - 1
-	scatter_particle<APIC, QUIRK>(0, 0, 0, t, v, c, hworld, [&](int comp, int hx, int hy, int hz, float wv, float wgt) {
+	scatter_particle<APIC, QUIRK>(0, 0, 0, t, v, c, hworld, 0, [&](int comp, int hx, int hy, int hz, float wv, float wgt) {
 		int x = cx + hx - 1, y = cy + hy - 1, z = cz + hz - 1;
 		if (!in_grid(g, x, y, z)) return;
 		size_t b = blocked_index(g, x, y, z);

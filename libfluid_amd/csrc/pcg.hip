@@ -163,6 +163,18 @@ k_spmv(TileCtx tc, const uint8_t *abits, const real *s, real *z, real scale, dou
 	block_partial_sum(acc, red, part_zs);
 }
 
+/// r -= q and (ZERO) p = 0 over the particle tiles: the residual of a warm start, r = b - A p_guess.
+template <typename real, bool ZERO>
+__global__ void __launch_bounds__(256) k_warm_residual(TileCtx tc, real *r, const real *q, real *p) {
+	for (int slot = blockIdx.x; slot < tc.n_ptiles; slot += gridDim.x) {
+		const size_t base = (size_t)tc.ptiles[slot] * LFA_TILE_CELLS;
+		for (int l = threadIdx.x; l < LFA_TILE_CELLS; l += 256) {
+			if (ZERO) p[base + l] = (real)0;
+			else r[base + l] -= q[base + l];
+		}
+	}
+}
+
 // ================================================================================================= AXPY x2 + max
 /// p += alpha s ; r += (-alpha) z (_muladd, src/pressure_solver.cpp:364-370) ; signed max of r over the unknowns (:54).
 template <typename real>
@@ -1696,10 +1708,25 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 		for (double x : hb) tot += x;
 	}
 	if (tot != tot) return lfa_fail(s, LFA_E_NAN, "NaN in the divergence right-hand side");
-	if (tot < 1e-6) return LFA_OK;
+	if (tot < 1e-6) {
+		if (s->warm_started) {  // the reference returns p = 0 here (src/pressure_solver.cpp:33-35), not the guess
+			hipLaunchKernelGGL((k_warm_residual<real, true>), dim3(G), dim3(256), 0, s->stream, tc, v.r, (const real *)v.q, v.p);
+			LFA_LAUNCH_CHECK(s);
+		}
+		s->pressure_epoch = s->solve_epoch;
+		return LFA_OK;
+	}
 
 	int init_state[2] = {-1, 0};
 	LFA_HIP(s, hipMemcpyAsync(s->pcg_state, init_state, 8, hipMemcpyHostToDevice, s->stream));
+	if (s->warm_started) {
+		// r = b - A p_guess: one SpMV and one subtraction before the first preconditioner application
+		hipLaunchKernelGGL(k_spmv<real>, dim3(G), dim3(256), 0, s->stream, tc, s->abits, (const real *)v.p, v.q, scale, P + PART_ZS,
+		                   s->pcg_state);
+		hipLaunchKernelGGL((k_warm_residual<real, false>), dim3(G), dim3(256), 0, s->stream, tc, v.r, (const real *)v.q, v.p);
+		LFA_LAUNCH_CHECK(s);
+	}
+	s->pressure_epoch = s->solve_epoch;  // whatever comes out of this solve is the guess of the next one
 	const int NS = sigma_parts(s);
 	// where the consumers find a reduced scalar: the per-workgroup partials (they re-add them in a fixed order), or -
 	// with slabs - the all-reduced value

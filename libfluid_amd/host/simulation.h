@@ -246,6 +246,7 @@ namespace fluid_amd {
 		// -- device-path selectors (not in the reference) and status
 		int device = -1;                            ///< HIP device (-1: current); takes effect at resize()
 		int apic_unscaled_kernel = 1;               ///< 1: the reference's APIC hat on world distances (simulation.cpp:367-369)
+		int pcg_warm_start = 0;                     ///< 1: the PCG starts from the previous step's pressure (0: from p = 0 like the reference)
 		int p2g_variant = LFA_P2G_LDS_BINNED, precond = LFA_PRECOND_MULTIGRID, pcg_dtype = LFA_PCG_F32;
 		double pcg_tau = 0.97, pcg_sigma = 0.25, pcg_tolerance = 1e-6;   ///< pressure_solver.h:39-41
 		std::size_t pcg_max_iterations = 200;                             ///< pressure_solver.h:42
@@ -356,7 +357,7 @@ namespace fluid_amd {
 		p.velocity_extrapolation_iterations = velocity_extrapolation_iterations;
 		p.simulation_method = static_cast<int>(simulation_method);
 		p.tau = pcg_tau; p.sigma = pcg_sigma; p.tolerance = pcg_tolerance; p.max_iterations = pcg_max_iterations;
-		p.p2g_variant = p2g_variant; p.precond = precond; p.pcg_dtype = pcg_dtype; p.apic_unscaled_kernel = apic_unscaled_kernel;
+		p.p2g_variant = p2g_variant; p.precond = precond; p.pcg_dtype = pcg_dtype; p.apic_unscaled_kernel = apic_unscaled_kernel; p.pcg_warm_start = pcg_warm_start;
 		return _ok(lfa_set_params(_dev, &p));
 	}
 	/// Solid cells are set by the hosts directly on grid() (testbed/main.cpp:167-176, grid_node.cpp:330-339); they are

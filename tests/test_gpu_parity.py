@@ -479,3 +479,25 @@ def test_multigrid_cell_parallel_variants_are_bitwise_the_wave_per_tile_code(dty
         s.close()
     assert res[0][0] == res[1][0]
     assert np.array_equal(res[0][1], res[1][1])
+
+
+def test_pcg_warm_start_converges_to_the_same_pressure_in_fewer_iterations():
+    """lfa_params.pcg_warm_start: the second solve of a state that barely changed starts from the first one's pressure."""
+    c, parts, solid, s = make_gpu("apic16_solid", pcg_warm_start=1)
+    g = util.load_golden("apic16_solid")
+    s.hash(); s.p2g(); s.add_gravity(util.DT)
+    p0, res0, it0, rc0 = s.solve(util.DT)
+    cells = s.cells()
+    cells["vel"] *= 1.001  # a slightly different right-hand side
+    s.upload_cells(cells)
+    p1, res1, it1, rc1 = s.solve(util.DT)
+    assert rc0 == 0 and rc1 == 0 and res1 < 1e-6 and 0 < it1 < it0, (it0, it1)
+    t = lfa.Sim(c["size"], method=c["method"], blending=c["blend"])
+    t.set_solid_cells(solid)
+    t.upload_particles(parts)
+    t.hash()
+    t.upload_cells(cells)
+    pc, _, itc, _ = t.solve(util.DT)
+    assert itc >= it0 - 1
+    util.assert_close(p1, pc, P_REL, "warm-started pressure")
+    s.close(); t.close()
