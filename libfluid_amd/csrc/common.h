@@ -148,6 +148,7 @@ struct lfa_sim {
 	// lfa_particles_materialize first.
 	uint32_t *vc_src = nullptr;             // index in pb[cur ^ 1] of the particle now at i (valid while vc_pending)
 	bool vc_pending = false;
+	bool vmax2_valid = false;               // pcg_state[7] holds max |v|^2 of the particles (written by the last G2P, nothing has touched v since)
 	bool vc_with_c = false;                 // C is deferred as well (APIC); PIC / FLIP move C with the particle and defer v only
 	unsigned solid_epoch = 1;               // bumped whenever the solid mask changes (caches keyed on it: mg.hip)
 

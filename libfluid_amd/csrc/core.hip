@@ -324,45 +324,68 @@ int lfa_ensure_io(lfa_sim *s, size_t bytes) {
 }
 
 // =============================================================================================== particles in/out
+static int alloc_soa(lfa_sim *s, ParticleSoA &p, size_t cap) {
+	p = ParticleSoA();
+	hipError_t e = hipMalloc(&p.base, cap * 17 * 4);
+	if (e != hipSuccess) return lfa_fail(s, LFA_E_OOM, "hipMalloc of particle SoA (%zu particles) failed", cap);
+	float *f = (float *)p.base;
+	p.key = (uint32_t *)f;
+	for (int k = 0; k < 3; ++k) p.t[k] = f + cap * (1 + k);
+	for (int k = 0; k < 3; ++k) p.v[k] = f + cap * (4 + k);
+	for (int k = 0; k < 9; ++k) p.c[k] = f + cap * (7 + k);
+	p.id = (uint32_t *)(f + cap * 16);
+	return LFA_OK;
+}
+
+/// (Re)allocates the particle arrays for n particles, DISCARDING their contents. Everything new is allocated before anything
+/// old is released, so an out-of-memory failure leaves the handle with its old (still consistent) arrays and capacity.
 int lfa_particles_alloc(lfa_sim *s, size_t n) {
 	if (n <= s->pcap) return LFA_OK;
 	LFA_HIP(s, hipStreamSynchronize(s->stream));
-	size_t cap = (n + 1023) & ~(size_t)1023;
-	for (int b = 0; b < 2; ++b) {
-		free_soa(s->pb[b]);
-		ParticleSoA &p = s->pb[b];
-		hipError_t e = hipMalloc(&p.base, cap * 17 * 4);
-		if (e != hipSuccess) return lfa_fail(s, LFA_E_OOM, "hipMalloc of particle SoA (%zu particles) failed", cap);
-		float *f = (float *)p.base;
-		p.key = (uint32_t *)f;
-		for (int k = 0; k < 3; ++k) p.t[k] = f + cap * (1 + k);
-		for (int k = 0; k < 3; ++k) p.v[k] = f + cap * (4 + k);
-		for (int k = 0; k < 9; ++k) p.c[k] = f + cap * (7 + k);
-		p.id = (uint32_t *)(f + cap * 16);
+	const size_t cap = (n + 1023) & ~(size_t)1023;
+	ParticleSoA nb[2];
+	uint32_t *rank = nullptr, *vc_src = nullptr;
+	int rc = alloc_soa(s, nb[0], cap);
+	if (rc == LFA_OK) rc = alloc_soa(s, nb[1], cap);
+	if (rc == LFA_OK && hipMalloc(&rank, cap * 4) != hipSuccess) rc = lfa_fail(s, LFA_E_OOM, "hipMalloc of the rank array failed");
+	if (rc == LFA_OK && hipMalloc(&vc_src, cap * 4) != hipSuccess) rc = lfa_fail(s, LFA_E_OOM, "hipMalloc of the source-index array failed");
+	if (rc != LFA_OK) {
+		free_soa(nb[0]);
+		free_soa(nb[1]);
+		if (rank) (void)hipFree(rank);
+		if (vc_src) (void)hipFree(vc_src);
+		return rc;
 	}
-	if (s->rank) LFA_HIP(s, hipFree(s->rank));
-	s->rank = nullptr;
-	LFA_HIP(s, hipMalloc(&s->rank, cap * 4));
-	if (s->vc_src) LFA_HIP(s, hipFree(s->vc_src));
-	s->vc_src = nullptr;
-	LFA_HIP(s, hipMalloc(&s->vc_src, cap * 4));
+	free_soa(s->pb[0]);
+	free_soa(s->pb[1]);
+	if (s->rank) (void)hipFree(s->rank);
+	if (s->vc_src) (void)hipFree(s->vc_src);
+	s->pb[0] = nb[0];
+	s->pb[1] = nb[1];
+	s->rank = rank;
+	s->vc_src = vc_src;
 	s->vc_pending = false;
 	s->pcap = cap;
 	return LFA_OK;
 }
 
-/// Grows the particle arrays to hold n_total particles, keeping the first n_keep of the current buffer.
+/// Grows the particle arrays to hold n_total particles, keeping the first n_keep of the current buffer. On failure the
+/// resident particles stay where they are.
 int lfa_particles_reserve(lfa_sim *s, size_t n_keep, size_t n_total) {
 	LFA_TRY(lfa_particles_materialize(s));
 	if (n_total <= s->pcap) return LFA_OK;
 	LFA_HIP(s, hipStreamSynchronize(s->stream));
-	const size_t cap = ((n_total + n_total / 8) + 1023) & ~(size_t)1023, old_cap = s->pcap;
+	const size_t cap = ((n_total + n_total / 8) + 1023) & ~(size_t)1023;
 	ParticleSoA keep = s->pb[s->cur];
-	void *keep_base = keep.base;
-	s->pb[s->cur].base = nullptr;  // detach so that the reallocation below does not free it
+	const size_t old_cap = s->pcap;
+	s->pb[s->cur] = ParticleSoA();  // detached: the reallocation below must not free it
 	s->pcap = 0;
 	int rc = lfa_particles_alloc(s, cap);
-	if (rc != LFA_OK) return rc;
+	if (rc != LFA_OK) {  // nothing was released: put the live buffer back
+		s->pb[s->cur] = keep;
+		s->pcap = old_cap;
+		return rc;
+	}
 	ParticleSoA &dst = s->pb[s->cur];
 	const uint32_t *src_arrays[17];
 	uint32_t *dst_arrays[17];
@@ -374,8 +397,7 @@ int lfa_particles_reserve(lfa_sim *s, size_t n_keep, size_t n_total) {
 	for (int a = 0; a < 17; ++a)
 		if (n_keep) LFA_HIP(s, hipMemcpyAsync(dst_arrays[a], src_arrays[a], n_keep * 4, hipMemcpyDeviceToDevice, s->stream));
 	LFA_HIP(s, hipStreamSynchronize(s->stream));
-	(void)old_cap;
-	if (keep_base) LFA_HIP(s, hipFree(keep_base));
+	free_soa(keep);
 	return LFA_OK;
 }
 
@@ -425,6 +447,7 @@ __global__ void k_ingest(const double *aos, size_t n, ParticleSoA p, GridDims g,
 extern "C" int lfa_upload_particles(lfa_sim *s, const void *aos152, uint64_t n) {
 	if (!s || (!aos152 && n)) return LFA_E_INVALID;
 	s->vc_pending = false;  // the particle set is replaced
+	s->vmax2_valid = false;
 	if (!(s->prm.cell_size > 0.0)) return lfa_fail(s, LFA_E_INVALID, "set cell_size (lfa_set_params) before uploading");
 	if (n >= ((uint64_t)1 << 32)) return lfa_fail(s, LFA_E_INVALID, "more than 2^32 particles");
 	LFA_HIP(s, hipSetDevice(s->device));
@@ -570,6 +593,7 @@ extern "C" int lfa_seed_block(lfa_sim *s, const int64_t lo[3], const int64_t hi[
 	LFA_TRY(lfa_particles_alloc(s, n));
 	s->np = n;
 	s->np_live = n;
+	s->vmax2_valid = false;
 	s->binned = false;
 	s->grid_valid = false;
 	s->system_valid = false;
@@ -1120,10 +1144,17 @@ __global__ void __launch_bounds__(256) k_max_speed2(size_t n, const float *vx, c
 
 extern "C" int lfa_cfl(lfa_sim *s, double *out) {
 	if (!s || !out) return LFA_E_INVALID;
-	LFA_TRY(lfa_particles_materialize(s));
 	LFA_HIP(s, hipSetDevice(s->device));
 	double m = 0.0;
-	if (s->np_live) {
+	if (s->vmax2_valid && s->np_live) {
+		// the last G2P reduced max |v|^2 while it wrote the velocities: 4 bytes instead of a pass over the particles
+		LFA_HIP(s, hipMemcpyAsync(s->h_pinned + 100, s->pcg_state + 7, 4, hipMemcpyDeviceToHost, s->stream));
+		LFA_HIP(s, hipStreamSynchronize(s->stream));
+		float f;
+		memcpy(&f, s->h_pinned + 100, 4);
+		m = (double)f;
+	} else if (s->np_live) {
+		LFA_TRY(lfa_particles_materialize(s));
 		int grid = (int)((s->np_live + 255) / 256);
 		if (grid > 1024) grid = 1024;
 		const ParticleSoA &p = s->pb[s->cur];

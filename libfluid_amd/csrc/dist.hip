@@ -528,17 +528,19 @@ struct LocalDist : lfa_dist {
 		me.lo = send_lo; me.n_lo = n_send_lo; me.hi = send_hi; me.n_hi = n_send_hi;
 		if (!hub->barrier()) return lfa_fail(s, LFA_E_HIP, "slab exchange: a peer rank failed or timed out");
 		int rc = LFA_OK;
-		if (rank > 0 && n_recv_lo) {
+		// sizes are checked even when this side expects nothing: over RCCL an unmatched ncclSend (or ncclRecv) hangs, so the
+		// in-process transport must refuse what the real one cannot do
+		if (rank > 0) {
 			const lfa_hub::Mail &nb = hub->mail[rank - 1];
 			if (nb.n_hi != n_recv_lo) rc = lfa_fail(s, LFA_E_INVALID, "slab exchange size mismatch with rank %d: %zu vs %zu",
 			                                        rank - 1, nb.n_hi, n_recv_lo);
-			else if (hipMemcpy(recv_lo, nb.hi, n_recv_lo, hipMemcpyDeviceToDevice) != hipSuccess) rc = LFA_E_HIP;
+			else if (n_recv_lo && hipMemcpy(recv_lo, nb.hi, n_recv_lo, hipMemcpyDeviceToDevice) != hipSuccess) rc = LFA_E_HIP;
 		}
-		if (rank + 1 < nranks && n_recv_hi && rc == LFA_OK) {
+		if (rank + 1 < nranks && rc == LFA_OK) {
 			const lfa_hub::Mail &nb = hub->mail[rank + 1];
 			if (nb.n_lo != n_recv_hi) rc = lfa_fail(s, LFA_E_INVALID, "slab exchange size mismatch with rank %d: %zu vs %zu",
 			                                        rank + 1, nb.n_lo, n_recv_hi);
-			else if (hipMemcpy(recv_hi, nb.lo, n_recv_hi, hipMemcpyDeviceToDevice) != hipSuccess) rc = LFA_E_HIP;
+			else if (n_recv_hi && hipMemcpy(recv_hi, nb.lo, n_recv_hi, hipMemcpyDeviceToDevice) != hipSuccess) rc = LFA_E_HIP;
 		}
 		if (rc == LFA_OK && hipDeviceSynchronize() != hipSuccess) rc = LFA_E_HIP;  // D2D hipMemcpy may return early
 		if (rc != LFA_OK) hub->fail();

@@ -253,8 +253,9 @@ struct G2PParams {
 /// corner(b0, b1, b2) names the sample cell particle cell + (b0, b1, b2); fetch(field, comp, corner, k) = clamped staggered
 /// sample of field (0-2: u v w, 3-5: FLIP's old grid) at that cell + ((k & 1), (k >> 1) & 1, k >> 2).
 /// `pold`, `j`: where FLIP finds the particle's velocity from before the step (a deferred binning leaves it in the other buffer).
+/// Returns |v|^2 of the new velocity (the CFL reduction of simulation::cfl rides along, src/simulation.cpp:199-205).
 template <int METHOD, typename Corner, typename Fetch>
-__device__ inline void g2p_particle(const ParticleSoA &p, uint32_t i, const ParticleSoA &pold, uint32_t j, const G2PParams &gp,
+__device__ inline float g2p_particle(const ParticleSoA &p, uint32_t i, const ParticleSoA &pold, uint32_t j, const G2PParams &gp,
                                     Corner &&corner, Fetch &&fetch) {
 	const float t[3] = {p.t[0][i], p.t[1][i], p.t[2][i]};
 	float vnew[3], vold[3];
@@ -303,17 +304,21 @@ __device__ inline void g2p_particle(const ParticleSoA &p, uint32_t i, const Part
 			cvec[3 * comp] = cx; cvec[3 * comp + 1] = cy; cvec[3 * comp + 2] = cz;
 		}
 	}
+	float vout[3];
 	if (METHOD == LFA_FLIP_BLEND) {
 #pragma unroll
-		for (int k = 0; k < 3; ++k) p.v[k][i] = vnew[k] + (pold.v[k][j] - vold[k]) * gp.blend;
+		for (int k = 0; k < 3; ++k) vout[k] = vnew[k] + (pold.v[k][j] - vold[k]) * gp.blend;
 	} else {
 #pragma unroll
-		for (int k = 0; k < 3; ++k) p.v[k][i] = vnew[k];
+		for (int k = 0; k < 3; ++k) vout[k] = vnew[k];
 	}
+#pragma unroll
+	for (int k = 0; k < 3; ++k) p.v[k][i] = vout[k];
 	if (METHOD == LFA_APIC) {
 #pragma unroll
 		for (int k = 0; k < 9; ++k) p.c[k][i] = cvec[k];
 	}
+	return vout[0] * vout[0] + vout[1] * vout[1] + vout[2] * vout[2];
 }
 
 /// One workgroup per particle tile: stage u,v,w (and FLIP's old grid) of the tile + 1-cell ring in LDS with the
@@ -326,10 +331,11 @@ template <int METHOD, bool STALE>
 __global__ void __launch_bounds__(256)
 k_g2p(const int *ptiles, int n_ptiles, GridDims g, ParticleSoA p, const uint32_t *tile_start, const float *u,
       const float *v, const float *w, const float *uo, const float *vo, const float *wo, G2PParams gp, uint32_t *leavers,
-      uint32_t *n_leavers, ParticleSoA pold, const uint32_t *from) {
+      uint32_t *n_leavers, ParticleSoA pold, const uint32_t *from, uint32_t *vmax2_bits) {
 	constexpr int NF = METHOD == LFA_FLIP_BLEND ? 6 : 3;
 	__shared__ float lds[NF * LFA_HALO_CELLS];
 	__shared__ uint32_t lv[STALE ? G2P_LV_CAP : 1], lv_n, lv_base;
+	float vmax2 = 0.0f;
 	for (int slot = blockIdx.x; slot < n_ptiles; slot += gridDim.x) {
 		const int tile = ptiles[slot];
 		int tx, ty, tz;
@@ -360,10 +366,11 @@ k_g2p(const int *ptiles, int n_ptiles, GridDims g, ParticleSoA p, const uint32_t
 			}
 			const int l = (int)(key & 511);
 			const int cell = ((l & 7) + 1) + 10 * (((l >> 3) & 7) + 1) + 100 * ((l >> 6) + 1);
-			g2p_particle<METHOD>(
+			const float v2 = g2p_particle<METHOD>(
 			    p, i, pold, (METHOD == LFA_FLIP_BLEND && from) ? from[i] : i, gp,
 			    [&](int b0, int b1, int b2) { return cell + b0 + 10 * b1 + 100 * b2; },
 			    [&](int field, int, int base, int k) { return lds[field * LFA_HALO_CELLS + base + (k & 1) + 10 * ((k >> 1) & 1) + 100 * (k >> 2)]; });
+			vmax2 = fmaxf(vmax2, v2);
 		}
 		if (STALE) {  // one global atomic per tile
 			__syncthreads();
@@ -373,14 +380,19 @@ k_g2p(const int *ptiles, int n_ptiles, GridDims g, ParticleSoA p, const uint32_t
 			for (uint32_t k = threadIdx.x; k < n; k += 256) leavers[lv_base + k] = lv[k];
 		}
 	}
+	// max |v|^2 over the particles this workgroup transferred: non-negative floats order like their bit patterns
+	vmax2 = wave_max(vmax2);
+	if ((threadIdx.x & 63) == 0 && vmax2 > 0.0f) atomicMax(vmax2_bits, __float_as_uint(vmax2));
 }
 
 /// The particles k_g2p<.., STALE> set aside: the same transfer with the samples gathered from the grid in global memory.
 template <int METHOD>
 __global__ void __launch_bounds__(256)
 k_g2p_leavers(GridDims g, ParticleSoA p, const float *u, const float *v, const float *w, const float *uo, const float *vo,
-              const float *wo, G2PParams gp, const uint32_t *leavers, const uint32_t *n_leavers, ParticleSoA pold, const uint32_t *from) {
+              const float *wo, G2PParams gp, const uint32_t *leavers, const uint32_t *n_leavers, ParticleSoA pold, const uint32_t *from,
+              uint32_t *vmax2_bits) {
 	const uint32_t n = *n_leavers;
+	float vmax2 = 0.0f;
 	for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
 		const uint32_t i = leavers[k], key = p.key[i];
 		if (key == 0xFFFFFFFFu) continue;
@@ -389,11 +401,14 @@ k_g2p_leavers(GridDims g, ParticleSoA p, const float *u, const float *v, const f
 		tile_coords(g, tile, tx, ty, tz);
 		const int cx = tx * 8 + (l & 7), cy = ty * 8 + ((l >> 3) & 7), cz = tz * 8 + (l >> 6);
 		const float *F[6] = {u, v, w, uo, vo, wo};
-		g2p_particle<METHOD>(
+		const float v2 = g2p_particle<METHOD>(
 		    p, i, pold, (METHOD == LFA_FLIP_BLEND && from) ? from[i] : i, gp,
 		    [&](int b0, int b1, int b2) { return make_int3(cx + b0, cy + b1, cz + b2); },
 		    [&](int field, int comp, int3 c, int k) { return clamped_sample(g, F[field], comp, c.x + (k & 1), c.y + ((k >> 1) & 1), c.z + (k >> 2)); });
+		vmax2 = fmaxf(vmax2, v2);
 	}
+	vmax2 = wave_max(vmax2);
+	if ((threadIdx.x & 63) == 0 && vmax2 > 0.0f) atomicMax(vmax2_bits, __float_as_uint(vmax2));
 }
 }  // namespace
 
@@ -530,15 +545,18 @@ static int g2p_run(lfa_sim *s, bool stale) {
 	const ParticleSoA &pold = s->vc_pending ? s->pb[s->cur ^ 1] : s->pb[s->cur];
 	const uint32_t *from = s->vc_pending ? (const uint32_t *)s->vc_src : (const uint32_t *)nullptr;
 	if (stale) LFA_HIP(s, hipMemsetAsync(n_leavers, 0, 4, s->stream));
+	// the CFL reduction rides along: max |v|^2 of the velocities this transfer writes (every live particle gets one)
+	uint32_t *vmax2_bits = (uint32_t *)(s->pcg_state + 7);
+	LFA_HIP(s, hipMemsetAsync(vmax2_bits, 0, 4, s->stream));
 	// (the STALE instantiation serves both cases: it allocates 62 VGPRs where the plain one gets 129 - 8 instead of 3 waves
 	// per SIMD; on freshly binned particles it finds no leavers)
 #define G2P_LAUNCH(M)                                                                                                        \
 	do {                                                                                                                     \
 		hipLaunchKernelGGL((k_g2p<M, true>), grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, s->g, p, s->tile_start,   \
-		                   s->u, s->v, s->w, s->uo, s->vo, s->wo, gp, leavers, n_leavers, pold, from);                       \
+		                   s->u, s->v, s->w, s->uo, s->vo, s->wo, gp, leavers, n_leavers, pold, from, vmax2_bits);           \
 		if (stale)                                                                                                           \
 			hipLaunchKernelGGL(k_g2p_leavers<M>, dim3(512), dim3(256), 0, s->stream, s->g, p, s->u, s->v, s->w, s->uo, s->vo, \
-			                   s->wo, gp, (const uint32_t *)leavers, (const uint32_t *)n_leavers, pold, from);               \
+			                   s->wo, gp, (const uint32_t *)leavers, (const uint32_t *)n_leavers, pold, from, vmax2_bits);   \
 	} while (0)
 	switch (s->prm.simulation_method) {
 	case LFA_PIC: G2P_LAUNCH(LFA_PIC); break;
@@ -548,6 +566,7 @@ static int g2p_run(lfa_sim *s, bool stale) {
 #undef G2P_LAUNCH
 	LFA_LAUNCH_CHECK(s);
 	s->vc_pending = false;
+	s->vmax2_valid = !s->dist || !s->holes;  // (slabs: particles handed over since the binning are not in the tile lists)
 	return LFA_OK;
 }
 /// (the public entry point takes the leaver path too: it costs a 4-byte memset and an empty launch on freshly binned

@@ -1042,6 +1042,7 @@ extern "C" int lfa_update_sources(lfa_sim *s, uint64_t *n_seeded) {
 	LFA_LAUNCH_CHECK(s);
 	s->np_live = base + total;
 	s->np = s->np_live;
+	s->vmax2_valid = false;  // the new particles carry their source's velocity
 	if (n_seeded) *n_seeded = total;
 	return lfa_hash_particles(s);  // the reference re-hashes after seeding (src/simulation.cpp:64)
 }
@@ -1054,6 +1055,7 @@ extern "C" int lfa_advect_collide(lfa_sim *s, double dt) {
 	LFA_TRY(lfa_sources_sync(s));
 	if (n) {
 		const dim3 grid((unsigned)((n + 255) / 256));
+		if (s->any_coerce) s->vmax2_valid = false;  // velocities are overwritten inside the coercing sources' cells
 		if (s->any_coerce)
 			hipLaunchKernelGGL(k_advect_collide<true>, grid, dim3(256), 0, s->stream, n, s->pb[s->cur], s->g, s->solid, move_params(s, dt),
 			                   (const uint8_t *)s->coerce_map, (const float *)s->src_vel);

@@ -212,9 +212,7 @@ def test_virtual_slabs_full_time_step_with_migration(size, block, method, bounds
     util.assert_close(pn["vel"], p1["vel"], 1e-2, "particle velocities after full steps, slabs vs single domain", atol=vel_atol)
 
 
-@pytest.mark.skipif(os.environ.get("LFA_TEST_RCCL") != "1",
-                    reason="loading the 570 MB librccl on a fresh box takes ~4 min; set LFA_TEST_RCCL=1 "
-                           "(last run: profiles/r01_rccl_single_rank.txt)")
+@pytest.mark.skipif(os.environ.get("LFA_SKIP_RCCL") == "1", reason="LFA_SKIP_RCCL=1")
 @pytest.mark.parametrize("precond,dtype", [(lfa.PRECOND_MULTILEVEL, lfa.PCG_F64), (lfa.PRECOND_MULTIGRID, lfa.PCG_F32),
                                            (lfa.PRECOND_MULTIGRID, lfa.PCG_F64)])
 def test_rccl_transport_single_rank(precond, dtype, monkeypatch):
