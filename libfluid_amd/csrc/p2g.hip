@@ -144,7 +144,7 @@ __device__ inline void load_particle(const ParticleSoA &p, const ParticleSoA &pv
 template <bool APIC, bool QUIRK>
 __global__ void __launch_bounds__(256)
 k_p2g_binned(const int *ptiles, int n_ptiles, ParticleSoA p, ParticleSoA pvc, const uint32_t *from, const uint32_t *tile_start,
-             float *stage, float hworld) {
+             float *stage, float hworld, int rot_mask) {
 	__shared__ unsigned long long acc[6 * LFA_HALO_CELLS];  // 48 KB: [comp][wv | w][10x10x10]
 	for (int slot = blockIdx.x; slot < n_ptiles; slot += gridDim.x) {
 		const int tile = ptiles[slot];
@@ -163,7 +163,7 @@ k_p2g_binned(const int *ptiles, int n_ptiles, ParticleSoA p, ParticleSoA pvc, co
 			if (in < end) load_particle<APIC>(p, pvc, in, jn, nxt);
 			jn = jnn;
 			const int l = (int)(cur.key & 511);
-			scatter_particle<APIC, QUIRK>(l & 7, (l >> 3) & 7, l >> 6, cur.t, cur.v, cur.c, hworld, (int)(threadIdx.x & 7),
+			scatter_particle<APIC, QUIRK>(l & 7, (l >> 3) & 7, l >> 6, cur.t, cur.v, cur.c, hworld, (int)(threadIdx.x & rot_mask),
 			                       [&](int comp, int hx, int hy, int hz, float wv, float wgt) {
 				                       unsigned long long *a = acc + comp * 2 * LFA_HALO_CELLS + hx + 10 * hy + 100 * hz;
 				                       atomicAdd(a, to_fixed(wv, P2G_FIX_SCALE_V));
@@ -329,7 +329,8 @@ static void launch_binned(lfa_sim *s, const ParticleSoA &p, const ParticleSoA &p
 	const float hworld = (float)s->prm.cell_size;
 #define LB(A, Q)                                                                                                             \
 	hipLaunchKernelGGL((k_p2g_binned<A, Q>), grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, p, pvc, from, s->tile_start, \
-	                   stage_own, hworld)
+	                   stage_own, hworld, rot_mask)
+	const int rot_mask = getenv("LFA_P2G_NO_ROT") ? 0 : 7;  // A/B switch for the lane-rotated node order (profiles/r02_p2g_lds_pmc.txt)
 	switch (scatter_mode(s)) {
 	case 0: LB(false, false); break;
 	case 1: LB(true, false); break;

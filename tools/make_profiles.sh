@@ -1,14 +1,17 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): kernel-trace stats + the two HBM PMC passes of the default bench, summaries under gpurun_out/.
+# Runs on the GPU box (gpurun): the bench line, the kernel-trace summary (mean / median / p95 per kernel) of the same command and
+# the two HBM PMC passes; everything lands under gpurun_out/ (copy what is to be judged into profiles/).
 # usage: tools/make_profiles.sh TAG [bench args...]
-TAG=${1:-r01_c4}; shift
+TAG=${1:-r02_c4}; shift
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp; mkdir -p gpurun_out
 python3 bench.py "$@" > gpurun_out/${TAG}_bench.json 2> /tmp/bench.err || tail -5 /tmp/bench.err
-rm -rf /tmp/kt && rocprofv3 --kernel-trace --stats -d /tmp/kt -- python3 bench.py --no-cpu-baseline "$@" > gpurun_out/${TAG}_bench_under_rocprof.json 2> /tmp/kt.log
-python3 tools/rocprof_summary.py "$(find /tmp/kt -name '*results.db' | head -1)" > gpurun_out/${TAG}_kernel_stats.csv
+LIGHT="--no-cpu-baseline --no-hot-path --no-kernel-timing"
+rm -rf /tmp/kt && rocprofv3 --kernel-trace --stats -d /tmp/kt -- python3 bench.py $LIGHT "$@" > gpurun_out/${TAG}_bench_under_rocprof.json 2> /tmp/kt.log
+# the first (lead-in) dispatches of every kernel are dropped from mean / median / p95: the table describes the timed region
+python3 tools/kernel_trace_summary.py "$(find /tmp/kt -name '*results.db' | head -1)" 20 > gpurun_out/${TAG}_kernel_stats.csv
 for C in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pmc_$C && rocprofv3 --pmc $C --kernel-trace -d /tmp/pmc_$C -- python3 bench.py --no-cpu-baseline --no-full-step "$@" > /dev/null 2> /tmp/pmc_$C.log
+  rm -rf /tmp/pmc_$C && rocprofv3 --pmc $C --kernel-trace -d /tmp/pmc_$C -- python3 bench.py $LIGHT --steps 10 --warmup 20 "$@" > /dev/null 2> /tmp/pmc_$C.log
   python3 tools/pmc_summary.py "$(find /tmp/pmc_$C -name '*results.db' | head -1)" > gpurun_out/${TAG}_pmc_$(echo $C | tr A-Z a-z | sed 's/_size//').csv
 done
 python3 tools/pmc_traffic.py gpurun_out/${TAG}_pmc_fetch.csv gpurun_out/${TAG}_pmc_write.csv gpurun_out/${TAG}_pmc_traffic.json "$TAG: python3 bench.py $*"
-head -12 gpurun_out/${TAG}_kernel_stats.csv
+head -14 gpurun_out/${TAG}_kernel_stats.csv

@@ -1,4 +1,4 @@
-"""Per-kernel value of a rocprofv3 --pmc counter (FETCH_SIZE / WRITE_SIZE, in KiB per dispatch) from a results.db.
+"""Per-kernel value of a rocprofv3 --pmc counter (FETCH_SIZE / WRITE_SIZE: KiB per dispatch; SQ_*: raw counts) from a results.db.
 
 The value is the MEDIAN over the kernel's dispatches (each dispatch: sum over the counter's instances): the first launch of
 a kernel is often not a steady-state one (the first binning after seeding applies a rank permutation and writes 9x the
@@ -16,7 +16,7 @@ for name, ctr, _, val, dur in rows:
     nm = name.replace("void ", "").replace("(anonymous namespace)::", "")
     m = re.match(r"([A-Za-z_0-9]+(<[^>]*>)?)", nm)
     groups.setdefault((m.group(1) if m else nm[:40], ctr), []).append((val, dur))
-print("kernel,counter,dispatches,mean_KiB_per_dispatch,mean_duration_ns,max_KiB_per_dispatch")
+print("kernel,counter,dispatches,median_value_per_dispatch,median_duration_ns,max_value_per_dispatch")
 for (nm, ctr), v in sorted(groups.items(), key=lambda kv: -statistics.median(x[0] for x in kv[1]) * len(kv[1])):
     vals, durs = [x[0] for x in v], [x[1] for x in v]
     print(f'"{nm}",{ctr},{len(v)},{statistics.median(vals):.1f},{statistics.median(durs):.0f},{max(vals):.1f}')

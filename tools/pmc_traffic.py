@@ -11,7 +11,11 @@ import sys
 NAMES = {"k_pcg_a<float, false, true>": "pcg_a", "k_pcg_b<float, true>": "pcg_b",
          "k_pcg_a<float, false, false>": "pcg_a", "k_pcg_b<float, false>": "pcg_b",
          "k_spmv<float>": "spmv_dot", "k_axpy_max<float>": "axpy_max", "k_mic_apply<float, 0, true>": "mic_apply_dot",
-         "k_update_s<float>": "update_s", "k_p2g_binned<true>": "p2g_scatter", "k_p2g_binned<false>": "p2g_scatter",
+         "k_update_s<float>": "update_s", "k_p2g_binned<true>": "p2g_scatter", "k_p2g_binned<false>": "p2g_scatter", "k_p2g_binned<true, false>": "p2g_scatter",
+         "k_p2g_binned<false, false>": "p2g_scatter", "k_p2g_binned<true, true>": "p2g_scatter", "k_correct_fine": "correct_tiled",
+         "k_build_cell_index": "correct_cell_index", "k_advect_collide<false>": "advect_collide", "k_advect_collide<true>": "advect_collide",
+         "k_tile_scatter<1>": "bin_scatter", "k_tile_scatter<2>": "bin_scatter", "k_tile_scatter<0>": "bin_scatter",
+         "k_mg_residual_restrict<float>": "mg_down0",
          "k_p2g_finalize<true>": "p2g_finalize", "k_p2g_finalize<false>": "p2g_finalize", "k_g2p<2>": "g2p",
          "k_g2p<1>": "g2p", "k_g2p<0>": "g2p", "k_g2p<2, true>": "g2p", "k_g2p<1, true>": "g2p", "k_g2p<0, true>": "g2p",
          "k_tile_scatter": "bin_scatter", "k_tile_scatter<true>": "bin_scatter", "k_tile_scatter<false>": "bin_scatter", "k_gather_vc": "bin_deferred_gather", "k_tile_count": "bin_count", "k_cell_count": "bin_cells",
@@ -22,14 +26,14 @@ def load(path, counter):
     out = {}
     for row in csv.DictReader(open(path)):
         if row["counter"] == counter and row["kernel"] in NAMES:
-            out[NAMES[row["kernel"]]] = float(row["mean_KiB_per_dispatch"]) * 1024.0
+            out[NAMES[row["kernel"]]] = float(row["median_value_per_dispatch"]) * 1024.0
     return out
 
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 res = {"workload": sys.argv[4],
-       "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py --no-cpu-baseline "
-                 "--no-full-step`; FETCH_SIZE doubled (gfx950 counts 128-B read requests as 64 B, MI355X_MICROARCH.md "
+       "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of the bench command "
+                 "(--no-cpu-baseline --no-hot-path --no-kernel-timing); FETCH_SIZE doubled (gfx950 counts 128-B read requests as 64 B, MI355X_MICROARCH.md "
                  "section HBM)",
        "statistic": "median over the dispatches of a kernel (the first binning after seeding is not steady state)",
        "hbm_bytes_per_launch": {}}
