@@ -371,15 +371,35 @@ def main():
                            "algorithmic_GBps": 91 * n_unknowns * sum(its) / (sum(ms) * 1e-3) * 1e-9 if sum(ms) > 0 else None,
                            "note": "91 n bytes per iteration (SURVEY 8d); the reference does 58 MIC(0) iterations at C2 where this does 77"}
         sim.set_params(precond=lfa.PRECOND_MULTIGRID)
-    if args.mesh and world == 1:
-        m = lfa.Mesher(size, (0.0, 0.0, 0.0), 1.0, 1.0, 2, device=local_rank)  # mesher settings of testbed/main.cpp:101-107 at cell size 1
+    if args.mesh and (world == 1 or slabs):
+        # BASELINE configs[4]: the surface of the resident particles (mesher settings of testbed/main.cpp:101-107 at cell size 1).
+        # On slabs every rank meshes its own cell layers (lfa_mesher_create_window) from its own particles and the ghost copies of
+        # its neighbours' adjacent tile layers; the only exchange is the exclusive scan of the vertex counts.
+        window = None
+        if slabs:
+            sim.hash()
+            lo, hi = sim.slab()
+            window = (lo * 8, min(hi * 8, size[2]))
+        m = lfa.Mesher(size, (0.0, 0.0, 0.0), 1.0, 1.0, 2, device=local_rank, window=window)
+        barrier()
         t0 = time.perf_counter()
         m.sample_sim(sim, 0.5)
         t1 = time.perf_counter()
-        mpos, midx = m.marching_cubes()
+        m.marching_cubes()
+        nv, ni = m._counts
+        if slabs:
+            counts = torch.zeros(world, dtype=torch.int64, device="cuda")
+            counts[rank] = nv
+            dist.all_reduce(counts)
+            m.rebase(int(counts[:rank].sum().item()))
+            tot = torch.tensor([float(nv), float(ni)], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tot)
+            nv, ni = int(tot[0].item()), int(tot[1].item())
+        mpos, midx = m.download_mesh()
         t2 = time.perf_counter()
         extras["mesher"] = {"grid_points": (size[0] + 1) * (size[1] + 1) * (size[2] + 1), "sample_ms": 1e3 * (t1 - t0),
-                            "marching_cubes_ms_incl_download": 1e3 * (t2 - t1), "vertices": int(len(mpos)), "triangles": int(len(midx) // 3)}
+                            "marching_cubes_ms_incl_download": 1e3 * (t2 - t1), "vertices": int(nv), "triangles": int(ni // 3),
+                            "windows": world if slabs else 1}
         m.close()
     out.update(extras)
     sim.close()

@@ -286,7 +286,28 @@ int lfa_set_solid_from_voxels(lfa_sim *s, lfa_voxels *v, int include_interior, i
  *   lfa_mesher_sample          : mesher::_sample_surface_function(particles, r) (mesher.cpp:333-376)
  *   lfa_mesher_marching_cubes  : mesher::_marching_cubes() (mesher.cpp:400-515); the two together = generate_mesh (:325)
  *   lfa_mesher_upload_values / download_values : the sampled function, for stage-level parity tests */
+/* A z-window of the grid (slab decompositions, BASELINE configs[4] on 8 GPUs): the handle stores, samples and meshes only the
+ * cell layers [zlo, zhi) of the whole grid `size` - plus what it needs around them: the point planes zlo - 1 .. zhi and the
+ * cells cell_radius beyond those. All arithmetic uses the whole grid's coordinates, so N windows that partition [0, size[2])
+ * produce, concatenated in z order, exactly the single-grid mesh: the same vertex positions in the same order, and the same
+ * index list once every window's indices have been shifted by the number of vertices of all windows below it
+ * (lfa_mesher_rebase; the vertices on the plane between two windows belong to the lower one, the upper one refers to them).
+ * The only thing the windows have to tell each other is a vertex count: an exclusive scan over the ranks.
+ *   lfa_mesher_create_window : as lfa_mesher_create for the layers [zlo, zhi)
+ *   lfa_mesher_window        : first stored point plane, number of stored planes (what lfa_mesher_download_values returns),
+ *                              first and one-past-last own cell layer
+ *   lfa_mesher_sample_ids    : lfa_mesher_sample with an order key per particle: inside a cell the reference visits the newest
+ *                              particle first (space_hashing.h:55-62), i.e. descending index in the host's array; a rank that
+ *                              holds its particles in some other order passes their global indices
+ *   lfa_mesher_rebase        : adds `vertices_below` to every index of the mesh just extracted
+ * lfa_mesher_sample_sim works on a handle with a slab decomposition too: the rank's own particles plus the ghost copies of its
+ * neighbours' adjacent tile layers, ordered by global id (the window must not need more than those 8 cells beyond the slab). */
 typedef struct lfa_mesher lfa_mesher;
+int lfa_mesher_create_window(lfa_mesher **out, const uint64_t size[3], const double grid_offset[3], double cell_size,
+                             double particle_extent, uint64_t cell_radius, uint64_t zlo, uint64_t zhi, int device);
+int lfa_mesher_window(const lfa_mesher *m, uint64_t *z0, uint64_t *n_planes, uint64_t *own_lo, uint64_t *own_hi);
+int lfa_mesher_sample_ids(lfa_mesher *m, const double *positions, const uint32_t *ids, uint64_t n, double r);
+int lfa_mesher_rebase(lfa_mesher *m, uint64_t vertices_below);
 int lfa_mesher_create(lfa_mesher **out, const uint64_t size[3], const double grid_offset[3], double cell_size,
                       double particle_extent, uint64_t cell_radius, int device);
 void lfa_mesher_destroy(lfa_mesher *m);

@@ -122,6 +122,10 @@ SIGNATURES = {
     "lfa_voxels_cells": (_int, [_vp, _int, _int, _vp, _vp, _u64, C.POINTER(_u64)]),
     "lfa_set_solid_from_voxels": (_int, [_vp, _vp, _int, _int]),
     "lfa_mesher_create": (_int, [C.POINTER(_vp), _vp, _vp, _dbl, _dbl, _u64, _int]),
+    "lfa_mesher_create_window": (_int, [C.POINTER(_vp), _vp, _vp, _dbl, _dbl, _u64, _u64, _u64, _int]),
+    "lfa_mesher_window": (_int, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
+    "lfa_mesher_sample_ids": (_int, [_vp, _vp, _vp, _u64, _dbl]),
+    "lfa_mesher_rebase": (_int, [_vp, _u64]),
     "lfa_mesher_destroy": (None, [_vp]),
     "lfa_mesher_last_error": (C.c_char_p, [_vp]),
     "lfa_mesher_sample": (_int, [_vp, _vp, _u64, _dbl]),
@@ -291,33 +295,46 @@ class Voxels:
 class Mesher:
     """Device surface mesher (lfa_mesher): mirrors fluid::mesher (resize + public fields, generate_mesh)."""
 
-    def __init__(self, size, grid_offset=(0.0, 0.0, 0.0), cell_size=1.0, particle_extent=0.5, cell_radius=2, device=-1):
+    def __init__(self, size, grid_offset=(0.0, 0.0, 0.0), cell_size=1.0, particle_extent=0.5, cell_radius=2, device=-1,
+                 window=None):
+        """window = (zlo, zhi): only the cell layers [zlo, zhi) of the grid (lfa_mesher_create_window)."""
         self.lib = load_library()
         self.size = tuple(int(x) for x in size)
         sz, off = np.asarray(self.size, dtype=np.uint64), np.asarray(grid_offset, dtype=np.float64)
         h = C.c_void_p()
-        rc = self.lib.lfa_mesher_create(C.byref(h), _ptr(sz), _ptr(off), float(cell_size), float(particle_extent),
-                                        int(cell_radius), int(device))
+        zlo, zhi = (0, self.size[2]) if window is None else window
+        rc = self.lib.lfa_mesher_create_window(C.byref(h), _ptr(sz), _ptr(off), float(cell_size), float(particle_extent),
+                                               int(cell_radius), int(zlo), int(zhi), int(device))
         if rc != 0:
             raise LibfluidError(rc, self.lib.lfa_last_error(None).decode())
         self.h = h
+        z0, npl, lo, hi = _u64(), _u64(), _u64(), _u64()
+        self._chk(self.lib.lfa_mesher_window(self.h, C.byref(z0), C.byref(npl), C.byref(lo), C.byref(hi)))
+        self.z0, self.n_planes, self.own = z0.value, npl.value, (lo.value, hi.value)
 
     def _chk(self, rc):
         if rc < 0:
             raise LibfluidError(rc, self.lib.lfa_mesher_last_error(self.h).decode())
         return rc
 
-    def sample(self, points, r):
+    def sample(self, points, r, ids=None):
         pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
-        self._chk(self.lib.lfa_mesher_sample(self.h, _ptr(pts), pts.shape[0], float(r)))
+        if ids is None:
+            self._chk(self.lib.lfa_mesher_sample(self.h, _ptr(pts), pts.shape[0], float(r)))
+        else:
+            ids = np.ascontiguousarray(ids, dtype=np.uint32)
+            self._chk(self.lib.lfa_mesher_sample_ids(self.h, _ptr(pts), _ptr(ids), pts.shape[0], float(r)))
+
+    def rebase(self, vertices_below):
+        self._chk(self.lib.lfa_mesher_rebase(self.h, int(vertices_below)))
 
     def sample_sim(self, sim, r):
         """Samples from the particles resident in a Sim handle (no host copy)."""
         self._chk(self.lib.lfa_mesher_sample_sim(self.h, sim.h, float(r)))
 
     def values(self):
-        """float64[nz+1, ny+1, nx+1]."""
-        out = np.empty((self.size[2] + 1, self.size[1] + 1, self.size[0] + 1), dtype=np.float64)
+        """float64[stored planes, ny+1, nx+1] (the whole grid: nz + 1 planes; a window: planes z0 .. z0 + n_planes - 1)."""
+        out = np.empty((self.n_planes, self.size[1] + 1, self.size[0] + 1), dtype=np.float64)
         self._chk(self.lib.lfa_mesher_download_values(self.h, _ptr(out)))
         return out
 
@@ -330,7 +347,13 @@ class Mesher:
         """(positions float64[nv,3], indices uint64[ni])"""
         nv, ni = _u64(), _u64()
         self._chk(self.lib.lfa_mesher_marching_cubes(self.h, C.byref(nv), C.byref(ni)))
-        pos, idx = np.empty((nv.value, 3), dtype=np.float64), np.empty(ni.value, dtype=np.uint64)
+        self._counts = (nv.value, ni.value)
+        return self.download_mesh()
+
+    def download_mesh(self):
+        """The mesh of the last marching_cubes() (indices as lfa_mesher_rebase left them)."""
+        nv, ni = self._counts
+        pos, idx = np.empty((nv, 3), dtype=np.float64), np.empty(ni, dtype=np.uint64)
         self._chk(self.lib.lfa_mesher_download_mesh(self.h, _ptr(pos), _ptr(idx)))
         return pos, idx
 

@@ -467,8 +467,9 @@ int lfa_dist_exchange_ghost_particles(lfa_sim *s) {
 	}
 	const size_t send_lo_at = hs[0], send_lo_n = lfa_has_lo(s) ? hs[1] - hs[0] : 0;
 	const size_t send_hi_at = hs[2], send_hi_n = lfa_has_hi(s) ? hs[3] - hs[2] : 0;
-	uint32_t *arr[4] = {p.key, (uint32_t *)p.t[0], (uint32_t *)p.t[1], (uint32_t *)p.t[2]};
-	for (int a = 0; a < 4; ++a)
+	// key, in-cell position and the global id (the mesher orders the particles of a cell by it)
+	uint32_t *arr[5] = {p.key, (uint32_t *)p.t[0], (uint32_t *)p.t[1], (uint32_t *)p.t[2], p.id};
+	for (int a = 0; a < 5; ++a)
 		LFA_TRY(s->dist->exchange(s, arr[a] + send_lo_at, send_lo_n * 4, arr[a] + at_lo, n_g[0] * 4, arr[a] + send_hi_at,
 		                          send_hi_n * 4, arr[a] + at_hi, n_g[1] * 4));
 	s->ghost_at[0] = at_lo;

@@ -26,7 +26,13 @@
 struct lfa_mesher {
 	int device = 0;
 	hipStream_t stream = nullptr;
-	uint64_t n[3] = {0, 0, 0};  // cells (mesher::resize); the surface function has n + 1 points per axis
+	uint64_t n[3] = {0, 0, 0};  // cells of the WHOLE grid (mesher::resize); the surface function has n + 1 points per axis
+	// z-window (lfa_mesher_create_window; the whole grid: z0 = 0, nzl = n[2], everything from 0 to n[2]): the arrays hold the cell
+	// layers [z0, z0 + nzl) / point planes [z0, z0 + nzl]; planes [s_lo, s_hi] are sampled, cell layers [c_lo, c_hi) are
+	// classified, and vertices / triangles are emitted for the layers from own_lo on (layer own_lo - 1, when it exists, is only
+	// there to number the vertices the cells above it share with it)
+	uint64_t z0 = 0, nzl = 0, s_lo = 0, s_hi = 0, c_lo = 0, c_hi = 0, own_lo = 0;
+	uint32_t *ids = nullptr;       // order keys of the uploaded particles (lfa_mesher_sample_ids), else input order
 	size_t ncell = 0, npts = 0;
 	double off[3] = {0, 0, 0}, cs = 0.0, extent = 0.5;
 	uint64_t radius = 2;
@@ -74,9 +80,10 @@ __constant__ uint32_t d_before[12] = {0x000, 0x001, 0x003, 0x007, 0x00F, 0xB9F, 
 __device__ uint8_t d_tri_table[256 * 16];
 
 struct MeshGrid {
-	uint64_t nx, ny, nz;  // cells
+	uint64_t nx, ny, nz;  // cells of the whole grid
 	double ox, oy, oz, cs, extent;
 	uint64_t radius;
+	uint64_t z0, nzl, s_lo, s_hi, c_lo, c_hi, own_lo;  // window (see lfa_mesher); arrays are indexed with z - z0
 };
 
 // ------------------------------------------------------------------------------------------------ exclusive scan
@@ -141,8 +148,9 @@ __global__ void __launch_bounds__(256) k_block_scan_apply(const uint32_t *in, ui
 /// cell_size) by truncation; kept only if every index is > 0 (sic) and inside the hash (space_hashing.h:33-49).
 __device__ inline uint32_t particle_cell(const MeshGrid &g, const double *p) {
 	const int ix = (int)((p[0] - g.ox) / g.cs), iy = (int)((p[1] - g.oy) / g.cs), iz = (int)((p[2] - g.oz) / g.cs);
-	if (ix > 0 && iy > 0 && iz > 0 && (uint64_t)ix < g.nx && (uint64_t)iy < g.ny && (uint64_t)iz < g.nz)
-		return (uint32_t)((uint64_t)ix + g.nx * ((uint64_t)iy + g.ny * (uint64_t)iz));
+	if (ix > 0 && iy > 0 && iz > 0 && (uint64_t)ix < g.nx && (uint64_t)iy < g.ny && (uint64_t)iz < g.nz &&
+	    (uint64_t)iz >= g.z0 && (uint64_t)iz < g.z0 + g.nzl)  // (and inside the z-window this handle stores)
+		return (uint32_t)((uint64_t)ix + g.nx * ((uint64_t)iy + g.ny * ((uint64_t)iz - g.z0)));
 	return 0xFFFFFFFFu;
 }
 __global__ void k_count_particles(MeshGrid g, const double *pos, size_t np, uint32_t *cell_count, uint8_t *blk_flag) {
@@ -151,7 +159,7 @@ __global__ void k_count_particles(MeshGrid g, const double *pos, size_t np, uint
 	const uint32_t c = particle_cell(g, pos + 3 * i);
 	if (c == 0xFFFFFFFFu) return;
 	atomicAdd(&cell_count[c], 1u);
-	const uint64_t x = c % g.nx, y = (c / g.nx) % g.ny, z = c / (g.nx * g.ny);
+	const uint64_t x = c % g.nx, y = (c / g.nx) % g.ny, z = c / (g.nx * g.ny);  // z: layer inside the window
 	blk_flag[(x >> 3) + ((g.nx + 7) >> 3) * ((y >> 3) + ((g.ny + 7) >> 3) * (z >> 3))] = 1;
 }
 __global__ void k_scatter_particles(MeshGrid g, const double *pos, size_t np, const uint32_t *cell_start, uint32_t *cell_fill,
@@ -165,14 +173,16 @@ __global__ void k_scatter_particles(MeshGrid g, const double *pos, size_t np, co
 /// in DESCENDING input order. Cells are x fastest, so the cells [x0, x1) of one row of a neighbourhood are one contiguous
 /// run of `order` that already is in the reference's visiting order (cells ascending, newest first inside a cell).
 /// Groups are a handful of particles: insertion sort, one thread per cell.
-__global__ void k_sort_groups(const uint32_t *cell_start, size_t ncell, uint32_t *order) {
+/// `ids` (optional): the order key of particle i instead of i itself - a rank of a slab run holds its particles in storage
+/// order and orders them by their global ids, which is the single domain's input order.
+__global__ void k_sort_groups(const uint32_t *cell_start, size_t ncell, uint32_t *order, const uint32_t *ids) {
 	const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= ncell) return;
 	const uint32_t b = cell_start[c], e = cell_start[c + 1];
 	for (uint32_t i = b + 1; i < e; ++i) {
 		const uint32_t v = order[i];
 		uint32_t j = i;
-		while (j > b && order[j - 1] < v) {
+		while (j > b && (ids ? ids[order[j - 1]] < ids[v] : order[j - 1] < v)) {
 			order[j] = order[j - 1];
 			--j;
 		}
@@ -195,10 +205,11 @@ __global__ void k_gather_positions(const double *pos, const uint32_t *order, con
 /// mesher::_sample_surface_function (src/mesher.cpp:342-375), one thread per grid point.
 __global__ void __launch_bounds__(256)
 k_sample_surface(MeshGrid g, const double *spos, const uint32_t *cell_start, const uint8_t *blk_flag, double r, double *values) {
-	const uint64_t px = g.nx + 1, py = g.ny + 1, pz = g.nz + 1;
+	const uint64_t px = g.nx + 1, py = g.ny + 1, pz = g.nzl + 1;
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= px * py * pz) return;
-	const uint64_t x = i % px, y = (i / px) % py, z = i / (px * py);
+	const uint64_t x = i % px, y = (i / px) % py, z = g.z0 + i / (px * py);  // z: plane of the whole grid
+	if (z < g.s_lo || z > g.s_hi) return;
 	const double gx = g.ox + g.cs * (double)x, gy = g.oy + g.cs * (double)y, gz = g.oz + g.cs * (double)z;
 	const uint64_t R = g.radius;
 	// for_each_in_range_checked(center, radius, radius - 1): cells [g - R, g + R - 1], clamped (grid.h:116-135)
@@ -212,14 +223,14 @@ k_sample_surface(MeshGrid g, const double *spos, const uint32_t *cell_start, con
 	bool maybe = false;
 	if (x0 < x1 && y0 < y1 && z0 < z1) {
 		const uint64_t bnx = (g.nx + 7) >> 3, bny = (g.ny + 7) >> 3;
-		for (uint64_t bz = z0 >> 3; bz <= (z1 - 1) >> 3; ++bz)
+		for (uint64_t bz = (z0 - g.z0) >> 3; bz <= (z1 - 1 - g.z0) >> 3; ++bz)
 			for (uint64_t by = y0 >> 3; by <= (y1 - 1) >> 3; ++by)
 				for (uint64_t bx = x0 >> 3; bx <= (x1 - 1) >> 3; ++bx) maybe |= blk_flag[bx + bnx * (by + bny * bz)] != 0;
 	}
 	if (maybe)
 	for (uint64_t cz = z0; cz < z1; ++cz)
 		for (uint64_t cy = y0; cy < y1; ++cy) {
-				const size_t row = (size_t)(g.nx * (cy + g.ny * cz));
+				const size_t row = (size_t)(g.nx * (cy + g.ny * (cz - g.z0)));
 				const uint32_t e = cell_start[row + x1];
 				for (uint32_t k = cell_start[row + x0]; k < e; ++k) {
 					const double *p = spos + 3 * (size_t)k;
@@ -303,7 +314,7 @@ __device__ inline uint8_t cell_case(const MeshGrid &g, const double *values, uin
 	uint8_t occ = 0;
 #pragma unroll
 	for (int i = 0; i < 8; ++i) {
-		f[i] = values[(x + d_corner_offsets[3 * i]) + px * ((y + d_corner_offsets[3 * i + 1]) + py * (z + d_corner_offsets[3 * i + 2]))];
+		f[i] = values[(x + d_corner_offsets[3 * i]) + px * ((y + d_corner_offsets[3 * i + 1]) + py * (z - g.z0 + d_corner_offsets[3 * i + 2]))];
 		occ |= (uint8_t)((f[i] < 0 ? 1 : 0) << i);
 	}
 	return occ;
@@ -312,13 +323,18 @@ __device__ inline uint8_t cell_case(const MeshGrid &g, const double *values, uin
 __global__ void __launch_bounds__(256)
 k_mc_classify(MeshGrid g, const double *values, uint8_t *occ_out, uint16_t *created, uint32_t *vcount, uint32_t *icount) {
 	const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= g.nx * g.ny * g.nz) return;
-	const uint64_t x = c % g.nx, y = (c / g.nx) % g.ny, z = c / (g.nx * g.ny);
+	if (c >= g.nx * g.ny * g.nzl) return;
+	const uint64_t x = c % g.nx, y = (c / g.nx) % g.ny, z = g.z0 + c / (g.nx * g.ny);  // z: layer of the whole grid
+	if (z < g.c_lo || z >= g.c_hi) {
+		occ_out[c] = 0; created[c] = 0; vcount[c] = 0; icount[c] = 0;
+		return;
+	}
 	double f[8];
 	const uint8_t occ = cell_case(g, values, x, y, z, f);
 	const uint32_t mine = edge_mask_dev(occ) & owned_mask(x, y, z);
 	int ni = 0;
 	while (ni < 16 && d_tri_table[occ * 16 + ni] != MC_END) ++ni;
+	if (z < g.own_lo) ni = 0;  // the layer below the window's own ones: its triangles belong to the rank below
 	occ_out[c] = occ;
 	created[c] = (uint16_t)mine;
 	vcount[c] = (uint32_t)__popc(mine);
@@ -327,12 +343,13 @@ k_mc_classify(MeshGrid g, const double *values, uint8_t *occ_out, uint16_t *crea
 
 /// mesher::_add_point (src/mesher.cpp:378-392) for every vertex a cell creates, at its index in the sweep's numbering.
 __global__ void __launch_bounds__(256)
-k_mc_vertices(MeshGrid g, const double *values, const uint16_t *created, const uint32_t *vbase, double *vpos) {
+k_mc_vertices(MeshGrid g, const double *values, const uint16_t *created, const uint32_t *vbase, double *vpos, uint32_t vsub) {
 	const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= g.nx * g.ny * g.nz) return;
+	if (c >= g.nx * g.ny * g.nzl) return;
 	const uint32_t mine = created[c];
 	if (!mine) return;
-	const uint64_t x = c % g.nx, y = (c / g.nx) % g.ny, z = c / (g.nx * g.ny);
+	const uint64_t x = c % g.nx, y = (c / g.nx) % g.ny, z = g.z0 + c / (g.nx * g.ny);
+	if (z < g.own_lo) return;  // numbered here, created by the rank below
 	double f[8];
 	cell_case(g, values, x, y, z, f);
 	const double cell[3] = {(double)x, (double)y, (double)z}, off[3] = {g.ox, g.oy, g.oz};
@@ -340,7 +357,7 @@ k_mc_vertices(MeshGrid g, const double *values, const uint16_t *created, const u
 		if (!(mine & (1u << e))) continue;
 		const int a = d_edge_corners[2 * e], b = d_edge_corners[2 * e + 1];
 		const double v1 = f[a], v2 = f[b], t = v1 / (v1 - v2);
-		double *o = vpos + 3 * ((size_t)vbase[c] + __popc(mine & before_mask(e)));
+		double *o = vpos + 3 * ((size_t)(vbase[c] - vsub) + __popc(mine & before_mask(e)));
 #pragma unroll
 		for (int d = 0; d < 3; ++d) {
 			// vec3d(cell + offset): integer sum converted to double; lerp(a, b, t) = a (1 - t) + b t (misc.h:20-22)
@@ -352,22 +369,30 @@ k_mc_vertices(MeshGrid g, const double *values, const uint16_t *created, const u
 
 __global__ void __launch_bounds__(256)
 k_mc_triangles(MeshGrid g, const uint8_t *occ_in, const uint16_t *created, const uint32_t *vbase, const uint32_t *ibase,
-               uint64_t *vidx) {
+               uint64_t *vidx, uint32_t vsub) {
 	const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= g.nx * g.ny * g.nz) return;
+	if (c >= g.nx * g.ny * g.nzl) return;
 	const uint8_t occ = occ_in[c];
 	if (d_tri_table[occ * 16] == MC_END) return;
-	const uint64_t x = c % g.nx, y = (c / g.nx) % g.ny, z = c / (g.nx * g.ny);
+	const uint64_t x = c % g.nx, y = (c / g.nx) % g.ny, z = g.z0 + c / (g.nx * g.ny);
+	if (z < g.own_lo || z >= g.c_hi) return;
 	uint64_t *o = vidx + ibase[c];
 	for (int k = 0; k < 16 && d_tri_table[occ * 16 + k] != MC_END; ++k) {
 		const EdgeRef r = edge_owner(d_tri_table[occ * 16 + k], x, y, z);
 		const size_t oc = (size_t)((int64_t)c + r.dx + (int64_t)g.nx * (r.dy + (int64_t)g.ny * r.dz));
-		o[k] = (uint64_t)vbase[oc] + (uint64_t)__popc((uint32_t)created[oc] & before_mask(r.e));
+		// relative to the first vertex this window creates: negative (two's complement) for a vertex of the layer below, which
+		// the rank below creates; lfa_mesher_rebase adds the number of vertices of all ranks below
+		o[k] = (uint64_t)((int64_t)vbase[oc] - (int64_t)vsub + (int64_t)__popc((uint32_t)created[oc] & before_mask(r.e)));
 	}
 }
 
 MeshGrid make_grid(const lfa_mesher *m) {
-	return MeshGrid{m->n[0], m->n[1], m->n[2], m->off[0], m->off[1], m->off[2], m->cs, m->extent, m->radius};
+	return MeshGrid{m->n[0], m->n[1], m->n[2], m->off[0], m->off[1], m->off[2], m->cs, m->extent, m->radius,
+	                m->z0, m->nzl, m->s_lo, m->s_hi, m->c_lo, m->c_hi, m->own_lo};
+}
+__global__ void k_rebase(uint64_t *idx, size_t n, int64_t base) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) idx[i] = (uint64_t)((int64_t)idx[i] + base);
 }
 
 int scan_u32(lfa_mesher *m, const uint32_t *in, uint32_t *out, size_t n) {
@@ -381,15 +406,21 @@ int scan_u32(lfa_mesher *m, const uint32_t *in, uint32_t *out, size_t n) {
 }  // namespace
 
 // ================================================================================================= C ABI
-extern "C" int lfa_mesher_create(lfa_mesher **out, const uint64_t size[3], const double grid_offset[3], double cell_size,
-                                 double particle_extent, uint64_t cell_radius, int device) {
+extern "C" int lfa_mesher_create_window(lfa_mesher **out, const uint64_t size[3], const double grid_offset[3], double cell_size,
+                                        double particle_extent, uint64_t cell_radius, uint64_t zlo, uint64_t zhi, int device) {
 	if (!out || !size || !grid_offset) return lfa_fail(nullptr, LFA_E_INVALID, "lfa_mesher_create: NULL argument");
 	*out = nullptr;
 	if (!(cell_size > 0.0) || !(particle_extent > 0.0) || cell_radius < 1 || cell_radius > 64)
 		return lfa_fail(nullptr, LFA_E_INVALID, "lfa_mesher_create: cell_size, particle_extent must be positive, cell_radius in [1, 64]");
 	for (int d = 0; d < 3; ++d)
 		if (size[d] == 0 || size[d] > 4096) return lfa_fail(nullptr, LFA_E_INVALID, "lfa_mesher_create: grid size out of range");
-	if ((size[0] + 1) * (size[1] + 1) * (size[2] + 1) >= (1ull << 32))
+	if (zlo >= zhi || zhi > size[2]) return lfa_fail(nullptr, LFA_E_INVALID, "lfa_mesher_create_window: need 0 <= zlo < zhi <= size[2]");
+	// storage window: the planes to sample are those of the own layers and of the layer below (whose vertices the own cells
+	// share), the cells to hash are the ones a sampled point can see (cell_radius around it)
+	const uint64_t c_lo = zlo > 0 ? zlo - 1 : 0, s_lo = c_lo, s_hi = zhi;
+	const uint64_t z0 = s_lo > cell_radius ? s_lo - cell_radius : 0, z1 = s_hi + cell_radius < size[2] ? s_hi + cell_radius : size[2];
+	const uint64_t nzl = z1 - z0;
+	if ((size[0] + 1) * (size[1] + 1) * (nzl + 1) >= (1ull << 32))
 		return lfa_fail(nullptr, LFA_E_INVALID, "lfa_mesher_create: more than 2^32 sample points");
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -405,8 +436,9 @@ extern "C" int lfa_mesher_create(lfa_mesher **out, const uint64_t size[3], const
 	m->cs = cell_size;
 	m->extent = particle_extent;
 	m->radius = cell_radius;
-	m->ncell = (size_t)size[0] * size[1] * size[2];
-	m->npts = (size_t)(size[0] + 1) * (size[1] + 1) * (size[2] + 1);
+	m->z0 = z0; m->nzl = nzl; m->s_lo = s_lo; m->s_hi = s_hi; m->c_lo = c_lo; m->c_hi = zhi; m->own_lo = zlo;
+	m->ncell = (size_t)size[0] * size[1] * nzl;
+	m->npts = (size_t)(size[0] + 1) * (size[1] + 1) * (nzl + 1);
 	m->nblk = (m->ncell + SCAN_BLOCK - 1) / SCAN_BLOCK;
 	bool ok = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) == hipSuccess &&
 	          hipMalloc(&m->values, m->npts * 8) == hipSuccess && hipMalloc(&m->cell_start, (m->ncell + 1) * 4) == hipSuccess &&
@@ -427,11 +459,26 @@ extern "C" int lfa_mesher_create(lfa_mesher **out, const uint64_t size[3], const
 	return LFA_OK;
 }
 
+extern "C" int lfa_mesher_create(lfa_mesher **out, const uint64_t size[3], const double grid_offset[3], double cell_size,
+                                 double particle_extent, uint64_t cell_radius, int device) {
+	if (!size) return lfa_fail(nullptr, LFA_E_INVALID, "lfa_mesher_create: NULL argument");
+	return lfa_mesher_create_window(out, size, grid_offset, cell_size, particle_extent, cell_radius, 0, size[2], device);
+}
+
+extern "C" int lfa_mesher_window(const lfa_mesher *m, uint64_t *z0, uint64_t *n_planes, uint64_t *own_lo, uint64_t *own_hi) {
+	if (!m) return LFA_E_INVALID;
+	if (z0) *z0 = m->z0;
+	if (n_planes) *n_planes = m->nzl + 1;
+	if (own_lo) *own_lo = m->own_lo;
+	if (own_hi) *own_hi = m->c_hi;
+	return LFA_OK;
+}
+
 extern "C" void lfa_mesher_destroy(lfa_mesher *m) {
 	if (!m) return;
 	(void)hipSetDevice(m->device);
 	if (m->stream) (void)hipStreamSynchronize(m->stream);
-	void *ptrs[] = {m->values, m->cell_start, m->cell_fill, m->order, m->pos, m->spos, m->blk_flag, m->vcount, m->icount, m->created, m->occ, m->blk,
+	void *ptrs[] = {m->ids, m->values, m->cell_start, m->cell_fill, m->order, m->pos, m->spos, m->blk_flag, m->vcount, m->icount, m->created, m->occ, m->blk,
 	                m->vpos, m->vidx};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
@@ -441,11 +488,11 @@ extern "C" void lfa_mesher_destroy(lfa_mesher *m) {
 
 extern "C" const char *lfa_mesher_last_error(const lfa_mesher *m) { return m ? m->err.c_str() : lfa_last_error(nullptr); }
 
-static int sample_device_positions(lfa_mesher *m, const double *dpos, uint64_t n, double r) {
+static int sample_device_positions(lfa_mesher *m, const double *dpos, uint64_t n, double r, const uint32_t *dids = nullptr) {
 	const MeshGrid g = make_grid(m);
 	MSH_HIP(m, hipMemsetAsync(m->cell_start, 0, (m->ncell + 1) * 4, m->stream));
 	MSH_HIP(m, hipMemsetAsync(m->cell_fill, 0, m->ncell * 4, m->stream));
-	const size_t nbf = (size_t)((m->n[0] + 7) >> 3) * ((m->n[1] + 7) >> 3) * ((m->n[2] + 7) >> 3);
+	const size_t nbf = (size_t)((m->n[0] + 7) >> 3) * ((m->n[1] + 7) >> 3) * ((m->nzl + 7) >> 3);
 	if (nbf > m->n_blk_flag) {
 		if (m->blk_flag) MSH_HIP(m, hipFree(m->blk_flag));
 		m->blk_flag = nullptr;
@@ -464,7 +511,7 @@ static int sample_device_positions(lfa_mesher *m, const double *dpos, uint64_t n
 		hipLaunchKernelGGL(k_scatter_particles, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, g, dpos, (size_t)n,
 		                   (const uint32_t *)m->cell_start, m->cell_fill, m->order);
 		hipLaunchKernelGGL(k_sort_groups, dim3((unsigned)((m->ncell + 255) / 256)), dim3(256), 0, m->stream,
-		                   (const uint32_t *)m->cell_start, m->ncell, m->order);
+		                   (const uint32_t *)m->cell_start, m->ncell, m->order, dids);
 		hipLaunchKernelGGL(k_gather_positions, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, dpos,
 		                   (const uint32_t *)m->order, (const uint32_t *)m->cell_start, m->ncell, m->spos);
 	}
@@ -475,73 +522,91 @@ static int sample_device_positions(lfa_mesher *m, const double *dpos, uint64_t n
 	return LFA_OK;
 }
 
-extern "C" int lfa_mesher_sample(lfa_mesher *m, const double *positions, uint64_t n, double r) {
+static int ensure_particle_capacity(lfa_mesher *m, size_t n) {
+	if (n <= m->pcap) return LFA_OK;
+	void *old[] = {m->pos, m->order, m->spos, m->ids};
+	for (void *q : old)
+		if (q) MSH_HIP(m, hipFree(q));
+	m->pos = nullptr; m->order = nullptr; m->spos = nullptr; m->ids = nullptr;
+	m->pcap = 0;
+	MSH_HIP(m, hipMalloc(&m->pos, n * 24));
+	MSH_HIP(m, hipMalloc(&m->spos, n * 24));
+	MSH_HIP(m, hipMalloc(&m->order, n * 4));
+	MSH_HIP(m, hipMalloc(&m->ids, n * 4));
+	m->pcap = n;
+	return LFA_OK;
+}
+
+extern "C" int lfa_mesher_sample_ids(lfa_mesher *m, const double *positions, const uint32_t *ids, uint64_t n, double r) {
 	if (!m || (!positions && n)) return LFA_E_INVALID;
 	if (n >= (1ull << 32)) return mfail(m, LFA_E_INVALID, "lfa_mesher_sample: more than 2^32 particles");
 	MSH_HIP(m, hipSetDevice(m->device));
-	if (n > m->pcap) {
-		if (m->pos) MSH_HIP(m, hipFree(m->pos));
-		if (m->order) MSH_HIP(m, hipFree(m->order));
-		if (m->spos) MSH_HIP(m, hipFree(m->spos));
-		m->pos = nullptr;
-		m->order = nullptr;
-		m->spos = nullptr;
-		m->pcap = 0;
-		MSH_HIP(m, hipMalloc(&m->pos, (size_t)n * 24));
-		MSH_HIP(m, hipMalloc(&m->spos, (size_t)n * 24));
-		MSH_HIP(m, hipMalloc(&m->order, (size_t)n * 4));
-		m->pcap = n;
-	}
+	int rc = ensure_particle_capacity(m, (size_t)n);
+	if (rc != LFA_OK) return rc;
 	if (n) MSH_HIP(m, hipMemcpyAsync(m->pos, positions, (size_t)n * 24, hipMemcpyHostToDevice, m->stream));
-	int rc = sample_device_positions(m, m->pos, n, r);
+	if (n && ids) MSH_HIP(m, hipMemcpyAsync(m->ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, m->stream));
+	rc = sample_device_positions(m, m->pos, n, r, ids ? (const uint32_t *)m->ids : (const uint32_t *)nullptr);
 	if (rc != LFA_OK) return rc;
 	MSH_HIP(m, hipStreamSynchronize(m->stream));
 	return LFA_OK;
 }
+extern "C" int lfa_mesher_sample(lfa_mesher *m, const double *positions, uint64_t n, double r) {
+	return lfa_mesher_sample_ids(m, positions, nullptr, n, r);
+}
 
 /// World positions of a simulation's resident particles, in upload order: the doubles lfa_download_particles writes with
 /// LFA_DL_POSITIONS (core.hip:k_export), so meshing from the device equals meshing the downloaded particles.
-__global__ void k_sim_positions(ParticleSoA p, size_t n, GridDims g, double ox, double oy, double oz, double h, double *pos) {
-	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
+__global__ void k_sim_positions(ParticleSoA p, size_t first, size_t n, size_t out_at, int by_slot, GridDims g, double ox, double oy,
+                                double oz, double h, double *pos, uint32_t *ids) {
+	const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n) return;
+	const size_t i = first + k;
 	const uint32_t b = p.key[i];
 	const int tile = (int)(b >> 9), l = (int)(b & 511);
 	int tx, ty, tz;
 	tile_coords(g, tile, tx, ty, tz);
 	const int c[3] = {tx * 8 + (l & 7), ty * 8 + ((l >> 3) & 7), tz * 8 + (l >> 6)};
 	const double off[3] = {ox, oy, oz};
-	double *q = pos + 3 * (size_t)p.id[i];
+	// single domain: element id of the array = the particle's place in the host's array (what a download writes); slabs: storage
+	// order, with the global id as the order key inside a cell
+	const size_t at = by_slot ? out_at + k : (size_t)p.id[i];
+	double *q = pos + 3 * at;
 #pragma unroll
-	for (int k = 0; k < 3; ++k) q[k] = off[k] + ((double)c[k] + (double)p.t[k][i]) * h;
+	for (int d = 0; d < 3; ++d) q[d] = off[d] + ((double)c[d] + (double)p.t[d][i]) * h;
+	if (by_slot) ids[at] = p.id[i];
 }
 
 extern "C" int lfa_mesher_sample_sim(lfa_mesher *m, lfa_sim *s, double r) {
 	if (!m || !s) return LFA_E_INVALID;
 	if (s->device != m->device) return mfail(m, LFA_E_INVALID, "lfa_mesher_sample_sim: handles live on different devices");
-	if (s->dist) return mfail(m, LFA_E_UNSUPPORTED, "lfa_mesher_sample_sim: not available with a slab decomposition");
-	const size_t n = s->np;
-	if (n >= (1ull << 32)) return mfail(m, LFA_E_INVALID, "lfa_mesher_sample_sim: more than 2^32 particles");
 	MSH_HIP(m, hipSetDevice(m->device));
-	if (n > m->pcap) {
-		if (m->pos) MSH_HIP(m, hipFree(m->pos));
-		if (m->order) MSH_HIP(m, hipFree(m->order));
-		if (m->spos) MSH_HIP(m, hipFree(m->spos));
-		m->pos = nullptr;
-		m->order = nullptr;
-		m->spos = nullptr;
-		m->pcap = 0;
-		MSH_HIP(m, hipMalloc(&m->pos, n * 24));
-		MSH_HIP(m, hipMalloc(&m->spos, n * 24));
-		MSH_HIP(m, hipMalloc(&m->order, n * 4));
-		m->pcap = n;
+	size_t n = s->np, n_live = s->np;
+	if (s->dist) {
+		// a rank of a slab run: its own particles and the ghost copies of the neighbours' adjacent tile layers (8 cells each side);
+		// the window of `m` must only need particles from there
+		if (!s->binned || s->holes) return mfail(m, LFA_E_INVALID, "lfa_mesher_sample_sim: slab decomposition: call lfa_hash_particles first");
+		const double h = s->prm.cell_size, lo = s->prm.grid_offset[2] + h * 8.0 * (double)(lfa_has_lo(s) ? s->slab_lo - 1 : 0),
+		             hi = s->prm.grid_offset[2] + h * 8.0 * (double)(lfa_has_hi(s) ? s->slab_hi + 1 : s->g.ntz);
+		const double need_lo = m->off[2] + m->cs * ((double)m->s_lo - (double)m->radius), need_hi = m->off[2] + m->cs * ((double)m->s_hi + (double)m->radius);
+		if ((lfa_has_lo(s) && need_lo < lo) || (lfa_has_hi(s) && need_hi > hi))
+			return mfail(m, LFA_E_INVALID, "lfa_mesher_sample_sim: the mesher window reaches beyond this rank's slab and ghost tile layers");
+		if (lfa_particles_materialize(s) != LFA_OK || lfa_dist_exchange_ghost_particles(s) != LFA_OK)
+			return mfail(m, LFA_E_HIP, lfa_last_error(s));
+		n_live = s->np_live;
+		n = n_live + s->n_ghost_particles;
 	}
+	if (n >= (1ull << 32)) return mfail(m, LFA_E_INVALID, "lfa_mesher_sample_sim: more than 2^32 particles");
+	int rc = ensure_particle_capacity(m, n);
+	if (rc != LFA_OK) return rc;
 	MSH_HIP(m, hipStreamSynchronize(s->stream));
 	if (n) {
-		hipLaunchKernelGGL(k_sim_positions, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, s->pb[s->cur], n, s->g,
-		                   s->prm.grid_offset[0], s->prm.grid_offset[1], s->prm.grid_offset[2], s->prm.cell_size, m->pos);
+		// live particles [0, n_live), ghosts behind them (lfa_dist_exchange_ghost_particles): one launch over the lot
+		hipLaunchKernelGGL(k_sim_positions, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, s->pb[s->cur], (size_t)0, n,
+		                   (size_t)0, s->dist ? 1 : 0, s->g, s->prm.grid_offset[0], s->prm.grid_offset[1], s->prm.grid_offset[2],
+		                   s->prm.cell_size, m->pos, m->ids);
 		MSH_HIP(m, hipGetLastError());
 	}
-	int rc = sample_device_positions(m, m->pos, n, r);
+	rc = sample_device_positions(m, m->pos, n, r, s->dist ? (const uint32_t *)m->ids : (const uint32_t *)nullptr);
 	if (rc != LFA_OK) return rc;
 	MSH_HIP(m, hipStreamSynchronize(m->stream));
 	return LFA_OK;
@@ -575,16 +640,19 @@ extern "C" int lfa_mesher_marching_cubes(lfa_mesher *m, uint64_t *n_vertices, ui
 	int rc = scan_u32(m, m->vcount, m->vcount, m->ncell);
 	if (rc == LFA_OK) rc = scan_u32(m, m->icount, m->icount, m->ncell);
 	if (rc != LFA_OK) return rc;
-	uint32_t tot[2] = {0, 0};
+	uint32_t tot[3] = {0, 0, 0};
+	const size_t first_own = (size_t)m->n[0] * m->n[1] * (m->own_lo - m->z0);
 	MSH_HIP(m, hipMemcpyAsync(&tot[0], m->vcount + m->ncell, 4, hipMemcpyDeviceToHost, m->stream));
 	MSH_HIP(m, hipMemcpyAsync(&tot[1], m->icount + m->ncell, 4, hipMemcpyDeviceToHost, m->stream));
+	MSH_HIP(m, hipMemcpyAsync(&tot[2], m->vcount + first_own, 4, hipMemcpyDeviceToHost, m->stream));  // vertices of the layer below
 	MSH_HIP(m, hipStreamSynchronize(m->stream));
-	if (tot[0] > m->vcap) {
+	const uint32_t vsub = tot[2], nv = tot[0] - tot[2];
+	if (nv > m->vcap) {
 		if (m->vpos) MSH_HIP(m, hipFree(m->vpos));
 		m->vpos = nullptr;
 		m->vcap = 0;
-		MSH_HIP(m, hipMalloc(&m->vpos, (size_t)tot[0] * 24));
-		m->vcap = tot[0];
+		MSH_HIP(m, hipMalloc(&m->vpos, (size_t)nv * 24));
+		m->vcap = nv;
 	}
 	if (tot[1] > m->icap) {
 		if (m->vidx) MSH_HIP(m, hipFree(m->vidx));
@@ -595,17 +663,30 @@ extern "C" int lfa_mesher_marching_cubes(lfa_mesher *m, uint64_t *n_vertices, ui
 	}
 	if (tot[0]) {
 		hipLaunchKernelGGL(k_mc_vertices, dim3(grid), dim3(256), 0, m->stream, g, (const double *)m->values,
-		                   (const uint16_t *)m->created, (const uint32_t *)m->vcount, m->vpos);
+		                   (const uint16_t *)m->created, (const uint32_t *)m->vcount, m->vpos, vsub);
 		hipLaunchKernelGGL(k_mc_triangles, dim3(grid), dim3(256), 0, m->stream, g, (const uint8_t *)m->occ,
-		                   (const uint16_t *)m->created, (const uint32_t *)m->vcount, (const uint32_t *)m->icount, m->vidx);
+		                   (const uint16_t *)m->created, (const uint32_t *)m->vcount, (const uint32_t *)m->icount, m->vidx, vsub);
 		MSH_HIP(m, hipGetLastError());
 		MSH_HIP(m, hipStreamSynchronize(m->stream));
 	}
-	m->n_vertices = tot[0];
+	m->n_vertices = nv;
 	m->n_indices = tot[1];
 	m->have_mesh = true;
-	if (n_vertices) *n_vertices = tot[0];
+	if (n_vertices) *n_vertices = nv;
 	if (n_indices) *n_indices = tot[1];
+	return LFA_OK;
+}
+
+extern "C" int lfa_mesher_rebase(lfa_mesher *m, uint64_t vertices_below) {
+	if (!m) return LFA_E_INVALID;
+	if (!m->have_mesh) return mfail(m, LFA_E_INVALID, "lfa_mesher_rebase: call lfa_mesher_marching_cubes first");
+	MSH_HIP(m, hipSetDevice(m->device));
+	if (m->n_indices && vertices_below) {
+		hipLaunchKernelGGL(k_rebase, dim3((unsigned)((m->n_indices + 255) / 256)), dim3(256), 0, m->stream, m->vidx, (size_t)m->n_indices,
+		                   (int64_t)vertices_below);
+		MSH_HIP(m, hipGetLastError());
+		MSH_HIP(m, hipStreamSynchronize(m->stream));
+	}
 	return LFA_OK;
 }
 

@@ -129,3 +129,37 @@ def test_dam_break_surface_at_scale():
     _, counts = np.unique(e, axis=0, return_counts=True)
     assert (counts == 2).all()
     m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", mc.PARTICLE_CASES)
+@pytest.mark.parametrize("cuts", [(0.5,), (0.25, 0.6), (0.1, 0.2, 0.3, 0.7, 0.9)])
+def test_z_windows_reproduce_the_single_grid_mesh(name, cuts, golden):
+    """lfa_mesher_create_window (a rank of a slab run meshes its own cell layers): N windows that partition the grid in z, each
+    fed only the particles it can see, in an arbitrary order, plus their global indices, give - concatenated in z order, indices
+    shifted by the vertex counts of the windows below - the reference's mesh bit for bit (golden vectors of the single grid)."""
+    p, kw = mc.particle_case(name)
+    kw = dict(kw)
+    r = kw.pop("r")
+    nz = kw["size"][2]
+    bounds = sorted({0, nz} | {max(1, min(nz - 1, int(round(c * nz)))) for c in cuts})
+    rng = np.random.default_rng(3)
+    pos_parts, idx_parts, below = [], [], 0
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        m = lfa.Mesher(window=(lo, hi), **kw)
+        assert m.own == (lo, hi)
+        # the particles this window may see (a slab rank holds its own layers and some ghosts), shuffled, with their input indices
+        zc = (p[:, 2] - kw["grid_offset"][2]) / kw["cell_size"]
+        see = np.nonzero((zc >= m.z0 - 1.0) & (zc <= m.z0 + m.n_planes + 1.0))[0]
+        see = see[rng.permutation(len(see))]
+        m.sample(p[see], r, ids=see.astype(np.uint32))
+        s_lo = max(lo - 1, 0)
+        assert same(m.values()[s_lo - m.z0: hi - m.z0 + 1], golden[f"{name}_values"][s_lo: hi + 1])
+        m.marching_cubes()
+        m.rebase(below)
+        pos, idx = m.download_mesh()
+        pos_parts.append(pos); idx_parts.append(idx)
+        below += len(pos)
+        m.close()
+    assert same(np.concatenate(pos_parts), golden[f"{name}_pos"])
+    assert np.array_equal(np.concatenate(idx_parts), golden[f"{name}_idx"])
