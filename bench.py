@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--mesh", action="store_true", help="BASELINE configs[4]: extract the surface mesh from the resident particles "
                     "after the timed steps (lfa_mesher_sample_sim + marching cubes), timed separately")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent copies of the domain instead of z-slabs")
+    ap.add_argument("--force-slabs", action="store_true", help="run the z-slab code path (RCCL communicator, halo calls, global CFL "
+                    "reduction) even with one rank: the only way to exercise it end to end on a 1-GPU box")
     ap.add_argument("--strong", action="store_true", help="N > 1: the FIXED BASELINE domain (configs[3]/[4]) split into N z-slabs "
                     "instead of a domain that grows with N")
     args = ap.parse_args()
@@ -125,7 +127,7 @@ def main():
     from libfluid_amd import scenes
 
     dist = None
-    if world > 1:
+    if world > 1 or (args.force_slabs and "RANK" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -137,7 +139,7 @@ def main():
     cfg = dict(scenes.CONFIGS[cfg_name])
     size, (blo, bhi) = list(cfg["size"]), [list(x) for x in cfg["block"]]
     parallelism = "1 GPU"
-    slabs = world > 1 and not args.replicas
+    slabs = (world > 1 and not args.replicas) or args.force_slabs
     if slabs and not args.strong:
         # weak scaling: the domain and the dam-break block grow along z with the number of GPUs, every rank owns a slab
         # as large as the single-GPU workload
@@ -156,7 +158,8 @@ def main():
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             uid.copy_(torch.frombuffer(bytearray(lfa.rccl_unique_id()), dtype=torch.uint8))
-        dist.broadcast(uid, src=0)
+        if dist is not None:
+            dist.broadcast(uid, src=0)
         ntz = (size[2] + 7) // 8
         bounds = lfa.balanced_layer_bounds(ntz, world, blo[2] // 8, (bhi[2] + 7) // 8)
         sim.init_rccl_slab(rank, world, uid.cpu().numpy().tobytes(), bounds)
@@ -190,7 +193,7 @@ def main():
     def global_cfl():
         """simulation::cfl over the whole domain: each rank reduces its own particles, the minimum over ranks is the CFL step."""
         c = sim.cfl()
-        if slabs:
+        if slabs and dist is not None:
             t = torch.tensor([c], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             c = float(t.item())
@@ -266,7 +269,7 @@ def main():
         "stage_ms_median": stage_med, "stage_ms_p95": stage_p95,
     }
 
-    if rank == 0 and world == 1 and not args.no_kernel_timing:
+    if rank == 0 and world == 1 and not slabs and not args.no_kernel_timing:
         apic = cfg["method"] == 2
         flip = cfg["method"] == 1
         ncell_all = cfg["size"][0] * cfg["size"][1] * cfg["size"][2]
@@ -331,7 +334,7 @@ def main():
             kernels[name] = {"ms": ms, "algorithmic_bytes": b, "GBps": b / ms * 1e-6}
         out["kernels_isolated"] = kernels
 
-    if world == 1 and not args.no_hot_path:
+    if world == 1 and not slabs and not args.no_hot_path:
         # secondary figure: the hot path alone (no advection / correction) on the state the dam has reached
         hot_ms, hot_it = [], 0
         stage = {}
@@ -352,7 +355,7 @@ def main():
                            "stage_ms_median": {k: med(v) for k, v in stage.items()},
                            "note": "lfa_step_hot on the state reached by the timed steps: bin + P2G + gravity + PCG + apply + "
                                    "extrapolate + G2P without advection (round 1's headline)"}
-    if world == 1 and rank == 0 and not args.no_mic0_record and args.precond == "multigrid":
+    if world == 1 and not slabs and rank == 0 and not args.no_mic0_record and args.precond == "multigrid":
         # The reference's PCG is MIC(0)-preconditioned (src/pressure_solver.cpp:19-71): the iteration rate that can be set beside
         # its iterations/s is the one of the MIC(0)-based preconditioner (tile-local MIC(0) + coarse correction: the reference's
         # iteration counts within a few per cent), measured on the same state with a second handle's worth of parameters.
@@ -387,7 +390,7 @@ def main():
         t1 = time.perf_counter()
         m.marching_cubes()
         nv, ni = m._counts
-        if slabs:
+        if slabs and dist is not None:
             counts = torch.zeros(world, dtype=torch.int64, device="cuda")
             counts[rank] = nv
             dist.all_reduce(counts)
