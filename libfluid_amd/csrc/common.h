@@ -150,6 +150,8 @@ struct lfa_sim {
 	bool vc_pending = false;
 	bool vmax2_valid = false;               // pcg_state[7] holds max |v|^2 of the particles (written by the last G2P, nothing has touched v since)
 	bool vc_with_c = false;                 // C is deferred as well (APIC); PIC / FLIP move C with the particle and defer v only
+	uint8_t *tile_clear = nullptr;          // [nt] no solid cell within one tile (+ [nt] scratch: tile holds a solid cell)
+	unsigned clear_epoch = 0;               // solid_epoch tile_clear was computed for
 	unsigned solid_epoch = 1;               // bumped whenever the solid mask changes (caches keyed on it: mg.hip)
 
 	// fluid sources (particles.hip): the host-side list as handed in, and its flattened device form (rebuilt when it changes)

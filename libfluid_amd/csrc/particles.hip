@@ -87,6 +87,22 @@ __device__ inline void collide(const GridDims &g, const uint8_t *solid, double f
 	}
 }
 
+/// What is left of `collide` when no solid cell is within reach: nothing stops the segment, and the skin push-out (:654-681)
+/// only ever fires at the domain walls.
+__device__ inline void collide_walls_only(const GridDims &g, double to[3], double skin) {
+	const int n[3] = {g.nx, g.ny, g.nz};
+	const double skin_max = 1.0 - skin;
+#pragma unroll
+	for (int d = 0; d < 3; ++d) {
+		const int ci = (int)to[d];
+		const double cp = to[d] - (double)ci;
+		double x = to[d];
+		if (cp < skin && ci == 0) x += skin - cp;
+		if (cp > skin_max && ci + 1 >= n[d]) x += skin_max - cp;
+		to[d] = x;
+	}
+}
+
 __device__ inline void cell_of_key(const GridDims &g, uint32_t key, int c[3]) {
 	int tile = (int)(key >> 9), l = (int)(key & 511), tx, ty, tz;
 	tile_coords(g, tile, tx, ty, tz);
@@ -121,13 +137,39 @@ struct MoveParams {
 };
 
 /// _advect_particles (x += v dt, clamp to [skin, n - skin]) fused with _detect_collisions (from = the old position).
+/// tile_solid[t] = tile t holds a solid cell (or padding of a ragged grid, which counts as one)
+__global__ void __launch_bounds__(256) k_tile_has_solid(const uint8_t *solid, int nt, uint8_t *tile_solid) {
+	for (int t = blockIdx.x; t < nt; t += gridDim.x) {
+		const uint8_t *c = solid + (size_t)t * LFA_TILE_CELLS;
+		const int any = __syncthreads_or((c[threadIdx.x] | c[threadIdx.x + 256]) != 0);
+		if (threadIdx.x == 0) tile_solid[t] = (uint8_t)(any ? 1 : 0);
+	}
+}
+/// tile_clear[t] = no solid cell within one tile of tile t: a particle that starts in t and moves less than 8 cells per axis
+/// cannot meet one, so its collision handling reduces to the domain walls (which the clamp of the advection already enforces).
+__global__ void k_tile_clear(GridDims g, const uint8_t *tile_solid, uint8_t *tile_clear) {
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= g.nt) return;
+	int tx, ty, tz;
+	tile_coords(g, t, tx, ty, tz);
+	int any = 0;
+	for (int dz = -1; dz <= 1; ++dz)
+		for (int dy = -1; dy <= 1; ++dy)
+			for (int dx = -1; dx <= 1; ++dx) {
+				const int x = tx + dx, y = ty + dy, z = tz + dz;
+				if ((unsigned)x < (unsigned)g.ntx && (unsigned)y < (unsigned)g.nty && (unsigned)z < (unsigned)g.ntz)
+					any |= tile_solid[x + g.ntx * (y + g.nty * z)];
+			}
+	tile_clear[t] = (uint8_t)(any ? 0 : 1);
+}
+
 /// COERCE: the velocity coercion of the fluid sources first (src/simulation.cpp:227-238): a particle inside a cell of an active
 /// coercing source takes the source's velocity and C = 0 (the cell is the particle's current one: the reference hashes at the
 /// start of the step, :49).
 template <bool COERCE>
 __global__ void __launch_bounds__(256)
 k_advect_collide(size_t n, ParticleSoA p, GridDims g, const uint8_t *solid, MoveParams mp, const uint8_t *coerce_map,
-                 const float *src_vel) {
+                 const float *src_vel, const uint8_t *tile_clear) {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	if (p.key[i] == 0xFFFFFFFFu) return;  // outside this rank's slab (dropped at the next binning)
@@ -155,7 +197,13 @@ k_advect_collide(size_t n, ParticleSoA p, GridDims g, const uint8_t *solid, Move
 		const double lo = mp.skin, hi = (double)nn[d] - mp.skin;
 		to[d] = x < lo ? lo : (hi < x ? hi : x);
 	}
-	collide(g, solid, from, to, mp.skin);
+	// No solid cell within a tile of the start and a move of less than a tile: the march of _detect_collisions meets nothing,
+	// and of its skin push-out only the domain walls remain - where the clamp above has already left the particle at least
+	// `skin` inside (to[d] in [skin, n - skin] => cp >= skin in cell 0, cp <= 1 - skin in cell n - 1). The general path costs
+	// a dependent byte load per crossed cell and per near face; most tiles of a scene are nowhere near a solid.
+	const bool open_water = (tile_clear[p.key[i] >> 9] & 1) && fabs(to[0] - from[0]) < 8.0 && fabs(to[1] - from[1]) < 8.0 &&
+	                        fabs(to[2] - from[2]) < 8.0;
+	if (!open_water) collide(g, solid, from, to, mp.skin);
 	int nc[3];
 	float nt[3];
 #pragma unroll
@@ -542,7 +590,7 @@ k_correct_tiled(const int *ptiles, int n_ptiles, ParticleSoA p, uint32_t *out_ke
 __global__ void __launch_bounds__(CORR_THREADS, 4)
 k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx, float *out_ty, float *out_tz, GridDims g,
                const uint8_t *solid, const uint32_t *tile_flag, const uint32_t *cell_count, const uint32_t *cell_start,
-               const float4 *spos, MoveParams mp, uint32_t *overflow_tiles) {
+               const float4 *spos, MoveParams mp, uint32_t *overflow_tiles, const uint8_t *tile_clear) {
 	__shared__ float px[FINE_CAP], py[FINE_CAP], pz[FINE_CAP];
 	__shared__ uint16_t hk[FINE_CAP];            // (halo cell << 6 | index in the cell) of the staged particle
 	__shared__ uint32_t fcnt[FINE_N];            // per fine cell: count, then running cursor; afterwards the own list (u16)
@@ -564,6 +612,7 @@ k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx
 		int tx, ty, tz;
 		tile_coords(g, tile, tx, ty, tz);
 		const int ox = tx * 8 - 1, oy = ty * 8 - 1, oz = tz * 8 + CORR_ZT * half - 1;  // origin of the halo block
+		const bool open_water = (tile_clear[tile] & 1) != 0;  // no solid cell within a tile of this one
 		__syncthreads();
 		// ---- the halo cells: where their particles sit in the cell-ordered records
 		for (int h = threadIdx.x; h < CORR_HCELLS; h += CORR_THREADS) {
@@ -829,7 +878,12 @@ k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx
 				double x = from[d] + spring[d] * mp.corr;
 				to[d] = x < 0.0 ? 0.0 : ((double)nn[d] < x ? (double)nn[d] : x);
 			}
-			collide(g, solid, from, to, mp.skin);
+			// (a correction moves a particle by a fraction of a cell: in open water there is nothing to march against, only the
+			// domain walls push back)
+			if (!open_water || fabs(to[0] - from[0]) >= 7.0 || fabs(to[1] - from[1]) >= 7.0 || fabs(to[2] - from[2]) >= 7.0)
+				collide(g, solid, from, to, mp.skin);
+			else
+				collide_walls_only(g, to, mp.skin);
 			int nc[3];
 			float nt[3];
 #pragma unroll
@@ -1047,21 +1101,36 @@ extern "C" int lfa_update_sources(lfa_sim *s, uint64_t *n_seeded) {
 	return lfa_hash_particles(s);  // the reference re-hashes after seeding (src/simulation.cpp:64)
 }
 
+/// Which tiles are nowhere near a solid cell / a domain wall (k_tile_clear): recomputed when the solid mask has changed.
+static int refresh_tile_clear(lfa_sim *s) {
+	if (s->clear_epoch == s->solid_epoch && s->tile_clear) return LFA_OK;
+	if (!s->tile_clear) LFA_HIP(s, hipMalloc(&s->tile_clear, (size_t)s->g.nt * 2));
+	uint8_t *tile_solid = s->tile_clear + s->g.nt;
+	hipLaunchKernelGGL(k_tile_has_solid, dim3(s->g.nt < 16384 ? s->g.nt : 16384), dim3(256), 0, s->stream, (const uint8_t *)s->solid,
+	                   s->g.nt, tile_solid);
+	hipLaunchKernelGGL(k_tile_clear, dim3((s->g.nt + 255) / 256), dim3(256), 0, s->stream, s->g, (const uint8_t *)tile_solid,
+	                   s->tile_clear);
+	LFA_LAUNCH_CHECK(s);
+	s->clear_epoch = s->solid_epoch;
+	return LFA_OK;
+}
+
 extern "C" int lfa_advect_collide(lfa_sim *s, double dt) {
 	if (!s) return LFA_E_INVALID;
 	LFA_HIP(s, hipSetDevice(s->device));
 	LFA_TRY(lfa_particles_materialize(s));  // reads v
 	const size_t n = s->binned ? s->np_live : s->np;
 	LFA_TRY(lfa_sources_sync(s));
+	LFA_TRY(refresh_tile_clear(s));
 	if (n) {
 		const dim3 grid((unsigned)((n + 255) / 256));
 		if (s->any_coerce) s->vmax2_valid = false;  // velocities are overwritten inside the coercing sources' cells
 		if (s->any_coerce)
 			hipLaunchKernelGGL(k_advect_collide<true>, grid, dim3(256), 0, s->stream, n, s->pb[s->cur], s->g, s->solid, move_params(s, dt),
-			                   (const uint8_t *)s->coerce_map, (const float *)s->src_vel);
+			                   (const uint8_t *)s->coerce_map, (const float *)s->src_vel, (const uint8_t *)s->tile_clear);
 		else
 			hipLaunchKernelGGL(k_advect_collide<false>, grid, dim3(256), 0, s->stream, n, s->pb[s->cur], s->g, s->solid, move_params(s, dt),
-			                   (const uint8_t *)nullptr, (const float *)nullptr);
+			                   (const uint8_t *)nullptr, (const float *)nullptr, (const uint8_t *)s->tile_clear);
 		LFA_LAUNCH_CHECK(s);
 	}
 	LFA_TRY(lfa_dist_migrate(s));
@@ -1088,6 +1157,7 @@ extern "C" int lfa_correct_collide(lfa_sim *s, double dt) {
 		if (lfa_has_hi(s))
 			LFA_HIP(s, hipMemsetAsync(s->cell_count + (size_t)s->slab_hi * L * LFA_TILE_CELLS, 0, (size_t)L * LFA_TILE_CELLS * 4, s->stream));
 	}
+	LFA_TRY(refresh_tile_clear(s));
 	const int n_index = s->dist ? s->n_ptiles_all : s->n_ptiles;
 	const int grid = n_index < 16384 ? (n_index > 0 ? n_index : 1) : 16384;
 	ParticleSoA &cur = s->pb[s->cur], &oth = s->pb[s->cur ^ 1];
@@ -1120,7 +1190,7 @@ extern "C" int lfa_correct_collide(lfa_sim *s, double dt) {
 			else
 				hipLaunchKernelGGL(k_correct_fine, dim3(g2), dim3(CORR_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, cur.key, cur.t[0],
 				                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_flag, s->cell_count, s->cell_start, (const float4 *)spos,
-				                   move_params(s, dt), ovf);
+				                   move_params(s, dt), ovf, (const uint8_t *)s->tile_clear);
 			LFA_LAUNCH_CHECK(s);
 			if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[42], s->stream));
 		}
