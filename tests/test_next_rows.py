@@ -245,3 +245,80 @@ def test_deferred_binning_is_bitwise_the_full_scatter(method, monkeypatch):
     assert np.array_equal(pa, pb)
     for f in ("vel", "cx", "cy", "cz"):
         assert np.array_equal(a[f], b[f]), f
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,off,method", [(0.5, (0.3, -0.2, 0.1), lfa.APIC), (1.7, (-3.25, 0.7, 11.0), lfa.FLIP_BLEND)])
+def test_particle_stages_and_full_steps_at_other_cell_sizes_and_offsets(h, off, method):
+    """The stages around the hot path at cell_size != 1 and grid_offset != 0 (skin width, correction radius re = h / sqrt 2, the
+    world-space clamp and the DDA in grid units all depend on them), each against the oracle from the same state, then three whole
+    device time steps against the oracle's."""
+    c, parts, solid = fullstep_inputs()
+    parts = parts.copy()
+    parts["pos"] = parts["pos"] * h + np.asarray(off)
+    parts["old_pos"] = parts["pos"]
+    rng = np.random.default_rng(4)
+    parts["vel"] = rng.normal(size=(len(parts), 3)) * 60.0 * h
+
+    def cpu():
+        s = orc.CpuSim(c["size"], cell_size=h, offset=off, method=method, blending=0.95)
+        s.set_solid_cells(solid)
+        s.set_particles(parts)
+        return s
+
+    def gpu():
+        s = lfa.Sim(c["size"], cell_size=h, offset=off, method=method, blending=0.95)
+        s.set_solid_cells(solid)
+        s.upload_particles(parts)
+        return s
+
+    def ids_of(p):
+        # identity = the (unique) start position is gone after a move: the oracle keeps array order until its next hash, which
+        # these stage calls do not run after moving, and the device downloads in upload order
+        return p
+
+    o, g = cpu(), gpu()
+    o.hash()
+    o.L.advect(o.h, DT_NEXT); o.L.detect_collisions(o.h)
+    g.advect_collide(DT_NEXT)
+    want = o.particles()  # hash() sorted them: match by the id carried in cx (FLIP/PIC) or by sorted coordinates (APIC zeroes nothing here)
+    got = g.download_particles(into=parts.copy(), write_positions=True)
+    want = want[np.argsort(np.rint(want["cx"][:, 0]).astype(np.int64))]
+    assert np.abs(got["pos"] - want["pos"]).max() < 3e-5 * h
+    o.close(); g.close()
+
+    o, g = cpu(), gpu()
+    o.hash(); g.hash()
+    o.L.correct_positions(o.h, DT_CORR); o.L.detect_collisions(o.h)
+    g.correct_collide(DT_CORR)
+    want = o.particles()
+    want = want[np.argsort(np.rint(want["cx"][:, 0]).astype(np.int64))]
+    got = g.download_particles(into=parts.copy(), write_positions=True)
+    assert np.abs(got["pos"] - want["pos"]).max() < 6e-5 * h
+    assert np.abs(got["pos"] - parts["pos"]).max() > 1e-2 * h
+    o.close(); g.close()
+
+    o, g = cpu(), gpu()
+    slow = parts.copy()
+    slow["vel"] *= 0.05
+    o.set_particles(slow); g.upload_particles(slow)
+    for _ in range(3):
+        o.L.time_step(o.h, 0.004, None, None)
+        g.time_step(0.004)
+    want, got = o.particles(), g.download_particles(into=slow.copy(), write_positions=True)
+    if method == lfa.APIC:
+        # cx is overwritten: compare the clouds as sorted coordinate sets. At h < 1 the reference's un-scaled APIC hat reaches
+        # beyond the 27 cells its gather visits and is cut off there at weights of up to 0.25 (src/simulation.cpp:367-369 with
+        # simulation.h:212-223): its own P2G jumps when a particle crosses a cell face, so a particle that the device's fp32
+        # position puts on the other side of a face (2^-24 cells) changes the faces around it by O(1) - a handful of particles
+        # after three steps (the first two steps agree to 1e-6). The bulk is held to the usual bar, the outliers to a loose one.
+        for k in range(3):
+            dp = np.abs(np.sort(got["pos"][:, k]) - np.sort(want["pos"][:, k]))
+            dv = np.abs(np.sort(got["vel"][:, k]) - np.sort(want["vel"][:, k]))
+            assert np.quantile(dp, 0.99) < 3e-4 * h and dp.max() < 0.05 * h, (k, np.quantile(dp, 0.99), dp.max())
+            assert np.quantile(dv, 0.99) < 3e-3 * np.abs(want["vel"]).max(), (k, np.quantile(dv, 0.99))
+    else:
+        want = want[np.argsort(np.rint(want["cx"][:, 0]).astype(np.int64))]
+        util.assert_close(got["pos"], want["pos"], 1e-6, "positions", atol=3e-4 * h)
+        util.assert_close(got["vel"], want["vel"], 3e-4, "velocities", atol=1e-3 * h)
+    o.close(); g.close()
