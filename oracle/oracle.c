@@ -9,7 +9,7 @@
  *
  * PARITY PINNING: the reference ships no tests or golden vectors, so this restatement is pinned
  * against outputs of the reference itself: oracle/_ref/libref.so (the reference's own sources compiled in place,
- * oracle/ref_harness.cpp) in tests/test_oracle_vs_reference.py, and against the fixtures that build generated,
+ * oracle/ref_harness.cpp) live in tests/test_oracle.py, tests/test_configs.py and tests/test_sources.py, and against the fixtures that build generated,
  * committed under tests/golden/ (generator: tests/golden/make_golden.py).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
