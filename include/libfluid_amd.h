@@ -211,9 +211,28 @@ int lfa_time_step(lfa_sim *s, double dt, double *residual, uint64_t *iterations)
  * [4] pressure system + preconditioner set-up  [5] PCG loop  [6] pressure gradient  [7] cell index of the position
  * correction (k_build_cell_index)  [8] LDS-tiled correction kernel alone  [9] correct+collide as a whole (7 + 8 + fallback)
  * [10] extrapolation  [11] G2P  [12] whole step  [13] PCG iterations of the step (a count, not a time)
- * [14] mean PCG iteration ([5] / [13])  [15] reserved */
+ * [14] mean PCG iteration ([5] / [13])  [15] 1 if the correction ran beside the solve (lfa_set_step_overlap), else 0.
+ * Overlapped, [7] [8] [9] are spans on the correction's own stream and [4] [5] [6] [10] spans on the main one: each is
+ * stretched by the other side's kernels sharing the device, and they no longer add up to [12]. */
 #define LFA_NUM_STEP_TIMERS 16
 int lfa_get_step_timings(lfa_sim *s, double ms[LFA_NUM_STEP_TIMERS]);
+/* lfa_time_step on a single domain runs the position correction (particle arrays only; simulation.cpp:99-106) on a second HIP
+ * stream beside the pressure solve, the pressure gradient and the extrapolation (grid arrays only; :82-97, :119): forked after
+ * the P2G, joined before the G2P. Results are identical either way; on = 0 runs the stages back to back (stage attribution).
+ * Default: on. Slab decompositions always run serially. */
+int lfa_set_step_overlap(lfa_sim *s, int on);
+/* The same fork / join for a host that calls the stages one by one (libfluid_amd/host/simulation.h with stage callbacks):
+ * _begin enqueues lfa_correct_collide on the second stream behind everything enqueued so far and returns; until _end the
+ * particle arrays and the solid mask are the correction's - grid-only calls (lfa_add_gravity, lfa_build_system, lfa_pcg_solve,
+ * lfa_download/upload_pressure, lfa_apply_pressure, lfa_extrapolate, lfa_download_cells) run beside it, every other entry
+ * point joins first (as if _end had been called). _end makes the main stream wait for it (no-op if nothing is in flight).
+ * _undo (only between _begin and _end) joins and puts back the positions of before the correction - exactly: the correction
+ * keeps its inputs - for a host whose callback asks for particles(), or changes the solid mask, at a point of the reference's
+ * step order that lies before the correction (simulation.cpp:82-99); it then calls lfa_correct_collide where the reference does.
+ * Single domain only (LFA_E_UNSUPPORTED on a slab decomposition). */
+int lfa_correct_collide_begin(lfa_sim *s, double dt);
+int lfa_correct_collide_end(lfa_sim *s);
+int lfa_correct_collide_undo(lfa_sim *s);
 
 /* -- multi-GPU: z-slab domain decomposition ---------------------------------------------------------
  * One handle per GPU/process, every handle created with the GLOBAL grid size. Rank r owns the tile layers

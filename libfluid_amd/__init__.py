@@ -24,7 +24,7 @@ NUM_TIMERS = 10
 NUM_STEP_TIMERS = 16
 STEP_TIMER_NAMES = ["advect_collide", "bin", "p2g", "p2g_scatter_kernel", "build_system", "pcg_loop", "apply_pressure",
                     "correct_cell_index", "correct_tiled_kernel", "correct_collide", "extrapolate", "g2p", "time_step",
-                    "pcg_iterations", "pcg_iteration_mean", "reserved"]
+                    "pcg_iterations", "pcg_iteration_mean", "overlapped"]
 TIMER_NAMES = ["bin", "p2g", "gravity", "build_system", "pcg_loop", "apply_pressure", "extrapolate", "g2p",
                "p2g_scatter_kernel", "pcg_iteration_mean"]
 
@@ -141,6 +141,10 @@ SIGNATURES = {
     "lfa_correct_collide": (_int, [_vp, _dbl]),
     "lfa_time_step": (_int, [_vp, _dbl, C.POINTER(_dbl), C.POINTER(_u64)]),
     "lfa_get_step_timings": (_int, [_vp, C.POINTER(_dbl * NUM_STEP_TIMERS)]),
+    "lfa_set_step_overlap": (_int, [_vp, _int]),
+    "lfa_correct_collide_begin": (_int, [_vp, _dbl]),
+    "lfa_correct_collide_end": (_int, [_vp]),
+    "lfa_correct_collide_undo": (_int, [_vp]),
     "lfa_dist_unique_id": (_int, [_vp]),
     "lfa_dist_init_rccl": (_int, [_vp, _int, _int, _vp, _vp]),
     "lfa_dist_local_hub_create": (_vp, [_int]),
@@ -601,6 +605,16 @@ class Sim:
     def correct_collide(self, dt):
         self._chk(self.lib.lfa_correct_collide(self.h, float(dt)))
 
+    def correct_collide_begin(self, dt):
+        """lfa_correct_collide on the second stream; grid-only stages may run beside it until correct_collide_end."""
+        self._chk(self.lib.lfa_correct_collide_begin(self.h, float(dt)))
+
+    def correct_collide_end(self):
+        self._chk(self.lib.lfa_correct_collide_end(self.h))
+
+    def correct_collide_undo(self):
+        self._chk(self.lib.lfa_correct_collide_undo(self.h))
+
     def time_step(self, dt):
         """Device-resident simulation::time_step(dt); returns (residual, iterations, return code)."""
         res, it = C.c_double(0.0), C.c_uint64(0)
@@ -610,7 +624,11 @@ class Sim:
     def step_timings(self):
         arr = (C.c_double * NUM_STEP_TIMERS)()
         self._chk(self.lib.lfa_get_step_timings(self.h, C.byref(arr)))
-        return dict(zip(STEP_TIMER_NAMES[:15], list(arr)[:15]))
+        return dict(zip(STEP_TIMER_NAMES, list(arr)))
+
+    def set_step_overlap(self, on):
+        """time_step: position correction on a second stream beside the pressure solve (default on); off = back to back."""
+        self._chk(self.lib.lfa_set_step_overlap(self.h, int(bool(on))))
 
     # -- z-slab decomposition ------------------------------------------------------------------------------
     def init_local_slab(self, hub, rank, layer_bounds):

@@ -55,6 +55,14 @@ struct lfa_sim {
 	hipStream_t stream = nullptr;
 	hipStream_t stream2 = nullptr;  // side stream: the coarse levels of the preconditioner run beside the fine sweep
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	// lfa_time_step runs the position correction (VALU-bound, particle arrays only) on stream3 beside the pressure solve
+	// (launch- and HBM-bound, grid arrays only): fork after the P2G, join before the G2P
+	hipStream_t stream3 = nullptr;
+	hipEvent_t ev_cfork = nullptr, ev_cjoin = nullptr;
+	bool overlap_correction = true;
+	bool corr_in_flight = false;   // lfa_correct_collide_begin .. _end: the particle arrays belong to the correction on stream3
+	bool corr_undo_valid = false;  // nothing has changed positions, binning or solids since: lfa_correct_collide_undo can restore
+	uint32_t *corr_ovf = nullptr;  // overflow bitmap of the tiled correction (2 bits per particle tile)
 	GridDims g{};
 	size_t nc = 0, ncp = 0;  // real / padded cell count
 	lfa_params prm{};
@@ -284,4 +292,13 @@ int lfa_dist_ensure_xbuf(lfa_sim *s, int which, size_t bytes);
 int lfa_dist_migrate(lfa_sim *s);
 int lfa_dist_exchange_ghost_particles(lfa_sim *s);
 int lfa_particles_reserve(lfa_sim *s, size_t n_keep, size_t n_total);
+/// Orders the main stream behind a correction that lfa_correct_collide_begin has running on stream3; every entry point that
+/// touches particle arrays or the solid mask calls it first (no-op otherwise).
+int lfa_corr_join(lfa_sim *s);
+/// The same for entry points that change positions, the binning or the solid mask: the correction can no longer be undone.
+inline int lfa_corr_commit(lfa_sim *s) {
+	s->corr_undo_valid = false;
+	return lfa_corr_join(s);
+}
+#define LFA_EV_CORRECT_END 30  // ev[] slot: end of the correction (B_CORRECT of lfa_time_step)
 int lfa_sources_sync(lfa_sim *s);  // flattens `sources` to the device arrays if they changed (particles.hip)

@@ -166,6 +166,14 @@ __global__ void k_init_ctype(uint8_t *ctype, uint8_t *solid, GridDims g, size_t 
 	solid[b] = in ? 0 : 1;
 }
 
+/// The correction's stream yields to the main one: the solve's short kernels should not queue behind a long VALU-bound launch.
+static hipError_t create_low_priority_stream(hipStream_t *st) {
+	int least = 0, greatest = 0;
+	if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+	if (getenv("LFA_CORR_PRIO")) least = atoi(getenv("LFA_CORR_PRIO"));
+	return hipStreamCreateWithPriority(st, hipStreamNonBlocking, least);
+}
+
 extern "C" int lfa_create(lfa_sim **out, uint64_t nx, uint64_t ny, uint64_t nz, int device) {
 	if (!out) return lfa_fail(nullptr, LFA_E_INVALID, "lfa_create: out is NULL");
 	*out = nullptr;
@@ -201,6 +209,9 @@ extern "C" int lfa_create(lfa_sim **out, uint64_t nx, uint64_t ny, uint64_t nz, 
 		return lfa_fail(nullptr, LFA_E_HIP, "hipStreamCreate failed");
 	}
 	if (hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking) != hipSuccess ||
+	    create_low_priority_stream(&s->stream3) != hipSuccess ||
+	    hipEventCreateWithFlags(&s->ev_cfork, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&s->ev_cjoin, hipEventDisableTiming) != hipSuccess ||
 	    hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
 	    hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess) {
 		lfa_destroy(s);
@@ -255,9 +266,10 @@ extern "C" void lfa_destroy(lfa_sim *s) {
 	(void)hipSetDevice(s->device);
 	if (s->stream) (void)hipStreamSynchronize(s->stream);
 	if (s->stream2) (void)hipStreamSynchronize(s->stream2);
+	if (s->stream3) (void)hipStreamSynchronize(s->stream3);
 	free_soa(s->pb[0]);
 	free_soa(s->pb[1]);
-	void *ptrs[] = {s->tile_clear, s->tile_epoch, s->src_cell, s->src_lo, s->src_target, s->src_of, s->src_need, s->src_vel, s->coerce_map, s->cell_start, s->grid_flag, s->rank, s->vc_src, s->tile_count, s->tile_start, s->tile_flag, s->tile_scan, s->ptiles_all, s->dtiles, s->halo_tiles, s->dist_red,
+	void *ptrs[] = {s->corr_ovf, s->tile_clear, s->tile_epoch, s->src_cell, s->src_lo, s->src_target, s->src_of, s->src_need, s->src_vel, s->coerce_map, s->cell_start, s->grid_flag, s->rank, s->vc_src, s->tile_count, s->tile_start, s->tile_flag, s->tile_scan, s->ptiles_all, s->dtiles, s->halo_tiles, s->dist_red,
 	                s->xbuf[0], s->xbuf[1], s->xbuf[2], s->xbuf[3],
 	                s->tile_pslot, s->scan_tmp, s->u, s->v, s->w, s->uo, s->vo, s->wo, s->ctype, s->solid,
 	                s->cell_count, s->stage, s->acc, s->abits, s->vp, s->vr, s->vz, s->vs, s->vpre, s->vq, s->vs2, s->c_as, s->nbr_table,
@@ -274,6 +286,9 @@ extern "C" void lfa_destroy(lfa_sim *s) {
 		for (auto &e : s->ev) (void)hipEventDestroy(e);
 	if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
 	if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+	if (s->ev_cfork) (void)hipEventDestroy(s->ev_cfork);
+	if (s->ev_cjoin) (void)hipEventDestroy(s->ev_cjoin);
+	if (s->stream3) (void)hipStreamDestroy(s->stream3);
 	if (s->stream2) (void)hipStreamDestroy(s->stream2);
 	if (s->stream) (void)hipStreamDestroy(s->stream);
 	delete s;
@@ -283,6 +298,7 @@ extern "C" const char *lfa_last_error(const lfa_sim *s) { return s ? s->err.c_st
 
 extern "C" int lfa_set_params(lfa_sim *s, const lfa_params *p) {
 	if (!s || !p) return LFA_E_INVALID;
+	LFA_TRY(lfa_corr_commit(s));
 	if (!(p->cell_size > 0.0)) return lfa_fail(s, LFA_E_INVALID, "cell_size must be > 0 (got %g)", p->cell_size);
 	if (p->simulation_method < 0 || p->simulation_method > 2) return lfa_fail(s, LFA_E_INVALID, "bad simulation_method");
 	if (p->velocity_extrapolation_iterations > 8)
@@ -307,6 +323,7 @@ extern "C" int lfa_get_params(const lfa_sim *s, lfa_params *p) {
 extern "C" int lfa_synchronize(lfa_sim *s) {
 	if (!s) return LFA_E_INVALID;
 	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	if (s->corr_in_flight) LFA_HIP(s, hipStreamSynchronize(s->stream3));  // (still to be joined: lfa_correct_collide_end)
 	return LFA_OK;
 }
 extern "C" void *lfa_stream(lfa_sim *s) { return s ? (void *)s->stream : nullptr; }
@@ -451,6 +468,7 @@ extern "C" int lfa_upload_particles(lfa_sim *s, const void *aos152, uint64_t n) 
 	if (!(s->prm.cell_size > 0.0)) return lfa_fail(s, LFA_E_INVALID, "set cell_size (lfa_set_params) before uploading");
 	if (n >= ((uint64_t)1 << 32)) return lfa_fail(s, LFA_E_INVALID, "more than 2^32 particles");
 	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_corr_commit(s));
 	LFA_TRY(lfa_particles_alloc(s, n));
 	s->np = n;
 	s->np_live = n;
@@ -504,6 +522,7 @@ extern "C" int lfa_download_particles(lfa_sim *s, void *aos152, uint64_t n, int 
 	if (s->dist && (!s->binned || s->holes))
 		return lfa_fail(s, LFA_E_INVALID, "slab decomposition: call lfa_hash_particles before downloading particles");
 	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_corr_join(s));
 	LFA_TRY(lfa_ensure_io(s, n * 152));
 	// start from the caller's records so fields the device does not own (positions unless asked) survive
 	LFA_HIP(s, hipMemcpyAsync(s->io_buf, aos152, n * 152, hipMemcpyHostToDevice, s->stream));
@@ -523,6 +542,7 @@ extern "C" int lfa_download_particle_ids(lfa_sim *s, uint32_t *ids, uint64_t n) 
 	if (n != s->np) return lfa_fail(s, LFA_E_INVALID, "download of %llu ids but %zu particles are resident", (unsigned long long)n, s->np);
 	if (n == 0) return LFA_OK;
 	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_corr_join(s));
 	if (!s->dist) {  // single domain: record i of a download IS particle i
 		for (uint64_t i = 0; i < n; ++i) ids[i] = (uint32_t)i;
 		return LFA_OK;
@@ -573,6 +593,7 @@ __global__ void k_seed_block(size_t n, size_t first, ParticleSoA p, GridDims g, 
 
 extern "C" int lfa_seed_block(lfa_sim *s, const int64_t lo[3], const int64_t hi[3], uint64_t seed) {
 	if (!s || !lo || !hi) return LFA_E_INVALID;
+	LFA_TRY(lfa_corr_commit(s));
 	LFA_TRY(lfa_particles_materialize(s));
 	if (!(s->prm.cell_size > 0.0)) return lfa_fail(s, LFA_E_INVALID, "set cell_size before seeding");
 	const int nn[3] = {s->g.nx, s->g.ny, s->g.nz};
@@ -626,6 +647,7 @@ extern "C" int lfa_set_solid_cells(lfa_sim *s, const int32_t *xyz, uint64_t k) {
 	++s->solid_epoch;
 	if (k == 0) return LFA_OK;
 	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_corr_commit(s));
 	LFA_TRY(lfa_ensure_io(s, k * 12));
 	LFA_HIP(s, hipMemcpyAsync(s->io_buf, xyz, k * 12, hipMemcpyHostToDevice, s->stream));
 	hipLaunchKernelGGL(k_set_solid, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, s->stream,
@@ -640,6 +662,7 @@ extern "C" int lfa_clear_solid_cells(lfa_sim *s) {
 	if (!s) return LFA_E_INVALID;
 	++s->solid_epoch;
 	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_corr_commit(s));
 	hipLaunchKernelGGL(k_init_ctype, dim3((unsigned)((s->ncp + 255) / 256)), dim3(256), 0, s->stream, s->ctype, s->solid,
 	                   s->g, s->ncp);
 	LFA_LAUNCH_CHECK(s);
@@ -719,6 +742,7 @@ extern "C" int lfa_upload_cells(lfa_sim *s, const void *aos32) {
 	if (!s || !aos32) return LFA_E_INVALID;
 	++s->solid_epoch;
 	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_corr_join(s));
 	LFA_TRY(lfa_ensure_io(s, s->nc * 32));
 	LFA_HIP(s, hipMemcpyAsync(s->io_buf, aos32, s->nc * 32, hipMemcpyHostToDevice, s->stream));
 	hipLaunchKernelGGL(k_import_cells, dim3((unsigned)((s->nc + 255) / 256)), dim3(256), 0, s->stream,
@@ -916,6 +940,7 @@ static int compact_tiles(lfa_sim *s, const uint32_t *flag, int lo, int hi, int *
 
 int lfa_particles_materialize(lfa_sim *s) {
 	if (!s->vc_pending) return LFA_OK;
+	LFA_TRY(lfa_corr_commit(s));  // the gather writes the v / C arrays a correction in flight keeps its inputs in
 	s->vc_pending = false;
 	LFA_HIP(s, hipSetDevice(s->device));
 	const size_t n = s->np_live;
@@ -929,6 +954,7 @@ int lfa_particles_materialize(lfa_sim *s) {
 extern "C" int lfa_hash_particles(lfa_sim *s) {
 	if (!s) return LFA_E_INVALID;
 	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_corr_commit(s));
 	LFA_TRY(lfa_particles_materialize(s));  // a binning on top of a deferred one: complete that first
 	const GridDims &g = s->g;
 	const int nt = g.nt, L = g.ntx * g.nty;
@@ -1145,6 +1171,7 @@ __global__ void __launch_bounds__(256) k_max_speed2(size_t n, const float *vx, c
 extern "C" int lfa_cfl(lfa_sim *s, double *out) {
 	if (!s || !out) return LFA_E_INVALID;
 	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_corr_join(s));
 	double m = 0.0;
 	if (s->vmax2_valid && s->np_live) {
 		// the last G2P reduced max |v|^2 while it wrote the velocities: 4 bytes instead of a pass over the particles

@@ -698,6 +698,7 @@ extern "C" int lfa_dist_init_rccl(lfa_sim *s, int rank, int nranks, const void *
 	if (!s || !id128 || !layer_bounds || rank < 0 || rank >= nranks) return LFA_E_INVALID;
 	if (!g_rccl.load()) return lfa_fail(s, LFA_E_UNSUPPORTED, "librccl could not be loaded");
 	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_corr_commit(s));
 	RcclDist *d = new RcclDist();
 	d->rank = rank;
 	d->nranks = nranks;
@@ -723,6 +724,7 @@ extern "C" void lfa_dist_local_hub_destroy(lfa_hub *h) { delete h; }
 
 extern "C" int lfa_dist_init_local(lfa_sim *s, lfa_hub *h, int rank, const int32_t *layer_bounds) {
 	if (!s || !h || !layer_bounds || rank < 0 || rank >= h->n) return LFA_E_INVALID;
+	LFA_TRY(lfa_corr_commit(s));
 	LocalDist *d = new LocalDist();
 	d->rank = rank;
 	d->nranks = h->n;

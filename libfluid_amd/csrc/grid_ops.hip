@@ -526,6 +526,7 @@ static int g2p_run(lfa_sim *s, bool stale) {
 	if (!s) return LFA_E_INVALID;
 	if (!s->binned) return lfa_fail(s, LFA_E_INVALID, "lfa_g2p: call lfa_hash_particles first");
 	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_corr_commit(s));
 	LFA_TRY(lfa_dist_refresh_grid(s, false));  // extrapolated velocities of the neighbour's adjacent layer
 	if (!s->n_ptiles) {
 		s->vc_pending = false;

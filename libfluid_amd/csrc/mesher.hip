@@ -580,6 +580,7 @@ extern "C" int lfa_mesher_sample_sim(lfa_mesher *m, lfa_sim *s, double r) {
 	if (!m || !s) return LFA_E_INVALID;
 	if (s->device != m->device) return mfail(m, LFA_E_INVALID, "lfa_mesher_sample_sim: handles live on different devices");
 	MSH_HIP(m, hipSetDevice(m->device));
+	if (lfa_corr_join(s) < 0) return mfail(m, LFA_E_HIP, "lfa_mesher_sample_sim: joining the simulation's position correction failed");
 	size_t n = s->np, n_live = s->np;
 	if (s->dist) {
 		// a rank of a slab run: its own particles and the ghost copies of the neighbours' adjacent tile layers (8 cells each side);

@@ -353,6 +353,7 @@ static void launch_atomic(lfa_sim *s, const ParticleSoA &p) {
 int lfa_p2g_run(lfa_sim *s, bool fuse_gravity, double dt) {
 	if (!s->binned) return lfa_fail(s, LFA_E_INVALID, "lfa_p2g: call lfa_hash_particles first");
 	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_corr_commit(s));
 	const int method = s->prm.simulation_method;
 	if (method == LFA_FLIP_BLEND && !s->uo) {
 		LFA_HIP(s, hipMalloc(&s->uo, s->ncp * 4));

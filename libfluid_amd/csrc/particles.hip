@@ -830,42 +830,69 @@ k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx
 					}
 				}
 			};
-			auto pair = [&](uint32_t q, float qx, float qy, float qz) {
-				const float dx = mx - qx, dy = my - qy, dz = mz - qz;
-				const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-				const float kl = __builtin_fmaf(-d2, inv_re2, 1.0f);
-				if (kl > 0.0f) {
-					if (d2 < 1e-12f) {
-						if (q != me) { sx += hash_unit(j, q, 0); sy += hash_unit(j, q, 1); sz += hash_unit(j, q, 2); }
-					} else {
-						const float f = kl * kl * kl * rsqrtf(d2);
-						sx += f * dx; sy += f * dy; sz += f * dz;
+			// The nine x-runs of three fine cells around the particle; `p2` takes two candidates at a time (a far-away dummy pads
+			// an odd tail: it contributes exactly 0).
+			auto walk = [&](auto &&p2, auto &&p2_centre) {
+				for (int dz = -1; dz <= 1; ++dz) {
+					const int zz = fz + dz;
+					if (zz < 0 || zz >= FINE_NZ) continue;
+					for (int dy = -1; dy <= 1; ++dy) {
+						const int yy = fy + dy;
+						if (yy < 0 || yy >= FINE_NX) continue;
+						const int row = FINE_NX * (yy + FINE_NX * zz);
+						const uint32_t b = foff[row + xa], e = foff[row + xb + 1];
+						auto run = [&](auto &&pp) {
+							uint32_t q = b;
+							for (; q + 4 <= e; q += 4) {
+								const float x0 = px[q], x1 = px[q + 1], x2 = px[q + 2], x3 = px[q + 3];
+								const float y0 = py[q], y1 = py[q + 1], y2 = py[q + 2], y3 = py[q + 3];
+								const float z0 = pz[q], z1 = pz[q + 1], z2 = pz[q + 2], z3 = pz[q + 3];
+								pp(q, f2{x0, x1}, f2{y0, y1}, f2{z0, z1});
+								pp(q + 2, f2{x2, x3}, f2{y2, y3}, f2{z2, z3});
+							}
+							if (q + 2 <= e) {
+								pp(q, f2{px[q], px[q + 1]}, f2{py[q], py[q + 1]}, f2{pz[q], pz[q + 1]});
+								q += 2;
+							}
+							if (q < e) pp(q, f2{px[q], 1e6f}, f2{py[q], 1e6f}, f2{pz[q], 1e6f});
+						};
+						if (dy == 0 && dz == 0) run(p2_centre);  // (uniform) the run that holds the particle itself
+						else run(p2);
 					}
 				}
 			};
-			for (int dz = -1; dz <= 1; ++dz) {
-				const int zz = fz + dz;
-				if (zz < 0 || zz >= FINE_NZ) continue;
-				for (int dy = -1; dy <= 1; ++dy) {
-					const int yy = fy + dy;
-					if (yy < 0 || yy >= FINE_NX) continue;
-					const int row = FINE_NX * (yy + FINE_NX * zz);
-					const uint32_t b = foff[row + xa], e = foff[row + xb + 1];
-					uint32_t q = b;
-					for (; q + 4 <= e; q += 4) {
-						const float x0 = px[q], x1 = px[q + 1], x2 = px[q + 2], x3 = px[q + 3];
-						const float y0 = py[q], y1 = py[q + 1], y2 = py[q + 2], y3 = py[q + 3];
-						const float z0 = pz[q], z1 = pz[q + 1], z2 = pz[q + 2], z3 = pz[q + 3];
-						pair2(q, f2{x0, x1}, f2{y0, y1}, f2{z0, z1});
-						pair2(q + 2, f2{x2, x3}, f2{y2, y3}, f2{z2, z3});
-					}
-					// tail of 1-3: pairs again (an odd one out is paired with a far-away dummy): at most two evaluations instead of three
-					if (q + 2 <= e) {
-						pair2(q, f2{px[q], px[q + 1]}, f2{py[q], py[q + 1]}, f2{pz[q], pz[q + 1]});
-						q += 2;
-					}
-					if (q < e) pair2(q, f2{px[q], 1e6f}, f2{py[q], 1e6f}, f2{pz[q], 1e6f});
-				}
+			// Fast walk, no branch per candidate: the force is evaluated for every candidate with the kernel clamped at 0 - the same
+			// sums, since fma(0, d, s) == s. The self pair (d = 0 exactly) contributes 0 through d^2 + 1e-30. What this cannot do
+			// is the reference's random push for COINCIDENT pairs (d^2 < 1e-12, :584-587): a lane that has met one - a d^2 below
+			// the threshold in the eight other runs (running minimum), or a second one in its own run (count) - redoes its
+			// particle with the branching walk.
+			float d2_min = 1.0f;
+			uint32_t n_tiny = 0;
+			auto fast = [&](f2 qx, f2 qy, f2 qz) -> f2 {
+				const f2 dx = mx - qx, dy = my - qy, dz = mz - qz;
+				const f2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dx, dx, (f2)1e-30f)));
+				f2 kl;
+				kl.x = __builtin_amdgcn_fmed3f(__builtin_fmaf(-d2.x, inv_re2, 1.0f), 0.0f, 1.0f);
+				kl.y = __builtin_amdgcn_fmed3f(__builtin_fmaf(-d2.y, inv_re2, 1.0f), 0.0f, 1.0f);
+				f2 f = kl * kl * kl;
+				f.x *= __builtin_amdgcn_rsqf(d2.x);  // d^2 >= 1e-30: a normal number, the bare v_rsq_f32 (what rsqrtf compiles to
+				f.y *= __builtin_amdgcn_rsqf(d2.y);  // behind the d^2 >= 1e-12 test of the branching walk)
+				s2x = __builtin_elementwise_fma(f, dx, s2x);
+				s2y = __builtin_elementwise_fma(f, dy, s2y);
+				s2z = __builtin_elementwise_fma(f, dz, s2z);
+				return d2;
+			};
+			walk([&](uint32_t, f2 qx, f2 qy, f2 qz) {
+				     const f2 d2 = fast(qx, qy, qz);
+				     d2_min = fminf(d2_min, fminf(d2.x, d2.y));
+			     },
+			     [&](uint32_t, f2 qx, f2 qy, f2 qz) {
+				     const f2 d2 = fast(qx, qy, qz);
+				     n_tiny += (d2.x < 1e-12f ? 1u : 0u) + (d2.y < 1e-12f ? 1u : 0u);
+			     });
+			if (d2_min < 1e-12f || n_tiny != 1u) {  // rare
+				s2x = 0.f; s2y = 0.f; s2z = 0.f;
+				walk(pair2, pair2);
 			}
 			sx += s2x.x + s2x.y;
 			sy += s2y.x + s2y.y;
@@ -1072,6 +1099,7 @@ extern "C" int lfa_update_sources(lfa_sim *s, uint64_t *n_seeded) {
 	if (n_seeded) *n_seeded = 0;
 	if (!s->binned) return lfa_fail(s, LFA_E_INVALID, "lfa_update_sources: call lfa_hash_particles first");
 	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_corr_commit(s));
 	LFA_TRY(lfa_sources_sync(s));
 	const size_t n = s->n_src_entries;
 	if (!n) return LFA_OK;
@@ -1118,6 +1146,7 @@ static int refresh_tile_clear(lfa_sim *s) {
 extern "C" int lfa_advect_collide(lfa_sim *s, double dt) {
 	if (!s) return LFA_E_INVALID;
 	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_corr_commit(s));
 	LFA_TRY(lfa_particles_materialize(s));  // reads v
 	const size_t n = s->binned ? s->np_live : s->np;
 	LFA_TRY(lfa_sources_sync(s));
@@ -1138,10 +1167,17 @@ extern "C" int lfa_advect_collide(lfa_sim *s, double dt) {
 	return LFA_OK;
 }
 
-extern "C" int lfa_correct_collide(lfa_sim *s, double dt) {
-	if (!s) return LFA_E_INVALID;
-	if (!s->binned) return lfa_fail(s, LFA_E_INVALID, "lfa_correct_collide: call lfa_hash_particles first");
-	LFA_HIP(s, hipSetDevice(s->device));
+/// The correction's scratch for the cell-ordered positions: four consecutive v / c arrays that are free between the binning and
+/// the G2P - the other buffer's v.. ; with a deferred binning, where the other buffer still holds the v (and for APIC the C)
+/// that the P2G / G2P read: this buffer's own v.. (APIC: the G2P is yet to fill them) or the other buffer's c[0..3] (PIC /
+/// FLIP: its C has moved here already)
+static float4 *correction_scratch(lfa_sim *s) {
+	ParticleSoA &cur = s->pb[s->cur], &oth = s->pb[s->cur ^ 1];
+	return (float4 *)(!s->vc_pending ? oth.v[0] : (s->vc_with_c ? cur.v[0] : oth.c[0]));
+}
+
+/// First half of lfa_correct_collide: per-cell particle lists + cell-ordered positions (reads the (key, t) of the current binning).
+static int correct_build_index(lfa_sim *s) {
 	const size_t n = s->np_live;
 	if (!n && !s->dist) return LFA_OK;
 	if (!s->cell_start) {
@@ -1160,22 +1196,30 @@ extern "C" int lfa_correct_collide(lfa_sim *s, double dt) {
 	LFA_TRY(refresh_tile_clear(s));
 	const int n_index = s->dist ? s->n_ptiles_all : s->n_ptiles;
 	const int grid = n_index < 16384 ? (n_index > 0 ? n_index : 1) : 16384;
-	ParticleSoA &cur = s->pb[s->cur], &oth = s->pb[s->cur ^ 1];
-	// cell-ordered positions: scratch in four consecutive v / c arrays that are free right now - the other buffer's v.. ; with a
-	// deferred binning, where the other buffer still holds the v (and for APIC the C) that the P2G / G2P read: this buffer's
-	// own v.. (APIC: the G2P is yet to fill them) or the other buffer's c[0..3] (PIC / FLIP: its C has moved here already)
-	float4 *spos = (float4 *)(!s->vc_pending ? oth.v[0] : (s->vc_with_c ? cur.v[0] : oth.c[0]));
+	ParticleSoA &cur = s->pb[s->cur];
+	float4 *spos = correction_scratch(s);
 	if (s->timing && n) LFA_HIP(s, hipEventRecord(s->ev[40], s->stream));
 	hipLaunchKernelGGL(k_build_cell_index, dim3(grid), dim3(256), 0, s->stream, s->dist ? s->ptiles_all : s->ptiles, n_index, cur.key,
 	                   cur.t[0], cur.t[1], cur.t[2], s->tile_start, s->tile_count, s->cell_start, spos, s->cell_count,
 	                   s->slab_lo * L, s->slab_hi * L);
 	LFA_LAUNCH_CHECK(s);
+	return LFA_OK;
+}
+
+/// Second half: the pairwise correction + collision; writes (key, t) in place.
+static int correct_apply(lfa_sim *s, double dt) {
+	const size_t n = s->np_live;
+	ParticleSoA &cur = s->pb[s->cur], &oth = s->pb[s->cur ^ 1];
+	float4 *spos = correction_scratch(s);
 	if (n) {
 		// LDS-tiled pass; half tiles whose neighbourhood exceeds the LDS capacity are flagged and redone by the global-gather
 		// kernel (restricted to those particles)
-		uint32_t *ovf = (uint32_t *)s->partials;  // scratch: 2 * n_ptiles bits
 		const size_t ovf_words = ((size_t)CORR_PARTS * s->n_ptiles + 31) / 32 + 1;
-		if (ovf_words * 4 > 16384 * 8) return lfa_fail(s, LFA_E_INVALID, "too many particle tiles for the overflow bitmap");
+		if (!s->corr_ovf) {  // 2 bits per tile of the grid; its own array: the pressure solve may be running beside this
+			hipError_t e = hipMalloc(&s->corr_ovf, (((size_t)CORR_PARTS * s->g.nt + 31) / 32 + 1) * 4);
+			if (e != hipSuccess) return lfa_fail(s, LFA_E_OOM, "hipMalloc of the correction's overflow bitmap failed");
+		}
+		uint32_t *ovf = s->corr_ovf;
 		LFA_HIP(s, hipMemsetAsync(ovf, 0, ovf_words * 4, s->stream));
 		{
 			const int work = CORR_PARTS * s->n_ptiles, g2 = work < 65536 ? (work > 0 ? work : 1) : 65536;
@@ -1204,15 +1248,93 @@ extern "C" int lfa_correct_collide(lfa_sim *s, double dt) {
 	return LFA_OK;
 }
 
+extern "C" int lfa_correct_collide(lfa_sim *s, double dt) {
+	if (!s) return LFA_E_INVALID;
+	if (!s->binned) return lfa_fail(s, LFA_E_INVALID, "lfa_correct_collide: call lfa_hash_particles first");
+	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_corr_commit(s));
+	if (!s->np_live && !s->dist) return LFA_OK;
+	LFA_TRY(correct_build_index(s));
+	return correct_apply(s, dt);
+}
+
+int lfa_corr_join(lfa_sim *s) {
+	if (!s->corr_in_flight) return LFA_OK;
+	s->corr_in_flight = false;
+	LFA_HIP(s, hipStreamWaitEvent(s->stream, s->ev_cjoin, 0));
+	return LFA_OK;
+}
+
+extern "C" int lfa_correct_collide_begin(lfa_sim *s, double dt) {
+	if (!s) return LFA_E_INVALID;
+	if (!s->binned) return lfa_fail(s, LFA_E_INVALID, "lfa_correct_collide_begin: call lfa_hash_particles first");
+	if (s->dist) return lfa_fail(s, LFA_E_UNSUPPORTED, "lfa_correct_collide_begin: slab decompositions exchange particles inside the correction (use lfa_correct_collide)");
+	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_corr_commit(s));
+	if (!s->np_live) return LFA_OK;
+	LFA_HIP(s, hipEventRecord(s->ev_cfork, s->stream));
+	LFA_HIP(s, hipStreamWaitEvent(s->stream3, s->ev_cfork, 0));
+	hipStream_t main_stream = s->stream;
+	s->stream = s->stream3;
+	int rc = correct_build_index(s);
+	if (rc == LFA_OK) rc = correct_apply(s, dt);
+	s->stream = main_stream;
+	const hipError_t e1 = s->timing ? hipEventRecord(s->ev[LFA_EV_CORRECT_END], s->stream3) : hipSuccess;
+	// the join event is recorded whatever happened: the main stream waits for it before it touches particles again
+	const hipError_t e2 = hipEventRecord(s->ev_cjoin, s->stream3);
+	s->corr_in_flight = true;
+	s->corr_undo_valid = rc == LFA_OK;
+	if (rc < 0) return rc;
+	LFA_HIP(s, e1);
+	LFA_HIP(s, e2);
+	return LFA_OK;
+}
+
+extern "C" int lfa_correct_collide_end(lfa_sim *s) {
+	if (!s) return LFA_E_INVALID;
+	LFA_HIP(s, hipSetDevice(s->device));
+	return lfa_corr_join(s);
+}
+
+namespace {
+/// (key, t) of before the correction: the keys from their copy, the fractions from the cell-ordered records (record k
+/// belongs to particle spos[k].w) - both are inputs the correction does not write.
+__global__ void __launch_bounds__(256)
+k_correct_undo(size_t n, const float4 *spos, const uint32_t *old_key, uint32_t *key, float *t0, float *t1, float *t2) {
+	const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n) return;
+	const float4 rec = spos[k];
+	const uint32_t i = __float_as_uint(rec.w);
+	t0[i] = rec.x; t1[i] = rec.y; t2[i] = rec.z;
+	key[k] = old_key[k];
+}
+}  // namespace
+
+extern "C" int lfa_correct_collide_undo(lfa_sim *s) {
+	if (!s) return LFA_E_INVALID;
+	if (!s->corr_in_flight) return lfa_fail(s, LFA_E_INVALID, "lfa_correct_collide_undo: no correction between lfa_correct_collide_begin and _end");
+	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_corr_commit(s));
+	const size_t n = s->np_live;
+	if (!n) return LFA_OK;
+	ParticleSoA &cur = s->pb[s->cur], &oth = s->pb[s->cur ^ 1];
+	hipLaunchKernelGGL(k_correct_undo, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, (const float4 *)correction_scratch(s),
+	                   (const uint32_t *)oth.key, cur.key, cur.t[0], cur.t[1], cur.t[2]);
+	LFA_LAUNCH_CHECK(s);
+	return LFA_OK;
+}
+
 /// Device-resident simulation::time_step(dt) (src/simulation.cpp:43-125) without fluid sources and host callbacks:
 /// advect+collide, hash, P2G, gravity, pressure solve, pressure gradient, correct+collide, extrapolate, hash, G2P.
 int lfa_g2p_stale(lfa_sim *s);  // grid_ops.hip
 extern "C" int lfa_time_step(lfa_sim *s, double dt, double *residual, uint64_t *iterations) {
 	if (!s) return LFA_E_INVALID;
 	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_corr_commit(s));
 	const bool tm = s->timing;
 	// stage boundaries: ev[24 + k]
-	enum { B_START = 24, B_ADVECT, B_BIN, B_P2G, B_SOLVE, B_APPLY, B_CORRECT, B_EXTRAP, B_G2P };
+	enum { B_START = 24, B_ADVECT, B_BIN, B_P2G, B_SOLVE, B_APPLY, B_CORRECT, B_EXTRAP, B_G2P, B_JOIN };
+	static_assert(B_CORRECT == LFA_EV_CORRECT_END, "event slot of the end of the correction");
 	auto rec = [&](int id) -> int {
 		if (tm) LFA_HIP(s, hipEventRecord(s->ev[id], s->stream));
 		return LFA_OK;
@@ -1223,19 +1345,36 @@ extern "C" int lfa_time_step(lfa_sim *s, double dt, double *residual, uint64_t *
 	LFA_TRY(lfa_hash_particles(s));
 	if (!s->sources.empty()) LFA_TRY(lfa_update_sources(s, nullptr));  // _update_sources + hash_particles (:63-64)
 	LFA_TRY(rec(B_BIN));
+	// The correction reads and writes particle positions only, the pressure solve / gradient / extrapolation grid arrays only:
+	// the two run side by side (the solve is a chain of short launch- and HBM-bound kernels, the correction one long VALU-bound
+	// one); the correction's stream has the lower priority. (Starting its cell index already beside the P2G - it only reads the
+	// binned (key, t) - changed nothing at C4.) Slabs exchange ghost particles and migrate inside the correction, on the main
+	// stream: serial there.
+	const bool overlap = s->overlap_correction && !s->dist && s->np_live;
 	LFA_TRY(lfa_p2g_run(s, true, dt));
 	LFA_TRY(rec(B_P2G));
+	if (overlap) LFA_TRY(lfa_correct_collide_begin(s, dt));
 	double res = 0.0;
 	uint64_t it = 0;
-	int rc = lfa_pcg_solve(s, dt, &res, &it);
-	if (rc < 0) return rc;
-	LFA_TRY(rec(B_SOLVE));
-	LFA_TRY(lfa_apply_pressure(s, dt));
-	LFA_TRY(rec(B_APPLY));
-	LFA_TRY(lfa_correct_collide(s, dt));
-	LFA_TRY(rec(B_CORRECT));
-	LFA_TRY(lfa_extrapolate(s));  // the valid set is the one of the P2G-time hash, like the reference (:119)
-	LFA_TRY(rec(B_EXTRAP));
+	int rc = LFA_OK;
+	auto grid_stages = [&]() -> int {
+		rc = lfa_pcg_solve(s, dt, &res, &it);
+		if (rc < 0) return rc;
+		LFA_TRY(rec(B_SOLVE));
+		LFA_TRY(lfa_apply_pressure(s, dt));
+		LFA_TRY(rec(B_APPLY));
+		if (!overlap) {
+			LFA_TRY(lfa_correct_collide(s, dt));
+			LFA_TRY(rec(B_CORRECT));
+		}
+		LFA_TRY(lfa_extrapolate(s));  // the valid set is the one of the P2G-time hash, like the reference (:119)
+		return rec(B_EXTRAP);
+	};
+	const int rc_grid = grid_stages();
+	// joined whatever happened in between: nothing that follows on the main stream may race with the correction
+	if (overlap) LFA_TRY(lfa_corr_join(s));
+	if (rc_grid < 0) return rc_grid;
+	LFA_TRY(rec(B_JOIN));
 	// The G2P gathers per tile. Single domain: the particles keep the order of the P2G-time binning and the few whose
 	// corrected position left their tile take the global-gather path (lfa_g2p_stale); like after lfa_advect_collide the
 	// order is stale afterwards and the next step re-bins. Slabs: re-bin first (arrivals from the neighbour ranks).
@@ -1274,17 +1413,28 @@ extern "C" int lfa_time_step(lfa_sim *s, double dt, double *residual, uint64_t *
 		} else {
 			m[7] = m[8] = 0.0;
 		}
-		LFA_TRY(span(B_APPLY, B_CORRECT, m[9]));
-		LFA_TRY(span(B_CORRECT, B_EXTRAP, m[10]));
-		LFA_TRY(span(B_EXTRAP, B_G2P, m[11]));
+		// overlapped: the correction's own span on its stream (its kernels share the device with the solve's)
+		if (overlap && !s->np_live) {
+			m[9] = 0.0;
+		} else {
+			LFA_TRY(span(overlap ? 40 : B_APPLY, B_CORRECT, m[9]));
+		}
+		LFA_TRY(span(overlap ? B_APPLY : B_CORRECT, B_EXTRAP, m[10]));
+		LFA_TRY(span(B_JOIN, B_G2P, m[11]));
+		m[15] = overlap ? 1.0 : 0.0;
 		LFA_TRY(span(B_START, B_G2P, m[12]));
 		m[13] = (double)it;
 		m[14] = it ? m[5] / (double)it : 0.0;
-		m[15] = 0.0;
 	}
 	if (residual) *residual = res;
 	if (iterations) *iterations = it;
 	return rc;
+}
+
+extern "C" int lfa_set_step_overlap(lfa_sim *s, int on) {
+	if (!s) return LFA_E_INVALID;
+	s->overlap_correction = on != 0;
+	return LFA_OK;
 }
 
 extern "C" int lfa_get_step_timings(lfa_sim *s, double ms[LFA_NUM_STEP_TIMERS]) {

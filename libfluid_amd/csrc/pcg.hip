@@ -1990,6 +1990,7 @@ static int ev_rec(lfa_sim *s, int i) {
 extern "C" int lfa_step_hot(lfa_sim *s, double dt, double *residual, uint64_t *iterations) {
 	if (!s) return LFA_E_INVALID;
 	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_corr_commit(s));
 	LFA_TRY(ev_rec(s, 0));
 	LFA_TRY(lfa_hash_particles(s));
 	LFA_TRY(ev_rec(s, 1));
@@ -2108,6 +2109,7 @@ extern "C" int lfa_bench_kernel(lfa_sim *s, int which, int reps, double *mean_ms
 	if (!s || !mean_ms || reps < 1) return LFA_E_INVALID;
 	if (!s->binned || !s->n_ptiles) return lfa_fail(s, LFA_E_INVALID, "lfa_bench_kernel: run lfa_step_hot first");
 	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_corr_commit(s));
 	LFA_TRY(lfa_enable_timing(s, s->timing ? 1 : 0));
 	if (!s->ev_created) {
 		for (auto &e : s->ev) LFA_HIP(s, hipEventCreate(&e));

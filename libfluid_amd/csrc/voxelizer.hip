@@ -576,6 +576,7 @@ extern "C" int lfa_set_solid_from_voxels(lfa_sim *s, lfa_voxels *v, int include_
 	if (s->device != v->device) return lfa_fail(s, LFA_E_INVALID, "lfa_set_solid_from_voxels: handles live on different devices");
 	if (v->nc == 0) return LFA_OK;
 	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_corr_commit(s));
 	LFA_HIP(s, hipStreamSynchronize(v->stream));
 	const int64_t ref[3] = {s->g.nx, s->g.ny, s->g.nz};
 	const Select sel = make_select(v, include_interior, include_surface, ref);

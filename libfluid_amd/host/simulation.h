@@ -19,6 +19,10 @@
 // Two callbacks see a slightly later state than in the reference because the device fuses the collision pass into the kernel
 // before it: post_advection_callback and post_correction_callback run AFTER the collision handling that follows them in
 // src/simulation.cpp:51-59,111-117 (no host in the reference tree installs either).
+// The position correction - particle positions only - runs on a second HIP stream beside the pressure solve - grid only -
+// (`overlap_correction`, default on), in the staged step as well: callbacks between the P2G and the correction that read the
+// pressure or the grid never notice; one that asks for particles() or edits the solid cells there has the device take the
+// correction back (exactly) and run it at the reference's place.
 // The class never throws on the step path. A device error is latched: last_status() < 0, last_error() has the text, the failed
 // time_step() leaves the particles untouched and every later time_step()/update() returns immediately until clear_status().
 #pragma once
@@ -247,6 +251,7 @@ namespace fluid_amd {
 		int device = -1;                            ///< HIP device (-1: current); takes effect at resize()
 		int apic_unscaled_kernel = 1;               ///< 1: the reference's APIC hat on world distances (simulation.cpp:367-369)
 		int pcg_warm_start = 0;                     ///< 1: the PCG starts from the previous step's pressure (0: from p = 0 like the reference)
+		bool overlap_correction = true;             ///< the position correction runs on a second stream beside the pressure solve
 		int p2g_variant = LFA_P2G_LDS_BINNED, precond = LFA_PRECOND_MULTIGRID, pcg_dtype = LFA_PCG_F32;
 		double pcg_tau = 0.97, pcg_sigma = 0.25, pcg_tolerance = 1e-6;   ///< pressure_solver.h:39-41
 		std::size_t pcg_max_iterations = 200;                             ///< pressure_solver.h:42
@@ -271,6 +276,11 @@ namespace fluid_amd {
 		bool _particles_handed_out = false, _grid_handed_out = false;  // a mutable reference went out since the last hash
 		std::uint64_t _particles_hash = 0, _grid_vel_hash = 0, _grid_solid_hash = 0;
 		bool _in_step = false;     // between two device stages of a staged time_step (edits need a re-binning / a grid upload)
+		// Staged step: the correction has been started on the device's second stream right after the P2G
+		// (lfa_correct_collide_begin) although the reference runs it after the pressure gradient. Callbacks in between that only
+		// look at the pressure / the grid velocities never notice; one that asks for particles() or changes the solid cells takes
+		// the correction back (lfa_correct_collide_undo: exact) and the stage runs where the reference has it.
+		bool _corr_in_flight = false;
 
 		/// 64-bit content hash of words [first_word, first_word + n_words) of every record of `stride_words` 64-bit words:
 		/// multiply-xorshift per word, chunks of 16 Ki records combined with their index. At most 8 OpenMP threads, and only for
@@ -312,8 +322,15 @@ namespace fluid_amd {
 			return h;
 		}
 
+		/// Takes back a correction that runs ahead of the reference's step order (see _corr_in_flight).
+		bool _take_back_correction() {
+			if (!_corr_in_flight) return true;
+			_corr_in_flight = false;
+			return _ok(lfa_correct_collide_undo(_dev));
+		}
 		void _sync_host() {
 			if (_host_stale && _dev) {
+				if (!_take_back_correction()) return;
 				_particles.resize(static_cast<std::size_t>(lfa_num_particles(_dev)));  // sources create particles on the device
 				_ok(lfa_download_particles(_dev, _particles.data(), _particles.size(), LFA_DL_POSITIONS));
 				_host_stale = false;
@@ -496,6 +513,7 @@ namespace fluid_amd {
 			const std::uint64_t vel_before = _grid_vel_hash, solid_before = _grid_solid_hash;
 			_rehash_grid();
 			if (_grid_solid_hash != solid_before) _solids_dirty = true;
+			if (_solids_dirty && !_take_back_correction()) return false;  // the correction collides against the solid cells
 			if (_in_step && (_grid_vel_hash != vel_before || _grid_solid_hash != solid_before)) {
 				if (!_ok(lfa_upload_cells(_dev, _grid.grid().data()))) return false;
 				_solids_dirty = false;
@@ -508,6 +526,9 @@ namespace fluid_amd {
 			_grid_solid_hash = _solid_hash();
 		}
 		if (_dev_stale) {
+			// (a correction running ahead worked on the particles this upload replaces: lfa_upload_particles joins it, and the
+			// stage runs again, serially, where the reference has it)
+			_corr_in_flight = false;
 			if (!_ok(lfa_upload_particles(_dev, _particles.data(), _particles.size()))) return false;
 			_dev_stale = false;
 			_host_stale = false;
@@ -542,9 +563,15 @@ namespace fluid_amd {
 		_in_step = true;
 		bool ok = stage(lfa_advect_collide(_dev, dt)) && after(post_advection_callback) &&
 		          stage(lfa_hash_particles(_dev)) && (sources.empty() || stage(lfa_update_sources(_dev, nullptr))) &&
-		          stage(lfa_p2g(_dev)) && after(post_particle_to_grid_transfer_callback) &&
-		          stage(lfa_add_gravity(_dev, dt)) && after(post_gravity_callback) &&
-		          stage(lfa_pcg_solve(_dev, dt, &residual, &iters));
+		          stage(lfa_p2g(_dev)) && after(post_particle_to_grid_transfer_callback);
+		// From here to the correction the reference's stages touch the grid only (simulation.cpp:82-99): the correction starts now,
+		// on the second stream (see _corr_in_flight).
+		if (ok && overlap_correction) {
+			ok = _ok(lfa_correct_collide_begin(_dev, dt));
+			_corr_in_flight = ok;
+		}
+		ok = ok && stage(lfa_add_gravity(_dev, dt)) && after(post_gravity_callback) &&
+		     stage(lfa_pcg_solve(_dev, dt, &residual, &iters));
 		if (ok && post_pressure_solve_callback) {
 			// the callback gets the pressure vector by reference and may edit it (simulation.h:166): n doubles down, and up again
 			// only if it did
@@ -558,9 +585,15 @@ namespace fluid_amd {
 				ok = ok && _flush_host_edits();
 			}
 		}
-		ok = ok && stage(lfa_apply_pressure(_dev, dt)) && after(post_apply_pressure_callback) &&
-		     stage(lfa_correct_collide(_dev, dt)) && after(post_correction_callback) &&
-		     stage(lfa_extrapolate(_dev)) && stage(lfa_g2p(_dev));
+		ok = ok && stage(lfa_apply_pressure(_dev, dt)) && after(post_apply_pressure_callback);
+		if (ok && _corr_in_flight) {  // nobody has asked for it to be taken back: it is the reference's correction, finished early
+			_corr_in_flight = false;
+			ok = stage(lfa_correct_collide_end(_dev));
+		} else {
+			ok = ok && stage(lfa_correct_collide(_dev, dt));
+		}
+		_corr_in_flight = false;
+		ok = ok && after(post_correction_callback) && stage(lfa_extrapolate(_dev)) && stage(lfa_g2p(_dev));
 		_in_step = false;
 		if (ok && post_grid_to_particle_transfer_callback) {
 			post_grid_to_particle_transfer_callback(dt);

@@ -8,6 +8,9 @@
 //         two       the first two only (nothing touches particles() during the run)
 //         edit      callbacks that EDIT device-resident state through the mutable references: the pressure vector, the grid
 //                   (post_gravity: zero a face) and the particles (post_g2p: scale one velocity) - the edits must reach the device
+//         window    a callback BETWEEN the P2G and the correction (post_apply_pressure) reads particles() and edits one: the class
+//                   has started the correction on the second stream by then and must take it back, exactly (prints the sum of
+//                   the x coordinates it saw: the positions of BEFORE the correction)
 //         obstacle  nocb, and the solid cells are only put in after the first step, then removed again before the last one
 //                   (the testbed's scene reset edits sim.grid() between steps, testbed/main.cpp:125-178)
 //   Prints "step_ms <mean wall milliseconds per step>" (after one warm-up step when steps > 2).
@@ -69,7 +72,7 @@ int main(int argc, char **argv) {
 	std::size_t iters_total = 0;
 	int calls = 0;
 	double max_speed = 0.0;
-	if (mode == "callbacks" || mode == "two" || mode == "edit") {
+	if (mode == "callbacks" || mode == "two" || mode == "edit" || mode == "window") {
 		sim.pre_time_step_callback = [](double step) { std::printf("  time step %g\n", step); };
 		sim.post_pressure_solve_callback = [&](double, std::vector<double> &p, double res, std::size_t it) {
 			iters_total += it;
@@ -91,6 +94,13 @@ int main(int argc, char **argv) {
 		sim.post_gravity_callback = [&](double) { sim.grid().grid()(1, 1, 1).velocities_posface = vec3d(); };
 		sim.post_grid_to_particle_transfer_callback = [&](double) { sim.particles()[0].velocity = sim.particles()[0].velocity * 0.5; };
 	}
+	if (mode == "window")
+		sim.post_apply_pressure_callback = [&](double) {
+			double sum = 0.0;
+			for (const simulation::particle &p : sim.particles()) sum += p.position.x;
+			std::printf("window_pos_sum %.9f\n", sum);
+			sim.particles()[0].velocity = sim.particles()[0].velocity * 0.5;
+		};
 	double wall_ms = 0.0;
 	int timed = 0;
 	for (int i = 0; i < steps; ++i) {

@@ -147,6 +147,39 @@ def test_edits_through_mutable_references_reach_the_device(tmp_path):
 
 
 @pytest.mark.gpu
+def test_callback_between_p2g_and_correction_sees_uncorrected_particles(tmp_path):
+    """With stage callbacks the class starts the position correction on the device's second stream right after the P2G
+    (lfa_correct_collide_begin). A callback that asks for particles() before the reference's correction stage
+    (post_apply_pressure here) must still see - and may edit - the positions of BEFORE it: the class takes the correction
+    back (lfa_correct_collide_undo) and runs it at the reference's place. Against the same stage sequence made serially
+    over the C ABI; an inexact take-back would be off by the correction's displacements (1e-2 cells)."""
+    c, parts, solid = fullstep_inputs()
+    exe = build_driver(tmp_path)
+    out, stdout, _ = run_driver(tmp_path, exe, c, parts, solid, "window")
+    seen = [float(m) for m in re.findall(r"window_pos_sum ([0-9.eE+-]+)", stdout)]
+    s = lfa.Sim(c["size"], method=c["method"], blending=c["blend"])
+    s.set_solid_cells(solid)
+    s.upload_particles(parts)
+    host, want_seen = parts.copy(), []
+    for _ in range(c["steps"]):
+        s.advect_collide(c["dt"]); s.hash(); s.p2g(); s.add_gravity(c["dt"]); s.solve(c["dt"]); s.apply_pressure(c["dt"])
+        host = s.download_particles(into=host, write_positions=True)
+        want_seen.append(float(host["pos"][:, 0].sum()))
+        host["vel"][0] *= 0.5
+        s.upload_particles(host)
+        s.hash()
+        s.correct_collide(c["dt"]); s.extrapolate(); s.g2p()
+    want = s.download_particles(into=host.copy(), write_positions=True)
+    s.close()
+    assert len(seen) == c["steps"]
+    # 9600 positions of O(10): a correction left in place would move the sum by ~1 (1e-4 cells per particle on average)
+    assert np.allclose(seen, want_seen, rtol=0, atol=2e-3), (seen, want_seen)
+    out, want = by_id(out, len(parts)), by_id(want, len(parts))
+    util.assert_close(out["pos"], want["pos"], 1e-7, "positions", atol=2e-6)
+    util.assert_close(out["vel"], want["vel"], 1e-6, "velocities", atol=2e-4)
+
+
+@pytest.mark.gpu
 def test_solid_cells_edited_between_steps(tmp_path):
     """Hosts put solids in and take them out through sim.grid() between steps (testbed scene reset, testbed/main.cpp:125-178;
     grid_node.cpp:330-339). Step 0 runs without the sphere, steps 1 .. n-2 with it, the last one without again."""

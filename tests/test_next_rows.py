@@ -152,6 +152,122 @@ def test_position_correction_fallback_for_crowded_tiles(dense):
 
 
 @pytest.mark.gpu
+def test_position_correction_with_coincident_particles():
+    """Coincident pairs get a random push in the reference (src/simulation.cpp:584-587, std::random_device) and a hashed one
+    here: the branch-free pair walk of the LDS-tiled kernel detects them and redoes those particles with the branching walk.
+    Every OTHER particle reads old positions only, so it still has to match the oracle; the twins have to come apart."""
+    size, lo, hi = (24, 24, 24), (2, 2, 2), (18, 16, 18)
+    parts = util.scenes.seed_block(lo, hi)
+    rng = np.random.default_rng(11)
+    twins = rng.choice(len(parts), 200, replace=False)
+    parts = np.concatenate([parts, parts[twins]])
+    parts["cx"][:, 0] = np.arange(len(parts))
+    n0 = len(parts) - len(twins)
+    cpu = orc.CpuSim(size, method=orc.PIC)
+    cpu.set_particles(parts)
+    cpu.hash()
+    cpu.L.correct_positions(cpu.h, DT_CORR)
+    cpu.L.detect_collisions(cpu.h)
+    want = by_id(cpu.particles())["pos"].copy()
+    cpu.close()
+    s = lfa.Sim(size, method=lfa.PIC)
+    s.upload_particles(parts)
+    s.hash()
+    s.correct_collide(DT_CORR)
+    out = by_id(s.download_particles(into=parts.copy(), write_positions=True))
+    s.close()
+    single = np.ones(len(parts), bool)
+    single[twins] = False
+    single[n0:] = False
+    assert np.abs(out["pos"][single] - want[single]).max() < 5e-5
+    apart = np.abs(out["pos"][twins] - out["pos"][n0:]).max(axis=1)
+    assert (apart > 1e-4).all() and np.isfinite(out["pos"]).all()
+    # a twin feels its other partners like the oracle's does; the push itself is a unit-box vector times dt * stiffness * re
+    assert np.abs(out["pos"][twins] - want[twins]).max() < 2.0 * DT_CORR * 5.0 * 0.7072 * np.sqrt(3.0) + 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", [lfa.APIC, lfa.FLIP_BLEND, lfa.PIC])
+def test_correct_collide_begin_end_undo(method):
+    """lfa_correct_collide_begin / _end = lfa_correct_collide on the second stream, with grid-only stages beside it;
+    _undo puts back the positions of before it, bit for bit (the correction keeps its inputs), also after a download has
+    joined it; entry points that change positions or the binning make _undo refuse."""
+    c, parts, solid = fullstep_inputs()
+    s = lfa.Sim(c["size"], method=method, blending=c["blend"])
+    s.set_solid_cells(solid)
+    s.upload_particles(parts)
+    s.advect_collide(c["dt"]); s.hash(); s.p2g()
+    before = s.download_particles(into=parts.copy(), write_positions=True)
+    s.correct_collide_begin(DT_CORR)
+    s.add_gravity(c["dt"]); s.solve(c["dt"]); s.apply_pressure(c["dt"])  # grid only: beside the correction
+    s.correct_collide_end()
+    moved = s.download_particles(into=parts.copy(), write_positions=True)
+    assert np.abs(moved["pos"] - before["pos"]).max() > 1e-2
+    with pytest.raises(lfa.LibfluidError):  # _end .. then a binning: nothing to take back any more
+        s.hash()
+        s.correct_collide_undo()
+    # the same from the same state, serially
+    t = lfa.Sim(c["size"], method=method, blending=c["blend"])
+    t.set_solid_cells(solid)
+    t.upload_particles(parts)
+    t.advect_collide(c["dt"]); t.hash(); t.p2g(); t.add_gravity(c["dt"]); t.solve(c["dt"]); t.apply_pressure(c["dt"])
+    t.correct_collide(DT_CORR)
+    serial = t.download_particles(into=parts.copy(), write_positions=True)
+    assert np.abs(moved["pos"] - serial["pos"]).max() < 2e-6  # (neighbour sums in the order of an atomically ordered binning)
+    # undo: after grid-only stages beside it; and after a download has joined it - then either exact or refused (a download that
+    # had to complete a deferred binning has overwritten the arrays the correction keeps its inputs in)
+    for joined_first in (False, True):
+        t.hash()
+        here = t.download_particles(into=parts.copy(), write_positions=True)
+        t.hash()  # (a deferred binning again: the download above completed the last one)
+        t.correct_collide_begin(DT_CORR)
+        if joined_first:
+            mid = t.download_particles(into=parts.copy(), write_positions=True)
+            assert np.abs(mid["pos"] - here["pos"]).max() > 1e-3
+            try:
+                t.correct_collide_undo()
+            except lfa.LibfluidError:
+                continue
+        else:
+            t.extrapolate()
+            t.correct_collide_undo()
+        back = t.download_particles(into=parts.copy(), write_positions=True)
+        assert np.array_equal(back["pos"], here["pos"]) and np.array_equal(back["vel"], here["vel"])
+        t.correct_collide(DT_CORR)  # and the stage still runs from there
+    s.close()
+    t.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", [lfa.APIC, lfa.FLIP_BLEND])
+def test_time_step_with_the_correction_beside_the_solve_equals_the_serial_step(method):
+    """lfa_time_step forks the position correction onto a second stream after the P2G and joins before the G2P
+    (lfa_set_step_overlap): same kernels on the same data. Not bitwise - the binning orders the particles of a tile with
+    atomics, so the correction's neighbour sums are taken in a different order from run to run: two SERIAL runs of two steps
+    differ by 1e-6 cells / 4e-4 in velocities of O(30) as well (and after five, when particles piled up in a corner coincide
+    and the hashed stand-in for the reference's random push depends on that order, by 0.1 cells for a few of them). A stage
+    that read positions before the other stream had written them would be off by the correction's displacements, 1e-2 cells."""
+    c, parts, solid = fullstep_inputs()
+    outs = []
+    for overlap in (True, False):
+        s = lfa.Sim(c["size"], method=method, blending=c["blend"])
+        s.set_solid_cells(solid)
+        s.upload_particles(parts)
+        s.set_step_overlap(overlap)
+        s.enable_timing(True)
+        for _ in range(2):
+            _, it, rc = s.time_step(c["dt"])
+            assert rc == 0 and it > 0
+        assert s.step_timings()["overlapped"] == float(overlap)
+        outs.append(s.download_particles(into=parts.copy(), write_positions=True))
+        s.close()
+    a, b = outs  # (download_particles keeps the upload order)
+    assert np.abs(a["pos"] - b["pos"]).max() < 1e-5
+    assert np.abs(a["vel"] - b["vel"]).max() < 3e-3
+    assert np.abs(a["pos"] - parts["pos"]).max() > 0.1
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("method", [lfa.PIC, lfa.FLIP_BLEND, lfa.APIC])
 def test_g2p_on_the_order_of_the_last_binning_equals_g2p_after_rebinning(method):
     """lfa_time_step bins once per step: after the position correction the G2P runs on the P2G-time order, and the
