@@ -109,6 +109,7 @@ struct lfa_sim {
 	float *uo = nullptr, *vo = nullptr, *wo = nullptr;
 	uint8_t *ctype = nullptr, *solid = nullptr;
 	uint32_t *cell_count = nullptr;
+	uint32_t *fine_start = nullptr;  // position correction: first record of every fine cell of every tile (particles.hip, FT_STRIDE per tile)
 	uint32_t *cell_start = nullptr;  // first entry of every cell in the cell-grouped index (rank[]), position correction only
 	float *stage = nullptr;  // P2G per-tile partial sums [n_ptiles][6][1000]
 	size_t stage_tiles = 0;

@@ -590,7 +590,7 @@ k_correct_tiled(const int *ptiles, int n_ptiles, ParticleSoA p, uint32_t *out_ke
 __global__ void __launch_bounds__(CORR_THREADS, 4)
 k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx, float *out_ty, float *out_tz, GridDims g,
                const uint8_t *solid, const uint32_t *tile_flag, const uint32_t *cell_count, const uint32_t *cell_start,
-               const float4 *spos, MoveParams mp, uint32_t *overflow_tiles, const uint8_t *tile_clear) {
+               const float4 *spos, MoveParams mp, uint32_t *overflow_tiles, const uint8_t *tile_clear, int dbg) {
 	__shared__ float px[FINE_CAP], py[FINE_CAP], pz[FINE_CAP];
 	__shared__ uint16_t hk[FINE_CAP];            // (halo cell << 6 | index in the cell) of the staged particle
 	__shared__ uint32_t fcnt[FINE_N];            // per fine cell: count, then running cursor; afterwards the own list (u16)
@@ -867,7 +867,7 @@ k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx
 			// the threshold in the eight other runs (running minimum), or a second one in its own run (count) - redoes its
 			// particle with the branching walk.
 			float d2_min = 1.0f;
-			uint32_t n_tiny = 0;
+			uint32_t n_tiny = dbg == 1 ? 1u : 0u;
 			auto fast = [&](f2 qx, f2 qy, f2 qz) -> f2 {
 				const f2 dx = mx - qx, dy = my - qy, dz = mz - qz;
 				const f2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dx, dx, (f2)1e-30f)));
@@ -882,7 +882,7 @@ k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx
 				s2z = __builtin_elementwise_fma(f, dz, s2z);
 				return d2;
 			};
-			walk([&](uint32_t, f2 qx, f2 qy, f2 qz) {
+			if (dbg != 1) walk([&](uint32_t, f2 qx, f2 qy, f2 qz) {
 				     const f2 d2 = fast(qx, qy, qz);
 				     d2_min = fminf(d2_min, fminf(d2.x, d2.y));
 			     },
@@ -917,6 +917,485 @@ k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx
 			for (int d = 0; d < 3; ++d) split_position(to[d], nn[d], nc[d], nt[d]);
 			out_key[j] = blocked_index(g, nc[0], nc[1], nc[2]);
 			out_tx[j] = nt[0]; out_ty[j] = nt[1]; out_tz[j] = nt[2];
+		}
+	}
+}
+
+
+// ------------------------------------------------------------------------------------------------ tile-aligned fine cells
+// Round 2, second version of the neighbour search. The staging of k_correct_fine (halo-cell tables, a raw list, two passes over
+// the records with LDS atomics to re-sort them by fine cell, a scan for the own list) was 2.1 of the kernel's 5.0 ms at C4 and
+// 585 of its 2140 VALU instructions per particle. Fine cells of 8/11 = 0.7273 cells (still >= re = 0.7071) are ALIGNED with the
+// 8-cell tiles - 11 per axis - so the per-tile index can be sorted by fine cell once, by the index kernel, and a workgroup's
+// block of 13 x 13 x 8 fine cells is put together from contiguous runs of its 27 source tiles: per fine row one cell of the
+// x-1 tile, the eleven cells of the own x tile (one run), one cell of the x+1 tile, in that order = sorted by fine cell.
+#define FT 11                                // fine cells per tile axis
+#define FT3 (FT * FT * FT)
+#define FT_STRIDE (FT3 + 1)                  // per tile: first record of every fine cell + the end
+#define FT_INV 1.375f                        // 11 / 8 (exact)
+#define FT_SPLIT 6                           // own fine layers (z) of part 0; part 1 takes the other FT - FT_SPLIT
+#define FB 13                                // block: the own 11 x 11 fine cells + one on each side
+#define FBZ (FT_SPLIT + 2)
+#define FB_N (FB * FB * FBZ)
+#define FB_ROWS (FB * FBZ)
+#define FINE2_CAP 5632                       // staged particles (13 x 13 x 8 fine cells hold 4160 at 8 per cell)
+#define FINE2_OWN 3072
+#define FINE2_CNT 1536                       // >= FB_N, a multiple of CORR_THREADS
+#define FIDX_STAGE 4608                      // records staged in LDS per tile by the index kernel (72 KB)
+
+__device__ inline int fine_coord(int l, float t) {
+	const int f = (int)(((float)l + t) * FT_INV);
+	return f < FT - 1 ? f : FT - 1;  // (t == 1 in the last cell: the max face belongs to the last fine cell)
+}
+/// A record of the fine index: the in-cell fractions (exact) + the particle index, and the cell inside the tile in the two top
+/// bits of the fractions (a fraction is in [0, 1]: sign and top exponent bit are clear): lx whole (3 bits); of ly, lz the lowest
+/// bit - a fine row overlaps two cells per axis at most, floor(8 f / 11) and the next one.
+__device__ inline float4 fine_record(int lx, int ly, int lz, float t0, float t1, float t2, uint32_t index) {
+	const uint32_t b0 = (__float_as_uint(t0) & 0x3FFFFFFFu) | ((uint32_t)(lx & 3) << 30);
+	const uint32_t b1 = (__float_as_uint(t1) & 0x3FFFFFFFu) | ((uint32_t)(lx >> 2) << 31) | ((uint32_t)(ly & 1) << 30);
+	const uint32_t b2 = (__float_as_uint(t2) & 0x3FFFFFFFu) | ((uint32_t)(lz & 1) << 31);
+	return make_float4(__uint_as_float(b0), __uint_as_float(b1), __uint_as_float(b2), __uint_as_float(index));
+}
+__device__ inline void fine_decode(const float4 &r, int fy, int fz, float t[3], int l[3]) {
+	const uint32_t b0 = __float_as_uint(r.x), b1 = __float_as_uint(r.y), b2 = __float_as_uint(r.z);
+	t[0] = __uint_as_float(b0 & 0x3FFFFFFFu); t[1] = __uint_as_float(b1 & 0x3FFFFFFFu); t[2] = __uint_as_float(b2 & 0x3FFFFFFFu);
+	l[0] = (int)(b0 >> 30) | ((int)(b1 >> 31) << 2);
+	const int y0 = (8 * fy) / FT, z0 = (8 * fz) / FT;
+	l[1] = y0 + ((y0 ^ (int)(b1 >> 30)) & 1);
+	l[2] = z0 + ((z0 ^ (int)(b2 >> 31)) & 1);
+}
+
+/// Per particle tile: its particles grouped by fine cell - fine_start[tile][f] = first record of fine cell f (absolute), records
+/// (fine_record) in spos. (What the reference's _space_hash is to its 27-cell walk, include/fluid/simulation.h:193-197.)
+__global__ void __launch_bounds__(256)
+k_build_fine_index(const int *ptiles, int n_ptiles, const uint32_t *key, const float *t0, const float *t1, const float *t2,
+                   const uint32_t *tile_start, const uint32_t *tile_count, uint32_t *fine_start, float4 *spos) {
+	__shared__ uint32_t cnt[FINE2_CNT];
+	__shared__ uint32_t wsum[4];
+	__shared__ float4 stage[FIDX_STAGE];
+	constexpr int PER = FINE2_CNT / 256;
+	auto fine_of = [&](uint32_t i, int l[3], float t[3]) -> int {
+		const uint32_t k = key[i];
+		l[0] = (int)(k & 7); l[1] = (int)((k >> 3) & 7); l[2] = (int)((k >> 6) & 7);
+		t[0] = t0[i]; t[1] = t1[i]; t[2] = t2[i];
+		return fine_coord(l[0], t[0]) + FT * (fine_coord(l[1], t[1]) + FT * fine_coord(l[2], t[2]));
+	};
+	for (int slot = blockIdx.x; slot < n_ptiles; slot += gridDim.x) {
+		const int tile = ptiles[slot];
+		// ghost tiles (slab decomposition) keep their particles behind the live ones: the range end comes from the count
+		const uint32_t b = tile_start[tile], e = b + tile_count[tile];
+#pragma unroll
+		for (int k = 0; k < PER; ++k) cnt[threadIdx.x + 256 * k] = 0;
+		__syncthreads();
+		for (uint32_t i = b + threadIdx.x; i < e; i += 256) {
+			int l[3];
+			float t[3];
+			atomicAdd(&cnt[fine_of(i, l, t)], 1u);
+		}
+		__syncthreads();
+		// exclusive scan: thread t owns entries PER t .. PER t + PER - 1
+		uint32_t c[PER], incl = 0;
+#pragma unroll
+		for (int k = 0; k < PER; ++k) {
+			c[k] = cnt[PER * threadIdx.x + k];
+			incl += c[k];
+		}
+		const uint32_t sum = incl;
+		const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			uint32_t t = __shfl_up(incl, o, 64);
+			if (lane >= o) incl += t;
+		}
+		if (lane == 63) wsum[wid] = incl;
+		__syncthreads();
+		uint32_t ex = b + incl - sum;
+		for (int w = 0; w < wid; ++w) ex += wsum[w];
+		__syncthreads();
+#pragma unroll
+		for (int k = 0; k < PER; ++k) {
+			const int f = PER * threadIdx.x + k;
+			cnt[f] = ex;  // cursor
+			if (f <= FT3) fine_start[(size_t)tile * FT_STRIDE + f] = ex;
+			ex += c[k];
+		}
+		__syncthreads();
+		// the records are put in place in LDS and written out as one contiguous run (scattered 16-B stores straight to HBM cost
+		// 1.6x); a tile with more particles than the staging area holds writes them directly
+		const bool staged = e - b <= FIDX_STAGE;
+		for (uint32_t i = b + threadIdx.x; i < e; i += 256) {
+			int l[3];
+			float t[3];
+			const uint32_t at = atomicAdd(&cnt[fine_of(i, l, t)], 1u);
+			const float4 rec = fine_record(l[0], l[1], l[2], t[0], t[1], t[2], i);
+			if (staged) stage[at - b] = rec;
+			else spos[at] = rec;
+		}
+		__syncthreads();
+		if (staged)
+			for (uint32_t k = threadIdx.x; k < e - b; k += 256) spos[b + k] = stage[k];
+		__syncthreads();
+	}
+}
+
+/// Where block fine cell (gx, gy, gz) - own-tile fine coordinates, -1 .. FT - lives: the source tile (-1: none) and its fine
+/// coordinates there.
+__device__ inline int fine_source(const GridDims &g, const uint32_t *tile_count, int tx, int ty, int tz, int gx, int gy, int gz, int &fx,
+                                  int &fy, int &fz) {
+	const int dx = gx < 0 ? -1 : (gx >= FT ? 1 : 0), dy = gy < 0 ? -1 : (gy >= FT ? 1 : 0), dz = gz < 0 ? -1 : (gz >= FT ? 1 : 0);
+	fx = gx - FT * dx; fy = gy - FT * dy; fz = gz - FT * dz;
+	const int x = tx + dx, y = ty + dy, z = tz + dz;
+	if ((unsigned)x >= (unsigned)g.ntx || (unsigned)y >= (unsigned)g.nty || (unsigned)z >= (unsigned)g.ntz) return -1;
+	const int tile = x + g.ntx * (y + g.nty * z);
+	return tile_count[tile] ? tile : -1;  // (tile_flag marks the DILATED set: only tiles with particles have an index)
+}
+
+/// _correct_positions + _detect_collisions for the particles of the flagged half tiles (those the LDS-tiled kernel could not
+/// hold) - or, without a flag bitmap, of all: a thread per particle gathers its 27 fine cells from the index in global memory.
+/// `n` = live particles = records of the owned tiles (ghost tiles' records lie behind them).
+__global__ void __launch_bounds__(256)
+k_correct_collide2(size_t n, ParticleSoA p, uint32_t *out_key, float *out_tx, float *out_ty, float *out_tz, GridDims g,
+                   const uint8_t *solid, const uint32_t *tile_count, const uint32_t *fine_start, const float4 *spos, MoveParams mp,
+                   const uint32_t *only_flagged, const int *tile_pslot, int p_off, const uint32_t *key_before) {
+	// A thread per RECORD of the index: everything about the particle as it was BEFORE the correction - the tiled kernel has
+	// already rewritten, in place, key and fractions of the particles it moved, and which part a particle belongs to depends on
+	// its old fraction - comes from the record (fractions, index) and the copy of the old keys.
+	const size_t rk = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (rk >= n) return;
+	const float4 me = spos[rk];
+	const size_t i = __float_as_uint(me.w);
+	const uint32_t key_i = key_before ? key_before[i] : p.key[i];
+	if (key_i == 0xFFFFFFFFu) return;
+	const int tile = (int)(key_i >> 9);
+	const int l[3] = {(int)(key_i & 7), (int)((key_i >> 3) & 7), (int)((key_i >> 6) & 7)};
+	const float t[3] = {__uint_as_float(__float_as_uint(me.x) & 0x3FFFFFFFu), __uint_as_float(__float_as_uint(me.y) & 0x3FFFFFFFu),
+	                    __uint_as_float(__float_as_uint(me.z) & 0x3FFFFFFFu)};
+	const int f[3] = {fine_coord(l[0], t[0]), fine_coord(l[1], t[1]), fine_coord(l[2], t[2])};
+	if (only_flagged) {
+		const int work = CORR_PARTS * (tile_pslot[tile] - p_off) + (f[2] >= FT_SPLIT ? 1 : 0);
+		if (!((only_flagged[work >> 5] >> (work & 31)) & 1u)) return;
+	}
+	int tx, ty, tz;
+	tile_coords(g, tile, tx, ty, tz);
+	const int nn[3] = {g.nx, g.ny, g.nz};
+	const float inv_re2 = (float)mp.inv_re2;
+	double spring[3] = {0.0, 0.0, 0.0};
+	for (int dz = -1; dz <= 1; ++dz)
+		for (int dy = -1; dy <= 1; ++dy)
+			for (int dx = -1; dx <= 1; ++dx) {
+				int sf[3];
+				const int src = fine_source(g, tile_count, tx, ty, tz, f[0] + dx, f[1] + dy, f[2] + dz, sf[0], sf[1], sf[2]);
+				if (src < 0) continue;
+				const uint32_t *fs = fine_start + (size_t)src * FT_STRIDE + (sf[0] + FT * (sf[1] + FT * sf[2]));
+				const uint32_t kb = fs[0], ke = fs[1];
+				int stx, sty, stz;
+				tile_coords(g, src, stx, sty, stz);
+				for (uint32_t k = kb; k < ke; ++k) {
+					const float4 rec = spos[k];  // the neighbours' OLD positions (the outputs go back in place)
+					if (__float_as_uint(rec.w) == (uint32_t)i) continue;
+					float nt[3];
+					int nl[3];
+					fine_decode(rec, sf[1], sf[2], nt, nl);
+					const float ddx = ((float)(8 * (tx - stx) + l[0] - nl[0]) + t[0]) - nt[0];
+					const float ddy = ((float)(8 * (ty - sty) + l[1] - nl[1]) + t[1]) - nt[1];
+					const float ddz = ((float)(8 * (tz - stz) + l[2] - nl[2]) + t[2]) - nt[2];
+					const float d2 = ddx * ddx + ddy * ddy + ddz * ddz;  // grid units^2
+					if (d2 < 1e-12f) {
+						// coincident pair: the reference adds a random unit-box vector (:584-587, std::random_device)
+						const uint32_t j = __float_as_uint(rec.w);
+						spring[0] += hash_unit((uint32_t)i, j, 0); spring[1] += hash_unit((uint32_t)i, j, 1);
+						spring[2] += hash_unit((uint32_t)i, j, 2);
+					} else {
+						const float kl = 1.0f - d2 * inv_re2;
+						if (kl > 0.0f) {
+							const float fr = kl * kl * kl * rsqrtf(d2);
+							spring[0] += (double)(fr * ddx); spring[1] += (double)(fr * ddy); spring[2] += (double)(fr * ddz);
+						}
+					}
+				}
+			}
+	const int c[3] = {8 * tx + l[0], 8 * ty + l[1], 8 * tz + l[2]};
+	double from[3], to[3];
+#pragma unroll
+	for (int d = 0; d < 3; ++d) {
+		from[d] = (double)c[d] + (double)t[d];
+		double x = from[d] + spring[d] * mp.corr;
+		to[d] = x < 0.0 ? 0.0 : ((double)nn[d] < x ? (double)nn[d] : x);  // clamp to [offset, grid max] (:604-609)
+	}
+	collide(g, solid, from, to, mp.skin);
+	int nc[3];
+	float ntt[3];
+#pragma unroll
+	for (int d = 0; d < 3; ++d) split_position(to[d], nn[d], nc[d], ntt[d]);
+	out_key[i] = blocked_index(g, nc[0], nc[1], nc[2]);
+	out_tx[i] = ntt[0]; out_ty[i] = ntt[1]; out_tz[i] = ntt[2];
+}
+
+/// LDS-tiled _correct_positions + _detect_collisions on the fine index. One workgroup per (particle tile, z part): part 0 moves the
+/// particles of fine layers 0 .. FT_SPLIT - 1, part 1 the rest; the block staged in LDS is those layers + one fine cell all around.
+__global__ void __launch_bounds__(CORR_THREADS, 4)
+k_correct_fine2(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx, float *out_ty, float *out_tz, GridDims g,
+                const uint8_t *solid, const uint32_t *tile_count, const uint32_t *fine_start, const float4 *spos, MoveParams mp,
+                uint32_t *overflow_tiles, const uint8_t *tile_clear, int dbg) {
+	__shared__ float px[FINE2_CAP], py[FINE2_CAP], pz[FINE2_CAP];
+	__shared__ uint32_t fcnt[FINE2_CNT];       // particles per block fine cell; afterwards the own list (u16)
+	__shared__ uint16_t foff[FB_N + 1];        // first staged slot of every block fine cell
+	__shared__ uint32_t rowsrc[FB_ROWS * 3];   // first source record of the three runs of a fine row (x-1 tile, own x tile, x+1 tile)
+	__shared__ uint32_t ownoff[FT * FT_SPLIT + 1];
+	__shared__ uint32_t wsum[CORR_THREADS / 64];
+	uint16_t *own = (uint16_t *)fcnt;
+	static_assert(FINE2_CNT * 2 >= FINE2_OWN && FINE2_CNT >= FB_N && FINE2_CNT % CORR_THREADS == 0, "fcnt sizing");
+	constexpr int PER = FINE2_CNT / CORR_THREADS;
+	const int nn[3] = {g.nx, g.ny, g.nz};
+	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+	for (int work = blockIdx.x; work < CORR_PARTS * n_ptiles; work += gridDim.x) {
+		const int tile = ptiles[work / CORR_PARTS], part = work % CORR_PARTS;
+		int tx, ty, tz;
+		tile_coords(g, tile, tx, ty, tz);
+		const int gz0 = part == 0 ? -1 : FT_SPLIT - 1;                  // own-tile fine layer of block layer 0
+		const int nzb = part == 0 ? FT_SPLIT + 2 : FT - FT_SPLIT + 2;   // block layers
+		const int nrows = FB * nzb, nown_rows = FT * (nzb - 2);
+		const bool open_water = (tile_clear[tile] & 1) != 0;  // no solid cell within a tile of this one
+		__syncthreads();
+		// ---- the block's fine cells: where their records are, how many
+#pragma unroll
+		for (int k = 0; k < PER; ++k) {
+			const int f = threadIdx.x + CORR_THREADS * k;
+			uint32_t cnt = 0, src0 = 0;
+			if (f < FB * nrows) {
+				const int bx = f % FB, row = f / FB, by = row % FB, bz = row / FB;
+				int fx, fy, fz;
+				const int src = fine_source(g, tile_count, tx, ty, tz, bx - 1, by - 1, gz0 + bz, fx, fy, fz);
+				if (src >= 0) {
+					const uint32_t *fs = fine_start + (size_t)src * FT_STRIDE + (fx + FT * (fy + FT * fz));
+					src0 = fs[0];
+					cnt = fs[1] - src0;
+				}
+				if (bx <= 1 || bx == FB - 1) rowsrc[row * 3 + (bx <= 1 ? bx : 2)] = src0;
+			}
+			fcnt[f] = cnt;
+		}
+		__syncthreads();
+		// ---- exclusive scan over the block's fine cells (thread t owns cells PER t .. PER t + PER - 1)
+		uint32_t c4[PER], sum = 0;
+#pragma unroll
+		for (int k = 0; k < PER; ++k) {
+			c4[k] = fcnt[PER * threadIdx.x + k];
+			sum += c4[k];
+		}
+		uint32_t incl = sum;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			uint32_t t = __shfl_up(incl, o, 64);
+			if (lane >= o) incl += t;
+		}
+		if (lane == 63) wsum[wid] = incl;
+		__syncthreads();
+		uint32_t woff = 0, total = 0;
+		for (int w = 0; w < CORR_THREADS / 64; ++w) {
+			if (w < wid) woff += wsum[w];
+			total += wsum[w];
+		}
+		if (total > FINE2_CAP) {  // uniform
+			if (threadIdx.x == 0) atomicOr(&overflow_tiles[work >> 5], 1u << (work & 31));
+			continue;
+		}
+		{
+			uint32_t ex = woff + incl - sum;
+#pragma unroll
+			for (int k = 0; k < PER; ++k) {
+				const int f = PER * threadIdx.x + k;
+				if (f <= FB_N) foff[f] = (uint16_t)ex;
+				ex += c4[k];
+			}
+		}
+		__syncthreads();
+		// ---- own particles: the middle runs of the rows by = 1 .. FT, bz = 1 .. nzb - 2; their lengths, scanned by the first waves
+		uint32_t own_total = 0;
+		{
+			uint32_t len = 0;
+			if (threadIdx.x < (unsigned)nown_rows) {
+				const int row = (1 + threadIdx.x % FT) + FB * (1 + threadIdx.x / FT);
+				len = (uint32_t)foff[row * FB + FB - 1] - (uint32_t)foff[row * FB + 1];
+			}
+			uint32_t in2 = len;
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) {
+				uint32_t t = __shfl_up(in2, o, 64);
+				if (lane >= o) in2 += t;
+			}
+			if (lane == 63) wsum[wid] = in2;
+			__syncthreads();
+			uint32_t wo = 0;
+			for (int w = 0; w < CORR_THREADS / 64; ++w) {
+				if (w < wid) wo += wsum[w];
+				own_total += wsum[w];
+			}
+			if (threadIdx.x < (unsigned)nown_rows) ownoff[threadIdx.x] = wo + in2 - len;
+			if (threadIdx.x == 0) ownoff[nown_rows] = own_total;
+		}
+		if (own_total > FINE2_OWN) {  // uniform
+			if (threadIdx.x == 0) atomicOr(&overflow_tiles[work >> 5], 1u << (work & 31));
+			continue;
+		}
+		__syncthreads();  // (every count has been read: `own` may overwrite the array)
+		// ---- stage the rows: a wave per fine row copies its three runs - one cell of the x-1 tile, the own x tile's eleven, one
+		// of the x+1 tile - which follow each other in the block (positions relative to the own tile's origin, in cells)
+		for (int row = wid; row < nrows; row += CORR_THREADS / 64) {
+			const int by = row % FB, bz = row / FB;
+			const int gy = by - 1, gz = gz0 + bz;
+			const int dy = gy < 0 ? -1 : (gy >= FT ? 1 : 0), dz = gz < 0 ? -1 : (gz >= FT ? 1 : 0);
+			const int fy = gy - FT * dy, fz = gz - FT * dz;
+			const uint32_t d0 = foff[row * FB], d1 = foff[row * FB + 1], d2 = foff[row * FB + FB - 1], d3 = foff[row * FB + FB];
+			const uint32_t s0 = rowsrc[row * 3], s1 = rowsrc[row * 3 + 1], s2 = rowsrc[row * 3 + 2];
+			for (uint32_t slot = d0 + lane; slot < d3; slot += 64) {
+				const int seg = slot < d1 ? 0 : (slot < d2 ? 1 : 2);
+				const uint32_t src = seg == 0 ? s0 + (slot - d0) : (seg == 1 ? s1 + (slot - d1) : s2 + (slot - d2));
+				float t[3];
+				int l[3];
+				fine_decode(spos[src], fy, fz, t, l);
+				px[slot] = (float)(8 * (seg - 1) + l[0]) + t[0];
+				py[slot] = (float)(8 * dy + l[1]) + t[1];
+				pz[slot] = (float)(8 * dz + l[2]) + t[2];
+			}
+			// the own list: slot order = fine-cell order
+			if (by >= 1 && by <= FT && bz >= 1 && bz <= nzb - 2) {
+				const uint32_t o = ownoff[(by - 1) + FT * (bz - 1)];
+				for (uint32_t k = lane; k < d2 - d1; k += 64) own[o + k] = (uint16_t)(d1 + k);
+			}
+		}
+		__syncthreads();
+		// ---- one thread per own particle
+		if (dbg == 3) { if (threadIdx.x == 0 && px[0] == 123.f) out_tx[0] = py[own[0]]; continue; }
+		for (uint32_t w = threadIdx.x; w < own_total; w += CORR_THREADS) {
+			const uint32_t me = own[w];
+			const float mx = px[me], my = py[me], mz = pz[me];
+			// block coordinates of its fine cell (the same arithmetic the index was built with: mx = (float)lx + t exactly)
+			int fx = (int)(mx * FT_INV), fy = (int)(my * FT_INV), fz = (int)(mz * FT_INV);
+			fx = fx < FT - 1 ? fx : FT - 1; fy = fy < FT - 1 ? fy : FT - 1; fz = fz < FT - 1 ? fz : FT - 1;
+			const int bx = fx + 1, by = fy + 1, bz = fz - gz0;
+			float sx = 0.f, sy = 0.f, sz = 0.f;
+			typedef float f2 __attribute__((ext_vector_type(2)));
+			f2 s2x = 0.f, s2y = 0.f, s2z = 0.f;
+			const float inv_re2 = (float)mp.inv_re2;
+			uint32_t j = 0xFFFFFFFFu;  // (the coincidence hash needs the particle's index: loaded by the rare branch only)
+			const uint32_t myrow = by + FB * bz;
+			const uint32_t grec = rowsrc[myrow * 3 + 1] + (me - (uint32_t)foff[myrow * FB + 1]);
+			auto pair2 = [&](uint32_t q, f2 qx, f2 qy, f2 qz) {
+				const f2 dx = mx - qx, dy = my - qy, dz = mz - qz;
+				const f2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+				const f2 kl = __builtin_elementwise_fma(-d2, (f2)inv_re2, (f2)1.0f);
+				if (kl.x > 0.0f || kl.y > 0.0f) {
+#pragma unroll
+					for (int k = 0; k < 2; ++k) {
+						const float d2k = k ? d2.y : d2.x, klk = k ? kl.y : kl.x;
+						if (!(klk > 0.0f)) continue;
+						if (d2k < 1e-12f) {
+							// coincident (or the particle itself): the reference adds a random unit-box vector (:584-587)
+							if (q + k != me) {
+								if (j == 0xFFFFFFFFu) j = __float_as_uint(spos[grec].w);
+								sx += hash_unit(j, q + k, 0); sy += hash_unit(j, q + k, 1); sz += hash_unit(j, q + k, 2);
+							}
+						} else {
+							const float f = klk * klk * klk * rsqrtf(d2k);
+							sx += f * (k ? dx.y : dx.x); sy += f * (k ? dy.y : dy.x); sz += f * (k ? dz.y : dz.x);
+						}
+					}
+				}
+			};
+			// The nine x-runs of three fine cells around the particle (always inside the block); `p2` takes two candidates at a time
+			// (a far-away dummy pads an odd tail: it contributes exactly 0).
+			auto walk = [&](auto &&p2, auto &&p2_centre) {
+				for (int dz = -1; dz <= 1; ++dz)
+					for (int dy = -1; dy <= 1; ++dy) {
+						const int rowf = FB * ((by + dy) + FB * (bz + dz)) + bx;
+						const uint32_t b = foff[rowf - 1], e = foff[rowf + 2];
+						auto run = [&](auto &&pp) {
+							uint32_t q = b;
+							for (; q + 4 <= e; q += 4) {
+								const float x0 = px[q], x1 = px[q + 1], x2 = px[q + 2], x3 = px[q + 3];
+								const float y0 = py[q], y1 = py[q + 1], y2 = py[q + 2], y3 = py[q + 3];
+								const float z0 = pz[q], z1 = pz[q + 1], z2 = pz[q + 2], z3 = pz[q + 3];
+								pp(q, f2{x0, x1}, f2{y0, y1}, f2{z0, z1});
+								pp(q + 2, f2{x2, x3}, f2{y2, y3}, f2{z2, z3});
+							}
+							if (q + 2 <= e) {
+								pp(q, f2{px[q], px[q + 1]}, f2{py[q], py[q + 1]}, f2{pz[q], pz[q + 1]});
+								q += 2;
+							}
+							if (q < e) pp(q, f2{px[q], 1e6f}, f2{py[q], 1e6f}, f2{pz[q], 1e6f});
+						};
+						if (dy == 0 && dz == 0) run(p2_centre);  // (uniform) the run that holds the particle itself
+						else run(p2);
+					}
+			};
+			// Fast walk, no branch per candidate: the force is evaluated for every candidate with the kernel clamped at 0 - the same
+			// sums, since fma(0, d, s) == s. The self pair (d = 0 exactly) contributes 0 through d^2 + 1e-30. What this cannot do
+			// is the reference's random push for COINCIDENT pairs (d^2 < 1e-12, :584-587): a lane that has met one - a d^2 below
+			// the threshold in the eight other runs (running minimum), or a second one in its own run (count) - redoes its
+			// particle with the branching walk. (With ~0.72-cell fine cells one candidate in seven is a partner and a wave tests
+			// 128 per step: a "nobody has a partner" branch around the force is almost never skipped - measured: 5.77 -> 5.00 ms.)
+			float d2_min = 1.0f;
+			uint32_t n_tiny = dbg == 1 ? 1u : 0u;
+			auto fast = [&](f2 qx, f2 qy, f2 qz) -> f2 {
+				const f2 dx = mx - qx, dy = my - qy, dz = mz - qz;
+				const f2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dx, dx, (f2)1e-30f)));
+				f2 kl;
+				kl.x = __builtin_amdgcn_fmed3f(__builtin_fmaf(-d2.x, inv_re2, 1.0f), 0.0f, 1.0f);
+				kl.y = __builtin_amdgcn_fmed3f(__builtin_fmaf(-d2.y, inv_re2, 1.0f), 0.0f, 1.0f);
+				f2 f = kl * kl * kl;
+				f.x *= __builtin_amdgcn_rsqf(d2.x);  // d^2 >= 1e-30: a normal number, the bare v_rsq_f32 (what rsqrtf compiles to
+				f.y *= __builtin_amdgcn_rsqf(d2.y);  // behind the d^2 >= 1e-12 test of the branching walk)
+				s2x = __builtin_elementwise_fma(f, dx, s2x);
+				s2y = __builtin_elementwise_fma(f, dy, s2y);
+				s2z = __builtin_elementwise_fma(f, dz, s2z);
+				return d2;
+			};
+			if (dbg != 1)
+				walk([&](uint32_t, f2 qx, f2 qy, f2 qz) {
+					     const f2 d2 = fast(qx, qy, qz);
+					     d2_min = fminf(d2_min, fminf(d2.x, d2.y));
+				     },
+				     [&](uint32_t, f2 qx, f2 qy, f2 qz) {
+					     const f2 d2 = fast(qx, qy, qz);
+					     n_tiny += (d2.x < 1e-12f ? 1u : 0u) + (d2.y < 1e-12f ? 1u : 0u);
+				     });
+			if (d2_min < 1e-12f || n_tiny != 1u) {  // rare
+				s2x = 0.f; s2y = 0.f; s2z = 0.f;
+				walk(pair2, pair2);
+			}
+			sx += s2x.x + s2x.y;
+			sy += s2y.x + s2y.y;
+			sz += s2z.x + s2z.y;
+			// the particle's exact cell and fractions (the staged copy is tile-relative fp32) and its index
+			float tme[3];
+			int lme[3];
+			const float4 rec = spos[grec];
+			fine_decode(rec, fy, fz, tme, lme);
+			const uint32_t jj = __float_as_uint(rec.w);
+			const int c[3] = {8 * tx + lme[0], 8 * ty + lme[1], 8 * tz + lme[2]};
+			const double spring[3] = {(double)sx, (double)sy, (double)sz};
+			double from[3], to[3];
+#pragma unroll
+			for (int d = 0; d < 3; ++d) {
+				from[d] = (double)c[d] + (double)tme[d];
+				double x = from[d] + spring[d] * mp.corr;
+				to[d] = x < 0.0 ? 0.0 : ((double)nn[d] < x ? (double)nn[d] : x);
+			}
+			// (a correction moves a particle by a fraction of a cell: in open water there is nothing to march against, only the
+			// domain walls push back)
+			if (dbg == 4) {
+			} else if (!open_water || fabs(to[0] - from[0]) >= 7.0 || fabs(to[1] - from[1]) >= 7.0 || fabs(to[2] - from[2]) >= 7.0)
+				collide(g, solid, from, to, mp.skin);
+			else
+				collide_walls_only(g, to, mp.skin);
+			int nc[3];
+			float nt[3];
+#pragma unroll
+			for (int d = 0; d < 3; ++d) split_position(to[d], nn[d], nc[d], nt[d]);
+			const uint32_t oo = dbg == 2 ? grec : jj;  // EXPERIMENT: coalesced (wrong) destination
+			out_key[oo] = blocked_index(g, nc[0], nc[1], nc[2]);
+			out_tx[oo] = nt[0]; out_ty[oo] = nt[1]; out_tz[oo] = nt[2];
 		}
 	}
 }
@@ -1176,6 +1655,11 @@ static float4 *correction_scratch(lfa_sim *s) {
 	return (float4 *)(!s->vc_pending ? oth.v[0] : (s->vc_with_c ? cur.v[0] : oth.c[0]));
 }
 
+static bool corr_old() {
+	static const bool v = getenv("LFA_CORR_OLD") != nullptr;  // the cell-based index + kernels (A/B runs)
+	return v;
+}
+
 /// First half of lfa_correct_collide: per-cell particle lists + cell-ordered positions (reads the (key, t) of the current binning).
 static int correct_build_index(lfa_sim *s) {
 	const size_t n = s->np_live;
@@ -1199,9 +1683,18 @@ static int correct_build_index(lfa_sim *s) {
 	ParticleSoA &cur = s->pb[s->cur];
 	float4 *spos = correction_scratch(s);
 	if (s->timing && n) LFA_HIP(s, hipEventRecord(s->ev[40], s->stream));
-	hipLaunchKernelGGL(k_build_cell_index, dim3(grid), dim3(256), 0, s->stream, s->dist ? s->ptiles_all : s->ptiles, n_index, cur.key,
-	                   cur.t[0], cur.t[1], cur.t[2], s->tile_start, s->tile_count, s->cell_start, spos, s->cell_count,
-	                   s->slab_lo * L, s->slab_hi * L);
+	if (corr_old()) {
+		hipLaunchKernelGGL(k_build_cell_index, dim3(grid), dim3(256), 0, s->stream, s->dist ? s->ptiles_all : s->ptiles, n_index, cur.key,
+		                   cur.t[0], cur.t[1], cur.t[2], s->tile_start, s->tile_count, s->cell_start, spos, s->cell_count,
+		                   s->slab_lo * L, s->slab_hi * L);
+	} else {
+		if (!s->fine_start) {
+			hipError_t e = hipMalloc(&s->fine_start, (size_t)s->g.nt * FT_STRIDE * 4);
+			if (e != hipSuccess) return lfa_fail(s, LFA_E_OOM, "hipMalloc of the fine-cell index (%zu bytes) failed", (size_t)s->g.nt * FT_STRIDE * 4);
+		}
+		hipLaunchKernelGGL(k_build_fine_index, dim3(grid), dim3(256), 0, s->stream, s->dist ? s->ptiles_all : s->ptiles, n_index, cur.key,
+		                   cur.t[0], cur.t[1], cur.t[2], s->tile_start, s->tile_count, s->fine_start, spos);
+	}
 	LFA_LAUNCH_CHECK(s);
 	return LFA_OK;
 }
@@ -1227,20 +1720,30 @@ static int correct_apply(lfa_sim *s, double dt) {
 			// are written in place; the fallback pass below selects its particles by their old keys
 			LFA_HIP(s, hipMemcpyAsync(oth.key, cur.key, n * 4, hipMemcpyDeviceToDevice, s->stream));
 			if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[41], s->stream));
-			if (getenv("LFA_CORR_COARSE"))  // round 1's walk over the 27 cells (A/B runs)
+			const int dbg = getenv("LFA_CORR_DBG") ? atoi(getenv("LFA_CORR_DBG")) : 0;
+			if (!corr_old())
+				hipLaunchKernelGGL(k_correct_fine2, dim3(g2), dim3(CORR_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, cur.key, cur.t[0],
+				                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_count, s->fine_start, (const float4 *)spos, move_params(s, dt), ovf,
+				                   (const uint8_t *)s->tile_clear, dbg);
+			else if (getenv("LFA_CORR_COARSE"))  // round 1's walk over the 27 cells (A/B runs)
 				hipLaunchKernelGGL(k_correct_tiled, dim3(g2), dim3(CORR_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, cur, cur.key, cur.t[0],
 				                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_flag, s->cell_count, s->cell_start, (const float4 *)spos,
 				                   move_params(s, dt), ovf);
 			else
 				hipLaunchKernelGGL(k_correct_fine, dim3(g2), dim3(CORR_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, cur.key, cur.t[0],
 				                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_flag, s->cell_count, s->cell_start, (const float4 *)spos,
-				                   move_params(s, dt), ovf, (const uint8_t *)s->tile_clear);
+				                   move_params(s, dt), ovf, (const uint8_t *)s->tile_clear, dbg);
 			LFA_LAUNCH_CHECK(s);
 			if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[42], s->stream));
 		}
-		hipLaunchKernelGGL(k_correct_collide, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, cur, cur.key, cur.t[0],
-		                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_flag, s->cell_count, s->cell_start, (const float4 *)spos,
-		                   move_params(s, dt), (const uint32_t *)ovf, (const int *)s->tile_pslot, s->p_off, (const uint32_t *)oth.key);
+		if (!corr_old())
+			hipLaunchKernelGGL(k_correct_collide2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, cur, cur.key, cur.t[0],
+			                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_count, s->fine_start, (const float4 *)spos, move_params(s, dt),
+			                   (const uint32_t *)ovf, (const int *)s->tile_pslot, s->p_off, (const uint32_t *)oth.key);
+		else
+			hipLaunchKernelGGL(k_correct_collide, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, cur, cur.key, cur.t[0],
+			                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_flag, s->cell_count, s->cell_start, (const float4 *)spos,
+			                   move_params(s, dt), (const uint32_t *)ovf, (const int *)s->tile_pslot, s->p_off, (const uint32_t *)oth.key);
 		LFA_LAUNCH_CHECK(s);
 	}
 	LFA_TRY(lfa_dist_migrate(s));
@@ -1305,7 +1808,10 @@ k_correct_undo(size_t n, const float4 *spos, const uint32_t *old_key, uint32_t *
 	if (k >= n) return;
 	const float4 rec = spos[k];
 	const uint32_t i = __float_as_uint(rec.w);
-	t0[i] = rec.x; t1[i] = rec.y; t2[i] = rec.z;
+	// (the records of the fine index keep cell bits in the two top bits of the fractions: fine_record)
+	t0[i] = __uint_as_float(__float_as_uint(rec.x) & 0x3FFFFFFFu);
+	t1[i] = __uint_as_float(__float_as_uint(rec.y) & 0x3FFFFFFFu);
+	t2[i] = __uint_as_float(__float_as_uint(rec.z) & 0x3FFFFFFFu);
 	key[k] = old_key[k];
 }
 }  // namespace
