@@ -110,7 +110,6 @@ struct lfa_sim {
 	uint8_t *ctype = nullptr, *solid = nullptr;
 	uint32_t *cell_count = nullptr;
 	uint32_t *fine_start = nullptr;  // position correction: first record of every fine cell of every tile (particles.hip, FT_STRIDE per tile)
-	uint32_t *cell_start = nullptr;  // first entry of every cell in the cell-grouped index (rank[]), position correction only
 	float *stage = nullptr;  // P2G per-tile partial sums [n_ptiles][6][1000]
 	size_t stage_tiles = 0;
 	float *acc = nullptr;    // global-atomic P2G accumulators [6][ncp]

@@ -121,13 +121,8 @@ __device__ inline void split_position(double p, int n, int &cell, float &t) {
 	t = tf;
 }
 
-#define CORR_ZT 4                          // own cells per workgroup: 8 x 8 x CORR_ZT
-#define CORR_PARTS (8 / CORR_ZT)           // workgroups per tile
-#define CORR_HCELLS (100 * (CORR_ZT + 2))  // halo block 10 x 10 x (CORR_ZT + 2)
-#define CORR_CAP 5632
-#define CORR_OWN 3072
+#define CORR_PARTS 2                       // workgroups per tile of the LDS-tiled position correction (split in z)
 #define CORR_THREADS 512                   // 8 waves per workgroup, 2 workgroups per CU (LDS)
-#define CORR_CPT ((CORR_HCELLS + CORR_THREADS - 1) / CORR_THREADS)
 
 struct MoveParams {
 	double dt_over_h;   // dt / cell_size
@@ -213,722 +208,26 @@ k_advect_collide(size_t n, ParticleSoA p, GridDims g, const uint8_t *solid, Move
 	for (int d = 0; d < 3; ++d) p.t[d][i] = nt[d];
 }
 
-#define CIDX_STAGE 4608  // records staged in LDS per tile (72 KB: two workgroups per CU); 8 per cell fill 4096
-/// Per particle tile: indices of the tile's particles grouped by cell (the `begin` half of the reference's _space_hash,
-/// include/fluid/simulation.h:193-197) - only the position correction needs cell lists.
-__global__ void __launch_bounds__(256)
-k_build_cell_index(const int *ptiles, int n_ptiles, const uint32_t *key, const float *t0, const float *t1, const float *t2,
-                   const uint32_t *tile_start, const uint32_t *tile_count, uint32_t *cell_start, float4 *spos,
-                   uint32_t *ghost_cell_count, int own_lo, int own_hi) {
-	__shared__ uint32_t cnt[LFA_TILE_CELLS];
-	__shared__ uint32_t wsum[4];
-	__shared__ float4 stage[CIDX_STAGE];
-	for (int slot = blockIdx.x; slot < n_ptiles; slot += gridDim.x) {
-		const int tile = ptiles[slot];
-		// ghost tiles (slab decomposition) keep their particles behind the live ones: the range end comes from the count
-		const uint32_t b = tile_start[tile], e = b + tile_count[tile];
-		cnt[threadIdx.x] = 0;
-		cnt[threadIdx.x + 256] = 0;
-		__syncthreads();
-		for (uint32_t i = b + threadIdx.x; i < e; i += 256) atomicAdd(&cnt[key[i] & 511], 1u);
-		__syncthreads();
-		if (tile < own_lo || tile >= own_hi) {  // the binning counted the owned tiles only
-			ghost_cell_count[(size_t)tile * LFA_TILE_CELLS + threadIdx.x] = cnt[threadIdx.x];
-			ghost_cell_count[(size_t)tile * LFA_TILE_CELLS + 256 + threadIdx.x] = cnt[threadIdx.x + 256];
-		}
-		// exclusive scan of the 512 counts: thread t owns cells 2t, 2t+1
-		const uint32_t c0 = cnt[2 * threadIdx.x], c1 = cnt[2 * threadIdx.x + 1];
-		uint32_t incl = c0 + c1;
-		const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-#pragma unroll
-		for (int o = 1; o < 64; o <<= 1) {
-			uint32_t t = __shfl_up(incl, o, 64);
-			if (lane >= o) incl += t;
-		}
-		if (lane == 63) wsum[wid] = incl;
-		__syncthreads();
-		uint32_t woff = 0;
-		for (int w = 0; w < wid; ++w) woff += wsum[w];
-		const uint32_t ex = b + woff + incl - (c0 + c1);
-		__syncthreads();
-		cnt[2 * threadIdx.x] = ex;
-		cnt[2 * threadIdx.x + 1] = ex + c0;
-		cell_start[(size_t)tile * LFA_TILE_CELLS + 2 * threadIdx.x] = ex;
-		cell_start[(size_t)tile * LFA_TILE_CELLS + 2 * threadIdx.x + 1] = ex + c0;
-		__syncthreads();
-		// besides the index list, the in-cell positions in the same cell order (+ the particle index): the tiled correction
-		// stages whole cell runs from it with contiguous reads (gathering t[d][cidx[..]] cost 16x its bytes: 7 of 13 ms at C4)
-		// The records are put in place in LDS and written out as one contiguous run (scattered 16-B stores straight to HBM made
-		// this kernel 1.7 ms at C4); a tile with more particles than the staging area holds writes them directly.
-		const bool staged = e - b <= CIDX_STAGE;
-		for (uint32_t i = b + threadIdx.x; i < e; i += 256) {
-			const uint32_t at = atomicAdd(&cnt[key[i] & 511], 1u);
-			const float4 rec = make_float4(t0[i], t1[i], t2[i], __uint_as_float(i));
-			if (staged) stage[at - b] = rec;
-			else spos[at] = rec;
-		}
-		__syncthreads();
-		if (staged)
-			for (uint32_t k = threadIdx.x; k < e - b; k += 256) spos[b + k] = stage[k];
-		__syncthreads();
-	}
-}
-
 __device__ inline float hash_unit(uint32_t a, uint32_t b, uint32_t k) {
 	uint32_t x = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u ^ k * 0xC2B2AE3Du;
 	x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
 	return (float)(x >> 8) * (2.0f / 16777216.0f) - 1.0f;
 }
 
-/// _correct_positions (pairwise springs over the 27-cell neighbourhood, all from the OLD positions) fused with the
-/// _detect_collisions that follows it. Reads (key, t) of its own particle from `p` and the neighbours from the cell-ordered
-/// records `spos` (k_build_cell_index), so `out` may be `p` itself.
-__global__ void __launch_bounds__(256)
-k_correct_collide(size_t n, ParticleSoA p, uint32_t *out_key, float *out_tx, float *out_ty, float *out_tz, GridDims g,
-                  const uint8_t *solid, const uint32_t *tile_flag, const uint32_t *cell_count, const uint32_t *cell_start,
-                  const float4 *spos, MoveParams mp, const uint32_t *only_flagged, const int *tile_pslot, int p_off,
-                  const uint32_t *key_before) {
-	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	// the key BEFORE the correction: k_correct_tiled has already rewritten, in place, the keys of the particles it moved
-	// (a particle of a flagged half tile still has its old key and position)
-	const uint32_t key_i = key_before ? key_before[i] : p.key[i];
-	if (only_flagged) {  // fallback pass: only particles of the half tiles the LDS-tiled kernel could not hold
-		const int work = CORR_PARTS * (tile_pslot[key_i >> 9] - p_off) + (int)(((key_i >> 6) & 7) / CORR_ZT);
-		if (!((only_flagged[work >> 5] >> (work & 31)) & 1u)) return;
-	}
-	int c[3];
-	cell_of_key(g, key_i, c);
-	const float t[3] = {p.t[0][i], p.t[1][i], p.t[2][i]};
-	const int nn[3] = {g.nx, g.ny, g.nz};
-	int lo[3], hi[3];
-#pragma unroll
-	for (int d = 0; d < 3; ++d) {
-		// particle::compute_cell_index truncates WITHOUT clamping (src/simulation.cpp:13-15): a particle on the max face
-		// sits in "cell n", whose clamped neighbourhood is the last cell only (grid.h:126-135)
-		const int ci = c[d] + (t[d] >= 1.0f ? 1 : 0);
-		lo[d] = ci - 1 < 0 ? 0 : ci - 1;
-		hi[d] = ci + 1 > nn[d] - 1 ? nn[d] - 1 : ci + 1;
-	}
-	double spring[3] = {0.0, 0.0, 0.0};
-	for (int zz = lo[2]; zz <= hi[2]; ++zz)
-		for (int yy = lo[1]; yy <= hi[1]; ++yy)
-			for (int xx = lo[0]; xx <= hi[0]; ++xx) {
-				const uint32_t b = blocked_index(g, xx, yy, zz);
-				if (!tile_flag[b >> 9]) continue;
-				const uint32_t cnt = cell_count[b];
-				if (!cnt) continue;
-				const uint32_t st = cell_start[b];
-				const float ox = (float)(c[0] - xx) + t[0], oy = (float)(c[1] - yy) + t[1], oz = (float)(c[2] - zz) + t[2];
-				for (uint32_t k = 0; k < cnt; ++k) {
-					const float4 sp = spos[st + k];  // the neighbours' OLD positions (the outputs go back in place)
-					const uint32_t j = __float_as_uint(sp.w);
-					if (j == (uint32_t)i) continue;
-					const float dx = ox - sp.x, dy = oy - sp.y, dz = oz - sp.z;
-					const float d2 = dx * dx + dy * dy + dz * dz;  // grid units^2
-					if (d2 < 1e-12f) {
-						// coincident pair: the reference adds a random unit-box vector (:584-587, std::random_device)
-						spring[0] += hash_unit((uint32_t)i, j, 0); spring[1] += hash_unit((uint32_t)i, j, 1);
-						spring[2] += hash_unit((uint32_t)i, j, 2);
-					} else {
-						const float kl = 1.0f - d2 * (float)mp.inv_re2;
-						if (kl > 0.0f) {
-							const float f = kl * kl * kl * rsqrtf(d2);
-							spring[0] += (double)(f * dx); spring[1] += (double)(f * dy); spring[2] += (double)(f * dz);
-						}
-					}
-				}
-			}
-	double from[3], to[3];
-#pragma unroll
-	for (int d = 0; d < 3; ++d) {
-		from[d] = (double)c[d] + (double)t[d];
-		double x = from[d] + spring[d] * mp.corr;
-		to[d] = x < 0.0 ? 0.0 : ((double)nn[d] < x ? (double)nn[d] : x);  // clamp to [offset, grid max] (:604-609)
-	}
-	collide(g, solid, from, to, mp.skin);
-	int nc[3];
-	float nt[3];
-#pragma unroll
-	for (int d = 0; d < 3; ++d) split_position(to[d], nn[d], nc[d], nt[d]);
-	out_key[i] = blocked_index(g, nc[0], nc[1], nc[2]);
-	out_tx[i] = nt[0]; out_ty[i] = nt[1]; out_tz[i] = nt[2];
-}
-
-/// LDS-tiled _correct_positions + _detect_collisions. One workgroup per (particle tile, z-half): the positions of every
-/// particle in the 10x10x6 cells around the 8x8x4 half tile are staged in LDS once (tile-relative fp32), then one thread
-/// per cell walks the 27-cell neighbourhoods of its particles out of LDS. The per-particle global gather of
-/// k_correct_collide (216 dependent index->position loads) was latency-bound: 264 ms at C4.
-/// A half tile whose neighbourhood does not fit CORR_CAP particles sets *overflow and is left to k_correct_collide.
-__global__ void __launch_bounds__(CORR_THREADS)
-k_correct_tiled(const int *ptiles, int n_ptiles, ParticleSoA p, uint32_t *out_key, float *out_tx, float *out_ty, float *out_tz,
-                GridDims g, const uint8_t *solid, const uint32_t *tile_flag, const uint32_t *cell_count,
-                const uint32_t *cell_start, const float4 *spos, MoveParams mp, uint32_t *overflow_tiles) {
-	__shared__ uint32_t off[CORR_HCELLS + 1];
-	__shared__ uint32_t gstart[CORR_HCELLS];
-	__shared__ float px[CORR_CAP], py[CORR_CAP], pz[CORR_CAP];
-	__shared__ uint16_t own[CORR_OWN];  // (halo cell << 6 | index in cell) of the particles this workgroup moves
-	__shared__ uint32_t wsum[CORR_THREADS / 64], n_own;
-	const int nn[3] = {g.nx, g.ny, g.nz};
-	for (int work = blockIdx.x; work < CORR_PARTS * n_ptiles; work += gridDim.x) {
-		const int tile = ptiles[work / CORR_PARTS], half = work % CORR_PARTS;
-		int tx, ty, tz;
-		tile_coords(g, tile, tx, ty, tz);
-		const int ox = tx * 8 - 1, oy = ty * 8 - 1, oz = tz * 8 + CORR_ZT * half - 1;  // origin of the halo block
-		__syncthreads();
-		// ---- counts of the 600 halo cells, exclusive scan
-		uint32_t c3[CORR_CPT], sum = 0;
-#pragma unroll
-		for (int k = 0; k < CORR_CPT; ++k) {
-			const int h = CORR_CPT * threadIdx.x + k;
-			uint32_t cnt = 0, st = 0;
-			if (h < CORR_HCELLS) {
-				const int x = ox + h % 10, y = oy + (h / 10) % 10, z = oz + h / 100;
-				if (in_grid(g, x, y, z)) {
-					const uint32_t b = blocked_index(g, x, y, z);
-					if (tile_flag[b >> 9]) {
-						cnt = cell_count[b];
-						st = cnt ? cell_start[b] : 0;
-					}
-				}
-				gstart[h] = st;
-			}
-			c3[k] = cnt;
-			sum += cnt;
-		}
-		uint32_t incl = sum;
-		const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-#pragma unroll
-		for (int o = 1; o < 64; o <<= 1) {
-			uint32_t t = __shfl_up(incl, o, 64);
-			if (lane >= o) incl += t;
-		}
-		if (lane == 63) wsum[wid] = incl;
-		__syncthreads();
-		uint32_t woff = 0, total = 0;
-		for (int w = 0; w < CORR_THREADS / 64; ++w) {
-			if (w < wid) woff += wsum[w];
-			total += wsum[w];
-		}
-		uint32_t ex = woff + incl - sum;
-#pragma unroll
-		for (int k = 0; k < CORR_CPT; ++k) {
-			const int h = CORR_CPT * threadIdx.x + k;
-			if (h < CORR_HCELLS) off[h] = ex;
-			ex += c3[k];
-		}
-		if (threadIdx.x == 0) {
-			off[CORR_HCELLS] = total;
-			n_own = 0;
-		}
-		__syncthreads();
-		// own particles = those of the 8 x 8 x 4 interior cells
-		uint32_t own_total = 0;
-		{
-			const int lx = threadIdx.x & 7, ly = (threadIdx.x >> 3) & 7, lz = threadIdx.x >> 6;
-			if (threadIdx.x < 64 * CORR_ZT) {
-				const int hc = (lx + 1) + 10 * (ly + 1) + 100 * (lz + 1);
-				const uint32_t cnt = off[hc + 1] - off[hc];
-				const uint32_t base = atomicAdd(&n_own, cnt);
-				if (cnt > 63) atomicAdd(&n_own, 4096u);  // does not fit the packing: force the fallback
-				for (uint32_t k = 0; k < cnt && k < 64 && base + k < CORR_OWN; ++k) own[base + k] = (uint16_t)((hc << 6) | k);
-			}
-		}
-		__syncthreads();
-		own_total = n_own;
-		if (total > CORR_CAP || own_total > CORR_OWN) {
-			if (threadIdx.x == 0) atomicOr(&overflow_tiles[work >> 5], 1u << (work & 31));
-			continue;
-		}
-		// ---- stage positions (relative to the halo block origin, in cells)
-		for (int h = threadIdx.x; h < CORR_HCELLS; h += CORR_THREADS) {
-			const uint32_t o = off[h], cnt = off[h + 1] - o, st = gstart[h];
-			const float bx = (float)(h % 10), by = (float)((h / 10) % 10), bz = (float)(h / 100);
-			for (uint32_t k = 0; k < cnt; ++k) {
-				const float4 sp = spos[st + k];
-				px[o + k] = bx + sp.x;
-				py[o + k] = by + sp.y;
-				pz[o + k] = bz + sp.z;
-			}
-		}
-		__syncthreads();
-		// ---- one thread per own particle
-		for (uint32_t w = threadIdx.x; w < own_total; w += CORR_THREADS) {
-			const int hc = (int)(own[w] >> 6);
-			const uint32_t k0 = own[w] & 63u;
-			const int cx = ox + hc % 10, cy = oy + (hc / 10) % 10, cz = oz + hc / 100;
-			const uint32_t me = off[hc] + k0;
-			const float mx = px[me], my = py[me], mz = pz[me];
-			const float4 sp = spos[gstart[hc] + k0];
-			const uint32_t j = __float_as_uint(sp.w);
-			const float tme[3] = {sp.x, sp.y, sp.z};  // exact fraction (the staged copy is block-relative)
-			const int c[3] = {cx, cy, cz};
-			// (Round 2, measured at C4 on a moving dam, 9.2 ms for this kernel: (a) per-particle pruning of cells and x-runs by
-			// their box distance - 92 instead of 216 candidates - with the nine runs of a lane flattened into one loop so that
-			// lanes do not wait for each other's runs: 62 ms, the divergent loop control costs more than the pairs it saves;
-			// (b) branch-free pairs (force computed unconditionally, kl clamped at 0, d^2 floored at 1e-12, coincidences detected
-			// by a side sum): 11.8 ms - PMC SQ_INSTS_VALU 6.5e9 against 4.1e9 for the branch: the lanes of a wave walk the same
-			// RELATIVE cell at the same time, and for the 20 corner and edge cells of the 27 no lane of the wave has a partner
-			// most of the time, so the branch does skip the force for the whole wave. The kernel is VALU bound either way: 74 % /
-			// 89 % of the SIMD cycles issue VALU instructions.)
-			// Every particle of a cell walks the same 3 x 3 x 3 cells, whole: the (up to 8) lanes of a cell then read the same LDS
-			// word at the same time. Skipping, per particle, the neighbour cells whose nearest face is beyond the kernel radius
-			// made the lanes of a cell read different words: the wave ran the longest trip count anyway and the LDS reads
-			// conflicted 3x (7.1 ms of pair tests at C4). Partners within the radius (0.71 cells) always lie in these cells, also
-			// for a particle stored with t == 1 (the reference visits c .. c + 2 for it, :13-15); all others contribute exactly 0.
-			int lo[3], hi[3];
-#pragma unroll
-			for (int d = 0; d < 3; ++d) {
-				lo[d] = c[d] - 1 < 0 ? 0 : c[d] - 1;
-				hi[d] = c[d] + 1 > nn[d] - 1 ? nn[d] - 1 : c[d] + 1;
-			}
-			float sx = 0.f, sy = 0.f, sz = 0.f;
-			float __attribute__((ext_vector_type(2))) s2x = 0.f, s2y = 0.f, s2z = 0.f;
-			const float inv_re2 = (float)mp.inv_re2;
-			for (int zz = lo[2]; zz <= hi[2]; ++zz)
-				for (int yy = lo[1]; yy <= hi[1]; ++yy) {
-					// the x-run of up to three cells is contiguous in the halo block: one LDS range
-					const int hrow = (lo[0] - ox) + 10 * (yy - oy) + 100 * (zz - oz);
-					const uint32_t b = off[hrow], e = off[hrow + (hi[0] - lo[0]) + 1];
-					// The pair test is what this kernel spends its time on, and it is VALU bound (PMC: 86 % VALU busy, 21 VALU
-					// instructions per candidate; a wave64 instruction issues over four cycles): two candidates per instruction
-					// with the packed fp32 operations (v_pk_add/mul/fma_f32), explicit FMAs, the self-pair left to the rare branch.
-					typedef float f2 __attribute__((ext_vector_type(2)));
-					auto pair2 = [&](uint32_t q, f2 qx, f2 qy, f2 qz) {
-						const f2 dx = mx - qx, dy = my - qy, dz = mz - qz;
-						const f2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-						const f2 kl = __builtin_elementwise_fma(-d2, (f2)inv_re2, (f2)1.0f);
-						if (kl.x > 0.0f || kl.y > 0.0f) {  // ~1 pair in 10 is inside the kernel radius
-							if (d2.x < 1e-12f || d2.y < 1e-12f) {
-								// coincident (or the particle itself): the reference adds a random unit-box vector (:584-587)
-#pragma unroll
-								for (int k = 0; k < 2; ++k) {
-									const float d2k = k ? d2.y : d2.x, klk = k ? kl.y : kl.x;
-									if (!(klk > 0.0f)) continue;
-									if (d2k < 1e-12f) {
-										if (q + k != me) { sx += hash_unit(me, q + k, 0); sy += hash_unit(me, q + k, 1); sz += hash_unit(me, q + k, 2); }
-									} else {
-										const float f = klk * klk * klk * rsqrtf(d2k);
-										sx += f * (k ? dx.y : dx.x); sy += f * (k ? dy.y : dy.x); sz += f * (k ? dz.y : dz.x);
-									}
-								}
-							} else {
-								const f2 klp = __builtin_elementwise_max(kl, (f2)0.0f);
-								f2 f = klp * klp * klp;
-								f.x *= rsqrtf(d2.x);
-								f.y *= rsqrtf(d2.y);
-								s2x = __builtin_elementwise_fma(f, dx, s2x);
-								s2y = __builtin_elementwise_fma(f, dy, s2y);
-								s2z = __builtin_elementwise_fma(f, dz, s2z);
-							}
-						}
-					};
-					auto pair = [&](uint32_t q, float qx, float qy, float qz) {
-						const float dx = mx - qx, dy = my - qy, dz = mz - qz;
-						const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-						const float kl = __builtin_fmaf(-d2, inv_re2, 1.0f);
-						if (kl > 0.0f) {
-							if (d2 < 1e-12f) {
-								if (q != me) { sx += hash_unit(me, q, 0); sy += hash_unit(me, q, 1); sz += hash_unit(me, q, 2); }
-							} else {
-								const float f = kl * kl * kl * rsqrtf(d2);
-								sx += f * dx; sy += f * dy; sz += f * dz;
-							}
-						}
-					};
-					// four candidates per round: their twelve LDS reads are in flight together
-					uint32_t q = b;
-					for (; q + 4 <= e; q += 4) {
-						const float x0 = px[q], x1 = px[q + 1], x2 = px[q + 2], x3 = px[q + 3];
-						const float y0 = py[q], y1 = py[q + 1], y2 = py[q + 2], y3 = py[q + 3];
-						const float z0 = pz[q], z1 = pz[q + 1], z2 = pz[q + 2], z3 = pz[q + 3];
-						pair2(q, f2{x0, x1}, f2{y0, y1}, f2{z0, z1});
-						pair2(q + 2, f2{x2, x3}, f2{y2, y3}, f2{z2, z3});
-					}
-					for (; q < e; ++q) pair(q, px[q], py[q], pz[q]);
-				}
-			sx += s2x.x + s2x.y;
-			sy += s2y.x + s2y.y;
-			sz += s2z.x + s2z.y;
-			const double spring[3] = {(double)sx, (double)sy, (double)sz};
-			double from[3], to[3];
-#pragma unroll
-			for (int d = 0; d < 3; ++d) {
-				from[d] = (double)c[d] + (double)tme[d];
-				double x = from[d] + spring[d] * mp.corr;
-				to[d] = x < 0.0 ? 0.0 : ((double)nn[d] < x ? (double)nn[d] : x);
-			}
-			collide(g, solid, from, to, mp.skin);
-			int nc[3];
-			float nt[3];
-#pragma unroll
-			for (int d = 0; d < 3; ++d) split_position(to[d], nn[d], nc[d], nt[d]);
-			out_key[j] = blocked_index(g, nc[0], nc[1], nc[2]);
-			out_tx[j] = nt[0]; out_ty[j] = nt[1]; out_tz[j] = nt[2];
-		}
-	}
-}
-
-
-// ------------------------------------------------------------------------------------------------ fine-cell variant
-// The pair tests of k_correct_tiled are VALU bound and cannot get cheaper per pair (PMC: 74 % of the SIMD cycles issue VALU,
-// ~13 instructions per candidate with packed fp32), so the lever is the number of candidates: the 27 CELLS around a particle
-// hold 216 of them for 12 partners, because a cell (1) is wider than the kernel radius re = 0.7071 cells needs. Here the halo
-// block is re-sorted, in LDS, by FINE cells of 0.72 cells: the 27 fine cells around a particle hold 27 x 8 x 0.72^3 = 81
-// candidates. Lanes are own particles in fine-cell order, so the lanes of a fine cell still walk the same ranges together
-// (broadcast LDS reads, shared trip counts) - the property per-particle pruning of cells loses (see k_correct_tiled).
-#define FINE_S 0.72f
-#define FINE_INV_S (1.0f / 0.72f)
-#define FINE_R 0.7072f                          // particles farther than this from the own region cannot be partners
-#define FINE_NX 14                              // ceil(10 / 0.72)
-#define FINE_NZ (((CORR_ZT + 2) * 100 + 71) / 72)  // ceil((CORR_ZT + 2) / 0.72)
-#define FINE_N (FINE_NX * FINE_NX * FINE_NZ)
-#define FINE_CAP 4608                           // staged particles (the needed region holds 3840 at 8 per cell)
-#define FINE_PER_THREAD ((FINE_N + CORR_THREADS - 1) / CORR_THREADS)
-#define FINE_RAW_PER_THREAD 11                  // particles of the whole 10 x 10 x (CORR_ZT + 2) block per thread: 5632 in all
-
-__global__ void __launch_bounds__(CORR_THREADS, 4)
-k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx, float *out_ty, float *out_tz, GridDims g,
-               const uint8_t *solid, const uint32_t *tile_flag, const uint32_t *cell_count, const uint32_t *cell_start,
-               const float4 *spos, MoveParams mp, uint32_t *overflow_tiles, const uint8_t *tile_clear, int dbg) {
-	__shared__ float px[FINE_CAP], py[FINE_CAP], pz[FINE_CAP];
-	__shared__ uint16_t hk[FINE_CAP];            // (halo cell << 6 | index in the cell) of the staged particle
-	__shared__ uint32_t fcnt[FINE_N];            // per fine cell: count, then running cursor; afterwards the own list (u16)
-	__shared__ uint16_t foff[FINE_N + 1];        // first staged slot of every fine cell
-	__shared__ uint32_t gstart[CORR_HCELLS];
-	__shared__ uint16_t ccnt[CORR_HCELLS];
-	__shared__ uint32_t wsum[CORR_THREADS / 64], n_bad;
-	uint16_t *own = (uint16_t *)fcnt;            // FINE_N * 2 >= CORR_OWN entries
-	static_assert(FINE_N * 2 >= CORR_OWN, "own list does not fit the cursor array");
-	const int nn[3] = {g.nx, g.ny, g.nz};
-	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-	auto fine_of = [](float x, float y, float z) -> int {
-		int fx = (int)(x * FINE_INV_S), fy = (int)(y * FINE_INV_S), fz = (int)(z * FINE_INV_S);
-		fx = fx < FINE_NX - 1 ? fx : FINE_NX - 1; fy = fy < FINE_NX - 1 ? fy : FINE_NX - 1; fz = fz < FINE_NZ - 1 ? fz : FINE_NZ - 1;
-		return fx + FINE_NX * (fy + FINE_NX * fz);
-	};
-	for (int work = blockIdx.x; work < CORR_PARTS * n_ptiles; work += gridDim.x) {
-		const int tile = ptiles[work / CORR_PARTS], half = work % CORR_PARTS;
-		int tx, ty, tz;
-		tile_coords(g, tile, tx, ty, tz);
-		const int ox = tx * 8 - 1, oy = ty * 8 - 1, oz = tz * 8 + CORR_ZT * half - 1;  // origin of the halo block
-		const bool open_water = (tile_clear[tile] & 1) != 0;  // no solid cell within a tile of this one
-		__syncthreads();
-		// ---- the halo cells: where their particles sit in the cell-ordered records
-		for (int h = threadIdx.x; h < CORR_HCELLS; h += CORR_THREADS) {
-			uint32_t cnt = 0, st = 0;
-			const int x = ox + h % 10, y = oy + (h / 10) % 10, z = oz + h / 100;
-			if (in_grid(g, x, y, z)) {
-				const uint32_t b = blocked_index(g, x, y, z);
-				if (tile_flag[b >> 9]) {
-					cnt = cell_count[b];
-					st = cnt ? cell_start[b] : 0;
-				}
-			}
-			gstart[h] = st;
-			ccnt[h] = (uint16_t)(cnt < 65535u ? cnt : 65535u);
-		}
-		for (int f = threadIdx.x; f < FINE_N; f += CORR_THREADS) fcnt[f] = 0;
-		if (threadIdx.x == 0) n_bad = 0;
-		__syncthreads();
-		// ---- the raw particle list of the halo block: (cell, index) of its r-th particle, so that the loads below can be spread
-		// evenly over the threads and issued together. (A loop per cell - a thread walking its cell's records one after the
-		// other - waited for a dependent HBM/L2 round trip per particle: the staging was a third of the kernel.)
-		uint16_t *rawhk = (uint16_t *)px;  // consumed before px is written
-		static_assert(sizeof(float) * FINE_CAP >= 2 * FINE_RAW_PER_THREAD * CORR_THREADS, "raw list does not fit");
-		uint32_t craw = 0;
-		{
-			// exclusive scan of the cell counts (thread t owns cells CORR_CPT t .. CORR_CPT t + CORR_CPT - 1)
-			uint32_t c3[CORR_CPT], sum0 = 0;
-#pragma unroll
-			for (int k = 0; k < CORR_CPT; ++k) {
-				const int h = CORR_CPT * threadIdx.x + k;
-				c3[k] = h < CORR_HCELLS ? ccnt[h] : 0u;
-				if (c3[k] > 63) atomicAdd(&n_bad, 1u);  // does not fit the (cell, index) packing: the fallback kernel takes the block
-				sum0 += c3[k];
-			}
-			uint32_t inc0 = sum0;
-#pragma unroll
-			for (int o = 1; o < 64; o <<= 1) {
-				uint32_t t = __shfl_up(inc0, o, 64);
-				if (lane >= o) inc0 += t;
-			}
-			if (lane == 63) wsum[wid] = inc0;
-			__syncthreads();
-			uint32_t woff0 = 0;
-			for (int w = 0; w < CORR_THREADS / 64; ++w) {
-				if (w < wid) woff0 += wsum[w];
-				craw += wsum[w];
-			}
-			__syncthreads();  // wsum is reused below
-			if (craw > FINE_RAW_PER_THREAD * CORR_THREADS || n_bad) {  // uniform
-				if (threadIdx.x == 0) atomicOr(&overflow_tiles[work >> 5], 1u << (work & 31));
-				continue;
-			}
-			uint32_t r = woff0 + inc0 - sum0;
-#pragma unroll
-			for (int k = 0; k < CORR_CPT; ++k) {
-				const int h = CORR_CPT * threadIdx.x + k;
-				for (uint32_t i = 0; i < c3[k]; ++i) rawhk[r++] = (uint16_t)((h << 6) | i);
-			}
-		}
-		__syncthreads();
-		// ---- pass 1 over the records: fine-cell histogram of the particles that can be partners of an own particle. The loads of a
-		// thread are independent and issued in batches; only the packed (fine cell, cell, index) word of each survives to pass 2
-		// (keeping the positions in registers across the scan took 163 VGPRs: one workgroup per CU instead of two).
-		const float zhi = (float)(1 + CORR_ZT) + FINE_R;
-		uint32_t rinfo[FINE_RAW_PER_THREAD];  // fine cell << 16 | (cell << 6 | index); 0xFFFFFFFF: not staged
-		auto staged_pos = [&](uint32_t e, const float4 &sp, float &x, float &y, float &z) -> bool {
-			const int h = (int)(e >> 6);
-			// in-cell fractions are kept below 1 (a particle ON the max face is stored with t == 1): it stays in its cell's box
-			x = (float)(h % 10) + fminf(sp.x, 0.99999994f);
-			y = (float)((h / 10) % 10) + fminf(sp.y, 0.99999994f);
-			z = (float)(h / 100) + fminf(sp.z, 0.99999994f);
-			return x >= 1.0f - FINE_R && x < 9.0f + FINE_R && y >= 1.0f - FINE_R && y < 9.0f + FINE_R && z >= 1.0f - FINE_R && z < zhi;
-		};
-#pragma unroll
-		for (int i = 0; i < FINE_RAW_PER_THREAD; ++i) {
-			const uint32_t r = threadIdx.x + CORR_THREADS * i;
-			rinfo[i] = 0xFFFFFFFFu;
-			if (r < craw) {
-				const uint32_t e = rawhk[r];
-				float x, y, z;
-				if (staged_pos(e, spos[gstart[e >> 6] + (e & 63u)], x, y, z)) {
-					const uint32_t f = (uint32_t)fine_of(x, y, z);
-					rinfo[i] = (f << 16) | e;
-					atomicAdd(&fcnt[f], 1u);
-				}
-			}
-		}
-		__syncthreads();
-		// ---- exclusive scan over the fine cells
-		uint32_t c4[FINE_PER_THREAD], sum = 0;
-#pragma unroll
-		for (int k = 0; k < FINE_PER_THREAD; ++k) {
-			const int f = FINE_PER_THREAD * threadIdx.x + k;
-			c4[k] = f < FINE_N ? fcnt[f] : 0u;
-			sum += c4[k];
-		}
-		uint32_t incl = sum;
-#pragma unroll
-		for (int o = 1; o < 64; o <<= 1) {
-			uint32_t t = __shfl_up(incl, o, 64);
-			if (lane >= o) incl += t;
-		}
-		if (lane == 63) wsum[wid] = incl;
-		__syncthreads();
-		uint32_t woff = 0, total = 0;
-		for (int w = 0; w < CORR_THREADS / 64; ++w) {
-			if (w < wid) woff += wsum[w];
-			total += wsum[w];
-		}
-		if (total > FINE_CAP) {  // uniform
-			if (threadIdx.x == 0) atomicOr(&overflow_tiles[work >> 5], 1u << (work & 31));
-			continue;
-		}
-		uint32_t ex = woff + incl - sum;
-#pragma unroll
-		for (int k = 0; k < FINE_PER_THREAD; ++k) {
-			const int f = FINE_PER_THREAD * threadIdx.x + k;
-			if (f < FINE_N) {
-				foff[f] = (uint16_t)ex;
-				fcnt[f] = ex;  // cursor
-			}
-			ex += c4[k];
-		}
-		if (threadIdx.x == 0) foff[FINE_N] = (uint16_t)total;
-		__syncthreads();  // (the raw list in px has been consumed by every thread)
-		// ---- pass 2: scatter into fine-cell order (the records come from L2 this time)
-#pragma unroll
-		for (int i = 0; i < FINE_RAW_PER_THREAD; ++i)
-			if (rinfo[i] != 0xFFFFFFFFu) {
-				const uint32_t e = rinfo[i] & 0xFFFFu;
-				float x, y, z;
-				staged_pos(e, spos[gstart[e >> 6] + (e & 63u)], x, y, z);
-				const uint32_t slot = atomicAdd(&fcnt[rinfo[i] >> 16], 1u);
-				px[slot] = x; py[slot] = y; pz[slot] = z;
-				hk[slot] = (uint16_t)e;
-			}
-		__syncthreads();
-		// ---- own particles (those of the 8 x 8 x CORR_ZT interior cells) in slot order = fine-cell order
-		constexpr int SPT = (FINE_CAP + CORR_THREADS - 1) / CORR_THREADS;  // slots per thread
-		auto is_own = [&](uint32_t slot) -> bool {
-			const int h = hk[slot] >> 6, hx = h % 10, hy = (h / 10) % 10, hz = h / 100;
-			return hx >= 1 && hx <= 8 && hy >= 1 && hy <= 8 && hz >= 1 && hz <= CORR_ZT;
-		};
-		uint32_t mine = 0;
-		for (int k = 0; k < SPT; ++k) {
-			const uint32_t slot = SPT * threadIdx.x + k;
-			if (slot < total && is_own(slot)) ++mine;
-		}
-		incl = mine;
-#pragma unroll
-		for (int o = 1; o < 64; o <<= 1) {
-			uint32_t t = __shfl_up(incl, o, 64);
-			if (lane >= o) incl += t;
-		}
-		if (lane == 63) wsum[wid] = incl;
-		__syncthreads();  // (also: every cursor read of pass 2 is done before `own` overwrites the array)
-		woff = 0;
-		uint32_t own_total = 0;
-		for (int w = 0; w < CORR_THREADS / 64; ++w) {
-			if (w < wid) woff += wsum[w];
-			own_total += wsum[w];
-		}
-		if (own_total > CORR_OWN) {  // uniform
-			if (threadIdx.x == 0) atomicOr(&overflow_tiles[work >> 5], 1u << (work & 31));
-			continue;
-		}
-		uint32_t at = woff + incl - mine;
-		for (int k = 0; k < SPT; ++k) {
-			const uint32_t slot = SPT * threadIdx.x + k;
-			if (slot < total && is_own(slot)) own[at++] = (uint16_t)slot;
-		}
-		__syncthreads();
-		// ---- one thread per own particle
-		for (uint32_t w = threadIdx.x; w < own_total; w += CORR_THREADS) {
-			const uint32_t me = own[w];
-			const float mx = px[me], my = py[me], mz = pz[me];
-			const int hc = hk[me] >> 6;
-			const float4 sp = spos[gstart[hc] + (hk[me] & 63u)];
-			const uint32_t j = __float_as_uint(sp.w);
-			const float tme[3] = {sp.x, sp.y, sp.z};  // exact fraction (the staged copy is block-relative)
-			const int c[3] = {ox + hc % 10, oy + (hc / 10) % 10, oz + hc / 100};
-			int fx = (int)(mx * FINE_INV_S), fy = (int)(my * FINE_INV_S), fz = (int)(mz * FINE_INV_S);
-			fx = fx < FINE_NX - 1 ? fx : FINE_NX - 1; fy = fy < FINE_NX - 1 ? fy : FINE_NX - 1; fz = fz < FINE_NZ - 1 ? fz : FINE_NZ - 1;
-			const int xa = fx > 0 ? fx - 1 : 0, xb = fx + 1 < FINE_NX ? fx + 1 : FINE_NX - 1;
-			float sx = 0.f, sy = 0.f, sz = 0.f;
-			typedef float f2 __attribute__((ext_vector_type(2)));
-			f2 s2x = 0.f, s2y = 0.f, s2z = 0.f;
-			const float inv_re2 = (float)mp.inv_re2;
-			auto pair2 = [&](uint32_t q, f2 qx, f2 qy, f2 qz) {
-				const f2 dx = mx - qx, dy = my - qy, dz = mz - qz;
-				const f2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-				const f2 kl = __builtin_elementwise_fma(-d2, (f2)inv_re2, (f2)1.0f);
-				if (kl.x > 0.0f || kl.y > 0.0f) {
-					if (d2.x < 1e-12f || d2.y < 1e-12f) {
-						// coincident (or the particle itself): the reference adds a random unit-box vector (:584-587)
-#pragma unroll
-						for (int k = 0; k < 2; ++k) {
-							const float d2k = k ? d2.y : d2.x, klk = k ? kl.y : kl.x;
-							if (!(klk > 0.0f)) continue;
-							if (d2k < 1e-12f) {
-								if (q + k != me) { sx += hash_unit(j, q + k, 0); sy += hash_unit(j, q + k, 1); sz += hash_unit(j, q + k, 2); }
-							} else {
-								const float f = klk * klk * klk * rsqrtf(d2k);
-								sx += f * (k ? dx.y : dx.x); sy += f * (k ? dy.y : dy.x); sz += f * (k ? dz.y : dz.x);
-							}
-						}
-					} else {
-						const f2 klp = __builtin_elementwise_max(kl, (f2)0.0f);
-						f2 f = klp * klp * klp;
-						f.x *= rsqrtf(d2.x);
-						f.y *= rsqrtf(d2.y);
-						s2x = __builtin_elementwise_fma(f, dx, s2x);
-						s2y = __builtin_elementwise_fma(f, dy, s2y);
-						s2z = __builtin_elementwise_fma(f, dz, s2z);
-					}
-				}
-			};
-			// The nine x-runs of three fine cells around the particle; `p2` takes two candidates at a time (a far-away dummy pads
-			// an odd tail: it contributes exactly 0).
-			auto walk = [&](auto &&p2, auto &&p2_centre) {
-				for (int dz = -1; dz <= 1; ++dz) {
-					const int zz = fz + dz;
-					if (zz < 0 || zz >= FINE_NZ) continue;
-					for (int dy = -1; dy <= 1; ++dy) {
-						const int yy = fy + dy;
-						if (yy < 0 || yy >= FINE_NX) continue;
-						const int row = FINE_NX * (yy + FINE_NX * zz);
-						const uint32_t b = foff[row + xa], e = foff[row + xb + 1];
-						auto run = [&](auto &&pp) {
-							uint32_t q = b;
-							for (; q + 4 <= e; q += 4) {
-								const float x0 = px[q], x1 = px[q + 1], x2 = px[q + 2], x3 = px[q + 3];
-								const float y0 = py[q], y1 = py[q + 1], y2 = py[q + 2], y3 = py[q + 3];
-								const float z0 = pz[q], z1 = pz[q + 1], z2 = pz[q + 2], z3 = pz[q + 3];
-								pp(q, f2{x0, x1}, f2{y0, y1}, f2{z0, z1});
-								pp(q + 2, f2{x2, x3}, f2{y2, y3}, f2{z2, z3});
-							}
-							if (q + 2 <= e) {
-								pp(q, f2{px[q], px[q + 1]}, f2{py[q], py[q + 1]}, f2{pz[q], pz[q + 1]});
-								q += 2;
-							}
-							if (q < e) pp(q, f2{px[q], 1e6f}, f2{py[q], 1e6f}, f2{pz[q], 1e6f});
-						};
-						if (dy == 0 && dz == 0) run(p2_centre);  // (uniform) the run that holds the particle itself
-						else run(p2);
-					}
-				}
-			};
-			// Fast walk, no branch per candidate: the force is evaluated for every candidate with the kernel clamped at 0 - the same
-			// sums, since fma(0, d, s) == s. The self pair (d = 0 exactly) contributes 0 through d^2 + 1e-30. What this cannot do
-			// is the reference's random push for COINCIDENT pairs (d^2 < 1e-12, :584-587): a lane that has met one - a d^2 below
-			// the threshold in the eight other runs (running minimum), or a second one in its own run (count) - redoes its
-			// particle with the branching walk.
-			float d2_min = 1.0f;
-			uint32_t n_tiny = dbg == 1 ? 1u : 0u;
-			auto fast = [&](f2 qx, f2 qy, f2 qz) -> f2 {
-				const f2 dx = mx - qx, dy = my - qy, dz = mz - qz;
-				const f2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dx, dx, (f2)1e-30f)));
-				f2 kl;
-				kl.x = __builtin_amdgcn_fmed3f(__builtin_fmaf(-d2.x, inv_re2, 1.0f), 0.0f, 1.0f);
-				kl.y = __builtin_amdgcn_fmed3f(__builtin_fmaf(-d2.y, inv_re2, 1.0f), 0.0f, 1.0f);
-				f2 f = kl * kl * kl;
-				f.x *= __builtin_amdgcn_rsqf(d2.x);  // d^2 >= 1e-30: a normal number, the bare v_rsq_f32 (what rsqrtf compiles to
-				f.y *= __builtin_amdgcn_rsqf(d2.y);  // behind the d^2 >= 1e-12 test of the branching walk)
-				s2x = __builtin_elementwise_fma(f, dx, s2x);
-				s2y = __builtin_elementwise_fma(f, dy, s2y);
-				s2z = __builtin_elementwise_fma(f, dz, s2z);
-				return d2;
-			};
-			if (dbg != 1) walk([&](uint32_t, f2 qx, f2 qy, f2 qz) {
-				     const f2 d2 = fast(qx, qy, qz);
-				     d2_min = fminf(d2_min, fminf(d2.x, d2.y));
-			     },
-			     [&](uint32_t, f2 qx, f2 qy, f2 qz) {
-				     const f2 d2 = fast(qx, qy, qz);
-				     n_tiny += (d2.x < 1e-12f ? 1u : 0u) + (d2.y < 1e-12f ? 1u : 0u);
-			     });
-			if (d2_min < 1e-12f || n_tiny != 1u) {  // rare
-				s2x = 0.f; s2y = 0.f; s2z = 0.f;
-				walk(pair2, pair2);
-			}
-			sx += s2x.x + s2x.y;
-			sy += s2y.x + s2y.y;
-			sz += s2z.x + s2z.y;
-			const double spring[3] = {(double)sx, (double)sy, (double)sz};
-			double from[3], to[3];
-#pragma unroll
-			for (int d = 0; d < 3; ++d) {
-				from[d] = (double)c[d] + (double)tme[d];
-				double x = from[d] + spring[d] * mp.corr;
-				to[d] = x < 0.0 ? 0.0 : ((double)nn[d] < x ? (double)nn[d] : x);
-			}
-			// (a correction moves a particle by a fraction of a cell: in open water there is nothing to march against, only the
-			// domain walls push back)
-			if (!open_water || fabs(to[0] - from[0]) >= 7.0 || fabs(to[1] - from[1]) >= 7.0 || fabs(to[2] - from[2]) >= 7.0)
-				collide(g, solid, from, to, mp.skin);
-			else
-				collide_walls_only(g, to, mp.skin);
-			int nc[3];
-			float nt[3];
-#pragma unroll
-			for (int d = 0; d < 3; ++d) split_position(to[d], nn[d], nc[d], nt[d]);
-			out_key[j] = blocked_index(g, nc[0], nc[1], nc[2]);
-			out_tx[j] = nt[0]; out_ty[j] = nt[1]; out_tz[j] = nt[2];
-		}
-	}
-}
-
-
-// ------------------------------------------------------------------------------------------------ tile-aligned fine cells
-// Round 2, second version of the neighbour search. The staging of k_correct_fine (halo-cell tables, a raw list, two passes over
-// the records with LDS atomics to re-sort them by fine cell, a scan for the own list) was 2.1 of the kernel's 5.0 ms at C4 and
-// 585 of its 2140 VALU instructions per particle. Fine cells of 8/11 = 0.7273 cells (still >= re = 0.7071) are ALIGNED with the
-// 8-cell tiles - 11 per axis - so the per-tile index can be sorted by fine cell once, by the index kernel, and a workgroup's
-// block of 13 x 13 x 8 fine cells is put together from contiguous runs of its 27 source tiles: per fine row one cell of the
-// x-1 tile, the eleven cells of the own x tile (one run), one cell of the x+1 tile, in that order = sorted by fine cell.
+// ------------------------------------------------------------------------------------------------ position correction
+// _correct_positions (src/simulation.cpp:562-610): pairwise springs between particles closer than re = cell / sqrt 2, all from
+// the OLD positions, fused with the _detect_collisions that follows it.
+// The pair tests are VALU bound and cannot get cheaper per pair, so the lever is the number of candidates. History (C4, a
+// moving dam, ms of the tiled kernel): round 1 walked the 27 CELLS around a particle - 216 candidates for 12 partners - 10.5;
+// packed fp32 pair math 9.2; per-particle pruning of cells by box distance 62 (divergent loop control costs more than the pairs
+// it saves); FINE cells of 0.72 cells, the halo block re-sorted in LDS per workgroup, 81 candidates: 5.8; the force evaluated
+// branch-free for every candidate (below): 5.0. This version: fine cells of 8/11 = 0.7273 cells (still >= re = 0.7071),
+// ALIGNED with the 8-cell tiles - 11 per axis - so the per-tile index is sorted by fine cell once, by the index kernel (1.02 ms
+// instead of 1.17 for the cell index), and a workgroup's block of 13 x 13 x 8 fine cells is put together from contiguous runs
+// of its 27 source tiles without atomics or a second pass: per fine row one cell of the x-1 tile, the eleven cells of the own x
+// tile (one run), one cell of the x+1 tile, in that order = sorted by fine cell. The kernel itself stayed at 5.0 ms (PMC: 2.3e9
+// VALU wave-instructions, 70 % of them the pair walk at ~57 % lane occupancy - the lanes of a wave are particles of ~21
+// different fine cells whose runs have different lengths; staging 18 %, the per-particle epilogue 11 %).
 #define FT 11                                // fine cells per tile axis
 #define FT3 (FT * FT * FT)
 #define FT_STRIDE (FT3 + 1)                  // per tile: first record of every fine cell + the end
@@ -938,9 +237,9 @@ k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx
 #define FBZ (FT_SPLIT + 2)
 #define FB_N (FB * FB * FBZ)
 #define FB_ROWS (FB * FBZ)
-#define FINE2_CAP 5632                       // staged particles (13 x 13 x 8 fine cells hold 4160 at 8 per cell)
-#define FINE2_OWN 3072
-#define FINE2_CNT 1536                       // >= FB_N, a multiple of CORR_THREADS
+#define FINE_CAP 5632                       // staged particles (13 x 13 x 8 fine cells hold 4160 at 8 per cell)
+#define FINE_OWN 3072
+#define FINE_CNT 1536                       // >= FB_N, a multiple of CORR_THREADS
 #define FIDX_STAGE 4608                      // records staged in LDS per tile by the index kernel (72 KB)
 
 __device__ inline int fine_coord(int l, float t) {
@@ -970,10 +269,10 @@ __device__ inline void fine_decode(const float4 &r, int fy, int fz, float t[3], 
 __global__ void __launch_bounds__(256)
 k_build_fine_index(const int *ptiles, int n_ptiles, const uint32_t *key, const float *t0, const float *t1, const float *t2,
                    const uint32_t *tile_start, const uint32_t *tile_count, uint32_t *fine_start, float4 *spos) {
-	__shared__ uint32_t cnt[FINE2_CNT];
+	__shared__ uint32_t cnt[FINE_CNT];
 	__shared__ uint32_t wsum[4];
 	__shared__ float4 stage[FIDX_STAGE];
-	constexpr int PER = FINE2_CNT / 256;
+	constexpr int PER = FINE_CNT / 256;
 	auto fine_of = [&](uint32_t i, int l[3], float t[3]) -> int {
 		const uint32_t k = key[i];
 		l[0] = (int)(k & 7); l[1] = (int)((k >> 3) & 7); l[2] = (int)((k >> 6) & 7);
@@ -1054,7 +353,7 @@ __device__ inline int fine_source(const GridDims &g, const uint32_t *tile_count,
 /// hold) - or, without a flag bitmap, of all: a thread per particle gathers its 27 fine cells from the index in global memory.
 /// `n` = live particles = records of the owned tiles (ghost tiles' records lie behind them).
 __global__ void __launch_bounds__(256)
-k_correct_collide2(size_t n, ParticleSoA p, uint32_t *out_key, float *out_tx, float *out_ty, float *out_tz, GridDims g,
+k_correct_collide(size_t n, ParticleSoA p, uint32_t *out_key, float *out_tx, float *out_ty, float *out_tz, GridDims g,
                    const uint8_t *solid, const uint32_t *tile_count, const uint32_t *fine_start, const float4 *spos, MoveParams mp,
                    const uint32_t *only_flagged, const int *tile_pslot, int p_off, const uint32_t *key_before) {
 	// A thread per RECORD of the index: everything about the particle as it was BEFORE the correction - the tiled kernel has
@@ -1062,6 +361,7 @@ k_correct_collide2(size_t n, ParticleSoA p, uint32_t *out_key, float *out_tx, fl
 	// its old fraction - comes from the record (fractions, index) and the copy of the old keys.
 	const size_t rk = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (rk >= n) return;
+	if (only_flagged && only_flagged[0] == 0) return;  // (word 0 counts the flagged parts: none, as a rule)
 	const float4 me = spos[rk];
 	const size_t i = __float_as_uint(me.w);
 	const uint32_t key_i = key_before ? key_before[i] : p.key[i];
@@ -1073,7 +373,7 @@ k_correct_collide2(size_t n, ParticleSoA p, uint32_t *out_key, float *out_tx, fl
 	const int f[3] = {fine_coord(l[0], t[0]), fine_coord(l[1], t[1]), fine_coord(l[2], t[2])};
 	if (only_flagged) {
 		const int work = CORR_PARTS * (tile_pslot[tile] - p_off) + (f[2] >= FT_SPLIT ? 1 : 0);
-		if (!((only_flagged[work >> 5] >> (work & 31)) & 1u)) return;
+		if (!((only_flagged[1 + (work >> 5)] >> (work & 31)) & 1u)) return;
 	}
 	int tx, ty, tz;
 	tile_coords(g, tile, tx, ty, tz);
@@ -1134,18 +434,18 @@ k_correct_collide2(size_t n, ParticleSoA p, uint32_t *out_key, float *out_tx, fl
 /// LDS-tiled _correct_positions + _detect_collisions on the fine index. One workgroup per (particle tile, z part): part 0 moves the
 /// particles of fine layers 0 .. FT_SPLIT - 1, part 1 the rest; the block staged in LDS is those layers + one fine cell all around.
 __global__ void __launch_bounds__(CORR_THREADS, 4)
-k_correct_fine2(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx, float *out_ty, float *out_tz, GridDims g,
+k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx, float *out_ty, float *out_tz, GridDims g,
                 const uint8_t *solid, const uint32_t *tile_count, const uint32_t *fine_start, const float4 *spos, MoveParams mp,
-                uint32_t *overflow_tiles, const uint8_t *tile_clear, int dbg) {
-	__shared__ float px[FINE2_CAP], py[FINE2_CAP], pz[FINE2_CAP];
-	__shared__ uint32_t fcnt[FINE2_CNT];       // particles per block fine cell; afterwards the own list (u16)
+                uint32_t *overflow_tiles, const uint8_t *tile_clear) {
+	__shared__ float px[FINE_CAP], py[FINE_CAP], pz[FINE_CAP];
+	__shared__ uint32_t fcnt[FINE_CNT];       // particles per block fine cell; afterwards the own list (u16)
 	__shared__ uint16_t foff[FB_N + 1];        // first staged slot of every block fine cell
 	__shared__ uint32_t rowsrc[FB_ROWS * 3];   // first source record of the three runs of a fine row (x-1 tile, own x tile, x+1 tile)
 	__shared__ uint32_t ownoff[FT * FT_SPLIT + 1];
 	__shared__ uint32_t wsum[CORR_THREADS / 64];
 	uint16_t *own = (uint16_t *)fcnt;
-	static_assert(FINE2_CNT * 2 >= FINE2_OWN && FINE2_CNT >= FB_N && FINE2_CNT % CORR_THREADS == 0, "fcnt sizing");
-	constexpr int PER = FINE2_CNT / CORR_THREADS;
+	static_assert(FINE_CNT * 2 >= FINE_OWN && FINE_CNT >= FB_N && FINE_CNT % CORR_THREADS == 0, "fcnt sizing");
+	constexpr int PER = FINE_CNT / CORR_THREADS;
 	const int nn[3] = {g.nx, g.ny, g.nz};
 	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 	for (int work = blockIdx.x; work < CORR_PARTS * n_ptiles; work += gridDim.x) {
@@ -1196,8 +496,11 @@ k_correct_fine2(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_t
 			if (w < wid) woff += wsum[w];
 			total += wsum[w];
 		}
-		if (total > FINE2_CAP) {  // uniform
-			if (threadIdx.x == 0) atomicOr(&overflow_tiles[work >> 5], 1u << (work & 31));
+		if (total > FINE_CAP) {  // uniform
+			if (threadIdx.x == 0) {
+				atomicOr(&overflow_tiles[1 + (work >> 5)], 1u << (work & 31));
+				atomicAdd(&overflow_tiles[0], 1u);
+			}
 			continue;
 		}
 		{
@@ -1234,8 +537,11 @@ k_correct_fine2(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_t
 			if (threadIdx.x < (unsigned)nown_rows) ownoff[threadIdx.x] = wo + in2 - len;
 			if (threadIdx.x == 0) ownoff[nown_rows] = own_total;
 		}
-		if (own_total > FINE2_OWN) {  // uniform
-			if (threadIdx.x == 0) atomicOr(&overflow_tiles[work >> 5], 1u << (work & 31));
+		if (own_total > FINE_OWN) {  // uniform
+			if (threadIdx.x == 0) {
+				atomicOr(&overflow_tiles[1 + (work >> 5)], 1u << (work & 31));
+				atomicAdd(&overflow_tiles[0], 1u);
+			}
 			continue;
 		}
 		__syncthreads();  // (every count has been read: `own` may overwrite the array)
@@ -1266,7 +572,6 @@ k_correct_fine2(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_t
 		}
 		__syncthreads();
 		// ---- one thread per own particle
-		if (dbg == 3) { if (threadIdx.x == 0 && px[0] == 123.f) out_tx[0] = py[own[0]]; continue; }
 		for (uint32_t w = threadIdx.x; w < own_total; w += CORR_THREADS) {
 			const uint32_t me = own[w];
 			const float mx = px[me], my = py[me], mz = pz[me];
@@ -1336,7 +641,7 @@ k_correct_fine2(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_t
 			// particle with the branching walk. (With ~0.72-cell fine cells one candidate in seven is a partner and a wave tests
 			// 128 per step: a "nobody has a partner" branch around the force is almost never skipped - measured: 5.77 -> 5.00 ms.)
 			float d2_min = 1.0f;
-			uint32_t n_tiny = dbg == 1 ? 1u : 0u;
+			uint32_t n_tiny = 0;
 			auto fast = [&](f2 qx, f2 qy, f2 qz) -> f2 {
 				const f2 dx = mx - qx, dy = my - qy, dz = mz - qz;
 				const f2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dx, dx, (f2)1e-30f)));
@@ -1351,8 +656,7 @@ k_correct_fine2(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_t
 				s2z = __builtin_elementwise_fma(f, dz, s2z);
 				return d2;
 			};
-			if (dbg != 1)
-				walk([&](uint32_t, f2 qx, f2 qy, f2 qz) {
+			walk([&](uint32_t, f2 qx, f2 qy, f2 qz) {
 					     const f2 d2 = fast(qx, qy, qz);
 					     d2_min = fminf(d2_min, fminf(d2.x, d2.y));
 				     },
@@ -1384,8 +688,7 @@ k_correct_fine2(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_t
 			}
 			// (a correction moves a particle by a fraction of a cell: in open water there is nothing to march against, only the
 			// domain walls push back)
-			if (dbg == 4) {
-			} else if (!open_water || fabs(to[0] - from[0]) >= 7.0 || fabs(to[1] - from[1]) >= 7.0 || fabs(to[2] - from[2]) >= 7.0)
+			if (!open_water || fabs(to[0] - from[0]) >= 7.0 || fabs(to[1] - from[1]) >= 7.0 || fabs(to[2] - from[2]) >= 7.0)
 				collide(g, solid, from, to, mp.skin);
 			else
 				collide_walls_only(g, to, mp.skin);
@@ -1393,9 +696,8 @@ k_correct_fine2(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_t
 			float nt[3];
 #pragma unroll
 			for (int d = 0; d < 3; ++d) split_position(to[d], nn[d], nc[d], nt[d]);
-			const uint32_t oo = dbg == 2 ? grec : jj;  // EXPERIMENT: coalesced (wrong) destination
-			out_key[oo] = blocked_index(g, nc[0], nc[1], nc[2]);
-			out_tx[oo] = nt[0]; out_ty[oo] = nt[1]; out_tz[oo] = nt[2];
+			out_key[jj] = blocked_index(g, nc[0], nc[1], nc[2]);
+			out_tx[jj] = nt[0]; out_ty[jj] = nt[1]; out_tz[jj] = nt[2];
 		}
 	}
 }
@@ -1655,46 +957,24 @@ static float4 *correction_scratch(lfa_sim *s) {
 	return (float4 *)(!s->vc_pending ? oth.v[0] : (s->vc_with_c ? cur.v[0] : oth.c[0]));
 }
 
-static bool corr_old() {
-	static const bool v = getenv("LFA_CORR_OLD") != nullptr;  // the cell-based index + kernels (A/B runs)
-	return v;
-}
-
 /// First half of lfa_correct_collide: per-cell particle lists + cell-ordered positions (reads the (key, t) of the current binning).
 static int correct_build_index(lfa_sim *s) {
 	const size_t n = s->np_live;
 	if (!n && !s->dist) return LFA_OK;
-	if (!s->cell_start) {
-		hipError_t e = hipMalloc(&s->cell_start, s->ncp * 4);
-		if (e != hipSuccess) return lfa_fail(s, LFA_E_OOM, "hipMalloc of the per-cell start offsets failed");
+	if (!s->fine_start) {
+		const size_t bytes = (size_t)s->g.nt * FT_STRIDE * 4;
+		hipError_t e = hipMalloc(&s->fine_start, bytes);
+		if (e != hipSuccess) return lfa_fail(s, LFA_E_OOM, "hipMalloc of the fine-cell index (%zu bytes) failed", bytes);
 	}
-	const int L = s->g.ntx * s->g.nty;
-	if (s->dist) {
-		// neighbours within one cell across the slab faces: ghost copies of the adjacent tile layers' particles
-		LFA_TRY(lfa_dist_exchange_ghost_particles(s));
-		if (lfa_has_lo(s))
-			LFA_HIP(s, hipMemsetAsync(s->cell_count + (size_t)(s->slab_lo - 1) * L * LFA_TILE_CELLS, 0, (size_t)L * LFA_TILE_CELLS * 4, s->stream));
-		if (lfa_has_hi(s))
-			LFA_HIP(s, hipMemsetAsync(s->cell_count + (size_t)s->slab_hi * L * LFA_TILE_CELLS, 0, (size_t)L * LFA_TILE_CELLS * 4, s->stream));
-	}
+	// neighbours within one cell across the slab faces: ghost copies of the adjacent tile layers' particles
+	if (s->dist) LFA_TRY(lfa_dist_exchange_ghost_particles(s));
 	LFA_TRY(refresh_tile_clear(s));
 	const int n_index = s->dist ? s->n_ptiles_all : s->n_ptiles;
 	const int grid = n_index < 16384 ? (n_index > 0 ? n_index : 1) : 16384;
 	ParticleSoA &cur = s->pb[s->cur];
-	float4 *spos = correction_scratch(s);
 	if (s->timing && n) LFA_HIP(s, hipEventRecord(s->ev[40], s->stream));
-	if (corr_old()) {
-		hipLaunchKernelGGL(k_build_cell_index, dim3(grid), dim3(256), 0, s->stream, s->dist ? s->ptiles_all : s->ptiles, n_index, cur.key,
-		                   cur.t[0], cur.t[1], cur.t[2], s->tile_start, s->tile_count, s->cell_start, spos, s->cell_count,
-		                   s->slab_lo * L, s->slab_hi * L);
-	} else {
-		if (!s->fine_start) {
-			hipError_t e = hipMalloc(&s->fine_start, (size_t)s->g.nt * FT_STRIDE * 4);
-			if (e != hipSuccess) return lfa_fail(s, LFA_E_OOM, "hipMalloc of the fine-cell index (%zu bytes) failed", (size_t)s->g.nt * FT_STRIDE * 4);
-		}
-		hipLaunchKernelGGL(k_build_fine_index, dim3(grid), dim3(256), 0, s->stream, s->dist ? s->ptiles_all : s->ptiles, n_index, cur.key,
-		                   cur.t[0], cur.t[1], cur.t[2], s->tile_start, s->tile_count, s->fine_start, spos);
-	}
+	hipLaunchKernelGGL(k_build_fine_index, dim3(grid), dim3(256), 0, s->stream, s->dist ? s->ptiles_all : s->ptiles, n_index, cur.key,
+	                   cur.t[0], cur.t[1], cur.t[2], s->tile_start, s->tile_count, s->fine_start, correction_scratch(s));
 	LFA_LAUNCH_CHECK(s);
 	return LFA_OK;
 }
@@ -1707,43 +987,28 @@ static int correct_apply(lfa_sim *s, double dt) {
 	if (n) {
 		// LDS-tiled pass; half tiles whose neighbourhood exceeds the LDS capacity are flagged and redone by the global-gather
 		// kernel (restricted to those particles)
-		const size_t ovf_words = ((size_t)CORR_PARTS * s->n_ptiles + 31) / 32 + 1;
+		const size_t ovf_words = ((size_t)CORR_PARTS * s->n_ptiles + 31) / 32 + 2;  // word 0: how many are flagged
 		if (!s->corr_ovf) {  // 2 bits per tile of the grid; its own array: the pressure solve may be running beside this
-			hipError_t e = hipMalloc(&s->corr_ovf, (((size_t)CORR_PARTS * s->g.nt + 31) / 32 + 1) * 4);
+			hipError_t e = hipMalloc(&s->corr_ovf, (((size_t)CORR_PARTS * s->g.nt + 31) / 32 + 2) * 4);
 			if (e != hipSuccess) return lfa_fail(s, LFA_E_OOM, "hipMalloc of the correction's overflow bitmap failed");
 		}
 		uint32_t *ovf = s->corr_ovf;
 		LFA_HIP(s, hipMemsetAsync(ovf, 0, ovf_words * 4, s->stream));
 		{
 			const int work = CORR_PARTS * s->n_ptiles, g2 = work < 65536 ? (work > 0 ? work : 1) : 65536;
-			// every neighbour position comes from the cell-ordered records built above (the OLD positions), so the new ones
-			// are written in place; the fallback pass below selects its particles by their old keys
+			// every neighbour position comes from the records of the index built above (the OLD positions), so the new ones are
+			// written in place; the fallback pass below takes its particles' old state from the records and this copy of the keys
 			LFA_HIP(s, hipMemcpyAsync(oth.key, cur.key, n * 4, hipMemcpyDeviceToDevice, s->stream));
 			if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[41], s->stream));
-			const int dbg = getenv("LFA_CORR_DBG") ? atoi(getenv("LFA_CORR_DBG")) : 0;
-			if (!corr_old())
-				hipLaunchKernelGGL(k_correct_fine2, dim3(g2), dim3(CORR_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, cur.key, cur.t[0],
-				                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_count, s->fine_start, (const float4 *)spos, move_params(s, dt), ovf,
-				                   (const uint8_t *)s->tile_clear, dbg);
-			else if (getenv("LFA_CORR_COARSE"))  // round 1's walk over the 27 cells (A/B runs)
-				hipLaunchKernelGGL(k_correct_tiled, dim3(g2), dim3(CORR_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, cur, cur.key, cur.t[0],
-				                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_flag, s->cell_count, s->cell_start, (const float4 *)spos,
-				                   move_params(s, dt), ovf);
-			else
-				hipLaunchKernelGGL(k_correct_fine, dim3(g2), dim3(CORR_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, cur.key, cur.t[0],
-				                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_flag, s->cell_count, s->cell_start, (const float4 *)spos,
-				                   move_params(s, dt), ovf, (const uint8_t *)s->tile_clear, dbg);
+			hipLaunchKernelGGL(k_correct_fine, dim3(g2), dim3(CORR_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, cur.key, cur.t[0],
+			                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_count, s->fine_start, (const float4 *)spos, move_params(s, dt), ovf,
+			                   (const uint8_t *)s->tile_clear);
 			LFA_LAUNCH_CHECK(s);
 			if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[42], s->stream));
 		}
-		if (!corr_old())
-			hipLaunchKernelGGL(k_correct_collide2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, cur, cur.key, cur.t[0],
-			                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_count, s->fine_start, (const float4 *)spos, move_params(s, dt),
-			                   (const uint32_t *)ovf, (const int *)s->tile_pslot, s->p_off, (const uint32_t *)oth.key);
-		else
-			hipLaunchKernelGGL(k_correct_collide, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, cur, cur.key, cur.t[0],
-			                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_flag, s->cell_count, s->cell_start, (const float4 *)spos,
-			                   move_params(s, dt), (const uint32_t *)ovf, (const int *)s->tile_pslot, s->p_off, (const uint32_t *)oth.key);
+		hipLaunchKernelGGL(k_correct_collide, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, cur, cur.key, cur.t[0],
+		                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_count, s->fine_start, (const float4 *)spos, move_params(s, dt),
+		                   (const uint32_t *)ovf, (const int *)s->tile_pslot, s->p_off, (const uint32_t *)oth.key);
 		LFA_LAUNCH_CHECK(s);
 	}
 	LFA_TRY(lfa_dist_migrate(s));
