@@ -104,6 +104,10 @@ def main():
     ap.add_argument("--no-hot-path", action="store_true")
     ap.add_argument("--no-mic0-record", action="store_true", help="skip the reference-comparable MIC(0)-PCG figure")
     ap.add_argument("--hot-steps", type=int, default=10)
+    ap.add_argument("--no-overlap", action="store_true", help="stages of time_step back to back (lfa_set_step_overlap(0)): "
+                    "what the per-kernel profiles under profiles/ are taken with")
+    ap.add_argument("--no-serial-stages", action="store_true", help="skip the second loop (stages back to back) that the per-stage "
+                    "figures come from: stage_ms_* are then the stretched spans of the overlapped steps")
     ap.add_argument("--unfused", action="store_true", help="one launch per vector operation in the PCG loop (pcg_fused = 0)")
     ap.add_argument("--obstacle", action="store_true", help="BASELINE configs[4]: voxelize a sphere mesh on the device "
                     "(lfa_voxelize_mesh) and mark it solid before the steps")
@@ -183,6 +187,8 @@ def main():
         vox.close()
     sim.seed_block(blo, bhi)
     sim.enable_timing(True)
+    if args.no_overlap:
+        sim.set_step_overlap(False)
 
     def barrier():
         sim.synchronize()
@@ -238,7 +244,7 @@ def main():
     stage_overlapped = {k: med([s[k] for s in per_step]) for k in names} if overlapped else None
     iters_timed = iters_total
     serial_ms = None
-    if overlapped:
+    if overlapped and not args.no_serial_stages:
         # Stage attribution: in the timed steps the position correction runs on its own stream beside the pressure solve, so the
         # stage spans stretch each other and do not add up. The same steps back to back (lfa_set_step_overlap(0)), AFTER the
         # timed region, give the per-stage / per-kernel times every roofline figure below is priced on; `value` is not.
@@ -288,7 +294,7 @@ def main():
         },
         "stage_ms_median": stage_med, "stage_ms_p95": stage_p95,
     }
-    if overlapped:
+    if overlapped and serial_ms is not None:
         out["stage_ms_note"] = (f"stage_ms_* and every per-kernel figure: {args.steps} further steps with the stages back to back "
                                 f"(lfa_set_step_overlap(0): {serial_ms:.3f} ms per step wall); `value` / ms_per_step: the timed steps "
                                 "with the position correction on a second stream beside the pressure solve (the default)")

@@ -13,13 +13,13 @@ NAMES = {"k_pcg_a<float, false, true>": "pcg_a", "k_pcg_b<float, true>": "pcg_b"
          "k_spmv<float>": "spmv_dot", "k_axpy_max<float>": "axpy_max", "k_mic_apply<float, 0, true>": "mic_apply_dot",
          "k_update_s<float>": "update_s", "k_p2g_binned<true>": "p2g_scatter", "k_p2g_binned<false>": "p2g_scatter", "k_p2g_binned<true, false>": "p2g_scatter",
          "k_p2g_binned<false, false>": "p2g_scatter", "k_p2g_binned<true, true>": "p2g_scatter", "k_correct_fine": "correct_tiled",
-         "k_build_cell_index": "correct_cell_index", "k_advect_collide<false>": "advect_collide", "k_advect_collide<true>": "advect_collide",
+         "k_build_fine_index": "correct_cell_index", "k_advect_collide<false>": "advect_collide", "k_advect_collide<true>": "advect_collide",
          "k_tile_scatter<1>": "bin_scatter", "k_tile_scatter<2>": "bin_scatter", "k_tile_scatter<0>": "bin_scatter",
          "k_mg_residual_restrict<float>": "mg_down0",
          "k_p2g_finalize<true>": "p2g_finalize", "k_p2g_finalize<false>": "p2g_finalize", "k_g2p<2>": "g2p",
          "k_g2p<1>": "g2p", "k_g2p<0>": "g2p", "k_g2p<2, true>": "g2p", "k_g2p<1, true>": "g2p", "k_g2p<0, true>": "g2p",
          "k_tile_scatter": "bin_scatter", "k_tile_scatter<true>": "bin_scatter", "k_tile_scatter<false>": "bin_scatter", "k_gather_vc": "bin_deferred_gather", "k_tile_count": "bin_count", "k_cell_count": "bin_cells",
-         "k_mg_axpy_presmooth<float>": "mg_axpy_presmooth", "k_mg_prolong_postsmooth<float, true>": "mg_up0", "k_mg_tail<float>": "mg_tail", "k_correct_tiled": "correct_positions"}
+         "k_mg_axpy_presmooth<float>": "mg_axpy_presmooth", "k_mg_prolong_postsmooth<float, true>": "mg_up0", "k_mg_tail<float>": "mg_tail"}
 
 
 def load(path, counter):
