@@ -121,6 +121,61 @@ __device__ inline unsigned long long to_fixed(float x, double scale) {
 	return (unsigned long long)(__double_as_longlong(d) - __double_as_longlong(magic));
 }
 
+/// The 2 x 2 x 2 scatter of one particle straight into the LDS accumulators, trimmed for the binned kernel (its VALU work - 725
+/// instructions per particle, 76 % of the SIMD cycles - bounds it as much as the LDS atomics do):
+/// * the lane's rotation is an XOR (node n of the unrolled loop is node n ^ rot, a bijection for every rot, so the lanes of a cell
+///   still hit eight different nodes at the same time) and is applied ONCE per axis by swapping the axis' pair of weights, affine
+///   terms and offsets - the nodes then index those pairs with compile-time bits: no select, no index arithmetic per node;
+/// * the fixed-point scales ride on the factors: the x weights carry 2^40, v and the affine terms 2^-4 (powers of two: every
+///   product and sum rounds as before, the results are bit-identical), so a value converts with one cvt, one f64 add of the magic
+///   constant and one 64-bit subtract instead of cvt + two moves + fma + subtract.
+template <bool APIC>
+__device__ inline void scatter_particle_lds(unsigned long long *acc, int lx, int ly, int lz, const float t[3], const float v[3],
+                                            const float c[9], float hworld, int rot) {
+	const bool r0 = (rot & 1) != 0, r1 = (rot & 2) != 0, r2 = (rot & 4) != 0;
+	const double magic = 6755399441055744.0;  // 1.5 * 2^52 (to_fixed)
+	auto conv = [&](float scaled) -> unsigned long long {
+		return (unsigned long long)(__double_as_longlong((double)scaled + magic) - __double_as_longlong(magic));
+	};
+	const float sw = (float)P2G_FIX_SCALE_W, sv = (float)(P2G_FIX_SCALE_V / P2G_FIX_SCALE_W);
+#pragma unroll
+	for (int comp = 0; comp < 3; ++comp) {
+		int b[3];
+		float f[3];
+#pragma unroll
+		for (int a = 0; a < 3; ++a) axis_bf(t[a], a == comp, b[a], f[a]);
+		// byte offsets: node (i, j, k) = base + ox[i] + oy[j] + oz[k] (the sum of w sits LFA_HALO_CELLS entries behind the sum of w v)
+		const uint32_t a0 = 8u * (uint32_t)(comp * 2 * LFA_HALO_CELLS + ((lx + 1 + b[0]) + 10 * (ly + 1 + b[1]) + 100 * (lz + 1 + b[2])));
+		const float wx_lo = (1.0f - f[0]) * sw, wx_hi = f[0] * sw, wy_lo = 1.0f - f[1], wy_hi = f[1], wz_lo = 1.0f - f[2], wz_hi = f[2];
+		const float wx[2] = {r0 ? wx_hi : wx_lo, r0 ? wx_lo : wx_hi}, wy[2] = {r1 ? wy_hi : wy_lo, r1 ? wy_lo : wy_hi},
+		            wz[2] = {r2 ? wz_hi : wz_lo, r2 ? wz_lo : wz_hi};
+		const uint32_t ox[2] = {r0 ? 8u : 0u, r0 ? 0u : 8u}, oy[2] = {r1 ? 80u : 0u, r1 ? 0u : 80u};
+		const uint32_t oz[2] = {a0 + (r2 ? 800u : 0u), a0 + (r2 ? 0u : 800u)};
+		const uint32_t oxy[4] = {ox[0] + oy[0], ox[1] + oy[0], ox[0] + oy[1], ox[1] + oy[1]};
+		float ax[2] = {0.f, 0.f}, ay[2] = {0.f, 0.f}, az[2] = {0.f, 0.f};
+		const float vs = v[comp] * sv;
+		if (APIC) {
+			// affine term dot(c_comp, face - p) (src/simulation.cpp:371-375); (face - p)_a = -(f_a - i) * h
+			const float *cc = c + 3 * comp;
+			const float ax_lo = (-hworld * cc[0] * f[0]) * sv, ax_hi = (-hworld * cc[0] * (f[0] - 1.0f)) * sv;
+			const float ay_lo = (-hworld * cc[1] * f[1]) * sv, ay_hi = (-hworld * cc[1] * (f[1] - 1.0f)) * sv;
+			const float az_lo = (-hworld * cc[2] * f[2]) * sv, az_hi = (-hworld * cc[2] * (f[2] - 1.0f)) * sv;
+			ax[0] = r0 ? ax_hi : ax_lo; ax[1] = r0 ? ax_lo : ax_hi;
+			ay[0] = r1 ? ay_hi : ay_lo; ay[1] = r1 ? ay_lo : ay_hi;
+			az[0] = r2 ? az_hi : az_lo; az[1] = r2 ? az_lo : az_hi;
+		}
+#pragma unroll
+		for (int n = 0; n < 8; ++n) {
+			const int i = n & 1, j = (n >> 1) & 1, k = n >> 2;
+			const float wgt = (wx[i] * wy[j]) * wz[k];  // product order of _kernel, :209-212 (x 2^40)
+			const float val = APIC ? vs + ((ax[i] + ay[j]) + az[k]) : vs;  // (x 2^-4)
+			unsigned long long *a = (unsigned long long *)((char *)acc + (oxy[i + 2 * j] + oz[k]));
+			atomicAdd(a, conv(wgt * val));
+			atomicAdd(a + LFA_HALO_CELLS, conv(wgt));
+		}
+	}
+}
+
 struct ParticleRegs {
 	uint32_t key;
 	float t[3], v[3], c[9];
@@ -163,12 +218,15 @@ k_p2g_binned(const int *ptiles, int n_ptiles, ParticleSoA p, ParticleSoA pvc, co
 			if (in < end) load_particle<APIC>(p, pvc, in, jn, nxt);
 			jn = jnn;
 			const int l = (int)(cur.key & 511);
-			scatter_particle<APIC, QUIRK>(l & 7, (l >> 3) & 7, l >> 6, cur.t, cur.v, cur.c, hworld, (int)(threadIdx.x & rot_mask),
-			                       [&](int comp, int hx, int hy, int hz, float wv, float wgt) {
-				                       unsigned long long *a = acc + comp * 2 * LFA_HALO_CELLS + hx + 10 * hy + 100 * hz;
-				                       atomicAdd(a, to_fixed(wv, P2G_FIX_SCALE_V));
-				                       atomicAdd(a + LFA_HALO_CELLS, to_fixed(wgt, P2G_FIX_SCALE_W));
-			                       });
+			if (!QUIRK)
+				scatter_particle_lds<APIC>(acc, l & 7, (l >> 3) & 7, l >> 6, cur.t, cur.v, cur.c, hworld, (int)(threadIdx.x & rot_mask));
+			else
+				scatter_particle<APIC, QUIRK>(l & 7, (l >> 3) & 7, l >> 6, cur.t, cur.v, cur.c, hworld, (int)(threadIdx.x & rot_mask),
+				                       [&](int comp, int hx, int hy, int hz, float wv, float wgt) {
+					                       unsigned long long *a = acc + comp * 2 * LFA_HALO_CELLS + hx + 10 * hy + 100 * hz;
+					                       atomicAdd(a, to_fixed(wv, P2G_FIX_SCALE_V));
+					                       atomicAdd(a + LFA_HALO_CELLS, to_fixed(wgt, P2G_FIX_SCALE_W));
+				                       });
 			cur = nxt;
 		}
 		__syncthreads();
