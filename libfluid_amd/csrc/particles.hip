@@ -279,17 +279,39 @@ k_build_fine_index(const int *ptiles, int n_ptiles, const uint32_t *key, const f
 		t[0] = t0[i]; t[1] = t1[i]; t[2] = t2[i];
 		return fine_coord(l[0], t[0]) + FT * (fine_coord(l[1], t[1]) + FT * fine_coord(l[2], t[2]));
 	};
+	constexpr int RPT = FIDX_STAGE / 256;  // particles per thread of a tile that fits the staging area: kept in registers
 	for (int slot = blockIdx.x; slot < n_ptiles; slot += gridDim.x) {
 		const int tile = ptiles[slot];
 		// ghost tiles (slab decomposition) keep their particles behind the live ones: the range end comes from the count
 		const uint32_t b = tile_start[tile], e = b + tile_count[tile];
+		const bool staged = e - b <= FIDX_STAGE;  // (uniform)
 #pragma unroll
 		for (int k = 0; k < PER; ++k) cnt[threadIdx.x + 256 * k] = 0;
 		__syncthreads();
-		for (uint32_t i = b + threadIdx.x; i < e; i += 256) {
-			int l[3];
-			float t[3];
-			atomicAdd(&cnt[fine_of(i, l, t)], 1u);
+		// pass 1: histogram. A tile that fits keeps what it has read - (fine cell << 9 | cell in the tile) and the fractions -
+		// in registers for pass 2 (reading key and t a second time was a third of the kernel's HBM traffic)
+		uint32_t rf[RPT];
+		float r0[RPT], r1[RPT], r2[RPT];
+		if (staged) {
+#pragma unroll
+			for (int r = 0; r < RPT; ++r) {
+				const uint32_t i = b + threadIdx.x + 256 * r;
+				rf[r] = 0xFFFFFFFFu;
+				if (i < e) {
+					int l[3];
+					float t[3];
+					const int f = fine_of(i, l, t);
+					rf[r] = ((uint32_t)f << 9) | (uint32_t)(l[0] | (l[1] << 3) | (l[2] << 6));
+					r0[r] = t[0]; r1[r] = t[1]; r2[r] = t[2];
+					atomicAdd(&cnt[f], 1u);
+				}
+			}
+		} else {
+			for (uint32_t i = b + threadIdx.x; i < e; i += 256) {
+				int l[3];
+				float t[3];
+				atomicAdd(&cnt[fine_of(i, l, t)], 1u);
+			}
 		}
 		__syncthreads();
 		// exclusive scan: thread t owns entries PER t .. PER t + PER - 1
@@ -319,20 +341,26 @@ k_build_fine_index(const int *ptiles, int n_ptiles, const uint32_t *key, const f
 			ex += c[k];
 		}
 		__syncthreads();
-		// the records are put in place in LDS and written out as one contiguous run (scattered 16-B stores straight to HBM cost
-		// 1.6x); a tile with more particles than the staging area holds writes them directly
-		const bool staged = e - b <= FIDX_STAGE;
-		for (uint32_t i = b + threadIdx.x; i < e; i += 256) {
-			int l[3];
-			float t[3];
-			const uint32_t at = atomicAdd(&cnt[fine_of(i, l, t)], 1u);
-			const float4 rec = fine_record(l[0], l[1], l[2], t[0], t[1], t[2], i);
-			if (staged) stage[at - b] = rec;
-			else spos[at] = rec;
-		}
-		__syncthreads();
-		if (staged)
+		// pass 2: the records are put in place in LDS and written out as one contiguous run (scattered 16-B stores straight to
+		// HBM cost 1.6x); a tile with more particles than the staging area holds reads them again and writes them directly
+		if (staged) {
+#pragma unroll
+			for (int r = 0; r < RPT; ++r)
+				if (rf[r] != 0xFFFFFFFFu) {
+					const uint32_t at = atomicAdd(&cnt[rf[r] >> 9], 1u);
+					stage[at - b] = fine_record((int)(rf[r] & 7), (int)((rf[r] >> 3) & 7), (int)((rf[r] >> 6) & 7), r0[r], r1[r], r2[r],
+					                            b + threadIdx.x + 256 * r);
+				}
+			__syncthreads();
 			for (uint32_t k = threadIdx.x; k < e - b; k += 256) spos[b + k] = stage[k];
+		} else {
+			for (uint32_t i = b + threadIdx.x; i < e; i += 256) {
+				int l[3];
+				float t[3];
+				const uint32_t at = atomicAdd(&cnt[fine_of(i, l, t)], 1u);
+				spos[at] = fine_record(l[0], l[1], l[2], t[0], t[1], t[2], i);
+			}
+		}
 		__syncthreads();
 	}
 }
