@@ -470,6 +470,7 @@ k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx
 	__shared__ uint16_t foff[FB_N + 1];        // first staged slot of every block fine cell
 	__shared__ uint32_t rowsrc[FB_ROWS * 3];   // first source record of the three runs of a fine row (x-1 tile, own x tile, x+1 tile)
 	__shared__ uint32_t ownoff[FT * FT_SPLIT + 1];
+	__shared__ int srct[27];                   // the source tiles around the own one
 	__shared__ uint32_t wsum[CORR_THREADS / 64];
 	uint16_t *own = (uint16_t *)fcnt;
 	static_assert(FINE_CNT * 2 >= FINE_OWN && FINE_CNT >= FB_N && FINE_CNT % CORR_THREADS == 0, "fcnt sizing");
@@ -485,17 +486,26 @@ k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx
 		const int nrows = FB * nzb, nown_rows = FT * (nzb - 2);
 		const bool open_water = (tile_clear[tile] & 1) != 0;  // no solid cell within a tile of this one
 		__syncthreads();
-		// ---- the block's fine cells: where their records are, how many
+		// ---- the 27 source tiles (-1: outside the grid or without particles), then the block's fine cells: where their records
+		// are, how many
+		if (threadIdx.x < 27) {
+			int fx, fy, fz;
+			srct[threadIdx.x] = fine_source(g, tile_count, tx, ty, tz, FT * ((int)threadIdx.x % 3 - 1), FT * (((int)threadIdx.x / 3) % 3 - 1),
+			                                FT * ((int)threadIdx.x / 9 - 1), fx, fy, fz);
+		}
+		__syncthreads();
 #pragma unroll
 		for (int k = 0; k < PER; ++k) {
 			const int f = threadIdx.x + CORR_THREADS * k;
 			uint32_t cnt = 0, src0 = 0;
 			if (f < FB * nrows) {
 				const int bx = f % FB, row = f / FB, by = row % FB, bz = row / FB;
-				int fx, fy, fz;
-				const int src = fine_source(g, tile_count, tx, ty, tz, bx - 1, by - 1, gz0 + bz, fx, fy, fz);
+				const int gx = bx - 1, gy = by - 1, gz = gz0 + bz;
+				const int dx = gx < 0 ? 0 : (gx >= FT ? 2 : 1), dy = gy < 0 ? 0 : (gy >= FT ? 2 : 1), dz = gz < 0 ? 0 : (gz >= FT ? 2 : 1);
+				const int src = srct[dx + 3 * dy + 9 * dz];
 				if (src >= 0) {
-					const uint32_t *fs = fine_start + (size_t)src * FT_STRIDE + (fx + FT * (fy + FT * fz));
+					const uint32_t fid = (uint32_t)((gx - FT * (dx - 1)) + FT * ((gy - FT * (dy - 1)) + FT * (gz - FT * (dz - 1))));
+					const uint32_t *fs = fine_start + ((uint32_t)src * FT_STRIDE + fid);  // (nt * FT_STRIDE < 2^32 up to 3 M tiles)
 					src0 = fs[0];
 					cnt = fs[1] - src0;
 				}
