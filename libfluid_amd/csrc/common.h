@@ -61,6 +61,7 @@ struct lfa_sim {
 	hipEvent_t ev_cfork = nullptr, ev_cjoin = nullptr;
 	bool overlap_correction = true;
 	bool corr_in_flight = false;   // lfa_correct_collide_begin .. _end: the particle arrays belong to the correction on stream3
+	bool counts_fresh = false;     // tile_count / rank were produced by the advection of lfa_time_step: the binning skips its pass 1
 	bool corr_undo_valid = false;  // nothing has changed positions, binning or solids since: lfa_correct_collide_undo can restore
 	uint32_t *corr_ovf = nullptr;  // overflow bitmap of the tiled correction (2 bits per particle tile)
 	GridDims g{};
@@ -239,6 +240,50 @@ __host__ __device__ inline uint64_t raw_from_blocked(const GridDims &g, uint32_t
 }
 
 // ---------------------------------------------------------------------------------------------------- wave helpers
+/// Binning, pass 1 (core.hip: k_tile_count; particles.hip: the advection of lfa_time_step does it on the way): a wave holds
+/// TC_CHUNKS x 64 consecutive particles, tile[c] = tile of the particle of chunk c in this lane (0xFFFFFFFF: none). One atomic per
+/// distinct tile among them; a wave's particles of one tile get consecutive ranks in input order.
+#define TC_CHUNKS 8
+template <int CH>
+__device__ inline void lfa_wave_tile_ranks(const uint32_t (&tile)[CH], uint32_t *tile_count, uint32_t (&my_rank)[CH]) {
+	const int lane = threadIdx.x & 63;
+	const unsigned long long lt = (1ull << lane) - 1ull;
+	unsigned long long todo[CH];
+#pragma unroll
+	for (int c = 0; c < CH; ++c) {
+		todo[c] = __ballot(tile[c] != 0xFFFFFFFFu);
+		my_rank[c] = 0;
+	}
+	for (;;) {
+		// the first pending particle (chunk-major) names the tile of this round
+		uint32_t t = 0xFFFFFFFFu;
+		bool found = false;
+#pragma unroll
+		for (int c = 0; c < CH; ++c)
+			if (!found && todo[c]) {
+				t = __shfl(tile[c], __ffsll((long long)todo[c]) - 1, 64);
+				found = true;
+			}
+		if (!found) break;
+		unsigned long long same[CH];
+		uint32_t total = 0;
+#pragma unroll
+		for (int c = 0; c < CH; ++c) {
+			same[c] = __ballot(tile[c] == t) & todo[c];
+			total += (uint32_t)__popcll(same[c]);
+		}
+		uint32_t base = 0;
+		if (lane == 0) base = atomicAdd(&tile_count[t], total);
+		base = __shfl(base, 0, 64);
+#pragma unroll
+		for (int c = 0; c < CH; ++c) {
+			if ((same[c] >> lane) & 1ull) my_rank[c] = base + (uint32_t)__popcll(same[c] & lt);
+			base += (uint32_t)__popcll(same[c]);
+			todo[c] &= ~same[c];
+		}
+	}
+}
+
 template <typename T> __device__ inline T wave_sum(T v) {
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -258,6 +303,7 @@ int lfa_exclusive_scan_u32(lfa_sim *s, const uint32_t *in, uint32_t *out, size_t
 
 // stage entry points implemented per file
 int lfa_particles_alloc(lfa_sim *s, size_t n);
+int lfa_hash_particles_impl(lfa_sim *s, bool counts_done);  // counts_done: tile_count / rank already hold pass 1 (lfa_time_step)
 int lfa_particles_materialize(lfa_sim *s);  // completes a deferred binning (no-op otherwise)
 int lfa_ensure_io(lfa_sim *s, size_t bytes);
 int lfa_pcg_alloc(lfa_sim *s);

@@ -762,50 +762,18 @@ extern "C" int lfa_upload_cells(lfa_sim *s, const void *aos32) {
 /// tile), so that is 1-3 atomics per 256 particles, and a wave's particles of one tile get consecutive ranks in input order
 /// (the scatter then writes runs of up to 1 KB per field). One particle per lane spent its time waiting for the returning
 /// atomic (0.54 ms at C4; 4 chunks: see DESIGN.md).
-#define TC_CHUNKS 8
 __global__ void __launch_bounds__(256) k_tile_count(const uint32_t *key, size_t n, uint32_t *tile_count, uint32_t *rank) {
 	const int lane = threadIdx.x & 63;
 	const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
 	const size_t i0 = wave * (64 * TC_CHUNKS) + lane;
-	const unsigned long long lt = (1ull << lane) - 1ull;
 	uint32_t tile[TC_CHUNKS], my_rank[TC_CHUNKS];
-	unsigned long long todo[TC_CHUNKS];
 #pragma unroll
 	for (int c = 0; c < TC_CHUNKS; ++c) {
 		const size_t i = i0 + 64 * c;
 		const uint32_t k = i < n ? key[i] : 0xFFFFFFFFu;
 		tile[c] = k != 0xFFFFFFFFu ? k >> 9 : 0xFFFFFFFFu;
-		todo[c] = __ballot(k != 0xFFFFFFFFu);
-		my_rank[c] = 0;
 	}
-	for (;;) {
-		// the first pending particle (chunk-major) names the tile of this round
-		uint32_t t = 0xFFFFFFFFu;
-		bool found = false;
-#pragma unroll
-		for (int c = 0; c < TC_CHUNKS; ++c)
-			if (!found && todo[c]) {
-				t = __shfl(tile[c], __ffsll((long long)todo[c]) - 1, 64);
-				found = true;
-			}
-		if (!found) break;
-		unsigned long long same[TC_CHUNKS];
-		uint32_t total = 0;
-#pragma unroll
-		for (int c = 0; c < TC_CHUNKS; ++c) {
-			same[c] = __ballot(tile[c] == t) & todo[c];
-			total += (uint32_t)__popcll(same[c]);
-		}
-		uint32_t base = 0;
-		if (lane == 0) base = atomicAdd(&tile_count[t], total);
-		base = __shfl(base, 0, 64);
-#pragma unroll
-		for (int c = 0; c < TC_CHUNKS; ++c) {
-			if ((same[c] >> lane) & 1ull) my_rank[c] = base + (uint32_t)__popcll(same[c] & lt);
-			base += (uint32_t)__popcll(same[c]);
-			todo[c] &= ~same[c];
-		}
-	}
+	lfa_wave_tile_ranks(tile, tile_count, my_rank);
 #pragma unroll
 	for (int c = 0; c < TC_CHUNKS; ++c) {
 		const size_t i = i0 + 64 * c;
@@ -951,7 +919,8 @@ int lfa_particles_materialize(lfa_sim *s) {
 	return LFA_OK;
 }
 
-extern "C" int lfa_hash_particles(lfa_sim *s) {
+extern "C" int lfa_hash_particles(lfa_sim *s) { return lfa_hash_particles_impl(s, false); }
+int lfa_hash_particles_impl(lfa_sim *s, bool counts_done) {
 	if (!s) return LFA_E_INVALID;
 	LFA_HIP(s, hipSetDevice(s->device));
 	LFA_TRY(lfa_corr_commit(s));
@@ -964,11 +933,14 @@ extern "C" int lfa_hash_particles(lfa_sim *s) {
 	const int own_lo = s->slab_lo * L, own_hi = s->slab_hi * L;
 	const int all_lo = lfa_has_lo(s) ? own_lo - L : own_lo, all_hi = lfa_has_hi(s) ? own_hi + L : own_hi;
 
-	LFA_HIP(s, hipMemsetAsync(s->tile_count, 0, (size_t)(nt + 1) * 4, s->stream));
-	if (n) {
-		hipLaunchKernelGGL(k_tile_count, dim3((unsigned)((n + 256 * TC_CHUNKS - 1) / (256 * TC_CHUNKS))), dim3(256), 0, s->stream, src.key, n,
-		                   s->tile_count, s->rank);
-		LFA_LAUNCH_CHECK(s);
+	// pass 1 (particles per tile, rank inside the tile) - unless the advection kernel of lfa_time_step has just done it
+	if (!counts_done) {
+		LFA_HIP(s, hipMemsetAsync(s->tile_count, 0, (size_t)(nt + 1) * 4, s->stream));
+		if (n) {
+			hipLaunchKernelGGL(k_tile_count, dim3((unsigned)((n + 256 * TC_CHUNKS - 1) / (256 * TC_CHUNKS))), dim3(256), 0, s->stream, src.key, n,
+			                   s->tile_count, s->rank);
+			LFA_LAUNCH_CHECK(s);
+		}
 	}
 	// tile_start[0..nt] (exclusive scan; entry nt = number of live particles because tile_count[nt] == 0)
 	LFA_TRY(lfa_exclusive_scan_u32(s, s->tile_count, s->tile_start, (size_t)nt + 1, nullptr));

@@ -162,18 +162,16 @@ __global__ void k_tile_clear(GridDims g, const uint8_t *tile_solid, uint8_t *til
 /// coercing source takes the source's velocity and C = 0 (the cell is the particle's current one: the reference hashes at the
 /// start of the step, :49).
 template <bool COERCE>
-__global__ void __launch_bounds__(256)
-k_advect_collide(size_t n, ParticleSoA p, GridDims g, const uint8_t *solid, MoveParams mp, const uint8_t *coerce_map,
-                 const float *src_vel, const uint8_t *tile_clear) {
-	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	if (p.key[i] == 0xFFFFFFFFu) return;  // outside this rank's slab (dropped at the next binning)
+__device__ inline uint32_t advect_one(size_t i, const ParticleSoA &p, const GridDims &g, const uint8_t *solid, const MoveParams &mp,
+                                      const uint8_t *coerce_map, const float *src_vel, const uint8_t *tile_clear) {
+	const uint32_t key = p.key[i];
+	if (key == 0xFFFFFFFFu) return key;  // outside this rank's slab (dropped at the next binning)
 	int c[3];
-	cell_of_key(g, p.key[i], c);
+	cell_of_key(g, key, c);
 	const int nn[3] = {g.nx, g.ny, g.nz};
 	float vel[3] = {p.v[0][i], p.v[1][i], p.v[2][i]};
 	if (COERCE) {
-		const uint32_t src = coerce_map[p.key[i]];
+		const uint32_t src = coerce_map[key];
 		if (src) {
 #pragma unroll
 			for (int d = 0; d < 3; ++d) {
@@ -196,16 +194,52 @@ k_advect_collide(size_t n, ParticleSoA p, GridDims g, const uint8_t *solid, Move
 	// and of its skin push-out only the domain walls remain - where the clamp above has already left the particle at least
 	// `skin` inside (to[d] in [skin, n - skin] => cp >= skin in cell 0, cp <= 1 - skin in cell n - 1). The general path costs
 	// a dependent byte load per crossed cell and per near face; most tiles of a scene are nowhere near a solid.
-	const bool open_water = (tile_clear[p.key[i] >> 9] & 1) && fabs(to[0] - from[0]) < 8.0 && fabs(to[1] - from[1]) < 8.0 &&
+	const bool open_water = (tile_clear[key >> 9] & 1) && fabs(to[0] - from[0]) < 8.0 && fabs(to[1] - from[1]) < 8.0 &&
 	                        fabs(to[2] - from[2]) < 8.0;
 	if (!open_water) collide(g, solid, from, to, mp.skin);
 	int nc[3];
 	float nt[3];
 #pragma unroll
 	for (int d = 0; d < 3; ++d) split_position(to[d], nn[d], nc[d], nt[d]);
-	p.key[i] = blocked_index(g, nc[0], nc[1], nc[2]);
+	const uint32_t new_key = blocked_index(g, nc[0], nc[1], nc[2]);
+	p.key[i] = new_key;
 #pragma unroll
 	for (int d = 0; d < 3; ++d) p.t[d][i] = nt[d];
+	return new_key;
+}
+
+template <bool COERCE>
+__global__ void __launch_bounds__(256)
+k_advect_collide(size_t n, ParticleSoA p, GridDims g, const uint8_t *solid, MoveParams mp, const uint8_t *coerce_map,
+                 const float *src_vel, const uint8_t *tile_clear) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) advect_one<COERCE>(i, p, g, solid, mp, coerce_map, src_vel, tile_clear);
+}
+
+/// The same with pass 1 of the binning that follows it in lfa_time_step (core.hip: k_tile_count) done on the way: the new keys are
+/// in registers, so a wave ranks its AC_CHUNKS x 64 particles inside their new tiles right here (one atomic per distinct tile) and
+/// the binning neither reads the keys again nor waits for that pass's returning atomics (0.24 ms at C4).
+#define AC_CHUNKS 8  // particles per lane (4: 0.80 ms, 8: 0.74, 16: 0.73 at C4; the plain advection 0.58 + k_tile_count 0.24)
+template <bool COERCE>
+__global__ void __launch_bounds__(256)
+k_advect_collide_count(size_t n, ParticleSoA p, GridDims g, const uint8_t *solid, MoveParams mp, const uint8_t *coerce_map,
+                       const float *src_vel, const uint8_t *tile_clear, uint32_t *tile_count, uint32_t *rank) {
+	const int lane = threadIdx.x & 63;
+	const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const size_t i0 = wave * (64 * AC_CHUNKS) + lane;
+	uint32_t tile[AC_CHUNKS], my_rank[AC_CHUNKS];
+#pragma unroll
+	for (int c = 0; c < AC_CHUNKS; ++c) {
+		const size_t i = i0 + 64 * c;
+		const uint32_t k = i < n ? advect_one<COERCE>(i, p, g, solid, mp, coerce_map, src_vel, tile_clear) : 0xFFFFFFFFu;
+		tile[c] = k != 0xFFFFFFFFu ? k >> 9 : 0xFFFFFFFFu;
+	}
+	lfa_wave_tile_ranks(tile, tile_count, my_rank);
+#pragma unroll
+	for (int c = 0; c < AC_CHUNKS; ++c) {
+		const size_t i = i0 + 64 * c;
+		if (tile[c] != 0xFFFFFFFFu) rank[i] = my_rank[c];
+	}
 }
 
 __device__ inline float hash_unit(uint32_t a, uint32_t b, uint32_t k) {
@@ -962,7 +996,8 @@ static int refresh_tile_clear(lfa_sim *s) {
 	return LFA_OK;
 }
 
-extern "C" int lfa_advect_collide(lfa_sim *s, double dt) {
+/// `with_count`: lfa_time_step's variant - the binning that follows finds tile_count / rank done (lfa_sim::counts_fresh).
+static int advect_collide(lfa_sim *s, double dt, bool with_count) {
 	if (!s) return LFA_E_INVALID;
 	LFA_HIP(s, hipSetDevice(s->device));
 	LFA_TRY(lfa_corr_commit(s));
@@ -970,21 +1005,37 @@ extern "C" int lfa_advect_collide(lfa_sim *s, double dt) {
 	const size_t n = s->binned ? s->np_live : s->np;
 	LFA_TRY(lfa_sources_sync(s));
 	LFA_TRY(refresh_tile_clear(s));
+	s->counts_fresh = false;
 	if (n) {
-		const dim3 grid((unsigned)((n + 255) / 256));
 		if (s->any_coerce) s->vmax2_valid = false;  // velocities are overwritten inside the coercing sources' cells
-		if (s->any_coerce)
-			hipLaunchKernelGGL(k_advect_collide<true>, grid, dim3(256), 0, s->stream, n, s->pb[s->cur], s->g, s->solid, move_params(s, dt),
-			                   (const uint8_t *)s->coerce_map, (const float *)s->src_vel, (const uint8_t *)s->tile_clear);
-		else
-			hipLaunchKernelGGL(k_advect_collide<false>, grid, dim3(256), 0, s->stream, n, s->pb[s->cur], s->g, s->solid, move_params(s, dt),
-			                   (const uint8_t *)nullptr, (const float *)nullptr, (const uint8_t *)s->tile_clear);
+		const uint8_t *cm = s->any_coerce ? (const uint8_t *)s->coerce_map : (const uint8_t *)nullptr;
+		const float *sv = s->any_coerce ? (const float *)s->src_vel : (const float *)nullptr;
+		if (with_count && !s->dist) {
+			LFA_HIP(s, hipMemsetAsync(s->tile_count, 0, (size_t)(s->g.nt + 1) * 4, s->stream));
+			const dim3 grid((unsigned)((n + 256 * AC_CHUNKS - 1) / (256 * AC_CHUNKS)));
+			if (s->any_coerce)
+				hipLaunchKernelGGL(k_advect_collide_count<true>, grid, dim3(256), 0, s->stream, n, s->pb[s->cur], s->g, s->solid,
+				                   move_params(s, dt), cm, sv, (const uint8_t *)s->tile_clear, s->tile_count, s->rank);
+			else
+				hipLaunchKernelGGL(k_advect_collide_count<false>, grid, dim3(256), 0, s->stream, n, s->pb[s->cur], s->g, s->solid,
+				                   move_params(s, dt), cm, sv, (const uint8_t *)s->tile_clear, s->tile_count, s->rank);
+			s->counts_fresh = true;
+		} else {
+			const dim3 grid((unsigned)((n + 255) / 256));
+			if (s->any_coerce)
+				hipLaunchKernelGGL(k_advect_collide<true>, grid, dim3(256), 0, s->stream, n, s->pb[s->cur], s->g, s->solid, move_params(s, dt),
+				                   cm, sv, (const uint8_t *)s->tile_clear);
+			else
+				hipLaunchKernelGGL(k_advect_collide<false>, grid, dim3(256), 0, s->stream, n, s->pb[s->cur], s->g, s->solid, move_params(s, dt),
+				                   cm, sv, (const uint8_t *)s->tile_clear);
+		}
 		LFA_LAUNCH_CHECK(s);
 	}
 	LFA_TRY(lfa_dist_migrate(s));
 	s->unknown_count_valid = false;
 	return LFA_OK;
 }
+extern "C" int lfa_advect_collide(lfa_sim *s, double dt) { return advect_collide(s, dt, false); }
 
 /// The correction's scratch for the cell-ordered positions: four consecutive v / c arrays that are free between the binning and
 /// the G2P - the other buffer's v.. ; with a deferred binning, where the other buffer still holds the v (and for APIC the C)
@@ -1149,9 +1200,13 @@ extern "C" int lfa_time_step(lfa_sim *s, double dt, double *residual, uint64_t *
 		return LFA_OK;
 	};
 	LFA_TRY(rec(B_START));
-	LFA_TRY(lfa_advect_collide(s, dt));
+	LFA_TRY(advect_collide(s, dt, true));
 	LFA_TRY(rec(B_ADVECT));
-	LFA_TRY(lfa_hash_particles(s));
+	{
+		const bool counted = s->counts_fresh;
+		s->counts_fresh = false;
+		LFA_TRY(lfa_hash_particles_impl(s, counted));
+	}
 	if (!s->sources.empty()) LFA_TRY(lfa_update_sources(s, nullptr));  // _update_sources + hash_particles (:63-64)
 	LFA_TRY(rec(B_BIN));
 	// The correction reads and writes particle positions only, the pressure solve / gradient / extrapolation grid arrays only:
