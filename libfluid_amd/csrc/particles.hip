@@ -121,7 +121,9 @@ __device__ inline void split_position(double p, int n, int &cell, float &t) {
 	t = tf;
 }
 
-#define CORR_PARTS 2                       // workgroups per tile of the LDS-tiled position correction (split in z)
+#ifndef CORR_PARTS
+#define CORR_PARTS 2                       // workgroups per tile of the LDS-tiled position correction (split in z; 4: 5.6 instead of 5.0 ms alone, and no better beside the pressure solve)
+#endif
 #define CORR_THREADS 512                   // 8 waves per workgroup, 2 workgroups per CU (LDS)
 
 struct MoveParams {
@@ -266,14 +268,15 @@ __device__ inline float hash_unit(uint32_t a, uint32_t b, uint32_t k) {
 #define FT3 (FT * FT * FT)
 #define FT_STRIDE (FT3 + 1)                  // per tile: first record of every fine cell + the end
 #define FT_INV 1.375f                        // 11 / 8 (exact)
-#define FT_SPLIT 6                           // own fine layers (z) of part 0; part 1 takes the other FT - FT_SPLIT
+#define FT_PL ((FT + CORR_PARTS - 1) / CORR_PARTS)  // own fine layers (z) of a part (the last part takes what is left)
 #define FB 13                                // block: the own 11 x 11 fine cells + one on each side
-#define FBZ (FT_SPLIT + 2)
+#define FBZ (FT_PL + 2)
 #define FB_N (FB * FB * FBZ)
 #define FB_ROWS (FB * FBZ)
 #define FINE_CAP 5632                       // staged particles (13 x 13 x 8 fine cells hold 4160 at 8 per cell)
-#define FINE_OWN 3072
-#define FINE_CNT 1536                       // >= FB_N, a multiple of CORR_THREADS
+#define FINE_OWN (FINE_CNT * 2 < 3072 ? FINE_CNT * 2 : 3072)  // own particles of a part (the list lives in the count array as u16)
+#define FINE_CNT (((FB_N + 1 + CORR_THREADS - 1) / CORR_THREADS) * CORR_THREADS)  // >= FB_N + 1, a multiple of CORR_THREADS
+#define FIDX_CNT 1536                       // index kernel: >= FT3 + 1, a multiple of 256
 #define FIDX_STAGE 4608                      // records staged in LDS per tile by the index kernel (72 KB)
 
 __device__ inline int fine_coord(int l, float t) {
@@ -303,10 +306,10 @@ __device__ inline void fine_decode(const float4 &r, int fy, int fz, float t[3], 
 __global__ void __launch_bounds__(256)
 k_build_fine_index(const int *ptiles, int n_ptiles, const uint32_t *key, const float *t0, const float *t1, const float *t2,
                    const uint32_t *tile_start, const uint32_t *tile_count, uint32_t *fine_start, float4 *spos) {
-	__shared__ uint32_t cnt[FINE_CNT];
+	__shared__ uint32_t cnt[FIDX_CNT];
 	__shared__ uint32_t wsum[4];
 	__shared__ float4 stage[FIDX_STAGE];
-	constexpr int PER = FINE_CNT / 256;
+	constexpr int PER = FIDX_CNT / 256;
 	auto fine_of = [&](uint32_t i, int l[3], float t[3]) -> int {
 		const uint32_t k = key[i];
 		l[0] = (int)(k & 7); l[1] = (int)((k >> 3) & 7); l[2] = (int)((k >> 6) & 7);
@@ -434,7 +437,7 @@ k_correct_collide(size_t n, ParticleSoA p, uint32_t *out_key, float *out_tx, flo
 	                    __uint_as_float(__float_as_uint(me.z) & 0x3FFFFFFFu)};
 	const int f[3] = {fine_coord(l[0], t[0]), fine_coord(l[1], t[1]), fine_coord(l[2], t[2])};
 	if (only_flagged) {
-		const int work = CORR_PARTS * (tile_pslot[tile] - p_off) + (f[2] >= FT_SPLIT ? 1 : 0);
+		const int work = CORR_PARTS * (tile_pslot[tile] - p_off) + f[2] / FT_PL;
 		if (!((only_flagged[1 + (work >> 5)] >> (work & 31)) & 1u)) return;
 	}
 	int tx, ty, tz;
@@ -494,7 +497,7 @@ k_correct_collide(size_t n, ParticleSoA p, uint32_t *out_key, float *out_tx, flo
 }
 
 /// LDS-tiled _correct_positions + _detect_collisions on the fine index. One workgroup per (particle tile, z part): part 0 moves the
-/// particles of fine layers 0 .. FT_SPLIT - 1, part 1 the rest; the block staged in LDS is those layers + one fine cell all around.
+/// particles of FT_PL fine layers (the last part of what is left); the block staged in LDS is those layers + one fine cell all around.
 __global__ void __launch_bounds__(CORR_THREADS, 4)
 k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx, float *out_ty, float *out_tz, GridDims g,
                 const uint8_t *solid, const uint32_t *tile_count, const uint32_t *fine_start, const float4 *spos, MoveParams mp,
@@ -503,11 +506,11 @@ k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx
 	__shared__ uint32_t fcnt[FINE_CNT];       // particles per block fine cell; afterwards the own list (u16)
 	__shared__ uint16_t foff[FB_N + 1];        // first staged slot of every block fine cell
 	__shared__ uint32_t rowsrc[FB_ROWS * 3];   // first source record of the three runs of a fine row (x-1 tile, own x tile, x+1 tile)
-	__shared__ uint32_t ownoff[FT * FT_SPLIT + 1];
+	__shared__ uint32_t ownoff[FT * FT_PL + 1];
 	__shared__ int srct[27];                   // the source tiles around the own one
 	__shared__ uint32_t wsum[CORR_THREADS / 64];
 	uint16_t *own = (uint16_t *)fcnt;
-	static_assert(FINE_CNT * 2 >= FINE_OWN && FINE_CNT >= FB_N && FINE_CNT % CORR_THREADS == 0, "fcnt sizing");
+	static_assert(FINE_CNT * 2 >= FINE_OWN && FINE_CNT > FB_N && FINE_CNT % CORR_THREADS == 0, "fcnt sizing");
 	constexpr int PER = FINE_CNT / CORR_THREADS;
 	const int nn[3] = {g.nx, g.ny, g.nz};
 	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -515,8 +518,9 @@ k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx
 		const int tile = ptiles[work / CORR_PARTS], part = work % CORR_PARTS;
 		int tx, ty, tz;
 		tile_coords(g, tile, tx, ty, tz);
-		const int gz0 = part == 0 ? -1 : FT_SPLIT - 1;                  // own-tile fine layer of block layer 0
-		const int nzb = part == 0 ? FT_SPLIT + 2 : FT - FT_SPLIT + 2;   // block layers
+		const int own_lo = part * FT_PL, own_n = (own_lo + FT_PL <= FT ? FT_PL : FT - own_lo);
+		const int gz0 = own_lo - 1;  // own-tile fine layer of block layer 0
+		const int nzb = own_n + 2;   // block layers
 		const int nrows = FB * nzb, nown_rows = FT * (nzb - 2);
 		const bool open_water = (tile_clear[tile] & 1) != 0;  // no solid cell within a tile of this one
 		__syncthreads();
