@@ -219,7 +219,8 @@ int lfa_get_step_timings(lfa_sim *s, double ms[LFA_NUM_STEP_TIMERS]);
 /* lfa_time_step on a single domain runs the position correction (particle arrays only; simulation.cpp:99-106) on a second HIP
  * stream beside the pressure solve, the pressure gradient and the extrapolation (grid arrays only; :82-97, :119): forked after
  * the P2G, joined before the G2P. Results are identical either way; on = 0 runs the stages back to back (stage attribution).
- * Default: on. Slab decompositions always run serially. */
+ * Default: on. A slab decomposition overlaps the same way: the ghost-particle exchange happens on the main stream before the fork,
+ * the migration after the join - no communication is issued from the correction's stream. */
 int lfa_set_step_overlap(lfa_sim *s, int on);
 /* The same fork / join for a host that calls the stages one by one (libfluid_amd/host/simulation.h with stage callbacks):
  * _begin enqueues lfa_correct_collide on the second stream behind everything enqueued so far and returns; until _end the

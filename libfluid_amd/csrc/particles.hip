@@ -1051,7 +1051,7 @@ static float4 *correction_scratch(lfa_sim *s) {
 }
 
 /// First half of lfa_correct_collide: per-cell particle lists + cell-ordered positions (reads the (key, t) of the current binning).
-static int correct_build_index(lfa_sim *s) {
+static int correct_build_index(lfa_sim *s, bool exchange = true) {
 	const size_t n = s->np_live;
 	if (!n && !s->dist) return LFA_OK;
 	if (!s->fine_start) {
@@ -1060,7 +1060,7 @@ static int correct_build_index(lfa_sim *s) {
 		if (e != hipSuccess) return lfa_fail(s, LFA_E_OOM, "hipMalloc of the fine-cell index (%zu bytes) failed", bytes);
 	}
 	// neighbours within one cell across the slab faces: ghost copies of the adjacent tile layers' particles
-	if (s->dist) LFA_TRY(lfa_dist_exchange_ghost_particles(s));
+	if (s->dist && exchange) LFA_TRY(lfa_dist_exchange_ghost_particles(s));
 	LFA_TRY(refresh_tile_clear(s));
 	const int n_index = s->dist ? s->n_ptiles_all : s->n_ptiles;
 	const int grid = n_index < 16384 ? (n_index > 0 ? n_index : 1) : 16384;
@@ -1073,7 +1073,7 @@ static int correct_build_index(lfa_sim *s) {
 }
 
 /// Second half: the pairwise correction + collision; writes (key, t) in place.
-static int correct_apply(lfa_sim *s, double dt) {
+static int correct_apply(lfa_sim *s, double dt, bool migrate = true) {
 	const size_t n = s->np_live;
 	ParticleSoA &cur = s->pb[s->cur], &oth = s->pb[s->cur ^ 1];
 	float4 *spos = correction_scratch(s);
@@ -1104,7 +1104,7 @@ static int correct_apply(lfa_sim *s, double dt) {
 		                   (const uint32_t *)ovf, (const int *)s->tile_pslot, s->p_off, (const uint32_t *)oth.key);
 		LFA_LAUNCH_CHECK(s);
 	}
-	LFA_TRY(lfa_dist_migrate(s));
+	if (migrate) LFA_TRY(lfa_dist_migrate(s));
 	s->unknown_count_valid = false;
 	return LFA_OK;
 }
@@ -1126,30 +1126,34 @@ int lfa_corr_join(lfa_sim *s) {
 	return LFA_OK;
 }
 
-extern "C" int lfa_correct_collide_begin(lfa_sim *s, double dt) {
+/// `slab_exchanged`: lfa_time_step on a slab decomposition has already exchanged the ghost particles on the main stream and
+/// migrates after the join - no communication happens on the correction's stream.
+static int correct_begin(lfa_sim *s, double dt, bool slab_exchanged) {
 	if (!s) return LFA_E_INVALID;
 	if (!s->binned) return lfa_fail(s, LFA_E_INVALID, "lfa_correct_collide_begin: call lfa_hash_particles first");
-	if (s->dist) return lfa_fail(s, LFA_E_UNSUPPORTED, "lfa_correct_collide_begin: slab decompositions exchange particles inside the correction (use lfa_correct_collide)");
+	if (s->dist && !slab_exchanged)
+		return lfa_fail(s, LFA_E_UNSUPPORTED, "lfa_correct_collide_begin: slab decompositions exchange particles inside the correction (use lfa_correct_collide or lfa_time_step)");
 	LFA_HIP(s, hipSetDevice(s->device));
 	LFA_TRY(lfa_corr_commit(s));
-	if (!s->np_live) return LFA_OK;
+	if (!s->np_live && !s->dist) return LFA_OK;
 	LFA_HIP(s, hipEventRecord(s->ev_cfork, s->stream));
 	LFA_HIP(s, hipStreamWaitEvent(s->stream3, s->ev_cfork, 0));
 	hipStream_t main_stream = s->stream;
 	s->stream = s->stream3;
-	int rc = correct_build_index(s);
-	if (rc == LFA_OK) rc = correct_apply(s, dt);
+	int rc = correct_build_index(s, false);
+	if (rc == LFA_OK) rc = correct_apply(s, dt, false);
 	s->stream = main_stream;
 	const hipError_t e1 = s->timing ? hipEventRecord(s->ev[LFA_EV_CORRECT_END], s->stream3) : hipSuccess;
 	// the join event is recorded whatever happened: the main stream waits for it before it touches particles again
 	const hipError_t e2 = hipEventRecord(s->ev_cjoin, s->stream3);
 	s->corr_in_flight = true;
-	s->corr_undo_valid = rc == LFA_OK;
+	s->corr_undo_valid = rc == LFA_OK && !s->dist;
 	if (rc < 0) return rc;
 	LFA_HIP(s, e1);
 	LFA_HIP(s, e2);
 	return LFA_OK;
 }
+extern "C" int lfa_correct_collide_begin(lfa_sim *s, double dt) { return correct_begin(s, dt, false); }
 
 extern "C" int lfa_correct_collide_end(lfa_sim *s) {
 	if (!s) return LFA_E_INVALID;
@@ -1216,12 +1220,16 @@ extern "C" int lfa_time_step(lfa_sim *s, double dt, double *residual, uint64_t *
 	// The correction reads and writes particle positions only, the pressure solve / gradient / extrapolation grid arrays only:
 	// the two run side by side (the solve is a chain of short launch- and HBM-bound kernels, the correction one long VALU-bound
 	// one); the correction's stream has the lower priority. (Starting its cell index already beside the P2G - it only reads the
-	// binned (key, t) - changed nothing at C4.) Slabs exchange ghost particles and migrate inside the correction, on the main
-	// stream: serial there.
-	const bool overlap = s->overlap_correction && !s->dist && s->np_live;
+	// binned (key, t) - changed nothing at C4.) Slabs exchange ghost particles and migrate around the correction, on the main
+	// stream: they do the exchange before the fork and the migration after the join (the decision must be the same on every
+	// rank - a rank without particles included -, or the ranks would issue their collectives in different orders).
+	const bool overlap = s->overlap_correction && (s->dist || s->np_live);
 	LFA_TRY(lfa_p2g_run(s, true, dt));
 	LFA_TRY(rec(B_P2G));
-	if (overlap) LFA_TRY(lfa_correct_collide_begin(s, dt));
+	if (overlap) {
+		if (s->dist) LFA_TRY(lfa_dist_exchange_ghost_particles(s));
+		LFA_TRY(correct_begin(s, dt, true));
+	}
 	double res = 0.0;
 	uint64_t it = 0;
 	int rc = LFA_OK;
@@ -1242,6 +1250,7 @@ extern "C" int lfa_time_step(lfa_sim *s, double dt, double *residual, uint64_t *
 	// joined whatever happened in between: nothing that follows on the main stream may race with the correction
 	if (overlap) LFA_TRY(lfa_corr_join(s));
 	if (rc_grid < 0) return rc_grid;
+	if (overlap && s->dist) LFA_TRY(lfa_dist_migrate(s));
 	LFA_TRY(rec(B_JOIN));
 	// The G2P gathers per tile. Single domain: the particles keep the order of the P2G-time binning and the few whose
 	// corrected position left their tile take the global-gather path (lfa_g2p_stale); like after lfa_advect_collide the
