@@ -262,7 +262,7 @@ __device__ inline float hash_unit(uint32_t a, uint32_t b, uint32_t k) {
 // instead of 1.17 for the cell index), and a workgroup's block of 13 x 13 x 8 fine cells is put together from contiguous runs
 // of its 27 source tiles without atomics or a second pass: per fine row one cell of the x-1 tile, the eleven cells of the own x
 // tile (one run), one cell of the x+1 tile, in that order = sorted by fine cell. The kernel itself stayed at 5.0 ms (PMC: 2.3e9
-// VALU wave-instructions, 70 % of them the pair walk at ~57 % lane occupancy - the lanes of a wave are particles of ~21
+// VALU wave-instructions, 70 % of them the pair walk, 47 of 64 lanes active on average - the lanes of a wave are particles of ~21
 // different fine cells whose runs have different lengths; staging 18 %, the per-particle epilogue 11 %).
 #define FT 11                                // fine cells per tile axis
 #define FT3 (FT * FT * FT)
