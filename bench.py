@@ -232,6 +232,7 @@ def main():
         elapsed = float(t.item())
 
     counts = sim.counts()
+    corr_fallback = sim.correction_stats()
     npart, n_unknowns = counts["particles"], counts["unknowns"]
     npart_total = npart
     if dist is not None:
@@ -293,6 +294,8 @@ def main():
                     "`--precond multilevel` (same iteration counts as the reference's MIC(0)-PCG within a few per cent)",
         },
         "stage_ms_median": stage_med, "stage_ms_p95": stage_p95,
+        "correction_fallback_half_tiles": {"flagged": corr_fallback[0], "of": corr_fallback[1],
+                                           "note": "half tiles of the last step whose neighbourhood did not fit the LDS-tiled correction kernel"},
     }
     if overlapped and serial_ms is not None:
         out["stage_ms_note"] = (f"stage_ms_* and every per-kernel figure: {args.steps} further steps with the stages back to back "

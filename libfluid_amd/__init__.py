@@ -142,6 +142,7 @@ SIGNATURES = {
     "lfa_time_step": (_int, [_vp, _dbl, C.POINTER(_dbl), C.POINTER(_u64)]),
     "lfa_get_step_timings": (_int, [_vp, C.POINTER(_dbl * NUM_STEP_TIMERS)]),
     "lfa_set_step_overlap": (_int, [_vp, _int]),
+    "lfa_get_correction_stats": (_int, [_vp, C.POINTER(_u64 * 2)]),
     "lfa_correct_collide_begin": (_int, [_vp, _dbl]),
     "lfa_correct_collide_end": (_int, [_vp]),
     "lfa_correct_collide_undo": (_int, [_vp]),
@@ -625,6 +626,12 @@ class Sim:
         arr = (C.c_double * NUM_STEP_TIMERS)()
         self._chk(self.lib.lfa_get_step_timings(self.h, C.byref(arr)))
         return dict(zip(STEP_TIMER_NAMES, list(arr)))
+
+    def correction_stats(self):
+        """(half tiles the last position correction handed to its slow fallback, half tiles in all)."""
+        arr = (C.c_uint64 * 2)()
+        self._chk(self.lib.lfa_get_correction_stats(self.h, C.byref(arr)))
+        return int(arr[0]), int(arr[1])
 
     def set_step_overlap(self, on):
         """time_step: position correction on a second stream beside the pressure solve (default on); off = back to back."""

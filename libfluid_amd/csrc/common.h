@@ -63,7 +63,8 @@ struct lfa_sim {
 	bool corr_in_flight = false;   // lfa_correct_collide_begin .. _end: the particle arrays belong to the correction on stream3
 	bool counts_fresh = false;     // tile_count / rank were produced by the advection of lfa_time_step: the binning skips its pass 1
 	bool corr_undo_valid = false;  // nothing has changed positions, binning or solids since: lfa_correct_collide_undo can restore
-	uint32_t *corr_ovf = nullptr;  // overflow bitmap of the tiled correction (2 bits per particle tile)
+	uint32_t *corr_ovf = nullptr;  // tiled correction: word 0 = number of flagged (overflowing) half tiles, then their bitmap
+	int corr_parts_tiles = 0;      // particle tiles of the last correction
 	GridDims g{};
 	size_t nc = 0, ncp = 0;  // real / padded cell count
 	lfa_params prm{};

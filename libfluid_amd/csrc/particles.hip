@@ -1086,6 +1086,7 @@ static int correct_apply(lfa_sim *s, double dt, bool migrate = true) {
 			if (e != hipSuccess) return lfa_fail(s, LFA_E_OOM, "hipMalloc of the correction's overflow bitmap failed");
 		}
 		uint32_t *ovf = s->corr_ovf;
+		s->corr_parts_tiles = s->n_ptiles;
 		LFA_HIP(s, hipMemsetAsync(ovf, 0, ovf_words * 4, s->stream));
 		{
 			const int work = CORR_PARTS * s->n_ptiles, g2 = work < 65536 ? (work > 0 ? work : 1) : 65536;
@@ -1306,6 +1307,20 @@ extern "C" int lfa_time_step(lfa_sim *s, double dt, double *residual, uint64_t *
 	if (residual) *residual = res;
 	if (iterations) *iterations = it;
 	return rc;
+}
+
+extern "C" int lfa_get_correction_stats(lfa_sim *s, uint64_t stats[2]) {
+	if (!s || !stats) return LFA_E_INVALID;
+	stats[0] = stats[1] = 0;
+	if (!s->corr_ovf) return LFA_OK;  // no correction has run yet
+	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_corr_join(s));
+	uint32_t flagged = 0;
+	LFA_HIP(s, hipMemcpyAsync(&flagged, s->corr_ovf, 4, hipMemcpyDeviceToHost, s->stream));
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	stats[0] = flagged;
+	stats[1] = (uint64_t)CORR_PARTS * (uint64_t)s->corr_parts_tiles;
+	return LFA_OK;
 }
 
 extern "C" int lfa_set_step_overlap(lfa_sim *s, int on) {

@@ -170,6 +170,22 @@ def test_c3_workload_against_live_oracle_and_full_size_properties():
     s.solve(0.033); s.apply_pressure(0.033); s.build_system(0.033)
     assert np.abs(s.b()).max() < 1e-3 * b0
     s.close()
+    # 25 whole steps of the dam break at full size: particles stay inside the domain, none is lost, and the position correction
+    # never needs its slow fallback (a dam break stays near 8 particles per cell: every half tile fits the LDS-tiled kernel)
+    s = lfa.Sim(cfg["size"], method=cfg["method"], blending=cfg["blending"])
+    s.seed_block(*cfg["block"])
+    worst = 0
+    for _ in range(25):
+        res, it, rc = s.time_step(min(3.0 * s.cfl(), 0.033))
+        assert rc == 0 and it <= 30
+        flagged, total = s.correction_stats()
+        assert total > 0
+        worst = max(worst, flagged)
+    assert worst == 0, worst
+    assert s.counts()["particles"] == 16777216
+    ids = np.sort(s.particle_ids())
+    assert ids[0] == 0 and ids[-1] == len(ids) - 1 and np.all(np.diff(ids) == 1)
+    s.close()
 
 
 def _obstacle(size, block):

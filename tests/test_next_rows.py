@@ -145,6 +145,8 @@ def test_position_correction_fallback_for_crowded_tiles(dense):
     s.upload_particles(parts)
     s.hash()
     s.correct_collide(DT_CORR)
+    flagged, total = s.correction_stats()
+    assert 0 < flagged < total  # both kernels ran (also in "all": the sparsely filled half tiles at the block's edge fit the tiled one)
     out = s.download_particles(into=parts.copy(), write_positions=True)
     s.close()
     assert np.abs(out["pos"] - parts["pos"]).max() > 1e-2  # the correction did move particles
