@@ -209,7 +209,7 @@ int lfa_time_step(lfa_sim *s, double dt, double *residual, uint64_t *iterations)
 /* Device time of the stages of the last lfa_time_step in milliseconds (timing enabled), HIP events on the handle's stream:
  * [0] advect+collide  [1] binning  [2] P2G (scatter + finalize + gravity)  [3] P2G scatter kernel alone
  * [4] pressure system + preconditioner set-up  [5] PCG loop  [6] pressure gradient  [7] cell index of the position
- * correction (k_build_cell_index)  [8] LDS-tiled correction kernel alone  [9] correct+collide as a whole (7 + 8 + fallback)
+ * correction (k_build_fine_index)  [8] LDS-tiled correction kernel alone  [9] correct+collide as a whole (7 + 8 + fallback)
  * [10] extrapolation  [11] G2P  [12] whole step  [13] PCG iterations of the step (a count, not a time)
  * [14] mean PCG iteration ([5] / [13])  [15] 1 if the correction ran beside the solve (lfa_set_step_overlap), else 0.
  * Overlapped, [7] [8] [9] are spans on the correction's own stream and [4] [5] [6] [10] spans on the main one: each is
