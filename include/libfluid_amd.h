@@ -352,7 +352,7 @@ int lfa_get_timings(lfa_sim *s, double ms[LFA_NUM_TIMERS]);
  * by grid kernels (dilated set) [4] padded cell count */
 int lfa_get_counts(lfa_sim *s, uint64_t counts[5]);
 /* The last position correction: [0] half tiles handled by the LDS-tiled kernel's fallback (a thread per particle gathering from
- * global memory: crowded blocks of more than 5632 staged / 3072 own particles) [1] half tiles in all. Joins a correction in
+ * global memory: crowded blocks of more than 5632 staged particles) [1] half tiles in all. Joins a correction in
  * flight. A large [0] / [1] means the scene is far denser than 8 particles per cell and the correction runs slowly. */
 int lfa_get_correction_stats(lfa_sim *s, uint64_t stats[2]);
 

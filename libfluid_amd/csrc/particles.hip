@@ -274,7 +274,7 @@ __device__ inline float hash_unit(uint32_t a, uint32_t b, uint32_t k) {
 #define FB_N (FB * FB * FBZ)
 #define FB_ROWS (FB * FBZ)
 #define FINE_CAP 5632                       // staged particles (13 x 13 x 8 fine cells hold 4160 at 8 per cell)
-#define FINE_OWN (FINE_CNT * 2 < 3072 ? FINE_CNT * 2 : 3072)  // own particles of a part (the list lives in the count array as u16)
+#define FINE_OWN (FINE_CNT * 2)  // own particles the u16 list holds (it lives in the count array); more are found through the row offsets
 #define FINE_CNT (((FB_N + 1 + CORR_THREADS - 1) / CORR_THREADS) * CORR_THREADS)  // >= FB_N + 1, a multiple of CORR_THREADS
 #define FIDX_CNT 1536                       // index kernel: >= FT3 + 1, a multiple of 256
 #define FIDX_STAGE 4608                      // records staged in LDS per tile by the index kernel (72 KB)
@@ -510,7 +510,7 @@ k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx
 	__shared__ int srct[27];                   // the source tiles around the own one
 	__shared__ uint32_t wsum[CORR_THREADS / 64];
 	uint16_t *own = (uint16_t *)fcnt;
-	static_assert(FINE_CNT * 2 >= FINE_OWN && FINE_CNT > FB_N && FINE_CNT % CORR_THREADS == 0, "fcnt sizing");
+	static_assert(FINE_CNT > FB_N && FINE_CNT % CORR_THREADS == 0, "fcnt sizing");
 	constexpr int PER = FINE_CNT / CORR_THREADS;
 	const int nn[3] = {g.nx, g.ny, g.nz};
 	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -613,13 +613,9 @@ k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx
 			if (threadIdx.x < (unsigned)nown_rows) ownoff[threadIdx.x] = wo + in2 - len;
 			if (threadIdx.x == 0) ownoff[nown_rows] = own_total;
 		}
-		if (own_total > FINE_OWN) {  // uniform
-			if (threadIdx.x == 0) {
-				atomicOr(&overflow_tiles[1 + (work >> 5)], 1u << (work & 31));
-				atomicAdd(&overflow_tiles[0], 1u);
-			}
-			continue;
-		}
+		// (a crowded part with more own particles than the list holds - it lives in the count array - finds them through the row
+		// offsets instead: uniform)
+		const bool listed = own_total <= FINE_OWN;
 		__syncthreads();  // (every count has been read: `own` may overwrite the array)
 		// ---- stage the rows: a wave per fine row copies its three runs - one cell of the x-1 tile, the own x tile's eleven, one
 		// of the x+1 tile - which follow each other in the block (positions relative to the own tile's origin, in cells)
@@ -641,7 +637,7 @@ k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx
 				pz[slot] = (float)(8 * dz + l[2]) + t[2];
 			}
 			// the own list: slot order = fine-cell order
-			if (by >= 1 && by <= FT && bz >= 1 && bz <= nzb - 2) {
+			if (listed && by >= 1 && by <= FT && bz >= 1 && bz <= nzb - 2) {
 				const uint32_t o = ownoff[(by - 1) + FT * (bz - 1)];
 				for (uint32_t k = lane; k < d2 - d1; k += 64) own[o + k] = (uint16_t)(d1 + k);
 			}
@@ -649,7 +645,18 @@ k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx
 		__syncthreads();
 		// ---- one thread per own particle
 		for (uint32_t w = threadIdx.x; w < own_total; w += CORR_THREADS) {
-			const uint32_t me = own[w];
+			uint32_t me;
+			if (listed) {
+				me = own[w];
+			} else {  // the own row that holds the w-th own particle: last r with ownoff[r] <= w
+				int lo = 0, hi = nown_rows - 1;
+				while (lo < hi) {
+					const int mid = (lo + hi + 1) >> 1;
+					if (ownoff[mid] <= w) lo = mid;
+					else hi = mid - 1;
+				}
+				me = (uint32_t)foff[((1 + lo % FT) + FB * (1 + lo / FT)) * FB + 1] + (w - ownoff[lo]);
+			}
 			const float mx = px[me], my = py[me], mz = pz[me];
 			// block coordinates of its fine cell (the same arithmetic the index was built with: mx = (float)lx + t exactly)
 			int fx = (int)(mx * FT_INV), fy = (int)(my * FT_INV), fz = (int)(mz * FT_INV);
