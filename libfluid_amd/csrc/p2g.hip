@@ -299,17 +299,17 @@ k_p2g_finalize(const int *dtiles, int n_dtiles, GridDims g, const int *tile_pslo
 			const int x = tx * 8 + lx, y = ty * 8 + ly, z = tz * 8 + lz;
 			float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 			if (BINNED) {
-				// fixed visiting order => the sum does not depend on which workgroup ran first
-				for (int oz = -1; oz <= 1; ++oz) {
-					if ((oz == -1 && lz != 0) || (oz == 1 && lz != 7)) continue;
+				// fixed visiting order (ascending tile offsets) => the sum does not depend on which workgroup ran first. Only the
+				// blocks that reach this cell are visited: its own tile's and, for a cell on a face of the tile, the neighbour's there
+				const int ox0 = lx == 0 ? -1 : 0, ox1 = lx == 7 ? 1 : 0, oy0 = ly == 0 ? -1 : 0, oy1 = ly == 7 ? 1 : 0;
+				const int oz0 = lz == 0 ? -1 : 0, oz1 = lz == 7 ? 1 : 0;
+				for (int oz = oz0; oz <= oz1; ++oz) {
 					const int nz_ = tz + oz;
 					if ((unsigned)nz_ >= (unsigned)g.ntz) continue;
-					for (int oy = -1; oy <= 1; ++oy) {
-						if ((oy == -1 && ly != 0) || (oy == 1 && ly != 7)) continue;
+					for (int oy = oy0; oy <= oy1; ++oy) {
 						const int ny_ = ty + oy;
 						if ((unsigned)ny_ >= (unsigned)g.nty) continue;
-						for (int ox = -1; ox <= 1; ++ox) {
-							if ((ox == -1 && lx != 0) || (ox == 1 && lx != 7)) continue;
+						for (int ox = ox0; ox <= ox1; ++ox) {
 							const int nx_ = tx + ox;
 							if ((unsigned)nx_ >= (unsigned)g.ntx) continue;
 							const int ps = tile_pslot[nx_ + g.ntx * (ny_ + g.nty * nz_)];
