@@ -3,7 +3,7 @@
 //
 // All kernels walk the tile lists built by lfa_hash_particles: `ptiles` (tiles holding particles = tiles holding PCG
 // unknowns) and `dtiles` (their 27-neighbourhoods). A cell outside the dilated set is never read as data: its type is
-// solid/air from the persistent solid mask and it is never an unknown (cell_type_at / is_unknown_at below).
+// solid/air from the persistent solid mask and it is never an unknown (stage_halo_types / is_unknown_at below).
 #include "common.h"
 #include "pcg.h"
 
@@ -14,13 +14,6 @@ struct GridView {
 	const uint8_t *ctype, *solid;
 	const uint32_t *cell_count, *tile_flag;
 };
-/// mac_grid::get_cell_and_type (src/mac_grid.cpp:26-31): outside the grid => solid.
-__device__ inline int cell_type_at(const GridView &gv, int x, int y, int z) {
-	if (!in_grid(gv.g, x, y, z)) return CT_SOLID;
-	uint32_t b = blocked_index(gv.g, x, y, z);
-	if (gv.tile_flag[b >> 9]) return gv.ctype[b] & 7;
-	return gv.solid[b] ? CT_SOLID : CT_AIR;
-}
 /// Membership in the reference's _fluid_cells list (cells holding particles, src/simulation.cpp:83-94).
 __device__ inline bool is_unknown_at(const GridView &gv, int x, int y, int z) {
 	if (!in_grid(gv.g, x, y, z)) return false;
@@ -28,15 +21,15 @@ __device__ inline bool is_unknown_at(const GridView &gv, int x, int y, int z) {
 	return gv.tile_flag[b >> 9] && gv.cell_count[b] > 0;
 }
 
-/// The types of a tile's cells and of the ring around it, once per workgroup in LDS: H[hx + 10 hy + 100 hz] = cell_type_at of
-/// cell (8 tx + hx - 1, ..) in bits 0-2, is_unknown_at in bit 3. The per-cell kernels below look at six neighbours per cell:
+/// The types of a tile's cells and of the ring around it, once per workgroup in LDS: H[hx + 10 hy + 100 hz] = type of cell
+/// (8 tx + hx - 1, ..) in bits 0-2 (a cell outside the processed tiles is solid / air by the solid mask), is_unknown_at in bit 3. The per-cell kernels below look at six neighbours per cell:
 /// straight from global memory that is a tile lookup + two dependent byte loads each (k_rhs 0.18 ms, k_apply_pressure 0.18 ms,
 /// k_abits 0.09 ms at C4 for a few hundred MB).
 #define HT_UNKNOWN 8
 __device__ inline void stage_halo_types(const GridView &gv, int tx, int ty, int tz, uint8_t *H) {
 	for (int i = threadIdx.x; i < LFA_HALO_CELLS; i += 256) {
 		const int x = 8 * tx + i % 10 - 1, y = 8 * ty + (i / 10) % 10 - 1, z = 8 * tz + i / 100 - 1;
-		uint8_t t = CT_SOLID;
+		uint8_t t = CT_SOLID;  // mac_grid::get_cell_and_type (src/mac_grid.cpp:26-31): outside the grid => solid
 		if (in_grid(gv.g, x, y, z)) {
 			const uint32_t b = blocked_index(gv.g, x, y, z);
 			if (gv.tile_flag[b >> 9]) t = (uint8_t)((gv.ctype[b] & 7) | (gv.cell_count[b] > 0 ? HT_UNKNOWN : 0));

@@ -89,7 +89,7 @@ namespace {
 enum { MT_SOLID = 0, MT_FLUID = 1, MT_AIR = 2 };
 
 // ------------------------------------------------------------------------------------------------ set-up kernels
-/// Level-0 cell type for the coarsening rule, from the simulation's own arrays (cell_type_at / is_unknown_at of
+/// Level-0 cell type for the coarsening rule, from the simulation's own arrays (stage_halo_types / is_unknown_at of
 /// grid_ops.hip): tiles that hold particles have explicit types, every other cell is solid or air by the solid mask.
 __device__ inline int fine_type(const uint32_t *tile_flag, const uint32_t *cell_count, const uint8_t *ctype, const uint8_t *solid,
                                 uint32_t b) {
