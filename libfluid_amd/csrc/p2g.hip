@@ -196,25 +196,28 @@ __device__ inline void load_particle(const ParticleSoA &p, const ParticleSoA &pv
 	}
 }
 
+#ifndef P2G_THREADS
+#define P2G_THREADS 512  // threads of a scatter workgroup (3 workgroups per CU by LDS; measured at C4: 256 1.60, 384 1.67, 512 1.53, 768 1.89 ms)
+#endif
 template <bool APIC, bool QUIRK>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(P2G_THREADS)
 k_p2g_binned(const int *ptiles, int n_ptiles, ParticleSoA p, ParticleSoA pvc, const uint32_t *from, const uint32_t *tile_start,
              float *stage, float hworld, int rot_mask) {
 	__shared__ unsigned long long acc[6 * LFA_HALO_CELLS];  // 48 KB: [comp][wv | w][10x10x10]
 	for (int slot = blockIdx.x; slot < n_ptiles; slot += gridDim.x) {
 		const int tile = ptiles[slot];
-		for (int i = threadIdx.x; i < 6 * LFA_HALO_CELLS; i += 256) acc[i] = 0ull;
+		for (int i = threadIdx.x; i < 6 * LFA_HALO_CELLS; i += P2G_THREADS) acc[i] = 0ull;
 		__syncthreads();
 		const uint32_t beg = tile_start[tile], end = tile_start[tile + 1];
 		// software pipeline: the loads of the next particle are in flight while the current one is scattered
 		// (with a deferred binning the index of the particle after next is loaded one round ahead of its v, C)
 		ParticleRegs cur, nxt;
 		uint32_t i = beg + threadIdx.x;
-		uint32_t jn = i + 256 < end ? (from ? from[i + 256] : i + 256) : 0u;
+		uint32_t jn = i + P2G_THREADS < end ? (from ? from[i + P2G_THREADS] : i + P2G_THREADS) : 0u;
 		if (i < end) load_particle<APIC>(p, pvc, i, from ? from[i] : i, cur);
-		for (; i < end; i += 256) {
-			const uint32_t in = i + 256;
-			const uint32_t jnn = in + 256 < end ? (from ? from[in + 256] : in + 256) : 0u;
+		for (; i < end; i += P2G_THREADS) {
+			const uint32_t in = i + P2G_THREADS;
+			const uint32_t jnn = in + P2G_THREADS < end ? (from ? from[in + P2G_THREADS] : in + P2G_THREADS) : 0u;
 			if (in < end) load_particle<APIC>(p, pvc, in, jn, nxt);
 			jn = jnn;
 			const int l = (int)(cur.key & 511);
@@ -231,7 +234,7 @@ k_p2g_binned(const int *ptiles, int n_ptiles, ParticleSoA p, ParticleSoA pvc, co
 		}
 		__syncthreads();
 		float *out = stage + (size_t)slot * 6 * LFA_HALO_CELLS;
-		for (int k = threadIdx.x; k < 6 * LFA_HALO_CELLS; k += 256)
+		for (int k = threadIdx.x; k < 6 * LFA_HALO_CELLS; k += P2G_THREADS)
 			out[k] = (float)((double)(long long)acc[k] * (((k / LFA_HALO_CELLS) & 1) ? 1.0 / P2G_FIX_SCALE_W : 1.0 / P2G_FIX_SCALE_V));
 		__syncthreads();
 	}
@@ -386,7 +389,7 @@ static void launch_binned(lfa_sim *s, const ParticleSoA &p, const ParticleSoA &p
 	const dim3 grid(grid_blocks(s->n_ptiles));
 	const float hworld = (float)s->prm.cell_size;
 #define LB(A, Q)                                                                                                             \
-	hipLaunchKernelGGL((k_p2g_binned<A, Q>), grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, p, pvc, from, s->tile_start, \
+	hipLaunchKernelGGL((k_p2g_binned<A, Q>), grid, dim3(P2G_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, p, pvc, from, s->tile_start, \
 	                   stage_own, hworld, rot_mask)
 	const int rot_mask = getenv("LFA_P2G_NO_ROT") ? 0 : 7;  // A/B switch for the lane-rotated node order (profiles/r02_p2g_lds_pmc.txt)
 	switch (scatter_mode(s)) {
