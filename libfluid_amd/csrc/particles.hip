@@ -276,7 +276,8 @@ __device__ inline float hash_unit(uint32_t a, uint32_t b, uint32_t k) {
 #define FINE_CAP 5632                       // staged particles (13 x 13 x 8 fine cells hold 4160 at 8 per cell)
 #define FINE_OWN (FINE_CNT * 2)  // own particles the u16 list holds (it lives in the count array); more are found through the row offsets
 #define FINE_CNT (((FB_N + 1 + CORR_THREADS - 1) / CORR_THREADS) * CORR_THREADS)  // >= FB_N + 1, a multiple of CORR_THREADS
-#define FIDX_CNT 1536                       // index kernel: >= FT3 + 1, a multiple of 256
+#define FIDX_THREADS 512   // (256: 0.75 ms at C4, 512: 0.58; FIDX_STAGE and FIDX_CNT are multiples of it)
+#define FIDX_CNT 1536                       // index kernel: >= FT3 + 1, a multiple of FIDX_THREADS
 #define FIDX_STAGE 4608                      // records staged in LDS per tile by the index kernel (72 KB)
 
 __device__ inline int fine_coord(int l, float t) {
@@ -303,27 +304,28 @@ __device__ inline void fine_decode(const float4 &r, int fy, int fz, float t[3], 
 
 /// Per particle tile: its particles grouped by fine cell - fine_start[tile][f] = first record of fine cell f (absolute), records
 /// (fine_record) in spos. (What the reference's _space_hash is to its 27-cell walk, include/fluid/simulation.h:193-197.)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(FIDX_THREADS)
 k_build_fine_index(const int *ptiles, int n_ptiles, const uint32_t *key, const float *t0, const float *t1, const float *t2,
                    const uint32_t *tile_start, const uint32_t *tile_count, uint32_t *fine_start, float4 *spos) {
 	__shared__ uint32_t cnt[FIDX_CNT];
-	__shared__ uint32_t wsum[4];
+	__shared__ uint32_t wsum[FIDX_THREADS / 64];
 	__shared__ float4 stage[FIDX_STAGE];
-	constexpr int PER = FIDX_CNT / 256;
+	static_assert(FIDX_CNT % FIDX_THREADS == 0 && FIDX_STAGE % FIDX_THREADS == 0, "index kernel sizing");
+	constexpr int PER = FIDX_CNT / FIDX_THREADS;
 	auto fine_of = [&](uint32_t i, int l[3], float t[3]) -> int {
 		const uint32_t k = key[i];
 		l[0] = (int)(k & 7); l[1] = (int)((k >> 3) & 7); l[2] = (int)((k >> 6) & 7);
 		t[0] = t0[i]; t[1] = t1[i]; t[2] = t2[i];
 		return fine_coord(l[0], t[0]) + FT * (fine_coord(l[1], t[1]) + FT * fine_coord(l[2], t[2]));
 	};
-	constexpr int RPT = FIDX_STAGE / 256;  // particles per thread of a tile that fits the staging area: kept in registers
+	constexpr int RPT = FIDX_STAGE / FIDX_THREADS;  // particles per thread of a tile that fits the staging area: kept in registers
 	for (int slot = blockIdx.x; slot < n_ptiles; slot += gridDim.x) {
 		const int tile = ptiles[slot];
 		// ghost tiles (slab decomposition) keep their particles behind the live ones: the range end comes from the count
 		const uint32_t b = tile_start[tile], e = b + tile_count[tile];
 		const bool staged = e - b <= FIDX_STAGE;  // (uniform)
 #pragma unroll
-		for (int k = 0; k < PER; ++k) cnt[threadIdx.x + 256 * k] = 0;
+		for (int k = 0; k < PER; ++k) cnt[threadIdx.x + FIDX_THREADS * k] = 0;
 		__syncthreads();
 		// pass 1: histogram. A tile that fits keeps what it has read - (fine cell << 9 | cell in the tile) and the fractions -
 		// in registers for pass 2 (reading key and t a second time was a third of the kernel's HBM traffic)
@@ -332,7 +334,7 @@ k_build_fine_index(const int *ptiles, int n_ptiles, const uint32_t *key, const f
 		if (staged) {
 #pragma unroll
 			for (int r = 0; r < RPT; ++r) {
-				const uint32_t i = b + threadIdx.x + 256 * r;
+				const uint32_t i = b + threadIdx.x + FIDX_THREADS * r;
 				rf[r] = 0xFFFFFFFFu;
 				if (i < e) {
 					int l[3];
@@ -344,7 +346,7 @@ k_build_fine_index(const int *ptiles, int n_ptiles, const uint32_t *key, const f
 				}
 			}
 		} else {
-			for (uint32_t i = b + threadIdx.x; i < e; i += 256) {
+			for (uint32_t i = b + threadIdx.x; i < e; i += FIDX_THREADS) {
 				int l[3];
 				float t[3];
 				atomicAdd(&cnt[fine_of(i, l, t)], 1u);
@@ -386,12 +388,12 @@ k_build_fine_index(const int *ptiles, int n_ptiles, const uint32_t *key, const f
 				if (rf[r] != 0xFFFFFFFFu) {
 					const uint32_t at = atomicAdd(&cnt[rf[r] >> 9], 1u);
 					stage[at - b] = fine_record((int)(rf[r] & 7), (int)((rf[r] >> 3) & 7), (int)((rf[r] >> 6) & 7), r0[r], r1[r], r2[r],
-					                            b + threadIdx.x + 256 * r);
+					                            b + threadIdx.x + FIDX_THREADS * r);
 				}
 			__syncthreads();
-			for (uint32_t k = threadIdx.x; k < e - b; k += 256) spos[b + k] = stage[k];
+			for (uint32_t k = threadIdx.x; k < e - b; k += FIDX_THREADS) spos[b + k] = stage[k];
 		} else {
-			for (uint32_t i = b + threadIdx.x; i < e; i += 256) {
+			for (uint32_t i = b + threadIdx.x; i < e; i += FIDX_THREADS) {
 				int l[3];
 				float t[3];
 				const uint32_t at = atomicAdd(&cnt[fine_of(i, l, t)], 1u);
@@ -1073,7 +1075,7 @@ static int correct_build_index(lfa_sim *s, bool exchange = true) {
 	const int grid = n_index < 16384 ? (n_index > 0 ? n_index : 1) : 16384;
 	ParticleSoA &cur = s->pb[s->cur];
 	if (s->timing && n) LFA_HIP(s, hipEventRecord(s->ev[40], s->stream));
-	hipLaunchKernelGGL(k_build_fine_index, dim3(grid), dim3(256), 0, s->stream, s->dist ? s->ptiles_all : s->ptiles, n_index, cur.key,
+	hipLaunchKernelGGL(k_build_fine_index, dim3(grid), dim3(FIDX_THREADS), 0, s->stream, s->dist ? s->ptiles_all : s->ptiles, n_index, cur.key,
 	                   cur.t[0], cur.t[1], cur.t[2], s->tile_start, s->tile_count, s->fine_start, correction_scratch(s));
 	LFA_LAUNCH_CHECK(s);
 	return LFA_OK;
