@@ -351,8 +351,11 @@ __device__ inline float g2p_particle(const ParticleSoA &p, uint32_t i, const Par
 /// whose cell has left the tile are appended to `leavers` for k_g2p_leavers instead (a second binning of all particles
 /// for the sake of the 1-3 % that crossed a tile face cost 2.1 ms of the 30 ms full step at C4).
 #define G2P_LV_CAP 256
+#ifndef G2P_THREADS
+#define G2P_THREADS 256  // (C4: 128 threads 1.42 ms, 256 1.28, 512 1.90)
+#endif
 template <int METHOD, bool STALE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(G2P_THREADS)
 k_g2p(const int *ptiles, int n_ptiles, GridDims g, ParticleSoA p, const uint32_t *tile_start, const float *u,
       const float *v, const float *w, const float *uo, const float *vo, const float *wo, G2PParams gp, uint32_t *leavers,
       uint32_t *n_leavers, ParticleSoA pold, const uint32_t *from, uint32_t *vmax2_bits) {
@@ -366,7 +369,7 @@ k_g2p(const int *ptiles, int n_ptiles, GridDims g, ParticleSoA p, const uint32_t
 		tile_coords(g, tile, tx, ty, tz);
 		__syncthreads();
 		if (STALE && threadIdx.x == 0) lv_n = 0;
-		for (int i = threadIdx.x; i < LFA_HALO_CELLS; i += 256) {
+		for (int i = threadIdx.x; i < LFA_HALO_CELLS; i += G2P_THREADS) {
 			const int hx = i % 10, hy = (i / 10) % 10, hz = i / 100;
 			const int x = tx * 8 + hx - 1, y = ty * 8 + hy - 1, z = tz * 8 + hz - 1;
 			lds[i] = clamped_sample(g, u, 0, x, y, z);
@@ -380,7 +383,7 @@ k_g2p(const int *ptiles, int n_ptiles, GridDims g, ParticleSoA p, const uint32_t
 		}
 		__syncthreads();
 		const uint32_t beg = tile_start[tile], end = tile_start[tile + 1];
-		for (uint32_t i = beg + threadIdx.x; i < end; i += 256) {
+		for (uint32_t i = beg + threadIdx.x; i < end; i += G2P_THREADS) {
 			const uint32_t key = p.key[i];
 			if (STALE && (int)(key >> 9) != tile) {
 				const uint32_t at = atomicAdd(&lv_n, 1u);
@@ -401,7 +404,7 @@ k_g2p(const int *ptiles, int n_ptiles, GridDims g, ParticleSoA p, const uint32_t
 			const uint32_t n = lv_n < G2P_LV_CAP ? lv_n : G2P_LV_CAP;
 			if (threadIdx.x == 0 && n) lv_base = atomicAdd(n_leavers, n);
 			__syncthreads();
-			for (uint32_t k = threadIdx.x; k < n; k += 256) leavers[lv_base + k] = lv[k];
+			for (uint32_t k = threadIdx.x; k < n; k += G2P_THREADS) leavers[lv_base + k] = lv[k];
 		}
 	}
 	// max |v|^2 over the particles this workgroup transferred: non-negative floats order like their bit patterns
@@ -577,7 +580,7 @@ static int g2p_run(lfa_sim *s, bool stale) {
 	// per SIMD; on freshly binned particles it finds no leavers)
 #define G2P_LAUNCH(M)                                                                                                        \
 	do {                                                                                                                     \
-		hipLaunchKernelGGL((k_g2p<M, true>), grid, dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, s->g, p, s->tile_start,   \
+		hipLaunchKernelGGL((k_g2p<M, true>), grid, dim3(G2P_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, s->g, p, s->tile_start,   \
 		                   s->u, s->v, s->w, s->uo, s->vo, s->wo, gp, leavers, n_leavers, pold, from, vmax2_bits);           \
 		if (stale)                                                                                                           \
 			hipLaunchKernelGGL(k_g2p_leavers<M>, dim3(512), dim3(256), 0, s->stream, s->g, p, s->u, s->v, s->w, s->uo, s->vo, \
