@@ -355,7 +355,18 @@ def main():
         hot = [k for k in ("p2g_scatter_kernel", "g2p", "bin") if k in kern]
         dom = max(hot, key=lambda k: kern[k]["share_of_step_ms"])
         out["roofline"] = roofline_of(dom, "dominant single kernel of the hot path (SURVEY 8a) by share of the median full step; "
-                                           "duration = in-step median over the timed steps (HIP events on the handle's stream)")
+                                           "duration = in-step median (HIP events on the handle's stream)")
+        if stage_overlapped is not None and stage_overlapped.get(dom, 0) > 0:
+            # the P2G / G2P / binning kernels run outside the window in which the correction shares the device with the solve: their
+            # launch duration IN THE TIMED REGION is the figure the contract asks for (the serial loop's is kept beside it)
+            ms_t = stage_overlapped[dom]
+            r = out["roofline"]
+            r["ms_serial_loop"], r["ms"] = r["ms"], ms_t
+            r["achieved"] = r["algorithmic_bytes"] / ms_t * 1e-6
+            r["frac"] = r["achieved"] / HBM_PEAK_GBS
+            r["note"] = ("dominant single kernel of the hot path (SURVEY 8a) by share of the median full step; duration = median launch "
+                         "duration over the TIMED steps (HIP events on the handle's stream; this kernel runs before the correction's "
+                         "stream is forked, so the overlap does not stretch it); ms_serial_loop = the same in the stage-attribution loop")
         dom_all = max(kern, key=lambda k: kern[k]["share_of_step_ms"] if k != "pcg_iteration_mean" else 0.0)
         out["roofline_full_step"] = roofline_of(dom_all, "largest kernel of the whole time_step; the position correction is VALU bound "
                                                          "(PMC: 69 % of the SIMD cycles issue VALU), its HBM fraction is not a quality measure")
