@@ -351,6 +351,13 @@ int lfa_get_timings(lfa_sim *s, double ms[LFA_NUM_TIMERS]);
 /* counts of the last step: [0] particles [1] unknowns (fluid cells) [2] tiles holding particles [3] tiles processed
  * by grid kernels (dilated set) [4] padded cell count */
 int lfa_get_counts(lfa_sim *s, uint64_t counts[5]);
+/* The last pressure solve, per PCG iteration (no member of the reference corresponds: pressure_solver::solve,
+ * src/pressure_solver.cpp:45-69, is one host loop): [0] kernel launches of one iteration [1] transport calls (neighbour
+ * exchanges + all-reduces; 0 on a single domain) of one iteration [2] levels of the multigrid hierarchy (0: another
+ * preconditioner) [3] first level that runs inside the single coarse-level launch [4] iterations of the solve
+ * [5] transport calls of the whole solve [6], [7] reserved (0). */
+#define LFA_NUM_SOLVER_STATS 8
+int lfa_get_solver_stats(lfa_sim *s, uint64_t stats[LFA_NUM_SOLVER_STATS]);
 /* The last position correction: [0] half tiles handled by the LDS-tiled kernel's fallback (a thread per particle gathering from
  * global memory: crowded blocks of more than 5632 staged particles) [1] half tiles in all. Joins a correction in
  * flight. A large [0] / [1] means the scene is far denser than 8 particles per cell and the correction runs slowly. */

@@ -97,6 +97,7 @@ SIGNATURES = {
     "lfa_apply_preconditioner": (_int, [_vp, _vp, _vp, _u64]),
     "lfa_apply_a": (_int, [_vp, _vp, _vp, _u64]),
     "lfa_pcg_solve": (_int, [_vp, _dbl, C.POINTER(_dbl), C.POINTER(_u64)]),
+    "lfa_get_solver_stats": (_int, [_vp, _vp]),
     "lfa_download_pressure": (_int, [_vp, _vp, _u64]),
     "lfa_upload_pressure": (_int, [_vp, _vp, _u64]),
     "lfa_apply_pressure": (_int, [_vp, _dbl]),
@@ -671,6 +672,12 @@ class Sim:
         c, r = C.c_double(0.0), C.c_double(0.0)
         self._chk(self.lib.lfa_bench_stream(self.h, int(nbytes), int(reps), C.byref(c), C.byref(r)))
         return c.value, r.value
+
+    def solver_stats(self):
+        arr = (C.c_uint64 * 8)()
+        self._chk(self.lib.lfa_get_solver_stats(self.h, C.byref(arr)))
+        return dict(zip(["launches_per_iteration", "transport_calls_per_iteration", "mg_levels", "mg_first_level_in_coarse_launch",
+                         "iterations", "transport_calls_per_solve"], list(arr)[:6]))
 
     def counts(self):
         arr = (C.c_uint64 * 5)()

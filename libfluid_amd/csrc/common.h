@@ -62,6 +62,7 @@ struct lfa_sim {
 	bool overlap_correction = true;
 	bool corr_in_flight = false;   // lfa_correct_collide_begin .. _end: the particle arrays belong to the correction on stream3
 	bool counts_fresh = false;     // tile_count / rank were produced by the advection of lfa_time_step: the binning skips its pass 1
+	bool corr_begun = false;       // the last lfa_correct_collide_begin started a correction (false: no particles, nothing to take back)
 	bool corr_undo_valid = false;  // nothing has changed positions, binning or solids since: lfa_correct_collide_undo can restore
 	uint32_t *corr_ovf = nullptr;  // tiled correction: word 0 = number of flagged (overflowing) half tiles, then their bitmap
 	int corr_parts_tiles = 0;      // particle tiles of the last correction
@@ -147,6 +148,8 @@ struct lfa_sim {
 	bool system_valid = false, unknown_count_valid = false;
 	double last_residual = 0.0;
 	uint64_t last_iters = 0;
+	// lfa_get_solver_stats
+	uint64_t stat_launches_iter = 0, stat_transport_iter = 0, stat_transport_solve = 0, stat_mg_levels = 0, stat_mg_first_co = 0;
 	// warm start of the PCG (lfa_params.pcg_warm_start)
 	uint32_t *tile_epoch = nullptr;   // [nt] solve counter of the last solve a tile took part in
 	uint32_t solve_epoch = 0;         // counter of system builds
@@ -314,11 +317,26 @@ int lfa_number_unknowns(lfa_sim *s);
 /// Transport between z-slab neighbours. lo = rank-1, hi = rank+1; all pointers are device pointers, sizes in bytes.
 struct lfa_dist {
 	int rank = 0, nranks = 1;
-	virtual int exchange(lfa_sim *s, const void *send_lo, size_t n_send_lo, void *recv_lo, size_t n_recv_lo,
-	                     const void *send_hi, size_t n_send_hi, void *recv_hi, size_t n_recv_hi) = 0;
-	virtual int allreduce(lfa_sim *s, double *dev, int count, bool is_max) = 0;
+	// every call of the three below is one transport call of lfa_get_solver_stats (a grouped send/recv pair or one collective)
+	int exchange(lfa_sim *s, const void *send_lo, size_t n_send_lo, void *recv_lo, size_t n_recv_lo, const void *send_hi,
+	             size_t n_send_hi, void *recv_hi, size_t n_recv_hi) {
+		++calls;
+		return exchange_impl(s, send_lo, n_send_lo, recv_lo, n_recv_lo, send_hi, n_send_hi, recv_hi, n_recv_hi);
+	}
+	int allreduce(lfa_sim *s, double *dev, int count, bool is_max) {
+		++calls;
+		return allreduce_impl(s, dev, count, is_max);
+	}
 	/// in-place all-reduce of a device array: dtype LFA_RED_U8 / F32 / F64, sum or max
-	virtual int allreduce_buf(lfa_sim *s, void *dev, size_t count, int dtype, bool is_max) = 0;
+	int allreduce_buf(lfa_sim *s, void *dev, size_t count, int dtype, bool is_max) {
+		++calls;
+		return allreduce_buf_impl(s, dev, count, dtype, is_max);
+	}
+	uint64_t calls = 0;
+	virtual int exchange_impl(lfa_sim *s, const void *send_lo, size_t n_send_lo, void *recv_lo, size_t n_recv_lo,
+	                          const void *send_hi, size_t n_send_hi, void *recv_hi, size_t n_recv_hi) = 0;
+	virtual int allreduce_impl(lfa_sim *s, double *dev, int count, bool is_max) = 0;
+	virtual int allreduce_buf_impl(lfa_sim *s, void *dev, size_t count, int dtype, bool is_max) = 0;
 	virtual ~lfa_dist() {}
 };
 enum { LFA_RED_U8 = 0, LFA_RED_F32 = 1, LFA_RED_F64 = 2 };

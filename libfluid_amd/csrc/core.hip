@@ -298,7 +298,6 @@ extern "C" const char *lfa_last_error(const lfa_sim *s) { return s ? s->err.c_st
 
 extern "C" int lfa_set_params(lfa_sim *s, const lfa_params *p) {
 	if (!s || !p) return LFA_E_INVALID;
-	LFA_TRY(lfa_corr_commit(s));
 	if (!(p->cell_size > 0.0)) return lfa_fail(s, LFA_E_INVALID, "cell_size must be > 0 (got %g)", p->cell_size);
 	if (p->simulation_method < 0 || p->simulation_method > 2) return lfa_fail(s, LFA_E_INVALID, "bad simulation_method");
 	if (p->velocity_extrapolation_iterations > 8)
@@ -310,8 +309,14 @@ extern "C" int lfa_set_params(lfa_sim *s, const lfa_params *p) {
 	if (p->p2g_variant != LFA_P2G_LDS_BINNED && p->p2g_variant != LFA_P2G_GLOBAL_ATOMIC)
 		return lfa_fail(s, LFA_E_INVALID, "bad p2g_variant %d", p->p2g_variant);
 	if (!(p->density > 0.0)) return lfa_fail(s, LFA_E_INVALID, "density must be > 0 (got %g)", p->density);
+	// (a rejected call has no side effects: everything above only reads). An unchanged parameter block - what the host class sends
+	// before every step - leaves a correction in flight alone.
+	if (memcmp(p, &s->prm, sizeof(lfa_params)) != 0) LFA_TRY(lfa_corr_commit(s));
 	if (p->simulation_method != s->prm.simulation_method) LFA_TRY(lfa_particles_materialize(s));  // what is deferred depends on it
-	if (p->pcg_dtype != s->prm.pcg_dtype || p->precond != s->prm.precond) s->system_valid = false;
+	if (p->pcg_dtype != s->prm.pcg_dtype || p->precond != s->prm.precond) {
+		s->system_valid = false;
+		s->pressure_epoch = 0;  // vp is about to be reinterpreted / re-allocated: no warm start from it
+	}
 	s->prm = *p;
 	return LFA_OK;
 }

@@ -423,6 +423,7 @@ int lfa_dist_migrate(lfa_sim *s) {
 	s->np_live = at;
 	if (!s->binned) s->np = at;
 	s->holes = true;
+	s->vmax2_valid = false;  // the cached max |v|^2 (written by the last G2P) knows nothing of arrivals: lfa_cfl reduces again
 	return LFA_OK;
 }
 
@@ -522,7 +523,7 @@ struct lfa_hub {
 namespace {
 struct LocalDist : lfa_dist {
 	lfa_hub *hub = nullptr;
-	int exchange(lfa_sim *s, const void *send_lo, size_t n_send_lo, void *recv_lo, size_t n_recv_lo, const void *send_hi,
+	int exchange_impl(lfa_sim *s, const void *send_lo, size_t n_send_lo, void *recv_lo, size_t n_recv_lo, const void *send_hi,
 	             size_t n_send_hi, void *recv_hi, size_t n_recv_hi) override {
 		LFA_HIP(s, hipStreamSynchronize(s->stream));
 		lfa_hub::Mail &me = hub->mail[rank];
@@ -549,7 +550,7 @@ struct LocalDist : lfa_dist {
 			rc = lfa_fail(s, LFA_E_HIP, "slab exchange: a peer rank failed or timed out");
 		return rc;
 	}
-	int allreduce(lfa_sim *s, double *dev, int count, bool is_max) override {
+	int allreduce_impl(lfa_sim *s, double *dev, int count, bool is_max) override {
 		if (count != 1) return lfa_fail(s, LFA_E_INVALID, "local all-reduce supports one scalar");
 		double v = 0.0;
 		LFA_HIP(s, hipMemcpyAsync(&v, dev, 8, hipMemcpyDeviceToHost, s->stream));
@@ -566,7 +567,7 @@ struct LocalDist : lfa_dist {
 		LFA_HIP(s, hipStreamSynchronize(s->stream));
 		return LFA_OK;
 	}
-	int allreduce_buf(lfa_sim *s, void *dev, size_t count, int dtype, bool is_max) override {
+	int allreduce_buf_impl(lfa_sim *s, void *dev, size_t count, int dtype, bool is_max) override {
 		const size_t es = dtype == LFA_RED_U8 ? 1 : (dtype == LFA_RED_F32 ? 4 : 8), bytes = count * es;
 		std::vector<uint8_t> &mine = hub->mail[rank].buf;
 		mine.resize(bytes);
@@ -637,7 +638,7 @@ struct RcclDist : lfa_dist {
 		if (r_ != ncclSuccess)                                                                            \
 			return lfa_fail((s), LFA_E_HIP, "%s failed: %s", #call, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?"); \
 	} while (0)
-	int exchange(lfa_sim *s, const void *send_lo, size_t n_send_lo, void *recv_lo, size_t n_recv_lo, const void *send_hi,
+	int exchange_impl(lfa_sim *s, const void *send_lo, size_t n_send_lo, void *recv_lo, size_t n_recv_lo, const void *send_hi,
 	             size_t n_send_hi, void *recv_hi, size_t n_recv_hi) override {
 		// sizes are known on both sides (they follow from the flags exchanged first), so no size handshake is needed
 		NCCL_TRY(s, g_rccl.GroupStart());
@@ -652,11 +653,11 @@ struct RcclDist : lfa_dist {
 		NCCL_TRY(s, g_rccl.GroupEnd());
 		return LFA_OK;
 	}
-	int allreduce(lfa_sim *s, double *dev, int count, bool is_max) override {
+	int allreduce_impl(lfa_sim *s, double *dev, int count, bool is_max) override {
 		NCCL_TRY(s, g_rccl.AllReduce(dev, dev, (size_t)count, ncclFloat64, is_max ? ncclMax : ncclSum, comm, s->stream));
 		return LFA_OK;
 	}
-	int allreduce_buf(lfa_sim *s, void *dev, size_t count, int dtype, bool is_max) override {
+	int allreduce_buf_impl(lfa_sim *s, void *dev, size_t count, int dtype, bool is_max) override {
 		const ncclDataType_t t = dtype == LFA_RED_U8 ? ncclUint8 : (dtype == LFA_RED_F32 ? ncclFloat32 : ncclFloat64);
 		NCCL_TRY(s, g_rccl.AllReduce(dev, dev, count, t, is_max ? ncclMax : ncclSum, comm, s->stream));
 		return LFA_OK;

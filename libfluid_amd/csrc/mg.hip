@@ -29,6 +29,7 @@
 
 #include <limits.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -59,6 +60,7 @@ struct lfa_mg_level {
 	size_t cap_tiles = 0;
 	int lo_layer = 0, hi_layer = 0;  // owned tile layers of this level (slabs: distributed levels only)
 	uint32_t *flag = nullptr, *prev_flag = nullptr;  // device, per tile of the level: active now / at the last set-up (single domain)
+	unsigned *ready = nullptr;  // device, 3 x tiles of the level: ready flags of k_mg_coarse (levels >= 1; never cleared: tags are unique)
 };
 struct lfa_mg {
 	int n_levels = 0;
@@ -73,10 +75,17 @@ struct lfa_mg {
 	uint8_t *l1_dirty = nullptr;  // device, per level-1 tile: a child tile was flagged at the last set-up (k_mg_types_from_fine_dirty)
 	unsigned solid_epoch = 0;     // solid mask the level-1 types were computed for
 	uint32_t *counts = nullptr;   // device, active tiles per level (single-domain set-up, read back once)
+	unsigned co_tag = 0;          // k_mg_coarse: launch counter = the value its ready flags are raised to (lfa_mg_level::ready)
+	unsigned long long *co_stamps = nullptr;  // LFA_MG_CO_STAMPS=1: phase stamps of the last k_mg_coarse launch, printed by lfa_mg_free
+	int co_phases = 0;
+	int launches_per_cycle = 0;   // launches of the last V-cycle incl. the AXPY / pre-smoothing kernel (lfa_get_solver_stats)
+	int first_co = 0;             // first level inside k_mg_coarse at the last V-cycle (0: launch-per-phase path)
 };
 // A level stays distributed while no tile layer straddles a slab face, and its ghost types follow from the one fine ghost tile
 // layer a rank mirrors (8 cells = one slice of level 3).
 #define MG_DIST_MAX 4
+#define MG_CO_PHASES 64
+#define MG_CO_MAX_LEVELS 8  // levels inside k_mg_coarse (a 2048^3 grid has 9 levels in all)
 
 namespace {
 #define MG_FENCE()                                             \
@@ -217,7 +226,8 @@ __global__ void k_mg_compact(const uint32_t *flag, const uint32_t *scan, int *li
 	if (t < nt && flag[t]) list[scan[t]] = t;
 }
 /// six face neighbours (tile id, -1: inactive or outside) + own id per slot
-__global__ void k_mg_build_nbr(const int *tiles, int n_tiles, GridDims g, const uint32_t *flag, int *nbr) {
+/// + in word 7 the mask of the active child tiles (level below; `flag_f` null on the finest level): k_mg_coarse waits for them
+__global__ void k_mg_build_nbr(const int *tiles, int n_tiles, GridDims g, const uint32_t *flag, int *nbr, GridDims gf, const uint32_t *flag_f) {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n_tiles) return;
 	const int t = tiles[i], sy = g.ntx, sz = g.ntx * g.nty;
@@ -228,7 +238,13 @@ __global__ void k_mg_build_nbr(const int *tiles, int n_tiles, GridDims g, const 
 #pragma unroll
 	for (int k = 0; k < 6; ++k) nbr[i * MG_NBR_STRIDE + k] = (cand[k] >= 0 && flag[cand[k]]) ? cand[k] : -1;
 	nbr[i * MG_NBR_STRIDE + 6] = t;
-	nbr[i * MG_NBR_STRIDE + 7] = 0;
+	int mask = 0;
+	if (flag_f)
+		for (int k = 0; k < 8; ++k) {
+			const int cx = 2 * tx + (k & 1), cy = 2 * ty + ((k >> 1) & 1), cz = 2 * tz + (k >> 2);
+			if (cx < gf.ntx && cy < gf.nty && cz < gf.ntz && flag_f[cx + gf.ntx * (cy + gf.nty * cz)]) mask |= 1 << k;
+		}
+	nbr[i * MG_NBR_STRIDE + 7] = mask;
 }
 /// Vectors of levels >= 1 are read where no tile of this solve writes (parents of ring cells): a tile that has left the active
 /// set must not leave values behind. One workgroup per tile that was active at the last set-up and is not now.
@@ -691,26 +707,34 @@ template <typename real> __device__ inline void cp_half_sweep(CpTile<real> &S, i
 }
 __device__ inline int cp_hi(int cell) { return ((cell & 7) + 1) + 10 * (((cell >> 3) & 7) + 1) + 100 * ((cell >> 6) + 1); }
 
-template <typename real>
-__global__ void __launch_bounds__(256) k_mg_presmooth_cp(MgLv<real> L, int inner, const int *state) {
-	__shared__ CpTile<real> S;
-	if (state[0] >= 0) return;
+/// How a kernel reaches the level arrays other workgroups write. MemPlain: ordinary accesses (one launch per phase, the kernel
+/// boundary makes them visible). MemAgent: agent-scope relaxed atomics (`sc1` on gfx950: the access is coherent across the eight
+/// per-XCD L2s by itself, no bulk write-back / invalidate) - what lets k_mg_coarse run its phases inside ONE launch.
+struct MemPlain {
+	template <typename T> static __device__ inline T ld(const T *p) { return *p; }
+	template <typename T> static __device__ inline void st(T *p, T v) { *p = v; }
+};
+struct MemAgent {
+	template <typename T> static __device__ inline T ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+	template <typename T> static __device__ inline void st(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+};
+
+/// Down, one tile, a workgroup of 256: x = `inner` red->black sweeps on A x = b from x = 0.
+template <typename real, typename MEM> __device__ inline void cp_presmooth_tile(CpTile<real> &S, const MgLv<real> &L, int slot, int inner) {
 	const int t = threadIdx.x;
-	for (int slot = blockIdx.x; slot < L.n_tiles; slot += gridDim.x) {
-		const size_t base = (size_t)L.tiles[slot] * 512;
-		for (int c = t; c < 512; c += 256) {
-			S.ab[c] = L.abits[base + c];
-			S.bb[c] = L.b[base + c];
-		}
-		for (int i = t; i < LFA_HALO_CELLS; i += 256) S.H[i] = (real)0;
-		__syncthreads();
-		for (int it = 0; it < inner; ++it) {
-			cp_half_sweep<real>(S, 0);
-			cp_half_sweep<real>(S, 1);
-		}
-		for (int c = t; c < 512; c += 256) L.x[base + c] = S.H[cp_hi(c)];
-		__syncthreads();
+	const size_t base = (size_t)L.tiles[slot] * 512;
+	for (int c = t; c < 512; c += 256) {
+		S.ab[c] = L.abits[base + c];
+		S.bb[c] = MEM::ld(L.b + base + c);
 	}
+	for (int i = t; i < LFA_HALO_CELLS; i += 256) S.H[i] = (real)0;
+	__syncthreads();
+	for (int it = 0; it < inner; ++it) {
+		cp_half_sweep<real>(S, 0);
+		cp_half_sweep<real>(S, 1);
+	}
+	for (int c = t; c < 512; c += 256) MEM::st(L.x + base + c, S.H[cp_hi(c)]);
+	__syncthreads();
 }
 
 /// Ring cell r (0..383) of a tile: face f = r >> 6, in-face lane (a, b) = (r & 7, (r >> 3) & 7) as in load_halo.
@@ -727,31 +751,315 @@ __device__ inline void cp_ring(int r, int &f, int &hidx, int &ncell, int &dx, in
 	}
 }
 
+/// Down, one tile: residual r = b - A x of the level and its restriction to the next (half the sum over the 8 children).
+template <typename real, typename MEM>
+__device__ inline void cp_residual_restrict_tile(CpTile<real> &S, real *R, const MgLv<real> &L, const GridDims &gc, real *b_coarse, int slot) {
+	const int t = threadIdx.x;
+	const int *nt = L.nbr + (size_t)slot * MG_NBR_STRIDE;
+	const int tile = nt[6];
+	const size_t base = (size_t)tile * 512;
+	for (int c = t; c < 512; c += 256) {
+		S.ab[c] = L.abits[base + c];
+		S.bb[c] = MEM::ld(L.b + base + c);
+		S.H[cp_hi(c)] = MEM::ld(L.x + base + c);
+	}
+	for (int r = t; r < 384; r += 256) {
+		int f, hidx, ncell, dx, dy, dz;
+		cp_ring(r, f, hidx, ncell, dx, dy, dz);
+		const int nb = nt[f];
+		S.H[hidx] = nb >= 0 ? MEM::ld(L.x + (size_t)nb * 512 + ncell) : (real)0;
+	}
+	__syncthreads();
+	for (int c = t; c < 512; c += 256) {
+		const int i = cp_hi(c);
+		const uint32_t a = S.ab[c];
+		real r = (real)0;
+		if (a & AB_UNKNOWN) {
+			const real F = (a & AB_FLUID) ? (real)1 : (real)0;
+			real val = (real)(a & 7) * S.H[i];
+			val -= F * S.H[i - 1];
+			val -= F * S.H[i - 10];
+			val -= F * S.H[i - 100];
+			val -= (real)((a >> 3) & 1) * S.H[i + 1];
+			val -= (real)((a >> 4) & 1) * S.H[i + 10];
+			val -= (real)((a >> 5) & 1) * S.H[i + 100];
+			r = S.bb[c] - val;
+		}
+		R[c] = r;
+	}
+	__syncthreads();
+	if (t < 64) {  // one coarse cell each: its 8 children in the order of the pair sums and the two shuffle steps
+		const int X = t & 3, Y = (t >> 2) & 3, Z = t >> 4;
+		auto pair = [&](int x, int y) { real p = R[x + 8 * y + 64 * (2 * Z)]; p += R[x + 8 * y + 64 * (2 * Z + 1)]; return p; };
+		real v = pair(2 * X, 2 * Y);
+		v += pair(2 * X + 1, 2 * Y);
+		real w = pair(2 * X, 2 * Y + 1);
+		w += pair(2 * X + 1, 2 * Y + 1);
+		v += w;
+		int tx, ty, tz;
+		tile_coords(L.g, tile, tx, ty, tz);
+		const int ptile = (tx >> 1) + gc.ntx * ((ty >> 1) + gc.nty * (tz >> 1));
+		MEM::st(b_coarse + (size_t)ptile * 512 + ((tz & 1) * 4 + Z) * 64 + ((ty & 1) * 4 + Y) * 8 + (tx & 1) * 4 + X, (real)0.5 * v);
+	}
+	__syncthreads();
+}
+
+/// Up, one tile: x += P e, then `inner` black->red sweeps with the corrected values of the neighbour tiles on the ring.
+template <typename real, typename MEM>
+__device__ inline void cp_prolong_postsmooth_tile(CpTile<real> &S, const MgLv<real> &L, const GridDims &gc, const real *e, int slot, int inner) {
+	const int t = threadIdx.x;
+	const int *nt = L.nbr + (size_t)slot * MG_NBR_STRIDE;
+	const int tile = nt[6];
+	const size_t base = (size_t)tile * 512;
+	int tx, ty, tz;
+	tile_coords(L.g, tile, tx, ty, tz);
+	auto corr = [&](int X, int Y, int Z) -> real { return MEM::ld(e + blocked_index(gc, X >> 1, Y >> 1, Z >> 1)); };
+	for (int c = t; c < 512; c += 256) {
+		const uint8_t a = L.abits[base + c];
+		S.ab[c] = a;
+		S.bb[c] = MEM::ld(L.b + base + c);
+		real v = MEM::ld(L.x + base + c);
+		if (a & AB_UNKNOWN) v += corr(tx * 8 + (c & 7), ty * 8 + ((c >> 3) & 7), tz * 8 + (c >> 6));
+		S.H[cp_hi(c)] = v;
+	}
+	for (int r = t; r < 384; r += 256) {
+		int f, hidx, ncell, dx, dy, dz;
+		cp_ring(r, f, hidx, ncell, dx, dy, dz);
+		const int nb = nt[f];
+		real v = (real)0;
+		if (nb >= 0) {
+			const size_t j = (size_t)nb * 512 + ncell;
+			v = MEM::ld(L.x + j);
+			if (L.abits[j] & AB_UNKNOWN) v += corr(tx * 8 + dx, ty * 8 + dy, tz * 8 + dz);
+		}
+		S.H[hidx] = v;
+	}
+	__syncthreads();
+	for (int it = 0; it < inner; ++it) {
+		cp_half_sweep<real>(S, 1);
+		cp_half_sweep<real>(S, 0);
+	}
+	for (int c = t; c < 512; c += 256) MEM::st(L.y + base + c, S.H[cp_hi(c)]);
+	__syncthreads();
+}
+
+/// Coarsest level (a single tile): nsw red->black sweeps followed by nsw black->red sweeps from zero (coarsest_tile, cell-parallel).
+template <typename real, typename MEM> __device__ inline void cp_coarsest_tile(CpTile<real> &S, const MgLv<real> &L, int nsw) {
+	const int t = threadIdx.x;
+	const size_t base = (size_t)L.tiles[0] * 512;
+	for (int c = t; c < 512; c += 256) {
+		S.ab[c] = L.abits[base + c];
+		S.bb[c] = MEM::ld(L.b + base + c);
+	}
+	for (int i = t; i < LFA_HALO_CELLS; i += 256) S.H[i] = (real)0;
+	__syncthreads();
+	for (int q = 0; q < 2 * nsw; ++q) {
+		const int fc = q < nsw ? 0 : 1;
+		cp_half_sweep<real>(S, fc);
+		cp_half_sweep<real>(S, fc ^ 1);
+	}
+	for (int c = t; c < 512; c += 256) MEM::st(L.y + base + c, S.H[cp_hi(c)]);
+	__syncthreads();
+}
+
+template <typename real>
+__global__ void __launch_bounds__(256) k_mg_presmooth_cp(MgLv<real> L, int inner, const int *state) {
+	__shared__ CpTile<real> S;
+	if (state[0] >= 0) return;
+	for (int slot = blockIdx.x; slot < L.n_tiles; slot += gridDim.x) cp_presmooth_tile<real, MemPlain>(S, L, slot, inner);
+}
 template <typename real>
 __global__ void __launch_bounds__(256) k_mg_residual_restrict_cp(MgLv<real> L, GridDims gc, real *b_coarse, const int *state) {
 	__shared__ CpTile<real> S;
 	__shared__ real R[512];
 	if (state[0] >= 0) return;
-	const int t = threadIdx.x;
-	for (int slot = blockIdx.x; slot < L.n_tiles; slot += gridDim.x) {
-		const int *nt = L.nbr + (size_t)slot * MG_NBR_STRIDE;
-		const int tile = nt[6];
-		const size_t base = (size_t)tile * 512;
-		for (int c = t; c < 512; c += 256) {
-			S.ab[c] = L.abits[base + c];
-			S.bb[c] = L.b[base + c];
-			S.H[cp_hi(c)] = L.x[base + c];
+	for (int slot = blockIdx.x; slot < L.n_tiles; slot += gridDim.x) cp_residual_restrict_tile<real, MemPlain>(S, R, L, gc, b_coarse, slot);
+}
+template <typename real>
+__global__ void __launch_bounds__(256) k_mg_prolong_postsmooth_cp(MgLv<real> L, GridDims gc, const real *e, int inner, const int *state) {
+	__shared__ CpTile<real> S;
+	if (state[0] >= 0) return;
+	for (int slot = blockIdx.x; slot < L.n_tiles; slot += gridDim.x) cp_prolong_postsmooth_tile<real, MemPlain>(S, L, gc, e, slot, inner);
+}
+
+// ------------------------------------------------------------------------------------------------ the coarse levels in ONE launch
+// A V-cycle below the finest level is a chain of short, dependent phases (pre-smoothing, residual + restriction per level, the
+// coarsest solve, prolongation + post-smoothing per level): as separate launches each costs 5-8 us of dispatch latency whatever
+// it computes (C4: 13.5 launches + the tail workgroup = 81 of an iteration's 315 us; C2: two thirds of the iteration).
+// k_mg_coarse runs all of them in one launch, as DATAFLOW between workgroups:
+//  * workgroup w owns tile slot w of EVERY level it reaches (a level has at most as many tiles as the one above, so a workgroup
+//    works on levels first .. lmax(w) on the way down and rejoins at lmax(w) on the way up). The state of its tile on each level -
+//    halo block with the pre-smoothed iterate and the neighbours' ring values, right-hand side, A bytes - stays in LDS from the
+//    way down to the way up; static data (tile ids, neighbour tables, A bytes) is fetched once, before anything is waited for.
+//  * what crosses workgroups - the ring values of the neighbour tiles, the restricted residual of the 8 children, the correction of
+//    the parents - goes through the level arrays in global memory with agent-scope relaxed atomics (MemAgent: `sc1`, coherent per
+//    access across the eight per-XCD L2s), so no release / acquire fence with its L2 write-back and invalidate is needed. That
+//    fence is what made the earlier cooperative attempt slow (tools/xcd_barrier_probe.hip: 4.6-13 us per round with fences,
+//    1.6-2.1 us with per-access coherence).
+//  * there is no grid barrier and no atomic read-modify-write: a tile that has stored its output waits for the stores to be
+//    acknowledged (`s_waitcnt vmcnt(0)`) and then stores this launch's TAG into its ready flag; a consumer polls the flags of
+//    exactly the tiles it reads from (<= 6 neighbours, <= 8 children, <= 4 parents). Tags are unique per launch: flags are never
+//    cleared. (A counter per phase was measured first: 256 producers incrementing one word serialise, 4-7 us per phase.)
+//  * a half sweep keeps the coefficients of a thread's two cells in registers: 7 LDS reads, the update, a barrier.
+// Deadlock freedom: every dependency points to an earlier phase of the same global phase order, and the launch has at most
+// MG_CO_MAX_TILES workgroups, which are resident at once (or become resident as other kernels' workgroups retire).
+// The arithmetic per cell is cp_*_tile's, so the result is bit-identical to the launch-per-phase path (LFA_MG_NO_PERSIST=1; tested).
+template <typename real> struct CoLevel {
+	real H[LFA_HALO_CELLS];  // halo block: pre-smoothed iterate + ring (0 where the neighbour tile is inactive)
+	real b[512];
+	uint8_t ab[512];
+	uint8_t rab[384];  // A bytes of the ring cells (cp_ring order)
+	int nb[8];         // the slot's row of the neighbour table: six neighbour tile ids, own tile id, mask of active child tiles
+};
+template <typename real> struct MgCo {
+	MgLv<real> lv[MG_MAX_LEVELS];
+	unsigned *ready[MG_MAX_LEVELS];  // per level 3 x (tiles of the level): tile has stored [0] its pre-smoothed iterate [1] its share of the next level's right-hand side [2] its result
+	int first, last, nsw, inner;
+	unsigned tag;
+	unsigned long long *stamps;  // LFA_MG_CO_STAMPS=1 (debugging): workgroup 0 records the 100 MHz clock around its phases
+};
+
+/// All threads: waits until every tile in dep[0 .. n) (n <= 8; -1 entries are skipped) carries this launch's tag in `flag`.
+__device__ inline void co_wait(const unsigned *flag, const int *dep, int n, unsigned tag) {
+	if ((int)threadIdx.x < n) {
+		const int d = dep[threadIdx.x];
+		if (d >= 0)
+			while (__hip_atomic_load(flag + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) __builtin_amdgcn_s_sleep(1);
+	}
+	__syncthreads();
+}
+/// All threads: this workgroup's stores so far have been acknowledged; then the tile's flag is raised.
+__device__ inline void co_post(unsigned *flag, int tile, unsigned tag) {
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	if (threadIdx.x == 0) __hip_atomic_store(flag + tile, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename real>
+__global__ void __launch_bounds__(256) k_mg_coarse(MgCo<real> P, const int *state) {
+	extern __shared__ unsigned char co_smem[];
+	__shared__ int dep[8];
+	const int t = threadIdx.x, wg = blockIdx.x, nlev = P.last - P.first + 1;
+	CoLevel<real> *st = (CoLevel<real> *)co_smem;
+	real *R = (real *)(st + nlev);
+	const unsigned tag = P.tag;
+	int n_stamp = 0;
+	auto stamp = [&]() {
+		if (P.stamps && wg == 0 && t == 0) P.stamps[n_stamp] = wall_clock64();
+		++n_stamp;
+	};
+	stamp();
+	// the two cells of a thread: column (qx, qy), z = 2 j and 2 j + 1
+	const int qx = t & 7, qy = (t >> 3) & 7, qj = t >> 6;
+	const int c0 = qx + 8 * qy + 128 * qj, c1 = c0 + 64, h0 = (qx + 1) + 10 * (qy + 1) + 100 * (2 * qj + 1), h1 = h0 + 100;
+	int lmax = P.first - 1;  // deepest level this workgroup owns a tile of
+	for (int l = P.first; l <= P.last; ++l)
+		if (wg < P.lv[l].n_tiles) lmax = l;
+	// ---- static data of every level, before anything is waited for: two dependent round trips in all (rows of the neighbour
+	// tables together with the solver state; then every level's A bytes and the first level's right-hand side, all loads in
+	// flight before the first of them is used)
+	int nbv = 0;
+	if (t < 8 * nlev && P.first + (t >> 3) <= lmax) nbv = P.lv[P.first + (t >> 3)].nbr[(size_t)wg * MG_NBR_STRIDE + (t & 7)];
+	const int st0 = state[0];
+	if (st0 >= 0) return;  // converged: the launches queued behind the stopping test are no-ops
+	if (t < 8 * nlev) st[t >> 3].nb[t & 7] = nbv;
+	for (int l = P.first; l <= lmax; ++l) {
+		CoLevel<real> &S = st[l - P.first];
+		for (int i = t; i < LFA_HALO_CELLS; i += 256) S.H[i] = (real)0;
+	}
+	__syncthreads();
+	{
+		uint8_t va[MG_CO_MAX_LEVELS][4];
+		int r1 = t + 256, f0, f1, hidx, nc0, nc1, dx, dy, dz;
+		cp_ring(t, f0, hidx, nc0, dx, dy, dz);
+		cp_ring(r1 < 384 ? r1 : 0, f1, hidx, nc1, dx, dy, dz);
+#pragma unroll
+		for (int k = 0; k < MG_CO_MAX_LEVELS; ++k) {
+			const int l = P.first + k;
+			va[k][0] = va[k][1] = va[k][2] = va[k][3] = 0;
+			if (l <= lmax) {
+				const uint8_t *ab = P.lv[l].abits;
+				const int *nb = st[k].nb;
+				va[k][0] = ab[(size_t)nb[6] * 512 + c0];
+				va[k][1] = ab[(size_t)nb[6] * 512 + c1];
+				if (nb[f0] >= 0) va[k][2] = ab[(size_t)nb[f0] * 512 + nc0];
+				if (r1 < 384 && nb[f1] >= 0) va[k][3] = ab[(size_t)nb[f1] * 512 + nc1];
+			}
 		}
+		// (issued behind the A bytes, consumed by the first phase: the right-hand side the previous kernel has restricted)
+		const size_t base0 = (size_t)st[0].nb[6] * 512;
+		const real fb0 = MemAgent::ld(P.lv[P.first].b + base0 + c0), fb1 = MemAgent::ld(P.lv[P.first].b + base0 + c1);
+#pragma unroll
+		for (int k = 0; k < MG_CO_MAX_LEVELS; ++k)
+			if (P.first + k <= lmax) {
+				st[k].ab[c0] = va[k][0];
+				st[k].ab[c1] = va[k][1];
+				st[k].rab[t] = va[k][2];
+				if (r1 < 384) st[k].rab[r1] = va[k][3];
+			}
+		st[0].b[c0] = fb0;
+		st[0].b[c1] = fb1;
+	}
+	__syncthreads();
+	stamp();
+	// one half sweep of colour `colour` on the halo block H with the coefficients of the thread's two cells
+	auto half_sweep = [&](real *H, uint32_t a0, uint32_t a1, real b0, real b1, int colour) {
+		const int k = (qx + qy + colour) & 1;
+		gs_cell<real>(H, k ? a1 : a0, k ? b1 : b0, k ? h1 : h0);
+		__syncthreads();
+	};
+	// ---- down
+	for (int l = P.first; l < P.last && l <= lmax; ++l) {
+		CoLevel<real> &S = st[l - P.first];
+		const MgLv<real> &L = P.lv[l];
+		const int tile = S.nb[6], nt = L.g.nt;
+		const size_t base = (size_t)tile * 512;
+		const uint32_t a0 = S.ab[c0], a1 = S.ab[c1];
+		if (l > P.first) {  // the right-hand side is the restricted residual of the child tiles (level l - 1)
+			const GridDims &gf = P.lv[l - 1].g;
+			if (t < 8) {
+				int tx, ty, tz;
+				tile_coords(L.g, tile, tx, ty, tz);
+				const int cx = 2 * tx + (t & 1), cy = 2 * ty + ((t >> 1) & 1), cz = 2 * tz + (t >> 2);
+				dep[t] = ((S.nb[7] >> t) & 1) ? cx + gf.ntx * (cy + gf.nty * cz) : -1;
+			}
+			__syncthreads();
+			co_wait(P.ready[l - 1] + gf.nt, dep, 8, tag);
+		}
+		real b0, b1;
+		if (l > P.first) {
+			b0 = MemAgent::ld(L.b + base + c0);
+			b1 = MemAgent::ld(L.b + base + c1);
+			S.b[c0] = b0;
+			S.b[c1] = b1;
+		} else {  // fetched with the static data
+			b0 = S.b[c0];
+			b1 = S.b[c1];
+		}
+		// pre-smoothing from zero: the ring does not enter (the interior of H is still zero here)
+		for (int it = 0; it < P.inner; ++it) {
+			half_sweep(S.H, a0, a1, b0, b1, 0);
+			half_sweep(S.H, a0, a1, b0, b1, 1);
+		}
+		MemAgent::st(L.x + base + c0, S.H[h0]);
+		MemAgent::st(L.x + base + c1, S.H[h1]);
+		co_post(P.ready[l], tile, tag);
+		stamp();
+		// residual: the ring holds the neighbours' pre-smoothed values
+		if (t < 6) dep[t] = S.nb[t];
+		__syncthreads();
+		co_wait(P.ready[l], dep, 6, tag);
 		for (int r = t; r < 384; r += 256) {
 			int f, hidx, ncell, dx, dy, dz;
 			cp_ring(r, f, hidx, ncell, dx, dy, dz);
-			const int nb = nt[f];
-			S.H[hidx] = nb >= 0 ? L.x[(size_t)nb * 512 + ncell] : (real)0;
+			const int nb = S.nb[f];
+			if (nb >= 0) S.H[hidx] = MemAgent::ld(L.x + (size_t)nb * 512 + ncell);
 		}
 		__syncthreads();
-		for (int c = t; c < 512; c += 256) {
-			const int i = cp_hi(c);
-			const uint32_t a = S.ab[c];
+#pragma unroll
+		for (int k = 0; k < 2; ++k) {
+			const uint32_t a = k ? a1 : a0;
+			const int i = k ? h1 : h0;
 			real r = (real)0;
 			if (a & AB_UNKNOWN) {
 				const real F = (a & AB_FLUID) ? (real)1 : (real)0;
@@ -762,9 +1070,9 @@ __global__ void __launch_bounds__(256) k_mg_residual_restrict_cp(MgLv<real> L, G
 				val -= (real)((a >> 3) & 1) * S.H[i + 1];
 				val -= (real)((a >> 4) & 1) * S.H[i + 10];
 				val -= (real)((a >> 5) & 1) * S.H[i + 100];
-				r = S.bb[c] - val;
+				r = (k ? b1 : b0) - val;
 			}
-			R[c] = r;
+			R[k ? c1 : c0] = r;
 		}
 		__syncthreads();
 		if (t < 64) {  // one coarse cell each: its 8 children in the order of the pair sums and the two shuffle steps
@@ -777,52 +1085,96 @@ __global__ void __launch_bounds__(256) k_mg_residual_restrict_cp(MgLv<real> L, G
 			v += w;
 			int tx, ty, tz;
 			tile_coords(L.g, tile, tx, ty, tz);
+			const GridDims &gc = P.lv[l + 1].g;
 			const int ptile = (tx >> 1) + gc.ntx * ((ty >> 1) + gc.nty * (tz >> 1));
-			b_coarse[(size_t)ptile * 512 + ((tz & 1) * 4 + Z) * 64 + ((ty & 1) * 4 + Y) * 8 + (tx & 1) * 4 + X] = (real)0.5 * v;
+			MemAgent::st(P.lv[l + 1].b + (size_t)ptile * 512 + ((tz & 1) * 4 + Z) * 64 + ((ty & 1) * 4 + Y) * 8 + (tx & 1) * 4 + X, (real)0.5 * v);
 		}
-		__syncthreads();
+		co_post(P.ready[l] + nt, tile, tag);
+		stamp();
 	}
-}
-
-template <typename real>
-__global__ void __launch_bounds__(256) k_mg_prolong_postsmooth_cp(MgLv<real> L, GridDims gc, const real *e, int inner, const int *state) {
-	__shared__ CpTile<real> S;
-	if (state[0] >= 0) return;
-	const int t = threadIdx.x;
-	for (int slot = blockIdx.x; slot < L.n_tiles; slot += gridDim.x) {
-		const int *nt = L.nbr + (size_t)slot * MG_NBR_STRIDE;
-		const int tile = nt[6];
+	// ---- coarsest level (one tile, workgroup 0): nsw sweeps red->black, nsw black->red from zero
+	if (wg == 0) {
+		const int l = P.last;
+		CoLevel<real> &S = st[l - P.first];
+		const MgLv<real> &L = P.lv[l];
+		const int tile = S.nb[6];
 		const size_t base = (size_t)tile * 512;
+		const uint32_t a0 = S.ab[c0], a1 = S.ab[c1];
+		if (l > P.first) {
+			const GridDims &gf = P.lv[l - 1].g;
+			if (t < 8) {
+				int tx, ty, tz;
+				tile_coords(L.g, tile, tx, ty, tz);
+				const int cx = 2 * tx + (t & 1), cy = 2 * ty + ((t >> 1) & 1), cz = 2 * tz + (t >> 2);
+				dep[t] = ((S.nb[7] >> t) & 1) ? cx + gf.ntx * (cy + gf.nty * cz) : -1;
+			}
+			__syncthreads();
+			co_wait(P.ready[l - 1] + gf.nt, dep, 8, tag);
+		}
+		real b0, b1;
+		if (l > P.first) {
+			b0 = MemAgent::ld(L.b + base + c0);
+			b1 = MemAgent::ld(L.b + base + c1);
+		} else {
+			b0 = S.b[c0];
+			b1 = S.b[c1];
+		}
+		for (int q = 0; q < 2 * P.nsw; ++q) {
+			const int fc = q < P.nsw ? 0 : 1;
+			half_sweep(S.H, a0, a1, b0, b1, fc);
+			half_sweep(S.H, a0, a1, b0, b1, fc ^ 1);
+		}
+		MemAgent::st(L.y + base + c0, S.H[h0]);
+		MemAgent::st(L.y + base + c1, S.H[h1]);
+		co_post(P.ready[l] + 2 * L.g.nt, tile, tag);
+		stamp();
+	}
+	// ---- up
+	for (int l = (lmax < P.last - 1 ? lmax : P.last - 1); l >= P.first; --l) {
+		CoLevel<real> &S = st[l - P.first];
+		const MgLv<real> &L = P.lv[l];
+		const GridDims &gc = P.lv[l + 1].g;
+		const int tile = S.nb[6];
+		const size_t base = (size_t)tile * 512;
+		const uint32_t a0 = S.ab[c0], a1 = S.ab[c1];
+		const real b0 = S.b[c0], b1 = S.b[c1];
 		int tx, ty, tz;
 		tile_coords(L.g, tile, tx, ty, tz);
-		auto corr = [&](int X, int Y, int Z) -> real { return e[blocked_index(gc, X >> 1, Y >> 1, Z >> 1)]; };
-		for (int c = t; c < 512; c += 256) {
-			const uint8_t a = L.abits[base + c];
-			S.ab[c] = a;
-			S.bb[c] = L.b[base + c];
-			real v = L.x[base + c];
-			if (a & AB_UNKNOWN) v += corr(tx * 8 + (c & 7), ty * 8 + ((c >> 3) & 7), tz * 8 + (c >> 6));
-			S.H[cp_hi(c)] = v;
+		// the corrections come from the parent tile and from the parents of the active neighbour tiles
+		if (t < 7) {
+			const int src = S.nb[t];  // six neighbour tiles, then the tile itself
+			int d = -1;
+			if (src >= 0) {
+				int sx, sy, sz;
+				tile_coords(L.g, src, sx, sy, sz);
+				d = (sx >> 1) + gc.ntx * ((sy >> 1) + gc.nty * (sz >> 1));
+			}
+			dep[t] = d;
+		}
+		__syncthreads();
+		co_wait(P.ready[l + 1] + 2 * gc.nt, dep, 7, tag);
+		const real *e = P.lv[l + 1].y;
+		{
+			// cells z = 2 j and 2 j + 1 of a column share their parent
+			const real corr = MemAgent::ld(e + blocked_index(gc, (tx * 8 + qx) >> 1, (ty * 8 + qy) >> 1, (tz * 8 + 2 * qj) >> 1));
+			if (a0 & AB_UNKNOWN) S.H[h0] = S.H[h0] + corr;
+			if (a1 & AB_UNKNOWN) S.H[h1] = S.H[h1] + corr;
 		}
 		for (int r = t; r < 384; r += 256) {
 			int f, hidx, ncell, dx, dy, dz;
 			cp_ring(r, f, hidx, ncell, dx, dy, dz);
-			const int nb = nt[f];
-			real v = (real)0;
-			if (nb >= 0) {
-				const size_t j = (size_t)nb * 512 + ncell;
-				v = L.x[j];
-				if (L.abits[j] & AB_UNKNOWN) v += corr(tx * 8 + dx, ty * 8 + dy, tz * 8 + dz);
-			}
-			S.H[hidx] = v;
+			if (S.nb[f] >= 0 && (S.rab[r] & AB_UNKNOWN))
+				S.H[hidx] = S.H[hidx] + MemAgent::ld(e + blocked_index(gc, (tx * 8 + dx) >> 1, (ty * 8 + dy) >> 1, (tz * 8 + dz) >> 1));
 		}
 		__syncthreads();
-		for (int it = 0; it < inner; ++it) {
-			cp_half_sweep<real>(S, 1);
-			cp_half_sweep<real>(S, 0);
+		for (int it = 0; it < P.inner; ++it) {
+			half_sweep(S.H, a0, a1, b0, b1, 1);
+			half_sweep(S.H, a0, a1, b0, b1, 0);
 		}
-		for (int c = t; c < 512; c += 256) L.y[base + c] = S.H[cp_hi(c)];
-		__syncthreads();
+		MemAgent::st(L.y + base + c0, S.H[h0]);
+		MemAgent::st(L.y + base + c1, S.H[h1]);
+		if (l > P.first) co_post(P.ready[l] + 2 * L.g.nt, tile, tag);
+		stamp();
 	}
 }
 
@@ -986,12 +1338,23 @@ bool mg_dist(const lfa_sim *s) { return s->dist && (s->dist->nranks > 1 || geten
 void lfa_mg_free(lfa_sim *s) {
 	if (!s->mg) return;
 	for (auto &L : s->mg->lv) {
-		void *ptrs[] = {L.tiles, L.nbr, L.ctype, L.abits, L.x, L.b, L.y, L.flag, L.prev_flag};
+		void *ptrs[] = {L.tiles, L.nbr, L.ctype, L.abits, L.x, L.b, L.y, L.flag, L.prev_flag, L.ready};
 		for (void *p : ptrs)
 			if (p) (void)hipFree(p);
 	}
 	if (s->mg->l1_dirty) (void)hipFree(s->mg->l1_dirty);
 	if (s->mg->counts) (void)hipFree(s->mg->counts);
+	if (s->mg->co_stamps) {
+		unsigned long long h[3 * MG_CO_PHASES];
+		if (hipMemcpy(h, s->mg->co_stamps, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+			fprintf(stderr, "k_mg_coarse, workgroup 0 (us since launch: start, static data in, then the end of every phase: pre-smoothing and residual per level, coarsest, up per level), tiles per level:");
+			for (int l = 0; l < s->mg->n_levels; ++l) fprintf(stderr, " %d", s->mg->lv[l].n_tiles);
+			fprintf(stderr, "\n ");
+			for (int k = 0; k < s->mg->co_phases; ++k) fprintf(stderr, " %.2f", (h[k] - h[0]) / 100.0);
+			fprintf(stderr, "\n");
+		}
+		(void)hipFree(s->mg->co_stamps);
+	}
 	delete s->mg;
 	s->mg = nullptr;
 }
@@ -1018,7 +1381,7 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 	if (realloc_all) {
 		LFA_HIP(s, hipStreamSynchronize(s->stream));
 		for (auto &L : M.lv) {
-			void *ptrs[] = {L.tiles, L.nbr, L.ctype, L.abits, L.x, L.b, L.y, L.flag, L.prev_flag};
+			void *ptrs[] = {L.tiles, L.nbr, L.ctype, L.abits, L.x, L.b, L.y, L.flag, L.prev_flag, L.ready};
 			for (void *p : ptrs)
 				if (p) LFA_HIP(s, hipFree(p));
 			L = lfa_mg_level();
@@ -1052,6 +1415,8 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 			LFA_HIP(s, hipMalloc(&L.x, L.ncp * sizeof(real)));
 			LFA_HIP(s, hipMalloc(&L.b, L.ncp * sizeof(real)));
 			LFA_HIP(s, hipMalloc(&L.y, L.ncp * sizeof(real)));
+			LFA_HIP(s, hipMalloc(&L.ready, (size_t)3 * gs[l].nt * sizeof(unsigned)));
+			LFA_HIP(s, hipMemsetAsync(L.ready, 0, (size_t)3 * gs[l].nt * sizeof(unsigned), s->stream));
 			LFA_HIP(s, hipMemsetAsync(L.ctype, MT_SOLID, L.ncp, s->stream));
 			if (!dist) {  // the device path clears only what a departed tile leaves behind
 				LFA_HIP(s, hipMemsetAsync(L.x, 0, L.ncp * sizeof(real), s->stream));
@@ -1109,7 +1474,8 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 			L.n_tiles = l == 0 ? s->n_ptiles : (int)hc[l];
 			if (L.n_tiles) {
 				hipLaunchKernelGGL(k_mg_build_nbr, dim3((L.n_tiles + 255) / 256), dim3(256), 0, s->stream, (const int *)L.tiles, L.n_tiles,
-				                   gs[l], (const uint32_t *)L.flag, L.nbr);
+				                   gs[l], (const uint32_t *)L.flag, L.nbr, gs[l > 0 ? l - 1 : 0],
+				                   l > 0 ? (const uint32_t *)M.lv[l - 1].prev_flag : (const uint32_t *)nullptr);  // (already swapped: the current set)
 				LFA_LAUNCH_CHECK(s);
 			}
 			if (l >= 1) {
@@ -1201,6 +1567,15 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 						nbr[i * MG_NBR_STRIDE + k] = v;
 					}
 					nbr[i * MG_NBR_STRIDE + 6] = a[i];
+					int mask = 0;  // active child tiles (k_mg_coarse waits for their shares of this tile's right-hand side)
+					if (l > 0)
+						for (int k = 0; k < 8; ++k) {
+							const int cx = 2 * tx + (k & 1), cy = 2 * ty + ((k >> 1) & 1), cz = 2 * tz + (k >> 2);
+							if (cx < gs[l - 1].ntx && cy < gs[l - 1].nty && cz < gs[l - 1].ntz &&
+							    std::binary_search(act[l - 1].begin(), act[l - 1].end(), cx + gs[l - 1].ntx * (cy + gs[l - 1].nty * cz)))
+								mask |= 1 << k;
+						}
+					nbr[i * MG_NBR_STRIDE + 7] = mask;
 				}
 				LFA_HIP(s, hipMemcpyAsync(L.tiles, a.data(), a.size() * 4, hipMemcpyHostToDevice, s->stream));
 				LFA_HIP(s, hipMemcpyAsync(L.nbr, nbr.data(), nbr.size() * 4, hipMemcpyHostToDevice, s->stream));
@@ -1275,11 +1650,17 @@ int lfa_mg_setup(lfa_sim *s) {
 /// A s), result in vz. `level0_presmoothed`: vq already holds the pre-smoothed iterate (k_mg_axpy_presmooth).
 #define MG_TAIL_TILES 1  // levels with at most this many tiles run inside k_mg_tail: with the cell-parallel kernels for the small
                          // levels only the single-tile ones are worth keeping there (C2 / C4: 1.52 / 8.63 ms per step, 8: 1.55 / 8.69)
-#define MG_COARSEST_SWEEPS 4
+#define MG_COARSEST_SWEEPS 2  // measured (moving dam, C2 / C3 / C4): 4: 14.0 / 15.05 / 16.15 iterations, 3: 14.05 / 15.0 / 16.0, 2: 14.1 / 15.05 / 15.85 - and 8 fewer half sweeps of latency per V-cycle
+#define MG_CO_MAX_TILES 512  // levels of at most this many tiles run inside k_mg_coarse
 enum { MG_PART_PRE0 = 1, MG_PART_DOWN0 = 2, MG_PART_COARSE = 4, MG_PART_UP0 = 8, MG_PART_ALL = 15 };
 template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, bool level0_presmoothed, int parts = MG_PART_ALL) {
 	lfa_mg &M = *s->mg;
-	const int nl = M.n_levels, last = nl - 1;  // every level down to the single-tile one has active tiles
+	const int nl = M.n_levels;
+	int last = nl - 1;  // every level down to the single-tile one has active tiles
+	// LFA_MG_STOP_AT_SINGLE=1 (experiment): the first level with ONE active tile is the coarsest (its sweeps stand in for the levels below)
+	if (getenv("LFA_MG_STOP_AT_SINGLE") && !mg_dist(s))
+		for (int l = 1; l < last; ++l)
+			if (M.lv[l].n_tiles == 1) { last = l; break; }
 	auto lvl = [&](int l) {
 		const lfa_mg_level &L = M.lv[l];
 		return MgLv<real>{L.tiles, L.nbr, L.n_tiles, L.g, l == 0 ? (const uint8_t *)s->abits : (const uint8_t *)L.abits,
@@ -1302,6 +1683,30 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 	// levels >= D are replicated (identical work on every rank), so the tail workgroup may only hold replicated levels
 	const int D = mg_dist(s) ? M.n_dist : 0;
 	tail = std::max(tail, D);
+	// Default: every level of at most MG_CO_MAX_TILES tiles (C4: levels >= 2, C2: levels >= 1) runs inside ONE launch, k_mg_coarse
+	// (phases chained by completion counters instead of kernel boundaries); the larger ones keep a launch per phase.
+	int co_max = MG_CO_MAX_TILES;
+	if (const char *e = getenv("LFA_MG_CO_MAX_TILES")) co_max = atoi(e);
+	const bool persist = !getenv("LFA_MG_NO_PERSIST");
+	if (persist) {
+		// every workgroup of k_mg_coarse must be resident at the same time (they wait for each other): one workgroup per tile of
+		// its first level, LDS per workgroup grows with the number of levels inside
+		static int n_cu = 0;
+		if (!n_cu) {
+			int dev = 0;
+			hipDeviceProp_t prop;
+			n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+			           ? prop.multiProcessorCount : 256;
+		}
+		auto fits = [&](int first) {
+			const size_t lds = (size_t)(last - first + 1) * sizeof(CoLevel<real>) + 512 * sizeof(real) + 64;
+			const size_t per_cu = std::min<size_t>(8, (size_t)(160 * 1024) / lds);
+			return last - first + 1 <= MG_CO_MAX_LEVELS && M.lv[first].n_tiles <= co_max && (size_t)M.lv[first].n_tiles <= per_cu * (size_t)n_cu;
+		};
+		tail = last;
+		while (tail > 1 && tail - 1 >= D && fits(tail - 1)) --tail;
+		tail = std::max(tail, std::max(D, 1));
+	}
 	// cell-parallel kernels for levels of up to 1024 tiles (C4: levels 2 and 3; level 1 with 2048 tiles fills the chip with a
 	// wave per tile: 8.58 ms per step against 8.75 with cell-parallel kernels on every coarse level, 8.79 with none)
 	int cp_max = 1024;
@@ -1310,6 +1715,7 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		if (l == 0) return lfa_dist_exchange_slices(s, vec, (int)sizeof(real));
 		return lfa_dist_exchange_layer_slices(s, vec, (int)sizeof(real), M.lv[l].g.ntx * M.lv[l].g.nty, M.lv[l].lo_layer, M.lv[l].hi_layer);
 	};
+	int launches = 0;
 	for (int l = 0; l < tail; ++l) {
 		const MgLv<real> L = lvl(l);
 		const int G = mg_grid(L.n_tiles);
@@ -1318,6 +1724,7 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		if (!(l == 0 && level0_presmoothed) && (parts & (l == 0 ? MG_PART_PRE0 : MG_PART_COARSE))) {
 			if (cp) hipLaunchKernelGGL(k_mg_presmooth_cp<real>, dim3(Gcp), dim3(256), 0, s->stream, L, MG_INNER_SWEEPS, st);
 			else hipLaunchKernelGGL(k_mg_presmooth<real>, dim3(G), dim3(256), 0, s->stream, L, st);
+			++launches;
 		}
 		if (l < D) {
 			LFA_TRY(exchange_level(l, L.x));  // the residual needs the pre-smoothed iterate across the slab faces
@@ -1327,12 +1734,45 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		if (parts & (l == 0 ? MG_PART_DOWN0 : MG_PART_COARSE)) {
 			if (cp) hipLaunchKernelGGL(k_mg_residual_restrict_cp<real>, dim3(Gcp), dim3(256), 0, s->stream, L, M.lv[l + 1].g, (real *)M.lv[l + 1].b, st);
 			else hipLaunchKernelGGL(k_mg_residual_restrict<real>, dim3(G), dim3(256), 0, s->stream, L, M.lv[l + 1].g, (real *)M.lv[l + 1].b, st);
+			++launches;
 		}
 		LFA_LAUNCH_CHECK(s);
 		if (l < D && l + 1 == D)
 			LFA_TRY(s->dist->allreduce_buf(s, M.lv[D].b, M.lv[D].ncp, sizeof(real) == 4 ? LFA_RED_F32 : LFA_RED_F64, false));
 	}
-	if (parts & MG_PART_COARSE) {
+	if ((parts & MG_PART_COARSE) && persist) {
+		MgCo<real> C;
+		for (int l = tail; l <= last; ++l) C.lv[l] = lvl(l);
+		C.first = tail;
+		C.last = last;
+		C.nsw = MG_COARSEST_SWEEPS;
+		C.inner = MG_INNER_SWEEPS;
+		if (const char *e = getenv("LFA_MG_TAIL_INNER")) C.inner = std::max(1, atoi(e));
+		if (const char *e = getenv("LFA_MG_NSW")) C.nsw = std::max(1, atoi(e));
+		for (int l = tail; l <= last; ++l) C.ready[l] = M.lv[l].ready;
+		C.tag = ++M.co_tag;
+		if (C.tag == 0) C.tag = ++M.co_tag;  // (0 is what the flags are initialised to)
+		C.stamps = nullptr;
+		if (getenv("LFA_MG_CO_STAMPS")) {
+			if (!M.co_stamps) {
+				LFA_HIP(s, hipMalloc(&M.co_stamps, 3 * MG_CO_PHASES * 8));
+				LFA_HIP(s, hipMemsetAsync(M.co_stamps, 0, 3 * MG_CO_PHASES * 8, s->stream));
+			}
+			C.stamps = M.co_stamps;
+			M.co_phases = 3 * (last - tail) + 3;
+		}
+		// one workgroup per tile of its first level: every workgroup owns one tile slot on every level it reaches
+		const int W = std::max(1, M.lv[tail].n_tiles);
+		const size_t lds = (size_t)(last - tail + 1) * sizeof(CoLevel<real>) + 512 * sizeof(real);
+		static bool attr_set = false;
+		if (!attr_set) {
+			LFA_HIP(s, hipFuncSetAttribute((const void *)k_mg_coarse<real>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+			attr_set = true;
+		}
+		hipLaunchKernelGGL(k_mg_coarse<real>, dim3(W), dim3(256), lds, s->stream, C, st);
+		LFA_LAUNCH_CHECK(s);
+		++launches;
+	} else if (parts & MG_PART_COARSE) {
 		MgTail<real> T;
 		for (int l = tail; l <= last; ++l) T.lv[l] = lvl(l);
 		T.first = tail;
@@ -1347,6 +1787,7 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		if (const char *e = getenv("LFA_MG_NSW")) T.nsw = std::max(1, atoi(e));
 		hipLaunchKernelGGL(k_mg_tail<real>, dim3(1), dim3(MG_TAIL_WAVES * 64), 0, s->stream, T, st);
 		LFA_LAUNCH_CHECK(s);
+		++launches;
 	}
 	for (int l = tail - 1; l >= 0; --l) {
 		const MgLv<real> L = lvl(l);
@@ -1362,10 +1803,21 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 			hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, false>), dim3(G), dim3(256), 0, s->stream, L, M.lv[l + 1].g,
 			                   (const real *)M.lv[l + 1].y, (real)1, (double *)nullptr, st);
 		LFA_LAUNCH_CHECK(s);
+		++launches;
 		// the finer level corrects its ring cells across a slab face with this level's result there
 		if (l >= 1 && l < D) LFA_TRY(exchange_level(l, L.y));
 	}
+	if (parts == MG_PART_ALL) {
+		M.launches_per_cycle = launches + (level0_presmoothed ? 1 : 0);
+		M.first_co = persist ? tail : 0;
+	}
 	return LFA_OK;
+}
+
+void lfa_mg_stats(const lfa_sim *s, uint64_t *launches_per_cycle, uint64_t *levels, uint64_t *first_co) {
+	*launches_per_cycle = s->mg ? (uint64_t)s->mg->launches_per_cycle : 0;
+	*levels = s->mg ? (uint64_t)s->mg->n_levels : 0;
+	*first_co = s->mg ? (uint64_t)s->mg->first_co : 0;
 }
 
 int lfa_mg_apply(lfa_sim *s, double *part_sigma) {

@@ -835,7 +835,9 @@ __global__ void k_source_seed(const uint32_t *cell, const uint32_t *src_of, cons
 		p.key[d] = b;
 #pragma unroll
 		for (int a = 0; a < 3; ++a) {
-			const uint64_t r = mix64(seed + ((uint64_t)b * 4096ull + (uint64_t)j * 3ull + (uint64_t)a + 1ull) * 0x9E3779B97F4A7C15ull);
+			// the generator is keyed on the particle's own slot d (unique over every entry of a call, so two entries that top up
+			// the same cell never create coincident particles, and no (cell, j) window can alias a neighbouring cell's)
+			const uint64_t r = mix64(seed + ((uint64_t)d * 3ull + (uint64_t)a + 1ull) * 0x9E3779B97F4A7C15ull + ((uint64_t)b << 40));
 			float t = (float)(r >> 40) * (1.0f / 16777216.0f);  // 24 random bits: [0, 1)
 			p.t[a][d] = t;
 			p.v[a][d] = vel[a];
@@ -919,15 +921,21 @@ int lfa_sources_sync(lfa_sim *s) {
 	LFA_HIP(s, hipStreamSynchronize(s->stream));
 	const size_t n = cell.size(), need = std::max(n, ccell.size());
 	if (need > s->src_cap) {
-		void *old[] = {s->src_cell, s->src_lo, s->src_target, s->src_of, s->src_need};
-		for (void *q : old)
-			if (q) LFA_HIP(s, hipFree(q));
-		s->src_cap = need + need / 2 + 64;
-		LFA_HIP(s, hipMalloc(&s->src_cell, s->src_cap * 4));
-		LFA_HIP(s, hipMalloc(&s->src_lo, s->src_cap * 4));
-		LFA_HIP(s, hipMalloc(&s->src_target, s->src_cap * 4));
-		LFA_HIP(s, hipMalloc(&s->src_of, s->src_cap * 4));
-		LFA_HIP(s, hipMalloc(&s->src_need, 2 * (s->src_cap + 1) * 4));  // counts | their exclusive scan
+		// the old arrays are dropped first and the handle never keeps a dangling pointer: a failing hipMalloc leaves nulls and a
+		// capacity of 0 behind (lfa_destroy frees what is non-null, the next sync allocates again)
+		uint32_t **arr[] = {&s->src_cell, &s->src_lo, &s->src_target, &s->src_of, &s->src_need};
+		s->src_cap = 0;
+		for (uint32_t **q : arr) {
+			if (*q) (void)hipFree(*q);
+			*q = nullptr;
+		}
+		const size_t cap = need + need / 2 + 64;
+		LFA_HIP(s, hipMalloc(&s->src_cell, cap * 4));
+		LFA_HIP(s, hipMalloc(&s->src_lo, cap * 4));
+		LFA_HIP(s, hipMalloc(&s->src_target, cap * 4));
+		LFA_HIP(s, hipMalloc(&s->src_of, cap * 4));
+		LFA_HIP(s, hipMalloc(&s->src_need, 2 * (cap + 1) * 4));  // counts | their exclusive scan
+		s->src_cap = cap;
 	}
 	if (s->src_vel) LFA_HIP(s, hipFree(s->src_vel));
 	s->src_vel = nullptr;
@@ -1145,7 +1153,8 @@ static int correct_begin(lfa_sim *s, double dt, bool slab_exchanged) {
 		return lfa_fail(s, LFA_E_UNSUPPORTED, "lfa_correct_collide_begin: slab decompositions exchange particles inside the correction (use lfa_correct_collide or lfa_time_step)");
 	LFA_HIP(s, hipSetDevice(s->device));
 	LFA_TRY(lfa_corr_commit(s));
-	if (!s->np_live && !s->dist) return LFA_OK;
+	s->corr_begun = false;
+	if (!s->np_live && !s->dist) return LFA_OK;  // nothing to correct: _end and _undo are no-ops
 	LFA_HIP(s, hipEventRecord(s->ev_cfork, s->stream));
 	LFA_HIP(s, hipStreamWaitEvent(s->stream3, s->ev_cfork, 0));
 	hipStream_t main_stream = s->stream;
@@ -1157,6 +1166,7 @@ static int correct_begin(lfa_sim *s, double dt, bool slab_exchanged) {
 	// the join event is recorded whatever happened: the main stream waits for it before it touches particles again
 	const hipError_t e2 = hipEventRecord(s->ev_cjoin, s->stream3);
 	s->corr_in_flight = true;
+	s->corr_begun = true;
 	s->corr_undo_valid = rc == LFA_OK && !s->dist;
 	if (rc < 0) return rc;
 	LFA_HIP(s, e1);
@@ -1190,9 +1200,15 @@ k_correct_undo(size_t n, const float4 *spos, const uint32_t *old_key, uint32_t *
 
 extern "C" int lfa_correct_collide_undo(lfa_sim *s) {
 	if (!s) return LFA_E_INVALID;
-	if (!s->corr_in_flight) return lfa_fail(s, LFA_E_INVALID, "lfa_correct_collide_undo: no correction between lfa_correct_collide_begin and _end");
+	// What decides is whether the correction's inputs are still there (corr_undo_valid), not whether it is still running: entry
+	// points that only read (lfa_cfl, lfa_upload_cells of a grid-editing callback, lfa_get_correction_stats, the mesher) join it
+	// without invalidating anything, and a begin that found no particles started nothing.
+	if (!s->corr_begun) return LFA_OK;
+	if (!s->corr_undo_valid)
+		return lfa_fail(s, LFA_E_INVALID, "lfa_correct_collide_undo: positions, binning or solid cells have changed since lfa_correct_collide_begin");
 	LFA_HIP(s, hipSetDevice(s->device));
-	LFA_TRY(lfa_corr_commit(s));
+	LFA_TRY(lfa_corr_commit(s));  // joins if still in flight; the restore below is the change that invalidates a second undo
+	s->corr_begun = false;
 	const size_t n = s->np_live;
 	if (!n) return LFA_OK;
 	ParticleSoA &cur = s->pb[s->cur], &oth = s->pb[s->cur ^ 1];

@@ -28,3 +28,4 @@ int lfa_mg_axpy_apply(lfa_sim *s, const void *sdir, const double *part_sigma, in
                       double *part_rmax, double *part_sigma_new);
 int lfa_mg_bench_part(lfa_sim *s, int part);
 void lfa_mg_free(lfa_sim *s);
+void lfa_mg_stats(const lfa_sim *s, uint64_t *launches_per_cycle, uint64_t *levels, uint64_t *first_co);

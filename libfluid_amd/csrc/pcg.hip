@@ -1683,6 +1683,8 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 	// still cost their launches (~40 us each). The count barely changes from step to step, so the first chunk is as long
 	// as the previous solve, the following ones short. (Identical on every rank of a slab run: the scalars are all-reduced.)
 	const int first_chunk = s->last_iters > 0 ? (int)std::min<uint64_t>(s->last_iters, 4096) : 8;
+	const uint64_t calls_at_start = s->dist ? s->dist->calls : 0;
+	s->stat_launches_iter = s->stat_transport_iter = s->stat_transport_solve = s->stat_mg_levels = s->stat_mg_first_co = 0;
 	s->last_residual = 0.0;
 	s->last_iters = 0;
 	if (residual) *residual = 0.0;
@@ -1726,7 +1728,7 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 		hipLaunchKernelGGL((k_warm_residual<real, false>), dim3(G), dim3(256), 0, s->stream, tc, v.r, (const real *)v.q, v.p);
 		LFA_LAUNCH_CHECK(s);
 	}
-	s->pressure_epoch = s->solve_epoch;  // whatever comes out of this solve is the guess of the next one
+	s->pressure_epoch = 0;  // set to this solve's epoch once it has converged: a NaN or a capped solve is no guess for the next one
 	const int NS = sigma_parts(s);
 	// where the consumers find a reduced scalar: the per-workgroup partials (they re-add them in a fixed order), or -
 	// with slabs - the all-reduced value
@@ -1764,6 +1766,7 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 		const int end = std::min(maxit, i + (i == 0 ? first_chunk : chunk));
 		for (; i < end; ++i) {
 			const int po = i & 1, pn = po ^ 1;
+			const uint64_t calls0 = dist ? s->dist->calls : 0;
 			// where a kernel finds the scalars of the previous one: per-workgroup partials (the application before the loop
 			// wrote NS sigma partials, k_pcg_b writes NSB), or - with slabs - the all-reduced values
 			// slabs: sigma_k (k >= 1) and the signed max of the residual it belongs to arrive together, one value per rank
@@ -1823,6 +1826,12 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 				}
 			}
 			if (dist) LFA_TRY(lfa_dist_gather_pair(s, P + PART_RMAX, GB, sig_new_part, NSB, pn));  // one collective for both
+			if (i == 0) {  // lfa_get_solver_stats: every iteration issues the same launches and transport calls
+				s->stat_transport_iter = dist ? s->dist->calls - calls0 : 0;
+				uint64_t mgl = 0;
+				if (is_mg(s)) lfa_mg_stats(s, &mgl, &s->stat_mg_levels, &s->stat_mg_first_co);
+				s->stat_launches_iter = 1 + (dist ? (g_face_lo > 0) + (g_face_hi > 0) : 0) + (is_mg(s) ? mgl : 1);
+			}
 		}
 		// the residual of the last iteration of the chunk is tested here (k_pcg_a tests the one before it)
 		hipLaunchKernelGGL(k_check_converged, dim3(1), dim3(256), 0, s->stream,
@@ -1872,10 +1881,20 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 	}
 	s->last_residual = res;
 	s->last_iters = (uint64_t)iters;
+	s->stat_transport_solve = s->dist ? s->dist->calls - calls_at_start : 0;
 	if (residual) *residual = res;
 	if (iterations) *iterations = (uint64_t)iters;
 	if (nan) return lfa_fail(s, LFA_E_NAN, "NaN in the PCG residual at iteration %d", iters);
+	if (done >= 0) s->pressure_epoch = s->solve_epoch;
 	return done >= 0 ? LFA_OK : LFA_W_PCG_NOT_CONVERGED;
+}
+
+extern "C" int lfa_get_solver_stats(lfa_sim *s, uint64_t stats[LFA_NUM_SOLVER_STATS]) {
+	if (!s || !stats) return LFA_E_INVALID;
+	const uint64_t v[LFA_NUM_SOLVER_STATS] = {s->stat_launches_iter, s->stat_transport_iter, s->stat_mg_levels, s->stat_mg_first_co,
+	                                          s->last_iters, s->stat_transport_solve, 0, 0};
+	for (int i = 0; i < LFA_NUM_SOLVER_STATS; ++i) stats[i] = v[i];
+	return LFA_OK;
 }
 
 extern "C" int lfa_pcg_solve(lfa_sim *s, double dt, double *residual, uint64_t *iterations) {
@@ -1939,6 +1958,7 @@ extern "C" int lfa_download_pressure(lfa_sim *s, double *p, uint64_t n) {
 }
 extern "C" int lfa_upload_pressure(lfa_sim *s, const double *p, uint64_t n) {
 	NEED_SYSTEM(s);
+	s->pressure_epoch = 0;  // a pressure the host put there is not the previous solve's: the next solve starts from p = 0
 	return F64(s) ? scatter<double>(s, (double *)s->vp, p, n) : scatter<float>(s, (float *)s->vp, p, n);
 }
 

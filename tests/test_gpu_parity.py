@@ -462,6 +462,7 @@ def test_multigrid_cell_parallel_variants_are_bitwise_the_wave_per_tile_code(dty
     pressures. The grid is ragged and large enough for three levels of several tiles with neighbours on every side."""
     size, block = (136, 72, 104), ((0, 0, 0), (90, 50, 70))
     res = []
+    monkeypatch.setenv("LFA_MG_NO_PERSIST", "1")  # the launch-per-phase path is what these switches select variants of
     for no_chain in (False, True):
         monkeypatch.setenv("LFA_MG_CP_MAX_TILES", "1000000")  # cell-parallel kernels on every coarse level
         if no_chain:
@@ -501,3 +502,54 @@ def test_pcg_warm_start_converges_to_the_same_pressure_in_fewer_iterations():
     assert itc >= it0 - 1
     util.assert_close(p1, pc, P_REL, "warm-started pressure")
     s.close(); t.close()
+
+
+@pytest.mark.parametrize("dtype", [lfa.PCG_F32, lfa.PCG_F64])
+@pytest.mark.parametrize("co_max", [None, 1000000, 40, 4, 1])
+def test_multigrid_single_launch_coarse_levels_are_bitwise_the_launch_per_phase_path(dtype, co_max, monkeypatch):
+    """k_mg_coarse runs every phase of the coarse levels (pre-smoothing, residual + restriction, coarsest solve, prolongation +
+    post-smoothing) inside one launch as dataflow between workgroups: one tile per workgroup and level, resident in LDS, ready
+    flags tagged with the launch number, the level arrays accessed with agent-scope atomics. Same arithmetic per cell as the
+    launch-per-phase kernels (LFA_MG_NO_PERSIST=1): identical iteration counts, bit-identical pressures - for the default level
+    split, with every level below the finest inside the launch (as many as fit the chip), and with only the deepest ones."""
+    size, block = (136, 72, 104), ((0, 0, 0), (90, 50, 70))
+    res = []
+    for persist in (True, False):
+        monkeypatch.setenv("LFA_MG_CP_MAX_TILES", "1000000")
+        for k, v in (("LFA_MG_CO_MAX_TILES", co_max),):
+            if v is None or not persist:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, str(v))
+        if persist:
+            monkeypatch.delenv("LFA_MG_NO_PERSIST", raising=False)
+        else:
+            monkeypatch.setenv("LFA_MG_NO_PERSIST", "1")
+        s = lfa.Sim(size, precond=lfa.PRECOND_MULTIGRID, pcg_dtype=dtype)
+        s.seed_block(*block)
+        its = []
+        for _ in range(3):
+            r, it, rc = s.step_hot(util.DT)
+            assert rc == 0
+            its.append(it)
+        res.append((its, s.pressure().copy()))
+        s.close()
+    assert res[0][0] == res[1][0]
+    assert np.array_equal(res[0][1], res[1][1])
+
+
+def test_multigrid_single_launch_coarse_levels_repeat_bitwise_over_many_solves():
+    """The hand-off between the phases of k_mg_coarse is a race if it is wrong: 40 solves of the same system must all return the
+    same bits."""
+    s = lfa.Sim((96, 64, 80), precond=lfa.PRECOND_MULTIGRID)
+    s.seed_block((0, 0, 0), (60, 40, 50))
+    r, it0, rc = s.step_hot(util.DT)
+    assert rc == 0
+    ref = None
+    for _ in range(40):
+        p, r, it, rc = s.solve(util.DT)
+        assert rc == 0
+        if ref is None:
+            ref = (it, p)
+        assert it == ref[0] and np.array_equal(p, ref[1])
+    s.close()
