@@ -58,8 +58,37 @@ def cpu_baseline(sample, steps, lfa):
         iters += it
         its.append(int(it))
     dt = time.perf_counter() - t0
+    # The headline metric is the FULL simulation::time_step (SURVEY 8(d) metric (1)): the reference's own, advection, collisions
+    # and position correction included (its OpenMP regions, src/simulation.cpp:226-249,562-683, use the threads named below;
+    # P2G / PCG / G2P are serial), on the state the hot-path steps above have produced, dt = min(3 cfl, 0.033).
+    full = None
+    if sim.L.time_step is not None:
+        import ctypes as C
+        n_full, its_full = max(1, steps), []
+        tf = time.perf_counter()
+        for _ in range(n_full):
+            it = C.c_uint64(0)
+            sim.L.time_step(sim.h, min(3.0 * sim.cfl(), 0.033), None, C.byref(it))
+            its_full.append(int(it.value))
+        df = time.perf_counter() - tf
+        full = {"value": len(parts) * n_full / df, "unit": "particle-steps/s", "steps": n_full, "seconds": df,
+                "pcg_iterations": its_full,
+                "what": "simulation::time_step (src/simulation.cpp:43-125) incl. cfl(), advection, collisions, position correction"}
+    cpu_model = "?"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
     out = {
         "value": len(parts) * steps / dt, "unit": "particle-steps/s", "cores": 1,
+        "host": {"cpu_model": cpu_model, "nproc": os.cpu_count(), "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS"),
+                 "omp_threads_in_parallel_regions": threads if kind == "ref" else 1},
+        "full_time_step": full,
         "kind": "reference" if kind == "ref" else "port",
         "sample": f"{sample}: {cfg['size'][0]}^3 grid, {len(parts)} particles, {steps} hot-path steps, "
                   f"{iters} PCG iterations, {dt:.1f} s; "
@@ -116,6 +145,9 @@ def main():
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent copies of the domain instead of z-slabs")
     ap.add_argument("--force-slabs", action="store_true", help="run the z-slab code path (RCCL communicator, halo calls, global CFL "
                     "reduction) even with one rank: the only way to exercise it end to end on a 1-GPU box")
+    ap.add_argument("--late", type=int, default=0, help="after everything else: run on to step N of the dam break (untimed), then time "
+                    "`--late-steps` full steps there and report them as `late_phase` (the fluid has spread over many partly filled tiles)")
+    ap.add_argument("--late-steps", type=int, default=20)
     ap.add_argument("--strong", action="store_true", help="N > 1: the FIXED BASELINE domain (configs[3]/[4]) split into N z-slabs "
                     "instead of a domain that grows with N")
     args = ap.parse_args()
@@ -290,6 +322,7 @@ def main():
             "iters_per_sec": iters_total / pcg_s if pcg_s > 0 else None,
             "unknown_iters_per_sec": n_unknowns * iters_total / pcg_s if pcg_s > 0 else None,
             "steps_hitting_max_iterations": not_converged,
+            "solver_stats_last_solve": sim.solver_stats(),
             "note": "iterations of the preconditioner named in config.precond; the reference-comparable MIC(0) figure is "
                     "`--precond multilevel` (same iteration counts as the reference's MIC(0)-PCG within a few per cent)",
         },
@@ -313,7 +346,8 @@ def main():
         # ---- measured HBM ceiling of this device ("report both")
         copy_gbs, read_gbs = sim.bench_stream(1 << 30, 10)
         out["hbm_ceiling_measured"] = {"device_copy_GBps": copy_gbs, "read_only_GBps": read_gbs, "spec_peak_GBps": HBM_PEAK_GBS,
-                                       "how": "lfa_bench_stream: float4 grid-stride kernels over 1 GiB, mean of 10 launches"}
+                                       "how": "lfa_bench_stream: float4 grid-stride kernels over 1 GiB, mean of 10 launches, best of 5 copy "
+                                              "variants (" + getattr(sim, "stream_variant", "") + "); MI355X_MICROARCH.md records 6.29 TB/s for a float4 copy"}
         # ---- in-step kernels / kernel groups: MEDIAN device time inside the timed steps (HIP events on the handle's stream)
         # algorithmic bytes: SURVEY 8(d). P2G scatter 60 Np (APIC) / 24 Np; PCG iteration 91 n (92.5 n for the V-cycle's own
         # passes); G2P 60 Np + 12 Nc (APIC), 36 Np + 24 Nc (FLIP), 24 Np + 12 Nc (PIC); binning: the bytes the deferred scheme
@@ -327,7 +361,7 @@ def main():
             "g2p": ((60 if apic else (36 if flip else 24)) * npart + (24 if flip else 12) * ncell_proc, 1.0),
             "bin": ((44 if apic else 116) * npart, 1.0),
             "correct_tiled_kernel": (24 * npart, 1.0),
-            "advect_collide": (32 * npart, 1.0),
+            "advect_collide": (44 * npart, 1.0),  # reads key, t, v (28 B), writes key, t (16 B)
         }
         kern = {}
         for k, (b, mult) in in_step.items():
@@ -336,7 +370,11 @@ def main():
                 kern[k] = {"ms_median": ms, "ms_p95": stage_p95[k], "algorithmic_bytes": int(b), "GBps": b / ms * 1e-6,
                            "frac": b / ms * 1e-6 / HBM_PEAK_GBS, "share_of_step_ms": ms * mult}
         out["in_step_kernels"] = kern
-        pmc = os.path.join(ROOT, "profiles", "r02_c4_pmc_traffic.json")
+        # `traffic`: HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs of this same command,
+        # tools/make_profiles.sh). It is NOT measured in this run: `traffic_source` names the committed file it is read from.
+        pmc = os.path.join(ROOT, "profiles", "r03_c4_pmc_traffic.json")
+        if not os.path.exists(pmc):
+            pmc = os.path.join(ROOT, "profiles", "r02_c4_pmc_traffic.json")
         pmc_names = {"p2g_scatter_kernel": "p2g_scatter", "correct_tiled_kernel": "correct_tiled", "g2p": "g2p",
                      "advect_collide": "advect_collide"}
         per_launch = {}
@@ -346,6 +384,8 @@ def main():
         def roofline_of(k, note):
             return {"bound": "hbm", "kernel": k, "achieved": kern[k]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": kern[k]["frac"], "traffic": per_launch.get(pmc_names.get(k, ""), {}).get("total"),
+                    "traffic_source": (os.path.relpath(pmc, ROOT) + " (rocprofv3 --pmc passes of the same command, not this run)")
+                                      if per_launch.get(pmc_names.get(k, "")) else None,
                     "algorithmic_bytes": kern[k]["algorithmic_bytes"], "ms": kern[k]["ms_median"],
                     "share_of_step_ms": kern[k]["share_of_step_ms"], "note": note}
         # `roofline`: the dominant single kernel of the HOT PATH (binning, P2G, PCG, G2P - the path north_star
@@ -430,6 +470,39 @@ def main():
                            "algorithmic_GBps": 91 * n_unknowns * sum(its) / (sum(ms) * 1e-3) * 1e-9 if sum(ms) > 0 else None,
                            "note": "91 n bytes per iteration (SURVEY 8d); the reference does 58 MIC(0) iterations at C2 where this does 77"}
         sim.set_params(precond=lfa.PRECOND_MULTIGRID)
+    if args.late > 0:
+        # A second timed window late in the run: the sheet has spread, tiles are partly filled, the solve has more of them to visit
+        # and the position correction meets crowded blocks where the fluid has piled up. Same step, same accounting.
+        done_steps = preroll + args.warmup + args.steps * (2 if (overlapped and not args.no_serial_stages) else 1)
+        while done_steps < args.late:
+            one_step()
+            done_steps += 1
+        barrier()
+        tl = time.perf_counter()
+        late_it, late_stage = 0, []
+        for _ in range(args.late_steps):
+            _, it, _ = one_step()
+            late_it += it
+            late_stage.append(sim.step_timings())
+        barrier()
+        late_s = time.perf_counter() - tl
+        if dist is not None:
+            t = torch.tensor([late_s], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            late_s = float(t.item())
+        lc, lf = sim.counts(), sim.correction_stats()
+        late_names = [k for k in late_stage[0] if k not in ("pcg_iterations", "overlapped")]
+        extras["late_phase"] = {
+            "from_step": done_steps, "steps": args.late_steps, "ms_per_step": 1e3 * late_s / args.late_steps,
+            "ratio_to_timed_region": (late_s / args.late_steps) / (elapsed / args.steps),
+            "particle_steps_per_sec": lc["particles"] * args.late_steps / late_s,
+            "pcg_iterations_per_step": late_it / args.late_steps,
+            "particle_tiles": lc["particle_tiles"], "processed_tiles": lc["processed_tiles"], "unknowns": lc["unknowns"],
+            "particles_per_particle_tile": lc["particles"] / max(lc["particle_tiles"], 1),
+            "particle_tiles_timed_region": counts["particle_tiles"], "processed_tiles_timed_region": counts["processed_tiles"],
+            "correction_fallback_half_tiles": {"flagged": lf[0], "of": lf[1]},
+            "stage_ms_median": {k: med([s_[k] for s_ in late_stage]) for k in late_names},
+        }
     if args.mesh and (world == 1 or slabs):
         # BASELINE configs[4]: the surface of the resident particles (mesher settings of testbed/main.cpp:101-107 at cell size 1).
         # On slabs every rank meshes its own cell layers (lfa_mesher_create_window) from its own particles and the ghost copies of

@@ -388,6 +388,8 @@ int lfa_bench_kernel(lfa_sim *s, int which, int reps, double *mean_ms);
 /* Measured HBM ceilings of this device beside the 8 TB/s spec peak (SURVEY.md 8d "report both"): a float4 grid-stride device
  * copy of `bytes` (read + write counted) and a read-only pass over the same buffer, GB/s, mean of `reps` launches. */
 int lfa_bench_stream(lfa_sim *s, uint64_t bytes, int reps, double *copy_gbs, double *read_gbs);
+/* Which copy kernel gave the figure of the last lfa_bench_stream (a static string; "" before the first call). */
+const char *lfa_bench_stream_variant(void);
 
 #ifdef __cplusplus
 }

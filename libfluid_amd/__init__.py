@@ -110,6 +110,7 @@ SIGNATURES = {
     "lfa_get_counts": (_int, [_vp, C.POINTER(_u64 * 5)]),
     "lfa_bench_kernel": (_int, [_vp, _int, _int, C.POINTER(_dbl)]),
     "lfa_bench_stream": (_int, [_vp, _u64, _int, C.POINTER(_dbl), C.POINTER(_dbl)]),
+    "lfa_bench_stream_variant": (C.c_char_p, []),
     "lfa_voxels_create": (_int, [C.POINTER(_vp), _vp, _vp, _dbl, _int]),
     "lfa_voxels_destroy": (None, [_vp]),
     "lfa_voxels_last_error": (C.c_char_p, [_vp]),
@@ -671,6 +672,7 @@ class Sim:
         """(device-copy GB/s, read-only GB/s) measured on this device."""
         c, r = C.c_double(0.0), C.c_double(0.0)
         self._chk(self.lib.lfa_bench_stream(self.h, int(nbytes), int(reps), C.byref(c), C.byref(r)))
+        self.stream_variant = self.lib.lfa_bench_stream_variant().decode()
         return c.value, r.value
 
     def solver_stats(self):

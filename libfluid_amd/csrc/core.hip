@@ -1174,16 +1174,65 @@ extern "C" int lfa_cfl(lfa_sim *s, double *out) {
 }
 
 // =============================================================================================== measured HBM ceiling
+// The copy is what the step's streaming kernels are compared with, so it must be a good copy: several independent 16-byte loads
+// in flight per thread (a one-load-per-iteration grid-stride loop reached 4.6 TB/s where MI355X_MICROARCH.md records 6.29 for a
+// float4 copy), optionally non-temporal stores (the destination is not read again). The best variant is reported, with its name.
+template <int U, bool NT>
 __global__ void __launch_bounds__(256) k_stream_copy(const float4 *in, float4 *out, size_t n) {
-	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = in[i];
+	const size_t chunk = (size_t)256 * U;
+	for (size_t base = (size_t)blockIdx.x * chunk; base < n; base += (size_t)gridDim.x * chunk) {
+		float4 v[U];
+#pragma unroll
+		for (int k = 0; k < U; ++k) {
+			const size_t i = base + (size_t)k * 256 + threadIdx.x;
+			if (i < n) {
+				if (NT) {
+					typedef float f4v __attribute__((ext_vector_type(4)));
+					const f4v w = __builtin_nontemporal_load((const f4v *)in + i);
+					v[k] = make_float4(w.x, w.y, w.z, w.w);
+				} else {
+					v[k] = in[i];
+				}
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < U; ++k) {
+			const size_t i = base + (size_t)k * 256 + threadIdx.x;
+			if (i < n) {
+				if (NT) {
+					typedef float f4v __attribute__((ext_vector_type(4)));
+					f4v w;
+					w.x = v[k].x; w.y = v[k].y; w.z = v[k].z; w.w = v[k].w;
+					__builtin_nontemporal_store(w, (f4v *)out + i);
+				} else {
+					out[i] = v[k];
+				}
+			}
+		}
+	}
 }
+template <int U>
 __global__ void __launch_bounds__(256) k_stream_read(const float4 *in, float *sink, size_t n) {
 	float acc = 0.f;
-	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-		const float4 v = in[i];
-		acc += (v.x + v.y) + (v.z + v.w);
+	const size_t chunk = (size_t)256 * U;
+	for (size_t base = (size_t)blockIdx.x * chunk; base < n; base += (size_t)gridDim.x * chunk) {
+		float4 v[U];
+#pragma unroll
+		for (int k = 0; k < U; ++k) {
+			const size_t i = base + (size_t)k * 256 + threadIdx.x;
+			v[k] = i < n ? in[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+		}
+#pragma unroll
+		for (int k = 0; k < U; ++k) acc += (v[k].x + v[k].y) + (v[k].z + v[k].w);
 	}
 	if (acc == 123.456f) sink[0] = acc;  // never true for the zero-filled buffer: keeps the loads alive
+}
+
+static int g_stream_best = -1;
+extern "C" const char *lfa_bench_stream_variant(void) {
+	static const char *names[] = {"1 x float4 per thread and iteration", "4 x float4 in flight", "4 x float4 in flight, non-temporal",
+	                              "8 x float4 in flight, non-temporal", "4 x float4 in flight, non-temporal, 32 workgroups per CU"};
+	return g_stream_best >= 0 ? names[g_stream_best] : "";
 }
 
 extern "C" int lfa_bench_stream(lfa_sim *s, uint64_t bytes, int reps, double *copy_gbs, double *read_gbs) {
@@ -1191,36 +1240,54 @@ extern "C" int lfa_bench_stream(lfa_sim *s, uint64_t bytes, int reps, double *co
 	LFA_HIP(s, hipSetDevice(s->device));
 	const size_t n = (size_t)bytes / 16;
 	float4 *a = nullptr, *b = nullptr;
-	if (hipMalloc((void **)&a, n * 16) != hipSuccess || hipMalloc((void **)&b, n * 16) != hipSuccess) {
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	auto cleanup = [&]() {
+		if (e0) (void)hipEventDestroy(e0);
+		if (e1) (void)hipEventDestroy(e1);
 		if (a) (void)hipFree(a);
+		if (b) (void)hipFree(b);
+	};
+	if (hipMalloc((void **)&a, n * 16) != hipSuccess || hipMalloc((void **)&b, n * 16) != hipSuccess) {
+		cleanup();
 		return lfa_fail(s, LFA_E_OOM, "lfa_bench_stream: hipMalloc of 2 x %llu bytes failed", (unsigned long long)bytes);
 	}
-	hipEvent_t e0, e1;
-	LFA_HIP(s, hipEventCreate(&e0));
-	LFA_HIP(s, hipEventCreate(&e1));
-	LFA_HIP(s, hipMemsetAsync(a, 0, n * 16, s->stream));
-	LFA_HIP(s, hipMemsetAsync(b, 0, n * 16, s->stream));
-	const dim3 grid(256 * 16);  // 16 workgroups per CU, grid-stride
-	float ms = 0.f;
-	for (int pass = 0; pass < 2; ++pass) {
-		for (int r = -1; r < reps; ++r) {  // r == -1: warm-up
-			if (r == 0) LFA_HIP(s, hipEventRecord(e0, s->stream));
-			if (pass == 0) hipLaunchKernelGGL(k_stream_copy, grid, dim3(256), 0, s->stream, (const float4 *)a, b, n);
-			else hipLaunchKernelGGL(k_stream_read, grid, dim3(256), 0, s->stream, (const float4 *)a, (float *)b, n);
+	int rc = LFA_OK;
+	auto run = [&]() -> int {
+		LFA_HIP(s, hipEventCreate(&e0));
+		LFA_HIP(s, hipEventCreate(&e1));
+		LFA_HIP(s, hipMemsetAsync(a, 0, n * 16, s->stream));
+		LFA_HIP(s, hipMemsetAsync(b, 0, n * 16, s->stream));
+		float ms = 0.f;
+		double best_copy = 0.0, best_read = 0.0;
+		for (int variant = 0; variant < 7; ++variant) {  // 0-4: copies, 5-6: reads
+			const dim3 grid(256 * (variant == 4 ? 32 : 16));  // 16 (32) workgroups per CU, grid-stride over chunks
+			for (int r = -1; r < reps; ++r) {  // r == -1: warm-up
+				if (r == 0) LFA_HIP(s, hipEventRecord(e0, s->stream));
+				switch (variant) {
+				case 0: hipLaunchKernelGGL((k_stream_copy<1, false>), grid, dim3(256), 0, s->stream, (const float4 *)a, b, n); break;
+				case 1: hipLaunchKernelGGL((k_stream_copy<4, false>), grid, dim3(256), 0, s->stream, (const float4 *)a, b, n); break;
+				case 2: hipLaunchKernelGGL((k_stream_copy<4, true>), grid, dim3(256), 0, s->stream, (const float4 *)a, b, n); break;
+				case 3: hipLaunchKernelGGL((k_stream_copy<8, true>), grid, dim3(256), 0, s->stream, (const float4 *)a, b, n); break;
+				case 4: hipLaunchKernelGGL((k_stream_copy<4, true>), grid, dim3(256), 0, s->stream, (const float4 *)a, b, n); break;
+				case 5: hipLaunchKernelGGL(k_stream_read<1>, grid, dim3(256), 0, s->stream, (const float4 *)a, (float *)b, n); break;
+				default: hipLaunchKernelGGL(k_stream_read<4>, grid, dim3(256), 0, s->stream, (const float4 *)a, (float *)b, n); break;
+				}
+			}
+			LFA_LAUNCH_CHECK(s);
+			LFA_HIP(s, hipEventRecord(e1, s->stream));
+			LFA_HIP(s, hipEventSynchronize(e1));
+			LFA_HIP(s, hipEventElapsedTime(&ms, e0, e1));
+			const double gbs = (double)(n * 16) * reps * (variant < 5 ? 2.0 : 1.0) / ((double)ms * 1e-3) * 1e-9;
+			if (variant < 5 && gbs > best_copy) { best_copy = gbs; g_stream_best = variant; }
+			if (variant >= 5 && gbs > best_read) best_read = gbs;
 		}
-		LFA_LAUNCH_CHECK(s);
-		LFA_HIP(s, hipEventRecord(e1, s->stream));
-		LFA_HIP(s, hipEventSynchronize(e1));
-		LFA_HIP(s, hipEventElapsedTime(&ms, e0, e1));
-		const double gbs = (double)(n * 16) * reps * (pass == 0 ? 2.0 : 1.0) / ((double)ms * 1e-3) * 1e-9;
-		if (pass == 0 && copy_gbs) *copy_gbs = gbs;
-		if (pass == 1 && read_gbs) *read_gbs = gbs;
-	}
-	(void)hipEventDestroy(e0);
-	(void)hipEventDestroy(e1);
-	(void)hipFree(a);
-	(void)hipFree(b);
-	return LFA_OK;
+		if (copy_gbs) *copy_gbs = best_copy;
+		if (read_gbs) *read_gbs = best_read;
+		return LFA_OK;
+	};
+	rc = run();
+	cleanup();  // (also on an error path: events and buffers never outlive the call)
+	return rc;
 }
 
 // =============================================================================================== timing / counts

@@ -100,7 +100,8 @@ def test_device_advect_collide_and_correct_collide():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precond,dtype", [(lfa.PRECOND_MIC0_EXACT, lfa.PCG_F64), (lfa.PRECOND_MULTILEVEL, lfa.PCG_F32)])
+@pytest.mark.parametrize("precond,dtype", [(lfa.PRECOND_MIC0_EXACT, lfa.PCG_F64), (lfa.PRECOND_MULTILEVEL, lfa.PCG_F32),
+                                           (lfa.PRECOND_MULTIGRID, lfa.PCG_F32)])  # the last one is the default configuration
 def test_device_time_step_matches_reference(precond, dtype):
     """Three device-resident simulation::time_step(dt) against the real reference's particles (fullstep_flip.npz)."""
     c, parts, solid = fullstep_inputs()

@@ -24,10 +24,10 @@ def test_oracle_matches_live_reference(name):
 
 
 @pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not built (no /root/reference on this box)")
-def test_golden_files_are_reference_outputs():
-    """The committed fixtures are reproducible from the reference (guards against stale or hand-edited files)."""
-    for name in ("apic16", "apic_tank"):
-        util.assert_same_record(util.staged_cpu_run(name, "ref"), util.load_golden(name), 0.0, name)
+@pytest.mark.parametrize("name", sorted(util.CASES))
+def test_golden_files_are_reference_outputs(name):
+    """Every committed staged fixture is reproducible from the reference, bit for bit (guards against stale or hand-edited files)."""
+    util.assert_same_record(util.staged_cpu_run(name, "ref"), util.load_golden(name), 0.0, name)
 
 
 def test_hydrostatic_pressure_known_answer():
