@@ -94,6 +94,7 @@ struct lfa_sim {
 	double *dist_red = nullptr;             // all-reduced scalars
 	size_t np_live = 0;
 	bool holes = false;  // slabs: leavers were invalidated in place since the last binning
+	size_t arrivals_at = 0, n_arrivals = 0;  // slabs: particles received since the last binning sit at [arrivals_at, arrivals_at + n_arrivals)
 	size_t ghost_at[2] = {0, 0}, n_ghost_particles = 0;  // ghost particles (key, t only) behind the live ones
 
 	// tiles
@@ -354,7 +355,7 @@ int lfa_dist_allreduce(lfa_sim *s, const double *partials, int n, int slot, bool
 double *lfa_dist_gather_buf(lfa_sim *s, int parity);  // [max per rank | sum per rank] of the last lfa_dist_gather_pair
 int lfa_dist_gather_pair(lfa_sim *s, const double *pmax, int n_max, const double *psum, int n_sum, int parity);
 int lfa_dist_ensure_xbuf(lfa_sim *s, int which, size_t bytes);
-int lfa_dist_migrate(lfa_sim *s);
+int lfa_dist_migrate(lfa_sim *s, bool vc_dead = false);
 int lfa_dist_exchange_ghost_particles(lfa_sim *s);
 int lfa_particles_reserve(lfa_sim *s, size_t n_keep, size_t n_total);
 /// Orders the main stream behind a correction that lfa_correct_collide_begin has running on stream3; every entry point that

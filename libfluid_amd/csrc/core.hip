@@ -394,8 +394,8 @@ int lfa_particles_alloc(lfa_sim *s, size_t n) {
 /// Grows the particle arrays to hold n_total particles, keeping the first n_keep of the current buffer. On failure the
 /// resident particles stay where they are.
 int lfa_particles_reserve(lfa_sim *s, size_t n_keep, size_t n_total) {
-	LFA_TRY(lfa_particles_materialize(s));
-	if (n_total <= s->pcap) return LFA_OK;
+	if (n_total <= s->pcap) return LFA_OK;  // (a deferred binning stays deferred: nothing moves)
+	LFA_TRY(lfa_particles_materialize(s));  // the reallocation below keeps the current buffer only
 	LFA_HIP(s, hipStreamSynchronize(s->stream));
 	const size_t cap = ((n_total + n_total / 8) + 1023) & ~(size_t)1023;
 	ParticleSoA keep = s->pb[s->cur];
@@ -494,12 +494,24 @@ extern "C" int lfa_upload_particles(lfa_sim *s, const void *aos152, uint64_t n) 
 	return LFA_OK;
 }
 
-__global__ void k_export(double *aos, size_t n, ParticleSoA p, GridDims g, IngestParams ip, int flags, int by_slot) {
+/// Slabs after a hand-over: valid[i] = record i is a resident particle (not one that went to a neighbour rank); its exclusive
+/// scan is the record's slot in a download, so holes never reach the host - and no binning (a collective on slabs) is needed.
+__global__ void k_valid_flags(const uint32_t *key, size_t n, uint32_t *valid) {
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) valid[i] = key[i] != 0xFFFFFFFFu ? 1u : 0u;
+}
+__global__ void k_export_ids(const uint32_t *key, const uint32_t *id, const uint32_t *slot, size_t n, uint32_t *out) {
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n && key[i] != 0xFFFFFFFFu) out[slot ? slot[i] : i] = id[i];
+}
+
+__global__ void k_export(double *aos, size_t n, ParticleSoA p, GridDims g, IngestParams ip, int flags, int by_slot, const uint32_t *slot) {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	// slab decomposition: particles migrate between ranks, so a rank's records come out in storage order (ids separately)
-	double *q = aos + (by_slot ? i : (size_t)p.id[i]) * 19;
 	uint32_t b = p.key[i];
+	if (slot && b == 0xFFFFFFFFu) return;
+	// slab decomposition: particles migrate between ranks, so a rank's records come out in storage order (ids separately)
+	double *q = aos + (by_slot ? (slot ? (size_t)slot[i] : i) : (size_t)p.id[i]) * 19;
 	if (flags & LFA_DL_POSITIONS) {
 		int tile = (int)(b >> 9), l = (int)(b & 511), tx, ty, tz;
 		tile_coords(g, tile, tx, ty, tz);
@@ -518,16 +530,36 @@ __global__ void k_export(double *aos, size_t n, ParticleSoA p, GridDims g, Inges
 	if (!(flags & LFA_DL_KEEP_RAW)) ((uint64_t *)q)[18] = raw_from_blocked(g, b);
 }
 
+/// Slabs with holes (particles handed over since the last binning): *slot = device array mapping record i of [0, np_live) to its
+/// place among the resident ones (the binning's rank array, free between two binnings); nullptr when the records are dense.
+static int lfa_slab_download_slots(lfa_sim *s, const uint32_t **slot) {
+	*slot = nullptr;
+	if (!s->dist || !s->holes || !s->np_live) return LFA_OK;
+	hipLaunchKernelGGL(k_valid_flags, dim3((unsigned)((s->np_live + 255) / 256)), dim3(256), 0, s->stream, (const uint32_t *)s->pb[s->cur].key,
+	                   s->np_live, s->rank);
+	LFA_LAUNCH_CHECK(s);
+	uint32_t *tot = (uint32_t *)(s->pcg_state + 5);
+	LFA_TRY(lfa_exclusive_scan_u32(s, s->rank, s->rank, s->np_live, tot));
+	uint32_t h = 0;
+	LFA_HIP(s, hipMemcpyAsync(&h, tot, 4, hipMemcpyDeviceToHost, s->stream));
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	if ((size_t)h != s->np) return lfa_fail(s, LFA_E_INVALID, "slab download: %u resident records but %zu expected", h, s->np);
+	*slot = s->rank;
+	return LFA_OK;
+}
+
 extern "C" int lfa_download_particles(lfa_sim *s, void *aos152, uint64_t n, int flags) {
 	if (!s || (!aos152 && n)) return LFA_E_INVALID;
+	LFA_HIP(s, hipSetDevice(s->device));
 	LFA_TRY(lfa_particles_materialize(s));
 	if (n != s->np) return lfa_fail(s, LFA_E_INVALID, "download of %llu particles but %zu are resident",
 	                                (unsigned long long)n, s->np);
 	if (n == 0) return LFA_OK;
-	if (s->dist && (!s->binned || s->holes))
+	if (s->dist && !s->binned)
 		return lfa_fail(s, LFA_E_INVALID, "slab decomposition: call lfa_hash_particles before downloading particles");
-	LFA_HIP(s, hipSetDevice(s->device));
 	LFA_TRY(lfa_corr_join(s));
+	const uint32_t *slot = nullptr;
+	LFA_TRY(lfa_slab_download_slots(s, &slot));
 	LFA_TRY(lfa_ensure_io(s, n * 152));
 	// start from the caller's records so fields the device does not own (positions unless asked) survive
 	LFA_HIP(s, hipMemcpyAsync(s->io_buf, aos152, n * 152, hipMemcpyHostToDevice, s->stream));
@@ -535,7 +567,7 @@ extern "C" int lfa_download_particles(lfa_sim *s, void *aos152, uint64_t n, int 
 	for (int k = 0; k < 3; ++k) ip.off[k] = s->prm.grid_offset[k];
 	ip.h = s->prm.cell_size;
 	hipLaunchKernelGGL(k_export, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, (double *)s->io_buf,
-	                   s->np_live, s->pb[s->cur], s->g, ip, flags, s->dist ? 1 : 0);
+	                   s->np_live, s->pb[s->cur], s->g, ip, flags, s->dist ? 1 : 0, slot);
 	LFA_LAUNCH_CHECK(s);
 	LFA_HIP(s, hipMemcpyAsync(aos152, s->io_buf, n * 152, hipMemcpyDeviceToHost, s->stream));
 	LFA_HIP(s, hipStreamSynchronize(s->stream));
@@ -544,15 +576,26 @@ extern "C" int lfa_download_particles(lfa_sim *s, void *aos152, uint64_t n, int 
 
 extern "C" int lfa_download_particle_ids(lfa_sim *s, uint32_t *ids, uint64_t n) {
 	if (!s || (!ids && n)) return LFA_E_INVALID;
+	LFA_HIP(s, hipSetDevice(s->device));
 	if (n != s->np) return lfa_fail(s, LFA_E_INVALID, "download of %llu ids but %zu particles are resident", (unsigned long long)n, s->np);
 	if (n == 0) return LFA_OK;
-	LFA_HIP(s, hipSetDevice(s->device));
 	LFA_TRY(lfa_corr_join(s));
 	if (!s->dist) {  // single domain: record i of a download IS particle i
 		for (uint64_t i = 0; i < n; ++i) ids[i] = (uint32_t)i;
 		return LFA_OK;
 	}
-	if (!s->binned || s->holes) return lfa_fail(s, LFA_E_INVALID, "slab decomposition: call lfa_hash_particles before downloading ids");
+	if (!s->binned) return lfa_fail(s, LFA_E_INVALID, "slab decomposition: call lfa_hash_particles before downloading ids");
+	const uint32_t *slot = nullptr;
+	LFA_TRY(lfa_slab_download_slots(s, &slot));
+	if (slot) {
+		LFA_TRY(lfa_ensure_io(s, n * 4));
+		hipLaunchKernelGGL(k_export_ids, dim3((unsigned)((s->np_live + 255) / 256)), dim3(256), 0, s->stream, (const uint32_t *)s->pb[s->cur].key,
+		                   (const uint32_t *)s->pb[s->cur].id, slot, s->np_live, (uint32_t *)s->io_buf);
+		LFA_LAUNCH_CHECK(s);
+		LFA_HIP(s, hipMemcpyAsync(ids, s->io_buf, n * 4, hipMemcpyDeviceToHost, s->stream));
+		LFA_HIP(s, hipStreamSynchronize(s->stream));
+		return LFA_OK;
+	}
 	LFA_HIP(s, hipMemcpyAsync(ids, s->pb[s->cur].id, n * 4, hipMemcpyDeviceToHost, s->stream));
 	LFA_HIP(s, hipStreamSynchronize(s->stream));
 	return LFA_OK;
@@ -961,6 +1004,7 @@ int lfa_hash_particles_impl(lfa_sim *s, bool counts_done) {
 	s->np_live = s->h_pinned[8];
 	if (s->dist) s->np = s->np_live;  // particles migrate: the resident count is the live count
 	s->holes = false;
+	s->n_arrivals = 0;
 	// counts per layer group = differences of the scan at the layer boundaries
 	{
 		int marks[4] = {own_lo, own_lo + L < own_hi ? own_lo + L : own_hi, own_hi - L > own_lo ? own_hi - L : own_lo, own_hi};

@@ -381,9 +381,12 @@ int lfa_particles_reserve(lfa_sim *s, size_t n_keep, size_t n_total);  // core.h
 
 /// After a stage that moves particles (advect+collide, correct+collide): hand the particles that left the slab to the
 /// neighbour ranks and take theirs. Moves of more than one slab per step are not handled (CFL bounds a step to 3 cells).
-int lfa_dist_migrate(lfa_sim *s) {
+/// `vc_dead`: the caller is about to run the G2P, which overwrites v (and, APIC, C) of every live particle without reading them
+/// (PIC, APIC; FLIP blends with the old velocity): a deferred binning then need not be completed for the leavers' sake - the
+/// records travel with whatever v / C the current buffer holds.
+int lfa_dist_migrate(lfa_sim *s, bool vc_dead) {
 	if (!s->dist) return LFA_OK;
-	LFA_TRY(lfa_particles_materialize(s));  // leavers travel as whole records
+	if (!(vc_dead && s->prm.simulation_method != LFA_FLIP_BLEND)) LFA_TRY(lfa_particles_materialize(s));  // leavers travel as whole records
 	const size_t n = s->binned ? s->np_live : s->np;
 	uint32_t *cnt = (uint32_t *)(s->dist_red + 32);  // [0,1] leaving lo/hi, [2,3] arriving from lo/hi
 	LFA_HIP(s, hipMemsetAsync(cnt, 0, 16, s->stream));
@@ -402,6 +405,7 @@ int lfa_dist_migrate(lfa_sim *s) {
 	LFA_HIP(s, hipStreamSynchronize(s->stream));
 	if (!lfa_has_lo(s)) h[0] = h[2] = 0;  // nothing can leave through a domain wall (positions are clamped into the grid)
 	if (!lfa_has_hi(s)) h[1] = h[3] = 0;
+	// (no early-out when nothing crosses this rank's faces: every rank issues the same sequence of transport calls)
 	for (int w = 0; w < 4; ++w) LFA_TRY(lfa_dist_ensure_xbuf(s, w, (size_t)h[w] * 68));
 	LFA_TRY(lfa_particles_reserve(s, n, n + h[2] + h[3]));
 	ParticleSoA &q = s->pb[s->cur];
@@ -421,7 +425,12 @@ int lfa_dist_migrate(lfa_sim *s) {
 		}
 	// the next binning scans [0, at): leavers carry an invalid key and are dropped there
 	s->np_live = at;
+	// lfa_num_particles: the resident count follows the hand-over at once (binned: np counted the live particles of the last
+	// binning; unbinned: np is the extent of the array, holes included, until the next binning compacts it)
 	if (!s->binned) s->np = at;
+	else s->np = s->np - h[0] - h[1] + h[2] + h[3];
+	s->arrivals_at = n;  // [n, at): in no tile's range until the next binning (the G2P takes them through its leaver path)
+	s->n_arrivals = at - n;
 	s->holes = true;
 	s->vmax2_valid = false;  // the cached max |v|^2 (written by the last G2P) knows nothing of arrivals: lfa_cfl reduces again
 	return LFA_OK;

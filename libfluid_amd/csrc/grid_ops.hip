@@ -412,6 +412,16 @@ k_g2p(const int *ptiles, int n_ptiles, GridDims g, ParticleSoA p, const uint32_t
 	if ((threadIdx.x & 63) == 0 && vmax2 > 0.0f) atomicMax(vmax2_bits, __float_as_uint(vmax2));
 }
 
+/// Slabs: the particles received from the neighbour ranks since the binning, [first, first + count), join the leaver list.
+__global__ void k_g2p_append_range(uint32_t *leavers, uint32_t *n_leavers, uint32_t first, uint32_t count) {
+	__shared__ uint32_t base;
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t mine = count - min(count, blockIdx.x * blockDim.x);
+	if (threadIdx.x == 0) base = atomicAdd(n_leavers, mine < blockDim.x ? mine : blockDim.x);
+	__syncthreads();
+	if (i < count) leavers[base + threadIdx.x] = first + i;
+}
+
 /// The particles k_g2p<.., STALE> set aside: the same transfer with the samples gathered from the grid in global memory.
 template <int METHOD>
 __global__ void __launch_bounds__(256)
@@ -555,7 +565,8 @@ static int g2p_run(lfa_sim *s, bool stale) {
 	LFA_HIP(s, hipSetDevice(s->device));
 	LFA_TRY(lfa_corr_commit(s));
 	LFA_TRY(lfa_dist_refresh_grid(s, false));  // extrapolated velocities of the neighbour's adjacent layer
-	if (!s->n_ptiles) {
+	const bool arrivals = stale && s->dist && s->n_arrivals;  // (a rank without particle tiles may still have received some)
+	if (!s->n_ptiles && !arrivals) {
 		s->vc_pending = false;
 		return LFA_OK;
 	}
@@ -580,8 +591,12 @@ static int g2p_run(lfa_sim *s, bool stale) {
 	// per SIMD; on freshly binned particles it finds no leavers)
 #define G2P_LAUNCH(M)                                                                                                        \
 	do {                                                                                                                     \
-		hipLaunchKernelGGL((k_g2p<M, true>), grid, dim3(G2P_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, s->g, p, s->tile_start,   \
-		                   s->u, s->v, s->w, s->uo, s->vo, s->wo, gp, leavers, n_leavers, pold, from, vmax2_bits);           \
+		if (s->n_ptiles)                                                                                                     \
+			hipLaunchKernelGGL((k_g2p<M, true>), grid, dim3(G2P_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, s->g, p, s->tile_start, \
+			                   s->u, s->v, s->w, s->uo, s->vo, s->wo, gp, leavers, n_leavers, pold, from, vmax2_bits);       \
+		if (arrivals)                                                                                                        \
+			hipLaunchKernelGGL(k_g2p_append_range, dim3((unsigned)((s->n_arrivals + 255) / 256)), dim3(256), 0, s->stream, leavers, \
+			                   n_leavers, (uint32_t)s->arrivals_at, (uint32_t)s->n_arrivals);                                 \
 		if (stale)                                                                                                           \
 			hipLaunchKernelGGL(k_g2p_leavers<M>, dim3(512), dim3(256), 0, s->stream, s->g, p, s->u, s->v, s->w, s->uo, s->vo, \
 			                   s->wo, gp, (const uint32_t *)leavers, (const uint32_t *)n_leavers, pold, from, vmax2_bits);   \
@@ -594,7 +609,7 @@ static int g2p_run(lfa_sim *s, bool stale) {
 #undef G2P_LAUNCH
 	LFA_LAUNCH_CHECK(s);
 	s->vc_pending = false;
-	s->vmax2_valid = !s->dist || !s->holes;  // (slabs: particles handed over since the binning are not in the tile lists)
+	s->vmax2_valid = true;  // every live particle has just got its velocity: the binned ones, the leavers and (slabs) the arrivals
 	return LFA_OK;
 }
 /// (the public entry point takes the leaver path too: it costs a 4-byte memset and an empty launch on freshly binned

@@ -322,3 +322,91 @@ def test_slab_ranks_mesh_their_windows_into_the_single_domain_mesh(bounds):
     assert len(pos) == len(want_pos) and np.array_equal(idx, want_idx)
     # (grid points that see particles only beyond the kernel's support are 0/0 = NaN in the reference too: same mask)
     assert np.array_equal(np.isnan(pos), np.isnan(want_pos)) and np.nanmax(np.abs(pos - want_pos)) < 1e-3
+
+
+def test_fixed_c4_domain_on_eight_virtual_slabs():
+    """BASELINE configs[3] as the driver's `--strong` run decomposes it: the FIXED 512^3 domain, 67 M particles, APIC, on 8
+    z-slabs (`balanced_layer_bounds(64, 8, 0, 32)`: interior bounds multiples of 4 tile layers, three distributed multigrid
+    levels, the rest replicated and run by the single coarse-level launch) - eight handles on one GPU, each allocating the
+    global grid, one host thread per rank, in-process transport. Two hot steps and one full time step (ghost particles,
+    position correction beside the solve, migration, G2P of arrivals through the leaver path) against the single domain:
+    cell types bit-exact, iteration counts within one, face velocities <= 1e-4, particles conserved and resident exactly once."""
+    size, block = (512, 512, 512), ((0, 0, 0), (128, 256, 256))
+    bounds = lfa.balanced_layer_bounds(64, 8, 0, 32)
+    assert bounds == [0, 4, 8, 12, 16, 20, 24, 28, 64]
+    n_expected = 128 * 256 * 256 * 8
+
+    def slim(cells):  # 32-byte records -> what is compared (the full structured array of 134 M cells is 4.3 GB)
+        return cells["type"].astype(np.uint8), cells["vel"].astype(np.float32)
+
+    s = lfa.Sim(size, method=lfa.APIC)
+    s.seed_block(*block)
+    it1 = []
+    for _ in range(2):
+        res, it, rc = s.step_hot(util.DT)
+        assert rc == 0
+        it1.append(it)
+    res, it, rc = s.time_step(util.DT)
+    assert rc == 0
+    it1.append(it)
+    assert s.num_particles == n_expected
+    type1, vel1 = slim(s.cells())
+    s.close()
+
+    n = len(bounds) - 1
+    hub = lfa.LocalHub(n)
+    sims = []
+    for r in range(n):
+        q = lfa.Sim(size, method=lfa.APIC)
+        q.init_local_slab(hub.h, r, bounds)
+        q.seed_block(*block)
+        sims.append(q)
+    assert sum(q.num_particles for q in sims) == n_expected
+    iters = [[] for _ in range(n)]
+    stats = [None] * n
+    errors = []
+
+    def worker(r):
+        try:
+            for _ in range(2):
+                res, it, rc = sims[r].step_hot(util.DT)
+                assert rc == 0
+                iters[r].append(it)
+            stats[r] = sims[r].solver_stats()
+            res, it, rc = sims[r].time_step(util.DT)
+            assert rc == 0
+            iters[r].append(it)
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(n)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    assert not any(t.is_alive() for t in threads), "slab threads hung"
+    assert all(it == iters[0] for it in iters), "ranks must agree on the iteration counts"
+    assert all(abs(a - b) <= 1 for a, b in zip(iters[0], it1)), (iters[0], it1)
+    # transport calls of one PCG iteration: the search direction's slices, q.s, one slice exchange per distributed level on the
+    # way down, the all-reduce of the first replicated level, one per distributed level >= 1 on the way up, (max r, z.r)
+    D = 3
+    assert all(st["transport_calls_per_iteration"] == 2 * D + 3 for st in stats), stats
+    # launches: k_pcg_a, two ghost-face row kernels, AXPY + pre-smoothing, two per distributed level down (one on level 0), the
+    # single coarse-level launch, one per distributed level up
+    assert all(st["launches_per_iteration"] <= 14 for st in stats), stats
+    assert sum(q.num_particles for q in sims) == n_expected, "particles were lost or duplicated by the migration"
+    ids = np.concatenate([q.particle_ids() for q in sims])
+    assert len(ids) == n_expected and len(np.unique(ids)) == n_expected, "a particle is resident on two ranks"
+    del ids
+    vel_atol = 1e-4 * 981.0 * util.DT
+    nz, ny, nx = size[2], size[1], size[0]
+    for r, q in enumerate(sims):
+        lo, hi = q.slab()
+        t, v = slim(q.cells())
+        z0, z1 = lo * 8 * ny * nx, min(hi * 8, nz) * ny * nx
+        assert np.array_equal(t[z0:z1], type1[z0:z1]), f"cell types of rank {r}"
+        util.assert_close(v[z0:z1], vel1[z0:z1], 1e-4, f"grid velocities of rank {r}, slabs vs single domain", atol=vel_atol)
+        del t, v
+        q.close()
+    hub.close()
