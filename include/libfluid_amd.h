@@ -388,6 +388,13 @@ int lfa_bench_kernel(lfa_sim *s, int which, int reps, double *mean_ms);
 /* Measured HBM ceilings of this device beside the 8 TB/s spec peak (SURVEY.md 8d "report both"): a float4 grid-stride device
  * copy of `bytes` (read + write counted) and a read-only pass over the same buffer, GB/s, mean of `reps` launches. */
 int lfa_bench_stream(lfa_sim *s, uint64_t bytes, int reps, double *copy_gbs, double *read_gbs);
+/* Handle re-creation is cheap (fluid::simulation::resize() per Maya evaluation, plugins/maya/nodes/grid_node.cpp:256-274): device
+ * blocks, streams, events and the pinned page of destroyed handles are cached process-wide and adopted by the next lfa_create /
+ * allocation of the same size. lfa_pool_trim releases the cache to the driver (shutdown, memory pressure; LFA_POOL_MAX_BYTES
+ * bounds it, default a quarter of the device memory). lfa_pool_stats: [0] cached bytes [1] cached blocks [2] allocations served
+ * from the cache [3] allocations that went to the driver. */
+void lfa_pool_trim(void);
+void lfa_pool_stats(uint64_t stats[4]);
 /* Which copy kernel gave the figure of the last lfa_bench_stream (a static string; "" before the first call). */
 const char *lfa_bench_stream_variant(void);
 

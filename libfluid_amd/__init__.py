@@ -111,6 +111,8 @@ SIGNATURES = {
     "lfa_bench_kernel": (_int, [_vp, _int, _int, C.POINTER(_dbl)]),
     "lfa_bench_stream": (_int, [_vp, _u64, _int, C.POINTER(_dbl), C.POINTER(_dbl)]),
     "lfa_bench_stream_variant": (C.c_char_p, []),
+    "lfa_pool_trim": (None, []),
+    "lfa_pool_stats": (None, [_vp]),
     "lfa_voxels_create": (_int, [C.POINTER(_vp), _vp, _vp, _dbl, _int]),
     "lfa_voxels_destroy": (None, [_vp]),
     "lfa_voxels_last_error": (C.c_char_p, [_vp]),
@@ -195,6 +197,17 @@ def balanced_layer_bounds(ntz, nranks, lo_layer=0, hi_layer=None):
     b = [lo_layer + (span * r) // nranks for r in range(nranks + 1)]
     b[0], b[-1] = 0, ntz
     return b
+
+
+def pool_trim():
+    """Releases the process-wide cache of device blocks / streams of destroyed handles (lfa_pool_trim)."""
+    load_library().lfa_pool_trim()
+
+
+def pool_stats():
+    arr = (C.c_uint64 * 4)()
+    load_library().lfa_pool_stats(C.byref(arr))
+    return dict(zip(["cached_bytes", "cached_blocks", "hits", "misses"], list(arr)))
 
 
 class LocalHub:
@@ -399,7 +412,10 @@ class Sim:
         self.size = tuple(int(s) for s in size)
         self.ncells = self.size[0] * self.size[1] * self.size[2]
         h = C.c_void_p()
+        import time as _time
+        t0 = _time.perf_counter()
         rc = self.lib.lfa_create(C.byref(h), *self.size, int(device))
+        self.create_ms = 1e3 * (_time.perf_counter() - t0)  # wall time of lfa_create (tests of the handle cache read it)
         if rc != 0:
             raise LibfluidError(rc, self.lib.lfa_last_error(None).decode())
         self.h = h

@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfluid_amd.so")
-SOURCES = ["core.hip", "p2g.hip", "grid_ops.hip", "pcg.hip", "dist.hip", "particles.hip", "voxelizer.hip", "mesher.hip", "mg.hip"]
+SOURCES = ["core.hip", "p2g.hip", "grid_ops.hip", "pcg.hip", "dist.hip", "particles.hip", "voxelizer.hip", "mesher.hip", "mg.hip", "pool.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=off",
          "-Wno-unused-result"]
 

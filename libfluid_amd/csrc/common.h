@@ -18,6 +18,20 @@
 
 #include "../../include/libfluid_amd.h"
 
+// Every device allocation of the library goes through the process-wide block cache (pool.hip): the HIP names are redirected
+// here, after hip_runtime.h has declared the real ones. hipFree keeps its synchronising semantics unless the caller has
+// synchronised itself (lfa_pool_nosync_begin / _end around the releases of lfa_destroy).
+hipError_t lfa_pool_malloc(void **p, size_t bytes);
+hipError_t lfa_pool_free(void *p);
+void lfa_pool_nosync_begin();
+void lfa_pool_nosync_end();
+template <typename T> inline hipError_t lfa_hip_malloc(T **p, size_t bytes) { return lfa_pool_malloc((void **)p, bytes); }
+#define hipMalloc(p, n) lfa_hip_malloc((p), (n))
+#define hipFree(p) lfa_pool_free((void *)(p))
+struct lfa_stream_set;  // streams, events and the pinned page of a destroyed handle, parked for the next lfa_create (pool.hip)
+lfa_stream_set *lfa_pool_take_set(int device);
+void lfa_pool_park_set(lfa_stream_set *q);
+
 #define LFA_TILE 8
 #define LFA_TILE_CELLS 512
 #define LFA_HALO 10            // tile + 1-cell ring

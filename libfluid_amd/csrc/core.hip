@@ -7,6 +7,7 @@
 
 #include "common.h"
 #include "pcg.h"
+#include "stream_set.h"
 
 static thread_local std::string g_create_error;
 
@@ -204,18 +205,28 @@ extern "C" int lfa_create(lfa_sim **out, uint64_t nx, uint64_t ny, uint64_t nz, 
 	lfa_default_params(&s->prm);
 	int rc = LFA_OK;
 	auto chk = [&](int r) { if (rc == LFA_OK && r != LFA_OK) rc = r; };
-	if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
-		delete s;
-		return lfa_fail(nullptr, LFA_E_HIP, "hipStreamCreate failed");
-	}
-	if (hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking) != hipSuccess ||
-	    create_low_priority_stream(&s->stream3) != hipSuccess ||
-	    hipEventCreateWithFlags(&s->ev_cfork, hipEventDisableTiming) != hipSuccess ||
-	    hipEventCreateWithFlags(&s->ev_cjoin, hipEventDisableTiming) != hipSuccess ||
-	    hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
-	    hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess) {
-		lfa_destroy(s);
-		return lfa_fail(nullptr, LFA_E_HIP, "side stream / event creation failed");
+	// streams, events and the pinned page: adopted from a destroyed handle when there is one (pool.hip)
+	if (lfa_stream_set *q = lfa_pool_take_set(device)) {
+		s->stream = q->stream; s->stream2 = q->stream2; s->stream3 = q->stream3;
+		s->ev_fork = q->ev_fork; s->ev_join = q->ev_join; s->ev_cfork = q->ev_cfork; s->ev_cjoin = q->ev_cjoin;
+		for (int i = 0; i < 48; ++i) s->ev[i] = q->ev[i];
+		s->ev_created = q->ev_created;
+		s->h_pinned = q->h_pinned;
+		delete q;
+	} else {
+		if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
+			delete s;
+			return lfa_fail(nullptr, LFA_E_HIP, "hipStreamCreate failed");
+		}
+		if (hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking) != hipSuccess ||
+		    create_low_priority_stream(&s->stream3) != hipSuccess ||
+		    hipEventCreateWithFlags(&s->ev_cfork, hipEventDisableTiming) != hipSuccess ||
+		    hipEventCreateWithFlags(&s->ev_cjoin, hipEventDisableTiming) != hipSuccess ||
+		    hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
+		    hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess) {
+			lfa_destroy(s);
+			return lfa_fail(nullptr, LFA_E_HIP, "side stream / event creation failed");
+		}
 	}
 	chk(dev_alloc(s, &s->tile_count, g.nt + 1, true));
 	chk(dev_alloc(s, &s->tile_start, g.nt + 1, true));
@@ -239,7 +250,7 @@ extern "C" int lfa_create(lfa_sim **out, uint64_t nx, uint64_t ny, uint64_t nz, 
 	chk(dev_alloc(s, &s->partials, 16384, true));  // >= PART_TOTAL (pcg.h)
 	chk(dev_alloc(s, &s->pcg_state, 16, true));
 	chk(dev_alloc(s, &s->pcg_hist, 8192, true));  // [0,4096) residual history, [6144,..) coarse r2 hand-off
-	if (rc == LFA_OK && hipHostMalloc((void **)&s->h_pinned, 4096, hipHostMallocDefault) != hipSuccess)
+	if (rc == LFA_OK && !s->h_pinned && hipHostMalloc((void **)&s->h_pinned, 4096, hipHostMallocDefault) != hipSuccess)
 		rc = lfa_fail(s, LFA_E_HIP, "hipHostMalloc failed");
 	if (rc == LFA_OK) {
 		hipLaunchKernelGGL(k_init_ctype, dim3((unsigned)((s->ncp + 255) / 256)), dim3(256), 0, s->stream, s->ctype,
@@ -267,6 +278,8 @@ extern "C" void lfa_destroy(lfa_sim *s) {
 	if (s->stream) (void)hipStreamSynchronize(s->stream);
 	if (s->stream2) (void)hipStreamSynchronize(s->stream2);
 	if (s->stream3) (void)hipStreamSynchronize(s->stream3);
+	// the handle's streams are idle: its blocks go back to the cache without a device-wide synchronisation each
+	lfa_pool_nosync_begin();
 	free_soa(s->pb[0]);
 	free_soa(s->pb[1]);
 	void *ptrs[] = {s->fine_start, s->corr_ovf, s->tile_clear, s->tile_epoch, s->src_cell, s->src_lo, s->src_target, s->src_of, s->src_need, s->src_vel, s->coerce_map, s->grid_flag, s->rank, s->vc_src, s->tile_count, s->tile_start, s->tile_flag, s->tile_scan, s->ptiles_all, s->dtiles, s->halo_tiles, s->dist_red,
@@ -278,19 +291,33 @@ extern "C" void lfa_destroy(lfa_sim *s) {
 	                s->l1_tiles, s->l1_l2};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
-	if (s->h_pinned) (void)hipHostFree(s->h_pinned);
 	if (s->dist) delete s->dist;
 	s->dist = nullptr;
 	lfa_mg_free(s);
-	if (s->ev_created)
-		for (auto &e : s->ev) (void)hipEventDestroy(e);
-	if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
-	if (s->ev_join) (void)hipEventDestroy(s->ev_join);
-	if (s->ev_cfork) (void)hipEventDestroy(s->ev_cfork);
-	if (s->ev_cjoin) (void)hipEventDestroy(s->ev_cjoin);
-	if (s->stream3) (void)hipStreamDestroy(s->stream3);
-	if (s->stream2) (void)hipStreamDestroy(s->stream2);
-	if (s->stream) (void)hipStreamDestroy(s->stream);
+	lfa_pool_nosync_end();
+	// streams, events and the pinned page are parked for the next lfa_create on this device (a handle whose creation failed
+	// half way is torn down instead)
+	if (s->stream && s->stream2 && s->stream3 && s->ev_fork && s->ev_join && s->ev_cfork && s->ev_cjoin && s->h_pinned) {
+		lfa_stream_set *q = new lfa_stream_set();
+		q->device = s->device;
+		q->stream = s->stream; q->stream2 = s->stream2; q->stream3 = s->stream3;
+		q->ev_fork = s->ev_fork; q->ev_join = s->ev_join; q->ev_cfork = s->ev_cfork; q->ev_cjoin = s->ev_cjoin;
+		for (int i = 0; i < 48; ++i) q->ev[i] = s->ev[i];
+		q->ev_created = s->ev_created;
+		q->h_pinned = s->h_pinned;
+		lfa_pool_park_set(q);
+	} else {
+		if (s->h_pinned) (void)hipHostFree(s->h_pinned);
+		if (s->ev_created)
+			for (auto &e : s->ev) (void)hipEventDestroy(e);
+		if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+		if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+		if (s->ev_cfork) (void)hipEventDestroy(s->ev_cfork);
+		if (s->ev_cjoin) (void)hipEventDestroy(s->ev_cjoin);
+		if (s->stream3) (void)hipStreamDestroy(s->stream3);
+		if (s->stream2) (void)hipStreamDestroy(s->stream2);
+		if (s->stream) (void)hipStreamDestroy(s->stream);
+	}
 	delete s;
 }
 

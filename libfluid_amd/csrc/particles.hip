@@ -990,7 +990,8 @@ extern "C" int lfa_update_sources(lfa_sim *s, uint64_t *n_seeded) {
 	if (!total) return LFA_OK;  // every source cell is full: the binning stands
 	if (s->np_live + total >= ((size_t)1 << 32)) return lfa_fail(s, LFA_E_INVALID, "more than 2^32 particles");
 	const size_t base = s->np_live;
-	LFA_TRY(lfa_particles_reserve(s, base, base + total));  // completes a deferred binning, keeps the live records
+	LFA_TRY(lfa_particles_materialize(s));  // the new particles bring their own v / C: a deferred binning is completed first
+	LFA_TRY(lfa_particles_reserve(s, base, base + total));  // keeps the live records
 	++s->source_epoch;
 	hipLaunchKernelGGL(k_source_seed, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, (const uint32_t *)s->src_cell,
 	                   (const uint32_t *)s->src_of, (const uint32_t *)s->src_need, (const uint32_t *)off, n, (const float *)s->src_vel,

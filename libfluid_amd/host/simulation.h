@@ -28,6 +28,7 @@
 #pragma once
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
@@ -170,7 +171,9 @@ namespace fluid_amd {
 			_grid = mac_grid(sz);
 			_space_hash = grid3<_cell_particles>(sz);
 			if (_dev) { lfa_destroy(_dev); _dev = nullptr; }
+			const auto t0 = std::chrono::steady_clock::now();
 			_status = lfa_create(&_dev, sz.x, sz.y, sz.z, device);
+			_create_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 			if (_status != LFA_OK) _error = lfa_last_error(nullptr);
 			_solids_dirty = true;
 			_host_stale = _grid_stale = false;  // the new handle holds nothing yet
@@ -256,6 +259,8 @@ namespace fluid_amd {
 		double pcg_tau = 0.97, pcg_sigma = 0.25, pcg_tolerance = 1e-6;   ///< pressure_solver.h:39-41
 		std::size_t pcg_max_iterations = 200;                             ///< pressure_solver.h:42
 		int last_status() const { return _status; }
+		/// Wall milliseconds the last resize() spent in lfa_create (cheap after the first handle of a size: csrc/pool.hip).
+		double device_create_ms() const { return _create_ms; }
 		void clear_status() { _status = LFA_OK; _error.clear(); }
 		const std::string &last_error() const { return _error; }
 		lfa_sim *device_handle() { return _dev; }
@@ -269,6 +274,7 @@ namespace fluid_amd {
 		lfa_sim *_dev = nullptr;
 		int _status = LFA_OK;
 		std::string _error;
+		double _create_ms = 0.0;  // wall time of the last lfa_create (device_create_ms())
 		bool _solids_dirty = true;
 		bool _host_stale = false;  // the device holds newer particles than _particles
 		bool _dev_stale = true;    // _particles must be uploaded before the next device stage

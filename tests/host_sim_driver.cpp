@@ -13,6 +13,9 @@
 //                   the x coordinates it saw: the positions of BEFORE the correction)
 //         obstacle  nocb, and the solid cells are only put in after the first step, then removed again before the last one
 //                   (the testbed's scene reset edits sim.grid() between steps, testbed/main.cpp:125-178)
+//         recreate  what the Maya node does per evaluation (plugins/maya/nodes/grid_node.cpp:256-274,350-366): `steps` times
+//                   { a NEW simulation, resize(), fields, particles, update(dt), read particles() } - prints
+//                   "cycle_ms <mean> resize_ms <mean>" over the cycles after the first (the first one fills the caches)
 //   Prints "step_ms <mean wall milliseconds per step>" (after one warm-up step when steps > 2).
 #include <chrono>
 #include <cstdio>
@@ -40,8 +43,58 @@ static std::vector<char> slurp(const char *path) {
 	return buf;
 }
 
+static int recreate_cycles(int argc, char **argv) {
+	const int steps = std::atoi(argv[7]);
+	const double dt = std::atof(argv[6]);
+	std::vector<char> in = slurp(argv[8]);
+	double cycle_ms = 0.0, resize_ms = 0.0, create_ms = 0.0;
+	int timed = 0;
+	std::vector<simulation::particle> last;
+	for (int i = 0; i < steps; ++i) {
+		const auto t0 = std::chrono::steady_clock::now();
+		simulation sim;
+		sim.resize(vec3s(std::atoi(argv[1]), std::atoi(argv[2]), std::atoi(argv[3])));
+		const auto t1 = std::chrono::steady_clock::now();
+		if (sim.last_status() != LFA_OK) {
+			std::fprintf(stderr, "device init failed: %s\n", sim.last_error().c_str());
+			return 3;
+		}
+		sim.cell_size = 1.0;
+		sim.grid_offset = vec3d();
+		sim.gravity = vec3d(0.0, -981.0, 0.0);
+		sim.simulation_method = static_cast<simulation::method>(std::atoi(argv[4]));
+		sim.blending_factor = std::atof(argv[5]);
+		sim.particles().resize(in.size() / sizeof(simulation::particle));
+		std::memcpy(static_cast<void*>(sim.particles().data()), in.data(), in.size());
+		sim.reset_space_hash();
+		sim.update(dt);
+		if (sim.last_status() < 0) {
+			std::fprintf(stderr, "cycle %d failed (%d): %s\n", i, sim.last_status(), sim.last_error().c_str());
+			return 4;
+		}
+		last = sim.particles();
+		const auto t2 = std::chrono::steady_clock::now();
+		if (i > 0) {
+			cycle_ms += std::chrono::duration<double, std::milli>(t2 - t0).count();
+			resize_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
+			create_ms += sim.device_create_ms();
+			++timed;
+		}
+	}
+	std::printf("cycle_ms %.4f resize_ms %.4f create_ms %.4f\n", timed ? cycle_ms / timed : 0.0, timed ? resize_ms / timed : 0.0,
+	            timed ? create_ms / timed : 0.0);
+	std::printf("step_ms %.4f\n", timed ? cycle_ms / timed : 0.0);
+	if (FILE *f = std::fopen(argv[9], "wb")) {
+		std::fwrite(last.data(), sizeof(simulation::particle), last.size(), f);
+		std::fclose(f);
+		return 0;
+	}
+	return 5;
+}
+
 int main(int argc, char **argv) {
 	if (argc < 10) return 2;
+	if (argc > 11 && std::string(argv[11]) == "recreate") return recreate_cycles(argc, argv);
 	simulation sim;
 	sim.resize(vec3s(std::atoi(argv[1]), std::atoi(argv[2]), std::atoi(argv[3])));
 	if (sim.last_status() != LFA_OK) {
