@@ -490,8 +490,8 @@ __global__ void __launch_bounds__(256) k_mg_presmooth(MgLv<real> L, const int *s
 
 /// The AXPYs of the iteration (k_axpy_max) fused with the pre-smoothing of the finest level: p += alpha s, r -= alpha q,
 /// signed max r, then x0 = red->black sweep on the new residual, tile by tile (x0 overwrites q: same tile, same wave).
-template <typename real>
-__global__ void __launch_bounds__(256)
+template <typename real, int MW>
+__global__ void __launch_bounds__(256, MW)
 k_mg_axpy_presmooth(const int *tiles, int n_tiles, const uint8_t *abits, real *p, const real *sdir, real *r, real *q_x,
                     const double *part_sigma, int n_sigma, const double *part_qs, int n_qs, double *part_rmax, const int *state) {
 	__shared__ real halo[PCG_WAVES][LFA_HALO_CELLS];
@@ -573,8 +573,8 @@ __global__ void __launch_bounds__(256) k_mg_residual_restrict(MgLv<real> L, Grid
 }
 
 /// LEVEL0: the result is scaled by 1/scale and dot(z, r) is formed.
-template <typename real, bool LEVEL0>
-__global__ void __launch_bounds__(256)
+template <typename real, bool LEVEL0, int MW>
+__global__ void __launch_bounds__(256, MW)
 k_mg_prolong_postsmooth(MgLv<real> L, GridDims gc, const real *e, real inv_scale, double *part_sigma, const int *state) {
 	__shared__ real halo[PCG_WAVES][LFA_HALO_CELLS];
 	__shared__ double red[4];
@@ -1328,6 +1328,34 @@ __global__ void __launch_bounds__(MG_TAIL_WAVES * 64) k_mg_tail(MgTail<real> T, 
 	}
 }
 
+
+/// Minimum waves per SIMD the two streaming kernels of the finest level are compiled for (their software pipelines hold a whole
+/// tile's loads in registers: unconstrained they take 134 / 154 VGPRs = 3 waves per SIMD). LFA_MG_MW_A / LFA_MG_MW_U select
+/// another instantiation for A/B runs.
+static int mg_min_waves(const char *env, int dflt) {
+	if (const char *e = getenv(env)) return atoi(e);
+	return dflt;
+}
+#define MG_MW_DEFAULT_A 4  // (C4: 65 -> 61 us; 5 / 6 waves spill the pipeline registers: 117 / 149 us)
+#define MG_MW_DEFAULT_U 1  // (C4: 54 us; 4 / 5 / 6: 61 / 101 / 142 us)
+template <typename real, typename... Args> static void launch_axpy_presmooth(int G, hipStream_t st, Args... a) {
+	switch (mg_min_waves("LFA_MG_MW_A", MG_MW_DEFAULT_A)) {
+	case 4: hipLaunchKernelGGL((k_mg_axpy_presmooth<real, 4>), dim3(G), dim3(256), 0, st, a...); break;
+	case 5: hipLaunchKernelGGL((k_mg_axpy_presmooth<real, 5>), dim3(G), dim3(256), 0, st, a...); break;
+	case 6: hipLaunchKernelGGL((k_mg_axpy_presmooth<real, 6>), dim3(G), dim3(256), 0, st, a...); break;
+	case 8: hipLaunchKernelGGL((k_mg_axpy_presmooth<real, 8>), dim3(G), dim3(256), 0, st, a...); break;
+	default: hipLaunchKernelGGL((k_mg_axpy_presmooth<real, 1>), dim3(G), dim3(256), 0, st, a...); break;
+	}
+}
+template <typename real, typename... Args> static void launch_up0(int G, hipStream_t st, Args... a) {
+	switch (mg_min_waves("LFA_MG_MW_U", MG_MW_DEFAULT_U)) {
+	case 4: hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true, 4>), dim3(G), dim3(256), 0, st, a...); break;
+	case 5: hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true, 5>), dim3(G), dim3(256), 0, st, a...); break;
+	case 6: hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true, 6>), dim3(G), dim3(256), 0, st, a...); break;
+	case 8: hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true, 8>), dim3(G), dim3(256), 0, st, a...); break;
+	default: hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true, 1>), dim3(G), dim3(256), 0, st, a...); break;
+	}
+}
 int mg_grid(int n_tiles) { return pcg_grid(n_tiles); }
 /// Slab mode of the hierarchy. A one-rank communicator needs none of it; LFA_MG_DIST_SINGLE=1 runs it anyway (tests: the array
 /// all-reduces then go through the real transport).
@@ -1671,8 +1699,7 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 	if (last == 0) {  // a single level: the two sweeps alone
 		const MgLv<real> L = lvl(0);
 		if (!level0_presmoothed) hipLaunchKernelGGL(k_mg_presmooth<real>, dim3(1), dim3(256), 0, s->stream, L, st);
-		hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true>), dim3(1), dim3(256), 0, s->stream, L, L.g, (const real *)nullptr,
-		                   inv_scale, part_sigma, st);
+		launch_up0<real>(1, s->stream, L, L.g, (const real *)nullptr, inv_scale, part_sigma, st);
 		LFA_LAUNCH_CHECK(s);
 		return LFA_OK;
 	}
@@ -1794,13 +1821,12 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		const int G = mg_grid(L.n_tiles);
 		if (!(parts & (l == 0 ? MG_PART_UP0 : MG_PART_COARSE))) continue;
 		if (l == 0)
-			hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true>), dim3(G), dim3(256), 0, s->stream, L, M.lv[1].g,
-			                   (const real *)M.lv[1].y, inv_scale, part_sigma, st);
+			launch_up0<real>(G, s->stream, L, M.lv[1].g, (const real *)M.lv[1].y, inv_scale, part_sigma, st);
 		else if (!getenv("LFA_MG_NO_CP") && L.n_tiles <= cp_max)
 			hipLaunchKernelGGL(k_mg_prolong_postsmooth_cp<real>, dim3(std::max(1, std::min(L.n_tiles, 8192))), dim3(256), 0, s->stream, L, M.lv[l + 1].g,
 			                   (const real *)M.lv[l + 1].y, MG_INNER_SWEEPS, st);
 		else
-			hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, false>), dim3(G), dim3(256), 0, s->stream, L, M.lv[l + 1].g,
+			hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, false, 1>), dim3(G), dim3(256), 0, s->stream, L, M.lv[l + 1].g,
 			                   (const real *)M.lv[l + 1].y, (real)1, (double *)nullptr, st);
 		LFA_LAUNCH_CHECK(s);
 		++launches;
@@ -1830,9 +1856,9 @@ template <typename real>
 static int mg_axpy_apply_t(lfa_sim *s, const void *sdir, const double *part_sigma, int n_sigma, const double *part_qs, int n_qs,
                            double *part_rmax, double *part_sigma_new) {
 	const int G = mg_grid(s->n_ptiles);
-	hipLaunchKernelGGL(k_mg_axpy_presmooth<real>, dim3(G), dim3(256), 0, s->stream, (const int *)s->ptiles, s->n_ptiles,
-	                   (const uint8_t *)s->abits, (real *)s->vp, (const real *)sdir, (real *)s->vr, (real *)s->vq, part_sigma, n_sigma,
-	                   part_qs, n_qs, part_rmax, (const int *)s->pcg_state);
+	launch_axpy_presmooth<real>(G, s->stream, (const int *)s->ptiles, s->n_ptiles, (const uint8_t *)s->abits, (real *)s->vp,
+	                            (const real *)sdir, (real *)s->vr, (real *)s->vq, part_sigma, n_sigma, part_qs, n_qs, part_rmax,
+	                            (const int *)s->pcg_state);
 	LFA_LAUNCH_CHECK(s);
 	return mg_apply_t<real>(s, part_sigma_new, true);
 }
@@ -1852,8 +1878,8 @@ int lfa_mg_bench_part(lfa_sim *s, int part) {
 	double *P = s->partials;
 	const int G = mg_grid(s->n_ptiles);
 	if (part == 0) {
-		if (f64) hipLaunchKernelGGL(k_mg_axpy_presmooth<double>, dim3(G), dim3(256), 0, s->stream, (const int *)s->ptiles, s->n_ptiles, (const uint8_t *)s->abits, (double *)s->vp, (const double *)s->vs, (double *)s->vr, (double *)s->vq, P + PART_SIG0, G, P + PART_ZS, G, P + PART_RMAX, (const int *)s->pcg_state);
-		else hipLaunchKernelGGL(k_mg_axpy_presmooth<float>, dim3(G), dim3(256), 0, s->stream, (const int *)s->ptiles, s->n_ptiles, (const uint8_t *)s->abits, (float *)s->vp, (const float *)s->vs, (float *)s->vr, (float *)s->vq, P + PART_SIG0, G, P + PART_ZS, G, P + PART_RMAX, (const int *)s->pcg_state);
+		if (f64) launch_axpy_presmooth<double>(G, s->stream, (const int *)s->ptiles, s->n_ptiles, (const uint8_t *)s->abits, (double *)s->vp, (const double *)s->vs, (double *)s->vr, (double *)s->vq, (const double *)(P + PART_SIG0), G, (const double *)(P + PART_ZS), G, P + PART_RMAX, (const int *)s->pcg_state);
+		else launch_axpy_presmooth<float>(G, s->stream, (const int *)s->ptiles, s->n_ptiles, (const uint8_t *)s->abits, (float *)s->vp, (const float *)s->vs, (float *)s->vr, (float *)s->vq, (const double *)(P + PART_SIG0), G, (const double *)(P + PART_ZS), G, P + PART_RMAX, (const int *)s->pcg_state);
 		LFA_LAUNCH_CHECK(s);
 		return LFA_OK;
 	}
