@@ -205,6 +205,15 @@ int lfa_add_source(lfa_sim *s, const int32_t *xyz, uint64_t k, const double velo
 int lfa_update_sources(lfa_sim *s, uint64_t *n_seeded);
 int lfa_advect_collide(lfa_sim *s, double dt);
 int lfa_correct_collide(lfa_sim *s, double dt);
+/* The same two stages with the collision handling split off, for hosts that install post_advection_callback or
+ * post_correction_callback: simulation::time_step runs _advect_particles -> callback -> _detect_collisions
+ * (src/simulation.cpp:50-59) and _correct_positions -> callback -> _detect_collisions (:111-117). lfa_advect / lfa_correct move
+ * the particles and keep the positions of before on the device; a download in between reports them as old_position;
+ * lfa_collide runs _detect_collisions (:612-683) from there to the current positions. After an upload in between lfa_collide
+ * starts from the uploaded positions (from = to: the skin push-out alone). Single domain only. */
+int lfa_advect(lfa_sim *s, double dt);
+int lfa_correct(lfa_sim *s, double dt);
+int lfa_collide(lfa_sim *s);
 int lfa_time_step(lfa_sim *s, double dt, double *residual, uint64_t *iterations);
 /* Device time of the stages of the last lfa_time_step in milliseconds (timing enabled), HIP events on the handle's stream:
  * [0] advect+collide  [1] binning  [2] P2G (scatter + finalize + gravity)  [3] P2G scatter kernel alone

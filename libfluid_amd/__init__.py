@@ -142,6 +142,9 @@ SIGNATURES = {
     "lfa_add_source": (_int, [_vp, _vp, _u64, _vp, _u64, _int, _int]),
     "lfa_update_sources": (_int, [_vp, C.POINTER(_u64)]),
     "lfa_advect_collide": (_int, [_vp, _dbl]),
+    "lfa_advect": (_int, [_vp, _dbl]),
+    "lfa_correct": (_int, [_vp, _dbl]),
+    "lfa_collide": (_int, [_vp]),
     "lfa_correct_collide": (_int, [_vp, _dbl]),
     "lfa_time_step": (_int, [_vp, _dbl, C.POINTER(_dbl), C.POINTER(_u64)]),
     "lfa_get_step_timings": (_int, [_vp, C.POINTER(_dbl * NUM_STEP_TIMERS)]),
@@ -617,6 +620,15 @@ class Sim:
         n = C.c_uint64(0)
         self._chk(self.lib.lfa_update_sources(self.h, C.byref(n)))
         return n.value
+
+    def advect(self, dt):
+        self._chk(self.lib.lfa_advect(self.h, float(dt)))
+
+    def correct(self, dt):
+        self._chk(self.lib.lfa_correct(self.h, float(dt)))
+
+    def collide(self):
+        self._chk(self.lib.lfa_collide(self.h))
 
     def advect_collide(self, dt):
         self._chk(self.lib.lfa_advect_collide(self.h, float(dt)))

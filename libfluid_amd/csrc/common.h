@@ -76,6 +76,7 @@ struct lfa_sim {
 	bool overlap_correction = true;
 	bool corr_in_flight = false;   // lfa_correct_collide_begin .. _end: the particle arrays belong to the correction on stream3
 	bool counts_fresh = false;     // tile_count / rank were produced by the advection of lfa_time_step: the binning skips its pass 1
+	bool move_pending = false;     // lfa_advect / lfa_correct have moved the particles and lfa_collide is due: the positions of before sit in the other buffer's key / t
 	bool corr_begun = false;       // the last lfa_correct_collide_begin started a correction (false: no particles, nothing to take back)
 	bool corr_undo_valid = false;  // nothing has changed positions, binning or solids since: lfa_correct_collide_undo can restore
 	uint32_t *corr_ovf = nullptr;  // tiled correction: word 0 = number of flagged (overflowing) half tiles, then their bitmap

@@ -496,6 +496,7 @@ __global__ void k_ingest(const double *aos, size_t n, ParticleSoA p, GridDims g,
 extern "C" int lfa_upload_particles(lfa_sim *s, const void *aos152, uint64_t n) {
 	if (!s || (!aos152 && n)) return LFA_E_INVALID;
 	s->vc_pending = false;  // the particle set is replaced
+	s->move_pending = false;
 	s->vmax2_valid = false;
 	if (!(s->prm.cell_size > 0.0)) return lfa_fail(s, LFA_E_INVALID, "set cell_size (lfa_set_params) before uploading");
 	if (n >= ((uint64_t)1 << 32)) return lfa_fail(s, LFA_E_INVALID, "more than 2^32 particles");
@@ -532,7 +533,10 @@ __global__ void k_export_ids(const uint32_t *key, const uint32_t *id, const uint
 	if (i < n && key[i] != 0xFFFFFFFFu) out[slot ? slot[i] : i] = id[i];
 }
 
-__global__ void k_export(double *aos, size_t n, ParticleSoA p, GridDims g, IngestParams ip, int flags, int by_slot, const uint32_t *slot) {
+/// `old`: lfa_advect / lfa_correct have moved the particles and lfa_collide is still due - old_position is the position of before
+/// the move (what a host callback between the two stages sees in the reference), kept in old.key / old.t.
+__global__ void k_export(double *aos, size_t n, ParticleSoA p, GridDims g, IngestParams ip, int flags, int by_slot, const uint32_t *slot,
+                         ParticleSoA old, int have_old) {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	uint32_t b = p.key[i];
@@ -548,6 +552,14 @@ __global__ void k_export(double *aos, size_t n, ParticleSoA p, GridDims g, Inges
 			double x = ip.off[k] + ((double)c[k] + (double)p.t[k][i]) * ip.h;
 			q[k] = x;
 			q[15 + k] = x;
+		}
+		if (have_old) {
+			const uint32_t ob = old.key[i];
+			int otile = (int)(ob >> 9), ol = (int)(ob & 511), ox, oy, oz;
+			tile_coords(g, otile, ox, oy, oz);
+			int oc[3] = {ox * 8 + (ol & 7), oy * 8 + ((ol >> 3) & 7), oz * 8 + (ol >> 6)};
+#pragma unroll
+			for (int k = 0; k < 3; ++k) q[15 + k] = ip.off[k] + ((double)oc[k] + (double)old.t[k][i]) * ip.h;
 		}
 	}
 #pragma unroll
@@ -594,7 +606,8 @@ extern "C" int lfa_download_particles(lfa_sim *s, void *aos152, uint64_t n, int 
 	for (int k = 0; k < 3; ++k) ip.off[k] = s->prm.grid_offset[k];
 	ip.h = s->prm.cell_size;
 	hipLaunchKernelGGL(k_export, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, (double *)s->io_buf,
-	                   s->np_live, s->pb[s->cur], s->g, ip, flags, s->dist ? 1 : 0, slot);
+	                   s->np_live, s->pb[s->cur], s->g, ip, flags, s->dist ? 1 : 0, slot, s->pb[s->cur ^ 1],
+	                   (s->move_pending && !s->dist) ? 1 : 0);
 	LFA_LAUNCH_CHECK(s);
 	LFA_HIP(s, hipMemcpyAsync(aos152, s->io_buf, n * 152, hipMemcpyDeviceToHost, s->stream));
 	LFA_HIP(s, hipStreamSynchronize(s->stream));
@@ -1032,6 +1045,7 @@ int lfa_hash_particles_impl(lfa_sim *s, bool counts_done) {
 	if (s->dist) s->np = s->np_live;  // particles migrate: the resident count is the live count
 	s->holes = false;
 	s->n_arrivals = 0;
+	s->move_pending = false;  // (a binning re-uses the buffer the positions of before a split move were kept in)
 	// counts per layer group = differences of the scan at the layer boundaries
 	{
 		int marks[4] = {own_lo, own_lo + L < own_hi ? own_lo + L : own_hi, own_hi - L > own_lo ? own_hi - L : own_lo, own_hi};

@@ -131,6 +131,8 @@ struct MoveParams {
 	double skin;        // boundary_skin_width / cell_size
 	double corr;        // dt * correction_stiffness * re / cell_size   (re = cell_size / sqrt 2)
 	double inv_re2;     // cell_size^2 / re^2 = 2
+	int collide;        // 1: the collision handling that follows the move in the reference runs inside the kernel (the default); 0: the
+	                    // caller runs it later (lfa_collide), after a host callback that sits between the two in simulation::time_step
 };
 
 /// _advect_particles (x += v dt, clamp to [skin, n - skin]) fused with _detect_collisions (from = the old position).
@@ -198,7 +200,7 @@ __device__ inline uint32_t advect_one(size_t i, const ParticleSoA &p, const Grid
 	// a dependent byte load per crossed cell and per near face; most tiles of a scene are nowhere near a solid.
 	const bool open_water = (tile_clear[key >> 9] & 1) && fabs(to[0] - from[0]) < 8.0 && fabs(to[1] - from[1]) < 8.0 &&
 	                        fabs(to[2] - from[2]) < 8.0;
-	if (!open_water) collide(g, solid, from, to, mp.skin);
+	if (!open_water && mp.collide) collide(g, solid, from, to, mp.skin);
 	int nc[3];
 	float nt[3];
 #pragma unroll
@@ -489,7 +491,7 @@ k_correct_collide(size_t n, ParticleSoA p, uint32_t *out_key, float *out_tx, flo
 		double x = from[d] + spring[d] * mp.corr;
 		to[d] = x < 0.0 ? 0.0 : ((double)nn[d] < x ? (double)nn[d] : x);  // clamp to [offset, grid max] (:604-609)
 	}
-	collide(g, solid, from, to, mp.skin);
+	if (mp.collide) collide(g, solid, from, to, mp.skin);
 	int nc[3];
 	float ntt[3];
 #pragma unroll
@@ -773,10 +775,12 @@ k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx
 			}
 			// (a correction moves a particle by a fraction of a cell: in open water there is nothing to march against, only the
 			// domain walls push back)
-			if (!open_water || fabs(to[0] - from[0]) >= 7.0 || fabs(to[1] - from[1]) >= 7.0 || fabs(to[2] - from[2]) >= 7.0)
-				collide(g, solid, from, to, mp.skin);
-			else
-				collide_walls_only(g, to, mp.skin);
+			if (mp.collide) {
+				if (!open_water || fabs(to[0] - from[0]) >= 7.0 || fabs(to[1] - from[1]) >= 7.0 || fabs(to[2] - from[2]) >= 7.0)
+					collide(g, solid, from, to, mp.skin);
+				else
+					collide_walls_only(g, to, mp.skin);
+			}
 			int nc[3];
 			float nt[3];
 #pragma unroll
@@ -796,6 +800,7 @@ static MoveParams move_params(const lfa_sim *s, double dt) {
 	mp.skin = s->prm.boundary_skin_width / h;
 	mp.corr = dt * s->prm.correction_stiffness * re / h;
 	mp.inv_re2 = h * h / (re * re);
+	mp.collide = 1;
 	return mp;
 }
 
@@ -1019,12 +1024,21 @@ static int refresh_tile_clear(lfa_sim *s) {
 }
 
 /// `with_count`: lfa_time_step's variant - the binning that follows finds tile_count / rank done (lfa_sim::counts_fresh).
-static int advect_collide(lfa_sim *s, double dt, bool with_count) {
+/// `split`: _advect_particles alone - the positions of before are kept (save_old_positions) for the lfa_collide that follows.
+static int save_old_positions(lfa_sim *s, size_t n);
+static int advect_collide(lfa_sim *s, double dt, bool with_count, bool split = false) {
 	if (!s) return LFA_E_INVALID;
 	LFA_HIP(s, hipSetDevice(s->device));
 	LFA_TRY(lfa_corr_commit(s));
 	LFA_TRY(lfa_particles_materialize(s));  // reads v
 	const size_t n = s->binned ? s->np_live : s->np;
+	MoveParams mp = move_params(s, dt);
+	s->move_pending = false;
+	if (split) {
+		if (s->dist) return lfa_fail(s, LFA_E_UNSUPPORTED, "lfa_advect: slab decompositions migrate inside lfa_advect_collide");
+		LFA_TRY(save_old_positions(s, n));
+		mp.collide = 0;
+	}
 	LFA_TRY(lfa_sources_sync(s));
 	LFA_TRY(refresh_tile_clear(s));
 	s->counts_fresh = false;
@@ -1037,27 +1051,91 @@ static int advect_collide(lfa_sim *s, double dt, bool with_count) {
 			const dim3 grid((unsigned)((n + 256 * AC_CHUNKS - 1) / (256 * AC_CHUNKS)));
 			if (s->any_coerce)
 				hipLaunchKernelGGL(k_advect_collide_count<true>, grid, dim3(256), 0, s->stream, n, s->pb[s->cur], s->g, s->solid,
-				                   move_params(s, dt), cm, sv, (const uint8_t *)s->tile_clear, s->tile_count, s->rank);
+				                   mp, cm, sv, (const uint8_t *)s->tile_clear, s->tile_count, s->rank);
 			else
 				hipLaunchKernelGGL(k_advect_collide_count<false>, grid, dim3(256), 0, s->stream, n, s->pb[s->cur], s->g, s->solid,
-				                   move_params(s, dt), cm, sv, (const uint8_t *)s->tile_clear, s->tile_count, s->rank);
+				                   mp, cm, sv, (const uint8_t *)s->tile_clear, s->tile_count, s->rank);
 			s->counts_fresh = true;
 		} else {
 			const dim3 grid((unsigned)((n + 255) / 256));
 			if (s->any_coerce)
-				hipLaunchKernelGGL(k_advect_collide<true>, grid, dim3(256), 0, s->stream, n, s->pb[s->cur], s->g, s->solid, move_params(s, dt),
+				hipLaunchKernelGGL(k_advect_collide<true>, grid, dim3(256), 0, s->stream, n, s->pb[s->cur], s->g, s->solid, mp,
 				                   cm, sv, (const uint8_t *)s->tile_clear);
 			else
-				hipLaunchKernelGGL(k_advect_collide<false>, grid, dim3(256), 0, s->stream, n, s->pb[s->cur], s->g, s->solid, move_params(s, dt),
+				hipLaunchKernelGGL(k_advect_collide<false>, grid, dim3(256), 0, s->stream, n, s->pb[s->cur], s->g, s->solid, mp,
 				                   cm, sv, (const uint8_t *)s->tile_clear);
 		}
 		LFA_LAUNCH_CHECK(s);
 	}
 	LFA_TRY(lfa_dist_migrate(s));
 	s->unknown_count_valid = false;
+	s->move_pending = split;
 	return LFA_OK;
 }
 extern "C" int lfa_advect_collide(lfa_sim *s, double dt) { return advect_collide(s, dt, false); }
+extern "C" int lfa_advect(lfa_sim *s, double dt) { return advect_collide(s, dt, false, true); }
+
+namespace {
+/// _detect_collisions as its own pass (lfa_collide): from = the position saved before the move, to = the current one.
+__global__ void __launch_bounds__(256)
+k_collide_only(size_t n, ParticleSoA p, const uint32_t *old_key, const float *ot0, const float *ot1, const float *ot2, GridDims g,
+               const uint8_t *solid, double skin) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t key = p.key[i];
+	if (key == 0xFFFFFFFFu) return;
+	const int nn[3] = {g.nx, g.ny, g.nz};
+	int c[3], oc[3];
+	cell_of_key(g, key, c);
+	double from[3], to[3];
+	const float ot[3] = {ot0 ? ot0[i] : p.t[0][i], ot1 ? ot1[i] : p.t[1][i], ot2 ? ot2[i] : p.t[2][i]};
+	cell_of_key(g, old_key ? old_key[i] : key, oc);
+#pragma unroll
+	for (int d = 0; d < 3; ++d) {
+		to[d] = (double)c[d] + (double)p.t[d][i];
+		from[d] = (double)oc[d] + (double)ot[d];
+	}
+	collide(g, solid, from, to, skin);
+	int nc[3];
+	float nt[3];
+#pragma unroll
+	for (int d = 0; d < 3; ++d) split_position(to[d], nn[d], nc[d], nt[d]);
+	p.key[i] = blocked_index(g, nc[0], nc[1], nc[2]);
+#pragma unroll
+	for (int d = 0; d < 3; ++d) p.t[d][i] = nt[d];
+}
+}  // namespace
+
+/// The positions (key, t) of before a split move go to the other buffer's key / t arrays (free between a binning and the G2P, and
+/// after the materialisation at the start of a step), where lfa_collide and a download in between (old_position) find them.
+static int save_old_positions(lfa_sim *s, size_t n) {
+	if (!n) return LFA_OK;
+	ParticleSoA &cur = s->pb[s->cur], &oth = s->pb[s->cur ^ 1];
+	LFA_HIP(s, hipMemcpyAsync(oth.key, cur.key, n * 4, hipMemcpyDeviceToDevice, s->stream));
+	for (int d = 0; d < 3; ++d) LFA_HIP(s, hipMemcpyAsync(oth.t[d], cur.t[d], n * 4, hipMemcpyDeviceToDevice, s->stream));
+	return LFA_OK;
+}
+
+extern "C" int lfa_collide(lfa_sim *s) {
+	if (!s) return LFA_E_INVALID;
+	if (s->dist) return lfa_fail(s, LFA_E_UNSUPPORTED, "lfa_collide: slab decompositions collide inside lfa_advect_collide / lfa_correct_collide");
+	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_corr_commit(s));
+	const size_t n = s->binned ? s->np_live : s->np;
+	const bool pending = s->move_pending;
+	s->move_pending = false;
+	if (!n) return LFA_OK;
+	LFA_TRY(refresh_tile_clear(s));
+	ParticleSoA &cur = s->pb[s->cur], &oth = s->pb[s->cur ^ 1];
+	// nothing pending (an upload in between has replaced the particles): from = to, i.e. the skin push-out alone
+	hipLaunchKernelGGL(k_collide_only, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, cur,
+	                   pending ? (const uint32_t *)oth.key : (const uint32_t *)nullptr, pending ? (const float *)oth.t[0] : (const float *)nullptr,
+	                   pending ? (const float *)oth.t[1] : (const float *)nullptr, pending ? (const float *)oth.t[2] : (const float *)nullptr, s->g,
+	                   (const uint8_t *)s->solid, move_params(s, 0.0).skin);
+	LFA_LAUNCH_CHECK(s);
+	s->unknown_count_valid = false;
+	return LFA_OK;
+}
 
 /// The correction's scratch for the cell-ordered positions: four consecutive v / c arrays that are free between the binning and
 /// the G2P - the other buffer's v.. ; with a deferred binning, where the other buffer still holds the v (and for APIC the C)
@@ -1091,8 +1169,10 @@ static int correct_build_index(lfa_sim *s, bool exchange = true) {
 }
 
 /// Second half: the pairwise correction + collision; writes (key, t) in place.
-static int correct_apply(lfa_sim *s, double dt, bool migrate = true) {
+static int correct_apply(lfa_sim *s, double dt, bool migrate = true, bool with_collide = true) {
 	const size_t n = s->np_live;
+	MoveParams mpc = move_params(s, dt);
+	mpc.collide = with_collide ? 1 : 0;
 	ParticleSoA &cur = s->pb[s->cur], &oth = s->pb[s->cur ^ 1];
 	float4 *spos = correction_scratch(s);
 	if (n) {
@@ -1113,13 +1193,13 @@ static int correct_apply(lfa_sim *s, double dt, bool migrate = true) {
 			LFA_HIP(s, hipMemcpyAsync(oth.key, cur.key, n * 4, hipMemcpyDeviceToDevice, s->stream));
 			if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[41], s->stream));
 			hipLaunchKernelGGL(k_correct_fine, dim3(g2), dim3(CORR_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, cur.key, cur.t[0],
-			                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_count, s->fine_start, (const float4 *)spos, move_params(s, dt), ovf,
+			                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_count, s->fine_start, (const float4 *)spos, mpc, ovf,
 			                   (const uint8_t *)s->tile_clear);
 			LFA_LAUNCH_CHECK(s);
 			if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[42], s->stream));
 		}
 		hipLaunchKernelGGL(k_correct_collide, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, cur, cur.key, cur.t[0],
-		                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_count, s->fine_start, (const float4 *)spos, move_params(s, dt),
+		                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_count, s->fine_start, (const float4 *)spos, mpc,
 		                   (const uint32_t *)ovf, (const int *)s->tile_pslot, s->p_off, (const uint32_t *)oth.key);
 		LFA_LAUNCH_CHECK(s);
 	}
@@ -1136,6 +1216,25 @@ extern "C" int lfa_correct_collide(lfa_sim *s, double dt) {
 	if (!s->np_live && !s->dist) return LFA_OK;
 	LFA_TRY(correct_build_index(s));
 	return correct_apply(s, dt);
+}
+
+/// _correct_positions alone (src/simulation.cpp:562-610): the collision handling that follows it in time_step (:115) is left to
+/// lfa_collide, so that a host's post_correction_callback sits exactly where the reference has it (:111-117).
+extern "C" int lfa_correct(lfa_sim *s, double dt) {
+	if (!s) return LFA_E_INVALID;
+	if (!s->binned) return lfa_fail(s, LFA_E_INVALID, "lfa_correct: call lfa_hash_particles first");
+	if (s->dist) return lfa_fail(s, LFA_E_UNSUPPORTED, "lfa_correct: slab decompositions collide and migrate inside lfa_correct_collide");
+	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_corr_commit(s));
+	s->move_pending = false;
+	if (!s->np_live) return LFA_OK;
+	LFA_TRY(correct_build_index(s));
+	// the positions of before: the keys are copied by correct_apply itself (other buffer), the fractions here
+	ParticleSoA &cur = s->pb[s->cur], &oth = s->pb[s->cur ^ 1];
+	for (int d = 0; d < 3; ++d) LFA_HIP(s, hipMemcpyAsync(oth.t[d], cur.t[d], s->np_live * 4, hipMemcpyDeviceToDevice, s->stream));
+	LFA_TRY(correct_apply(s, dt, true, false));
+	s->move_pending = true;
+	return LFA_OK;
 }
 
 int lfa_corr_join(lfa_sim *s) {

@@ -16,9 +16,10 @@
 // edit made through the mutable references they return is detected (64-bit content hash) and uploaded before the next device
 // stage. The testbed's three callbacks (testbed/main.cpp:101-123: print dt, read the pressure vector, read the particles after
 // the step) therefore cost one n-double download and one particle download per step, not a PCIe round trip per stage.
-// Two callbacks see a slightly later state than in the reference because the device fuses the collision pass into the kernel
-// before it: post_advection_callback and post_correction_callback run AFTER the collision handling that follows them in
-// src/simulation.cpp:51-59,111-117 (no host in the reference tree installs either).
+// The device fuses the collision handling into the advection and the position correction; a host that installs
+// post_advection_callback or post_correction_callback gets the split stages instead (lfa_advect / lfa_correct, the callback,
+// lfa_collide), i.e. the callback sits exactly where src/simulation.cpp:51-59,111-117 has it and sees the moved, not yet
+// collided particles with old_position = the position of before the move (no host in the reference tree installs either).
 // The position correction - particle positions only - runs on a second HIP stream beside the pressure solve - grid only -
 // (`overlap_correction`, default on), in the staged step as well: callbacks between the P2G and the correction that read the
 // pressure or the grid never notice; one that asks for particles() or edits the solid cells there has the device take the
@@ -567,12 +568,17 @@ namespace fluid_amd {
 			return _flush_host_edits();
 		};
 		_in_step = true;
-		bool ok = stage(lfa_advect_collide(_dev, dt)) && after(post_advection_callback) &&
+		// (a host that installs post_advection_callback gets it where the reference has it, between the advection and its
+		// collision handling, simulation.cpp:50-59: the two device stages are then called separately)
+		bool ok = (post_advection_callback
+		               ? stage(lfa_advect(_dev, dt)) && after(post_advection_callback) && stage(lfa_collide(_dev))
+		               : stage(lfa_advect_collide(_dev, dt))) &&
 		          stage(lfa_hash_particles(_dev)) && (sources.empty() || stage(lfa_update_sources(_dev, nullptr))) &&
 		          stage(lfa_p2g(_dev)) && after(post_particle_to_grid_transfer_callback);
 		// From here to the correction the reference's stages touch the grid only (simulation.cpp:82-99): the correction starts now,
 		// on the second stream (see _corr_in_flight).
-		if (ok && overlap_correction) {
+		// (not with a post_correction_callback: the correction then runs where the reference has it, split from its collisions)
+		if (ok && overlap_correction && !post_correction_callback) {
 			ok = _ok(lfa_correct_collide_begin(_dev, dt));
 			_corr_in_flight = ok;
 		}
@@ -595,11 +601,13 @@ namespace fluid_amd {
 		if (ok && _corr_in_flight) {  // nobody has asked for it to be taken back: it is the reference's correction, finished early
 			_corr_in_flight = false;
 			ok = stage(lfa_correct_collide_end(_dev));
+		} else if (post_correction_callback) {  // _correct_positions -> callback -> _detect_collisions (simulation.cpp:111-117)
+			ok = ok && stage(lfa_correct(_dev, dt)) && after(post_correction_callback) && stage(lfa_collide(_dev));
 		} else {
 			ok = ok && stage(lfa_correct_collide(_dev, dt));
 		}
 		_corr_in_flight = false;
-		ok = ok && after(post_correction_callback) && stage(lfa_extrapolate(_dev)) && stage(lfa_g2p(_dev));
+		ok = ok && stage(lfa_extrapolate(_dev)) && stage(lfa_g2p(_dev));
 		_in_step = false;
 		if (ok && post_grid_to_particle_transfer_callback) {
 			post_grid_to_particle_transfer_callback(dt);

@@ -11,6 +11,9 @@
 //         window    a callback BETWEEN the P2G and the correction (post_apply_pressure) reads particles() and edits one: the class
 //                   has started the correction on the second stream by then and must take it back, exactly (prints the sum of
 //                   the x coordinates it saw: the positions of BEFORE the correction)
+//         placed    post_advection_callback and post_correction_callback installed (they read particles(): the sum of |position -
+//                   old_position| they saw is printed as "moved_advect <sum>" / "moved_correct <sum>" - non-zero only if the callback
+//                   sits between the move and its collision handling, as in src/simulation.cpp:51-59,111-117)
 //         obstacle  nocb, and the solid cells are only put in after the first step, then removed again before the last one
 //                   (the testbed's scene reset edits sim.grid() between steps, testbed/main.cpp:125-178)
 //         recreate  what the Maya node does per evaluation (plugins/maya/nodes/grid_node.cpp:256-274,350-366): `steps` times
@@ -154,6 +157,16 @@ int main(int argc, char **argv) {
 			std::printf("window_pos_sum %.9f\n", sum);
 			sim.particles()[0].velocity = sim.particles()[0].velocity * 0.5;
 		};
+	double moved_advect = 0.0, moved_correct = 0.0;
+	if (mode == "placed") {
+		auto moved = [&]() {
+			double sum = 0.0;
+			for (const simulation::particle &p : sim.particles()) sum += std::sqrt((p.position - p.old_position).squared_length());
+			return sum;
+		};
+		sim.post_advection_callback = [&](double) { moved_advect += moved(); };
+		sim.post_correction_callback = [&](double) { moved_correct += moved(); };
+	}
 	double wall_ms = 0.0;
 	int timed = 0;
 	for (int i = 0; i < steps; ++i) {
@@ -169,6 +182,7 @@ int main(int argc, char **argv) {
 			return 4;
 		}
 	}
+	if (mode == "placed") std::printf("moved_advect %.9g moved_correct %.9g\n", moved_advect, moved_correct);
 	std::printf("step_ms %.4f\n", timed ? wall_ms / timed : 0.0);
 	std::printf("cfl %.9g fluid type of cell0 %d\n", sim.cfl(), static_cast<int>(sim.grid().grid()[0].cell_type));
 	if (FILE *f = std::fopen(argv[9], "wb")) {

@@ -277,3 +277,20 @@ def test_block_cache_serves_a_second_handle_and_can_be_trimmed():
     s.close()
     lfa.pool_trim()
     assert lfa.pool_stats()["cached_bytes"] == 0
+
+
+@pytest.mark.gpu
+def test_advection_and_correction_callbacks_sit_where_the_reference_has_them(tmp_path):
+    """post_advection_callback / post_correction_callback (src/simulation.cpp:51-59,111-117) run between the move and its collision
+    handling: they see particles whose position differs from old_position (the device keeps the positions of before a split
+    move), and the step's result is that of the fused stages - the reference's particles after three steps."""
+    c, parts, solid = fullstep_inputs()
+    g = util.load_golden("fullstep_flip")
+    exe = build_driver(tmp_path)
+    out, stdout, _ = run_driver(tmp_path, exe, c, parts, solid, "placed")
+    m = re.search(r"moved_advect ([0-9.e+-]+) moved_correct ([0-9.e+-]+)", stdout)
+    moved_advect, moved_correct = float(m.group(1)), float(m.group(2))
+    assert moved_advect > 1.0 and moved_correct > 1e-3, stdout  # summed over 1 200 particles and three steps
+    out = by_id(out, len(parts))
+    util.assert_close(out["pos"], g["pos"], 1e-6, "positions after 3 steps with the two callbacks placed", atol=3e-4)
+    util.assert_close(out["vel"], g["vel"], 3e-4, "velocities after 3 steps with the two callbacks placed")

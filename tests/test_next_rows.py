@@ -79,6 +79,57 @@ def test_oracle_full_time_step_matches_golden():
 
 
 @pytest.mark.gpu
+def test_device_split_move_and_collide_stages_against_the_oracle():
+    """lfa_advect / lfa_correct / lfa_collide: the two moving stages with their collision handling split off, for hosts that
+    install post_advection_callback / post_correction_callback (src/simulation.cpp:50-59,111-117). In between, the device reports
+    what such a callback sees in the reference: the moved, not yet collided position and the position of before as old_position
+    (oracle: advect / correct_positions without detect_collisions); after lfa_collide: the fused stages' result (golden)."""
+    c, parts, solid = next_inputs()
+    g = util.load_golden("next_stages")
+    o = orc.CpuSim(c["size"], method=c["method"], blending=c["blend"])
+    o.set_solid_cells(solid)
+    o.set_particles(parts)
+    o.hash()
+    o.L.advect(o.h, DT_NEXT)
+    mid = by_id(o.particles())
+    s = lfa.Sim(c["size"], method=c["method"], blending=c["blend"])
+    s.set_solid_cells(solid)
+    s.upload_particles(parts)
+    s.advect(DT_NEXT)
+    out = s.download_particles(into=parts.copy(), write_positions=True)
+    assert np.abs(out["pos"] - mid["pos"]).max() < 2e-5
+    assert np.abs(out["old_pos"] - parts["pos"]).max() < 1e-6  # the position of before the move
+    assert np.abs(out["pos"] - g["after_advect_collide"]).max() > 1e-3  # (the scene does collide)
+    s.collide()
+    out = s.download_particles(into=parts.copy(), write_positions=True)
+    assert np.abs(out["pos"] - g["after_advect_collide"]).max() < 2e-5
+    assert np.array_equal(out["pos"], out["old_pos"])
+    # correction
+    o.set_particles(parts)
+    o.hash()
+    o.L.correct_positions(o.h, DT_CORR)
+    mid = by_id(o.particles())
+    o.close()
+    s.upload_particles(parts)
+    s.hash()
+    s.correct(DT_CORR)
+    out = s.download_particles(into=parts.copy(), write_positions=True)
+    assert np.abs(out["pos"] - mid["pos"]).max() < 5e-5
+    assert np.abs(out["old_pos"] - parts["pos"]).max() < 1e-6
+    s.collide()
+    out = s.download_particles(into=parts.copy(), write_positions=True)
+    assert np.abs(out["pos"] - g["after_correct_collide"]).max() < 5e-5
+    # an upload between the move and lfa_collide replaces the particles: the collision pass starts from the uploaded positions
+    s.upload_particles(parts)
+    s.advect(DT_NEXT)
+    s.upload_particles(parts)
+    s.collide()
+    out = s.download_particles(into=parts.copy(), write_positions=True)
+    assert np.abs(out["pos"] - parts["pos"]).max() < 0.11  # at most the skin push-out (boundary_skin_width 0.1)
+    s.close()
+
+
+@pytest.mark.gpu
 def test_device_advect_collide_and_correct_collide():
     c, parts, solid = next_inputs()
     g = util.load_golden("next_stages")
