@@ -178,6 +178,12 @@ struct lfa_sim {
 	uint32_t *vc_src = nullptr;             // index in pb[cur ^ 1] of the particle now at i (valid while vc_pending)
 	bool vc_pending = false;
 	bool vmax2_valid = false;               // pcg_state[7] holds max |v|^2 of the particles (written by the last G2P, nothing has touched v since)
+	// PIC / FLIP never change C (their P2G does not read it, their G2P does not write it; the hosts' particle records carry it
+	// through): instead of moving 36 bytes per particle with every binning, C is parked in a HOME array indexed by the particle
+	// id (stable; single domain) and only a download, a change to APIC or an attach to slabs brings it back (core.hip: c_home_*)
+	float *c_home = nullptr;                // [9][c_home_cap]
+	size_t c_home_cap = 0;
+	bool c_home_valid = false;              // C lives in c_home (the c arrays of both particle buffers are scratch)
 	bool vc_with_c = false;                 // C is deferred as well (APIC); PIC / FLIP move C with the particle and defer v only
 	uint8_t *tile_clear = nullptr;          // [nt] no solid cell within one tile (+ [nt] scratch: tile holds a solid cell)
 	unsigned clear_epoch = 0;               // solid_epoch tile_clear was computed for
@@ -325,6 +331,8 @@ int lfa_exclusive_scan_u32(lfa_sim *s, const uint32_t *in, uint32_t *out, size_t
 int lfa_particles_alloc(lfa_sim *s, size_t n);
 int lfa_hash_particles_impl(lfa_sim *s, bool counts_done);  // counts_done: tile_count / rank already hold pass 1 (lfa_time_step)
 int lfa_particles_materialize(lfa_sim *s);  // completes a deferred binning (no-op otherwise)
+int lfa_c_home_restore(lfa_sim *s);         // C back from its home array into the current buffer (no-op unless c_home_valid)
+int lfa_c_home_ensure(lfa_sim *s, size_t n);  // capacity of the home array (keeps the entries of the resident particles)
 int lfa_ensure_io(lfa_sim *s, size_t bytes);
 int lfa_pcg_alloc(lfa_sim *s);
 int lfa_number_unknowns(lfa_sim *s);

@@ -1,6 +1,8 @@
 // libfluid_amd/csrc/core.hip -- handle lifetime, parameters, device scan, particle/grid boundary conversion and the
 // particle binning stage (reference rows a1, a2, a21, a22 of SURVEY.md section 8).
 #include <math.h>
+
+#include <algorithm>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -282,7 +284,7 @@ extern "C" void lfa_destroy(lfa_sim *s) {
 	lfa_pool_nosync_begin();
 	free_soa(s->pb[0]);
 	free_soa(s->pb[1]);
-	void *ptrs[] = {s->fine_start, s->corr_ovf, s->tile_clear, s->tile_epoch, s->src_cell, s->src_lo, s->src_target, s->src_of, s->src_need, s->src_vel, s->coerce_map, s->grid_flag, s->rank, s->vc_src, s->tile_count, s->tile_start, s->tile_flag, s->tile_scan, s->ptiles_all, s->dtiles, s->halo_tiles, s->dist_red,
+	void *ptrs[] = {s->c_home, s->fine_start, s->corr_ovf, s->tile_clear, s->tile_epoch, s->src_cell, s->src_lo, s->src_target, s->src_of, s->src_need, s->src_vel, s->coerce_map, s->grid_flag, s->rank, s->vc_src, s->tile_count, s->tile_start, s->tile_flag, s->tile_scan, s->ptiles_all, s->dtiles, s->halo_tiles, s->dist_red,
 	                s->xbuf[0], s->xbuf[1], s->xbuf[2], s->xbuf[3],
 	                s->tile_pslot, s->scan_tmp, s->u, s->v, s->w, s->uo, s->vo, s->wo, s->ctype, s->solid,
 	                s->cell_count, s->stage, s->acc, s->abits, s->vp, s->vr, s->vz, s->vs, s->vpre, s->vq, s->vs2, s->c_as, s->nbr_table,
@@ -339,7 +341,10 @@ extern "C" int lfa_set_params(lfa_sim *s, const lfa_params *p) {
 	// (a rejected call has no side effects: everything above only reads). An unchanged parameter block - what the host class sends
 	// before every step - leaves a correction in flight alone.
 	if (memcmp(p, &s->prm, sizeof(lfa_params)) != 0) LFA_TRY(lfa_corr_commit(s));
-	if (p->simulation_method != s->prm.simulation_method) LFA_TRY(lfa_particles_materialize(s));  // what is deferred depends on it
+	if (p->simulation_method != s->prm.simulation_method) {
+		LFA_TRY(lfa_particles_materialize(s));  // what is deferred depends on it
+		if (p->simulation_method == LFA_APIC) LFA_TRY(lfa_c_home_restore(s));  // APIC reads and writes C in particle order
+	}
 	if (p->pcg_dtype != s->prm.pcg_dtype || p->precond != s->prm.precond) {
 		s->system_valid = false;
 		s->pressure_epoch = 0;  // vp is about to be reinterpreted / re-allocated: no warm start from it
@@ -496,6 +501,7 @@ __global__ void k_ingest(const double *aos, size_t n, ParticleSoA p, GridDims g,
 extern "C" int lfa_upload_particles(lfa_sim *s, const void *aos152, uint64_t n) {
 	if (!s || (!aos152 && n)) return LFA_E_INVALID;
 	s->vc_pending = false;  // the particle set is replaced
+	s->c_home_valid = false;
 	s->move_pending = false;
 	s->vmax2_valid = false;
 	if (!(s->prm.cell_size > 0.0)) return lfa_fail(s, LFA_E_INVALID, "set cell_size (lfa_set_params) before uploading");
@@ -536,7 +542,7 @@ __global__ void k_export_ids(const uint32_t *key, const uint32_t *id, const uint
 /// `old`: lfa_advect / lfa_correct have moved the particles and lfa_collide is still due - old_position is the position of before
 /// the move (what a host callback between the two stages sees in the reference), kept in old.key / old.t.
 __global__ void k_export(double *aos, size_t n, ParticleSoA p, GridDims g, IngestParams ip, int flags, int by_slot, const uint32_t *slot,
-                         ParticleSoA old, int have_old) {
+                         ParticleSoA old, int have_old, const float *c_home, size_t c_home_stride) {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	uint32_t b = p.key[i];
@@ -565,7 +571,7 @@ __global__ void k_export(double *aos, size_t n, ParticleSoA p, GridDims g, Inges
 #pragma unroll
 	for (int k = 0; k < 3; ++k) q[3 + k] = (double)p.v[k][i];
 #pragma unroll
-	for (int k = 0; k < 9; ++k) q[6 + k] = (double)p.c[k][i];
+	for (int k = 0; k < 9; ++k) q[6 + k] = (double)(c_home ? c_home[k * c_home_stride + p.id[i]] : p.c[k][i]);
 	if (!(flags & LFA_DL_KEEP_RAW)) ((uint64_t *)q)[18] = raw_from_blocked(g, b);
 }
 
@@ -607,7 +613,8 @@ extern "C" int lfa_download_particles(lfa_sim *s, void *aos152, uint64_t n, int 
 	ip.h = s->prm.cell_size;
 	hipLaunchKernelGGL(k_export, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, (double *)s->io_buf,
 	                   s->np_live, s->pb[s->cur], s->g, ip, flags, s->dist ? 1 : 0, slot, s->pb[s->cur ^ 1],
-	                   (s->move_pending && !s->dist) ? 1 : 0);
+	                   (s->move_pending && !s->dist) ? 1 : 0, s->c_home_valid ? (const float *)s->c_home : (const float *)nullptr,
+	                   s->c_home_cap);
 	LFA_LAUNCH_CHECK(s);
 	LFA_HIP(s, hipMemcpyAsync(aos152, s->io_buf, n * 152, hipMemcpyDeviceToHost, s->stream));
 	LFA_HIP(s, hipStreamSynchronize(s->stream));
@@ -702,6 +709,7 @@ extern "C" int lfa_seed_block(lfa_sim *s, const int64_t lo[3], const int64_t hi[
 	LFA_TRY(lfa_particles_alloc(s, n));
 	s->np = n;
 	s->np_live = n;
+	s->c_home_valid = false;
 	s->vmax2_valid = false;
 	s->binned = false;
 	s->grid_valid = false;
@@ -927,6 +935,21 @@ __global__ void k_tile_scatter(size_t n, ParticleSoA src, ParticleSoA dst, const
 		for (int k = 0; k < 9; ++k) dst.c[k][d] = src.c[k][i];
 	}
 }
+/// C to / from its home array (indexed by particle id): see lfa_sim::c_home.
+__global__ void k_c_to_home(size_t n, ParticleSoA p, float *home, size_t stride) {
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n || p.key[i] == 0xFFFFFFFFu) return;
+	const size_t j = p.id[i];
+#pragma unroll
+	for (int k = 0; k < 9; ++k) home[k * stride + j] = p.c[k][i];
+}
+__global__ void k_c_from_home(size_t n, ParticleSoA p, const float *home, size_t stride) {
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n || p.key[i] == 0xFFFFFFFFu) return;
+	const size_t j = p.id[i];
+#pragma unroll
+	for (int k = 0; k < 9; ++k) p.c[k][i] = home[k * stride + j];
+}
 /// The deferred half: v, C of the particle now at d from where it was before the binning.
 __global__ void k_gather_vc(size_t n, ParticleSoA old, ParticleSoA cur, const uint32_t *from, int with_c) {
 	size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -991,6 +1014,34 @@ static int compact_tiles(lfa_sim *s, const uint32_t *flag, int lo, int hi, int *
 	LFA_HIP(s, hipMemcpyAsync(s->h_pinned, total, 4, hipMemcpyDeviceToHost, s->stream));
 	LFA_HIP(s, hipStreamSynchronize(s->stream));
 	*count = (int)s->h_pinned[0];
+	return LFA_OK;
+}
+
+int lfa_c_home_ensure(lfa_sim *s, size_t n) {
+	if (n <= s->c_home_cap) return LFA_OK;
+	const size_t cap = ((n + n / 8) + 1023) & ~(size_t)1023;
+	float *nh = nullptr;
+	LFA_HIP(s, hipMalloc(&nh, cap * 9 * sizeof(float)));
+	if (s->c_home && s->c_home_valid && s->np_live)
+		for (int k = 0; k < 9; ++k)
+			LFA_HIP(s, hipMemcpyAsync(nh + (size_t)k * cap, s->c_home + (size_t)k * s->c_home_cap, std::min(s->np_live, s->c_home_cap) * 4,
+			                          hipMemcpyDeviceToDevice, s->stream));
+	if (s->c_home) {
+		LFA_HIP(s, hipStreamSynchronize(s->stream));
+		LFA_HIP(s, hipFree(s->c_home));
+	}
+	s->c_home = nh;
+	s->c_home_cap = cap;
+	return LFA_OK;
+}
+int lfa_c_home_restore(lfa_sim *s) {
+	if (!s->c_home_valid) return LFA_OK;
+	s->c_home_valid = false;
+	const size_t n = s->binned ? s->np_live : s->np;
+	if (!n) return LFA_OK;
+	hipLaunchKernelGGL(k_c_from_home, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, s->pb[s->cur], (const float *)s->c_home,
+	                   s->c_home_cap);
+	LFA_LAUNCH_CHECK(s);
 	return LFA_OK;
 }
 
@@ -1091,10 +1142,22 @@ int lfa_hash_particles_impl(lfa_sim *s, bool counts_done) {
 		// new order (the slab migration, which packs whole records, completes the move first)
 		// PIC and FLIP carry C through the step unchanged (the reference's G2P does not touch it), so there C travels with the
 		// particle and only v stays behind
-		const int defer = getenv("LFA_FULL_SCATTER") ? 0 : (s->prm.simulation_method == LFA_APIC ? 1 : 2);
+		int defer = getenv("LFA_FULL_SCATTER") ? 0 : (s->prm.simulation_method == LFA_APIC ? 1 : 2);
 		const dim3 sgrid((unsigned)((n + 255) / 256));
+		// PIC / FLIP, single domain: C goes to its home array once and stays there - the scatter then moves key, t, id alone, like
+		// APIC's (LFA_C_TRAVELS=1: the round-2 behaviour, C moves with every binning)
+		const bool home = defer == 2 && !s->dist && !getenv("LFA_C_TRAVELS");
+		if (home && !s->c_home_valid) {
+			LFA_TRY(lfa_c_home_ensure(s, s->pcap));
+			hipLaunchKernelGGL(k_c_to_home, sgrid, dim3(256), 0, s->stream, n, src, s->c_home, s->c_home_cap);
+			LFA_LAUNCH_CHECK(s);
+			s->c_home_valid = true;
+		} else if (!home && s->c_home_valid) {  // the method has changed to APIC, or the handle has joined a slab decomposition
+			LFA_TRY(lfa_c_home_restore(s));
+		}
+		if (home) defer = 3;
 		const int shuffle = (!s->binned || getenv("LFA_BIN_SHUFFLE")) ? 1 : 0;
-		if (defer == 1)
+		if (defer == 1 || defer == 3)
 			hipLaunchKernelGGL(k_tile_scatter<1>, sgrid, dim3(256), 0, s->stream, n, src, dst, s->rank, s->tile_start, s->tile_count,
 			                   shuffle, s->vc_src);
 		else if (defer == 2)

@@ -679,6 +679,10 @@ int attach(lfa_sim *s, lfa_dist *d, const int32_t *bounds) {
 		delete d;
 		return lfa_fail(s, LFA_E_INVALID, "layer bounds must partition [0,%d) into non-empty slabs", s->g.ntz);
 	}
+	if (lfa_c_home_restore(s) < 0) {  // particles migrate between ranks with their C: it travels with the record on slabs
+		delete d;
+		return LFA_E_HIP;
+	}
 	if (s->dist) delete s->dist;
 	s->dist = d;
 	// the multigrid levels whose tile layers do not straddle a slab face stay distributed (mg.hip)

@@ -131,6 +131,8 @@ struct MoveParams {
 	double skin;        // boundary_skin_width / cell_size
 	double corr;        // dt * correction_stiffness * re / cell_size   (re = cell_size / sqrt 2)
 	double inv_re2;     // cell_size^2 / re^2 = 2
+	float *c_home;      // non-null: C lives in its home array, [9][c_home_stride] indexed by the particle id (lfa_sim::c_home)
+	size_t c_home_stride;
 	int collide;        // 1: the collision handling that follows the move in the reference runs inside the kernel (the default); 0: the
 	                    // caller runs it later (lfa_collide), after a host callback that sits between the two in simulation::time_step
 };
@@ -182,8 +184,14 @@ __device__ inline uint32_t advect_one(size_t i, const ParticleSoA &p, const Grid
 				vel[d] = src_vel[3 * (src - 1) + d];
 				p.v[d][i] = vel[d];
 			}
+			if (mp.c_home) {
+				const size_t j = p.id[i];
 #pragma unroll
-			for (int k = 0; k < 9; ++k) p.c[k][i] = 0.0f;
+				for (int k = 0; k < 9; ++k) mp.c_home[k * mp.c_home_stride + j] = 0.0f;
+			} else {
+#pragma unroll
+				for (int k = 0; k < 9; ++k) p.c[k][i] = 0.0f;
+			}
 		}
 	}
 	double from[3], to[3];
@@ -801,6 +809,8 @@ static MoveParams move_params(const lfa_sim *s, double dt) {
 	mp.corr = dt * s->prm.correction_stiffness * re / h;
 	mp.inv_re2 = h * h / (re * re);
 	mp.collide = 1;
+	mp.c_home = s->c_home_valid ? s->c_home : nullptr;
+	mp.c_home_stride = s->c_home_cap;
 	return mp;
 }
 
@@ -997,6 +1007,11 @@ extern "C" int lfa_update_sources(lfa_sim *s, uint64_t *n_seeded) {
 	const size_t base = s->np_live;
 	LFA_TRY(lfa_particles_materialize(s));  // the new particles bring their own v / C: a deferred binning is completed first
 	LFA_TRY(lfa_particles_reserve(s, base, base + total));  // keeps the live records
+	if (s->c_home_valid) {  // the new particles get the ids base .. base + total - 1 and C = 0
+		LFA_TRY(lfa_c_home_ensure(s, base + total));
+		for (int k = 0; k < 9; ++k)
+			LFA_HIP(s, hipMemsetAsync(s->c_home + (size_t)k * s->c_home_cap + base, 0, total * 4, s->stream));
+	}
 	++s->source_epoch;
 	hipLaunchKernelGGL(k_source_seed, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, (const uint32_t *)s->src_cell,
 	                   (const uint32_t *)s->src_of, (const uint32_t *)s->src_need, (const uint32_t *)off, n, (const float *)s->src_vel,

@@ -553,3 +553,65 @@ def test_multigrid_single_launch_coarse_levels_repeat_bitwise_over_many_solves()
             ref = (it, p)
         assert it == ref[0] and np.array_equal(p, ref[1])
     s.close()
+
+
+@pytest.mark.parametrize("method", [lfa.FLIP_BLEND, lfa.PIC])
+def test_pic_flip_keep_c_in_its_home_array_through_steps_sources_and_a_change_to_apic(method, monkeypatch):
+    """PIC / FLIP never change C (src/simulation.cpp:336-341,515-556: their transfers neither read nor write cx, cy, cz), the
+    hosts' records just carry it. The device parks it in an array indexed by the particle id instead of moving 36 bytes per
+    particle with every binning (lfa_sim::c_home). What must hold: a download returns every particle's C unchanged after full
+    steps; a coercing source zeroes the C of the particles in its cells and the particles it seeds have C = 0; a change to APIC
+    finds the C where APIC reads it. Each against the same run with C travelling with the particle (LFA_C_TRAVELS=1)."""
+    size = (24, 24, 24)
+    parts = util.scenes.seed_block((2, 2, 2), (14, 16, 12))
+    rng = np.random.default_rng(11)
+    for k in ("cx", "cy", "cz"):
+        parts[k] = rng.normal(size=(len(parts), 3)).astype(np.float32)  # exactly representable on the device
+    cells = np.array([(x, y, z) for x in (3, 4) for y in (3, 4, 5) for z in (3, 4)], dtype=np.int32)
+    runs = []
+    for travels in (False, True):
+        if travels:
+            monkeypatch.setenv("LFA_C_TRAVELS", "1")
+        else:
+            monkeypatch.delenv("LFA_C_TRAVELS", raising=False)
+        s = lfa.Sim(size, method=method, blending=0.95)
+        s.upload_particles(parts)
+        rec = []
+        for _ in range(3):
+            res, it, rc = s.time_step(0.004)
+            assert rc == 0
+        out = s.download_particles(into=parts.copy(), write_positions=True)
+        for k in ("cx", "cy", "cz"):
+            assert np.array_equal(out[k], parts[k]), k  # downloads come out in upload order (single domain)
+        rec.append(out)
+        # a coercing source that also seeds
+        s.add_source(cells, velocity=(30.0, 0.0, 5.0), density_cubic_root=3, active=True, coerce_velocity=True)
+        for _ in range(2):
+            res, it, rc = s.time_step(0.004)
+            assert rc == 0
+        n = s.num_particles
+        assert n > len(parts)
+        out = s.download_particles(into=np.zeros(n, dtype=lfa.PARTICLE_DTYPE), write_positions=True)
+        old, new = out[:len(parts)], out[len(parts):]
+        assert np.abs(np.concatenate([new["cx"], new["cy"], new["cz"]], axis=1)).max() == 0.0
+        zeroed = np.abs(np.concatenate([old["cx"], old["cy"], old["cz"]], axis=1)).max(axis=1) == 0.0
+        assert 0 < zeroed.sum() < len(parts)
+        kept = ~zeroed
+        assert np.array_equal(old["cx"][kept], parts["cx"][kept])
+        rec.append(out)
+        # on to APIC: its P2G reads C in particle order
+        s.clear_sources()
+        s.set_params(simulation_method=lfa.APIC)
+        res, it, rc = s.time_step(0.004)
+        assert rc == 0
+        rec.append(s.download_particles(into=np.zeros(n, dtype=lfa.PARTICLE_DTYPE), write_positions=True))
+        s.close()
+        runs.append(rec)
+    for stage, (a, b) in enumerate(zip(*runs)):
+        for k in ("cx", "cy", "cz"):
+            if stage < 2:
+                assert np.array_equal(a[k], b[k]), k
+            else:  # the APIC step has rewritten C from a grid its P2G built out of the C it found: same up to summation order
+                assert np.abs(a[k] - b[k]).max() <= 1e-4 * np.abs(b[k]).max(), k
+        # (positions / velocities differ by the summation order of a binning ordered by atomics, nothing else)
+        assert np.abs(a["pos"] - b["pos"]).max() < 1e-3 and np.abs(a["vel"] - b["vel"]).max() < 0.5
