@@ -19,7 +19,8 @@ NAMES = {"k_pcg_a<float, false, true>": "pcg_a", "k_pcg_b<float, true>": "pcg_b"
          "k_p2g_finalize<true>": "p2g_finalize", "k_p2g_finalize<false>": "p2g_finalize", "k_g2p<2>": "g2p",
          "k_g2p<1>": "g2p", "k_g2p<0>": "g2p", "k_g2p<2, true>": "g2p", "k_g2p<1, true>": "g2p", "k_g2p<0, true>": "g2p",
          "k_tile_scatter": "bin_scatter", "k_tile_scatter<true>": "bin_scatter", "k_tile_scatter<false>": "bin_scatter", "k_gather_vc": "bin_deferred_gather", "k_tile_count": "bin_count", "k_cell_count": "bin_cells",
-         "k_mg_axpy_presmooth<float>": "mg_axpy_presmooth", "k_mg_prolong_postsmooth<float, true>": "mg_up0", "k_mg_tail<float>": "mg_tail"}
+         "k_mg_axpy_presmooth<float>": "mg_axpy_presmooth", "k_mg_axpy_presmooth<float, 4>": "mg_axpy_presmooth", "k_mg_axpy_presmooth<float, 1>": "mg_axpy_presmooth",
+         "k_mg_prolong_postsmooth<float, true, 1>": "mg_up0", "k_mg_coarse<float>": "mg_coarse", "k_mg_prolong_postsmooth<float, true>": "mg_up0", "k_mg_tail<float>": "mg_tail"}
 
 
 def load(path, counter):

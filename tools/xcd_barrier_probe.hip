@@ -35,7 +35,9 @@ template <int MODE> __device__ inline unsigned get(unsigned *p) {
 
 template <int MODE> __device__ inline void grid_barrier(unsigned *counter, unsigned target) {
 	if (MODE == 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-	else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt: this thread's stores have been acknowledged
+	// this thread's stores have been acknowledged (the compiler does NOT put a vmcnt wait in front of s_barrier by itself, and a
+	// workgroup-scope release fence emits none either: checked in the ISA)
+	else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		if (MODE == 3) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
