@@ -165,7 +165,7 @@ struct lfa_sim {
 	double last_residual = 0.0;
 	uint64_t last_iters = 0;
 	// lfa_get_solver_stats
-	uint64_t stat_launches_iter = 0, stat_transport_iter = 0, stat_transport_solve = 0, stat_mg_levels = 0, stat_mg_first_co = 0;
+	uint64_t stat_launches_iter = 0, stat_transport_iter = 0, stat_transport_solve = 0, stat_mg_levels = 0, stat_mg_first_co = 0, stat_whole_solve = 0;
 	// warm start of the PCG (lfa_params.pcg_warm_start)
 	uint32_t *tile_epoch = nullptr;   // [nt] solve counter of the last solve a tile took part in
 	uint32_t solve_epoch = 0;         // counter of system builds

@@ -75,6 +75,7 @@ struct lfa_mg {
 	uint8_t *l1_dirty = nullptr;  // device, per level-1 tile: a child tile was flagged at the last set-up (k_mg_types_from_fine_dirty)
 	unsigned solid_epoch = 0;     // solid mask the level-1 types were computed for
 	uint32_t *counts = nullptr;   // device, active tiles per level (single-domain set-up, read back once)
+	double *ps_part = nullptr;    // k_pcg_small: [3][PS_MAX_TILES] partials, then (as unsigned) [2][PS_MAX_TILES] their tags
 	unsigned co_tag = 0;          // k_mg_coarse: launch counter = the value its ready flags are raised to (lfa_mg_level::ready)
 	unsigned long long *co_stamps = nullptr;  // LFA_MG_CO_STAMPS=1: phase stamps of the last k_mg_coarse launch, printed by lfa_mg_free
 	int co_phases = 0;
@@ -919,12 +920,26 @@ template <typename real> struct MgCo {
 	unsigned long long *stamps;  // LFA_MG_CO_STAMPS=1 (debugging): workgroup 0 records the 100 MHz clock around its phases
 };
 
+/// Back-off of a polling thread: 64 clocks at first, doubling to 8 K clocks. A producer may be late by far more than a phase -
+/// its workgroup may not even be resident yet while another kernel's workgroups hold the CUs (the position correction on its own
+/// stream) - and a few hundred workgroups re-reading the same words every 64 clocks starve exactly the kernel they wait for
+/// (measured: 1.3 s per C2 step with every thread of k_pcg_small's reductions polling without back-off).
+__device__ inline void co_backoff(int &n) {
+	if (n < 2) __builtin_amdgcn_s_sleep(1);
+	else if (n < 4) __builtin_amdgcn_s_sleep(4);
+	else if (n < 8) __builtin_amdgcn_s_sleep(16);
+	else if (n < 16) __builtin_amdgcn_s_sleep(64);
+	else __builtin_amdgcn_s_sleep(127);
+	++n;
+}
 /// All threads: waits until every tile in dep[0 .. n) (n <= 8; -1 entries are skipped) carries this launch's tag in `flag`.
 __device__ inline void co_wait(const unsigned *flag, const int *dep, int n, unsigned tag) {
 	if ((int)threadIdx.x < n) {
 		const int d = dep[threadIdx.x];
-		if (d >= 0)
-			while (__hip_atomic_load(flag + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) __builtin_amdgcn_s_sleep(1);
+		if (d >= 0) {
+			int tries = 0;
+			while (__hip_atomic_load(flag + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) co_backoff(tries);
+		}
 	}
 	__syncthreads();
 }
@@ -935,33 +950,125 @@ __device__ inline void co_post(unsigned *flag, int tile, unsigned tag) {
 	if (threadIdx.x == 0) __hip_atomic_store(flag + tile, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+/// Per-thread constants of the dataflow kernels: the two cells of a thread are column (qx, qy), z = 2 j and 2 j + 1.
+struct CoThread {
+	int t, wg, qx, qy, qj, c0, c1, h0, h1;
+	__device__ inline CoThread() {
+		t = threadIdx.x; wg = blockIdx.x;
+		qx = t & 7; qy = (t >> 3) & 7; qj = t >> 6;
+		c0 = qx + 8 * qy + 128 * qj; c1 = c0 + 64;
+		h0 = (qx + 1) + 10 * (qy + 1) + 100 * (2 * qj + 1); h1 = h0 + 100;
+	}
+};
+/// One half sweep of colour `colour` on the halo block H with the coefficients of the thread's two cells.
 template <typename real>
-__global__ void __launch_bounds__(256) k_mg_coarse(MgCo<real> P, const int *state) {
-	extern __shared__ unsigned char co_smem[];
-	__shared__ int dep[8];
-	const int t = threadIdx.x, wg = blockIdx.x, nlev = P.last - P.first + 1;
-	CoLevel<real> *st = (CoLevel<real> *)co_smem;
-	real *R = (real *)(st + nlev);
-	const unsigned tag = P.tag;
-	int n_stamp = 0;
-	auto stamp = [&]() {
-		if (P.stamps && wg == 0 && t == 0) P.stamps[n_stamp] = wall_clock64();
-		++n_stamp;
-	};
-	stamp();
-	// the two cells of a thread: column (qx, qy), z = 2 j and 2 j + 1
-	const int qx = t & 7, qy = (t >> 3) & 7, qj = t >> 6;
-	const int c0 = qx + 8 * qy + 128 * qj, c1 = c0 + 64, h0 = (qx + 1) + 10 * (qy + 1) + 100 * (2 * qj + 1), h1 = h0 + 100;
-	int lmax = P.first - 1;  // deepest level this workgroup owns a tile of
-	for (int l = P.first; l <= P.last; ++l)
-		if (wg < P.lv[l].n_tiles) lmax = l;
-	// ---- static data of every level, before anything is waited for: two dependent round trips in all (rows of the neighbour
-	// tables together with the solver state; then every level's A bytes and the first level's right-hand side, all loads in
-	// flight before the first of them is used)
+__device__ inline void co_half_sweep(const CoThread &T, real *H, uint32_t a0, uint32_t a1, real b0, real b1, int colour) {
+	const int k = (T.qx + T.qy + colour) & 1;
+	gs_cell<real>(H, k ? a1 : a0, k ? b1 : b0, k ? T.h1 : T.h0);
+	__syncthreads();
+}
+/// Residual b - A x of the thread's two cells from the halo block (unscaled operator), term by term as cp_residual_restrict_tile.
+template <typename real> __device__ inline real co_residual_cell(const real *H, uint32_t a, real b, int i) {
+	real r = (real)0;
+	if (a & AB_UNKNOWN) {
+		const real F = (a & AB_FLUID) ? (real)1 : (real)0;
+		real val = (real)(a & 7) * H[i];
+		val -= F * H[i - 1];
+		val -= F * H[i - 10];
+		val -= F * H[i - 100];
+		val -= (real)((a >> 3) & 1) * H[i + 1];
+		val -= (real)((a >> 4) & 1) * H[i + 10];
+		val -= (real)((a >> 5) & 1) * H[i + 100];
+		r = b - val;
+	}
+	return r;
+}
+/// Restriction of the residuals in R (512 cells of tile `tile` of level grid g) to its share of the parent level's right-hand
+/// side: half the sum over the 8 children, in the order of the pair sums and the two shuffle steps of residual_restrict_tile.
+template <typename real>
+__device__ inline void co_restrict_store(const CoThread &T, const real *R, const GridDims &g, const GridDims &gc, int tile, real *b_coarse) {
+	if (T.t < 64) {
+		const int X = T.t & 3, Y = (T.t >> 2) & 3, Z = T.t >> 4;
+		auto pair = [&](int x, int y) { real p = R[x + 8 * y + 64 * (2 * Z)]; p += R[x + 8 * y + 64 * (2 * Z + 1)]; return p; };
+		real v = pair(2 * X, 2 * Y);
+		v += pair(2 * X + 1, 2 * Y);
+		real w = pair(2 * X, 2 * Y + 1);
+		w += pair(2 * X + 1, 2 * Y + 1);
+		v += w;
+		int tx, ty, tz;
+		tile_coords(g, tile, tx, ty, tz);
+		const int ptile = (tx >> 1) + gc.ntx * ((ty >> 1) + gc.nty * (tz >> 1));
+		MemAgent::st(b_coarse + (size_t)ptile * 512 + ((tz & 1) * 4 + Z) * 64 + ((ty & 1) * 4 + Y) * 8 + (tx & 1) * 4 + X, (real)0.5 * v);
+	}
+}
+/// dep[0..8) = the active child tiles (level below, grid gf) of `tile` (grid g), -1 where there is none.
+__device__ inline void co_child_deps(const CoThread &T, int *dep, const GridDims &g, const GridDims &gf, int tile, int child_mask) {
+	if (T.t < 8) {
+		int tx, ty, tz;
+		tile_coords(g, tile, tx, ty, tz);
+		const int cx = 2 * tx + (T.t & 1), cy = 2 * ty + ((T.t >> 1) & 1), cz = 2 * tz + (T.t >> 2);
+		dep[T.t] = ((child_mask >> T.t) & 1) ? cx + gf.ntx * (cy + gf.nty * cz) : -1;
+	}
+	__syncthreads();
+}
+/// dep[0..7) = the parent tiles (grid gc) of the six neighbour tiles and of the tile itself (nb[0..7) of a level with grid g).
+__device__ inline void co_parent_deps(const CoThread &T, int *dep, const GridDims &g, const GridDims &gc, const int *nb) {
+	if (T.t < 7) {
+		const int src = nb[T.t];
+		int d = -1;
+		if (src >= 0) {
+			int sx, sy, sz;
+			tile_coords(g, src, sx, sy, sz);
+			d = (sx >> 1) + gc.ntx * ((sy >> 1) + gc.nty * (sz >> 1));
+		}
+		dep[T.t] = d;
+	}
+	__syncthreads();
+}
+/// x += P e on the thread's two cells and on the ring cells that are unknowns of an active neighbour (cp_prolong_postsmooth_tile).
+template <typename real>
+__device__ inline void co_add_correction(const CoThread &T, real *H, uint32_t a0, uint32_t a1, const uint8_t *rab, const int *nb,
+                                         const GridDims &g, const GridDims &gc, int tile, const real *e) {
+	int tx, ty, tz;
+	tile_coords(g, tile, tx, ty, tz);
+	{
+		// cells z = 2 j and 2 j + 1 of a column share their parent
+		const real corr = MemAgent::ld(e + blocked_index(gc, (tx * 8 + T.qx) >> 1, (ty * 8 + T.qy) >> 1, (tz * 8 + 2 * T.qj) >> 1));
+		if (a0 & AB_UNKNOWN) H[T.h0] = H[T.h0] + corr;
+		if (a1 & AB_UNKNOWN) H[T.h1] = H[T.h1] + corr;
+	}
+	for (int r = T.t; r < 384; r += 256) {
+		int f, hidx, ncell, dx, dy, dz;
+		cp_ring(r, f, hidx, ncell, dx, dy, dz);
+		if (nb[f] >= 0 && (rab[r] & AB_UNKNOWN))
+			H[hidx] = H[hidx] + MemAgent::ld(e + blocked_index(gc, (tx * 8 + dx) >> 1, (ty * 8 + dy) >> 1, (tz * 8 + dz) >> 1));
+	}
+	__syncthreads();
+}
+/// Ring of the halo block from the neighbour tiles' values in `v` (inactive neighbours: the ring keeps its zeros).
+template <typename real> __device__ inline void co_load_ring(const CoThread &T, real *H, const int *nb, const real *v) {
+	for (int r = T.t; r < 384; r += 256) {
+		int f, hidx, ncell, dx, dy, dz;
+		cp_ring(r, f, hidx, ncell, dx, dy, dz);
+		const int n = nb[f];
+		if (n >= 0) H[hidx] = MemAgent::ld(v + (size_t)n * 512 + ncell);
+	}
+	__syncthreads();
+}
+
+/// Static data of levels P.first .. lmax into st[] (LDS): neighbour-table rows, A bytes of the own tile and of its ring; the
+/// halo blocks are cleared. Two dependent round trips. `state` (may be null): read together with the first batch; returns false
+/// (uniformly) when the solve has converged. `prefetch_b`: the first level's right-hand side was written by an earlier kernel
+/// and is fetched here too.
+template <typename real>
+__device__ inline bool co_static(const MgCo<real> &P, const CoThread &T, CoLevel<real> *st, int lmax, const int *state, bool prefetch_b) {
+	const int t = T.t, nlev = P.last - P.first + 1;
 	int nbv = 0;
-	if (t < 8 * nlev && P.first + (t >> 3) <= lmax) nbv = P.lv[P.first + (t >> 3)].nbr[(size_t)wg * MG_NBR_STRIDE + (t & 7)];
-	const int st0 = state[0];
-	if (st0 >= 0) return;  // converged: the launches queued behind the stopping test are no-ops
+	if (t < 8 * nlev && P.first + (t >> 3) <= lmax) nbv = P.lv[P.first + (t >> 3)].nbr[(size_t)T.wg * MG_NBR_STRIDE + (t & 7)];
+	if (state) {
+		const int st0 = state[0];
+		if (st0 >= 0) return false;  // converged: the launches queued behind the stopping test are no-ops
+	}
 	if (t < 8 * nlev) st[t >> 3].nb[t & 7] = nbv;
 	for (int l = P.first; l <= lmax; ++l) {
 		CoLevel<real> &S = st[l - P.first];
@@ -969,45 +1076,55 @@ __global__ void __launch_bounds__(256) k_mg_coarse(MgCo<real> P, const int *stat
 	}
 	__syncthreads();
 	{
-		uint8_t va[MG_CO_MAX_LEVELS][4];
+		uint32_t va[MG_CO_MAX_LEVELS];  // four A bytes per level, packed: this batch is the kernel's register peak otherwise
 		int r1 = t + 256, f0, f1, hidx, nc0, nc1, dx, dy, dz;
 		cp_ring(t, f0, hidx, nc0, dx, dy, dz);
 		cp_ring(r1 < 384 ? r1 : 0, f1, hidx, nc1, dx, dy, dz);
 #pragma unroll
 		for (int k = 0; k < MG_CO_MAX_LEVELS; ++k) {
 			const int l = P.first + k;
-			va[k][0] = va[k][1] = va[k][2] = va[k][3] = 0;
+			va[k] = 0;
 			if (l <= lmax) {
 				const uint8_t *ab = P.lv[l].abits;
 				const int *nb = st[k].nb;
-				va[k][0] = ab[(size_t)nb[6] * 512 + c0];
-				va[k][1] = ab[(size_t)nb[6] * 512 + c1];
-				if (nb[f0] >= 0) va[k][2] = ab[(size_t)nb[f0] * 512 + nc0];
-				if (r1 < 384 && nb[f1] >= 0) va[k][3] = ab[(size_t)nb[f1] * 512 + nc1];
+				uint32_t b0 = ab[(size_t)nb[6] * 512 + T.c0], b1 = ab[(size_t)nb[6] * 512 + T.c1], b2 = 0, b3 = 0;
+				if (nb[f0] >= 0) b2 = ab[(size_t)nb[f0] * 512 + nc0];
+				if (r1 < 384 && nb[f1] >= 0) b3 = ab[(size_t)nb[f1] * 512 + nc1];
+				va[k] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
 			}
 		}
-		// (issued behind the A bytes, consumed by the first phase: the right-hand side the previous kernel has restricted)
-		const size_t base0 = (size_t)st[0].nb[6] * 512;
-		const real fb0 = MemAgent::ld(P.lv[P.first].b + base0 + c0), fb1 = MemAgent::ld(P.lv[P.first].b + base0 + c1);
+		real fb0 = (real)0, fb1 = (real)0;
+		if (prefetch_b && P.first <= lmax) {
+			// (issued behind the A bytes, consumed by the first phase: the right-hand side the previous kernel has restricted)
+			const size_t base0 = (size_t)st[0].nb[6] * 512;
+			fb0 = MemAgent::ld(P.lv[P.first].b + base0 + T.c0);
+			fb1 = MemAgent::ld(P.lv[P.first].b + base0 + T.c1);
+		}
 #pragma unroll
 		for (int k = 0; k < MG_CO_MAX_LEVELS; ++k)
 			if (P.first + k <= lmax) {
-				st[k].ab[c0] = va[k][0];
-				st[k].ab[c1] = va[k][1];
-				st[k].rab[t] = va[k][2];
-				if (r1 < 384) st[k].rab[r1] = va[k][3];
+				st[k].ab[T.c0] = (uint8_t)(va[k] & 255);
+				st[k].ab[T.c1] = (uint8_t)((va[k] >> 8) & 255);
+				st[k].rab[t] = (uint8_t)((va[k] >> 16) & 255);
+				if (r1 < 384) st[k].rab[r1] = (uint8_t)(va[k] >> 24);
 			}
-		st[0].b[c0] = fb0;
-		st[0].b[c1] = fb1;
+		if (prefetch_b && P.first <= lmax) {
+			st[0].b[T.c0] = fb0;
+			st[0].b[T.c1] = fb1;
+		}
 	}
 	__syncthreads();
-	stamp();
-	// one half sweep of colour `colour` on the halo block H with the coefficients of the thread's two cells
-	auto half_sweep = [&](real *H, uint32_t a0, uint32_t a1, real b0, real b1, int colour) {
-		const int k = (qx + qy + colour) & 1;
-		gs_cell<real>(H, k ? a1 : a0, k ? b1 : b0, k ? h1 : h0);
-		__syncthreads();
-	};
+	return true;
+}
+
+/// One V-cycle of levels P.first .. P.last: down, coarsest solve (workgroup 0), up. The halo blocks of st[] must be zero.
+/// `b_prefetched`: the first level's right-hand side is already in st[0].b (k_mg_coarse); otherwise it is waited for like
+/// every other level's (its children sit on level P.first - 1, whose flags P.ready[P.first - 1] must be valid).
+/// `post_first_y`: raise the result flag of the first level too (somebody inside this launch consumes it).
+template <typename real, typename STAMP>
+__device__ inline void co_cycle(const MgCo<real> &P, const CoThread &T, CoLevel<real> *st, real *R, int *dep, unsigned tag, int lmax,
+                                bool b_prefetched, bool post_first_y, STAMP &&stamp) {
+	const int t = T.t, c0 = T.c0, c1 = T.c1, h0 = T.h0, h1 = T.h1;
 	// ---- down
 	for (int l = P.first; l < P.last && l <= lmax; ++l) {
 		CoLevel<real> &S = st[l - P.first];
@@ -1015,19 +1132,14 @@ __global__ void __launch_bounds__(256) k_mg_coarse(MgCo<real> P, const int *stat
 		const int tile = S.nb[6], nt = L.g.nt;
 		const size_t base = (size_t)tile * 512;
 		const uint32_t a0 = S.ab[c0], a1 = S.ab[c1];
-		if (l > P.first) {  // the right-hand side is the restricted residual of the child tiles (level l - 1)
+		const bool waited = l > P.first || !b_prefetched;
+		if (waited) {  // the right-hand side is the restricted residual of the child tiles (level l - 1)
 			const GridDims &gf = P.lv[l - 1].g;
-			if (t < 8) {
-				int tx, ty, tz;
-				tile_coords(L.g, tile, tx, ty, tz);
-				const int cx = 2 * tx + (t & 1), cy = 2 * ty + ((t >> 1) & 1), cz = 2 * tz + (t >> 2);
-				dep[t] = ((S.nb[7] >> t) & 1) ? cx + gf.ntx * (cy + gf.nty * cz) : -1;
-			}
-			__syncthreads();
+			co_child_deps(T, dep, L.g, gf, tile, S.nb[7]);
 			co_wait(P.ready[l - 1] + gf.nt, dep, 8, tag);
 		}
 		real b0, b1;
-		if (l > P.first) {
+		if (waited) {
 			b0 = MemAgent::ld(L.b + base + c0);
 			b1 = MemAgent::ld(L.b + base + c1);
 			S.b[c0] = b0;
@@ -1036,10 +1148,10 @@ __global__ void __launch_bounds__(256) k_mg_coarse(MgCo<real> P, const int *stat
 			b0 = S.b[c0];
 			b1 = S.b[c1];
 		}
-		// pre-smoothing from zero: the ring does not enter (the interior of H is still zero here)
+		// pre-smoothing from zero: the ring does not enter (the halo block is still zero here)
 		for (int it = 0; it < P.inner; ++it) {
-			half_sweep(S.H, a0, a1, b0, b1, 0);
-			half_sweep(S.H, a0, a1, b0, b1, 1);
+			co_half_sweep<real>(T, S.H, a0, a1, b0, b1, 0);
+			co_half_sweep<real>(T, S.H, a0, a1, b0, b1, 1);
 		}
 		MemAgent::st(L.x + base + c0, S.H[h0]);
 		MemAgent::st(L.x + base + c1, S.H[h1]);
@@ -1049,70 +1161,30 @@ __global__ void __launch_bounds__(256) k_mg_coarse(MgCo<real> P, const int *stat
 		if (t < 6) dep[t] = S.nb[t];
 		__syncthreads();
 		co_wait(P.ready[l], dep, 6, tag);
-		for (int r = t; r < 384; r += 256) {
-			int f, hidx, ncell, dx, dy, dz;
-			cp_ring(r, f, hidx, ncell, dx, dy, dz);
-			const int nb = S.nb[f];
-			if (nb >= 0) S.H[hidx] = MemAgent::ld(L.x + (size_t)nb * 512 + ncell);
-		}
+		co_load_ring<real>(T, S.H, S.nb, L.x);
+		R[c0] = co_residual_cell<real>(S.H, a0, b0, h0);
+		R[c1] = co_residual_cell<real>(S.H, a1, b1, h1);
 		__syncthreads();
-#pragma unroll
-		for (int k = 0; k < 2; ++k) {
-			const uint32_t a = k ? a1 : a0;
-			const int i = k ? h1 : h0;
-			real r = (real)0;
-			if (a & AB_UNKNOWN) {
-				const real F = (a & AB_FLUID) ? (real)1 : (real)0;
-				real val = (real)(a & 7) * S.H[i];
-				val -= F * S.H[i - 1];
-				val -= F * S.H[i - 10];
-				val -= F * S.H[i - 100];
-				val -= (real)((a >> 3) & 1) * S.H[i + 1];
-				val -= (real)((a >> 4) & 1) * S.H[i + 10];
-				val -= (real)((a >> 5) & 1) * S.H[i + 100];
-				r = (k ? b1 : b0) - val;
-			}
-			R[k ? c1 : c0] = r;
-		}
-		__syncthreads();
-		if (t < 64) {  // one coarse cell each: its 8 children in the order of the pair sums and the two shuffle steps
-			const int X = t & 3, Y = (t >> 2) & 3, Z = t >> 4;
-			auto pair = [&](int x, int y) { real p = R[x + 8 * y + 64 * (2 * Z)]; p += R[x + 8 * y + 64 * (2 * Z + 1)]; return p; };
-			real v = pair(2 * X, 2 * Y);
-			v += pair(2 * X + 1, 2 * Y);
-			real w = pair(2 * X, 2 * Y + 1);
-			w += pair(2 * X + 1, 2 * Y + 1);
-			v += w;
-			int tx, ty, tz;
-			tile_coords(L.g, tile, tx, ty, tz);
-			const GridDims &gc = P.lv[l + 1].g;
-			const int ptile = (tx >> 1) + gc.ntx * ((ty >> 1) + gc.nty * (tz >> 1));
-			MemAgent::st(P.lv[l + 1].b + (size_t)ptile * 512 + ((tz & 1) * 4 + Z) * 64 + ((ty & 1) * 4 + Y) * 8 + (tx & 1) * 4 + X, (real)0.5 * v);
-		}
+		co_restrict_store<real>(T, R, L.g, P.lv[l + 1].g, tile, P.lv[l + 1].b);
 		co_post(P.ready[l] + nt, tile, tag);
 		stamp();
 	}
 	// ---- coarsest level (one tile, workgroup 0): nsw sweeps red->black, nsw black->red from zero
-	if (wg == 0) {
+	if (T.wg == 0) {
 		const int l = P.last;
 		CoLevel<real> &S = st[l - P.first];
 		const MgLv<real> &L = P.lv[l];
 		const int tile = S.nb[6];
 		const size_t base = (size_t)tile * 512;
 		const uint32_t a0 = S.ab[c0], a1 = S.ab[c1];
-		if (l > P.first) {
+		const bool waited = l > P.first || !b_prefetched;
+		if (waited) {
 			const GridDims &gf = P.lv[l - 1].g;
-			if (t < 8) {
-				int tx, ty, tz;
-				tile_coords(L.g, tile, tx, ty, tz);
-				const int cx = 2 * tx + (t & 1), cy = 2 * ty + ((t >> 1) & 1), cz = 2 * tz + (t >> 2);
-				dep[t] = ((S.nb[7] >> t) & 1) ? cx + gf.ntx * (cy + gf.nty * cz) : -1;
-			}
-			__syncthreads();
+			co_child_deps(T, dep, L.g, gf, tile, S.nb[7]);
 			co_wait(P.ready[l - 1] + gf.nt, dep, 8, tag);
 		}
 		real b0, b1;
-		if (l > P.first) {
+		if (waited) {
 			b0 = MemAgent::ld(L.b + base + c0);
 			b1 = MemAgent::ld(L.b + base + c1);
 		} else {
@@ -1121,12 +1193,12 @@ __global__ void __launch_bounds__(256) k_mg_coarse(MgCo<real> P, const int *stat
 		}
 		for (int q = 0; q < 2 * P.nsw; ++q) {
 			const int fc = q < P.nsw ? 0 : 1;
-			half_sweep(S.H, a0, a1, b0, b1, fc);
-			half_sweep(S.H, a0, a1, b0, b1, fc ^ 1);
+			co_half_sweep<real>(T, S.H, a0, a1, b0, b1, fc);
+			co_half_sweep<real>(T, S.H, a0, a1, b0, b1, fc ^ 1);
 		}
 		MemAgent::st(L.y + base + c0, S.H[h0]);
 		MemAgent::st(L.y + base + c1, S.H[h1]);
-		co_post(P.ready[l] + 2 * L.g.nt, tile, tag);
+		if (l > P.first || post_first_y) co_post(P.ready[l] + 2 * L.g.nt, tile, tag);
 		stamp();
 	}
 	// ---- up
@@ -1138,43 +1210,304 @@ __global__ void __launch_bounds__(256) k_mg_coarse(MgCo<real> P, const int *stat
 		const size_t base = (size_t)tile * 512;
 		const uint32_t a0 = S.ab[c0], a1 = S.ab[c1];
 		const real b0 = S.b[c0], b1 = S.b[c1];
-		int tx, ty, tz;
-		tile_coords(L.g, tile, tx, ty, tz);
 		// the corrections come from the parent tile and from the parents of the active neighbour tiles
-		if (t < 7) {
-			const int src = S.nb[t];  // six neighbour tiles, then the tile itself
-			int d = -1;
-			if (src >= 0) {
-				int sx, sy, sz;
-				tile_coords(L.g, src, sx, sy, sz);
-				d = (sx >> 1) + gc.ntx * ((sy >> 1) + gc.nty * (sz >> 1));
-			}
-			dep[t] = d;
-		}
-		__syncthreads();
+		co_parent_deps(T, dep, L.g, gc, S.nb);
 		co_wait(P.ready[l + 1] + 2 * gc.nt, dep, 7, tag);
-		const real *e = P.lv[l + 1].y;
-		{
-			// cells z = 2 j and 2 j + 1 of a column share their parent
-			const real corr = MemAgent::ld(e + blocked_index(gc, (tx * 8 + qx) >> 1, (ty * 8 + qy) >> 1, (tz * 8 + 2 * qj) >> 1));
-			if (a0 & AB_UNKNOWN) S.H[h0] = S.H[h0] + corr;
-			if (a1 & AB_UNKNOWN) S.H[h1] = S.H[h1] + corr;
-		}
-		for (int r = t; r < 384; r += 256) {
-			int f, hidx, ncell, dx, dy, dz;
-			cp_ring(r, f, hidx, ncell, dx, dy, dz);
-			if (S.nb[f] >= 0 && (S.rab[r] & AB_UNKNOWN))
-				S.H[hidx] = S.H[hidx] + MemAgent::ld(e + blocked_index(gc, (tx * 8 + dx) >> 1, (ty * 8 + dy) >> 1, (tz * 8 + dz) >> 1));
-		}
-		__syncthreads();
+		co_add_correction<real>(T, S.H, a0, a1, S.rab, S.nb, L.g, gc, tile, P.lv[l + 1].y);
 		for (int it = 0; it < P.inner; ++it) {
-			half_sweep(S.H, a0, a1, b0, b1, 1);
-			half_sweep(S.H, a0, a1, b0, b1, 0);
+			co_half_sweep<real>(T, S.H, a0, a1, b0, b1, 1);
+			co_half_sweep<real>(T, S.H, a0, a1, b0, b1, 0);
 		}
 		MemAgent::st(L.y + base + c0, S.H[h0]);
 		MemAgent::st(L.y + base + c1, S.H[h1]);
-		if (l > P.first) co_post(P.ready[l] + 2 * L.g.nt, tile, tag);
+		if (l > P.first || post_first_y) co_post(P.ready[l] + 2 * L.g.nt, tile, tag);
 		stamp();
+	}
+}
+
+template <typename real>
+__global__ void __launch_bounds__(256) k_mg_coarse(MgCo<real> P, const int *state) {
+	extern __shared__ unsigned char co_smem[];
+	__shared__ int dep[8];
+	const CoThread T;
+	const int nlev = P.last - P.first + 1;
+	CoLevel<real> *st = (CoLevel<real> *)co_smem;
+	real *R = (real *)(st + nlev);
+	int n_stamp = 0;
+	auto stamp = [&]() {
+		if (P.stamps && T.wg == 0 && T.t == 0) P.stamps[n_stamp] = wall_clock64();
+		++n_stamp;
+	};
+	stamp();
+	int lmax = P.first - 1;  // deepest level this workgroup owns a tile of
+	for (int l = P.first; l <= P.last; ++l)
+		if (T.wg < P.lv[l].n_tiles) lmax = l;
+	if (!co_static<real>(P, T, st, lmax, state, true)) return;
+	stamp();
+	co_cycle<real>(P, T, st, R, dep, P.tag, lmax, true, false, stamp);
+}
+
+// ------------------------------------------------------------------------------------------------ a whole solve in ONE launch
+// Small systems (a few hundred particle tiles: BASELINE's C2, and the 50^3 .. 128^3 grids the reference's hosts run) are latency
+// bound on every level, the finest included: with 600 tiles a wave-per-tile kernel is itself a 5 us chain of sweeps behind a
+// 5 us launch, four times per iteration (C2: 45 of an iteration's 78 us), and the host polls the solver state between chunks
+// of iterations. k_pcg_small runs the WHOLE preconditioned CG of pressure_solver::solve (src/pressure_solver.cpp:19-71) in one
+// launch, a workgroup per particle tile, with k_mg_coarse's dataflow:
+//  * the tile's p, r, s, q, z live in REGISTERS (two cells per thread) from the first to the last iteration; only the tile's
+//    faces cross workgroups (s for the product A s, the pre-smoothed iterate for the residual), through the solver's own global
+//    vectors with `sc1` accesses and tagged ready flags; p and r are stored once, at the end.
+//  * the two reductions of an iteration (q.s; z.r together with the signed max of r) are tagged per-workgroup partials that every
+//    workgroup sums in the same fixed order - alpha, beta and the stopping rule (:54-58) are identical everywhere, so all
+//    workgroups leave the loop in the same iteration; nothing visits the host until the solve is over.
+//  * below the finest level: co_cycle, i.e. exactly k_mg_coarse's phases.
+// Arithmetic per cell: k_spmv's / k_mg_axpy_presmooth's / cp_*'s expressions. The partial sums are grouped per tile instead of
+// per four tiles, so results agree with the multi-launch path to rounding, not bit for bit (tested: iterations +-1, pressure 1e-6).
+#define PS_MAX_TILES 256  // measured: 219 tiles (64^3) 0.064 -> 0.055 ms per iteration; ~900 tiles (C2) 0.082 -> 0.090: the faces and
+                          // reductions of many workgroups through memory cost more than the launches they save
+template <typename real> struct PcgSmall {
+	MgCo<real> C;          // lv[0 .. last], ready[0 .. last]; C.first = 1
+	real *p, *r, *s, *x0;  // pressure, residual, search direction (faces exchanged through it), pre-smoothed iterate (faces)
+	unsigned *sflag;       // [tiles of level 0] the tile's search direction of this iteration is stored
+	double *part;          // [3][PS_MAX_TILES] per-workgroup partials: q.s | z.r | signed max r
+	unsigned *pflag;       // [2][PS_MAX_TILES] tags of the two reductions
+	real scale, inv_scale;
+	double tol;
+	int maxit;
+	int *state;
+	double *hist;
+};
+
+/// All threads: every workgroup's partial of this tag is in; returns their sum (and, MAXTOO, the NaN-aware maximum of a second
+/// array), identical in every workgroup: strided private sums in index order, a butterfly per wave, one exchange through LDS.
+template <bool MAXTOO>
+__device__ inline void co_reduce(const double *sum_part, const double *max_part, const unsigned *flag, int W, unsigned tag, double *lds,
+                                 double &sum, double &mx) {
+	const int t = threadIdx.x;
+	if (t < 64) {
+		// ONE wave polls (a lane's four flags read together, one round trip per attempt, with back-off): every thread of every
+		// workgroup re-reading the flags is a storm that starves the producers when they are late (see co_backoff)
+		int tries = 0;
+		for (;;) {
+			unsigned f[PS_MAX_TILES / 64];
+#pragma unroll
+			for (int k = 0; k < PS_MAX_TILES / 64; ++k) {
+				const int i = t + 64 * k;
+				f[k] = i < W ? __hip_atomic_load(flag + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+			}
+			bool all = true;
+#pragma unroll
+			for (int k = 0; k < PS_MAX_TILES / 64; ++k) all &= f[k] == tag;
+			if (all) break;
+			co_backoff(tries);
+		}
+	}
+	__syncthreads();
+	double a = 0.0, m = -INFINITY;
+	bool nan = false;
+	for (int i = t; i < W; i += 256) {
+		a += MemAgent::ld(sum_part + i);
+		if (MAXTOO) {
+			const double x = MemAgent::ld(max_part + i);
+			nan |= x != x;
+			m = x > m ? x : m;
+		}
+	}
+	a = wave_sum(a);
+	if (MAXTOO) {
+		m = wave_max(m);
+		nan = __any(nan);
+	}
+	if ((t & 63) == 0) {
+		lds[t >> 6] = a;
+		if (MAXTOO) lds[4 + (t >> 6)] = nan ? NAN : m;
+	}
+	__syncthreads();
+	sum = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+	if (MAXTOO) {
+		mx = lds[4];
+		for (int k = 1; k < 4; ++k) mx = (mx != mx || lds[4 + k] != lds[4 + k]) ? NAN : (lds[4 + k] > mx ? lds[4 + k] : mx);
+	}
+	__syncthreads();
+}
+
+template <typename real>
+__global__ void __launch_bounds__(256) k_pcg_small(PcgSmall<real> Q) {
+	extern __shared__ unsigned char co_smem[];
+	__shared__ int dep[8], nb0[8];
+	__shared__ uint8_t rab0[384];
+	__shared__ double red[8];
+	const MgCo<real> &P = Q.C;
+	const CoThread T;
+	const int t = T.t, wg = T.wg, c0 = T.c0, c1 = T.c1, h0 = T.h0, h1 = T.h1;
+	const int nlev = P.last - P.first + 1, W = gridDim.x;
+	CoLevel<real> *st = (CoLevel<real> *)co_smem;
+	real *H0 = (real *)(st + nlev), *R = H0 + LFA_HALO_CELLS;
+	const MgLv<real> &L0 = P.lv[0];
+	const GridDims &g1 = P.lv[1].g;
+	const int nt0 = L0.g.nt;
+	int lmax = 0;
+	for (int l = P.first; l <= P.last; ++l)
+		if (wg < P.lv[l].n_tiles) lmax = l;
+	if (t < 8) nb0[t] = L0.nbr[(size_t)wg * MG_NBR_STRIDE + t];
+	co_static<real>(P, T, st, lmax, nullptr, false);  // (ends with a barrier: nb0 is visible)
+	const int tile0 = nb0[6];
+	const size_t base0 = (size_t)tile0 * 512;
+	const uint32_t a0 = L0.abits[base0 + c0], a1 = L0.abits[base0 + c1];
+	for (int r = t; r < 384; r += 256) {
+		int f, hidx, ncell, dx, dy, dz;
+		cp_ring(r, f, hidx, ncell, dx, dy, dz);
+		rab0[r] = nb0[f] >= 0 ? L0.abits[(size_t)nb0[f] * 512 + ncell] : (uint8_t)0;
+	}
+	// the vectors of the tile: two cells per thread, in registers for the whole solve
+	real p0 = Q.p[base0 + c0], p1 = Q.p[base0 + c1], r0 = Q.r[base0 + c0], r1 = Q.r[base0 + c1];
+	real s0 = (real)0, s1 = (real)0, q0 = (real)0, q1 = (real)0, z0 = (real)0, z1 = (real)0;
+	double sigma = 0.0;
+	auto nostamp = []() {};
+	int it = -1, done = -1;
+	bool nan_seen = false;
+	for (; it < Q.maxit; ++it) {
+		const unsigned tag = P.tag + (unsigned)(it + 1);
+		double m = -INFINITY;
+		bool nan = false;
+		if (it >= 0) {
+			// ---- q = A s (k_spmv's expression), partial q.s
+			for (int i = t; i < LFA_HALO_CELLS; i += 256) H0[i] = (real)0;
+			__syncthreads();
+			H0[h0] = s0;
+			H0[h1] = s1;
+			MemAgent::st(Q.s + base0 + c0, s0);
+			MemAgent::st(Q.s + base0 + c1, s1);
+			co_post(Q.sflag, tile0, tag);
+			if (t < 6) dep[t] = nb0[t];
+			__syncthreads();
+			co_wait(Q.sflag, dep, 6, tag);
+			co_load_ring<real>(T, H0, nb0, Q.s);
+			double acc = 0.0;
+#pragma unroll
+			for (int k = 0; k < 2; ++k) {
+				const uint32_t a = k ? a1 : a0;
+				const int i = k ? h1 : h0;
+				real out = (real)0;
+				if (a & AB_UNKNOWN) {
+					const real F = (a & AB_FLUID) ? (real)1 : (real)0;
+					const real si = H0[i];
+					real val = (real)(a & 7) * si;
+					val -= F * H0[i - 1];
+					val -= F * H0[i - 10];
+					val -= F * H0[i - 100];
+					val -= (real)((a >> 3) & 1) * H0[i + 1];
+					val -= (real)((a >> 4) & 1) * H0[i + 10];
+					val -= (real)((a >> 5) & 1) * H0[i + 100];
+					out = Q.scale * val;
+					acc += (double)out * (double)si;
+				}
+				if (k) q1 = out;
+				else q0 = out;
+			}
+			acc = wave_sum(acc);
+			if ((t & 63) == 0) red[t >> 6] = acc;
+			__syncthreads();
+			if (t == 0) {
+				MemAgent::st(Q.part + wg, (red[0] + red[1]) + (red[2] + red[3]));
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				__hip_atomic_store(Q.pflag + wg, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			double gamma, unused;
+			co_reduce<false>(Q.part, nullptr, Q.pflag, W, tag, red, gamma, unused);
+			// ---- p += alpha s, r -= alpha q, signed max of the new residual (k_mg_axpy_presmooth's expressions)
+			const real alpha = (real)(sigma / gamma);
+#pragma unroll
+			for (int k = 0; k < 2; ++k) {
+				const uint32_t a = k ? a1 : a0;
+				if (a & AB_UNKNOWN) {
+					real &pp = k ? p1 : p0, &rr = k ? r1 : r0;
+					pp = pp + alpha * (k ? s1 : s0);
+					const real rn = rr + (-alpha) * (k ? q1 : q0);
+					rr = rn;
+					nan |= rn != rn;
+					m = (double)rn > m ? (double)rn : m;
+				}
+			}
+		}
+		// ---- z = V(r) / scale: the finest level here, the others in co_cycle
+		for (int i = t; i < LFA_HALO_CELLS; i += 256) H0[i] = (real)0;
+		for (int l = P.first; l <= lmax; ++l) {
+			CoLevel<real> &S = st[l - P.first];
+			for (int i = t; i < LFA_HALO_CELLS; i += 256) S.H[i] = (real)0;
+		}
+		__syncthreads();
+		{
+			const real b0 = (a0 & AB_UNKNOWN) ? r0 : (real)0, b1 = (a1 & AB_UNKNOWN) ? r1 : (real)0;
+			for (int k = 0; k < P.inner; ++k) {
+				co_half_sweep<real>(T, H0, a0, a1, b0, b1, 0);
+				co_half_sweep<real>(T, H0, a0, a1, b0, b1, 1);
+			}
+			MemAgent::st(Q.x0 + base0 + c0, H0[h0]);
+			MemAgent::st(Q.x0 + base0 + c1, H0[h1]);
+			co_post(P.ready[0], tile0, tag);
+			if (t < 6) dep[t] = nb0[t];
+			__syncthreads();
+			co_wait(P.ready[0], dep, 6, tag);
+			co_load_ring<real>(T, H0, nb0, Q.x0);
+			R[c0] = co_residual_cell<real>(H0, a0, b0, h0);
+			R[c1] = co_residual_cell<real>(H0, a1, b1, h1);
+			__syncthreads();
+			co_restrict_store<real>(T, R, L0.g, g1, tile0, P.lv[1].b);
+			co_post(P.ready[0] + nt0, tile0, tag);
+			co_cycle<real>(P, T, st, R, dep, tag, lmax, false, true, nostamp);
+			co_parent_deps(T, dep, L0.g, g1, nb0);
+			co_wait(P.ready[1] + 2 * g1.nt, dep, 7, tag);
+			co_add_correction<real>(T, H0, a0, a1, rab0, nb0, L0.g, g1, tile0, P.lv[1].y);
+			for (int k = 0; k < P.inner; ++k) {
+				co_half_sweep<real>(T, H0, a0, a1, b0, b1, 1);
+				co_half_sweep<real>(T, H0, a0, a1, b0, b1, 0);
+			}
+			z0 = H0[h0] * Q.inv_scale;
+			z1 = H0[h1] * Q.inv_scale;
+			double acc = (double)z0 * (double)b0;
+			acc += (double)z1 * (double)b1;
+			acc = wave_sum(acc);
+			m = wave_max(m);
+			nan = __any(nan);
+			__syncthreads();
+			if ((t & 63) == 0) {
+				red[t >> 6] = acc;
+				red[4 + (t >> 6)] = nan ? NAN : m;
+			}
+			__syncthreads();
+			if (t == 0) {
+				double v = red[4];
+				for (int k = 1; k < 4; ++k) v = (v != v || red[4 + k] != red[4 + k]) ? NAN : (red[4 + k] > v ? red[4 + k] : v);
+				MemAgent::st(Q.part + PS_MAX_TILES + wg, (red[0] + red[1]) + (red[2] + red[3]));
+				MemAgent::st(Q.part + 2 * PS_MAX_TILES + wg, v);
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				__hip_atomic_store(Q.pflag + PS_MAX_TILES + wg, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+		double sigma_new, rmax;
+		co_reduce<true>(Q.part + PS_MAX_TILES, Q.part + 2 * PS_MAX_TILES, Q.pflag + PS_MAX_TILES, W, tag, red, sigma_new, rmax);
+		if (it >= 0) {
+			// stopping rule of pressure_solver::solve (:54-58) on the residual of this iteration; identical in every workgroup
+			if (wg == 0 && t == 0) Q.hist[it] = rmax;
+			if (rmax != rmax || rmax < Q.tol) {
+				done = it + 1;
+				nan_seen = rmax != rmax;
+				break;
+			}
+		}
+		// ---- s = z + beta s (:64-66; the first direction is z itself, :40)
+		const real beta = it >= 0 ? (real)(sigma_new / sigma) : (real)0;
+		s0 = it >= 0 ? z0 + beta * s0 : z0;
+		s1 = it >= 0 ? z1 + beta * s1 : z1;
+		sigma = sigma_new;
+	}
+	Q.p[base0 + c0] = p0;
+	Q.p[base0 + c1] = p1;
+	Q.r[base0 + c0] = r0;
+	Q.r[base0 + c1] = r1;
+	if (wg == 0 && t == 0 && done >= 0) {
+		if (nan_seen) Q.state[1] = 1;
+		Q.state[0] = done;
 	}
 }
 
@@ -1372,6 +1705,7 @@ void lfa_mg_free(lfa_sim *s) {
 	}
 	if (s->mg->l1_dirty) (void)hipFree(s->mg->l1_dirty);
 	if (s->mg->counts) (void)hipFree(s->mg->counts);
+	if (s->mg->ps_part) (void)hipFree(s->mg->ps_part);
 	if (s->mg->co_stamps) {
 		unsigned long long h[3 * MG_CO_PHASES];
 		if (hipMemcpy(h, s->mg->co_stamps, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -1437,7 +1771,11 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 				LFA_HIP(s, hipMalloc(&L.nbr, (size_t)gs[l].nt * MG_NBR_STRIDE * 4));
 				L.cap_tiles = (size_t)gs[l].nt;
 			}
-			if (l == 0) continue;
+			if (l == 0) {  // k_pcg_small: ready flags of the finest level (3 x tiles) followed by its search-direction flags (1 x tiles)
+				LFA_HIP(s, hipMalloc(&L.ready, (size_t)4 * gs[0].nt * sizeof(unsigned)));
+				LFA_HIP(s, hipMemsetAsync(L.ready, 0, (size_t)4 * gs[0].nt * sizeof(unsigned), s->stream));
+				continue;
+			}
 			LFA_HIP(s, hipMalloc(&L.ctype, L.ncp));
 			LFA_HIP(s, hipMalloc(&L.abits, L.ncp));
 			LFA_HIP(s, hipMalloc(&L.x, L.ncp * sizeof(real)));
@@ -1725,10 +2063,19 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 			n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
 			           ? prop.multiProcessorCount : 256;
 		}
+		static bool co_attr_set = false;
+		if (!co_attr_set) {
+			LFA_HIP(s, hipFuncSetAttribute((const void *)k_mg_coarse<real>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+			co_attr_set = true;
+		}
 		auto fits = [&](int first) {
 			const size_t lds = (size_t)(last - first + 1) * sizeof(CoLevel<real>) + 512 * sizeof(real) + 64;
-			const size_t per_cu = std::min<size_t>(8, (size_t)(160 * 1024) / lds);
-			return last - first + 1 <= MG_CO_MAX_LEVELS && M.lv[first].n_tiles <= co_max && (size_t)M.lv[first].n_tiles <= per_cu * (size_t)n_cu;
+			int per_cu = 0;  // by registers and LDS together
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_mg_coarse<real>, 256, lds) != hipSuccess) {
+				(void)hipGetLastError();
+				per_cu = 0;
+			}
+			return last - first + 1 <= MG_CO_MAX_LEVELS && M.lv[first].n_tiles <= co_max && (size_t)M.lv[first].n_tiles <= (size_t)per_cu * (size_t)n_cu;
 		};
 		tail = last;
 		while (tail > 1 && tail - 1 >= D && fits(tail - 1)) --tail;
@@ -1838,6 +2185,101 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		M.first_co = persist ? tail : 0;
 	}
 	return LFA_OK;
+}
+
+/// The whole solve in one launch (k_pcg_small) when the system is small enough for a resident workgroup per particle tile:
+/// *ran = false (nothing done) otherwise. Expects the system built (A bytes, right-hand side in vr, guess in vp) and the
+/// hierarchy set up; leaves the pressure in vp, the residual in vr, iterations / NaN flag in pcg_state, the residual history
+/// in pcg_hist - what the multi-launch loop leaves.
+bool lfa_pcg_small_eligible(const lfa_sim *s);
+template <typename real> static int pcg_small_t(lfa_sim *s, bool *ran) {
+	*ran = false;
+	if (!s->mg || !lfa_pcg_small_eligible(s)) return LFA_OK;
+	lfa_mg &M = *s->mg;
+	const int nl = M.n_levels, last = nl - 1, W = s->n_ptiles;
+	if (nl < 2 || W < 1 || W > PS_MAX_TILES || last > MG_CO_MAX_LEVELS || !M.lv[0].ready || M.lv[0].n_tiles != W) return LFA_OK;
+	static int n_cu = 0;
+	if (!n_cu) {
+		int dev = 0;
+		hipDeviceProp_t prop;
+		n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+		           ? prop.multiProcessorCount : 256;
+	}
+	// every workgroup must be resident at once: LDS per workgroup = the levels below the finest + the finest level's halo block
+	const size_t lds = (size_t)last * sizeof(CoLevel<real>) + (size_t)(LFA_HALO_CELLS + 512) * sizeof(real);
+	static bool attr_set = false;
+	if (!attr_set) {
+		LFA_HIP(s, hipFuncSetAttribute((const void *)k_pcg_small<real>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+		attr_set = true;
+	}
+	int per_cu = 0;  // by registers and LDS together (168 VGPRs in fp32: 3 workgroups per CU)
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_pcg_small<real>, 256, lds) != hipSuccess) per_cu = 0;
+	(void)hipGetLastError();
+	size_t cap = std::min<size_t>((size_t)per_cu * (size_t)n_cu, PS_MAX_TILES);
+	if (const char *e = getenv("LFA_PCG_SMALL_MAX")) cap = std::min<size_t>(cap, (size_t)atoi(e));
+	if ((size_t)W > cap) return LFA_OK;
+	if (!M.ps_part) {
+		const size_t bytes = (size_t)3 * PS_MAX_TILES * sizeof(double) + (size_t)2 * PS_MAX_TILES * sizeof(unsigned);
+		LFA_HIP(s, hipMalloc(&M.ps_part, bytes));
+		LFA_HIP(s, hipMemsetAsync(M.ps_part, 0, bytes, s->stream));
+	}
+	PcgSmall<real> Q;
+	for (int l = 0; l <= last; ++l) {
+		const lfa_mg_level &L = M.lv[l];
+		Q.C.lv[l] = MgLv<real>{L.tiles, L.nbr, L.n_tiles, L.g, l == 0 ? (const uint8_t *)s->abits : (const uint8_t *)L.abits,
+		                       l == 0 ? (real *)s->vr : (real *)L.b, l == 0 ? (real *)s->vq : (real *)L.x, l == 0 ? (real *)s->vz : (real *)L.y};
+		Q.C.ready[l] = L.ready;
+	}
+	Q.C.first = 1;
+	Q.C.last = last;
+	Q.C.nsw = MG_COARSEST_SWEEPS;
+	Q.C.inner = MG_INNER_SWEEPS;
+	if (const char *e = getenv("LFA_MG_TAIL_INNER")) Q.C.inner = std::max(1, atoi(e));
+	if (const char *e = getenv("LFA_MG_NSW")) Q.C.nsw = std::max(1, atoi(e));
+	Q.C.stamps = nullptr;
+	const int maxit = (int)s->prm.max_iterations;
+	// tags tag .. tag + maxit belong to this launch (one per V-cycle); 0 is what the flags are initialised to
+	if (M.co_tag > 0xFFFFFFFFu - (unsigned)(maxit + 4)) {
+		for (int l = 0; l <= last; ++l)
+			LFA_HIP(s, hipMemsetAsync(M.lv[l].ready, 0, (size_t)(l == 0 ? 4 : 3) * M.lv[l].g.nt * sizeof(unsigned), s->stream));
+		LFA_HIP(s, hipMemsetAsync(M.ps_part, 0, (size_t)3 * PS_MAX_TILES * sizeof(double) + (size_t)2 * PS_MAX_TILES * sizeof(unsigned), s->stream));
+		M.co_tag = 0;
+	}
+	Q.C.tag = M.co_tag + 1;
+	M.co_tag += (unsigned)maxit + 2;
+	Q.p = (real *)s->vp;
+	Q.r = (real *)s->vr;
+	Q.s = (real *)s->vs;
+	Q.x0 = (real *)s->vq;
+	Q.sflag = M.lv[0].ready + (size_t)3 * M.lv[0].g.nt;
+	Q.part = M.ps_part;
+	Q.pflag = (unsigned *)(M.ps_part + (size_t)3 * PS_MAX_TILES);
+	Q.scale = (real)s->a_scale;
+	Q.inv_scale = (real)(1.0 / s->a_scale);
+	Q.tol = s->prm.tolerance;
+	Q.maxit = maxit;
+	Q.state = s->pcg_state;
+	Q.hist = s->pcg_hist;
+	hipLaunchKernelGGL(k_pcg_small<real>, dim3(W), dim3(256), lds, s->stream, Q);
+	LFA_LAUNCH_CHECK(s);
+	M.launches_per_cycle = 0;
+	M.first_co = 1;
+	*ran = true;
+	return LFA_OK;
+}
+/// Whether the next solve of this handle will take the one-launch path (same conditions as pcg_small_t, before the hierarchy
+/// exists): the position correction then runs BEFORE the solve on the main stream instead of beside it - a kernel whose
+/// workgroups wait for each other must not share the device with a long-running kernel of another stream (its workgroups
+/// become resident only as the other's retire, the resident ones poll meanwhile: measured 1-2 s per C2 step).
+/// OPT-IN (LFA_PCG_SMALL=1). Measured on full steps: 64^3 / 262 144 particles, PCG loop 0.83 -> 0.69 ms, but the step 1.31 ->
+/// 1.41 ms because the correction no longer hides beside the solve; 50^3: 1.21 -> 1.21 ms. Alone (staged hosts, lfa_pcg_solve) it
+/// is the faster solve; inside the overlapped step it is not, so the default stays the multi-launch loop.
+bool lfa_pcg_small_eligible(const lfa_sim *s) {
+	return getenv("LFA_PCG_SMALL") && s->prm.precond == LFA_PRECOND_MULTIGRID && !s->dist && s->n_ptiles >= 1 &&
+	       s->n_ptiles <= PS_MAX_TILES && (s->g.nx > 8 || s->g.ny > 8 || s->g.nz > 8);
+}
+int lfa_pcg_small(lfa_sim *s, bool *ran) {
+	return s->prm.pcg_dtype == LFA_PCG_F64 ? pcg_small_t<double>(s, ran) : pcg_small_t<float>(s, ran);
 }
 
 void lfa_mg_stats(const lfa_sim *s, uint64_t *launches_per_cycle, uint64_t *levels, uint64_t *first_co) {

@@ -1270,6 +1270,17 @@ static int correct_begin(lfa_sim *s, double dt, bool slab_exchanged) {
 	LFA_TRY(lfa_corr_commit(s));
 	s->corr_begun = false;
 	if (!s->np_live && !s->dist) return LFA_OK;  // nothing to correct: _end and _undo are no-ops
+	if (lfa_pcg_small_eligible(s)) {
+		// A small system: its solve is ONE launch of workgroups that wait for each other and must have the device to itself. The
+		// correction (a fraction of a millisecond at this size) runs right here on the main stream - the same arithmetic at the same
+		// point of the data flow, nothing in flight afterwards; _end is a no-op, _undo restores as usual.
+		int rc = correct_build_index(s, false);
+		if (rc == LFA_OK) rc = correct_apply(s, dt, false);
+		if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[LFA_EV_CORRECT_END], s->stream));
+		s->corr_begun = true;
+		s->corr_undo_valid = rc == LFA_OK;
+		return rc < 0 ? rc : LFA_OK;
+	}
 	LFA_HIP(s, hipEventRecord(s->ev_cfork, s->stream));
 	LFA_HIP(s, hipStreamWaitEvent(s->stream3, s->ev_cfork, 0));
 	hipStream_t main_stream = s->stream;

@@ -28,4 +28,6 @@ int lfa_mg_axpy_apply(lfa_sim *s, const void *sdir, const double *part_sigma, in
                       double *part_rmax, double *part_sigma_new);
 int lfa_mg_bench_part(lfa_sim *s, int part);
 void lfa_mg_free(lfa_sim *s);
+bool lfa_pcg_small_eligible(const lfa_sim *s);  // the next solve takes the one-launch path: nothing may run beside it
+int lfa_pcg_small(lfa_sim *s, bool *ran);  // the whole PCG solve of a small system in one launch (mg.hip: k_pcg_small)
 void lfa_mg_stats(const lfa_sim *s, uint64_t *launches_per_cycle, uint64_t *levels, uint64_t *first_co);

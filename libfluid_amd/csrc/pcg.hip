@@ -1736,13 +1736,26 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 	auto sig_src = [&](int parity) { return dist ? red + 3 + parity : P + (parity ? PART_SIG1 : PART_SIG0); };
 	const int n_sig = dist ? 1 : NS, n_zs = dist ? 1 : G, n_max = dist ? 1 : G;
 	const real *cx = is_ml(s) ? (const real *)s->c_x : (const real *)nullptr;
+	// small systems: the whole solve in one launch (a workgroup per particle tile, vectors in registers; mg.hip: k_pcg_small)
+	bool small_ran = false;
+	if (is_mg(s) && !dist && s->n_ptiles && s->nbr_table) LFA_TRY(lfa_pcg_small(s, &small_ran));
+	s->stat_whole_solve = small_ran ? 1 : 0;
 	// z = M^-1 r ; s = z ; sigma = z.r
-	LFA_TRY(mic_apply<real>(s, P + PART_SIG0));
+	if (!small_ran) LFA_TRY(mic_apply<real>(s, P + PART_SIG0));
 	if (dist) LFA_TRY(lfa_dist_allreduce(s, P + PART_SIG0, NS, 3, false));
 	const int maxit = (int)s->prm.max_iterations;
 	const int chunk = 4;
 	int done = -1, nan = 0, i = 0;
 	int *hstate = (int *)s->h_pinned;
+	if (small_ran) {
+		LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 8, hipMemcpyDeviceToHost, s->stream));
+		LFA_HIP(s, hipStreamSynchronize(s->stream));
+		done = hstate[0];
+		nan = hstate[1];
+		i = maxit;  // (neither loop below runs)
+		uint64_t mgl = 0;
+		lfa_mg_stats(s, &mgl, &s->stat_mg_levels, &s->stat_mg_first_co);
+	}
 	// fused iteration (k_pcg_a / k_pcg_b): tile-local MIC(0) with or without the coarse levels, single domain or slabs
 	// (with the multigrid preconditioner the second kernel is the AXPY/pre-smoothing kernel followed by the V-cycle, mg.hip)
 	const bool fused = (is_mg(s) || s->prm.pcg_fused) && s->prm.precond != LFA_PRECOND_MIC0_EXACT && (s->n_ptiles == 0 || s->nbr_table);
@@ -1892,7 +1905,7 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 extern "C" int lfa_get_solver_stats(lfa_sim *s, uint64_t stats[LFA_NUM_SOLVER_STATS]) {
 	if (!s || !stats) return LFA_E_INVALID;
 	const uint64_t v[LFA_NUM_SOLVER_STATS] = {s->stat_launches_iter, s->stat_transport_iter, s->stat_mg_levels, s->stat_mg_first_co,
-	                                          s->last_iters, s->stat_transport_solve, 0, 0};
+	                                          s->last_iters, s->stat_transport_solve, s->stat_whole_solve, 0};
 	for (int i = 0; i < LFA_NUM_SOLVER_STATS; ++i) stats[i] = v[i];
 	return LFA_OK;
 }

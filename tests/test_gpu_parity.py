@@ -9,6 +9,8 @@ Bars (SURVEY.md 8d "parity gates"):
               error <= 2e-5 (fp32 storage and arithmetic against the fp64 reference; sums of O(64) terms)
   pressure    max-norm relative error <= 1e-4 (north star), in every preconditioner / dtype combination
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -615,3 +617,56 @@ def test_pic_flip_keep_c_in_its_home_array_through_steps_sources_and_a_change_to
                 assert np.abs(a[k] - b[k]).max() <= 1e-4 * np.abs(b[k]).max(), k
         # (positions / velocities differ by the summation order of a binning ordered by atomics, nothing else)
         assert np.abs(a["pos"] - b["pos"]).max() < 1e-3 and np.abs(a["vel"] - b["vel"]).max() < 0.5
+
+
+@pytest.mark.parametrize("dtype", [lfa.PCG_F32, lfa.PCG_F64])
+@pytest.mark.parametrize("name", ["apic16_solid", "flip16", "pic_ragged", "apic_tank", "apic_h17"])
+def test_whole_solve_in_one_launch_matches_the_multi_launch_solve_on_golden_scenes(name, dtype, monkeypatch):
+    """Opt-in (LFA_PCG_SMALL=1): small systems run pressure_solver::solve (src/pressure_solver.cpp:19-71) in ONE launch (k_pcg_small: a
+    workgroup per particle tile, the tile's vectors in registers, faces and reductions through tagged flags). Same expressions per
+    cell as the multi-launch path, partial sums grouped per tile instead of per four tiles: iteration counts within one, pressures
+    equal to rounding - and both within the usual bar of the reference's golden pressures."""
+    g = util.load_golden(name)
+    res = []
+    for small in (True, False):
+        if small:
+            monkeypatch.setenv("LFA_PCG_SMALL", "1")
+        else:
+            monkeypatch.delenv("LFA_PCG_SMALL", raising=False)
+        c, parts, solid, s = make_gpu(name, precond=lfa.PRECOND_MULTIGRID, pcg_dtype=dtype)
+        r, it, rc = s.step_hot(util.DT)
+        assert rc == 0
+        st = s.solver_stats()
+        assert st["whole_solve_in_one_launch"] == (1 if small else 0), st
+        res.append((it, s.pressure().copy(), r))
+        s.close()
+    (it_a, p_a, r_a), (it_b, p_b, r_b) = res
+    assert abs(it_a - it_b) <= 1, (it_a, it_b)
+    scale = np.abs(p_b).max()
+    assert np.abs(p_a - p_b).max() <= 2e-5 * scale
+    assert np.abs(p_a - g["p0"]).max() <= 1e-4 * np.abs(g["p0"]).max()
+
+
+def test_whole_solve_in_one_launch_over_full_steps_of_a_64_cube(monkeypatch):
+    """64^3 / 262 144 particles (the size of the reference's testbed scenes, ~220 particle tiles): the one-launch solve against the
+    multi-launch one over twelve full time steps of the moving dam (the correction then runs before the solve instead of beside it)
+    - iteration counts within one step by step, pressures equal to 1e-4 of their maximum, same particle count."""
+    its, ps = {}, {}
+    for small in (True, False):
+        if small:
+            monkeypatch.setenv("LFA_PCG_SMALL", "1")
+        else:
+            monkeypatch.delenv("LFA_PCG_SMALL", raising=False)
+        s = lfa.Sim((64, 64, 64), method=lfa.APIC)
+        s.seed_block((0, 0, 0), (32, 32, 32))
+        its[small] = []
+        for _ in range(12):
+            r, it, rc = s.time_step(0.004)
+            assert rc == 0 and r < 1e-6
+            its[small].append(it)
+        assert s.solver_stats()["whole_solve_in_one_launch"] == (1 if small else 0)
+        ps[small] = s.pressure().copy()
+        s.close()
+    assert all(abs(a - b) <= 1 for a, b in zip(its[True], its[False])), its
+    assert len(ps[True]) == len(ps[False])
+    assert np.abs(ps[True] - ps[False]).max() <= 1e-4 * np.abs(ps[False]).max()
