@@ -137,10 +137,6 @@ struct lfa_sim {
 
 	// pressure system
 	uint8_t *abits = nullptr;
-	// [2 * nt] per tile: which of its 64 (y, z) rows of 8 x-cells hold an unknown (bit 8 * z + y of the 64-bit pair; k_abits).
-	// The finest-level PCG kernels skip the LOADS of the other rows (their entries are exact zeros by the invariant of pcg.hip):
-	// late in a run tiles are a quarter full and half of their 128-byte lines hold no unknown (tools/tile_sparsity.py)
-	uint32_t *tile_rowmask = nullptr;
 	void *vp = nullptr, *vr = nullptr, *vz = nullptr, *vs = nullptr, *vpre = nullptr, *vq = nullptr;
 	struct lfa_mg *mg = nullptr;  // multigrid hierarchy (mg.hip)
 	int *nbr_table = nullptr;  // per particle-tile slot: neighbour tile ids + level-1 indices (k_build_nbr_table)

@@ -44,15 +44,13 @@ __device__ inline int halo_index(int l) { return ((l & 7) + 1) + 10 * (((l >> 3)
 // ---------------------------------------------------------------------------------------------- a10: A bits
 /// pressure_solver::_compute_a_matrix (src/pressure_solver.cpp:160-178) for every cell of every particle tile;
 /// non-unknown cells get 0 so that the PCG kernels can use the byte as a mask.
-__global__ void __launch_bounds__(256) k_abits(const int *ptiles, int n_ptiles, GridView gv, uint8_t *abits, uint32_t *rowmask) {
+__global__ void __launch_bounds__(256) k_abits(const int *ptiles, int n_ptiles, GridView gv, uint8_t *abits) {
 	__shared__ uint8_t H[LFA_HALO_CELLS];
-	__shared__ uint32_t rows[2];
 	for (int slot = blockIdx.x; slot < n_ptiles; slot += gridDim.x) {
 		const int tile = ptiles[slot];
 		int tx, ty, tz;
 		tile_coords(gv.g, tile, tx, ty, tz);
 		__syncthreads();
-		if (threadIdx.x < 2) rows[threadIdx.x] = 0u;
 		stage_halo_types(gv, tx, ty, tz, H);
 #pragma unroll
 		for (int half = 0; half < 2; ++half) {
@@ -69,11 +67,7 @@ __global__ void __launch_bounds__(256) k_abits(const int *ptiles, int n_ptiles, 
 				              AB_UNKNOWN | (((H[h] & 7) == CT_FLUID) ? AB_FLUID : 0));
 			}
 			abits[b] = a;
-			// (y, z) rows of the tile that hold an unknown: bit 8 z + y (the lanes of a wave that agree on a row issue one atomic)
-			if (a) atomicOr(&rows[l >> 8], 1u << ((l >> 3) & 31));
 		}
-		__syncthreads();
-		if (threadIdx.x < 2) rowmask[2 * (size_t)tile + threadIdx.x] = rows[threadIdx.x];
 	}
 }
 
@@ -488,9 +482,8 @@ int lfa_build_rhs(lfa_sim *s, double dt) {
 	s->sys_dt = dt;
 	if (!s->n_ptiles) return LFA_OK;
 	GridView gv = make_view(s);
-	if (!s->tile_rowmask) LFA_HIP(s, hipMalloc(&s->tile_rowmask, (size_t)2 * s->g.nt * sizeof(uint32_t)));
 	hipLaunchKernelGGL(k_abits, dim3(grid_blocks(s->n_ptiles)), dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, gv,
-	                   s->abits, s->tile_rowmask);
+	                   s->abits);
 	LFA_LAUNCH_CHECK(s);
 	const int G = pcg_grid(s->n_ptiles);
 	const float inv_h = (float)(1.0 / s->prm.cell_size);

@@ -269,7 +269,6 @@ template <typename real> struct MgLv {
 	GridDims g;
 	const uint8_t *abits;
 	real *b, *x, *y;
-	const uint32_t *rowmask;  // finest level: lfa_sim::tile_rowmask (rows of a tile without unknowns are not loaded); null: every row
 };
 
 /// 1 / (number of non-solid neighbours), 1..6: a table lookup by selects instead of an IEEE division in the smoother.
@@ -356,16 +355,6 @@ template <typename real> __device__ inline void load_halo(real *h, const real *v
 	h[(lx + 1) + 10 * (ly + 1) + 100 * 9] = nb[5] >= 0 ? v[(size_t)nb[5] * 512 + 0 * 64 + lane] : (real)0;
 }
 
-/// The six faces alone (the interior comes from registers).
-template <typename real> __device__ inline void load_halo_ring(real *h, const real *v, const int *nb, int lane, int lx, int ly) {
-	h[0 + 10 * (lx + 1) + 100 * (ly + 1)] = nb[0] >= 0 ? v[(size_t)nb[0] * 512 + ly * 64 + lx * 8 + 7] : (real)0;
-	h[9 + 10 * (lx + 1) + 100 * (ly + 1)] = nb[1] >= 0 ? v[(size_t)nb[1] * 512 + ly * 64 + lx * 8 + 0] : (real)0;
-	h[(lx + 1) + 10 * 0 + 100 * (ly + 1)] = nb[2] >= 0 ? v[(size_t)nb[2] * 512 + ly * 64 + 7 * 8 + lx] : (real)0;
-	h[(lx + 1) + 10 * 9 + 100 * (ly + 1)] = nb[3] >= 0 ? v[(size_t)nb[3] * 512 + ly * 64 + 0 * 8 + lx] : (real)0;
-	h[(lx + 1) + 10 * (ly + 1) + 100 * 0] = nb[4] >= 0 ? v[(size_t)nb[4] * 512 + 7 * 64 + lane] : (real)0;
-	h[(lx + 1) + 10 * (ly + 1) + 100 * 9] = nb[5] >= 0 ? v[(size_t)nb[5] * 512 + 0 * 64 + lane] : (real)0;
-}
-
 /// Down, one tile: residual r = b - A x of the level and its restriction to the next: half the sum over the 8 children.
 template <typename real>
 __device__ inline void residual_restrict_tile(const MgLv<real> &L, const GridDims &gc, real *b_coarse, int slot, real *h, int lane) {
@@ -376,22 +365,14 @@ __device__ inline void residual_restrict_tile(const MgLv<real> &L, const GridDim
 	// A bytes and right-hand side of the whole column up front, unconditionally (b is 0 where the cell is no unknown): a load
 	// inside the per-cell branch costs one HBM round trip per z
 	uint32_t ab[8];
-	real bb[8], xx[8];
-	const uint32_t mlo = L.rowmask ? L.rowmask[2 * (size_t)tile] : 0xFFFFFFFFu, mhi = L.rowmask ? L.rowmask[2 * (size_t)tile + 1] : 0xFFFFFFFFu;
+	real bb[8];
 #pragma unroll
 	for (int zz = 0; zz < 8; ++zz) {
-		ab[zz] = 0;
-		bb[zz] = xx[zz] = (real)0;
-		if (lfa_row_on(mlo, mhi, zz, ly)) {
-			ab[zz] = L.abits[base + zz * 64 + lane];
-			bb[zz] = L.b[base + zz * 64 + lane];
-			xx[zz] = L.x[base + zz * 64 + lane];
-		}
+		ab[zz] = L.abits[base + zz * 64 + lane];
+		bb[zz] = L.b[base + zz * 64 + lane];
 	}
 	MG_FENCE();
-	load_halo_ring<real>(h, L.x, nb, lane, lx, ly);
-#pragma unroll
-	for (int zz = 0; zz < 8; ++zz) h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)] = xx[zz];
+	load_halo<real>(h, L.x, base, nb, lane, lx, ly);
 	MG_FENCE();
 	real pair[4];
 #pragma unroll
@@ -513,8 +494,7 @@ __global__ void __launch_bounds__(256) k_mg_presmooth(MgLv<real> L, const int *s
 template <typename real, int MW>
 __global__ void __launch_bounds__(256, MW)
 k_mg_axpy_presmooth(const int *tiles, int n_tiles, const uint8_t *abits, real *p, const real *sdir, real *r, real *q_x,
-                    const double *part_sigma, int n_sigma, const double *part_qs, int n_qs, double *part_rmax, const int *state,
-                    const uint32_t *rowmask) {
+                    const double *part_sigma, int n_sigma, const double *part_qs, int n_qs, double *part_rmax, const int *state) {
 	__shared__ real halo[PCG_WAVES][LFA_HALO_CELLS];
 	__shared__ double lds[16];
 	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
@@ -539,18 +519,11 @@ k_mg_axpy_presmooth(const int *tiles, int n_tiles, const uint8_t *abits, real *p
 		real tp[8], ts[8], tr[8], tq[8];
 		size_t base = 0;
 		auto load_tile = [&](int sl) {
-			const int tile = tiles[sl];
-			base = (size_t)tile * 512;
-			// rows of the tile without an unknown are exact zeros in every vector: not loaded (late in a run half of a tile's lines)
-			const uint32_t mlo = rowmask[2 * (size_t)tile], mhi = rowmask[2 * (size_t)tile + 1];
+			base = (size_t)tiles[sl] * 512;
 #pragma unroll
 			for (int zz = 0; zz < 8; ++zz) {
 				const size_t c = base + zz * 64 + lane;
-				tab[zz] = 0;
-				tp[zz] = ts[zz] = tr[zz] = tq[zz] = (real)0;
-				if (lfa_row_on(mlo, mhi, zz, ly)) {
-					tab[zz] = abits[c]; tp[zz] = p[c]; ts[zz] = sdir[c]; tr[zz] = r[c]; tq[zz] = q_x[c];
-				}
+				tab[zz] = abits[c]; tp[zz] = p[c]; ts[zz] = sdir[c]; tr[zz] = r[c]; tq[zz] = q_x[c];
 			}
 		};
 		if (slot < n_tiles) load_tile(slot);
@@ -625,16 +598,11 @@ k_mg_prolong_postsmooth(MgLv<real> L, GridDims gc, const real *e, real inv_scale
 			int tx_, ty_, tz_;
 			tile_coords(L.g, tile, tx_, ty_, tz_);
 			auto corr = [&](int X, int Y, int Z) -> real { return e ? e[blocked_index(gc, X >> 1, Y >> 1, Z >> 1)] : (real)0; };
-			const uint32_t mlo = L.rowmask ? L.rowmask[2 * (size_t)tile] : 0xFFFFFFFFu, mhi = L.rowmask ? L.rowmask[2 * (size_t)tile + 1] : 0xFFFFFFFFu;
 #pragma unroll
 			for (int zz = 0; zz < 8; ++zz) {
-				tab[zz] = 0;
-				tb[zz] = tx[zz] = (real)0;
-				if (lfa_row_on(mlo, mhi, zz, ly)) {
-					tab[zz] = L.abits[base + zz * 64 + lane];
-					tb[zz] = L.b[base + zz * 64 + lane];
-					tx[zz] = L.x[base + zz * 64 + lane];
-				}
+				tab[zz] = L.abits[base + zz * 64 + lane];
+				tb[zz] = L.b[base + zz * 64 + lane];
+				tx[zz] = L.x[base + zz * 64 + lane];
 			}
 #pragma unroll
 			for (int j = 0; j < 4; ++j) tc[j] = corr(tx_ * 8 + lx, ty_ * 8 + ly, tz_ * 8 + 2 * j);
@@ -1722,21 +1690,6 @@ template <typename real, typename... Args> static void launch_up0(int G, hipStre
 	}
 }
 int mg_grid(int n_tiles) { return pcg_grid(n_tiles); }
-/// All-ones masks for LFA_PCG_NO_ROWSKIP=1 (the A/B of the row skipping): a second array, filled once.
-const uint32_t *mg_rowmask(lfa_sim *s) {
-	if (!getenv("LFA_PCG_NO_ROWSKIP")) return s->tile_rowmask;
-	static uint32_t *ones = nullptr;
-	static size_t ones_n = 0;
-	const size_t n = (size_t)2 * s->g.nt;
-	if (ones_n < n) {
-		if (ones) (void)hipFree(ones);
-		ones = nullptr;
-		if (hipMalloc(&ones, n * 4) != hipSuccess) return s->tile_rowmask;
-		(void)hipMemsetAsync(ones, 0xFF, n * 4, s->stream);
-		ones_n = n;
-	}
-	return ones;
-}
 /// Slab mode of the hierarchy. A one-rank communicator needs none of it; LFA_MG_DIST_SINGLE=1 runs it anyway (tests: the array
 /// all-reduces then go through the real transport).
 bool mg_dist(const lfa_sim *s) { return s->dist && (s->dist->nranks > 1 || getenv("LFA_MG_DIST_SINGLE")); }
@@ -2077,8 +2030,7 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 	auto lvl = [&](int l) {
 		const lfa_mg_level &L = M.lv[l];
 		return MgLv<real>{L.tiles, L.nbr, L.n_tiles, L.g, l == 0 ? (const uint8_t *)s->abits : (const uint8_t *)L.abits,
-		                  l == 0 ? (real *)s->vr : (real *)L.b, l == 0 ? (real *)s->vq : (real *)L.x, l == 0 ? (real *)s->vz : (real *)L.y,
-		                  (l == 0 && !getenv("LFA_PCG_NO_ROWSKIP")) ? (const uint32_t *)s->tile_rowmask : (const uint32_t *)nullptr};
+		                  l == 0 ? (real *)s->vr : (real *)L.b, l == 0 ? (real *)s->vq : (real *)L.x, l == 0 ? (real *)s->vz : (real *)L.y};
 	};
 	const real inv_scale = (real)(1.0 / s->a_scale);
 	const int *st = (const int *)s->pcg_state;
@@ -2275,8 +2227,7 @@ template <typename real> static int pcg_small_t(lfa_sim *s, bool *ran) {
 	for (int l = 0; l <= last; ++l) {
 		const lfa_mg_level &L = M.lv[l];
 		Q.C.lv[l] = MgLv<real>{L.tiles, L.nbr, L.n_tiles, L.g, l == 0 ? (const uint8_t *)s->abits : (const uint8_t *)L.abits,
-		                       l == 0 ? (real *)s->vr : (real *)L.b, l == 0 ? (real *)s->vq : (real *)L.x, l == 0 ? (real *)s->vz : (real *)L.y,
-		                       (const uint32_t *)nullptr};
+		                       l == 0 ? (real *)s->vr : (real *)L.b, l == 0 ? (real *)s->vq : (real *)L.x, l == 0 ? (real *)s->vz : (real *)L.y};
 		Q.C.ready[l] = L.ready;
 	}
 	Q.C.first = 1;
@@ -2349,7 +2300,7 @@ static int mg_axpy_apply_t(lfa_sim *s, const void *sdir, const double *part_sigm
 	const int G = mg_grid(s->n_ptiles);
 	launch_axpy_presmooth<real>(G, s->stream, (const int *)s->ptiles, s->n_ptiles, (const uint8_t *)s->abits, (real *)s->vp,
 	                            (const real *)sdir, (real *)s->vr, (real *)s->vq, part_sigma, n_sigma, part_qs, n_qs, part_rmax,
-	                            (const int *)s->pcg_state, mg_rowmask(s));
+	                            (const int *)s->pcg_state);
 	LFA_LAUNCH_CHECK(s);
 	return mg_apply_t<real>(s, part_sigma_new, true);
 }
@@ -2369,8 +2320,8 @@ int lfa_mg_bench_part(lfa_sim *s, int part) {
 	double *P = s->partials;
 	const int G = mg_grid(s->n_ptiles);
 	if (part == 0) {
-		if (f64) launch_axpy_presmooth<double>(G, s->stream, (const int *)s->ptiles, s->n_ptiles, (const uint8_t *)s->abits, (double *)s->vp, (const double *)s->vs, (double *)s->vr, (double *)s->vq, (const double *)(P + PART_SIG0), G, (const double *)(P + PART_ZS), G, P + PART_RMAX, (const int *)s->pcg_state, mg_rowmask(s));
-		else launch_axpy_presmooth<float>(G, s->stream, (const int *)s->ptiles, s->n_ptiles, (const uint8_t *)s->abits, (float *)s->vp, (const float *)s->vs, (float *)s->vr, (float *)s->vq, (const double *)(P + PART_SIG0), G, (const double *)(P + PART_ZS), G, P + PART_RMAX, (const int *)s->pcg_state, mg_rowmask(s));
+		if (f64) launch_axpy_presmooth<double>(G, s->stream, (const int *)s->ptiles, s->n_ptiles, (const uint8_t *)s->abits, (double *)s->vp, (const double *)s->vs, (double *)s->vr, (double *)s->vq, (const double *)(P + PART_SIG0), G, (const double *)(P + PART_ZS), G, P + PART_RMAX, (const int *)s->pcg_state);
+		else launch_axpy_presmooth<float>(G, s->stream, (const int *)s->ptiles, s->n_ptiles, (const uint8_t *)s->abits, (float *)s->vp, (const float *)s->vs, (float *)s->vr, (float *)s->vq, (const double *)(P + PART_SIG0), G, (const double *)(P + PART_ZS), G, P + PART_RMAX, (const int *)s->pcg_state);
 		LFA_LAUNCH_CHECK(s);
 		return LFA_OK;
 	}

@@ -10,12 +10,6 @@
 enum { PART_STRIDE = PCG_MAX_GRID + 64, PART_ZS = 0, PART_RMAX = PART_STRIDE, PART_SIG0 = 2 * PART_STRIDE,
        PART_SIG1 = 3 * PART_STRIDE, PART_B2 = 4 * PART_STRIDE, PART_TOTAL = 5 * PART_STRIDE };
 
-/// Row z-slice zz, lane row ly of a tile holds an unknown (lfa_sim::tile_rowmask: bit 8 z + y of the 64-bit pair). The finest-level
-/// kernels put the loads of a tile's interior under this predicate: a row without unknowns is exact zeros in every PCG vector.
-__device__ inline bool lfa_row_on(uint32_t mlo, uint32_t mhi, int zz, int ly) {
-	return (((zz < 4 ? mlo : mhi) >> ((zz & 3) * 8 + ly)) & 1u) != 0u;
-}
-
 static inline int pcg_grid(int n_ptiles) {
 	int g = (n_ptiles + PCG_WAVES - 1) / PCG_WAVES;
 	if (g < 1) g = 1;

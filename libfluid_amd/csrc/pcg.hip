@@ -1147,7 +1147,7 @@ k_pcg_a(int n_ptiles, const int *__restrict__ nbr, const uint8_t *__restrict__ a
         const double *part_sig_new, int n_sig_new, const double *part_sig_old, int n_sig_old,
         const double *part_rmax, int n_rmax, double tol, int iter, int *state, double *hist, double *part_qs,
         const real *__restrict__ coarse_x,
-        const real *__restrict__ coarse_x2, real *coarse_as, const uint32_t *__restrict__ rowmask) {
+        const real *__restrict__ coarse_x2, real *coarse_as) {
 	__shared__ real halo[PCG_WAVES][LFA_HALO_CELLS];
 	__shared__ double lds[256];
 	const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
@@ -1177,18 +1177,12 @@ k_pcg_a(int n_ptiles, const int *__restrict__ nbr, const uint8_t *__restrict__ a
 		const int own = r1.z;
 		base = (size_t)own * LFA_TILE_CELLS;
 		l1 = r1.w;
-		// rows of the tile without an unknown are exact zeros in z and s: not loaded (lfa_sim::tile_rowmask)
-		const uint32_t mlo = rowmask ? rowmask[2 * (size_t)own] : 0xFFFFFFFFu, mhi = rowmask ? rowmask[2 * (size_t)own + 1] : 0xFFFFFFFFu;
 #pragma unroll
 		for (int zz = 0; zz < 8; ++zz) {
 			const size_t b = base + zz * 64 + lane;
-			ab[zz] = 0;
-			zi[zz] = si[zz] = (real)0;
-			if (lfa_row_on(mlo, mhi, zz, ly)) {
-				ab[zz] = abits[b];
-				zi[zz] = z[b];
-				si[zz] = FIRST ? (real)0 : s_old[b];
-			}
+			ab[zz] = abits[b];
+			zi[zz] = z[b];
+			si[zz] = FIRST ? (real)0 : s_old[b];
 		}
 #pragma unroll
 		for (int k = 0; k < 6; ++k) {
@@ -1799,8 +1793,7 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 			launch_pcg_a<real>(i == 0, is_ml(s), GA, s->stream, s->n_ptiles, (const int *)s->nbr_table, (const uint8_t *)s->abits,
 			                   (const real *)v.z, (const real *)sbuf[po], sbuf[pn], v.q, scale, sig_po, n_sig_po, sig_pn, n_sig_pn,
 			                   rmax_prev, n_rmax_prev, s->prm.tolerance, i, s->pcg_state,
-			                   s->pcg_hist, P + PART_ZS, cx, (const real *)s->c_x2, is_ml(s) ? (real *)s->c_as : (real *)nullptr,
-			                   getenv("LFA_PCG_NO_ROWSKIP") ? (const uint32_t *)nullptr : (const uint32_t *)s->tile_rowmask);
+			                   s->pcg_hist, P + PART_ZS, cx, (const real *)s->c_x2, is_ml(s) ? (real *)s->c_as : (real *)nullptr);
 			LFA_LAUNCH_CHECK(s);
 			if (dist) {
 				// the new search direction across the slab faces, then the rows of q that needed it
@@ -2111,8 +2104,7 @@ template <typename real> static int bench_launch(lfa_sim *s, int which) {
 		                   (const real *)v.z, (const real *)v.s, (real *)s->vs2, v.q, scale, (const double *)(P + PART_SIG0), G,
 		                   (const double *)(P + PART_SIG0), G, (const double *)(P + PART_RMAX), G, -HUGE_VAL, 1, s->pcg_state,
 		                   s->pcg_hist + 4095, P + PART_ZS, is_ml(s) ? (const real *)s->c_x : (const real *)nullptr,
-		                   (const real *)s->c_x2, is_ml(s) ? (real *)s->c_as : (real *)nullptr,
-		                   getenv("LFA_PCG_NO_ROWSKIP") ? (const uint32_t *)nullptr : (const uint32_t *)s->tile_rowmask);
+		                   (const real *)s->c_x2, is_ml(s) ? (real *)s->c_as : (real *)nullptr);
 		break;
 	case LFA_K_PCG_B: {
 		if (!s->nbr_table || !s->prm.pcg_fused) return lfa_fail(s, LFA_E_INVALID, "fused kernels: solve with pcg_fused = 1 first");

@@ -670,29 +670,3 @@ def test_whole_solve_in_one_launch_over_full_steps_of_a_64_cube(monkeypatch):
     assert all(abs(a - b) <= 1 for a, b in zip(its[True], its[False])), its
     assert len(ps[True]) == len(ps[False])
     assert np.abs(ps[True] - ps[False]).max() <= 1e-4 * np.abs(ps[False]).max()
-
-
-@pytest.mark.parametrize("dtype", [lfa.PCG_F32, lfa.PCG_F64])
-def test_row_skipping_of_the_finest_level_is_bitwise_invisible(dtype, monkeypatch):
-    """The finest-level PCG kernels do not load the (y, z) rows of a tile that hold no unknown (lfa_sim::tile_rowmask, from k_abits):
-    their entries are exact zeros in every PCG vector, so iteration counts and pressures are bit for bit those of the kernels that
-    load everything (LFA_PCG_NO_ROWSKIP=1) - on a thin sheet (most rows of most tiles empty), a ragged block and a full one."""
-    scenes_ = [((72, 40, 56), ((0, 0, 0), (72, 2, 56))), ((72, 40, 56), ((3, 0, 5), (50, 11, 37))), ((40, 40, 40), ((0, 0, 0), (40, 24, 40)))]
-    for size, block in scenes_:
-        res = []
-        for skip in (True, False):
-            if skip:
-                monkeypatch.delenv("LFA_PCG_NO_ROWSKIP", raising=False)
-            else:
-                monkeypatch.setenv("LFA_PCG_NO_ROWSKIP", "1")
-            s = lfa.Sim(size, precond=lfa.PRECOND_MULTIGRID, pcg_dtype=dtype)
-            s.seed_block(*block)
-            its = []
-            for _ in range(3):  # (the hot path: a full step's position correction sums in the order the binning's atomics gave)
-                r, it, rc = s.step_hot(0.004)
-                assert rc == 0
-                its.append(it)
-            res.append((its, s.pressure().copy()))
-            s.close()
-        assert res[0][0] == res[1][0], (size, block)
-        assert np.array_equal(res[0][1], res[1][1]), (size, block)
