@@ -925,10 +925,11 @@ template <typename real> struct MgCo {
 /// stream) - and a few hundred workgroups re-reading the same words every 64 clocks starve exactly the kernel they wait for
 /// (measured: 1.3 s per C2 step with every thread of k_pcg_small's reductions polling without back-off).
 __device__ inline void co_backoff(int &n) {
-	if (n < 2) __builtin_amdgcn_s_sleep(1);
-	else if (n < 4) __builtin_amdgcn_s_sleep(4);
-	else if (n < 8) __builtin_amdgcn_s_sleep(16);
-	else if (n < 16) __builtin_amdgcn_s_sleep(64);
+	// (the first polls stay tight: a phase hands over within a few round trips, and 256 clocks of sleep too many per wait cost
+	// k_mg_coarse 7 us per launch at C4)
+	if (n < 16) __builtin_amdgcn_s_sleep(1);
+	else if (n < 32) __builtin_amdgcn_s_sleep(8);
+	else if (n < 64) __builtin_amdgcn_s_sleep(32);
 	else __builtin_amdgcn_s_sleep(127);
 	++n;
 }
