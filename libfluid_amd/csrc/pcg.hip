@@ -1682,7 +1682,7 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 	// The host polls the solver state between chunks of iterations; iterations launched after convergence are no-ops but
 	// still cost their launches (~40 us each). The count barely changes from step to step, so the first chunk is as long
 	// as the previous solve, the following ones short. (Identical on every rank of a slab run: the scalars are all-reduced.)
-	const int first_chunk = s->last_iters > 0 ? (int)std::min<uint64_t>(s->last_iters, 4096) : 8;
+	const int first_chunk = s->last_iters > 0 ? (int)std::min<uint64_t>(s->last_iters, 4096) : 8;  // (+1 / +2: no change, measured)
 	const uint64_t calls_at_start = s->dist ? s->dist->calls : 0;
 	s->stat_launches_iter = s->stat_transport_iter = s->stat_transport_solve = s->stat_mg_levels = s->stat_mg_first_co = 0;
 	s->last_residual = 0.0;
