@@ -148,6 +148,10 @@ def main():
     ap.add_argument("--late", type=int, default=0, help="after everything else: run on to step N of the dam break (untimed), then time "
                     "`--late-steps` full steps there and report them as `late_phase` (the fluid has spread over many partly filled tiles)")
     ap.add_argument("--late-steps", type=int, default=20)
+    ap.add_argument("--transport", choices=["auto", "rccl", "shm"], default="auto", help="z-slab messages: RCCL send/recv + all-reduce on "
+                    "the handle's stream, or staged through host shared memory (lfa_dist_init_shm: functional, two PCIe crossings per "
+                    "message). auto = rccl when every rank has its own GPU (falling back to shm only if the communicator cannot be "
+                    "created), shm when ranks share a GPU")
     ap.add_argument("--strong", action="store_true", help="N > 1: the FIXED BASELINE domain (configs[3]/[4]) split into N z-slabs "
                     "instead of a domain that grows with N")
     args = ap.parse_args()
@@ -163,11 +167,22 @@ def main():
     from libfluid_amd import scenes
 
     dist = None
+    n_dev = torch.cuda.device_count()
+    shared_gpu = world > n_dev  # more ranks than GPUs (a 1-GPU box running the N-process path): RCCL cannot be used
+    if shared_gpu and args.transport == "rccl":
+        raise SystemExit(f"--transport rccl needs one GPU per rank ({world} ranks, {n_dev} GPUs)")
+    transport = "shm" if (shared_gpu or args.transport == "shm") else "rccl"
+    local_rank %= max(n_dev, 1)
+    tdev = "cuda"  # where the tensors of the torch.distributed collectives live
     if world > 1 or (args.force_slabs and "RANK" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shared_gpu:
+            dist.init_process_group("gloo")
+            tdev = "cpu"
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
 
@@ -190,20 +205,46 @@ def main():
     fused = not args.unfused and args.precond != "exact"
     PCG_BYTES = PCG_BYTES_MG if args.precond == "multigrid" else (PCG_BYTES_FUSED if fused else PCG_BYTES_UNFUSED)
     if slabs:
-        # one RCCL communicator per handle: rank 0 creates the id, torch.distributed (RCCL) broadcasts it
-        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            uid.copy_(torch.frombuffer(bytearray(lfa.rccl_unique_id()), dtype=torch.uint8))
-        if dist is not None:
-            dist.broadcast(uid, src=0)
         ntz = (size[2] + 7) // 8
         bounds = lfa.balanced_layer_bounds(ntz, world, blo[2] // 8, (bhi[2] + 7) // 8)
-        sim.init_rccl_slab(rank, world, uid.cpu().numpy().tobytes(), bounds)
-        parallelism = (f"{world} z-slabs (tile layers {bounds}), {'strong' if args.strong else 'weak'} scaling, "
-                       "RCCL send/recv halos + scalar all-reduces + particle migration over xGMI")
+        transport_note = None
+        if transport == "rccl":
+            # one RCCL communicator per handle: rank 0 creates the id, torch.distributed (RCCL) broadcasts it
+            uid = torch.zeros(128, dtype=torch.uint8, device=tdev)
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(lfa.rccl_unique_id()), dtype=torch.uint8))
+            if dist is not None:
+                dist.broadcast(uid, src=0)
+            ok, err = 1, ""
+            try:
+                sim.init_rccl_slab(rank, world, uid.cpu().numpy().tobytes(), bounds)
+            except lfa.LibfluidError as e:
+                ok, err = 0, str(e)
+            if dist is not None:  # either every rank has its communicator or none uses it
+                t = torch.tensor([ok], dtype=torch.int32, device=tdev)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                ok = int(t.item())
+            if not ok:
+                if args.transport == "rccl":
+                    raise SystemExit(f"rank {rank}: RCCL communicator could not be created: {err or 'failed on another rank'}")
+                transport = "shm"
+                transport_note = f"RCCL communicator could not be created ({err or 'failed on another rank'}): host-staged fallback"
+                if rank == 0:
+                    print(f"bench.py: {transport_note}", file=sys.stderr)
+        if transport == "shm":
+            names = [f"/lfa_bench_{os.getpid()}_{int(time.time() * 1e3) & 0xffffff}"]
+            if dist is not None:
+                dist.broadcast_object_list(names, src=0)
+            sim.init_shm_slab(names[0], rank, world, bounds)
+        parallelism = (f"{world} z-slabs (tile layers {bounds}), {'strong' if args.strong else 'weak'} scaling, " +
+                       ("RCCL send/recv halos + scalar all-reduces + particle migration over xGMI" if transport == "rccl" else
+                        "halos, all-reduces and particle migration staged through host shared memory (lfa_dist_init_shm)" +
+                        (f", {world} ranks on {n_dev} GPU(s)" if shared_gpu else "")))
     elif world > 1:
         parallelism = f"{world} independent replicas (--replicas)"
     extras = {}
+    if slabs:
+        extras["transport"] = transport if not transport_note else f"shm ({transport_note})"
     if args.obstacle:
         # a sphere in the dry part of the tank, in the path of the collapsing column, voxelized on the device and marked solid
         # without leaving it (it must not overlap the seeded block: particles deep inside a solid give rows without a diagonal)
@@ -232,7 +273,7 @@ def main():
         """simulation::cfl over the whole domain: each rank reduces its own particles, the minimum over ranks is the CFL step."""
         c = sim.cfl()
         if slabs and dist is not None:
-            t = torch.tensor([c], dtype=torch.float64, device="cuda")
+            t = torch.tensor([c], dtype=torch.float64, device=tdev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             c = float(t.item())
         return c
@@ -259,7 +300,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -268,7 +309,7 @@ def main():
     npart, n_unknowns = counts["particles"], counts["unknowns"]
     npart_total = npart
     if dist is not None:
-        t = torch.tensor([float(npart)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([float(npart)], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         npart_total = int(t.item())
     value = npart_total * args.steps / elapsed
@@ -487,7 +528,7 @@ def main():
         barrier()
         late_s = time.perf_counter() - tl
         if dist is not None:
-            t = torch.tensor([late_s], dtype=torch.float64, device="cuda")
+            t = torch.tensor([late_s], dtype=torch.float64, device=tdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             late_s = float(t.item())
         lc, lf = sim.counts(), sim.correction_stats()
@@ -520,11 +561,11 @@ def main():
         m.marching_cubes()
         nv, ni = m._counts
         if slabs and dist is not None:
-            counts = torch.zeros(world, dtype=torch.int64, device="cuda")
+            counts = torch.zeros(world, dtype=torch.int64, device=tdev)
             counts[rank] = nv
             dist.all_reduce(counts)
             m.rebase(int(counts[:rank].sum().item()))
-            tot = torch.tensor([float(nv), float(ni)], dtype=torch.float64, device="cuda")
+            tot = torch.tensor([float(nv), float(ni)], dtype=torch.float64, device=tdev)
             dist.all_reduce(tot)
             nv, ni = int(tot[0].item()), int(tot[1].item())
         mpos, midx = m.download_mesh()

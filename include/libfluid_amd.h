@@ -257,13 +257,19 @@ int lfa_correct_collide_undo(lfa_sim *s);
  *   lfa_dist_init_rccl  : ncclCommInitRank on this handle's device; send/recv to z+-1 and all-reduce run on the
  *                         handle's stream over xGMI
  *   lfa_dist_local_*    : the same protocol between handles of ONE process (one host thread per handle), device-to-device
- *                         copies instead of RCCL: how the slab logic is tested on a single GPU ("virtual slabs") */
+ *                         copies instead of RCCL: how the slab logic is tested on a single GPU ("virtual slabs")
+ *   lfa_dist_init_shm   : one PROCESS per rank, messages staged through the POSIX shared-memory segment `name` ("/..."; rank 0
+ *                         creates it, every rank of the job passes the same name; LFA_SHM_SLOT_MB = per-rank slot, default 32).
+ *                         No RCCL and no peer access, ranks may share a GPU: the functional fallback when the communicator
+ *                         cannot be created, and the way N processes are exercised on a 1-GPU box. Two PCIe crossings per
+ *                         message: not a transport to quote throughput on. */
 int lfa_dist_unique_id(void *id128);
 int lfa_dist_init_rccl(lfa_sim *s, int rank, int nranks, const void *id128, const int32_t *layer_bounds);
 typedef struct lfa_hub lfa_hub;
 lfa_hub *lfa_dist_local_hub_create(int nranks);
 void lfa_dist_local_hub_destroy(lfa_hub *h);
 int lfa_dist_init_local(lfa_sim *s, lfa_hub *h, int rank, const int32_t *layer_bounds);
+int lfa_dist_init_shm(lfa_sim *s, const char *name, int rank, int nranks, const int32_t *layer_bounds);
 /* Owned tile layers of this handle ([0, ntz) without a decomposition). */
 int lfa_dist_get_slab(const lfa_sim *s, int32_t *lo, int32_t *hi);
 

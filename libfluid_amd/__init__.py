@@ -158,6 +158,7 @@ SIGNATURES = {
     "lfa_dist_local_hub_create": (_vp, [_int]),
     "lfa_dist_local_hub_destroy": (None, [_vp]),
     "lfa_dist_init_local": (_int, [_vp, _vp, _int, _vp]),
+    "lfa_dist_init_shm": (_int, [_vp, C.c_char_p, _int, _int, _vp]),
     "lfa_dist_get_slab": (_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
 KERNELS = {"spmv_dot": 0, "axpy_max": 1, "mic_apply_dot": 2, "update_s": 3, "p2g_scatter": 4, "p2g_finalize": 5,
@@ -676,6 +677,11 @@ class Sim:
         b = np.ascontiguousarray(layer_bounds, dtype=np.int32)
         uid = np.frombuffer(bytes(unique_id), dtype=np.uint8).copy()
         self._chk(self.lib.lfa_dist_init_rccl(self.h, int(rank), int(nranks), _ptr(uid), _ptr(b)))
+
+    def init_shm_slab(self, name, rank, nranks, layer_bounds):
+        """one process per rank, messages staged through the POSIX shared-memory segment `name` (lfa_dist_init_shm)"""
+        b = np.ascontiguousarray(layer_bounds, dtype=np.int32)
+        self._chk(self.lib.lfa_dist_init_shm(self.h, str(name).encode(), int(rank), int(nranks), _ptr(b)))
 
     def slab(self):
         lo, hi = C.c_int32(0), C.c_int32(0)

@@ -341,6 +341,7 @@ int lfa_number_unknowns(lfa_sim *s);
 /// Transport between z-slab neighbours. lo = rank-1, hi = rank+1; all pointers are device pointers, sizes in bytes.
 struct lfa_dist {
 	int rank = 0, nranks = 1;
+	int device_share = 1;  // ranks of this job that run on this handle's GPU (virtual slabs, processes sharing a device)
 	// every call of the three below is one transport call of lfa_get_solver_stats (a grouped send/recv pair or one collective)
 	int exchange(lfa_sim *s, const void *send_lo, size_t n_send_lo, void *recv_lo, size_t n_recv_lo, const void *send_hi,
 	             size_t n_send_hi, void *recv_hi, size_t n_recv_hi) {

@@ -16,13 +16,20 @@
 //
 // Transports: RCCL (ncclSend/ncclRecv grouped to z-1/z+1 + ncclAllReduce on the handle's stream; librccl is dlopen'ed so
 // that single-GPU use has no dependency on it) and an in-process one (one host thread per handle, device-to-device copies
-// at a rendezvous) used to test the protocol with several "virtual slabs" on one GPU.
+// at a rendezvous) used to test the protocol with several "virtual slabs" on one GPU; and a multi-process one staged through
+// host shared memory (no RCCL, no peer access: the functional fallback, and how N processes are run on a 1-GPU box).
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <math.h>
+#include <sched.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -673,6 +680,216 @@ struct RcclDist : lfa_dist {
 	}
 };
 
+// ================================================================================================= shared-memory transport
+// One PROCESS per rank, messages staged through a POSIX shared-memory segment on the host: device -> segment, rendezvous,
+// segment -> device. No peer access and no RCCL, so the ranks may even share one GPU. It is the functional multi-process
+// transport (bench.py --transport shm, and the fallback when the RCCL communicator cannot be created); its cost is two PCIe
+// crossings per message, so it is never the one a throughput figure should be quoted on.
+struct ShmHeader {
+	std::atomic<uint32_t> magic;
+	uint32_t nranks;
+	uint64_t slot_bytes;
+	std::atomic<uint32_t> failed;
+	alignas(64) std::atomic<uint32_t> arrived;
+	alignas(64) std::atomic<uint64_t> generation;
+};
+struct alignas(64) ShmMail {
+	uint64_t n_lo, n_hi, n_buf;
+	char device[16];  // PCI bus id of the rank's GPU
+};
+enum : uint32_t { SHM_MAGIC = 0x4c464131u };
+
+struct ShmDist : lfa_dist {
+	void *base = nullptr;
+	size_t map_bytes = 0;
+	bool registered = false;
+	ShmHeader *hdr = nullptr;
+	ShmMail *mail = nullptr;
+	uint8_t *slots = nullptr;
+	size_t slot_bytes = 0;
+	std::vector<uint8_t> acc;
+	~ShmDist() override {
+		if (registered) (void)hipHostUnregister(base);
+		if (base) munmap(base, map_bytes);
+	}
+	uint8_t *slot(int r) const { return slots + (size_t)r * slot_bytes; }
+	/// all ranks arrive, or false when one of them failed / did not arrive in 60 s
+	bool barrier() {
+		if (hdr->failed.load(std::memory_order_acquire)) return false;
+		const uint64_t gen = hdr->generation.load(std::memory_order_acquire);
+		if (hdr->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)nranks) {
+			hdr->arrived.store(0, std::memory_order_relaxed);
+			hdr->generation.store(gen + 1, std::memory_order_release);
+			return true;
+		}
+		const auto t0 = std::chrono::steady_clock::now();
+		for (unsigned spin = 0;; ++spin) {
+			if (hdr->generation.load(std::memory_order_acquire) != gen) return true;
+			if (hdr->failed.load(std::memory_order_acquire)) return false;
+			if (spin < 2000) continue;
+			sched_yield();
+			if ((spin & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
+				hdr->failed.store(1, std::memory_order_release);
+				return false;
+			}
+		}
+	}
+	void fail() { hdr->failed.store(1, std::memory_order_release); }
+	int exchange_impl(lfa_sim *s, const void *send_lo, size_t n_send_lo, void *recv_lo, size_t n_recv_lo, const void *send_hi,
+	                  size_t n_send_hi, void *recv_hi, size_t n_recv_hi) override {
+		if (rank == 0) n_send_lo = 0;  // as over RCCL: nothing leaves through a face without a neighbour
+		if (rank + 1 == nranks) n_send_hi = 0;
+		int rc = LFA_OK;
+		if (n_send_lo + n_send_hi > slot_bytes) {
+			rc = lfa_fail(s, LFA_E_INVALID, "slab exchange of %zu bytes does not fit the shared-memory slot (%zu; LFA_SHM_SLOT_MB)",
+			              n_send_lo + n_send_hi, slot_bytes);
+		} else {
+			uint8_t *mine = slot(rank);
+			if (n_send_lo && hipMemcpyAsync(mine, send_lo, n_send_lo, hipMemcpyDeviceToHost, s->stream) != hipSuccess) rc = LFA_E_HIP;
+			if (n_send_hi && hipMemcpyAsync(mine + n_send_lo, send_hi, n_send_hi, hipMemcpyDeviceToHost, s->stream) != hipSuccess)
+				rc = LFA_E_HIP;
+			if (hipStreamSynchronize(s->stream) != hipSuccess) rc = LFA_E_HIP;
+			mail[rank].n_lo = n_send_lo;
+			mail[rank].n_hi = n_send_hi;
+		}
+		if (rc != LFA_OK) fail();
+		if (!barrier()) return rc != LFA_OK ? rc : lfa_fail(s, LFA_E_HIP, "slab exchange: a peer rank failed or timed out");
+		if (rank > 0) {
+			const ShmMail &nb = mail[rank - 1];
+			if (nb.n_hi != n_recv_lo)
+				rc = lfa_fail(s, LFA_E_INVALID, "slab exchange size mismatch with rank %d: %zu vs %zu", rank - 1, (size_t)nb.n_hi, n_recv_lo);
+			else if (n_recv_lo &&
+			         hipMemcpyAsync(recv_lo, slot(rank - 1) + nb.n_lo, n_recv_lo, hipMemcpyHostToDevice, s->stream) != hipSuccess)
+				rc = LFA_E_HIP;
+		}
+		if (rank + 1 < nranks && rc == LFA_OK) {
+			const ShmMail &nb = mail[rank + 1];
+			if (nb.n_lo != n_recv_hi)
+				rc = lfa_fail(s, LFA_E_INVALID, "slab exchange size mismatch with rank %d: %zu vs %zu", rank + 1, (size_t)nb.n_lo, n_recv_hi);
+			else if (n_recv_hi && hipMemcpyAsync(recv_hi, slot(rank + 1), n_recv_hi, hipMemcpyHostToDevice, s->stream) != hipSuccess)
+				rc = LFA_E_HIP;
+		}
+		if (rc == LFA_OK && hipStreamSynchronize(s->stream) != hipSuccess) rc = LFA_E_HIP;
+		if (rc != LFA_OK) fail();
+		if (!barrier() && rc == LFA_OK)  // nobody overwrites its slot before every copy out of it is done
+			rc = lfa_fail(s, LFA_E_HIP, "slab exchange: a peer rank failed or timed out");
+		return rc;
+	}
+	int allreduce_impl(lfa_sim *s, double *dev, int count, bool is_max) override {
+		return allreduce_buf_impl(s, dev, (size_t)count, LFA_RED_F64, is_max);
+	}
+	int allreduce_buf_impl(lfa_sim *s, void *dev, size_t count, int dtype, bool is_max) override {
+		const size_t es = dtype == LFA_RED_U8 ? 1 : (dtype == LFA_RED_F32 ? 4 : 8), bytes = count * es;
+		int rc = LFA_OK;
+		if (bytes > slot_bytes) {
+			rc = lfa_fail(s, LFA_E_INVALID, "slab all-reduce of %zu bytes does not fit the shared-memory slot (%zu; LFA_SHM_SLOT_MB)", bytes,
+			              slot_bytes);
+		} else {
+			if (hipMemcpyAsync(slot(rank), dev, bytes, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+			    hipStreamSynchronize(s->stream) != hipSuccess)
+				rc = LFA_E_HIP;
+			mail[rank].n_buf = bytes;
+		}
+		if (rc != LFA_OK) fail();
+		if (!barrier()) return rc != LFA_OK ? rc : lfa_fail(s, LFA_E_HIP, "slab all-reduce: a peer rank failed or timed out");
+		acc.resize(bytes);
+		memcpy(acc.data(), slot(0), bytes);  // fixed rank order: every rank computes the identical array
+		bool ok = mail[0].n_buf == bytes;
+		for (int r = 1; r < nranks && ok; ++r) {
+			if (mail[r].n_buf != bytes) { ok = false; break; }
+			if (dtype == LFA_RED_U8) {
+				uint8_t *a = acc.data();
+				const uint8_t *b = slot(r);
+				for (size_t i = 0; i < count; ++i) a[i] = is_max ? std::max(a[i], b[i]) : (uint8_t)(a[i] + b[i]);
+			} else if (dtype == LFA_RED_F32) {
+				float *a = (float *)acc.data();
+				const float *b = (const float *)slot(r);
+				for (size_t i = 0; i < count; ++i) a[i] = is_max ? std::max(a[i], b[i]) : a[i] + b[i];
+			} else {
+				double *a = (double *)acc.data();
+				const double *b = (const double *)slot(r);
+				for (size_t i = 0; i < count; ++i) {
+					const double x = b[i], y = a[i];
+					a[i] = is_max ? ((x != x || y != y) ? NAN : (x > y ? x : y)) : y + x;
+				}
+			}
+		}
+		if (!ok) fail();
+		if (!barrier() || !ok) return lfa_fail(s, LFA_E_HIP, "slab all-reduce: size mismatch or a peer rank failed");
+		LFA_HIP(s, hipMemcpyAsync(dev, acc.data(), bytes, hipMemcpyHostToDevice, s->stream));
+		LFA_HIP(s, hipStreamSynchronize(s->stream));
+		return LFA_OK;
+	}
+	/// rank 0 creates the segment, the others wait for it; false with `why` set when it cannot be had
+	bool open(const char *name, int device, const char **why) {
+		size_t mb = 32;
+		if (const char *e = getenv("LFA_SHM_SLOT_MB")) mb = (size_t)std::max(1, atoi(e));
+		const size_t head = 4096 + (((size_t)nranks * sizeof(ShmMail) + 4095) & ~(size_t)4095);
+		int fd = -1;
+		if (rank == 0) {
+			shm_unlink(name);
+			fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+			if (fd < 0) { *why = "shm_open (create) failed"; return false; }
+			slot_bytes = mb << 20;
+			map_bytes = head + (size_t)nranks * slot_bytes;
+			// posix_fallocate, not only ftruncate: a segment larger than /dev/shm must fail here, not with SIGBUS at the first touch
+			if (ftruncate(fd, (off_t)map_bytes) != 0 || posix_fallocate(fd, 0, (off_t)map_bytes) != 0) {
+				::close(fd);
+				shm_unlink(name);
+				*why = "the segment does not fit /dev/shm (LFA_SHM_SLOT_MB sets the per-rank slot, default 32)";
+				return false;
+			}
+		} else {
+			const auto t0 = std::chrono::steady_clock::now();
+			struct stat st;
+			for (;;) {  // the segment exists and has its final size
+				if (fd < 0) fd = shm_open(name, O_RDWR, 0600);
+				if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size > head) break;
+				if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
+					if (fd >= 0) ::close(fd);
+					*why = "rank 0 did not create the segment within 60 s";
+					return false;
+				}
+				usleep(2000);
+			}
+			map_bytes = (size_t)st.st_size;
+			slot_bytes = (map_bytes - head) / (size_t)nranks;
+		}
+		base = mmap(nullptr, map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+		::close(fd);
+		if (base == MAP_FAILED) { base = nullptr; if (rank == 0) shm_unlink(name); *why = "mmap of the segment failed"; return false; }
+		hdr = (ShmHeader *)base;
+		mail = (ShmMail *)((uint8_t *)base + 4096);
+		slots = (uint8_t *)base + head;
+		if (rank == 0) {  // a fresh segment is zero-filled: counters start at 0
+			hdr->nranks = (uint32_t)nranks;
+			hdr->slot_bytes = slot_bytes;
+			hdr->magic.store(SHM_MAGIC, std::memory_order_release);
+		} else {
+			const auto t0 = std::chrono::steady_clock::now();
+			while (hdr->magic.load(std::memory_order_acquire) != SHM_MAGIC) {
+				if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) { *why = "rank 0 did not initialise the segment"; return false; }
+				usleep(1000);
+			}
+			if (hdr->nranks != (uint32_t)nranks || hdr->slot_bytes != slot_bytes) { *why = "the segment belongs to another job (rank count differs)"; return false; }
+		}
+		memset(mail[rank].device, 0, sizeof mail[rank].device);
+		if (hipDeviceGetPCIBusId(mail[rank].device, (int)sizeof mail[rank].device, device) != hipSuccess) {
+			(void)hipGetLastError();
+			snprintf(mail[rank].device, sizeof mail[rank].device, "dev%d", device);
+		}
+		const bool all = barrier();
+		if (rank == 0) shm_unlink(name);  // every rank holds its mapping: the name can go, nothing is left behind on a crash
+		if (!all) { *why = "a peer rank did not attach"; return false; }
+		device_share = 0;
+		for (int r = 0; r < nranks; ++r) device_share += strncmp(mail[r].device, mail[rank].device, sizeof mail[r].device) == 0;
+		// pinned staging: copies run at PCIe rate; without it they still work
+		registered = hipHostRegister(base, map_bytes, hipHostRegisterPortable) == hipSuccess;
+		if (!registered) (void)hipGetLastError();
+		return true;
+	}
+};
+
 int attach(lfa_sim *s, lfa_dist *d, const int32_t *bounds) {
 	const int lo = bounds[d->rank], hi = bounds[d->rank + 1];
 	if (bounds[0] != 0 || bounds[d->nranks] != s->g.ntz || lo >= hi || lo < 0 || hi > s->g.ntz) {
@@ -727,6 +944,21 @@ extern "C" int lfa_dist_init_rccl(lfa_sim *s, int rank, int nranks, const void *
 	return attach(s, d, layer_bounds);
 }
 
+extern "C" int lfa_dist_init_shm(lfa_sim *s, const char *name, int rank, int nranks, const int32_t *layer_bounds) {
+	if (!s || !name || name[0] != '/' || !layer_bounds || rank < 0 || rank >= nranks) return LFA_E_INVALID;
+	LFA_HIP(s, hipSetDevice(s->device));
+	LFA_TRY(lfa_corr_commit(s));
+	ShmDist *d = new ShmDist();
+	d->rank = rank;
+	d->nranks = nranks;
+	const char *why = "";
+	if (!d->open(name, s->device, &why)) {
+		delete d;
+		return lfa_fail(s, LFA_E_HIP, "shared-memory transport %s: %s", name, why);
+	}
+	return attach(s, d, layer_bounds);
+}
+
 extern "C" lfa_hub *lfa_dist_local_hub_create(int nranks) {
 	if (nranks < 1) return nullptr;
 	lfa_hub *h = new lfa_hub();
@@ -742,6 +974,7 @@ extern "C" int lfa_dist_init_local(lfa_sim *s, lfa_hub *h, int rank, const int32
 	LocalDist *d = new LocalDist();
 	d->rank = rank;
 	d->nranks = h->n;
+	d->device_share = h->n;  // (an upper bound: handles of one hub may sit on different devices)
 	d->hub = h;
 	return attach(s, d, layer_bounds);
 }

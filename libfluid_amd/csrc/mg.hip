@@ -2076,7 +2076,10 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 				(void)hipGetLastError();
 				per_cu = 0;
 			}
-			return last - first + 1 <= MG_CO_MAX_LEVELS && M.lv[first].n_tiles <= co_max && (size_t)M.lv[first].n_tiles <= (size_t)per_cu * (size_t)n_cu;
+			// ranks that share this GPU launch their k_mg_coarse at the same time: all of them must be resident together
+			const size_t share = s->dist ? (size_t)std::max(1, s->dist->device_share) : 1;
+			return last - first + 1 <= MG_CO_MAX_LEVELS && M.lv[first].n_tiles <= co_max &&
+			       (size_t)M.lv[first].n_tiles * share <= (size_t)per_cu * (size_t)n_cu;
 		};
 		tail = last;
 		while (tail > 1 && tail - 1 >= D && fits(tail - 1)) --tail;

@@ -410,3 +410,94 @@ def test_fixed_c4_domain_on_eight_virtual_slabs():
         del t, v
         q.close()
     hub.close()
+
+
+def run_shm_processes(size, block, method, bounds, hot_steps, full_steps, tmp_path, precond, pcg_dtype):
+    """One PROCESS per slab over the shared-memory transport, all of them on this box's GPU (tests/shm_slab_worker.py)."""
+    import json
+    import subprocess
+    import sys
+    n = len(bounds) - 1
+    name = f"/lfa_test_{os.getpid()}_{abs(hash(str(tmp_path))) & 0xffffff}"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for r in range(n):
+        spec = dict(size=list(size), block=[list(block[0]), list(block[1])], method=method, bounds=list(bounds), rank=r, name=name,
+                    hot_steps=hot_steps, full_steps=full_steps, precond=precond, pcg_dtype=pcg_dtype, out=str(tmp_path / f"rank{r}.npz"))
+        procs.append(subprocess.Popen([sys.executable, "-m", "tests.shm_slab_worker", json.dumps(spec)], cwd=root,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-2000:] for o in outs)
+    return [np.load(tmp_path / f"rank{r}.npz") for r in range(n)]
+
+
+@pytest.mark.parametrize("precond,dtype", [(lfa.PRECOND_MIC0_TILED, lfa.PCG_F64), (lfa.PRECOND_MULTIGRID, lfa.PCG_F32)])
+@pytest.mark.parametrize("bounds", [[0, 2, 4], [0, 1, 2, 4]])
+def test_shared_memory_transport_between_processes(bounds, precond, dtype, tmp_path):
+    """The N > 1 protocol with one process per rank (as bench.py --gpus N runs it): the shared-memory transport carries the
+    same packed messages as the in-process one and reduces in the same rank order, so the hot path agrees with the
+    virtual-slab run bit for bit; the full steps (position correction uses atomics) agree to the slab tolerances."""
+    size, block = (16, 16, 32), ((2, 0, 2), (14, 12, 16))
+    kw = dict(precond=precond, pcg_dtype=dtype)
+    ranks = run_shm_processes(size, block, lfa.APIC, bounds, 3, 5, tmp_path, precond, dtype)
+    cells_v, parts_v, iters_v = run_slabs(size, block, lfa.APIC, 3, bounds, **kw)
+    nx, ny, nz = size
+    cells = np.zeros(nx * ny * nz, dtype=lfa.CELL_DTYPE)
+    for r in ranks:
+        lo, hi = r["slab"]
+        z0, z1 = lo * 8, min(hi * 8, nz)
+        cells.reshape(nz, ny, nx)[z0:z1] = r["cells"].reshape(nz, ny, nx)[z0:z1]
+        assert list(r["iters"]) == iters_v[0]
+    assert np.array_equal(cells["type"], cells_v["type"])
+    assert np.array_equal(cells["vel"], cells_v["vel"]), "hot path over the shared-memory transport differs from the in-process one"
+    # the full steps: against the single domain, as for the virtual slabs
+    p1, _, _ = run_time_steps(size, block, lfa.APIC, 0, **kw)  # ids of the seeding
+    s1 = lfa.Sim(size, method=lfa.APIC, blending=0.95, **kw)
+    s1.seed_block(*block)
+    for _ in range(3):
+        s1.step_hot(util.DT)
+    for _ in range(5):
+        s1.time_step(util.DT)
+    ref = s1.download_particles()[np.argsort(s1.particle_ids())]
+    s1.close()
+    parts, ids = np.concatenate([r["parts"] for r in ranks]), np.concatenate([r["ids"] for r in ranks])
+    assert len(np.unique(ids)) == len(ids) == len(ref) == len(p1)
+    assert [int(r["before"]) for r in ranks] != [len(r["parts"]) for r in ranks], "the scene pushes particles across a slab face"
+    parts = parts[np.argsort(ids)]
+    assert np.abs(parts["pos"] - ref["pos"]).max() < 2e-3
+    util.assert_close(parts["vel"], ref["vel"], 1e-2, "particle velocities, shm slabs vs single domain", atol=1e-3 * 981.0 * util.DT)
+    assert all(int(r["transport_calls"]) > 0 for r in ranks)
+
+
+def test_bench_runs_n_processes_on_one_gpu(tmp_path):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), on a box with ONE GPU: the
+    ranks share the device, torch.distributed falls to gloo and the slab messages to the shared-memory transport. Checks the
+    N > 1 host path of bench.py end to end (rendezvous, slab bounds, global CFL, max-over-ranks timing, the JSON line)."""
+    import json
+    import subprocess
+    import sys
+    import socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, LFA_SHM_SLOT_MB="16")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "bench.py", "--gpus", "2", "--config", "C2", "--steps", "4", "--warmup", "2", "--transport", "shm",
+           "--no-serial-stages"]
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "weak"
+    assert out["transport"].startswith("shm")
+    assert out["value"] > 0 and out["ms_per_step"] > 0
+    assert "2 z-slabs" in out["config"]["parallelism"]
