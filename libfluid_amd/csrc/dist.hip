@@ -67,10 +67,11 @@ template <bool PACK>
 __global__ void __launch_bounds__(128) k_planes_copy(float *stage_all, int slot0, int n, int hz, float *buf) {
 	const int k = blockIdx.x;
 	if (k >= n) return;
-	float *slab = stage_all + (size_t)(slot0 + k) * 6 * LFA_HALO_CELLS + 100 * hz;
+	float *slab = stage_all + (size_t)(slot0 + k) * 6 * LFA_HALO_CELLS;
 	float *b = buf + (size_t)k * 600;
 	for (int i = threadIdx.x; i < 600; i += 128) {
-		float *g = slab + (i / 100) * LFA_HALO_CELLS + (i % 100);
+		const int c = i % 100;
+		float *g = slab + (i / 100) * LFA_HALO_CELLS + lfa_stage_index(c % 10, c / 10, hz);
 		if (PACK) b[i] = *g;
 		else *g = b[i];
 	}
