@@ -316,7 +316,7 @@ __device__ inline void fine_decode(const float4 &r, int fy, int fz, float t[3], 
 /// (fine_record) in spos. (What the reference's _space_hash is to its 27-cell walk, include/fluid/simulation.h:193-197.)
 __global__ void __launch_bounds__(FIDX_THREADS)
 k_build_fine_index(const int *ptiles, int n_ptiles, const uint32_t *key, const float *t0, const float *t1, const float *t2,
-                   const uint32_t *tile_start, const uint32_t *tile_count, uint32_t *fine_start, float4 *spos) {
+                   const uint32_t *tile_start, const uint32_t *tile_count, uint32_t *fine_start, float4 *spos, uint32_t *key_copy) {
 	__shared__ uint32_t cnt[FIDX_CNT];
 	__shared__ uint32_t wsum[FIDX_THREADS / 64];
 	__shared__ float4 stage[FIDX_STAGE];
@@ -400,6 +400,14 @@ k_build_fine_index(const int *ptiles, int n_ptiles, const uint32_t *key, const f
 					stage[at - b] = fine_record((int)(rf[r] & 7), (int)((rf[r] >> 3) & 7), (int)((rf[r] >> 6) & 7), r0[r], r1[r], r2[r],
 					                            b + threadIdx.x + FIDX_THREADS * r);
 				}
+			// `key_copy`: the keys of before the correction, for its fallback pass and lfa_correct_collide_undo - written here, from
+			// registers and together with the other stores (a store between the loads of pass 1 held them up: vmcnt is one
+			// in-order counter), instead of by a 2 x 4 Np byte copy of their own
+			if (key_copy) {
+#pragma unroll
+				for (int r = 0; r < RPT; ++r)
+					if (rf[r] != 0xFFFFFFFFu) key_copy[b + threadIdx.x + FIDX_THREADS * r] = ((uint32_t)tile << 9) | (rf[r] & 511u);
+			}
 			__syncthreads();
 			for (uint32_t k = threadIdx.x; k < e - b; k += FIDX_THREADS) spos[b + k] = stage[k];
 		} else {
@@ -408,6 +416,7 @@ k_build_fine_index(const int *ptiles, int n_ptiles, const uint32_t *key, const f
 				float t[3];
 				const uint32_t at = atomicAdd(&cnt[fine_of(i, l, t)], 1u);
 				spos[at] = fine_record(l[0], l[1], l[2], t[0], t[1], t[2], i);
+				if (key_copy) key_copy[i] = key[i];
 			}
 		}
 		__syncthreads();
@@ -426,19 +435,11 @@ __device__ inline int fine_source(const GridDims &g, const uint32_t *tile_count,
 	return tile_count[tile] ? tile : -1;  // (tile_flag marks the DILATED set: only tiles with particles have an index)
 }
 
-/// _correct_positions + _detect_collisions for the particles of the flagged half tiles (those the LDS-tiled kernel could not
-/// hold) - or, without a flag bitmap, of all: a thread per particle gathers its 27 fine cells from the index in global memory.
-/// `n` = live particles = records of the owned tiles (ghost tiles' records lie behind them).
-__global__ void __launch_bounds__(256)
-k_correct_collide(size_t n, ParticleSoA p, uint32_t *out_key, float *out_tx, float *out_ty, float *out_tz, GridDims g,
-                   const uint8_t *solid, const uint32_t *tile_count, const uint32_t *fine_start, const float4 *spos, MoveParams mp,
-                   const uint32_t *only_flagged, const int *tile_pslot, int p_off, const uint32_t *key_before) {
-	// A thread per RECORD of the index: everything about the particle as it was BEFORE the correction - the tiled kernel has
-	// already rewritten, in place, key and fractions of the particles it moved, and which part a particle belongs to depends on
-	// its old fraction - comes from the record (fractions, index) and the copy of the old keys.
-	const size_t rk = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (rk >= n) return;
-	if (only_flagged && only_flagged[0] == 0) return;  // (word 0 counts the flagged parts: none, as a rule)
+/// One record of the fallback pass below.
+__device__ inline void correct_collide_record(size_t rk, const ParticleSoA &p, uint32_t *out_key, float *out_tx, float *out_ty, float *out_tz,
+                                              const GridDims &g, const uint8_t *solid, const uint32_t *tile_count, const uint32_t *fine_start,
+                                              const float4 *spos, const MoveParams &mp, const uint32_t *only_flagged, const int *tile_pslot,
+                                              int p_off, const uint32_t *key_before) {
 	const float4 me = spos[rk];
 	const size_t i = __float_as_uint(me.w);
 	const uint32_t key_i = key_before ? key_before[i] : p.key[i];
@@ -506,6 +507,23 @@ k_correct_collide(size_t n, ParticleSoA p, uint32_t *out_key, float *out_tx, flo
 	for (int d = 0; d < 3; ++d) split_position(to[d], nn[d], nc[d], ntt[d]);
 	out_key[i] = blocked_index(g, nc[0], nc[1], nc[2]);
 	out_tx[i] = ntt[0]; out_ty[i] = ntt[1]; out_tz[i] = ntt[2];
+}
+
+/// _correct_positions + _detect_collisions for the particles of the flagged half tiles (those the LDS-tiled kernel could not
+/// hold) - or, without a flag bitmap, of all: a thread per particle gathers its 27 fine cells from the index in global memory.
+/// `n` = live particles = records of the owned tiles (ghost tiles' records lie behind them).
+__global__ void __launch_bounds__(256)
+k_correct_collide(size_t n, ParticleSoA p, uint32_t *out_key, float *out_tx, float *out_ty, float *out_tz, GridDims g,
+                   const uint8_t *solid, const uint32_t *tile_count, const uint32_t *fine_start, const float4 *spos, MoveParams mp,
+                   const uint32_t *only_flagged, const int *tile_pslot, int p_off, const uint32_t *key_before) {
+	// A thread per RECORD of the index: everything about the particle as it was BEFORE the correction - the tiled kernel has
+	// already rewritten, in place, key and fractions of the particles it moved, and which part a particle belongs to depends on
+	// its old fraction - comes from the record (fractions, index) and the copy of the old keys.
+	if (only_flagged && only_flagged[0] == 0) return;  // (word 0 counts the flagged parts: none, as a rule - the grid is bounded, so that
+	                                                     // costs a few thousand workgroups, not n / 256)
+	for (size_t rk = (size_t)blockIdx.x * blockDim.x + threadIdx.x; rk < n; rk += (size_t)gridDim.x * blockDim.x)
+		correct_collide_record(rk, p, out_key, out_tx, out_ty, out_tz, g, solid, tile_count, fine_start, spos, mp, only_flagged, tile_pslot,
+		                       p_off, key_before);
 }
 
 /// LDS-tiled _correct_positions + _detect_collisions on the fine index. One workgroup per (particle tile, z part): part 0 moves the
@@ -1178,7 +1196,7 @@ static int correct_build_index(lfa_sim *s, bool exchange = true) {
 	ParticleSoA &cur = s->pb[s->cur];
 	if (s->timing && n) LFA_HIP(s, hipEventRecord(s->ev[40], s->stream));
 	hipLaunchKernelGGL(k_build_fine_index, dim3(grid), dim3(FIDX_THREADS), 0, s->stream, s->dist ? s->ptiles_all : s->ptiles, n_index, cur.key,
-	                   cur.t[0], cur.t[1], cur.t[2], s->tile_start, s->tile_count, s->fine_start, correction_scratch(s));
+	                   cur.t[0], cur.t[1], cur.t[2], s->tile_start, s->tile_count, s->fine_start, correction_scratch(s), s->pb[s->cur ^ 1].key);
 	LFA_LAUNCH_CHECK(s);
 	return LFA_OK;
 }
@@ -1204,8 +1222,8 @@ static int correct_apply(lfa_sim *s, double dt, bool migrate = true, bool with_c
 		{
 			const int work = CORR_PARTS * s->n_ptiles, g2 = work < 65536 ? (work > 0 ? work : 1) : 65536;
 			// every neighbour position comes from the records of the index built above (the OLD positions), so the new ones are
-			// written in place; the fallback pass below takes its particles' old state from the records and this copy of the keys
-			LFA_HIP(s, hipMemcpyAsync(oth.key, cur.key, n * 4, hipMemcpyDeviceToDevice, s->stream));
+			// written in place; the fallback pass below takes its particles' old state from the records and the copy of the keys
+			// the index kernel has left in the other buffer
 			if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[41], s->stream));
 			hipLaunchKernelGGL(k_correct_fine, dim3(g2), dim3(CORR_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, cur.key, cur.t[0],
 			                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_count, s->fine_start, (const float4 *)spos, mpc, ovf,
@@ -1213,7 +1231,7 @@ static int correct_apply(lfa_sim *s, double dt, bool migrate = true, bool with_c
 			LFA_LAUNCH_CHECK(s);
 			if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[42], s->stream));
 		}
-		hipLaunchKernelGGL(k_correct_collide, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, cur, cur.key, cur.t[0],
+		hipLaunchKernelGGL(k_correct_collide, dim3((unsigned)std::min<size_t>((n + 255) / 256, 16384)), dim3(256), 0, s->stream, n, cur, cur.key, cur.t[0],
 		                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_count, s->fine_start, (const float4 *)spos, mpc,
 		                   (const uint32_t *)ovf, (const int *)s->tile_pslot, s->p_off, (const uint32_t *)oth.key);
 		LFA_LAUNCH_CHECK(s);

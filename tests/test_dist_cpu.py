@@ -41,6 +41,16 @@ def test_two_rank_plumbing_over_gloo(tmp_path):
         t = torch.tensor([1.0 + rank], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         assert t.item() == float(world)
+        # the transport hand-shake of bench.py: "did every rank get its communicator" (MIN over ranks: one failure moves all
+        # of them to the shared-memory transport), then rank 0's segment name reaches every rank
+        ok = torch.tensor([0 if rank == 1 else 1], dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        assert int(ok.item()) == 0
+        names = [f"/lfa_test_{{os.getpid()}}"] if rank == 0 else [None]
+        dist.broadcast_object_list(names, src=0)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, names[0])
+        assert names[0].startswith("/lfa_test_") and all(g == names[0] for g in gathered)
         dist.barrier()
         dist.destroy_process_group()
         print("rank", rank, "ok")

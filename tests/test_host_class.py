@@ -105,7 +105,9 @@ def test_callbacks_do_not_evict_the_step_from_the_device(tmp_path):
         best = min(run_driver(tmp_path, exe, cfg, parts, None, mode)[2] for _ in range(2))
         ms[mode] = best
     print("host class step ms:", ms)
-    assert ms["two"] <= 1.05 * ms["nocb"] + 0.15, ms      # + the extra launches / event syncs of the staged path
+    assert ms["two"] <= 1.10 * ms["nocb"] + 0.35, ms      # + the extra launches / event syncs of the staged path (measured +0.2 ms; a
+                                                            # timing on a shared box: the margin keeps the check from flaking, a step
+                                                            # that left the device costs tens of ms)
     assert ms["callbacks"] <= ms["two"] + 25.0, ms          # one 40 MB download + a max over it on one core
 
 
