@@ -38,8 +38,11 @@
 #define MG_MAX_LEVELS 12
 #define MG_NBR_STRIDE 8  // per slot: six face-neighbour tile ids (-1: inactive) + own tile id + pad
 // Sweeps per smoothing step. The values across the tile faces stay frozen during a step, so the extra sweep only touches LDS:
-// no HBM traffic, and a third fewer iterations (C4: 31 -> 19; a third sweep gains little).
+// no HBM traffic, and a third fewer iterations (C4: 31 -> 19). A third sweep LOSES (tools/ab_sweeps.sh, round 3: 16.0 / 16.6 instead
+// of 15.1 / 15.9 iterations at C3 / C4 and 7 % more time per iteration; C3 at step 550: 22.2 against 22.1 iterations).
+#ifndef MG_INNER_SWEEPS
 #define MG_INNER_SWEEPS 2
+#endif
 // Over-relaxation of the Gauss-Seidel update (red-black SOR as the smoother; forward and backward sweeps stay adjoint).
 // Measured iterations at C2 / C3 / C4: 1.0: 15 / 18 / 19, 1.08: 14 / 16 / 17, 1.15: - / 15 / 16, 1.2: 13 / 15 / 16, 1.3: - / 17 / 17, 1.5: - / 29 / 31.
 #define MG_OMEGA 1.15
