@@ -259,7 +259,8 @@ int lfa_correct_collide_undo(lfa_sim *s);
  *   lfa_dist_local_*    : the same protocol between handles of ONE process (one host thread per handle), device-to-device
  *                         copies instead of RCCL: how the slab logic is tested on a single GPU ("virtual slabs")
  *   lfa_dist_init_shm   : one PROCESS per rank, messages staged through the POSIX shared-memory segment `name` ("/..."; rank 0
- *                         creates it, every rank of the job passes the same name; LFA_SHM_SLOT_MB = per-rank slot, default 32).
+ *                         creates it, every rank of the job passes the same name; LFA_SHM_SLOT_MB = per-rank slot, default 32;
+ *                         LFA_SHM_TIMEOUT_S = how long a rank waits for its peers before the call fails, default 60).
  *                         No RCCL and no peer access, ranks may share a GPU: the functional fallback when the communicator
  *                         cannot be created, and the way N processes are exercised on a 1-GPU box. Two PCIe crossings per
  *                         message: not a transport to quote throughput on. */

@@ -700,6 +700,16 @@ struct alignas(64) ShmMail {
 };
 enum : uint32_t { SHM_MAGIC = 0x4c464131u };
 
+/// how long a rank waits for its peers (segment creation, every rendezvous) before it fails the job: LFA_SHM_TIMEOUT_S, default 60
+static int shm_timeout_s() {
+	static const int t = [] {
+		const char *e = getenv("LFA_SHM_TIMEOUT_S");
+		const int v = e ? atoi(e) : 60;
+		return v > 0 ? v : 60;
+	}();
+	return t;
+}
+
 struct ShmDist : lfa_dist {
 	void *base = nullptr;
 	size_t map_bytes = 0;
@@ -714,7 +724,7 @@ struct ShmDist : lfa_dist {
 		if (base) munmap(base, map_bytes);
 	}
 	uint8_t *slot(int r) const { return slots + (size_t)r * slot_bytes; }
-	/// all ranks arrive, or false when one of them failed / did not arrive in 60 s
+	/// all ranks arrive, or false when one of them failed / did not arrive in time (LFA_SHM_TIMEOUT_S, default 60 s)
 	bool barrier() {
 		if (hdr->failed.load(std::memory_order_acquire)) return false;
 		const uint64_t gen = hdr->generation.load(std::memory_order_acquire);
@@ -729,7 +739,7 @@ struct ShmDist : lfa_dist {
 			if (hdr->failed.load(std::memory_order_acquire)) return false;
 			if (spin < 2000) continue;
 			sched_yield();
-			if ((spin & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
+			if ((spin & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(shm_timeout_s())) {
 				hdr->failed.store(1, std::memory_order_release);
 				return false;
 			}
@@ -846,9 +856,9 @@ struct ShmDist : lfa_dist {
 			for (;;) {  // the segment exists and has its final size
 				if (fd < 0) fd = shm_open(name, O_RDWR, 0600);
 				if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size > head) break;
-				if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
+				if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(shm_timeout_s())) {
 					if (fd >= 0) ::close(fd);
-					*why = "rank 0 did not create the segment within 60 s";
+					*why = "rank 0 did not create the segment in time (LFA_SHM_TIMEOUT_S)";
 					return false;
 				}
 				usleep(2000);
@@ -869,7 +879,7 @@ struct ShmDist : lfa_dist {
 		} else {
 			const auto t0 = std::chrono::steady_clock::now();
 			while (hdr->magic.load(std::memory_order_acquire) != SHM_MAGIC) {
-				if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) { *why = "rank 0 did not initialise the segment"; return false; }
+				if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(shm_timeout_s())) { *why = "rank 0 did not initialise the segment"; return false; }
 				usleep(1000);
 			}
 			if (hdr->nranks != (uint32_t)nranks || hdr->slot_bytes != slot_bytes) { *why = "the segment belongs to another job (rank count differs)"; return false; }

@@ -501,3 +501,43 @@ def test_bench_runs_n_processes_on_one_gpu(tmp_path):
     assert out["transport"].startswith("shm")
     assert out["value"] > 0 and out["ms_per_step"] > 0
     assert "2 z-slabs" in out["config"]["parallelism"]
+
+
+def test_shared_memory_transport_fails_instead_of_hanging(tmp_path):
+    """A rank whose peer never shows up, or leaves in the middle of a run, gets an error after LFA_SHM_TIMEOUT_S - it does not wait
+    for ever (a rank that errors out of a step must not leave the others hanging: the driver's job would never end)."""
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rank.py"
+    script.write_text(textwrap.dedent(f"""
+        import sys, time
+        sys.path.insert(0, {root!r})
+        import libfluid_amd as lfa
+        rank, mode, name = int(sys.argv[1]), sys.argv[2], sys.argv[3]
+        if mode == "absent" and rank == 1:
+            sys.exit(0)  # never attaches
+        s = lfa.Sim((16, 16, 32), method=lfa.APIC)
+        t0 = time.time()
+        try:
+            s.init_shm_slab(name, rank, 2, [0, 2, 4])
+            s.seed_block((2, 0, 2), (14, 12, 30))
+            for k in range(3):
+                if mode == "leaves" and rank == 1 and k == 1:
+                    sys.exit(0)  # gone after the first step
+                s.step_hot(0.01)
+            print("rank", rank, "finished")
+        except lfa.LibfluidError as e:
+            print("rank", rank, "error after %.1f s:" % (time.time() - t0), str(e)[:160])
+            sys.exit(3)
+    """))
+    env = dict(os.environ, LFA_SHM_TIMEOUT_S="3")
+    for mode in ("absent", "leaves"):
+        name = f"/lfa_fail_{os.getpid()}_{mode}"
+        procs = [subprocess.Popen([sys.executable, str(script), str(r), mode, name], env=env, cwd=root, stdout=subprocess.PIPE,
+                                  stderr=subprocess.STDOUT, text=True) for r in range(2)]
+        outs = [p.communicate(timeout=120)[0] for p in procs]
+        assert procs[1].returncode == 0, outs[1]
+        assert procs[0].returncode == 3, (mode, outs[0][-1500:])
+        assert "error after" in outs[0] and ("peer" in outs[0] or "attach" in outs[0] or "timed out" in outs[0]), outs[0][-800:]
