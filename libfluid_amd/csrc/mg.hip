@@ -25,6 +25,8 @@
 // Slabs (dist.hip): the finest levels are distributed like the fine grid (own tiles, one slice per slab face exchanged where
 // a stencil crosses it), the coarser ones are replicated through one sum all-reduce of the restricted residual -- the same
 // V-cycle as on a single domain, so the iteration count does not depend on the decomposition (see lfa_mg::n_dist).
+#include <mutex>
+
 #include "pcg.h"
 
 #include <limits.h>
@@ -2060,24 +2062,43 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 	if (persist) {
 		// every workgroup of k_mg_coarse must be resident at the same time (they wait for each other): one workgroup per tile of
 		// its first level, LDS per workgroup grows with the number of levels inside
-		static int n_cu = 0;
-		if (!n_cu) {
-			int dev = 0;
-			hipDeviceProp_t prop;
-			n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-			           ? prop.multiProcessorCount : 256;
+		// (per device: a process may hold handles on several GPUs; what the queries return is kept - they sat in every V-cycle)
+		struct DevInfo {
+			int n_cu = 0;
+			bool attr_set = false;
+			int per_cu[MG_CO_MAX_LEVELS + 1];  // resident workgroups per CU by the number of levels inside, -1: not asked yet
+		};
+		static DevInfo info[64];
+		static std::mutex info_mutex;
+		DevInfo di;
+		const int dslot = s->device & 63;
+		{
+			std::lock_guard<std::mutex> lk(info_mutex);
+			DevInfo &d = info[dslot];
+			if (!d.n_cu) {
+				hipDeviceProp_t prop;
+				d.n_cu = (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+				for (int &v : d.per_cu) v = -1;
+			}
+			if (!d.attr_set) {
+				LFA_HIP(s, hipFuncSetAttribute((const void *)k_mg_coarse<real>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+				d.attr_set = true;
+			}
+			di = d;
 		}
-		static bool co_attr_set = false;
-		if (!co_attr_set) {
-			LFA_HIP(s, hipFuncSetAttribute((const void *)k_mg_coarse<real>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-			co_attr_set = true;
-		}
+		const int n_cu = di.n_cu;
 		auto fits = [&](int first) {
-			const size_t lds = (size_t)(last - first + 1) * sizeof(CoLevel<real>) + 512 * sizeof(real) + 64;
-			int per_cu = 0;  // by registers and LDS together
-			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_mg_coarse<real>, 256, lds) != hipSuccess) {
-				(void)hipGetLastError();
-				per_cu = 0;
+			const int nlev = last - first + 1;
+			if (nlev > MG_CO_MAX_LEVELS) return false;
+			const size_t lds = (size_t)nlev * sizeof(CoLevel<real>) + 512 * sizeof(real) + 64;
+			int per_cu = di.per_cu[nlev];  // by registers and LDS together
+			if (per_cu < 0) {
+				if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_mg_coarse<real>, 256, lds) != hipSuccess) {
+					(void)hipGetLastError();
+					per_cu = 0;
+				}
+				std::lock_guard<std::mutex> lk(info_mutex);
+				info[dslot].per_cu[nlev] = di.per_cu[nlev] = per_cu;
 			}
 			// ranks that share this GPU launch their k_mg_coarse at the same time: all of them must be resident together
 			const size_t share = s->dist ? (size_t)std::max(1, s->dist->device_share) : 1;
@@ -2145,12 +2166,7 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		// one workgroup per tile of its first level: every workgroup owns one tile slot on every level it reaches
 		const int W = std::max(1, M.lv[tail].n_tiles);
 		const size_t lds = (size_t)(last - tail + 1) * sizeof(CoLevel<real>) + 512 * sizeof(real);
-		static bool attr_set = false;
-		if (!attr_set) {
-			LFA_HIP(s, hipFuncSetAttribute((const void *)k_mg_coarse<real>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-			attr_set = true;
-		}
-		hipLaunchKernelGGL(k_mg_coarse<real>, dim3(W), dim3(256), lds, s->stream, C, st);
+		hipLaunchKernelGGL(k_mg_coarse<real>, dim3(W), dim3(256), lds, s->stream, C, st);  // (dynamic LDS limit: set where `fits` is)
 		LFA_LAUNCH_CHECK(s);
 		++launches;
 	} else if (parts & MG_PART_COARSE) {
@@ -2205,20 +2221,25 @@ template <typename real> static int pcg_small_t(lfa_sim *s, bool *ran) {
 	lfa_mg &M = *s->mg;
 	const int nl = M.n_levels, last = nl - 1, W = s->n_ptiles;
 	if (nl < 2 || W < 1 || W > PS_MAX_TILES || last > MG_CO_MAX_LEVELS || !M.lv[0].ready || M.lv[0].n_tiles != W) return LFA_OK;
-	static int n_cu = 0;
-	if (!n_cu) {
-		int dev = 0;
-		hipDeviceProp_t prop;
-		n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-		           ? prop.multiProcessorCount : 256;
+	static int n_cu_of[64];      // per device (a process may hold handles on several GPUs)
+	static bool attr_set_of[64];
+	static std::mutex once;
+	int n_cu;
+	{
+		std::lock_guard<std::mutex> lk(once);
+		const int d = s->device & 63;
+		if (!n_cu_of[d]) {
+			hipDeviceProp_t prop;
+			n_cu_of[d] = (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+		}
+		if (!attr_set_of[d]) {
+			LFA_HIP(s, hipFuncSetAttribute((const void *)k_pcg_small<real>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+			attr_set_of[d] = true;
+		}
+		n_cu = n_cu_of[d];
 	}
 	// every workgroup must be resident at once: LDS per workgroup = the levels below the finest + the finest level's halo block
 	const size_t lds = (size_t)last * sizeof(CoLevel<real>) + (size_t)(LFA_HALO_CELLS + 512) * sizeof(real);
-	static bool attr_set = false;
-	if (!attr_set) {
-		LFA_HIP(s, hipFuncSetAttribute((const void *)k_pcg_small<real>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-		attr_set = true;
-	}
 	int per_cu = 0;  // by registers and LDS together (168 VGPRs in fp32: 3 workgroups per CU)
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_pcg_small<real>, 256, lds) != hipSuccess) per_cu = 0;
 	(void)hipGetLastError();
