@@ -233,9 +233,8 @@ __global__ void k_mg_compact(const uint32_t *flag, const uint32_t *scan, int *li
 }
 /// six face neighbours (tile id, -1: inactive or outside) + own id per slot
 /// + in word 7 the mask of the active child tiles (level below; `flag_f` null on the finest level): k_mg_coarse waits for them
-__global__ void k_mg_build_nbr(const int *tiles, int n_tiles, GridDims g, const uint32_t *flag, int *nbr, GridDims gf, const uint32_t *flag_f) {
-	const int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n_tiles) return;
+__device__ inline void mg_build_nbr_slot(int i, const int *tiles, const GridDims &g, const uint32_t *flag, int *nbr, const GridDims &gf,
+                                         const uint32_t *flag_f) {
 	const int t = tiles[i], sy = g.ntx, sz = g.ntx * g.nty;
 	int tx, ty, tz;
 	tile_coords(g, t, tx, ty, tz);
@@ -251,6 +250,100 @@ __global__ void k_mg_build_nbr(const int *tiles, int n_tiles, GridDims g, const 
 			if (cx < gf.ntx && cy < gf.nty && cz < gf.ntz && flag_f[cx + gf.ntx * (cy + gf.nty * cz)]) mask |= 1 << k;
 		}
 	nbr[i * MG_NBR_STRIDE + 7] = mask;
+}
+__global__ void k_mg_build_nbr(const int *tiles, int n_tiles, GridDims g, const uint32_t *flag, int *nbr, GridDims gf, const uint32_t *flag_f) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n_tiles) mg_build_nbr_slot(i, tiles, g, flag, nbr, gf, flag_f);
+}
+
+/// The levels whose whole tile grid is at most MG_SMALL_NT tiles (C4: levels 2-6, C2: levels 1-4) get their tile lists, neighbour
+/// tables and clears from three launches in all instead of seven per level - at these sizes every one of those launches is its
+/// 5 us of launch latency and nothing else (35 of them, 0.15 ms per step at C4, before).
+#define MG_SMALL_NT 4096
+struct MgSmall {
+	int first, last;                   // levels first .. last (first >= 1)
+	GridDims g[MG_MAX_LEVELS];         // g[first - 1] is read too
+	uint32_t *flag[MG_MAX_LEVELS];     // the set being built; flag[first - 1] = the children's set of level `first` (an earlier launch)
+	const uint32_t *prev[MG_MAX_LEVELS];  // the set of the last set-up
+	int *tiles[MG_MAX_LEVELS], *nbr[MG_MAX_LEVELS];
+	void *x[MG_MAX_LEVELS], *b[MG_MAX_LEVELS], *y[MG_MAX_LEVELS];
+	uint8_t *abits[MG_MAX_LEVELS];
+};
+/// flags from the children's flags, exclusive scan, ascending list, count: level after level, one workgroup
+__global__ void __launch_bounds__(1024) k_mg_small_lists(MgSmall P, uint32_t *counts) {
+	__shared__ uint32_t fl[2][MG_SMALL_NT];  // the flags of the level being built and of the one below it
+	__shared__ uint32_t wsum[16];
+	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+	int cur = 0;
+	for (int l = P.first; l <= P.last; ++l, cur ^= 1) {
+		const GridDims gf = P.g[l - 1], gc = P.g[l];
+		const uint32_t *ff = P.flag[l - 1];
+		const bool below_in_lds = l > P.first;
+		uint32_t v[4], sum = 0;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int t = 4 * (int)threadIdx.x + k;
+			uint32_t any = 0;
+			if (t < gc.nt) {
+				int tx, ty, tz;
+				tile_coords(gc, t, tx, ty, tz);
+				for (int c = 0; c < 8; ++c) {
+					const int cx = 2 * tx + (c & 1), cy = 2 * ty + ((c >> 1) & 1), cz = 2 * tz + (c >> 2);
+					if (cx < gf.ntx && cy < gf.nty && cz < gf.ntz) {
+						const int ct = cx + gf.ntx * (cy + gf.nty * cz);
+						any |= below_in_lds ? fl[cur ^ 1][ct] : ff[ct];
+					}
+				}
+				any = any ? 1u : 0u;
+				fl[cur][t] = any;
+				P.flag[l][t] = any;
+			}
+			v[k] = any;
+			sum += any;
+		}
+		uint32_t incl = sum;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint32_t u = __shfl_up(incl, o, 64);
+			if (lane >= o) incl += u;
+		}
+		if (lane == 63) wsum[wid] = incl;
+		__syncthreads();
+		uint32_t ex = incl - sum, total = 0;
+		for (int w = 0; w < 16; ++w) {
+			if (w < wid) ex += wsum[w];
+			total += wsum[w];
+		}
+#pragma unroll
+		for (int k = 0; k < 4; ++k)
+			if (v[k]) P.tiles[l][ex++] = 4 * (int)threadIdx.x + k;
+		if (threadIdx.x == 0) counts[l] = total;
+		__syncthreads();  // (wsum is reused; fl[cur] is complete before the next level reads it)
+	}
+}
+/// neighbour tables (blockIdx.y = level - first) and the clears a departed tile needs, from the counts on the device
+template <typename real> __global__ void __launch_bounds__(256) k_mg_small_tables(MgSmall P, const uint32_t *counts) {
+	const int l = P.first + (int)blockIdx.y;
+	const int n = (int)counts[l];
+	// (the children's current set: flag[l - 1] for a small level below, what the caller put there for level first - 1)
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+		mg_build_nbr_slot(i, P.tiles[l], P.g[l], P.flag[l], P.nbr[l], P.g[l - 1], P.flag[l - 1]);
+	// departed tiles (in the last set, not in this one: rare): every lane looks at one tile, the wave clears the ones found together
+	const uint32_t *prev = P.prev[l], *cur = P.flag[l];
+	real *x = (real *)P.x[l], *b = (real *)P.b[l], *y = (real *)P.y[l];
+	const int lane = threadIdx.x & 63, nt = P.g[l].nt;
+	for (int t0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63; t0 < nt; t0 += gridDim.x * blockDim.x) {
+		const int t = t0 + lane;
+		unsigned long long gone = __ballot(t < nt && prev[t] && !cur[t]);
+		while (gone) {
+			const int k = __ffsll((long long)gone) - 1;
+			gone &= gone - 1;
+			const size_t base = (size_t)(t0 + k) * 512;
+			for (int c = lane; c < 512; c += 64) {
+				x[base + c] = (real)0; b[base + c] = (real)0; y[base + c] = (real)0; P.abits[l][base + c] = 0;
+			}
+		}
+	}
 }
 /// Vectors of levels >= 1 are read where no tile of this solve writes (parents of ring cells): a tile that has left the active
 /// set must not leave values behind. One workgroup per tile that was active at the last set-up and is not now.
@@ -1819,13 +1912,26 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 		// ---- single domain: flags -> scan -> compact per level on the device, ONE read-back of the counts, then the neighbour
 		// tables. (The host version below - download of the particle tiles, sorted parent lists, binary-searched neighbours,
 		// an upload per level - cost 2.8 ms per step at C4 once the dam moves and the tile set changes every step.)
+		// the levels from `small` on have at most MG_SMALL_NT tiles in their grid: their lists / tables come from three launches in all
+		int small = nl;
+		if (!getenv("LFA_MG_NO_SMALL_SETUP"))
+			for (int l = nl - 1; l >= 1 && gs[l].nt <= MG_SMALL_NT; --l) small = l;
+		MgSmall SP;
+		SP.first = small;
+		SP.last = nl - 1;
+		for (int l = std::max(small - 1, 0); l < nl; ++l) {
+			const lfa_mg_level &L = M.lv[l];
+			SP.g[l] = gs[l];
+			SP.flag[l] = L.flag; SP.prev[l] = L.prev_flag; SP.tiles[l] = L.tiles; SP.nbr[l] = L.nbr;
+			SP.x[l] = L.x; SP.b[l] = L.b; SP.y[l] = L.y; SP.abits[l] = L.abits;
+		}
 		hipLaunchKernelGGL(k_mg_flag_level0, dim3((gs[0].nt + 255) / 256), dim3(256), 0, s->stream, (const int *)s->tile_pslot,
 		                   M.lv[0].flag, gs[0].nt);
-		for (int l = 1; l < nl; ++l)
+		for (int l = 1; l < small; ++l)
 			hipLaunchKernelGGL(k_mg_flag_parents, dim3((gs[l].nt + 255) / 256), dim3(256), 0, s->stream, gs[l - 1], gs[l],
 			                   (const uint32_t *)M.lv[l - 1].flag, M.lv[l].flag);
 		LFA_LAUNCH_CHECK(s);
-		for (int l = 0; l < nl; ++l) {
+		for (int l = 0; l < small; ++l) {
 			lfa_mg_level &L = M.lv[l];
 			if (l == 0) {  // the binning's own list
 				LFA_HIP(s, hipMemcpyAsync(L.tiles, s->ptiles, (size_t)s->n_ptiles * 4, hipMemcpyDeviceToDevice, s->stream));
@@ -1836,12 +1942,21 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 			                   (const uint32_t *)s->tile_scan, L.tiles, gs[l].nt);
 			LFA_LAUNCH_CHECK(s);
 		}
+		if (small < nl) {
+			hipLaunchKernelGGL(k_mg_small_lists, dim3(1), dim3(1024), 0, s->stream, SP, M.counts);
+			LFA_LAUNCH_CHECK(s);
+		}
 		uint32_t *hc = s->h_pinned + 64;
 		if (nl > 1) {
 			LFA_HIP(s, hipMemcpyAsync(hc, M.counts, (size_t)nl * 4, hipMemcpyDeviceToHost, s->stream));
 			LFA_HIP(s, hipStreamSynchronize(s->stream));
 		}
-		for (int l = 0; l < nl; ++l) {
+		if (small < nl) {
+			// (the children's set of the first small level: level small - 1 swaps its flag arrays in the loop below - after it the
+			// set of this set-up is its prev_flag; within the small levels the sets are the arrays k_mg_small_lists has just written)
+			for (int l = small; l < nl; ++l) M.lv[l].n_tiles = (int)hc[l];
+		}
+		for (int l = 0; l < small; ++l) {
 			lfa_mg_level &L = M.lv[l];
 			L.n_tiles = l == 0 ? s->n_ptiles : (int)hc[l];
 			if (L.n_tiles) {
@@ -1857,6 +1972,12 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 				LFA_LAUNCH_CHECK(s);
 			}
 			std::swap(L.flag, L.prev_flag);  // prev_flag = this set-up's set; flag is rewritten by the next one
+		}
+		if (small < nl) {
+			SP.flag[small - 1] = M.lv[small - 1].prev_flag;  // (swapped just above: the current set of the level below)
+			hipLaunchKernelGGL(k_mg_small_tables<real>, dim3(16, nl - small), dim3(256), 0, s->stream, SP, (const uint32_t *)M.counts);
+			LFA_LAUNCH_CHECK(s);
+			for (int l = small; l < nl; ++l) std::swap(M.lv[l].flag, M.lv[l].prev_flag);
 		}
 		same_tiles = true;  // nothing left for the host path / the whole-array clears below
 	}
