@@ -86,10 +86,40 @@ k_scan_local(const uint32_t *in, uint32_t *out, const uint32_t *block_offsets, s
 	}
 	if (total_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_BS - 1) *total_out = off;
 }
+/// A few tiles (n <= SCAN_SERIAL_MAX) by ONE workgroup, tile after tile with a running offset: one launch instead of three (reduce,
+/// scan of the block sums, local scan) - at this size each of them is its launch latency (the tile arrays of a 128^3 grid: 4 096).
+constexpr size_t SCAN_SERIAL_MAX = 8 * SCAN_TILE;
+__global__ void __launch_bounds__(SCAN_BS) k_scan_serial(const uint32_t *in, uint32_t *out, size_t n, uint32_t *total_out) {
+	__shared__ uint32_t lds[SCAN_BS / 64];
+	uint32_t carry = 0;
+	for (size_t tile0 = 0; tile0 < n; tile0 += SCAN_TILE) {
+		const size_t base = tile0 + (size_t)threadIdx.x * SCAN_IPT;
+		uint32_t x[SCAN_IPT], sum = 0;
+#pragma unroll
+		for (int k = 0; k < SCAN_IPT; ++k) {
+			x[k] = base + k < n ? in[base + k] : 0u;
+			sum += x[k];
+		}
+		uint32_t total;
+		uint32_t off = carry + block_exclusive_scan(sum, lds, total);
+#pragma unroll
+		for (int k = 0; k < SCAN_IPT; ++k) {
+			if (base + k < n) out[base + k] = off;
+			off += x[k];
+		}
+		carry += total;
+	}
+	if (total_out && threadIdx.x == 0) *total_out = carry;
+}
 }  // namespace
 
 static int scan_rec(lfa_sim *s, const uint32_t *in, uint32_t *out, size_t n, uint32_t *tmp, uint32_t *total_dev) {
 	size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+	if (nb > 1 && n <= SCAN_SERIAL_MAX) {
+		hipLaunchKernelGGL(k_scan_serial, dim3(1), dim3(SCAN_BS), 0, s->stream, in, out, n, total_dev);
+		LFA_LAUNCH_CHECK(s);
+		return LFA_OK;
+	}
 	if (nb == 1) {
 		hipLaunchKernelGGL(k_scan_local, dim3(1), dim3(SCAN_BS), 0, s->stream, in, out, (const uint32_t *)nullptr, n,
 		                   total_dev);
