@@ -88,7 +88,7 @@ k_scan_local(const uint32_t *in, uint32_t *out, const uint32_t *block_offsets, s
 }
 /// A few tiles (n <= SCAN_SERIAL_MAX) by ONE workgroup, tile after tile with a running offset: one launch instead of three (reduce,
 /// scan of the block sums, local scan) - at this size each of them is its launch latency (the tile arrays of a 128^3 grid: 4 096).
-constexpr size_t SCAN_SERIAL_MAX = 8 * SCAN_TILE;
+constexpr size_t SCAN_SERIAL_MAX = 4 * SCAN_TILE;  // (8 tiles = 16 384 entries, C4's particle-tile arrays, are already slower this way than in three launches)
 __global__ void __launch_bounds__(SCAN_BS) k_scan_serial(const uint32_t *in, uint32_t *out, size_t n, uint32_t *total_out) {
 	__shared__ uint32_t lds[SCAN_BS / 64];
 	uint32_t carry = 0;
