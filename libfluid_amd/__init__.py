@@ -170,11 +170,12 @@ def load_library():
     """Loads libfluid_amd.so and binds every entry point of include/libfluid_amd.h. Raises if the library is missing."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("LFA_LIB_PATH") or LIB_PATH  # (A/B measurements: a variant build, libfluid_amd/build.py build_variant)
+        if not os.path.exists(path):
             raise ImportError(
-                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback for the hot path)")
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args

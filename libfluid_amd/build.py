@@ -58,5 +58,30 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_variant(name, defs, sources):
+    """A/B builds: `sources` recompiled with extra -D switches, linked with the other objects of the regular build into
+    libfluid_amd/variants/<name>.so (select it with LFA_LIB_PATH; the regular library is never overwritten)."""
+    build()
+    hipcc = _hipcc()
+    vdir = os.path.join(HERE, "variants")
+    os.makedirs(vdir, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        if src in sources:
+            o = os.path.join(vdir, name + "_" + src.replace(".hip", ".o"))
+            r = subprocess.run([hipcc, *FLAGS, *["-D" + d for d in defs], "-c", os.path.join(CSRC, src), "-o", o],
+                               capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+        objs.append(o)
+    lib = os.path.join(vdir, name + ".so")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs, "-ldl", "-lpthread"], check=True)
+    return lib
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if len(sys.argv) > 1 and sys.argv[1] == "variant":  # python build.py variant NAME p2g.hip[,core.hip] -DX=1 ...
+        print(build_variant(sys.argv[2], [a[2:] for a in sys.argv[4:]], sys.argv[3].split(",")))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

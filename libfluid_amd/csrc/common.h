@@ -37,6 +37,7 @@ void lfa_pool_park_set(lfa_stream_set *q);
 #define LFA_HALO 10            // tile + 1-cell ring
 #define LFA_HALO_CELLS 1000
 #define LFA_WAVE 64
+#define LFA_CS_JMAX 64         // cell-sorted order (core.hip: k_cell_sort): runs per z-slice; a cell's particles beyond that form its tail
 
 // cell type bits: reference values (include/fluid/mac_grid.h:17-21) + "outside the grid" marker for padding cells.
 #define CT_AIR 1
@@ -64,8 +65,22 @@ struct GridDims {
 	int nt;             // ntx*nty*ntz
 };
 
+/// A/B switches and tuning knobs, read from the environment ONCE, by lfa_create (core.hip: lfa_knobs_parse) - nothing below an entry
+/// point calls getenv. None is needed in normal use; they exist so that the measurements quoted in DESIGN.md can be repeated.
+struct lfa_knobs {
+	int bin_cellsort = 0;     // LFA_BIN_CELLSORT=1: the particles of a tile in cell order (k_cell_sort) + the cell-centric P2G scatter
+	                          // (k_p2g_cells). Built and measured in round 4: slower than the tile-order binning + particle-parallel
+	                          // scatter (profiles/r04_cells_pmc.txt) - the default stays off
+	int p2g_cells = 1;        // LFA_P2G_CELLS=0: the particle-parallel scatter also on the cell-sorted order
+	int full_scatter = 0;     // LFA_FULL_SCATTER=1: the binning moves whole records
+	int c_travels = 0;        // LFA_C_TRAVELS=1: PIC / FLIP move C with every binning (no home array)
+	int bin_shuffle = 0;      // LFA_BIN_SHUFFLE=1 (round-3 binning only)
+	int p2g_no_rot = 0;       // LFA_P2G_NO_ROT=1
+};
+
 struct lfa_sim {
 	int device = 0;
+	lfa_knobs knobs;
 	hipStream_t stream = nullptr;
 	hipStream_t stream2 = nullptr;  // side stream: the coarse levels of the preconditioner run beside the fine sweep
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -92,6 +107,10 @@ struct lfa_sim {
 	int cur = 0;
 	uint32_t *rank = nullptr;
 	bool binned = false;
+	// the particles of every tile are in CELL order (core.hip: k_cell_sort - per 64-cell z-slice of the tile the k-th particles of
+	// its cells, then the (k+1)-th ...) and cell_count describes exactly that order: true from a binning until anything moves a
+	// particle. The cell-centric P2G scatter (p2g.hip: k_p2g_cells) needs it.
+	bool cell_sorted = false;
 
 	// z-slab domain decomposition (dist.hip). Every rank indexes the GLOBAL grid; it owns the tile layers
 	// [slab_lo, slab_hi) and mirrors one ghost tile layer on each side. dist == nullptr: single domain.

@@ -207,6 +207,20 @@ static hipError_t create_low_priority_stream(hipStream_t *st) {
 	return hipStreamCreateWithPriority(st, hipStreamNonBlocking, least);
 }
 
+/// The process environment is read here and nowhere below an entry point (lfa_knobs, common.h).
+static void lfa_knobs_parse(lfa_knobs &k) {
+	auto flag = [](const char *name, int dflt) -> int {
+		const char *e = getenv(name);
+		return e ? (atoi(e) != 0 ? 1 : 0) : dflt;
+	};
+	k.bin_cellsort = flag("LFA_BIN_CELLSORT", 0);
+	k.p2g_cells = flag("LFA_P2G_CELLS", 1);
+	k.full_scatter = flag("LFA_FULL_SCATTER", 0);
+	k.c_travels = flag("LFA_C_TRAVELS", 0);
+	k.bin_shuffle = flag("LFA_BIN_SHUFFLE", 0);
+	k.p2g_no_rot = flag("LFA_P2G_NO_ROT", 0);
+}
+
 extern "C" int lfa_create(lfa_sim **out, uint64_t nx, uint64_t ny, uint64_t nz, int device) {
 	if (!out) return lfa_fail(nullptr, LFA_E_INVALID, "lfa_create: out is NULL");
 	*out = nullptr;
@@ -224,6 +238,7 @@ extern "C" int lfa_create(lfa_sim **out, uint64_t nx, uint64_t ny, uint64_t nz, 
 
 	lfa_sim *s = new lfa_sim();
 	s->device = device;
+	lfa_knobs_parse(s->knobs);
 	GridDims &g = s->g;
 	g.nx = (int)nx; g.ny = (int)ny; g.nz = (int)nz;
 	g.ntx = (g.nx + 7) / 8; g.nty = (g.ny + 7) / 8; g.ntz = (g.nz + 7) / 8;
@@ -542,6 +557,7 @@ extern "C" int lfa_upload_particles(lfa_sim *s, const void *aos152, uint64_t n) 
 	s->np = n;
 	s->np_live = n;
 	s->binned = false;  // the grid stays what it was (G2P re-uploads corrected positions between apply and gather)
+	s->cell_sorted = false;
 	s->system_valid = false;
 	s->unknown_count_valid = false;
 	s->cur = 0;
@@ -641,8 +657,10 @@ extern "C" int lfa_download_particles(lfa_sim *s, void *aos152, uint64_t n, int 
 	IngestParams ip;
 	for (int k = 0; k < 3; ++k) ip.off[k] = s->prm.grid_offset[k];
 	ip.h = s->prm.cell_size;
-	hipLaunchKernelGGL(k_export, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, (double *)s->io_buf,
-	                   s->np_live, s->pb[s->cur], s->g, ip, flags, s->dist ? 1 : 0, slot, s->pb[s->cur ^ 1],
+	// (slabs with holes: the records [0, np_live) include the leavers' holes, and the arrivals sit behind ceil256(np))
+	const size_t n_rec = s->binned ? s->np_live : s->np;
+	hipLaunchKernelGGL(k_export, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, s->stream, (double *)s->io_buf,
+	                   n_rec, s->pb[s->cur], s->g, ip, flags, s->dist ? 1 : 0, slot, s->pb[s->cur ^ 1],
 	                   (s->move_pending && !s->dist) ? 1 : 0, s->c_home_valid ? (const float *)s->c_home : (const float *)nullptr,
 	                   s->c_home_cap);
 	LFA_LAUNCH_CHECK(s);
@@ -742,6 +760,7 @@ extern "C" int lfa_seed_block(lfa_sim *s, const int64_t lo[3], const int64_t hi[
 	s->c_home_valid = false;
 	s->vmax2_valid = false;
 	s->binned = false;
+	s->cell_sorted = false;
 	s->grid_valid = false;
 	s->system_valid = false;
 	s->unknown_count_valid = false;
@@ -965,6 +984,191 @@ __global__ void k_tile_scatter(size_t n, ParticleSoA src, ParticleSoA dst, const
 		for (int k = 0; k < 9; ++k) dst.c[k][d] = src.c[k][i];
 	}
 }
+// ---- cell-sorted binning (round 4) ------------------------------------------------------------------------------------------
+// The reference sorts its particles by cell (src/simulation.cpp:266-291) and its transfers consume the sorted runs (:346-398).
+// Here the tile is the unit of storage; INSIDE a tile the particles are put in an order a wave can consume with one lane per
+// cell and coalesced loads: the tile's eight z-slices (64 cells each, cell = lane) one after the other, and inside a slice the
+// 0-th particles of its cells (in cell order, cells without one skipped), then the 1-st particles, ... ("jagged diagonal" order),
+// LFA_CS_JMAX deep; what a crowded cell holds beyond that follows cell by cell. A particle's rank inside its cell is its rank by
+// source index - i.e. by where it stood in the order of the step before - so the order is a function of the particle state and
+// the previous order alone, not of which workgroup's atomics came first: the per-cell float sums of k_p2g_cells are reproducible.
+// Pass 2a moves nothing but an index (12 bytes per particle); pass 2b gathers key, t, id through it and writes every record once,
+// straight into its final place (through LDS: the stores leave as contiguous runs), together with the per-cell counts that
+// k_cell_count used to produce in a pass of its own.
+__global__ void k_tile_scatter_idx(size_t n, const uint32_t *key, const uint32_t *rank, const uint32_t *tile_start, uint32_t *from_tmp) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t k = key[i];
+	if (k == 0xFFFFFFFFu) return;
+	from_tmp[(size_t)tile_start[k >> 9] + rank[i]] = (uint32_t)i;
+}
+
+#define CS_THREADS 512
+#define CS_RPT 12                        // particles per thread of a tile that is ranked canonically and staged (registers)
+#define CS_MAXT (CS_THREADS * CS_RPT)    // 6144: more crowded tiles take the slow path (provisional ranks, scattered stores)
+#define CS_CHUNK 2560                    // records staged in LDS per pass (24 bytes each)
+static_assert(LFA_CS_JMAX == 64, "the slice tables are sized for 64 runs");
+
+/// Position of the particle with rank j in cell l of a tile (relative to the tile's first record): the tables are the sort kernel's.
+__device__ inline uint32_t cs_position(uint32_t l, uint32_t j, const uint32_t *sbase, const uint32_t (*jrun)[LFA_CS_JMAX + 1],
+                                       const unsigned long long (*jmask)[LFA_CS_JMAX], const uint32_t *tail_off) {
+	const uint32_t w = l >> 6, c = l & 63;
+	if (j < LFA_CS_JMAX) return sbase[w] + jrun[w][j] + (uint32_t)__popcll(jmask[w][j] & ((1ull << c) - 1ull));
+	return sbase[w] + jrun[w][LFA_CS_JMAX] + tail_off[l] + (j - LFA_CS_JMAX);
+}
+
+__global__ void __launch_bounds__(CS_THREADS)
+k_cell_sort(const int *dtiles, int n_dtiles, ParticleSoA src, ParticleSoA dst, const uint32_t *from_tmp, const uint32_t *tile_start,
+            uint32_t *from_out, uint32_t *cell_count) {
+	__shared__ uint32_t cnt[LFA_TILE_CELLS];      // particles per cell
+	__shared__ uint32_t cstart[LFA_TILE_CELLS];   // first slot of the cell in the provisional (cell-major) order; slow path: cursor
+	__shared__ uint32_t tail_off[LFA_TILE_CELLS]; // start of the cell's tail (rank >= JMAX) among the tails of its slice
+	__shared__ unsigned long long jmask[8][LFA_CS_JMAX];  // cells of the slice that hold more than j particles
+	__shared__ uint32_t jrun[8][LFA_CS_JMAX + 1];         // first record of run j inside the slice; [JMAX]: start of the tails
+	__shared__ uint32_t sbase[9];                 // first record of every slice; [8] = particles of the tile
+	__shared__ uint32_t wsum[8];
+	__shared__ uint32_t buf[6 * CS_CHUNK];        // the sources in provisional order (ranking), then the staged records
+	static_assert(6 * CS_CHUNK >= CS_MAXT, "the staging area doubles as the ranking array");
+	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+	for (int slot = blockIdx.x; slot < n_dtiles; slot += gridDim.x) {
+		const int tile = dtiles[slot];
+		const uint32_t b = tile_start[tile], e = tile_start[tile + 1], nt = e - b;
+		if (nt == 0) {  // (uniform) a tile of the dilated set without particles
+			cell_count[(size_t)tile * LFA_TILE_CELLS + threadIdx.x] = 0;
+			continue;
+		}
+		const bool fast = nt <= CS_MAXT;  // (uniform)
+		__syncthreads();
+		cnt[threadIdx.x] = 0;
+		__syncthreads();
+		// ---- phase 1: where every particle comes from, its key (cell), and the histogram; the fast path keeps what it has read
+		uint32_t rs[CS_RPT], rk[CS_RPT], rid[CS_RPT], r0[CS_RPT];
+		float rt0[CS_RPT], rt1[CS_RPT], rt2[CS_RPT];
+		if (fast) {
+#pragma unroll
+			for (int r = 0; r < CS_RPT; ++r) {
+				const uint32_t i = b + threadIdx.x + CS_THREADS * r;
+				rs[r] = 0xFFFFFFFFu;
+				if (i < e) {
+					const uint32_t sidx = from_tmp[i];
+					rs[r] = sidx;
+					rk[r] = src.key[sidx];
+					rt0[r] = src.t[0][sidx]; rt1[r] = src.t[1][sidx]; rt2[r] = src.t[2][sidx];
+					rid[r] = src.id[sidx];
+				}
+			}
+#pragma unroll
+			for (int r = 0; r < CS_RPT; ++r)
+				if (rs[r] != 0xFFFFFFFFu) r0[r] = atomicAdd(&cnt[rk[r] & 511u], 1u);
+		} else {
+			for (uint32_t i = b + threadIdx.x; i < e; i += CS_THREADS) atomicAdd(&cnt[src.key[from_tmp[i]] & 511u], 1u);
+		}
+		__syncthreads();
+		// ---- phase 2: wave w owns slice w (lane = cell): slice totals, the run tables, the tails
+		const uint32_t c = cnt[threadIdx.x];
+		cell_count[(size_t)tile * LFA_TILE_CELLS + threadIdx.x] = c;
+		uint32_t incl = c;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint32_t t = __shfl_up(incl, o, 64);
+			if (lane >= o) incl += t;
+		}
+		if (lane == 63) wsum[wid] = incl;
+		{
+			uint32_t run = 0;
+			for (uint32_t j = 0; j < LFA_CS_JMAX; ++j) {
+				const unsigned long long m = __ballot(c > j);
+				if (m == 0ull) break;
+				if (lane == 0) {
+					jmask[wid][j] = m;
+					jrun[wid][j] = run;
+				}
+				run += (uint32_t)__popcll(m);
+			}
+			if (lane == 0) jrun[wid][LFA_CS_JMAX] = run;
+			const uint32_t tc = c > LFA_CS_JMAX ? c - LFA_CS_JMAX : 0u;
+			uint32_t ti = tc;
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) {
+				const uint32_t t = __shfl_up(ti, o, 64);
+				if (lane >= o) ti += t;
+			}
+			tail_off[threadIdx.x] = ti - tc;
+		}
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			uint32_t a = 0;
+			for (int w = 0; w < 8; ++w) {
+				sbase[w] = a;
+				a += wsum[w];
+			}
+			sbase[8] = a;
+		}
+		__syncthreads();
+		cstart[threadIdx.x] = fast ? sbase[wid] + incl - c : 0u;
+		__syncthreads();
+		if (fast) {
+			// ---- phase 3: the sources, grouped by cell (in the order the atomics came back)
+#pragma unroll
+			for (int r = 0; r < CS_RPT; ++r)
+				if (rs[r] != 0xFFFFFFFFu) buf[cstart[rk[r] & 511u] + r0[r]] = rs[r];
+			__syncthreads();
+			// ---- phase 4 + 5: rank inside the cell = number of its particles with a smaller source index; the final position
+			uint32_t rp[CS_RPT];
+#pragma unroll
+			for (int r = 0; r < CS_RPT; ++r) {
+				rp[r] = 0xFFFFFFFFu;
+				if (rs[r] != 0xFFFFFFFFu) {
+					const uint32_t l = rk[r] & 511u, cb = cstart[l], cn = cnt[l];
+					uint32_t j = 0;
+					for (uint32_t k = 0; k < cn; ++k) j += buf[cb + k] < rs[r] ? 1u : 0u;
+					rp[r] = cs_position(l, j, sbase, jrun, jmask, tail_off);
+				}
+			}
+			__syncthreads();  // (the ranking array is dead: the records are staged over it)
+			// ---- phase 6: records to their places, a chunk of positions at a time, written out as contiguous runs
+			for (uint32_t lo = 0; lo < nt; lo += CS_CHUNK) {
+#pragma unroll
+				for (int r = 0; r < CS_RPT; ++r) {
+					const uint32_t q = rp[r] - lo;  // (0xFFFFFFFF - lo is out of range as well)
+					if (rp[r] != 0xFFFFFFFFu && q < CS_CHUNK) {
+						buf[q] = rk[r];
+						buf[CS_CHUNK + q] = __float_as_uint(rt0[r]);
+						buf[2 * CS_CHUNK + q] = __float_as_uint(rt1[r]);
+						buf[3 * CS_CHUNK + q] = __float_as_uint(rt2[r]);
+						buf[4 * CS_CHUNK + q] = rid[r];
+						buf[5 * CS_CHUNK + q] = rs[r];
+					}
+				}
+				__syncthreads();
+				const uint32_t m = nt - lo < CS_CHUNK ? nt - lo : CS_CHUNK;
+				for (uint32_t q = threadIdx.x; q < m; q += CS_THREADS) {
+					const size_t d = (size_t)b + lo + q;
+					dst.key[d] = buf[q];
+					dst.t[0][d] = __uint_as_float(buf[CS_CHUNK + q]);
+					dst.t[1][d] = __uint_as_float(buf[2 * CS_CHUNK + q]);
+					dst.t[2][d] = __uint_as_float(buf[3 * CS_CHUNK + q]);
+					dst.id[d] = buf[4 * CS_CHUNK + q];
+					from_out[d] = buf[5 * CS_CHUNK + q];
+				}
+				__syncthreads();
+			}
+		} else {
+			// ---- a tile with more particles than the fast path holds: ranks in the order the atomics come back (a valid cell order,
+			// not a reproducible one), stores straight to their places
+			for (uint32_t i = b + threadIdx.x; i < e; i += CS_THREADS) {
+				const uint32_t sidx = from_tmp[i], k = src.key[sidx], l = k & 511u;
+				const uint32_t j = atomicAdd(&cstart[l], 1u);
+				const size_t d = (size_t)b + cs_position(l, j, sbase, jrun, jmask, tail_off);
+				dst.key[d] = k;
+				dst.t[0][d] = src.t[0][sidx]; dst.t[1][d] = src.t[1][sidx]; dst.t[2][d] = src.t[2][sidx];
+				dst.id[d] = src.id[sidx];
+				from_out[d] = sidx;
+			}
+		}
+	}
+}
+
 /// C to / from its home array (indexed by particle id): see lfa_sim::c_home.
 __global__ void k_c_to_home(size_t n, ParticleSoA p, float *home, size_t stride) {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -991,6 +1195,15 @@ __global__ void k_gather_vc(size_t n, ParticleSoA old, ParticleSoA cur, const ui
 #pragma unroll
 		for (int k = 0; k < 9; ++k) cur.c[k][d] = old.c[k][i];
 	}
+}
+
+/// DEFER 2 on the cell-sorted path: C follows the particle at once (v stays behind).
+__global__ void k_gather_c(size_t n, ParticleSoA old, ParticleSoA cur, const uint32_t *from) {
+	size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (d >= n) return;
+	const uint32_t i = from[d];
+#pragma unroll
+	for (int k = 0; k < 9; ++k) cur.c[k][d] = old.c[k][i];
 }
 
 /// Particles per cell for every processed tile (the `count` half of _space_hash, src/simulation.cpp:266-291);
@@ -1172,11 +1385,11 @@ int lfa_hash_particles_impl(lfa_sim *s, bool counts_done) {
 		// new order (the slab migration, which packs whole records, completes the move first)
 		// PIC and FLIP carry C through the step unchanged (the reference's G2P does not touch it), so there C travels with the
 		// particle and only v stays behind
-		int defer = getenv("LFA_FULL_SCATTER") ? 0 : (s->prm.simulation_method == LFA_APIC ? 1 : 2);
+		int defer = s->knobs.full_scatter ? 0 : (s->prm.simulation_method == LFA_APIC ? 1 : 2);
 		const dim3 sgrid((unsigned)((n + 255) / 256));
 		// PIC / FLIP, single domain: C goes to its home array once and stays there - the scatter then moves key, t, id alone, like
 		// APIC's (LFA_C_TRAVELS=1: the round-2 behaviour, C moves with every binning)
-		const bool home = defer == 2 && !s->dist && !getenv("LFA_C_TRAVELS");
+		const bool home = defer == 2 && !s->dist && !s->knobs.c_travels;
 		if (home && !s->c_home_valid) {
 			LFA_TRY(lfa_c_home_ensure(s, s->pcap));
 			hipLaunchKernelGGL(k_c_to_home, sgrid, dim3(256), 0, s->stream, n, src, s->c_home, s->c_home_cap);
@@ -1186,7 +1399,36 @@ int lfa_hash_particles_impl(lfa_sim *s, bool counts_done) {
 			LFA_TRY(lfa_c_home_restore(s));
 		}
 		if (home) defer = 3;
-		const int shuffle = (!s->binned || getenv("LFA_BIN_SHUFFLE")) ? 1 : 0;
+		if (s->knobs.bin_cellsort) {
+			// pass 2a: the destination of every particle as an index (into a particle array that is free right now: the last C
+			// array of the buffer being filled - the gathers that write it, if any, come after the sort); pass 2b: the records,
+			// once, into cell order
+			uint32_t *from_tmp = (uint32_t *)dst.c[8];
+			hipLaunchKernelGGL(k_tile_scatter_idx, sgrid, dim3(256), 0, s->stream, n, (const uint32_t *)src.key, (const uint32_t *)s->rank,
+			                   (const uint32_t *)s->tile_start, from_tmp);
+			LFA_LAUNCH_CHECK(s);
+			if (s->n_dtiles) {
+				const int grid = s->n_dtiles < 16384 ? s->n_dtiles : 16384;
+				hipLaunchKernelGGL(k_cell_sort, dim3(grid), dim3(CS_THREADS), 0, s->stream, (const int *)s->dtiles, s->n_dtiles, src, dst,
+				                   (const uint32_t *)from_tmp, (const uint32_t *)s->tile_start, s->vc_src, s->cell_count);
+				LFA_LAUNCH_CHECK(s);
+			}
+			s->cur ^= 1;
+			s->vc_pending = true;
+			s->vc_with_c = defer <= 1;  // (0: everything follows at once; 2: C follows at once, v stays deferred)
+			if (defer == 0) {
+				LFA_TRY(lfa_particles_materialize(s));
+			} else if (defer == 2) {
+				hipLaunchKernelGGL(k_gather_c, sgrid, dim3(256), 0, s->stream, n, s->pb[s->cur ^ 1], s->pb[s->cur], (const uint32_t *)s->vc_src);
+				LFA_LAUNCH_CHECK(s);
+			}
+			s->binned = true;
+			s->cell_sorted = true;
+			s->system_valid = false;
+			s->unknown_count_valid = false;
+			return LFA_OK;
+		}
+		const int shuffle = (!s->binned || s->knobs.bin_shuffle) ? 1 : 0;
 		if (defer == 1 || defer == 3)
 			hipLaunchKernelGGL(k_tile_scatter<1>, sgrid, dim3(256), 0, s->stream, n, src, dst, s->rank, s->tile_start, s->tile_count,
 			                   shuffle, s->vc_src);
@@ -1208,6 +1450,7 @@ int lfa_hash_particles_impl(lfa_sim *s, bool counts_done) {
 		LFA_LAUNCH_CHECK(s);
 	}
 	s->binned = true;
+	s->cell_sorted = false;
 	s->system_valid = false;
 	s->unknown_count_valid = false;
 	return LFA_OK;

@@ -433,6 +433,7 @@ int lfa_dist_migrate(lfa_sim *s, bool vc_dead) {
 		}
 	// the next binning scans [0, at): leavers carry an invalid key and are dropped there
 	s->np_live = at;
+	s->cell_sorted = false;
 	// lfa_num_particles: the resident count follows the hand-over at once (binned: np counted the live particles of the last
 	// binning; unbinned: np is the extent of the array, holes included, until the next binning compacts it)
 	if (!s->binned) s->np = at;
@@ -919,6 +920,7 @@ int attach(lfa_sim *s, lfa_dist *d, const int32_t *bounds) {
 	s->slab_lo = lo;
 	s->slab_hi = hi;
 	s->binned = false;
+	s->cell_sorted = false;
 	s->grid_valid = false;
 	s->system_valid = false;
 	if (!s->dist_red) LFA_HIP(s, hipMalloc(&s->dist_red, (64 + 4 * 32) * 8));  // scalars | 2 gather buffers of 2 x nranks

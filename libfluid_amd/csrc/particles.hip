@@ -1075,6 +1075,7 @@ static int advect_collide(lfa_sim *s, double dt, bool with_count, bool split = f
 	LFA_TRY(lfa_sources_sync(s));
 	LFA_TRY(refresh_tile_clear(s));
 	s->counts_fresh = false;
+	s->cell_sorted = false;  // keys change in place
 	if (n) {
 		if (s->any_coerce) s->vmax2_valid = false;  // velocities are overwritten inside the coercing sources' cells
 		const uint8_t *cm = s->any_coerce ? (const uint8_t *)s->coerce_map : (const uint8_t *)nullptr;
@@ -1157,6 +1158,7 @@ extern "C" int lfa_collide(lfa_sim *s) {
 	const size_t n = s->binned ? s->np_live : s->np;
 	const bool pending = s->move_pending;
 	s->move_pending = false;
+	s->cell_sorted = false;
 	if (!n) return LFA_OK;
 	LFA_TRY(refresh_tile_clear(s));
 	ParticleSoA &cur = s->pb[s->cur], &oth = s->pb[s->cur ^ 1];
@@ -1208,6 +1210,7 @@ static int correct_apply(lfa_sim *s, double dt, bool migrate = true, bool with_c
 	mpc.collide = with_collide ? 1 : 0;
 	ParticleSoA &cur = s->pb[s->cur], &oth = s->pb[s->cur ^ 1];
 	float4 *spos = correction_scratch(s);
+	s->cell_sorted = false;  // (key, t) are rewritten in place
 	if (n) {
 		// LDS-tiled pass; half tiles whose neighbourhood exceeds the LDS capacity are flagged and redone by the global-gather
 		// kernel (restricted to those particles)

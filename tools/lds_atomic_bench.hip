@@ -21,6 +21,16 @@ __global__ void __launch_bounds__(256) k(const uint32_t *idx, float *out, int it
 		const uint32_t r = idx[blockIdx.x * 256 + threadIdx.x], l = threadIdx.x & 63;
 		a = 111 + (l & 7) + 10 * (l >> 3) + 100 * (threadIdx.x >> 6) - (r & 1) - 10 * ((r >> 1) & 1) - 100 * ((r >> 2) & 1);
 	}
+	if (PATTERN == 5 || PATTERN == 6) {  // lanes = the 64 cells of an 8 x 8 slab (x fastest), node = cell + random (0|1)^3, on two accumulator layouts
+		const uint32_t r = idx[blockIdx.x * 256 + threadIdx.x], l = threadIdx.x & 63;
+		const uint32_t hx = (l & 7) + (r & 1), hy = (l >> 3) + ((r >> 1) & 1), hz = (threadIdx.x >> 6) + ((r >> 2) & 1);
+		if (PATTERN == 5) a = hx + 10 * hy + 100 * hz;  // row-major 10 x 10 x 10
+		else a = hx >= 1 ? (hx - 1) + 8 * (hy + 10 * hz) : 800 + hy + 10 * hz;  // 8-wide interior rows, the plane hx = 0 behind them
+	}
+	if (PATTERN == 7) {  // consecutive particles of a cell-sorted tile: 8 lanes per cell, each its own random corner
+		const uint32_t r = idx[blockIdx.x * 256 + threadIdx.x], c = threadIdx.x >> 3;
+		a = (c & 7) + (r & 1) + 10 * (((c >> 3) & 3) + ((r >> 1) & 1)) + 100 * ((r >> 2) & 1);
+	}
 	float v = 1.0f + threadIdx.x;
 	for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -71,6 +81,9 @@ int main() {
 	run<2, 2>("ds_add_u64 8 lanes/addr", idx, out);
 	run<2, 3>("ds_add_u64 monotone+gaps", idx, out);
 	run<2, 4>("ds_add_u64 slab cells +-1", idx, out);
+	run<2, 5>("ds_add_u64 jds cells 10-row", idx, out);
+	run<2, 6>("ds_add_u64 jds cells 8-row", idx, out);
+	run<2, 7>("ds_add_u64 cell-sorted 8/cell", idx, out);
 	run<1, 3>("ds_add_u32 monotone+gaps", idx, out);
 	run<1, 4>("ds_add_u32 slab cells +-1", idx, out);
 	run<3, 0>("ds_add_f64 conflict-free", idx, out);
