@@ -111,6 +111,75 @@ def cpu_baseline(sample, steps, lfa):
     return out
 
 
+def build_sim(args, cfg, lfa, torch, dist, tdev, rank, world, local_rank, n_dev, shared_gpu, transport, slabs, strong):
+    """The handle of one run: the BASELINE domain (single GPU, or `strong`: split into `world` z-slabs) or - slabs, not strong -
+    the weak-scaling domain that grows along z with the number of ranks. Slab runs get their transport here."""
+    size, (blo, bhi) = list(cfg["size"]), [list(x) for x in cfg["block"]]
+    parallelism = "1 GPU"
+    if slabs and not strong:
+        # weak scaling: the domain and the dam-break block grow along z with the number of GPUs, every rank owns a slab
+        # as large as the single-GPU workload
+        size[2] *= world
+        bhi[2] *= world
+    sim = lfa.Sim(size, method=cfg["method"], blending=cfg["blending"], device=local_rank,
+                  precond={"exact": lfa.PRECOND_MIC0_EXACT, "tiled": lfa.PRECOND_MIC0_TILED,
+                           "multilevel": lfa.PRECOND_MULTILEVEL, "multigrid": lfa.PRECOND_MULTIGRID}[args.precond],
+                  pcg_dtype=lfa.PCG_F64 if args.pcg_dtype == "f64" else lfa.PCG_F32,
+                  p2g_variant=lfa.P2G_GLOBAL_ATOMIC if args.p2g == "atomic" else lfa.P2G_LDS_BINNED,
+                  max_iterations=args.max_iterations, pcg_fused=0 if args.unfused else 1)
+    transport_note = None
+    if slabs:
+        ntz = (size[2] + 7) // 8
+        bounds = lfa.balanced_layer_bounds(ntz, world, blo[2] // 8, (bhi[2] + 7) // 8)
+        if transport == "rccl":
+            # one RCCL communicator per handle: rank 0 creates the id, torch.distributed (RCCL) broadcasts it
+            uid = torch.zeros(128, dtype=torch.uint8, device=tdev)
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(lfa.rccl_unique_id()), dtype=torch.uint8))
+            if dist is not None:
+                dist.broadcast(uid, src=0)
+            ok, err = 1, ""
+            try:
+                sim.init_rccl_slab(rank, world, uid.cpu().numpy().tobytes(), bounds)
+            except lfa.LibfluidError as e:
+                ok, err = 0, str(e)
+            if dist is not None:  # either every rank has its communicator or none uses it
+                t = torch.tensor([ok], dtype=torch.int32, device=tdev)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                ok = int(t.item())
+            if not ok:
+                if args.transport == "rccl":
+                    raise SystemExit(f"rank {rank}: RCCL communicator could not be created: {err or 'failed on another rank'}")
+                # the handle that tried keeps no half-built communicator: a fresh one takes the host-staged transport
+                sim.close()
+                sim = lfa.Sim(size, method=cfg["method"], blending=cfg["blending"], device=local_rank,
+                              precond={"exact": lfa.PRECOND_MIC0_EXACT, "tiled": lfa.PRECOND_MIC0_TILED,
+                                       "multilevel": lfa.PRECOND_MULTILEVEL, "multigrid": lfa.PRECOND_MULTIGRID}[args.precond],
+                              pcg_dtype=lfa.PCG_F64 if args.pcg_dtype == "f64" else lfa.PCG_F32,
+                              p2g_variant=lfa.P2G_GLOBAL_ATOMIC if args.p2g == "atomic" else lfa.P2G_LDS_BINNED,
+                              max_iterations=args.max_iterations, pcg_fused=0 if args.unfused else 1)
+                transport = "shm"
+                # (the ghost-particle exchange of a slab face is the largest message: ~16 B per particle of one tile layer)
+                need_mb = int(16 * (bhi[0] - blo[0]) * (bhi[1] - blo[1]) * 8 * 8 * 2 / 2**20) + 8
+                transport_note = (f"RCCL communicator could not be created ({err or 'failed on another rank'}): host-staged fallback "
+                                  f"(needs LFA_SHM_SLOT_MB >= {need_mb} at this size)")
+                os.environ.setdefault("LFA_SHM_SLOT_MB", str(max(32, need_mb)))
+                if rank == 0:
+                    print(f"bench.py: {transport_note}", file=sys.stderr)
+        if transport == "shm":
+            names = [f"/lfa_bench_{os.getpid()}_{int(time.time() * 1e3) & 0xffffff}_{int(strong)}"]
+            if dist is not None:
+                dist.broadcast_object_list(names, src=0)
+            sim.init_shm_slab(names[0], rank, world, bounds)
+        parallelism = (f"{world} z-slabs (tile layers {bounds}), {'strong' if strong else 'weak'} scaling, " +
+                       ("RCCL send/recv halos + scalar all-reduces + particle migration over xGMI" if transport == "rccl" else
+                        "halos, all-reduces and particle migration staged through host shared memory (lfa_dist_init_shm)" +
+                        (f", {world} ranks on {n_dev} GPU(s)" if shared_gpu else "")))
+    elif world > 1:
+        parallelism = f"{world} independent replicas (--replicas)"
+    return sim, size, blo, bhi, parallelism, (transport if not transport_note else f"shm ({transport_note})")
+
+
 def med(xs):
     return statistics.median(xs) if xs else 0.0
 
@@ -152,15 +221,34 @@ def main():
                     "the handle's stream, or staged through host shared memory (lfa_dist_init_shm: functional, two PCIe crossings per "
                     "message). auto = rccl when every rank has its own GPU (falling back to shm only if the communicator cannot be "
                     "created), shm when ranks share a GPU")
-    ap.add_argument("--strong", action="store_true", help="N > 1: the FIXED BASELINE domain (configs[3]/[4]) split into N z-slabs "
-                    "instead of a domain that grows with N")
+    ap.add_argument("--strong", action="store_true", help="N > 1: the FIXED BASELINE domain (configs[3]/[4]) split into N z-slabs - the "
+                    "configuration BASELINE.json quotes its multi-GPU target on, and the default headline of an N > 1 run")
+    ap.add_argument("--weak", action="store_true", help="N > 1: make the weak-scaling run (domain and block grow along z with N, every rank "
+                    "owns a single-GPU-sized slab) the headline `value` instead of the fixed domain")
+    ap.add_argument("--no-secondary", action="store_true", help="N > 1: skip the other scaling mode's run (reported under `weak` / `strong`)")
     args = ap.parse_args()
+    if args.weak and args.strong:
+        raise SystemExit("--weak and --strong exclude each other")
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `--gpus N` without N ranks: this process is not a rank. Start the ranks the way the driver does (nothing here has touched
+        # a GPU yet - the children are new processes, this one only waits and hands their exit code on) rather than print a
+        # one-GPU line labelled as something else.
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print("bench.py: --gpus %d without a rank environment: launching `%s`" % (args.gpus, " ".join(cmd)), file=sys.stderr)
+        raise SystemExit(subprocess.call(cmd))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would not describe the run")
 
     import torch
     import libfluid_amd as lfa
@@ -188,63 +276,17 @@ def main():
 
     cfg_name = args.config or "C4"
     cfg = dict(scenes.CONFIGS[cfg_name])
-    size, (blo, bhi) = list(cfg["size"]), [list(x) for x in cfg["block"]]
-    parallelism = "1 GPU"
     slabs = (world > 1 and not args.replicas) or args.force_slabs
-    if slabs and not args.strong:
-        # weak scaling: the domain and the dam-break block grow along z with the number of GPUs, every rank owns a slab
-        # as large as the single-GPU workload
-        size[2] *= world
-        bhi[2] *= world
-    sim = lfa.Sim(size, method=cfg["method"], blending=cfg["blending"], device=local_rank,
-                  precond={"exact": lfa.PRECOND_MIC0_EXACT, "tiled": lfa.PRECOND_MIC0_TILED,
-                           "multilevel": lfa.PRECOND_MULTILEVEL, "multigrid": lfa.PRECOND_MULTIGRID}[args.precond],
-                  pcg_dtype=lfa.PCG_F64 if args.pcg_dtype == "f64" else lfa.PCG_F32,
-                  p2g_variant=lfa.P2G_GLOBAL_ATOMIC if args.p2g == "atomic" else lfa.P2G_LDS_BINNED,
-                  max_iterations=args.max_iterations, pcg_fused=0 if args.unfused else 1)
+    # N > 1: the headline is the FIXED BASELINE domain split into N slabs (what configs[3] and the north star's ">= 6x at 8 GPUs"
+    # are quoted on); the weak-scaling run is reported beside it (`weak`). --weak swaps the two.
+    strong = slabs and not args.weak
+    sim, size, blo, bhi, parallelism, transport_used = build_sim(args, cfg, lfa, torch, dist, tdev, rank, world, local_rank, n_dev, shared_gpu,
+                                                                 transport, slabs, strong)
     fused = not args.unfused and args.precond != "exact"
     PCG_BYTES = PCG_BYTES_MG if args.precond == "multigrid" else (PCG_BYTES_FUSED if fused else PCG_BYTES_UNFUSED)
-    if slabs:
-        ntz = (size[2] + 7) // 8
-        bounds = lfa.balanced_layer_bounds(ntz, world, blo[2] // 8, (bhi[2] + 7) // 8)
-        transport_note = None
-        if transport == "rccl":
-            # one RCCL communicator per handle: rank 0 creates the id, torch.distributed (RCCL) broadcasts it
-            uid = torch.zeros(128, dtype=torch.uint8, device=tdev)
-            if rank == 0:
-                uid.copy_(torch.frombuffer(bytearray(lfa.rccl_unique_id()), dtype=torch.uint8))
-            if dist is not None:
-                dist.broadcast(uid, src=0)
-            ok, err = 1, ""
-            try:
-                sim.init_rccl_slab(rank, world, uid.cpu().numpy().tobytes(), bounds)
-            except lfa.LibfluidError as e:
-                ok, err = 0, str(e)
-            if dist is not None:  # either every rank has its communicator or none uses it
-                t = torch.tensor([ok], dtype=torch.int32, device=tdev)
-                dist.all_reduce(t, op=dist.ReduceOp.MIN)
-                ok = int(t.item())
-            if not ok:
-                if args.transport == "rccl":
-                    raise SystemExit(f"rank {rank}: RCCL communicator could not be created: {err or 'failed on another rank'}")
-                transport = "shm"
-                transport_note = f"RCCL communicator could not be created ({err or 'failed on another rank'}): host-staged fallback"
-                if rank == 0:
-                    print(f"bench.py: {transport_note}", file=sys.stderr)
-        if transport == "shm":
-            names = [f"/lfa_bench_{os.getpid()}_{int(time.time() * 1e3) & 0xffffff}"]
-            if dist is not None:
-                dist.broadcast_object_list(names, src=0)
-            sim.init_shm_slab(names[0], rank, world, bounds)
-        parallelism = (f"{world} z-slabs (tile layers {bounds}), {'strong' if args.strong else 'weak'} scaling, " +
-                       ("RCCL send/recv halos + scalar all-reduces + particle migration over xGMI" if transport == "rccl" else
-                        "halos, all-reduces and particle migration staged through host shared memory (lfa_dist_init_shm)" +
-                        (f", {world} ranks on {n_dev} GPU(s)" if shared_gpu else "")))
-    elif world > 1:
-        parallelism = f"{world} independent replicas (--replicas)"
     extras = {}
     if slabs:
-        extras["transport"] = transport if not transport_note else f"shm ({transport_note})"
+        extras["transport"] = transport_used
     if args.obstacle:
         # a sphere in the dry part of the tank, in the path of the collapsing column, voxelized on the device and marked solid
         # without leaving it (it must not overlap the seeded block: particles deep inside a solid give rows without a diagonal)
@@ -340,7 +382,7 @@ def main():
     out = {
         "metric": "particle_steps_per_sec", "value": value, "unit": "particle-steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "strong" if (slabs and args.strong) else "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "weak" if ((slabs and not strong) or (world > 1 and not slabs)) else "strong", "vs_baseline": None,
         "dtype": "f32" if args.pcg_dtype == "f32" else "f32 particles/grid, f64 PCG vectors", "data": "synthetic",
         "config": {
             "workload": f"{cfg_name}: {size[0]}x{size[1]}x{size[2]} MAC grid, dam-break block "
@@ -576,6 +618,52 @@ def main():
         m.close()
     out.update(extras)
     sim.close()
+    if slabs and world > 1 and not args.no_secondary:
+        # the other scaling mode, beside the headline: same step, same lead-in, same barrier + max-over-ranks timing, no stage breakdown
+        other = not strong
+        sim2, size2, blo2, bhi2, par2, tr2 = build_sim(args, cfg, lfa, torch, dist, tdev, rank, world, local_rank, n_dev, shared_gpu,
+                                                      transport, slabs, other)
+        sim2.seed_block(blo2, bhi2)
+        if args.no_overlap:
+            sim2.set_step_overlap(False)
+
+        def step2():
+            c = sim2.cfl()
+            if dist is not None:
+                t_ = torch.tensor([c], dtype=torch.float64, device=tdev)
+                dist.all_reduce(t_, op=dist.ReduceOp.MIN)
+                c = float(t_.item())
+            return sim2.time_step(min(3.0 * c, args.dt_max))
+
+        def barrier2():
+            sim2.synchronize()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+        for _ in range(preroll + args.warmup):
+            step2()
+        barrier2()
+        t2 = time.perf_counter()
+        it2 = 0
+        for _ in range(args.steps):
+            _, it, _ = step2()
+            it2 += it
+        barrier2()
+        el2 = time.perf_counter() - t2
+        n2 = float(sim2.counts()["particles"])
+        if dist is not None:
+            t_ = torch.tensor([el2, -n2], dtype=torch.float64, device=tdev)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            el2 = float(t_[0].item())
+            t_ = torch.tensor([n2], dtype=torch.float64, device=tdev)
+            dist.all_reduce(t_, op=dist.ReduceOp.SUM)
+            n2 = float(t_.item())
+        out["strong" if other else "weak"] = {
+            "value": n2 * args.steps / el2, "unit": "particle-steps/s", "ms_per_step": 1e3 * el2 / args.steps, "steps": args.steps,
+            "scaling": "strong" if other else "weak", "particles": int(n2), "grid": size2, "parallelism": par2, "transport": tr2,
+            "pcg_iterations_per_step": it2 / max(args.steps, 1),
+            "note": "the other scaling mode of the same command (the line's `value` is the " + ("weak" if other else "fixed-domain") + " run)"}
+        sim2.close()
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

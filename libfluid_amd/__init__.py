@@ -714,7 +714,7 @@ class Sim:
         arr = (C.c_uint64 * 8)()
         self._chk(self.lib.lfa_get_solver_stats(self.h, C.byref(arr)))
         return dict(zip(["launches_per_iteration", "transport_calls_per_iteration", "mg_levels", "mg_first_level_in_coarse_launch",
-                         "iterations", "transport_calls_per_solve", "whole_solve_in_one_launch"], list(arr)[:7]))
+                         "iterations", "transport_calls_per_solve", "whole_solve_in_one_launch", "device_waits_given_up"], list(arr)))
 
     def counts(self):
         arr = (C.c_uint64 * 5)()

@@ -76,6 +76,26 @@ struct lfa_knobs {
 	int c_travels = 0;        // LFA_C_TRAVELS=1: PIC / FLIP move C with every binning (no home array)
 	int bin_shuffle = 0;      // LFA_BIN_SHUFFLE=1 (round-3 binning only)
 	int p2g_no_rot = 0;       // LFA_P2G_NO_ROT=1
+	int corr_prio = 0x7fffffff;  // LFA_CORR_PRIO: priority of the correction's stream (default: the lowest the device has)
+	// pressure solve (mg.hip, pcg.hip); -1 / 0 / NaN = the built-in default
+	int mg_mw_a = -1, mg_mw_u = -1;    // LFA_MG_MW_A / _U: minimum waves per SIMD of the two finest-level streaming kernels
+	int mg_dist_single = 0;   // LFA_MG_DIST_SINGLE=1: the slab mode of the hierarchy with a one-rank communicator (tests)
+	int mg_no_small_setup = 0;  // LFA_MG_NO_SMALL_SETUP=1
+	int mg_stop_at_single = 0;  // LFA_MG_STOP_AT_SINGLE=1
+	int mg_tail_tiles = -1;   // LFA_MG_TAIL_TILES
+	int mg_co_max_tiles = -1; // LFA_MG_CO_MAX_TILES
+	int mg_no_persist = 0;    // LFA_MG_NO_PERSIST=1: a launch per coarse-level phase (the bitwise A/B of k_mg_coarse)
+	int mg_cp_max_tiles = -1; // LFA_MG_CP_MAX_TILES
+	int mg_no_cp = 0;         // LFA_MG_NO_CP=1
+	int mg_tail_inner = 0;    // LFA_MG_TAIL_INNER
+	int mg_nsw = 0;           // LFA_MG_NSW
+	int mg_co_stamps = 0;     // LFA_MG_CO_STAMPS=1
+	int mg_no_chain = 0;      // LFA_MG_NO_CHAIN=1
+	int mg_co_fault = 0;      // LFA_MG_CO_FAULT=n (tests): workgroup n - 1 of k_mg_coarse never raises its first flag
+	int pcg_small = 0;        // LFA_PCG_SMALL=1: the whole solve of a small system in one launch
+	int pcg_small_max = -1;   // LFA_PCG_SMALL_MAX
+	int pcg_ga = 0, pcg_gb = 0;  // LFA_PCG_GA / _GB
+	double coarse_w1 = __builtin_nan(""), coarse_w2 = __builtin_nan("");  // LFA_COARSE_W1 / _W2
 };
 
 struct lfa_sim {
@@ -185,6 +205,11 @@ struct lfa_sim {
 	uint64_t last_iters = 0;
 	// lfa_get_solver_stats
 	uint64_t stat_launches_iter = 0, stat_transport_iter = 0, stat_transport_solve = 0, stat_mg_levels = 0, stat_mg_first_co = 0, stat_whole_solve = 0;
+	// kernels whose workgroups wait for each other (k_mg_coarse, k_pcg_small): a wait that was given up (mg.hip: co_wait) ends
+	// their use on this handle; the solve that met it is repeated on the launch-per-phase path
+	bool co_disabled = false;
+	uint64_t stat_co_aborts = 0;
+	bool gate_counted = false;  // this handle is in the device's count of live handles (lfa_co_gate_handle)
 	// warm start of the PCG (lfa_params.pcg_warm_start)
 	uint32_t *tile_epoch = nullptr;   // [nt] solve counter of the last solve a tile took part in
 	uint32_t solve_epoch = 0;         // counter of system builds
@@ -424,4 +449,8 @@ inline int lfa_corr_commit(lfa_sim *s) {
 	return lfa_corr_join(s);
 }
 #define LFA_EV_CORRECT_END 30  // ev[] slot: end of the correction (B_CORRECT of lfa_time_step)
+/// Handles alive on a device (lfa_create +1, lfa_destroy -1). With more than one, the launches of kernels whose workgroups wait for
+/// each other are chained through events across the handles' streams (mg.hip: CoGate): two of them resident half each would wait
+/// for ever.
+void lfa_co_gate_handle(int device, int delta);
 int lfa_sources_sync(lfa_sim *s);  // flattens `sources` to the device arrays if they changed (particles.hip)

@@ -200,10 +200,10 @@ __global__ void k_init_ctype(uint8_t *ctype, uint8_t *solid, GridDims g, size_t 
 }
 
 /// The correction's stream yields to the main one: the solve's short kernels should not queue behind a long VALU-bound launch.
-static hipError_t create_low_priority_stream(hipStream_t *st) {
+static hipError_t create_low_priority_stream(hipStream_t *st, int prio_knob) {
 	int least = 0, greatest = 0;
 	if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
-	if (getenv("LFA_CORR_PRIO")) least = atoi(getenv("LFA_CORR_PRIO"));
+	if (prio_knob != 0x7fffffff) least = prio_knob;
 	return hipStreamCreateWithPriority(st, hipStreamNonBlocking, least);
 }
 
@@ -219,6 +219,36 @@ static void lfa_knobs_parse(lfa_knobs &k) {
 	k.c_travels = flag("LFA_C_TRAVELS", 0);
 	k.bin_shuffle = flag("LFA_BIN_SHUFFLE", 0);
 	k.p2g_no_rot = flag("LFA_P2G_NO_ROT", 0);
+	auto num = [](const char *name, int dflt) -> int {
+		const char *e = getenv(name);
+		return e ? atoi(e) : dflt;
+	};
+	auto real_ = [](const char *name) -> double {
+		const char *e = getenv(name);
+		return e ? atof(e) : __builtin_nan("");
+	};
+	k.corr_prio = num("LFA_CORR_PRIO", 0x7fffffff);
+	k.mg_mw_a = num("LFA_MG_MW_A", -1);
+	k.mg_mw_u = num("LFA_MG_MW_U", -1);
+	k.mg_dist_single = flag("LFA_MG_DIST_SINGLE", 0);
+	k.mg_no_small_setup = flag("LFA_MG_NO_SMALL_SETUP", 0);
+	k.mg_stop_at_single = flag("LFA_MG_STOP_AT_SINGLE", 0);
+	k.mg_tail_tiles = num("LFA_MG_TAIL_TILES", -1);
+	k.mg_co_max_tiles = num("LFA_MG_CO_MAX_TILES", -1);
+	k.mg_no_persist = flag("LFA_MG_NO_PERSIST", 0);
+	k.mg_cp_max_tiles = num("LFA_MG_CP_MAX_TILES", -1);
+	k.mg_no_cp = flag("LFA_MG_NO_CP", 0);
+	k.mg_tail_inner = num("LFA_MG_TAIL_INNER", 0);
+	k.mg_nsw = num("LFA_MG_NSW", 0);
+	k.mg_co_stamps = flag("LFA_MG_CO_STAMPS", 0);
+	k.mg_no_chain = flag("LFA_MG_NO_CHAIN", 0);
+	k.mg_co_fault = num("LFA_MG_CO_FAULT", 0);
+	k.pcg_small = flag("LFA_PCG_SMALL", 0);
+	k.pcg_small_max = num("LFA_PCG_SMALL_MAX", -1);
+	k.pcg_ga = num("LFA_PCG_GA", 0);
+	k.pcg_gb = num("LFA_PCG_GB", 0);
+	k.coarse_w1 = real_("LFA_COARSE_W1");
+	k.coarse_w2 = real_("LFA_COARSE_W2");
 }
 
 extern "C" int lfa_create(lfa_sim **out, uint64_t nx, uint64_t ny, uint64_t nz, int device) {
@@ -266,7 +296,7 @@ extern "C" int lfa_create(lfa_sim **out, uint64_t nx, uint64_t ny, uint64_t nz, 
 			return lfa_fail(nullptr, LFA_E_HIP, "hipStreamCreate failed");
 		}
 		if (hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking) != hipSuccess ||
-		    create_low_priority_stream(&s->stream3) != hipSuccess ||
+		    create_low_priority_stream(&s->stream3, s->knobs.corr_prio) != hipSuccess ||
 		    hipEventCreateWithFlags(&s->ev_cfork, hipEventDisableTiming) != hipSuccess ||
 		    hipEventCreateWithFlags(&s->ev_cjoin, hipEventDisableTiming) != hipSuccess ||
 		    hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -310,6 +340,8 @@ extern "C" int lfa_create(lfa_sim **out, uint64_t nx, uint64_t ny, uint64_t nz, 
 		lfa_destroy(s);
 		return rc;
 	}
+	lfa_co_gate_handle(device, +1);
+	s->gate_counted = true;
 	*out = s;
 	return LFA_OK;
 }
@@ -322,6 +354,7 @@ static void free_soa(ParticleSoA &p) {
 extern "C" void lfa_destroy(lfa_sim *s) {
 	if (!s) return;
 	(void)hipSetDevice(s->device);
+	if (s->gate_counted) lfa_co_gate_handle(s->device, -1);
 	if (s->stream) (void)hipStreamSynchronize(s->stream);
 	if (s->stream2) (void)hipStreamSynchronize(s->stream2);
 	if (s->stream3) (void)hipStreamSynchronize(s->stream3);

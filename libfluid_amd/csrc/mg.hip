@@ -1016,6 +1016,8 @@ template <typename real> struct MgCo {
 	int first, last, nsw, inner;
 	unsigned tag;
 	unsigned long long *stamps;  // LFA_MG_CO_STAMPS=1 (debugging): workgroup 0 records the 100 MHz clock around its phases
+	int *abort;                  // pcg_state + 2: raised by a workgroup whose wait has passed CO_TIMEOUT_TICKS; every waiter checks it
+	int fault;                   // LFA_MG_CO_FAULT=n (tests): workgroup n - 1 never raises its first flag
 };
 
 /// Back-off of a polling thread: 64 clocks at first, doubling to 8 K clocks. A producer may be late by far more than a phase -
@@ -1031,16 +1033,37 @@ __device__ inline void co_backoff(int &n) {
 	else __builtin_amdgcn_s_sleep(127);
 	++n;
 }
+/// Every device-side wait is bounded: a producer that never shows up - its workgroup not resident because another process's
+/// kernel of the same kind holds the compute units, a hardware fault, a bug - must end in an error code, not in a hung GPU.
+/// After CO_TIMEOUT_TICKS of the constant 100 MHz clock (50 ms; a hand-off takes microseconds) the polling lane raises the solve's
+/// abort word; every other waiter of the launch reads that word in its slow polls and leaves too. The host finds the word at its
+/// next poll of the solver state, stops using the kernels that wait and repeats the solve on the launch-per-phase path (pcg.hip).
+#define CO_TIMEOUT_TICKS 5000000ull
+__device__ inline bool co_poll_expired(int tries, unsigned long long &t0, int *abort_word) {
+	if (tries <= 64) return false;  // (the fast polls: a hand-off in time never gets here)
+	if (t0 == 0ull) t0 = wall_clock64();
+	return __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > CO_TIMEOUT_TICKS;
+}
 /// All threads: waits until every tile in dep[0 .. n) (n <= 8; -1 entries are skipped) carries this launch's tag in `flag`.
-__device__ inline void co_wait(const unsigned *flag, const int *dep, int n, unsigned tag) {
+/// Returns false (uniformly) when the wait was given up: the caller leaves the kernel.
+__device__ inline bool co_wait(const unsigned *flag, const int *dep, int n, unsigned tag, int *abort_word) {
+	int bad = 0;
 	if ((int)threadIdx.x < n) {
 		const int d = dep[threadIdx.x];
 		if (d >= 0) {
 			int tries = 0;
-			while (__hip_atomic_load(flag + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) co_backoff(tries);
+			unsigned long long t0 = 0ull;
+			while (__hip_atomic_load(flag + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) {
+				co_backoff(tries);
+				if (co_poll_expired(tries, t0, abort_word)) {
+					__hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					bad = 1;
+					break;
+				}
+			}
 		}
 	}
-	__syncthreads();
+	return __syncthreads_or(bad) == 0;
 }
 /// All threads: this workgroup's stores so far have been acknowledged; then the tile's flag is raised.
 __device__ inline void co_post(unsigned *flag, int tile, unsigned tag) {
@@ -1166,7 +1189,7 @@ __device__ inline bool co_static(const MgCo<real> &P, const CoThread &T, CoLevel
 	if (t < 8 * nlev && P.first + (t >> 3) <= lmax) nbv = P.lv[P.first + (t >> 3)].nbr[(size_t)T.wg * MG_NBR_STRIDE + (t & 7)];
 	if (state) {
 		const int st0 = state[0];
-		if (st0 >= 0) return false;  // converged: the launches queued behind the stopping test are no-ops
+		if (st0 >= 0 || state[2] != 0) return false;  // converged (or a wait was given up): the launches queued behind are no-ops
 	}
 	if (t < 8 * nlev) st[t >> 3].nb[t & 7] = nbv;
 	for (int l = P.first; l <= lmax; ++l) {
@@ -1221,7 +1244,7 @@ __device__ inline bool co_static(const MgCo<real> &P, const CoThread &T, CoLevel
 /// every other level's (its children sit on level P.first - 1, whose flags P.ready[P.first - 1] must be valid).
 /// `post_first_y`: raise the result flag of the first level too (somebody inside this launch consumes it).
 template <typename real, typename STAMP>
-__device__ inline void co_cycle(const MgCo<real> &P, const CoThread &T, CoLevel<real> *st, real *R, int *dep, unsigned tag, int lmax,
+__device__ inline bool co_cycle(const MgCo<real> &P, const CoThread &T, CoLevel<real> *st, real *R, int *dep, unsigned tag, int lmax,
                                 bool b_prefetched, bool post_first_y, STAMP &&stamp) {
 	const int t = T.t, c0 = T.c0, c1 = T.c1, h0 = T.h0, h1 = T.h1;
 	// ---- down
@@ -1235,7 +1258,7 @@ __device__ inline void co_cycle(const MgCo<real> &P, const CoThread &T, CoLevel<
 		if (waited) {  // the right-hand side is the restricted residual of the child tiles (level l - 1)
 			const GridDims &gf = P.lv[l - 1].g;
 			co_child_deps(T, dep, L.g, gf, tile, S.nb[7]);
-			co_wait(P.ready[l - 1] + gf.nt, dep, 8, tag);
+			if (!co_wait(P.ready[l - 1] + gf.nt, dep, 8, tag, P.abort)) return false;
 		}
 		real b0, b1;
 		if (waited) {
@@ -1254,12 +1277,12 @@ __device__ inline void co_cycle(const MgCo<real> &P, const CoThread &T, CoLevel<
 		}
 		MemAgent::st(L.x + base + c0, S.H[h0]);
 		MemAgent::st(L.x + base + c1, S.H[h1]);
-		co_post(P.ready[l], tile, tag);
+		if (!(P.fault && l == P.first && T.wg == P.fault - 1)) co_post(P.ready[l], tile, tag);  // (fault injection: see MgCo::fault)
 		stamp();
 		// residual: the ring holds the neighbours' pre-smoothed values
 		if (t < 6) dep[t] = S.nb[t];
 		__syncthreads();
-		co_wait(P.ready[l], dep, 6, tag);
+		if (!co_wait(P.ready[l], dep, 6, tag, P.abort)) return false;
 		co_load_ring<real>(T, S.H, S.nb, L.x);
 		R[c0] = co_residual_cell<real>(S.H, a0, b0, h0);
 		R[c1] = co_residual_cell<real>(S.H, a1, b1, h1);
@@ -1280,7 +1303,7 @@ __device__ inline void co_cycle(const MgCo<real> &P, const CoThread &T, CoLevel<
 		if (waited) {
 			const GridDims &gf = P.lv[l - 1].g;
 			co_child_deps(T, dep, L.g, gf, tile, S.nb[7]);
-			co_wait(P.ready[l - 1] + gf.nt, dep, 8, tag);
+			if (!co_wait(P.ready[l - 1] + gf.nt, dep, 8, tag, P.abort)) return false;
 		}
 		real b0, b1;
 		if (waited) {
@@ -1311,7 +1334,7 @@ __device__ inline void co_cycle(const MgCo<real> &P, const CoThread &T, CoLevel<
 		const real b0 = S.b[c0], b1 = S.b[c1];
 		// the corrections come from the parent tile and from the parents of the active neighbour tiles
 		co_parent_deps(T, dep, L.g, gc, S.nb);
-		co_wait(P.ready[l + 1] + 2 * gc.nt, dep, 7, tag);
+		if (!co_wait(P.ready[l + 1] + 2 * gc.nt, dep, 7, tag, P.abort)) return false;
 		co_add_correction<real>(T, S.H, a0, a1, S.rab, S.nb, L.g, gc, tile, P.lv[l + 1].y);
 		for (int it = 0; it < P.inner; ++it) {
 			co_half_sweep<real>(T, S.H, a0, a1, b0, b1, 1);
@@ -1322,6 +1345,7 @@ __device__ inline void co_cycle(const MgCo<real> &P, const CoThread &T, CoLevel<
 		if (l > P.first || post_first_y) co_post(P.ready[l] + 2 * L.g.nt, tile, tag);
 		stamp();
 	}
+	return true;
 }
 
 template <typename real>
@@ -1343,7 +1367,7 @@ __global__ void __launch_bounds__(256) k_mg_coarse(MgCo<real> P, const int *stat
 		if (T.wg < P.lv[l].n_tiles) lmax = l;
 	if (!co_static<real>(P, T, st, lmax, state, true)) return;
 	stamp();
-	co_cycle<real>(P, T, st, R, dep, P.tag, lmax, true, false, stamp);
+	(void)co_cycle<real>(P, T, st, R, dep, P.tag, lmax, true, false, stamp);
 }
 
 // ------------------------------------------------------------------------------------------------ a whole solve in ONE launch
@@ -1379,10 +1403,12 @@ template <typename real> struct PcgSmall {
 /// All threads: every workgroup's partial of this tag is in; returns their sum (and, MAXTOO, the NaN-aware maximum of a second
 /// array), identical in every workgroup: strided private sums in index order, a butterfly per wave, one exchange through LDS.
 template <bool MAXTOO>
-__device__ inline void co_reduce(const double *sum_part, const double *max_part, const unsigned *flag, int W, unsigned tag, double *lds,
-                                 double &sum, double &mx) {
+__device__ inline bool co_reduce(const double *sum_part, const double *max_part, const unsigned *flag, int W, unsigned tag, double *lds,
+                                 double &sum, double &mx, int *abort_word) {
 	const int t = threadIdx.x;
+	int bad = 0;
 	if (t < 64) {
+		unsigned long long t0 = 0ull;
 		// ONE wave polls (a lane's four flags read together, one round trip per attempt, with back-off): every thread of every
 		// workgroup re-reading the flags is a storm that starves the producers when they are late (see co_backoff)
 		int tries = 0;
@@ -1398,9 +1424,14 @@ __device__ inline void co_reduce(const double *sum_part, const double *max_part,
 			for (int k = 0; k < PS_MAX_TILES / 64; ++k) all &= f[k] == tag;
 			if (all) break;
 			co_backoff(tries);
+			if (co_poll_expired(tries, t0, abort_word)) {
+				__hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				bad = 1;
+				break;
+			}
 		}
 	}
-	__syncthreads();
+	if (__syncthreads_or(bad)) return false;
 	double a = 0.0, m = -INFINITY;
 	bool nan = false;
 	for (int i = t; i < W; i += 256) {
@@ -1427,6 +1458,7 @@ __device__ inline void co_reduce(const double *sum_part, const double *max_part,
 		for (int k = 1; k < 4; ++k) mx = (mx != mx || lds[4 + k] != lds[4 + k]) ? NAN : (lds[4 + k] > mx ? lds[4 + k] : mx);
 	}
 	__syncthreads();
+	return true;
 }
 
 template <typename real>
@@ -1479,7 +1511,7 @@ __global__ void __launch_bounds__(256) k_pcg_small(PcgSmall<real> Q) {
 			co_post(Q.sflag, tile0, tag);
 			if (t < 6) dep[t] = nb0[t];
 			__syncthreads();
-			co_wait(Q.sflag, dep, 6, tag);
+			if (!co_wait(Q.sflag, dep, 6, tag, P.abort)) return;  // (p and r stay what they were: the host repeats the solve)
 			co_load_ring<real>(T, H0, nb0, Q.s);
 			double acc = 0.0;
 #pragma unroll
@@ -1512,7 +1544,7 @@ __global__ void __launch_bounds__(256) k_pcg_small(PcgSmall<real> Q) {
 				__hip_atomic_store(Q.pflag + wg, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
 			double gamma, unused;
-			co_reduce<false>(Q.part, nullptr, Q.pflag, W, tag, red, gamma, unused);
+			if (!co_reduce<false>(Q.part, nullptr, Q.pflag, W, tag, red, gamma, unused, P.abort)) return;
 			// ---- p += alpha s, r -= alpha q, signed max of the new residual (k_mg_axpy_presmooth's expressions)
 			const real alpha = (real)(sigma / gamma);
 #pragma unroll
@@ -1546,16 +1578,16 @@ __global__ void __launch_bounds__(256) k_pcg_small(PcgSmall<real> Q) {
 			co_post(P.ready[0], tile0, tag);
 			if (t < 6) dep[t] = nb0[t];
 			__syncthreads();
-			co_wait(P.ready[0], dep, 6, tag);
+			if (!co_wait(P.ready[0], dep, 6, tag, P.abort)) return;
 			co_load_ring<real>(T, H0, nb0, Q.x0);
 			R[c0] = co_residual_cell<real>(H0, a0, b0, h0);
 			R[c1] = co_residual_cell<real>(H0, a1, b1, h1);
 			__syncthreads();
 			co_restrict_store<real>(T, R, L0.g, g1, tile0, P.lv[1].b);
 			co_post(P.ready[0] + nt0, tile0, tag);
-			co_cycle<real>(P, T, st, R, dep, tag, lmax, false, true, nostamp);
+			if (!co_cycle<real>(P, T, st, R, dep, tag, lmax, false, true, nostamp)) return;
 			co_parent_deps(T, dep, L0.g, g1, nb0);
-			co_wait(P.ready[1] + 2 * g1.nt, dep, 7, tag);
+			if (!co_wait(P.ready[1] + 2 * g1.nt, dep, 7, tag, P.abort)) return;
 			co_add_correction<real>(T, H0, a0, a1, rab0, nb0, L0.g, g1, tile0, P.lv[1].y);
 			for (int k = 0; k < P.inner; ++k) {
 				co_half_sweep<real>(T, H0, a0, a1, b0, b1, 1);
@@ -1584,7 +1616,7 @@ __global__ void __launch_bounds__(256) k_pcg_small(PcgSmall<real> Q) {
 			}
 		}
 		double sigma_new, rmax;
-		co_reduce<true>(Q.part + PS_MAX_TILES, Q.part + 2 * PS_MAX_TILES, Q.pflag + PS_MAX_TILES, W, tag, red, sigma_new, rmax);
+		if (!co_reduce<true>(Q.part + PS_MAX_TILES, Q.part + 2 * PS_MAX_TILES, Q.pflag + PS_MAX_TILES, W, tag, red, sigma_new, rmax, P.abort)) return;
 		if (it >= 0) {
 			// stopping rule of pressure_solver::solve (:54-58) on the residual of this iteration; identical in every workgroup
 			if (wg == 0 && t == 0) Q.hist[it] = rmax;
@@ -1764,14 +1796,10 @@ __global__ void __launch_bounds__(MG_TAIL_WAVES * 64) k_mg_tail(MgTail<real> T, 
 /// Minimum waves per SIMD the two streaming kernels of the finest level are compiled for (their software pipelines hold a whole
 /// tile's loads in registers: unconstrained they take 134 / 154 VGPRs = 3 waves per SIMD). LFA_MG_MW_A / LFA_MG_MW_U select
 /// another instantiation for A/B runs.
-static int mg_min_waves(const char *env, int dflt) {
-	if (const char *e = getenv(env)) return atoi(e);
-	return dflt;
-}
 #define MG_MW_DEFAULT_A 4  // (C4: 65 -> 61 us; 5 / 6 waves spill the pipeline registers: 117 / 149 us)
 #define MG_MW_DEFAULT_U 1  // (C4: 54 us; 4 / 5 / 6: 61 / 101 / 142 us)
-template <typename real, typename... Args> static void launch_axpy_presmooth(int G, hipStream_t st, Args... a) {
-	switch (mg_min_waves("LFA_MG_MW_A", MG_MW_DEFAULT_A)) {
+template <typename real, typename... Args> static void launch_axpy_presmooth(int mw, int G, hipStream_t st, Args... a) {
+	switch (mw >= 0 ? mw : MG_MW_DEFAULT_A) {
 	case 4: hipLaunchKernelGGL((k_mg_axpy_presmooth<real, 4>), dim3(G), dim3(256), 0, st, a...); break;
 	case 5: hipLaunchKernelGGL((k_mg_axpy_presmooth<real, 5>), dim3(G), dim3(256), 0, st, a...); break;
 	case 6: hipLaunchKernelGGL((k_mg_axpy_presmooth<real, 6>), dim3(G), dim3(256), 0, st, a...); break;
@@ -1779,8 +1807,8 @@ template <typename real, typename... Args> static void launch_axpy_presmooth(int
 	default: hipLaunchKernelGGL((k_mg_axpy_presmooth<real, 1>), dim3(G), dim3(256), 0, st, a...); break;
 	}
 }
-template <typename real, typename... Args> static void launch_up0(int G, hipStream_t st, Args... a) {
-	switch (mg_min_waves("LFA_MG_MW_U", MG_MW_DEFAULT_U)) {
+template <typename real, typename... Args> static void launch_up0(int mw, int G, hipStream_t st, Args... a) {
+	switch (mw >= 0 ? mw : MG_MW_DEFAULT_U) {
 	case 4: hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true, 4>), dim3(G), dim3(256), 0, st, a...); break;
 	case 5: hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true, 5>), dim3(G), dim3(256), 0, st, a...); break;
 	case 6: hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true, 6>), dim3(G), dim3(256), 0, st, a...); break;
@@ -1791,10 +1819,61 @@ template <typename real, typename... Args> static void launch_up0(int G, hipStre
 int mg_grid(int n_tiles) { return pcg_grid(n_tiles); }
 /// Slab mode of the hierarchy. A one-rank communicator needs none of it; LFA_MG_DIST_SINGLE=1 runs it anyway (tests: the array
 /// all-reduces then go through the real transport).
-bool mg_dist(const lfa_sim *s) { return s->dist && (s->dist->nranks > 1 || getenv("LFA_MG_DIST_SINGLE")); }
+bool mg_dist(const lfa_sim *s) { return s->dist && (s->dist->nranks > 1 || s->knobs.mg_dist_single); }
 }  // namespace
 
 // ================================================================================================= host side
+// Kernels whose workgroups wait for each other (k_mg_coarse, k_pcg_small) need all of them resident together; `fits` below sizes
+// one launch against the whole device. Independent handles on one GPU - several simulations of one host process, each on its own
+// thread and stream, as the C ABI allows (include/libfluid_amd.h: "different handles are independent"; the Maya host holds one
+// fluid node per simulated object, plugins/maya/nodes/grid_node.cpp:256) - could have two such launches in flight, each with part
+// of its workgroups resident and waiting for the rest. While more than one handle is alive on a device every such launch
+// therefore waits (an event, on the GPU: no host thread blocks) for the previous one of ANY handle. One handle alone pays nothing.
+// Other PROCESSES on the same GPU cannot be chained; for them - and for anything unforeseen - every wait is bounded (co_wait).
+namespace {
+struct CoGate {
+	std::mutex m;
+	hipEvent_t ev[2] = {nullptr, nullptr};
+	unsigned n = 0;       // launches chained so far
+	int handles = 0;
+};
+CoGate g_co_gate[64];
+/// Around a launch of a waiting kernel on s->stream: constructor = chain behind the previous one, done() = publish this one.
+struct CoGateScope {
+	CoGate &g;
+	lfa_sim *s;
+	bool on = false;
+	int rc = LFA_OK;
+	explicit CoGateScope(lfa_sim *s_) : g(g_co_gate[s_->device & 63]), s(s_) {
+		g.m.lock();
+		on = g.handles > 1;
+		if (!on) {
+			g.m.unlock();
+			return;
+		}
+		for (hipEvent_t &e : g.ev)
+			if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = LFA_E_HIP;
+		if (rc == LFA_OK && g.n > 0 && hipStreamWaitEvent(s->stream, g.ev[(g.n - 1) & 1], 0) != hipSuccess) rc = LFA_E_HIP;
+	}
+	int done() {
+		if (!on) return rc;
+		if (rc == LFA_OK && hipEventRecord(g.ev[g.n & 1], s->stream) != hipSuccess) rc = LFA_E_HIP;
+		++g.n;
+		on = false;
+		g.m.unlock();
+		return rc;
+	}
+	~CoGateScope() {
+		if (on) g.m.unlock();
+	}
+};
+}  // namespace
+void lfa_co_gate_handle(int device, int delta) {
+	CoGate &g = g_co_gate[device & 63];
+	std::lock_guard<std::mutex> lk(g.m);
+	g.handles += delta;
+}
+
 void lfa_mg_free(lfa_sim *s) {
 	if (!s->mg) return;
 	for (auto &L : s->mg->lv) {
@@ -1914,7 +1993,7 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 		// an upload per level - cost 2.8 ms per step at C4 once the dam moves and the tile set changes every step.)
 		// the levels from `small` on have at most MG_SMALL_NT tiles in their grid: their lists / tables come from three launches in all
 		int small = nl;
-		if (!getenv("LFA_MG_NO_SMALL_SETUP"))
+		if (!s->knobs.mg_no_small_setup)
 			for (int l = nl - 1; l >= 1 && gs[l].nt <= MG_SMALL_NT; --l) small = l;
 		MgSmall SP;
 		SP.first = small;
@@ -2151,7 +2230,7 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 	const int nl = M.n_levels;
 	int last = nl - 1;  // every level down to the single-tile one has active tiles
 	// LFA_MG_STOP_AT_SINGLE=1 (experiment): the first level with ONE active tile is the coarsest (its sweeps stand in for the levels below)
-	if (getenv("LFA_MG_STOP_AT_SINGLE") && !mg_dist(s))
+	if (s->knobs.mg_stop_at_single && !mg_dist(s))
 		for (int l = 1; l < last; ++l)
 			if (M.lv[l].n_tiles == 1) { last = l; break; }
 	auto lvl = [&](int l) {
@@ -2164,12 +2243,12 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 	if (last == 0) {  // a single level: the two sweeps alone
 		const MgLv<real> L = lvl(0);
 		if (!level0_presmoothed) hipLaunchKernelGGL(k_mg_presmooth<real>, dim3(1), dim3(256), 0, s->stream, L, st);
-		launch_up0<real>(1, s->stream, L, L.g, (const real *)nullptr, inv_scale, part_sigma, st);
+		launch_up0<real>(s->knobs.mg_mw_u, 1, s->stream, L, L.g, (const real *)nullptr, inv_scale, part_sigma, st);
 		LFA_LAUNCH_CHECK(s);
 		return LFA_OK;
 	}
 	int tail = last, tail_tiles = MG_TAIL_TILES;  // first level handled by the single-workgroup tail
-	if (const char *e = getenv("LFA_MG_TAIL_TILES")) tail_tiles = atoi(e);
+	if (s->knobs.mg_tail_tiles >= 0) tail_tiles = s->knobs.mg_tail_tiles;
 	while (tail > 1 && M.lv[tail - 1].n_tiles <= tail_tiles) --tail;
 	// slabs: levels < D run on the rank's own tiles with one slice per slab face exchanged where a stencil crosses it;
 	// levels >= D are replicated (identical work on every rank), so the tail workgroup may only hold replicated levels
@@ -2178,8 +2257,8 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 	// Default: every level of at most MG_CO_MAX_TILES tiles (C4: levels >= 2, C2: levels >= 1) runs inside ONE launch, k_mg_coarse
 	// (phases chained by completion counters instead of kernel boundaries); the larger ones keep a launch per phase.
 	int co_max = MG_CO_MAX_TILES;
-	if (const char *e = getenv("LFA_MG_CO_MAX_TILES")) co_max = atoi(e);
-	const bool persist = !getenv("LFA_MG_NO_PERSIST");
+	if (s->knobs.mg_co_max_tiles >= 0) co_max = s->knobs.mg_co_max_tiles;
+	const bool persist = !s->knobs.mg_no_persist && !s->co_disabled;
 	if (persist) {
 		// every workgroup of k_mg_coarse must be resident at the same time (they wait for each other): one workgroup per tile of
 		// its first level, LDS per workgroup grows with the number of levels inside
@@ -2233,7 +2312,7 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 	// cell-parallel kernels for levels of up to 1024 tiles (C4: levels 2 and 3; level 1 with 2048 tiles fills the chip with a
 	// wave per tile: 8.58 ms per step against 8.75 with cell-parallel kernels on every coarse level, 8.79 with none)
 	int cp_max = 1024;
-	if (const char *e = getenv("LFA_MG_CP_MAX_TILES")) cp_max = atoi(e);
+	if (s->knobs.mg_cp_max_tiles >= 0) cp_max = s->knobs.mg_cp_max_tiles;
 	auto exchange_level = [&](int l, void *vec) -> int {
 		if (l == 0) return lfa_dist_exchange_slices(s, vec, (int)sizeof(real));
 		return lfa_dist_exchange_layer_slices(s, vec, (int)sizeof(real), M.lv[l].g.ntx * M.lv[l].g.nty, M.lv[l].lo_layer, M.lv[l].hi_layer);
@@ -2242,7 +2321,7 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 	for (int l = 0; l < tail; ++l) {
 		const MgLv<real> L = lvl(l);
 		const int G = mg_grid(L.n_tiles);
-		const bool cp = l >= 1 && !getenv("LFA_MG_NO_CP") && L.n_tiles <= cp_max;  // a workgroup per tile on the coarser levels (see k_mg_*_cp)
+		const bool cp = l >= 1 && !s->knobs.mg_no_cp && L.n_tiles <= cp_max;  // a workgroup per tile on the coarser levels (see k_mg_*_cp)
 		const int Gcp = std::max(1, std::min(L.n_tiles, 8192));  // (a slab rank may hold no tile of a level)
 		if (!(l == 0 && level0_presmoothed) && (parts & (l == 0 ? MG_PART_PRE0 : MG_PART_COARSE))) {
 			if (cp) hipLaunchKernelGGL(k_mg_presmooth_cp<real>, dim3(Gcp), dim3(256), 0, s->stream, L, MG_INNER_SWEEPS, st);
@@ -2270,13 +2349,15 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		C.last = last;
 		C.nsw = MG_COARSEST_SWEEPS;
 		C.inner = MG_INNER_SWEEPS;
-		if (const char *e = getenv("LFA_MG_TAIL_INNER")) C.inner = std::max(1, atoi(e));
-		if (const char *e = getenv("LFA_MG_NSW")) C.nsw = std::max(1, atoi(e));
+		if (s->knobs.mg_tail_inner > 0) C.inner = s->knobs.mg_tail_inner;
+		if (s->knobs.mg_nsw > 0) C.nsw = s->knobs.mg_nsw;
 		for (int l = tail; l <= last; ++l) C.ready[l] = M.lv[l].ready;
 		C.tag = ++M.co_tag;
 		if (C.tag == 0) C.tag = ++M.co_tag;  // (0 is what the flags are initialised to)
 		C.stamps = nullptr;
-		if (getenv("LFA_MG_CO_STAMPS")) {
+		C.abort = s->pcg_state + 2;
+		C.fault = s->knobs.mg_co_fault;
+		if (s->knobs.mg_co_stamps) {
 			if (!M.co_stamps) {
 				LFA_HIP(s, hipMalloc(&M.co_stamps, 3 * MG_CO_PHASES * 8));
 				LFA_HIP(s, hipMemsetAsync(M.co_stamps, 0, 3 * MG_CO_PHASES * 8, s->stream));
@@ -2287,7 +2368,9 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		// one workgroup per tile of its first level: every workgroup owns one tile slot on every level it reaches
 		const int W = std::max(1, M.lv[tail].n_tiles);
 		const size_t lds = (size_t)(last - tail + 1) * sizeof(CoLevel<real>) + 512 * sizeof(real);
+		CoGateScope gate(s);
 		hipLaunchKernelGGL(k_mg_coarse<real>, dim3(W), dim3(256), lds, s->stream, C, st);  // (dynamic LDS limit: set where `fits` is)
+		if (gate.done() != LFA_OK) return lfa_fail(s, LFA_E_HIP, "chaining k_mg_coarse behind the device's previous one failed");
 		LFA_LAUNCH_CHECK(s);
 		++launches;
 	} else if (parts & MG_PART_COARSE) {
@@ -2297,12 +2380,12 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		T.last = last;
 		// the trailing run of single-tile levels (at most MG_CHAIN_MAX of them) stays inside one wave
 		T.chain = last;
-		if (!getenv("LFA_MG_NO_CHAIN"))
+		if (!s->knobs.mg_no_chain)
 			while (T.chain > tail && last - (T.chain - 1) + 1 <= MG_CHAIN_MAX && M.lv[T.chain - 1].n_tiles == 1) --T.chain;
 		T.nsw = MG_COARSEST_SWEEPS;
 		T.inner = MG_INNER_SWEEPS;  // measured at C4: 19 iterations; 1 sweep on the tail levels: 22
-		if (const char *e = getenv("LFA_MG_TAIL_INNER")) T.inner = std::max(1, atoi(e));
-		if (const char *e = getenv("LFA_MG_NSW")) T.nsw = std::max(1, atoi(e));
+		if (s->knobs.mg_tail_inner > 0) T.inner = s->knobs.mg_tail_inner;
+		if (s->knobs.mg_nsw > 0) T.nsw = s->knobs.mg_nsw;
 		hipLaunchKernelGGL(k_mg_tail<real>, dim3(1), dim3(MG_TAIL_WAVES * 64), 0, s->stream, T, st);
 		LFA_LAUNCH_CHECK(s);
 		++launches;
@@ -2312,8 +2395,8 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		const int G = mg_grid(L.n_tiles);
 		if (!(parts & (l == 0 ? MG_PART_UP0 : MG_PART_COARSE))) continue;
 		if (l == 0)
-			launch_up0<real>(G, s->stream, L, M.lv[1].g, (const real *)M.lv[1].y, inv_scale, part_sigma, st);
-		else if (!getenv("LFA_MG_NO_CP") && L.n_tiles <= cp_max)
+			launch_up0<real>(s->knobs.mg_mw_u, G, s->stream, L, M.lv[1].g, (const real *)M.lv[1].y, inv_scale, part_sigma, st);
+		else if (!s->knobs.mg_no_cp && L.n_tiles <= cp_max)
 			hipLaunchKernelGGL(k_mg_prolong_postsmooth_cp<real>, dim3(std::max(1, std::min(L.n_tiles, 8192))), dim3(256), 0, s->stream, L, M.lv[l + 1].g,
 			                   (const real *)M.lv[l + 1].y, MG_INNER_SWEEPS, st);
 		else
@@ -2365,7 +2448,7 @@ template <typename real> static int pcg_small_t(lfa_sim *s, bool *ran) {
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_pcg_small<real>, 256, lds) != hipSuccess) per_cu = 0;
 	(void)hipGetLastError();
 	size_t cap = std::min<size_t>((size_t)per_cu * (size_t)n_cu, PS_MAX_TILES);
-	if (const char *e = getenv("LFA_PCG_SMALL_MAX")) cap = std::min<size_t>(cap, (size_t)atoi(e));
+	if (s->knobs.pcg_small_max >= 0) cap = std::min<size_t>(cap, (size_t)s->knobs.pcg_small_max);
 	if ((size_t)W > cap) return LFA_OK;
 	if (!M.ps_part) {
 		const size_t bytes = (size_t)3 * PS_MAX_TILES * sizeof(double) + (size_t)2 * PS_MAX_TILES * sizeof(unsigned);
@@ -2383,9 +2466,11 @@ template <typename real> static int pcg_small_t(lfa_sim *s, bool *ran) {
 	Q.C.last = last;
 	Q.C.nsw = MG_COARSEST_SWEEPS;
 	Q.C.inner = MG_INNER_SWEEPS;
-	if (const char *e = getenv("LFA_MG_TAIL_INNER")) Q.C.inner = std::max(1, atoi(e));
-	if (const char *e = getenv("LFA_MG_NSW")) Q.C.nsw = std::max(1, atoi(e));
+	if (s->knobs.mg_tail_inner > 0) Q.C.inner = s->knobs.mg_tail_inner;
+	if (s->knobs.mg_nsw > 0) Q.C.nsw = s->knobs.mg_nsw;
 	Q.C.stamps = nullptr;
+	Q.C.abort = s->pcg_state + 2;
+	Q.C.fault = 0;
 	const int maxit = (int)s->prm.max_iterations;
 	// tags tag .. tag + maxit belong to this launch (one per V-cycle); 0 is what the flags are initialised to
 	if (M.co_tag > 0xFFFFFFFFu - (unsigned)(maxit + 4)) {
@@ -2409,7 +2494,9 @@ template <typename real> static int pcg_small_t(lfa_sim *s, bool *ran) {
 	Q.maxit = maxit;
 	Q.state = s->pcg_state;
 	Q.hist = s->pcg_hist;
+	CoGateScope gate(s);
 	hipLaunchKernelGGL(k_pcg_small<real>, dim3(W), dim3(256), lds, s->stream, Q);
+	if (gate.done() != LFA_OK) return lfa_fail(s, LFA_E_HIP, "chaining k_pcg_small behind the device's previous waiting kernel failed");
 	LFA_LAUNCH_CHECK(s);
 	M.launches_per_cycle = 0;
 	M.first_co = 1;
@@ -2424,7 +2511,7 @@ template <typename real> static int pcg_small_t(lfa_sim *s, bool *ran) {
 /// 1.41 ms because the correction no longer hides beside the solve; 50^3: 1.21 -> 1.21 ms. Alone (staged hosts, lfa_pcg_solve) it
 /// is the faster solve; inside the overlapped step it is not, so the default stays the multi-launch loop.
 bool lfa_pcg_small_eligible(const lfa_sim *s) {
-	return getenv("LFA_PCG_SMALL") && s->prm.precond == LFA_PRECOND_MULTIGRID && !s->dist && s->n_ptiles >= 1 &&
+	return s->knobs.pcg_small && !s->co_disabled && s->prm.precond == LFA_PRECOND_MULTIGRID && !s->dist && s->n_ptiles >= 1 &&
 	       s->n_ptiles <= PS_MAX_TILES && (s->g.nx > 8 || s->g.ny > 8 || s->g.nz > 8);
 }
 int lfa_pcg_small(lfa_sim *s, bool *ran) {
@@ -2447,7 +2534,7 @@ template <typename real>
 static int mg_axpy_apply_t(lfa_sim *s, const void *sdir, const double *part_sigma, int n_sigma, const double *part_qs, int n_qs,
                            double *part_rmax, double *part_sigma_new) {
 	const int G = mg_grid(s->n_ptiles);
-	launch_axpy_presmooth<real>(G, s->stream, (const int *)s->ptiles, s->n_ptiles, (const uint8_t *)s->abits, (real *)s->vp,
+	launch_axpy_presmooth<real>(s->knobs.mg_mw_a, G, s->stream, (const int *)s->ptiles, s->n_ptiles, (const uint8_t *)s->abits, (real *)s->vp,
 	                            (const real *)sdir, (real *)s->vr, (real *)s->vq, part_sigma, n_sigma, part_qs, n_qs, part_rmax,
 	                            (const int *)s->pcg_state);
 	LFA_LAUNCH_CHECK(s);
@@ -2469,8 +2556,8 @@ int lfa_mg_bench_part(lfa_sim *s, int part) {
 	double *P = s->partials;
 	const int G = mg_grid(s->n_ptiles);
 	if (part == 0) {
-		if (f64) launch_axpy_presmooth<double>(G, s->stream, (const int *)s->ptiles, s->n_ptiles, (const uint8_t *)s->abits, (double *)s->vp, (const double *)s->vs, (double *)s->vr, (double *)s->vq, (const double *)(P + PART_SIG0), G, (const double *)(P + PART_ZS), G, P + PART_RMAX, (const int *)s->pcg_state);
-		else launch_axpy_presmooth<float>(G, s->stream, (const int *)s->ptiles, s->n_ptiles, (const uint8_t *)s->abits, (float *)s->vp, (const float *)s->vs, (float *)s->vr, (float *)s->vq, (const double *)(P + PART_SIG0), G, (const double *)(P + PART_ZS), G, P + PART_RMAX, (const int *)s->pcg_state);
+		if (f64) launch_axpy_presmooth<double>(s->knobs.mg_mw_a, G, s->stream, (const int *)s->ptiles, s->n_ptiles, (const uint8_t *)s->abits, (double *)s->vp, (const double *)s->vs, (double *)s->vr, (double *)s->vq, (const double *)(P + PART_SIG0), G, (const double *)(P + PART_ZS), G, P + PART_RMAX, (const int *)s->pcg_state);
+		else launch_axpy_presmooth<float>(s->knobs.mg_mw_a, G, s->stream, (const int *)s->ptiles, s->n_ptiles, (const uint8_t *)s->abits, (float *)s->vp, (const float *)s->vs, (float *)s->vr, (float *)s->vq, (const double *)(P + PART_SIG0), G, (const double *)(P + PART_ZS), G, P + PART_RMAX, (const int *)s->pcg_state);
 		LFA_LAUNCH_CHECK(s);
 		return LFA_OK;
 	}

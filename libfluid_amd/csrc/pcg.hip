@@ -1370,8 +1370,8 @@ static int sigma_parts(const lfa_sim *s) { return pcg_grid(s->n_ptiles) + (is_ml
 template <typename real> static CoarseFields<real> make_coarse(lfa_sim *s) {
 	CoarseFields<real> cf{s->c_diag, {s->c_w[0], s->c_w[1], s->c_w[2]}, s->c_unk, (real *)s->c_pre,
 	                      s->c_r_cur ? (real *)s->c_r_cur : (real *)s->c_r, (real *)s->c_x};
-	if (const char *e = getenv("LFA_COARSE_W1")) cf.w1 = (real)atof(e);  // experiment knobs (tools/pcg_convergence.py)
-	if (const char *e = getenv("LFA_COARSE_W2")) cf.w2 = (real)atof(e);
+	if (s->knobs.coarse_w1 == s->knobs.coarse_w1) cf.w1 = (real)s->knobs.coarse_w1;  // experiment knobs (tools/pcg_convergence.py)
+	if (s->knobs.coarse_w2 == s->knobs.coarse_w2) cf.w2 = (real)s->knobs.coarse_w2;
 	return cf;
 }
 
@@ -1660,7 +1660,7 @@ static void launch_pcg_a(bool first, bool coarse, int grid, hipStream_t st, Args
 /// waves that start together stay in lockstep (their phases add up instead of overlapping): twice as many workgroups as
 /// fit, so that the second half starts staggered as the first retires, measured 66 vs 73 us at C4.
 /// LFA_PCG_GA / LFA_PCG_GB override them for experiments (tools/pcg_grid_sweep.sh).
-static void fused_grids(int G, int &GA, int &GB) {
+static void fused_grids(const lfa_sim *s, int G, int &GA, int &GB) {
 	static int n_cu = 0;
 	if (!n_cu) {
 		int dev = 0;
@@ -1670,8 +1670,8 @@ static void fused_grids(int G, int &GA, int &GB) {
 	}
 	GA = std::min(G, 4 * n_cu);
 	GB = std::min(G, 8 * n_cu);
-	if (const char *e = getenv("LFA_PCG_GA")) GA = std::max(1, std::min(atoi(e), G));
-	if (const char *e = getenv("LFA_PCG_GB")) GB = std::max(1, std::min(atoi(e), G));
+	if (s->knobs.pcg_ga > 0) GA = std::max(1, std::min(s->knobs.pcg_ga, G));
+	if (s->knobs.pcg_gb > 0) GB = std::max(1, std::min(s->knobs.pcg_gb, G));
 }
 
 template <typename real> static int solve_t(lfa_sim *s, double dt, double *residual, uint64_t *iterations) {
@@ -1719,8 +1719,8 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 		return LFA_OK;
 	}
 
-	int init_state[2] = {-1, 0};
-	LFA_HIP(s, hipMemcpyAsync(s->pcg_state, init_state, 8, hipMemcpyHostToDevice, s->stream));
+	int init_state[3] = {-1, 0, 0};
+	LFA_HIP(s, hipMemcpyAsync(s->pcg_state, init_state, 12, hipMemcpyHostToDevice, s->stream));
 	if (s->warm_started) {
 		// r = b - A p_guess: one SpMV and one subtraction before the first preconditioner application
 		hipLaunchKernelGGL(k_spmv<real>, dim3(G), dim3(256), 0, s->stream, tc, s->abits, (const real *)v.p, v.q, scale, P + PART_ZS,
@@ -1747,11 +1747,13 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 	const int chunk = 4;
 	int done = -1, nan = 0, i = 0;
 	int *hstate = (int *)s->h_pinned;
+	int aborted = 0;  // a kernel whose workgroups wait for each other gave a wait up (mg.hip: co_wait)
 	if (small_ran) {
-		LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 8, hipMemcpyDeviceToHost, s->stream));
+		LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 12, hipMemcpyDeviceToHost, s->stream));
 		LFA_HIP(s, hipStreamSynchronize(s->stream));
 		done = hstate[0];
 		nan = hstate[1];
+		aborted = hstate[2];
 		i = maxit;  // (neither loop below runs)
 		uint64_t mgl = 0;
 		lfa_mg_stats(s, &mgl, &s->stat_mg_levels, &s->stat_mg_first_co);
@@ -1769,13 +1771,13 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 	real *crbuf[2] = {(real *)s->c_r, is_ml(s) ? (real *)s->c_r + s->ncp1 : (real *)nullptr};
 	// launch widths of the two fused kernels (workgroups); each kernel reads the other's per-workgroup partials
 	int GA, GB;
-	fused_grids(G, GA, GB);
+	fused_grids(s, G, GA, GB);
 	if (is_mg(s)) GB = G;  // the V-cycle kernels write pcg_grid(n_ptiles) partials
 	const int NSB = GB + (is_ml(s) ? 1 : 0);
 	// slabs: boundary tile layers whose rows couple to the neighbour rank (k_ghost_face_rows)
 	const int n_face_lo = dist && lfa_has_lo(s) ? s->n_own_first : 0, n_face_hi = dist && lfa_has_hi(s) ? s->n_own_last : 0;
 	const int g_face_lo = std::min(16, (n_face_lo + PCG_WAVES - 1) / PCG_WAVES), g_face_hi = std::min(16, (n_face_hi + PCG_WAVES - 1) / PCG_WAVES);
-	while (fused && i < maxit && done < 0) {
+	while (fused && !aborted && i < maxit && done < 0) {
 		const int end = std::min(maxit, i + (i == 0 ? first_chunk : chunk));
 		for (; i < end; ++i) {
 			const int po = i & 1, pn = po ^ 1;
@@ -1851,12 +1853,14 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 		                   dist ? (const double *)lfa_dist_gather_buf(s, i & 1) : P + PART_RMAX, dist ? s->dist->nranks : GB,
 		                   s->prm.tolerance, i - 1, s->pcg_state, s->pcg_hist);
 		LFA_LAUNCH_CHECK(s);
-		LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 8, hipMemcpyDeviceToHost, s->stream));
+		LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 12, hipMemcpyDeviceToHost, s->stream));
 		LFA_HIP(s, hipStreamSynchronize(s->stream));
 		done = hstate[0];
 		nan = hstate[1];
+		aborted = hstate[2];
+		if (aborted) break;
 	}
-	while (!fused && i < maxit && done < 0) {
+	while (!fused && !aborted && i < maxit && done < 0) {
 		const int end = std::min(maxit, i + (i == 0 ? first_chunk : chunk));
 		for (; i < end; ++i) {
 			const int po = i & 1, pn = po ^ 1;
@@ -1885,6 +1889,18 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 		done = hstate[0];
 		nan = hstate[1];
 	}
+	if (aborted) {
+		// What the wait was for never came (a workgroup that is not resident: another process's kernel of the same kind on this GPU,
+		// a fault). Whatever the iterations after it computed is void. This handle stops using the kernels that wait and the solve
+		// is repeated from the right-hand side on the launch-per-phase path - once: that path waits for nothing.
+		if (s->co_disabled) return lfa_fail(s, LFA_E_HIP, "a device-side wait of the pressure solve was given up twice");
+		s->co_disabled = true;
+		++s->stat_co_aborts;
+		s->system_valid = false;
+		s->warm_started = false;
+		s->pressure_epoch = 0;  // (the pressure the aborted iterations left is no guess)
+		return solve_t<real>(s, dt, residual, iterations);
+	}
 	const int iters = done >= 0 ? done : maxit;
 	double res = 0.0;
 	if (iters > 0) {
@@ -1905,7 +1921,7 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 extern "C" int lfa_get_solver_stats(lfa_sim *s, uint64_t stats[LFA_NUM_SOLVER_STATS]) {
 	if (!s || !stats) return LFA_E_INVALID;
 	const uint64_t v[LFA_NUM_SOLVER_STATS] = {s->stat_launches_iter, s->stat_transport_iter, s->stat_mg_levels, s->stat_mg_first_co,
-	                                          s->last_iters, s->stat_transport_solve, s->stat_whole_solve, 0};
+	                                          s->last_iters, s->stat_transport_solve, s->stat_whole_solve, s->stat_co_aborts};
 	for (int i = 0; i < LFA_NUM_SOLVER_STATS; ++i) stats[i] = v[i];
 	return LFA_OK;
 }
@@ -1977,8 +1993,8 @@ extern "C" int lfa_upload_pressure(lfa_sim *s, const double *p, uint64_t n) {
 
 template <typename real> static int apply_precon_t(lfa_sim *s, const double *r, double *z, uint64_t n) {
 	LFA_TRY(scatter<real>(s, (real *)s->vr, r, n));
-	int init_state[2] = {-1, 0};
-	LFA_HIP(s, hipMemcpyAsync(s->pcg_state, init_state, 8, hipMemcpyHostToDevice, s->stream));
+	int init_state[3] = {-1, 0, 0};
+	LFA_HIP(s, hipMemcpyAsync(s->pcg_state, init_state, 12, hipMemcpyHostToDevice, s->stream));
 	if (s->n_ptiles) {
 		LFA_TRY(mic_apply<real>(s, s->partials + PART_SIG0));
 		if (is_ml(s)) {
@@ -1997,8 +2013,8 @@ extern "C" int lfa_apply_preconditioner(lfa_sim *s, const double *r, double *z, 
 }
 template <typename real> static int apply_a_t(lfa_sim *s, const double *vin, double *out, uint64_t n) {
 	LFA_TRY(scatter<real>(s, (real *)s->vs, vin, n));
-	int init_state[2] = {-1, 0};
-	LFA_HIP(s, hipMemcpyAsync(s->pcg_state, init_state, 8, hipMemcpyHostToDevice, s->stream));
+	int init_state[3] = {-1, 0, 0};
+	LFA_HIP(s, hipMemcpyAsync(s->pcg_state, init_state, 12, hipMemcpyHostToDevice, s->stream));
 	if (s->dist) LFA_TRY(lfa_dist_exchange_slices(s, s->vs, (int)sizeof(real)));
 	if (s->n_ptiles) {
 		TileCtx tc = make_ctx(s);
@@ -2077,7 +2093,7 @@ template <typename real> static int bench_launch(lfa_sim *s, int which) {
 	const real scale = (real)s->a_scale;
 	double *P = s->partials;
 	int GA, GB;
-	fused_grids(G, GA, GB);
+	fused_grids(s, G, GA, GB);
 	switch (which) {
 	case LFA_K_SPMV_DOT:
 		hipLaunchKernelGGL(k_spmv<real>, dim3(G), dim3(256), 0, s->stream, tc, s->abits, (const real *)v.s, v.z, scale,
@@ -2152,8 +2168,8 @@ extern "C" int lfa_bench_kernel(lfa_sim *s, int which, int reps, double *mean_ms
 	                    which == LFA_K_PCG_A || which == LFA_K_PCG_B || (which >= LFA_K_MG_AXPY_PRESMOOTH && which <= LFA_K_MG_UP0);
 	if (is_pcg) {
 		if (!s->system_valid) return lfa_fail(s, LFA_E_INVALID, "lfa_bench_kernel: no pressure system on the device");
-		int init_state[2] = {-1, 0};  // "still iterating": the kernels early-out once a solve has converged
-		LFA_HIP(s, hipMemcpyAsync(s->pcg_state, init_state, 8, hipMemcpyHostToDevice, s->stream));
+		int init_state[3] = {-1, 0, 0};  // "still iterating": the kernels early-out once a solve has converged
+		LFA_HIP(s, hipMemcpyAsync(s->pcg_state, init_state, 12, hipMemcpyHostToDevice, s->stream));
 	}
 	auto once = [&]() -> int {
 		if (is_pcg) return F64(s) ? bench_launch<double>(s, which) : bench_launch<float>(s, which);

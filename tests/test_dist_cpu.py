@@ -60,3 +60,11 @@ def test_two_rank_plumbing_over_gloo(tmp_path):
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+def test_bench_refuses_a_rank_count_that_does_not_match_gpus():
+    """bench.py --gpus N inside a rank environment of another size exits non-zero before it touches a GPU: the JSON line would
+    carry the wrong n_gpus otherwise (round 3 printed `n_gpus: 1` for `--gpus 4` without ranks)."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stdout + r.stderr)

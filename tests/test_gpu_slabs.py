@@ -497,10 +497,31 @@ def test_bench_runs_n_processes_on_one_gpu(tmp_path):
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "weak"
+    # the headline of an N > 1 line is the FIXED BASELINE domain on N slabs (configs[3]); the weak-scaling run sits beside it
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "strong"
     assert out["transport"].startswith("shm")
     assert out["value"] > 0 and out["ms_per_step"] > 0
-    assert "2 z-slabs" in out["config"]["parallelism"]
+    assert "2 z-slabs" in out["config"]["parallelism"] and "strong scaling" in out["config"]["parallelism"]
+    assert "128x128x128" in out["config"]["workload"]
+    w = out["weak"]
+    assert w["scaling"] == "weak" and w["grid"] == [128, 128, 256] and w["particles"] == 2 * 2097152
+    assert w["value"] > 0
+
+
+def test_bench_gpus_n_without_ranks_starts_them(tmp_path):
+    """`python bench.py --gpus 2` from a plain shell (no torch.distributed.run around it): the process starts the two ranks itself -
+    before it has touched a GPU - and hands their line and exit code on, instead of printing a one-GPU line labelled n_gpus 1."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["LFA_SHM_SLOT_MB"] = "16"
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--config", "C2", "--steps", "3", "--warmup", "2", "--transport", "shm",
+                        "--no-serial-stages", "--no-secondary"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and "weak" not in out
 
 
 def test_shared_memory_transport_fails_instead_of_hanging(tmp_path):
