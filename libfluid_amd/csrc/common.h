@@ -256,6 +256,7 @@ struct lfa_sim {
 	uint8_t *coerce_map = nullptr;    // [ncp] 1 + index of the LAST active coercing source that lists the cell, 0: none
 	bool any_coerce = false;
 	uint64_t source_epoch = 0;        // counter of seeding calls: part of the counter-based generator's key
+	uint64_t next_global_id = 0;      // slabs: the id the next seeded particle of the whole job gets (ids are unique across ranks)
 
 	// boundary scratch
 	void *io_buf = nullptr;

@@ -589,6 +589,7 @@ extern "C" int lfa_upload_particles(lfa_sim *s, const void *aos152, uint64_t n) 
 	LFA_TRY(lfa_particles_alloc(s, n));
 	s->np = n;
 	s->np_live = n;
+	s->next_global_id = n;  // (slabs: every rank is handed the whole set, ids = upload index)
 	s->binned = false;  // the grid stays what it was (G2P re-uploads corrected positions between apply and gather)
 	s->cell_sorted = false;
 	s->system_valid = false;
@@ -788,6 +789,7 @@ extern "C" int lfa_seed_block(lfa_sim *s, const int64_t lo[3], const int64_t hi[
 	if (per_layer * (size_t)(hi[2] - lo[2]) >= ((size_t)1 << 32)) return lfa_fail(s, LFA_E_INVALID, "more than 2^32 particles");
 	LFA_HIP(s, hipSetDevice(s->device));
 	LFA_TRY(lfa_particles_alloc(s, n));
+	s->next_global_id = per_layer * (size_t)(hi[2] - lo[2]);
 	s->np = n;
 	s->np_live = n;
 	s->c_home_valid = false;

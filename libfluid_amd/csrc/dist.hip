@@ -921,6 +921,7 @@ int attach(lfa_sim *s, lfa_dist *d, const int32_t *bounds) {
 	s->slab_hi = hi;
 	s->binned = false;
 	s->cell_sorted = false;
+	s->sources_valid = false;  // the seeding entries are the ones of this rank's own tile layers
 	s->grid_valid = false;
 	s->system_valid = false;
 	if (!s->dist_red) LFA_HIP(s, hipMalloc(&s->dist_red, (64 + 4 * 32) * 8));  // scalars | 2 gather buffers of 2 x nranks

@@ -533,7 +533,6 @@ extern "C" int lfa_extrapolate(lfa_sim *s) {
 	if (!s->binned) return lfa_fail(s, LFA_E_INVALID, "lfa_extrapolate: call lfa_hash_particles first");
 	LFA_HIP(s, hipSetDevice(s->device));
 	const int iters = (int)s->prm.velocity_extrapolation_iterations;
-	if (s->dist && iters > 1) return lfa_fail(s, LFA_E_UNSUPPORTED, "more than one extrapolation sweep with slabs");
 	if (iters == 0) return LFA_OK;
 	LFA_TRY(lfa_dist_refresh_grid(s, false));  // post-projection velocities of the neighbour's adjacent layer
 	if (!s->n_dtiles) return LFA_OK;
@@ -554,6 +553,14 @@ extern "C" int lfa_extrapolate(lfa_sim *s) {
 		                   i == 0 ? (const uint8_t *)nullptr : (const uint8_t *)va, vb);
 		LFA_LAUNCH_CHECK(s);
 		uint8_t *t = va; va = vb; vb = t;
+		// slabs: the next sweep reads what this one has made valid in the neighbour's adjacent tile layer - its velocities and
+		// its validity bytes (a sweep reaches one cell, the ghost layer is eight deep: nothing beyond it can matter)
+		if (s->dist && i + 1 < iters) {
+			LFA_TRY(lfa_dist_refresh_grid(s, false));
+			void *f[1] = {va};
+			const int e[1] = {1};
+			LFA_TRY(lfa_dist_exchange_fields(s, 1, f, e));
+		}
 	}
 	return LFA_OK;
 }

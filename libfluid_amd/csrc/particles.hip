@@ -858,7 +858,7 @@ __device__ inline uint64_t mix64(uint64_t x) {
 }
 /// One workgroup-strided thread per seeding entry: position = cell + U[0,1)^3 (seed_cell :141-147), velocity = the source's.
 __global__ void k_source_seed(const uint32_t *cell, const uint32_t *src_of, const uint32_t *need, const uint32_t *off, size_t n,
-                              const float *src_vel, ParticleSoA p, size_t base, uint64_t seed) {
+                              const float *src_vel, ParticleSoA p, size_t base, uint64_t seed, uint64_t id_base) {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	const uint32_t cnt = need[i], b = cell[i];
@@ -870,14 +870,15 @@ __global__ void k_source_seed(const uint32_t *cell, const uint32_t *src_of, cons
 		for (int a = 0; a < 3; ++a) {
 			// the generator is keyed on the particle's own slot d (unique over every entry of a call, so two entries that top up
 			// the same cell never create coincident particles, and no (cell, j) window can alias a neighbouring cell's)
-			const uint64_t r = mix64(seed + ((uint64_t)d * 3ull + (uint64_t)a + 1ull) * 0x9E3779B97F4A7C15ull + ((uint64_t)b << 40));
+			// (a slab rank keys on the particle's id in the whole job, id_base + its index among this call's new particles)
+			const uint64_t r = mix64(seed + ((id_base + (uint64_t)(d - base)) * 3ull + (uint64_t)a + 1ull) * 0x9E3779B97F4A7C15ull + ((uint64_t)b << 40));
 			float t = (float)(r >> 40) * (1.0f / 16777216.0f);  // 24 random bits: [0, 1)
 			p.t[a][d] = t;
 			p.v[a][d] = vel[a];
 		}
 #pragma unroll
 		for (int k = 0; k < 9; ++k) p.c[k][d] = 0.0f;
-		p.id[d] = (uint32_t)d;
+		p.id[d] = (uint32_t)(id_base + (uint64_t)(d - base));
 	}
 }
 }  // namespace
@@ -918,8 +919,10 @@ int lfa_sources_sync(lfa_sim *s) {
 		s->sources_valid = true;
 		return LFA_OK;
 	}
-	if (s->dist && !s->sources.empty()) return lfa_fail(s, LFA_E_UNSUPPORTED, "fluid sources with a slab decomposition");
 	LFA_HIP(s, hipSetDevice(s->device));
+	// slabs: every rank is handed the whole list (like the solid cells) and seeds the cells of its own tile layers; the coercion
+	// map covers the whole grid (a particle's cell is always an owned one)
+	const int own_zlo = s->dist ? s->slab_lo * 8 : 0, own_zhi = s->dist ? s->slab_hi * 8 : s->g.nz;
 	std::vector<uint32_t> cell, lo, target, of, ccell, csrc;
 	std::vector<float> vel;
 	{
@@ -932,6 +935,8 @@ int lfa_sources_sync(lfa_sim *s) {
 			const uint32_t tgt = (uint32_t)(h.root * h.root * h.root);
 			for (size_t i = 0; i + 2 < h.xyz.size(); i += 3) {
 				const uint32_t b = blocked_index(s->g, h.xyz[i], h.xyz[i + 1], h.xyz[i + 2]);
+				if (h.coerce) coerce.push_back(std::make_pair(b, (uint32_t)si + 1));
+				if (h.xyz[i + 2] < own_zlo || h.xyz[i + 2] >= own_zhi) continue;  // another rank's cell
 				auto it = std::lower_bound(seen.begin(), seen.end(), std::make_pair(b, 0u),
 				                           [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &c) { return a.first < c.first; });
 				if (it != seen.end() && it->first == b) {
@@ -944,7 +949,6 @@ int lfa_sources_sync(lfa_sim *s) {
 					seen.insert(it, std::make_pair(b, tgt));
 					cell.push_back(b); lo.push_back(0xFFFFFFFFu); target.push_back(tgt); of.push_back((uint32_t)si);
 				}
-				if (h.coerce) coerce.push_back(std::make_pair(b, (uint32_t)si + 1));
 			}
 		}
 		std::stable_sort(coerce.begin(), coerce.end(), [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &c) { return a.first < c.first; });
@@ -1009,18 +1013,42 @@ extern "C" int lfa_update_sources(lfa_sim *s, uint64_t *n_seeded) {
 	LFA_TRY(lfa_corr_commit(s));
 	LFA_TRY(lfa_sources_sync(s));
 	const size_t n = s->n_src_entries;
-	if (!n) return LFA_OK;
-	hipLaunchKernelGGL(k_source_need, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, (const uint32_t *)s->src_cell,
-	                   (const uint32_t *)s->src_lo, (const uint32_t *)s->src_target, n, (const uint32_t *)s->cell_count,
-	                   (const uint32_t *)s->tile_flag, s->src_need);
-	LFA_LAUNCH_CHECK(s);
-	// exclusive scan into the second half of the scratch; the total is read back (the host has to size the particle arrays)
-	uint32_t *off = s->src_need + s->src_cap + 1;
-	LFA_TRY(lfa_exclusive_scan_u32(s, s->src_need, off, n, off + n));
-	LFA_HIP(s, hipMemcpyAsync(s->h_pinned + 96, off + n, 4, hipMemcpyDeviceToHost, s->stream));
-	LFA_HIP(s, hipStreamSynchronize(s->stream));
-	const size_t total = s->h_pinned[96];
-	if (!total) return LFA_OK;  // every source cell is full: the binning stands
+	if (!n && !s->dist) return LFA_OK;
+	size_t total = 0;
+	uint32_t *off = s->src_need ? s->src_need + s->src_cap + 1 : nullptr;
+	if (n) {
+		hipLaunchKernelGGL(k_source_need, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, (const uint32_t *)s->src_cell,
+		                   (const uint32_t *)s->src_lo, (const uint32_t *)s->src_target, n, (const uint32_t *)s->cell_count,
+		                   (const uint32_t *)s->tile_flag, s->src_need);
+		LFA_LAUNCH_CHECK(s);
+		// exclusive scan into the second half of the scratch; the total is read back (the host has to size the particle arrays)
+		LFA_TRY(lfa_exclusive_scan_u32(s, s->src_need, off, n, off + n));
+		LFA_HIP(s, hipMemcpyAsync(s->h_pinned + 96, off + n, 4, hipMemcpyDeviceToHost, s->stream));
+		LFA_HIP(s, hipStreamSynchronize(s->stream));
+		total = s->h_pinned[96];
+	}
+	// slabs: what every rank creates, gathered (one sum all-reduce of a vector with one slot per rank) - the ids of the new
+	// particles continue the job-wide numbering in rank order, and either every rank re-bins or none does
+	uint64_t id_base = s->np_live, total_all = total;
+	if (s->dist) {
+		const int nr = s->dist->nranks, me = s->dist->rank;
+		double hv[32] = {0};
+		hv[me] = (double)total;
+		double *dv = s->dist_red + 16;  // (slots 0-5 belong to the solve)
+		LFA_HIP(s, hipMemcpyAsync(dv, hv, (size_t)nr * 8, hipMemcpyHostToDevice, s->stream));
+		LFA_TRY(s->dist->allreduce(s, dv, nr, false));
+		LFA_HIP(s, hipMemcpyAsync(hv, dv, (size_t)nr * 8, hipMemcpyDeviceToHost, s->stream));
+		LFA_HIP(s, hipStreamSynchronize(s->stream));
+		id_base = s->next_global_id;
+		total_all = 0;
+		for (int r = 0; r < nr; ++r) {
+			if (r < me) id_base += (uint64_t)hv[r];
+			total_all += (uint64_t)hv[r];
+		}
+		if (s->next_global_id + total_all >= ((uint64_t)1 << 32)) return lfa_fail(s, LFA_E_INVALID, "more than 2^32 particles");
+		s->next_global_id += total_all;
+	}
+	if (!total_all) return LFA_OK;  // every source cell is full: the binning stands
 	if (s->np_live + total >= ((size_t)1 << 32)) return lfa_fail(s, LFA_E_INVALID, "more than 2^32 particles");
 	const size_t base = s->np_live;
 	LFA_TRY(lfa_particles_materialize(s));  // the new particles bring their own v / C: a deferred binning is completed first
@@ -1031,10 +1059,12 @@ extern "C" int lfa_update_sources(lfa_sim *s, uint64_t *n_seeded) {
 			LFA_HIP(s, hipMemsetAsync(s->c_home + (size_t)k * s->c_home_cap + base, 0, total * 4, s->stream));
 	}
 	++s->source_epoch;
-	hipLaunchKernelGGL(k_source_seed, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, (const uint32_t *)s->src_cell,
-	                   (const uint32_t *)s->src_of, (const uint32_t *)s->src_need, (const uint32_t *)off, n, (const float *)s->src_vel,
-	                   s->pb[s->cur], base, 0x5EED50ull + s->source_epoch * 0x632BE59BD9B4E019ull);
-	LFA_LAUNCH_CHECK(s);
+	if (total) {
+		hipLaunchKernelGGL(k_source_seed, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, (const uint32_t *)s->src_cell,
+		                   (const uint32_t *)s->src_of, (const uint32_t *)s->src_need, (const uint32_t *)off, n, (const float *)s->src_vel,
+		                   s->pb[s->cur], base, 0x5EED50ull + s->source_epoch * 0x632BE59BD9B4E019ull, id_base);
+		LFA_LAUNCH_CHECK(s);
+	}
 	s->np_live = base + total;
 	s->np = s->np_live;
 	s->vmax2_valid = false;  // the new particles carry their source's velocity

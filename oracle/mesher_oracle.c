@@ -190,7 +190,8 @@ void orc_mesher_mesh(const double *pos, size_t n, const uint64_t *size, const do
 	marching_cubes(&c, vals, &vp, &ix);
 	counts[0] = vp.n / 3;
 	counts[1] = ix.n;
-	if (vpos) memcpy(vpos, vp.v, (vp.n / 3 < cap_v ? vp.n / 3 : cap_v) * 24);
-	if (idx) memcpy(idx, ix.v, (ix.n < cap_i ? ix.n : cap_i) * 8);
+	/* (an empty mesh has null arrays: memcpy must not see them even for 0 bytes - found by the sanitizer run, `make asan`) */
+	if (vpos && vp.v) memcpy(vpos, vp.v, (vp.n / 3 < cap_v ? vp.n / 3 : cap_v) * 24);
+	if (idx && ix.v) memcpy(idx, ix.v, (ix.n < cap_i ? ix.n : cap_i) * 8);
 	free(vals); free(vp.v); free(ix.v);
 }

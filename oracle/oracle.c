@@ -18,6 +18,10 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+/* memcpy / memset of n bytes, n may be 0 and the pointers then null (empty particle or unknown sets): ISO C gives memcpy no
+ * licence for null arguments even then (found by `make asan`) */
+static void copy_n(void *dst, const void *src, size_t n) { if (n) memcpy(dst, src, n); }
+static void zero_n(void *dst, size_t n) { if (n) memset(dst, 0, n); }
 
 typedef struct {
 	double pos[3], vel[3], cx[3], cy[3], cz[3], old_pos[3]; /* include/fluid/simulation.h:24-33 */
@@ -110,11 +114,11 @@ void orc_set_particles(void *h, const void *aos152, size_t n) {
 		c->pcap = n;
 	}
 	c->np = n;
-	memcpy(c->p, aos152, n * sizeof(orc_particle));
+	copy_n(c->p, aos152, n * sizeof(orc_particle));
 }
 size_t orc_num_particles(void *h) { return ((orc_ctx *)h)->np; }
 void orc_get_particles(void *h, void *aos152) {
-	orc_ctx *c = (orc_ctx *)h; memcpy(aos152, c->p, c->np * sizeof(orc_particle));
+	orc_ctx *c = (orc_ctx *)h; copy_n(aos152, c->p, c->np * sizeof(orc_particle));
 }
 void orc_get_cells(void *h, void *aos32) { orc_ctx *c = (orc_ctx *)h; memcpy(aos32, c->grid, ncells(c) * 32); }
 void orc_set_cells(void *h, const void *aos32) { orc_ctx *c = (orc_ctx *)h; memcpy(c->grid, aos32, ncells(c) * 32); }
@@ -162,7 +166,7 @@ void orc_hash(void *hh) {
 	 * first run is 0 here as well. */
 }
 size_t orc_num_fluid_cells(void *h) { return ((orc_ctx *)h)->nfluid; }
-void orc_get_fluid_cells(void *h, uint64_t *out) { orc_ctx *c = (orc_ctx *)h; memcpy(out, c->fluid_raw, c->nfluid * 8); }
+void orc_get_fluid_cells(void *h, uint64_t *out) { orc_ctx *c = (orc_ctx *)h; copy_n(out, c->fluid_raw, c->nfluid * 8); }
 void orc_get_space_hash(void *h, uint64_t *begin, uint64_t *count) {
 	orc_ctx *c = (orc_ctx *)h; memcpy(begin, c->hbegin, ncells(c) * 8); memcpy(count, c->hcount, ncells(c) * 8);
 }
@@ -349,8 +353,8 @@ void orc_build_system(void *hh, double dt) {
 		c->precon[i] = 1.0 / sqrt(e * c->a_scale);
 	}
 }
-void orc_get_abits(void *h, uint8_t *out) { orc_ctx *c = (orc_ctx *)h; memcpy(out, c->abits, c->nsys); }
-void orc_get_precon(void *h, double *out) { orc_ctx *c = (orc_ctx *)h; memcpy(out, c->precon, c->nsys * 8); }
+void orc_get_abits(void *h, uint8_t *out) { orc_ctx *c = (orc_ctx *)h; copy_n(out, c->abits, c->nsys); }
+void orc_get_precon(void *h, double *out) { orc_ctx *c = (orc_ctx *)h; copy_n(out, c->precon, c->nsys * 8); }
 
 /* pressure_solver::_compute_b_vector src/pressure_solver.cpp:180-242. */
 static void rhs(const orc_ctx *c, double *b) {
@@ -415,7 +419,7 @@ static void lap_apply(const orc_ctx *c, double *out, const double *v) {
 void orc_apply_precon(void *h, const double *r, double *z) {
 	orc_ctx *c = (orc_ctx *)h;
 	double *q = (double *)calloc(c->nsys ? c->nsys : 1, 8);
-	memset(z, 0, c->nsys * 8);
+	zero_n(z, c->nsys * 8);
 	mic_apply(c, z, q, r);
 	free(q);
 }
@@ -443,7 +447,7 @@ void orc_solve(void *hh, double dt, double *p, double *residual, uint64_t *iters
 	double *r = b;
 	double *z = (double *)calloc(n, 8), *q = (double *)calloc(n, 8), *s = (double *)malloc(n * 8);
 	mic_apply(c, z, q, r);
-	memcpy(s, z, n * 8);
+	copy_n(s, z, n * 8);
 	double sigma_ps = dotv(z, r, n), res = 0.0;
 	size_t i = 0;
 	for (; i < c->maxit; ++i) {
@@ -689,7 +693,7 @@ void orc_add_source(void *hh, const int *xyz, size_t k, const double *vel, size_
 	c->src = (struct orc_source *)realloc(c->src, (c->nsrc + 1) * sizeof *c->src);
 	struct orc_source *s = &c->src[c->nsrc++];
 	s->xyz = (int *)malloc((k ? k : 1) * 12);
-	memcpy(s->xyz, xyz, k * 12);
+	copy_n(s->xyz, xyz, k * 12);
 	s->k = k; s->root = root; s->active = active; s->coerce = coerce;
 	memcpy(s->vel, vel, 24);
 }

@@ -34,7 +34,7 @@ def sample_mesh():
 @pytest.fixture(scope="module")
 def exe(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("fmt") / "host_formats_driver")
-    r = subprocess.run(["g++", "-std=c++17", "-O2", "-fopenmp", "-Wall", "-Wextra", "-o", out, SRC], capture_output=True, text=True)
+    r = subprocess.run(["g++", "-std=c++17", "-O2", "-fopenmp", "-Wall", "-Wextra", *os.environ.get("LFA_HOST_CXXFLAGS", "").split(), "-o", out, SRC], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return out
 

@@ -212,6 +212,100 @@ def test_virtual_slabs_full_time_step_with_migration(size, block, method, bounds
     util.assert_close(pn["vel"], p1["vel"], 1e-2, "particle velocities after full steps, slabs vs single domain", atol=vel_atol)
 
 
+def test_slab_download_after_hundreds_of_particles_have_crossed_a_face():
+    """A wide face and a dam that collapses through it: thousands of particles leave a rank between two binnings. The
+    records of a rank then are [resident | holes | arrivals]; a download walks all of them (the export kernel used to be sized by
+    the resident count and dropped the arrivals behind it - at 16 x 16 faces fewer than 256 cross, and 256 is its block size)."""
+    size, block, bounds = (64, 32, 32), ((0, 0, 0), (64, 24, 15)), [0, 2, 4]
+    kw = dict(precond=lfa.PRECOND_MULTIGRID)
+    p1, _, _ = run_time_steps(size, block, lfa.APIC, 6, **kw)
+    pn, before, after = run_time_steps(size, block, lfa.APIC, 6, bounds=bounds, **kw)
+    assert len(pn) == len(p1)
+    assert after[1] - before[1] > 1000, (before, after)
+    assert np.isfinite(pn["pos"]).all() and (pn["pos"].max(axis=0) > 1.0).all()
+    assert np.abs(pn["pos"] - p1["pos"]).max() < 5e-3
+
+
+@pytest.mark.parametrize("sweeps", [2, 3])
+def test_virtual_slabs_extrapolate_with_several_sweeps(sweeps):
+    """simulation::velocity_extrapolation_iterations > 1 (include/fluid/simulation.h:189) on slabs: cells made valid by sweep i
+    feed sweep i + 1 (src/simulation.cpp:694-698) also across a slab face - the neighbour's adjacent tile layer comes over
+    after every sweep, velocities and validity bytes."""
+    size, block, bounds = (16, 16, 32), ((2, 0, 3), (14, 10, 29)), [0, 1, 3, 4]
+    kw = dict(precond=lfa.PRECOND_MIC0_TILED, pcg_dtype=lfa.PCG_F64, velocity_extrapolation_iterations=sweeps)
+    c1, p1, it1 = run_single(size, block, lfa.APIC, 2, **kw)
+    cn, pn, itn = run_slabs(size, block, lfa.APIC, 2, bounds, **kw)
+    assert np.array_equal(cn["type"], c1["type"])
+    vel_atol = 1e-5 * 981.0 * util.DT
+    util.assert_close(cn["vel"], c1["vel"], 1e-4, "extrapolated grid velocities, slabs vs single domain", atol=vel_atol)
+    i1, i2 = util.order_by_position(p1), util.order_by_position(pn)
+    util.assert_close(pn["vel"][i2], p1["vel"][i1], 1e-4, "particle velocities, slabs vs single domain", atol=vel_atol)
+    # and the sweeps do something: one sweep leaves other velocities in the air cells next to the surface
+    c0, _, _ = run_single(size, block, lfa.APIC, 2, precond=lfa.PRECOND_MIC0_TILED, pcg_dtype=lfa.PCG_F64)
+    assert np.abs(c0["vel"] - c1["vel"]).max() > 1e-3
+
+
+def test_virtual_slabs_fluid_sources():
+    """Fluid sources (simulation::sources, src/simulation.cpp:756-765,136-151) on slabs: every rank is handed the whole list and
+    tops up the cells of its own tile layers; the new particles get ids that are unique over the job. Against the single
+    domain after three full steps: the same number of particles in total and per cell right after the first seeding (positions
+    inside a cell are random by design), every id once."""
+    size, bounds = (16, 16, 32), [0, 1, 3, 4]
+    block = ((2, 0, 3), (14, 6, 29))
+    src_cells = np.array([(x, 12, z) for x in (6, 7, 8) for z in (6, 7, 8, 9, 15, 16, 17, 23, 24, 25)], dtype=np.int32)  # straddles all faces
+
+    def run(bounds_):
+        n = 1 if bounds_ is None else len(bounds_) - 1
+        hub = lfa.LocalHub(n) if bounds_ is not None else None
+        sims = []
+        for r in range(n):
+            s = lfa.Sim(size, method=lfa.APIC, precond=lfa.PRECOND_MULTIGRID)
+            if hub is not None:
+                s.init_local_slab(hub.h, r, bounds_)
+            s.seed_block(*block)
+            s.add_source(src_cells, (0.0, -20.0, 0.0), 2, True, True)
+            sims.append(s)
+        counts0, errors = [None] * n, []
+
+        def worker(r):
+            try:
+                sims[r].hash()
+                sims[r].update_sources()
+                counts0[r] = sims[r].cell_counts().reshape(size[2], size[1], size[0])
+                for _ in range(3):
+                    res, it, rc = sims[r].time_step(util.DT)
+                    assert rc == 0
+            except Exception as e:  # noqa: BLE001
+                errors.append((r, repr(e)))
+        threads = [threading.Thread(target=worker, args=(r,)) for r in range(n)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=120)
+        assert not errors, errors
+        assert not any(t.is_alive() for t in threads), "slab threads hung"
+        cnt = np.zeros((size[2], size[1], size[0]), dtype=np.uint32)
+        ids, total = [], 0
+        for r, s in enumerate(sims):
+            lo, hi = s.slab() if hub is not None else (0, size[2] // 8)
+            cnt[lo * 8:hi * 8] = counts0[r][lo * 8:hi * 8]
+            total += s.num_particles
+            ids.append(s.particle_ids() if hub is not None else np.arange(s.num_particles))
+        for s in sims:
+            s.close()
+        if hub is not None:
+            hub.close()
+        return cnt, total, np.concatenate(ids)
+
+    c1, n1, _ = run(None)
+    cn, nn, ids = run(bounds)
+    n_block = 8 * 12 * 6 * 26
+    assert n1 > n_block + 8 * len(src_cells) - 1  # the first seeding alone fills 30 empty cells with 8 particles each
+    assert np.array_equal(cn, c1), "cells topped up differently on slabs"
+    assert nn == n1
+    assert len(np.unique(ids)) == len(ids) == nn
+
+
 @pytest.mark.skipif(os.environ.get("LFA_SKIP_RCCL") == "1", reason="LFA_SKIP_RCCL=1")
 @pytest.mark.parametrize("precond,dtype", [(lfa.PRECOND_MULTILEVEL, lfa.PCG_F64), (lfa.PRECOND_MULTIGRID, lfa.PCG_F32),
                                            (lfa.PRECOND_MULTIGRID, lfa.PCG_F64)])

@@ -33,7 +33,7 @@ def fullstep_inputs():
 def build_driver(tmp_path):
     exe = str(tmp_path / "host_sim_driver")
     lfa.load_library()
-    cmd = ["g++", "-std=c++17", "-O2", "-fopenmp", "-Wall", "-Wextra", "-o", exe, DRIVER_SRC,
+    cmd = ["g++", "-std=c++17", "-O2", "-fopenmp", "-Wall", "-Wextra", *os.environ.get("LFA_HOST_CXXFLAGS", "").split(), "-o", exe, DRIVER_SRC,
            "-L" + os.path.dirname(lfa.LIB_PATH), "-l:libfluid_amd.so", "-Wl,-rpath," + os.path.dirname(lfa.LIB_PATH)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr

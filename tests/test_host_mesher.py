@@ -22,7 +22,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden", "mesher.npz")
 def build_driver(tmp_path):
     exe = str(tmp_path / "host_mesher_driver")
     lfa.load_library()
-    cmd = ["g++", "-std=c++17", "-O2", "-fopenmp", "-Wall", "-Wextra", "-o", exe, SRC, "-L" + os.path.dirname(lfa.LIB_PATH),
+    cmd = ["g++", "-std=c++17", "-O2", "-fopenmp", "-Wall", "-Wextra", *os.environ.get("LFA_HOST_CXXFLAGS", "").split(), "-o", exe, SRC, "-L" + os.path.dirname(lfa.LIB_PATH),
            "-l:libfluid_amd.so", "-Wl,-rpath," + os.path.dirname(lfa.LIB_PATH)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
