@@ -1300,12 +1300,19 @@ int lfa_c_home_ensure(lfa_sim *s, size_t n) {
 	const size_t cap = ((n + n / 8) + 1023) & ~(size_t)1023;
 	float *nh = nullptr;
 	LFA_HIP(s, hipMalloc(&nh, cap * 9 * sizeof(float)));
+	auto fail = [&](hipError_t e, const char *what) {  // (the new array does not outlive a failure)
+		(void)hipFree(nh);
+		return lfa_fail(s, LFA_E_HIP, "%s failed: %s", what, hipGetErrorString(e));
+	};
 	if (s->c_home && s->c_home_valid && s->np_live)
-		for (int k = 0; k < 9; ++k)
-			LFA_HIP(s, hipMemcpyAsync(nh + (size_t)k * cap, s->c_home + (size_t)k * s->c_home_cap, std::min(s->np_live, s->c_home_cap) * 4,
-			                          hipMemcpyDeviceToDevice, s->stream));
+		for (int k = 0; k < 9; ++k) {
+			const hipError_t e = hipMemcpyAsync(nh + (size_t)k * cap, s->c_home + (size_t)k * s->c_home_cap,
+			                                    std::min(s->np_live, s->c_home_cap) * 4, hipMemcpyDeviceToDevice, s->stream);
+			if (e != hipSuccess) return fail(e, "copying C to its larger home array");
+		}
 	if (s->c_home) {
-		LFA_HIP(s, hipStreamSynchronize(s->stream));
+		const hipError_t e = hipStreamSynchronize(s->stream);
+		if (e != hipSuccess) return fail(e, "hipStreamSynchronize");
 		LFA_HIP(s, hipFree(s->c_home));
 	}
 	s->c_home = nh;
@@ -1691,6 +1698,7 @@ extern "C" const char *lfa_bench_stream_variant(void) {
 	return g_stream_best >= 0 ? names[g_stream_best] : "";
 }
 
+// (one-shot scratch: straight from / back to the driver, never parked in the handle cache)
 extern "C" int lfa_bench_stream(lfa_sim *s, uint64_t bytes, int reps, double *copy_gbs, double *read_gbs) {
 	if (!s || reps < 1 || bytes < (1u << 20)) return LFA_E_INVALID;
 	LFA_HIP(s, hipSetDevice(s->device));
@@ -1700,10 +1708,10 @@ extern "C" int lfa_bench_stream(lfa_sim *s, uint64_t bytes, int reps, double *co
 	auto cleanup = [&]() {
 		if (e0) (void)hipEventDestroy(e0);
 		if (e1) (void)hipEventDestroy(e1);
-		if (a) (void)hipFree(a);
-		if (b) (void)hipFree(b);
+		if (a) (void)(hipFree)(a);
+		if (b) (void)(hipFree)(b);
 	};
-	if (hipMalloc((void **)&a, n * 16) != hipSuccess || hipMalloc((void **)&b, n * 16) != hipSuccess) {
+	if ((hipMalloc)((void **)&a, n * 16) != hipSuccess || (hipMalloc)((void **)&b, n * 16) != hipSuccess) {
 		cleanup();
 		return lfa_fail(s, LFA_E_OOM, "lfa_bench_stream: hipMalloc of 2 x %llu bytes failed", (unsigned long long)bytes);
 	}

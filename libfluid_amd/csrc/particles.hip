@@ -1036,7 +1036,7 @@ extern "C" int lfa_update_sources(lfa_sim *s, uint64_t *n_seeded) {
 		hv[me] = (double)total;
 		double *dv = s->dist_red + 16;  // (slots 0-5 belong to the solve)
 		LFA_HIP(s, hipMemcpyAsync(dv, hv, (size_t)nr * 8, hipMemcpyHostToDevice, s->stream));
-		LFA_TRY(s->dist->allreduce(s, dv, nr, false));
+		LFA_TRY(s->dist->allreduce_buf(s, dv, (size_t)nr, LFA_RED_F64, false));
 		LFA_HIP(s, hipMemcpyAsync(hv, dv, (size_t)nr * 8, hipMemcpyDeviceToHost, s->stream));
 		LFA_HIP(s, hipStreamSynchronize(s->stream));
 		id_base = s->next_global_id;

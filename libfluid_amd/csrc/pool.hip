@@ -34,23 +34,33 @@ struct Pool {
 	std::unordered_map<void *, Block> live;                       // blocks handed out
 	std::map<std::pair<int, size_t>, std::vector<void *>> free_;  // (device, bytes) -> cached blocks
 	size_t cached_bytes = 0, cached_blocks = 0, hits = 0, misses = 0;
-	size_t max_bytes = 0;
 };
 Pool &pool() {
 	static Pool *p = new Pool();  // never destroyed: handles may be released after static destructors ran
 	return *p;
 }
 thread_local int t_nosync = 0;
-size_t max_bytes_for(Pool &P) {
-	if (P.max_bytes) return P.max_bytes;
+/// The cache's budget PER DEVICE (a quarter of that device's memory unless LFA_POOL_MAX_BYTES says otherwise; read once per
+/// device, with that device current), and what each device holds.
+struct DevBudget {
+	size_t max_bytes = 0, cached_bytes = 0;
+};
+DevBudget g_budget[64];
+size_t max_bytes_for(int device) {  // (P.m held)
+	DevBudget &b = g_budget[device & 63];
+	if (b.max_bytes) return b.max_bytes;
 	if (const char *e = getenv("LFA_POOL_MAX_BYTES")) {
-		P.max_bytes = (size_t)strtoull(e, nullptr, 10);
-		if (!P.max_bytes) P.max_bytes = 1;  // "0" = keep nothing
-		return P.max_bytes;
+		b.max_bytes = (size_t)strtoull(e, nullptr, 10);
+		if (!b.max_bytes) b.max_bytes = 1;  // "0" = keep nothing
+		return b.max_bytes;
 	}
+	int cur = 0;
+	(void)hipGetDevice(&cur);
+	if (cur != device) (void)hipSetDevice(device);
 	size_t fr = 0, tot = 0;
-	P.max_bytes = (hipMemGetInfo(&fr, &tot) == hipSuccess && tot) ? tot / 4 : ((size_t)8 << 30);
-	return P.max_bytes;
+	b.max_bytes = (hipMemGetInfo(&fr, &tot) == hipSuccess && tot) ? tot / 4 : ((size_t)8 << 30);
+	if (cur != device) (void)hipSetDevice(cur);
+	return b.max_bytes;
 }
 }  // namespace
 
@@ -68,6 +78,7 @@ hipError_t lfa_pool_malloc(void **p, size_t bytes) {
 			*p = it->second.back();
 			it->second.pop_back();
 			P.cached_bytes -= bytes;
+			g_budget[dev & 63].cached_bytes -= bytes;
 			--P.cached_blocks;
 			++P.hits;
 			P.live[*p] = Block{bytes, dev};
@@ -102,14 +113,33 @@ hipError_t lfa_pool_free(void *p) {
 		}
 	}
 	if (!known) return (hipFree)(p);
-	// hipFree waits for the device: a block may still be in use by work queued on some stream
+	// hipFree waits for the device: a block may still be in use by work queued on some stream - of ITS device, which need not
+	// be the current one (a host thread that drives several GPUs)
 	hipError_t e = hipSuccess;
+	int cur = 0;
+	(void)hipGetDevice(&cur);
+	if (cur != b.device) (void)hipSetDevice(b.device);
 	if (!t_nosync) e = hipDeviceSynchronize();
-	std::lock_guard<std::mutex> lk(P.m);
-	if (P.cached_bytes + b.bytes > max_bytes_for(P)) return (hipFree)(p);
-	P.free_[{b.device, b.bytes}].push_back(p);
-	P.cached_bytes += b.bytes;
-	++P.cached_blocks;
+	bool keep = false;
+	{
+		std::lock_guard<std::mutex> lk(P.m);
+		// kept: what fits the device's budget; a block larger than a quarter of the budget is one-shot scratch (the stream
+		// benchmark's two 1 GiB buffers, an outgrown particle capacity) and goes back to the driver
+		const size_t budget = max_bytes_for(b.device);
+		DevBudget &db = g_budget[b.device & 63];
+		if (b.bytes <= budget / 4 && db.cached_bytes + b.bytes <= budget) {
+			P.free_[{b.device, b.bytes}].push_back(p);
+			P.cached_bytes += b.bytes;
+			db.cached_bytes += b.bytes;
+			++P.cached_blocks;
+			keep = true;
+		}
+	}
+	if (!keep) {  // (outside the lock: the driver's free synchronises, other threads' allocations must not queue behind it)
+		const hipError_t ef = (hipFree)(p);
+		if (e == hipSuccess) e = ef;
+	}
+	if (cur != b.device) (void)hipSetDevice(cur);
 	return e;
 }
 
@@ -166,6 +196,7 @@ extern "C" void lfa_pool_trim(void) {
 		P.free_.clear();
 		P.cached_bytes = 0;
 		P.cached_blocks = 0;
+		for (DevBudget &b : g_budget) b.cached_bytes = 0;
 	}
 	for (void *p : blocks) (void)(hipFree)(p);
 	std::vector<lfa_stream_set *> sets;
