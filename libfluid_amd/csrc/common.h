@@ -207,6 +207,7 @@ struct lfa_sim {
 	uint64_t stat_launches_iter = 0, stat_transport_iter = 0, stat_transport_solve = 0, stat_mg_levels = 0, stat_mg_first_co = 0, stat_whole_solve = 0;
 	// kernels whose workgroups wait for each other (k_mg_coarse, k_pcg_small): a wait that was given up (mg.hip: co_wait) ends
 	// their use on this handle; the solve that met it is repeated on the launch-per-phase path
+	bool last_rhs_zero = false;  // the previous solve was the early-out of a zero right-hand side (pcg.hip: k_check_rhs)
 	bool co_disabled = false;
 	uint64_t stat_co_aborts = 0;
 	bool gate_counted = false;  // this handle is in the device's count of live handles (lfa_co_gate_handle)

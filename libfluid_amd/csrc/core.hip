@@ -325,7 +325,7 @@ extern "C" int lfa_create(lfa_sim **out, uint64_t nx, uint64_t ny, uint64_t nz, 
 	chk(dev_alloc(s, &s->cell_count, s->ncp, true));
 	chk(dev_alloc(s, &s->abits, s->ncp, true));
 	chk(dev_alloc(s, &s->partials, 16384, true));  // >= PART_TOTAL (pcg.h)
-	chk(dev_alloc(s, &s->pcg_state, 16, true));
+	chk(dev_alloc(s, &s->pcg_state, 32, true));  // [0] done [1] NaN [2] a wait was given up [3] 1: zero right-hand side, 2: NaN in it ... [16,17] the final residual (double)
 	chk(dev_alloc(s, &s->pcg_hist, 8192, true));  // [0,4096) residual history, [6144,..) coarse r2 hand-off
 	if (rc == LFA_OK && !s->h_pinned && hipHostMalloc((void **)&s->h_pinned, 4096, hipHostMallocDefault) != hipSuccess)
 		rc = lfa_fail(s, LFA_E_HIP, "hipHostMalloc failed");
@@ -1280,6 +1280,29 @@ __global__ void k_gather_u32(const uint32_t *src, const int *idx, int n, uint32_
 	if (i < n) dst[i] = src[idx[i]];
 }
 
+/// The same dilation from the slot table (>= 0: the tile holds particles), a thread per tile: needs no tile list - and so no count
+/// on the host - to size its launch (single domain: the binning reads its three counts back together, once).
+__global__ void k_dilate_slots(const int *tile_pslot, uint32_t *flag, GridDims g) {
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= g.nt || tile_pslot[t] < 0) return;
+	int tx, ty, tz;
+	tile_coords(g, t, tx, ty, tz);
+	for (int o = 0; o < 27; ++o) {
+		const int x = tx + o % 3 - 1, y = ty + (o / 3) % 3 - 1, z = tz + o / 9 - 1;
+		if ((unsigned)x < (unsigned)g.ntx && (unsigned)y < (unsigned)g.nty && (unsigned)z < (unsigned)g.ntz)
+			flag[x + g.ntx * (y + g.nty * z)] = 1u;
+	}
+}
+
+/// Compacts the flagged tiles of [lo, hi) into `list` (ascending tile id); the count stays on the device (*total_dev).
+static int compact_tiles_async(lfa_sim *s, const uint32_t *flag, int lo, int hi, int *list, int *slot_of, uint32_t *total_dev) {
+	LFA_TRY(lfa_exclusive_scan_u32(s, flag + lo, s->tile_scan + lo, (size_t)(hi - lo), total_dev));
+	hipLaunchKernelGGL(k_compact_range, dim3((hi - lo + 255) / 256), dim3(256), 0, s->stream, flag, s->tile_scan - 0,
+	                   list - 0, slot_of, lo, hi, 0);
+	LFA_LAUNCH_CHECK(s);
+	return LFA_OK;
+}
+
 /// Compacts the flagged tiles of [lo, hi) into `list` (ascending tile id); the count is returned through the host.
 static int compact_tiles(lfa_sim *s, const uint32_t *flag, int lo, int hi, int *list, int *slot_of, int *count) {
 	*count = 0;
@@ -1376,14 +1399,32 @@ int lfa_hash_particles_impl(lfa_sim *s, bool counts_done) {
 	LFA_TRY(lfa_dist_exchange_tile_layers_u32(s, s->tile_flag));
 	hipLaunchKernelGGL(k_fill_i32, dim3((nt + 255) / 256), dim3(256), 0, s->stream, s->tile_pslot, nt, -1);
 	LFA_LAUNCH_CHECK(s);
-	LFA_TRY(compact_tiles(s, s->tile_flag, all_lo, all_hi, s->ptiles_all, s->tile_pslot, &s->n_ptiles_all));
+	const bool one_sync = !s->dist;  // single domain: the tile lists are built without the host, their counts come back together
+	if (one_sync) {
+		uint32_t *tot = (uint32_t *)s->pcg_state + 8;  // [8] particle tiles, [9] processed tiles
+		LFA_TRY(compact_tiles_async(s, s->tile_flag, 0, nt, s->ptiles_all, s->tile_pslot, tot));
+		LFA_HIP(s, hipMemsetAsync(s->tile_flag, 0, (size_t)(nt + 1) * 4, s->stream));
+		hipLaunchKernelGGL(k_dilate_slots, dim3((nt + 255) / 256), dim3(256), 0, s->stream, (const int *)s->tile_pslot, s->tile_flag, g);
+		LFA_LAUNCH_CHECK(s);
+		LFA_TRY(compact_tiles_async(s, s->tile_flag, 0, nt, s->dtiles, nullptr, tot + 1));
+		LFA_HIP(s, hipMemcpyAsync(s->h_pinned + 9, tot, 8, hipMemcpyDeviceToHost, s->stream));
+		LFA_HIP(s, hipStreamSynchronize(s->stream));
+		s->n_ptiles_all = (int)s->h_pinned[9];
+		s->n_dtiles = (int)s->h_pinned[10];
+		s->p_off = 0;
+		s->n_ptiles = s->n_ptiles_all;
+		s->n_own_first = s->n_own_last = s->n_ghost_lo = s->n_ghost_hi = 0;
+		s->ptiles = s->ptiles_all;
+	} else {
+		LFA_TRY(compact_tiles(s, s->tile_flag, all_lo, all_hi, s->ptiles_all, s->tile_pslot, &s->n_ptiles_all));
+	}
 	s->np_live = s->h_pinned[8];
 	if (s->dist) s->np = s->np_live;  // particles migrate: the resident count is the live count
 	s->holes = false;
 	s->n_arrivals = 0;
 	s->move_pending = false;  // (a binning re-uses the buffer the positions of before a split move were kept in)
 	// counts per layer group = differences of the scan at the layer boundaries
-	{
+	if (!one_sync) {
 		int marks[4] = {own_lo, own_lo + L < own_hi ? own_lo + L : own_hi, own_hi - L > own_lo ? own_hi - L : own_lo, own_hi};
 		int vals[4];
 		int *didx = s->pcg_state + 12;
@@ -1408,19 +1449,19 @@ int lfa_hash_particles_impl(lfa_sim *s, bool counts_done) {
 	}
 
 	// ---- processed (dilated) tiles: owned ones are the work list, the neighbours' adjacent layers arrive by message
-	LFA_HIP(s, hipMemsetAsync(s->tile_flag, 0, (size_t)(nt + 1) * 4, s->stream));
-	if (s->n_ptiles_all) {
-		hipLaunchKernelGGL(k_dilate, dim3((s->n_ptiles_all * 27 + 255) / 256), dim3(256), 0, s->stream, s->ptiles_all,
-		                   s->n_ptiles_all, s->tile_flag, g);
-		LFA_LAUNCH_CHECK(s);
-	}
-	if (s->dist) {
+	if (!one_sync) {
+		LFA_HIP(s, hipMemsetAsync(s->tile_flag, 0, (size_t)(nt + 1) * 4, s->stream));
+		if (s->n_ptiles_all) {
+			hipLaunchKernelGGL(k_dilate, dim3((s->n_ptiles_all * 27 + 255) / 256), dim3(256), 0, s->stream, s->ptiles_all,
+			                   s->n_ptiles_all, s->tile_flag, g);
+			LFA_LAUNCH_CHECK(s);
+		}
 		if (own_lo > 0) LFA_HIP(s, hipMemsetAsync(s->tile_flag, 0, (size_t)own_lo * 4, s->stream));
 		if (own_hi < nt) LFA_HIP(s, hipMemsetAsync(s->tile_flag + own_hi, 0, (size_t)(nt - own_hi) * 4, s->stream));
 		LFA_TRY(lfa_dist_exchange_tile_layers_u32(s, s->tile_flag));
+		LFA_TRY(compact_tiles(s, s->tile_flag, own_lo, own_hi, s->dtiles, nullptr, &s->n_dtiles));
+		LFA_TRY(lfa_dist_build_halo_lists(s));
 	}
-	LFA_TRY(compact_tiles(s, s->tile_flag, own_lo, own_hi, s->dtiles, nullptr, &s->n_dtiles));
-	if (s->dist) LFA_TRY(lfa_dist_build_halo_lists(s));
 
 	if (n) {
 		// v and C (48 of the 68 bytes) stay behind and are read through vc_src by the P2G; the G2P writes the new ones in the

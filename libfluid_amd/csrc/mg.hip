@@ -1638,6 +1638,7 @@ __global__ void __launch_bounds__(256) k_pcg_small(PcgSmall<real> Q) {
 	Q.r[base0 + c1] = r1;
 	if (wg == 0 && t == 0 && done >= 0) {
 		if (nan_seen) Q.state[1] = 1;
+		*(double *)(Q.state + 16) = Q.hist[done - 1];
 		Q.state[0] = done;
 	}
 }

@@ -626,9 +626,31 @@ k_check_converged(const double *part_rmax, int n_part, double tol, int iter, int
 		hist[iter] = rmax;
 		if (rmax != rmax) {
 			state[1] = 1;
+			*(double *)(state + 16) = rmax;
 			state[0] = iter + 1;
 		} else if (rmax < tol) {
+			*(double *)(state + 16) = rmax;  // (the host reads it with the state words: no read-back of its own)
 			state[0] = iter + 1;
+		}
+	}
+}
+
+/// The early-out of pressure_solver::solve (src/pressure_solver.cpp:28-35: sum b^2 < 1e-6 returns p = 0, residual 0, 0 iterations)
+/// evaluated on the device: the solve is marked done before its first kernel - which, like every kernel of the loop, does nothing
+/// then - and the host learns it at its first poll instead of draining the GPU for one number ahead of every solve.
+/// state[3] = 1: zero right-hand side, 2: NaN in it.
+__global__ void __launch_bounds__(256) k_check_rhs(const double *part_b2, int n_part, int *state) {
+	__shared__ double lds[4];
+	const double tot = reduce_partials_sum(part_b2, n_part, lds);
+	if (threadIdx.x == 0) {
+		if (tot != tot) {
+			state[3] = 2;
+			state[1] = 1;
+			state[0] = 0;
+		} else if (tot < 1e-6) {
+			state[3] = 1;
+			*(double *)(state + 16) = 0.0;
+			state[0] = 0;
 		}
 	}
 }
@@ -1211,6 +1233,7 @@ k_pcg_a(int n_ptiles, const int *__restrict__ nbr, const uint8_t *__restrict__ a
 			hist[iter - 1] = rmax;
 			if (stop) {
 				if (rmax != rmax) state[1] = 1;
+				*(double *)(state + 16) = rmax;
 				state[0] = iter;
 			}
 		}
@@ -1696,31 +1719,40 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 	const real scale = (real)s->a_scale;
 	double *P = s->partials;
 	const bool dist = s->dist != nullptr;
-	// early out: sum b^2 < 1e-6 (src/pressure_solver.cpp:29-35)
-	double tot = 0.0;
-	if (dist) {
-		if (!s->n_ptiles) LFA_HIP(s, hipMemsetAsync(P + PART_B2, 0, 8, s->stream));
-		LFA_TRY(lfa_dist_allreduce(s, P + PART_B2, G, 0, false));
-		LFA_HIP(s, hipMemcpyAsync(&tot, s->dist_red, 8, hipMemcpyDeviceToHost, s->stream));
-		LFA_HIP(s, hipStreamSynchronize(s->stream));
-	} else {
-		std::vector<double> hb(G);
-		LFA_HIP(s, hipMemcpyAsync(hb.data(), P + PART_B2, (size_t)G * 8, hipMemcpyDeviceToHost, s->stream));
-		LFA_HIP(s, hipStreamSynchronize(s->stream));
-		for (double x : hb) tot += x;
-	}
-	if (tot != tot) return lfa_fail(s, LFA_E_NAN, "NaN in the divergence right-hand side");
-	if (tot < 1e-6) {
-		if (s->warm_started) {  // the reference returns p = 0 here (src/pressure_solver.cpp:33-35), not the guess
-			hipLaunchKernelGGL((k_warm_residual<real, true>), dim3(G), dim3(256), 0, s->stream, tc, v.r, (const real *)v.q, v.p);
-			LFA_LAUNCH_CHECK(s);
+	int init_state[4] = {-1, 0, 0, 0};
+	LFA_HIP(s, hipMemcpyAsync(s->pcg_state, init_state, 16, hipMemcpyHostToDevice, s->stream));
+	// early out: sum b^2 < 1e-6 (src/pressure_solver.cpp:29-35). Single domain: decided on the device (k_check_rhs marks the solve
+	// done, every kernel below is a no-op then, the host learns it at its first poll) - unless the previous solve ended that way: a
+	// scene at rest would queue a chunk of no-op iterations step after step, so it asks first, as slab runs (whose sum is a
+	// collective with a read-back anyway) always do.
+	const bool host_check = dist || s->last_rhs_zero;
+	if (host_check) {
+		double tot = 0.0;
+		if (dist) {
+			if (!s->n_ptiles) LFA_HIP(s, hipMemsetAsync(P + PART_B2, 0, 8, s->stream));
+			LFA_TRY(lfa_dist_allreduce(s, P + PART_B2, G, 0, false));
+			LFA_HIP(s, hipMemcpyAsync(&tot, s->dist_red, 8, hipMemcpyDeviceToHost, s->stream));
+			LFA_HIP(s, hipStreamSynchronize(s->stream));
+		} else {
+			std::vector<double> hb(G);
+			LFA_HIP(s, hipMemcpyAsync(hb.data(), P + PART_B2, (size_t)G * 8, hipMemcpyDeviceToHost, s->stream));
+			LFA_HIP(s, hipStreamSynchronize(s->stream));
+			for (double x : hb) tot += x;
 		}
-		s->pressure_epoch = s->solve_epoch;
-		return LFA_OK;
+		if (tot != tot) return lfa_fail(s, LFA_E_NAN, "NaN in the divergence right-hand side");
+		s->last_rhs_zero = tot < 1e-6;
+		if (tot < 1e-6) {
+			if (s->warm_started) {  // the reference returns p = 0 here (src/pressure_solver.cpp:33-35), not the guess
+				hipLaunchKernelGGL((k_warm_residual<real, true>), dim3(G), dim3(256), 0, s->stream, tc, v.r, (const real *)v.q, v.p);
+				LFA_LAUNCH_CHECK(s);
+			}
+			s->pressure_epoch = s->solve_epoch;
+			return LFA_OK;
+		}
+	} else {
+		hipLaunchKernelGGL(k_check_rhs, dim3(1), dim3(256), 0, s->stream, (const double *)(P + PART_B2), G, s->pcg_state);
+		LFA_LAUNCH_CHECK(s);
 	}
-
-	int init_state[3] = {-1, 0, 0};
-	LFA_HIP(s, hipMemcpyAsync(s->pcg_state, init_state, 12, hipMemcpyHostToDevice, s->stream));
 	if (s->warm_started) {
 		// r = b - A p_guess: one SpMV and one subtraction before the first preconditioner application
 		hipLaunchKernelGGL(k_spmv<real>, dim3(G), dim3(256), 0, s->stream, tc, s->abits, (const real *)v.p, v.q, scale, P + PART_ZS,
@@ -1749,7 +1781,7 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 	int *hstate = (int *)s->h_pinned;
 	int aborted = 0;  // a kernel whose workgroups wait for each other gave a wait up (mg.hip: co_wait)
 	if (small_ran) {
-		LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 12, hipMemcpyDeviceToHost, s->stream));
+		LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 72, hipMemcpyDeviceToHost, s->stream));
 		LFA_HIP(s, hipStreamSynchronize(s->stream));
 		done = hstate[0];
 		nan = hstate[1];
@@ -1853,7 +1885,7 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 		                   dist ? (const double *)lfa_dist_gather_buf(s, i & 1) : P + PART_RMAX, dist ? s->dist->nranks : GB,
 		                   s->prm.tolerance, i - 1, s->pcg_state, s->pcg_hist);
 		LFA_LAUNCH_CHECK(s);
-		LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 12, hipMemcpyDeviceToHost, s->stream));
+		LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 72, hipMemcpyDeviceToHost, s->stream));
 		LFA_HIP(s, hipStreamSynchronize(s->stream));
 		done = hstate[0];
 		nan = hstate[1];
@@ -1884,7 +1916,7 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 			                   s->pcg_state, s->abits, cx, (const int *)s->slot_l1, (const real *)s->c_x2, (const int *)s->l1_l2);
 			LFA_LAUNCH_CHECK(s);
 		}
-		LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 8, hipMemcpyDeviceToHost, s->stream));
+		LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 72, hipMemcpyDeviceToHost, s->stream));
 		LFA_HIP(s, hipStreamSynchronize(s->stream));
 		done = hstate[0];
 		nan = hstate[1];
@@ -1901,9 +1933,23 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 		s->pressure_epoch = 0;  // (the pressure the aborted iterations left is no guess)
 		return solve_t<real>(s, dt, residual, iterations);
 	}
+	if (!host_check) {  // what k_check_rhs found
+		if (hstate[3] == 2) return lfa_fail(s, LFA_E_NAN, "NaN in the divergence right-hand side");
+		s->last_rhs_zero = hstate[3] == 1;
+		if (hstate[3] == 1) {
+			if (s->warm_started) {  // the reference returns p = 0 here (src/pressure_solver.cpp:33-35), not the guess
+				hipLaunchKernelGGL((k_warm_residual<real, true>), dim3(G), dim3(256), 0, s->stream, tc, v.r, (const real *)v.q, v.p);
+				LFA_LAUNCH_CHECK(s);
+			}
+			s->pressure_epoch = s->solve_epoch;
+			return LFA_OK;
+		}
+	}
 	const int iters = done >= 0 ? done : maxit;
 	double res = 0.0;
-	if (iters > 0) {
+	if (done > 0) {
+		memcpy(&res, hstate + 16, 8);  // (left beside the state words by the kernel that ended the solve)
+	} else if (iters > 0) {
 		LFA_HIP(s, hipMemcpyAsync(s->h_pinned + 4, s->pcg_hist + (iters - 1), 8, hipMemcpyDeviceToHost, s->stream));
 		LFA_HIP(s, hipStreamSynchronize(s->stream));
 		memcpy(&res, s->h_pinned + 4, 8);
@@ -1993,8 +2039,8 @@ extern "C" int lfa_upload_pressure(lfa_sim *s, const double *p, uint64_t n) {
 
 template <typename real> static int apply_precon_t(lfa_sim *s, const double *r, double *z, uint64_t n) {
 	LFA_TRY(scatter<real>(s, (real *)s->vr, r, n));
-	int init_state[3] = {-1, 0, 0};
-	LFA_HIP(s, hipMemcpyAsync(s->pcg_state, init_state, 12, hipMemcpyHostToDevice, s->stream));
+	int init_state[4] = {-1, 0, 0, 0};
+	LFA_HIP(s, hipMemcpyAsync(s->pcg_state, init_state, 16, hipMemcpyHostToDevice, s->stream));
 	if (s->n_ptiles) {
 		LFA_TRY(mic_apply<real>(s, s->partials + PART_SIG0));
 		if (is_ml(s)) {
@@ -2013,8 +2059,8 @@ extern "C" int lfa_apply_preconditioner(lfa_sim *s, const double *r, double *z, 
 }
 template <typename real> static int apply_a_t(lfa_sim *s, const double *vin, double *out, uint64_t n) {
 	LFA_TRY(scatter<real>(s, (real *)s->vs, vin, n));
-	int init_state[3] = {-1, 0, 0};
-	LFA_HIP(s, hipMemcpyAsync(s->pcg_state, init_state, 12, hipMemcpyHostToDevice, s->stream));
+	int init_state[4] = {-1, 0, 0, 0};
+	LFA_HIP(s, hipMemcpyAsync(s->pcg_state, init_state, 16, hipMemcpyHostToDevice, s->stream));
 	if (s->dist) LFA_TRY(lfa_dist_exchange_slices(s, s->vs, (int)sizeof(real)));
 	if (s->n_ptiles) {
 		TileCtx tc = make_ctx(s);
@@ -2168,8 +2214,8 @@ extern "C" int lfa_bench_kernel(lfa_sim *s, int which, int reps, double *mean_ms
 	                    which == LFA_K_PCG_A || which == LFA_K_PCG_B || (which >= LFA_K_MG_AXPY_PRESMOOTH && which <= LFA_K_MG_UP0);
 	if (is_pcg) {
 		if (!s->system_valid) return lfa_fail(s, LFA_E_INVALID, "lfa_bench_kernel: no pressure system on the device");
-		int init_state[3] = {-1, 0, 0};  // "still iterating": the kernels early-out once a solve has converged
-		LFA_HIP(s, hipMemcpyAsync(s->pcg_state, init_state, 12, hipMemcpyHostToDevice, s->stream));
+		int init_state[4] = {-1, 0, 0, 0};  // "still iterating": the kernels early-out once a solve has converged
+		LFA_HIP(s, hipMemcpyAsync(s->pcg_state, init_state, 16, hipMemcpyHostToDevice, s->stream));
 	}
 	auto once = [&]() -> int {
 		if (is_pcg) return F64(s) ? bench_launch<double>(s, which) : bench_launch<float>(s, which);
