@@ -84,6 +84,9 @@ struct lfa_knobs {
 	int mg_stop_at_single = 0;  // LFA_MG_STOP_AT_SINGLE=1
 	int mg_tail_tiles = -1;   // LFA_MG_TAIL_TILES
 	int mg_co_max_tiles = -1; // LFA_MG_CO_MAX_TILES
+	int mg_top = 0;           // LFA_MG_TOP=1: the level above k_mg_coarse's first one joins that launch, several tile slots per
+	                          // workgroup (round 4: measured at C3 - 8 -> 5 launches per iteration, 0.138 -> 0.140 ms per iteration,
+	                          // step 4.75 -> 4.98 ms beside the correction; does not fit at C4 - so it stays off)
 	int mg_no_persist = 0;    // LFA_MG_NO_PERSIST=1: a launch per coarse-level phase (the bitwise A/B of k_mg_coarse)
 	int mg_cp_max_tiles = -1; // LFA_MG_CP_MAX_TILES
 	int mg_no_cp = 0;         // LFA_MG_NO_CP=1

@@ -1016,6 +1016,7 @@ template <typename real> struct MgCo {
 	int first, last, nsw, inner;
 	unsigned tag;
 	unsigned long long *stamps;  // LFA_MG_CO_STAMPS=1 (debugging): workgroup 0 records the 100 MHz clock around its phases
+	int top;                     // >= 1: level first - 1 runs inside the launch as well, several tile slots per workgroup (see k_mg_coarse); -1: none
 	int *abort;                  // pcg_state + 2: raised by a workgroup whose wait has passed CO_TIMEOUT_TICKS; every waiter checks it
 	int fault;                   // LFA_MG_CO_FAULT=n (tests): workgroup n - 1 never raises its first flag
 };
@@ -1365,9 +1366,44 @@ __global__ void __launch_bounds__(256) k_mg_coarse(MgCo<real> P, const int *stat
 	int lmax = P.first - 1;  // deepest level this workgroup owns a tile of
 	for (int l = P.first; l <= P.last; ++l)
 		if (T.wg < P.lv[l].n_tiles) lmax = l;
-	if (!co_static<real>(P, T, st, lmax, state, true)) return;
+	const bool with_top = P.top >= 0;
+	if (!co_static<real>(P, T, st, lmax, state, !with_top)) return;
 	stamp();
-	(void)co_cycle<real>(P, T, st, R, dep, P.tag, lmax, true, false, stamp);
+	// The level above (round 4): more tiles than workgroups can be resident, so a workgroup takes the slots wg, wg + W, ... of it
+	// (C4: level 1, ~2 400 tiles on 768 workgroups) with the launch-per-phase arithmetic (cp_*_tile, state through the level
+	// arrays instead of LDS) and this kernel's flags - its three launches and their gaps (33 us at C4) become ~3 tile phases of
+	// 2 us each side of the chain below.
+	CpTile<real> *Stop = (CpTile<real> *)(R + 512);
+	real *Rtop = (real *)(Stop + 1);
+	if (with_top) {
+		const MgLv<real> &L = P.lv[P.top];
+		const int nt = L.g.nt;
+		for (int slot = T.wg; slot < L.n_tiles; slot += (int)gridDim.x) {
+			cp_presmooth_tile<real, MemAgent>(*Stop, L, slot, P.inner);
+			co_post(P.ready[P.top], L.tiles[slot], P.tag);
+		}
+		for (int slot = T.wg; slot < L.n_tiles; slot += (int)gridDim.x) {
+			if (T.t < 6) dep[T.t] = L.nbr[(size_t)slot * MG_NBR_STRIDE + T.t];
+			__syncthreads();
+			if (!co_wait(P.ready[P.top], dep, 6, P.tag, P.abort)) return;
+			cp_residual_restrict_tile<real, MemAgent>(*Stop, Rtop, L, P.lv[P.first].g, P.lv[P.first].b, slot);
+			co_post(P.ready[P.top] + nt, L.tiles[slot], P.tag);
+		}
+		stamp();
+	}
+	if (!co_cycle<real>(P, T, st, R, dep, P.tag, lmax, !with_top, with_top, stamp)) return;
+	if (with_top) {
+		const MgLv<real> &L = P.lv[P.top];
+		const GridDims &gc = P.lv[P.first].g;
+		for (int slot = T.wg; slot < L.n_tiles; slot += (int)gridDim.x) {
+			// the corrections come from the parent tile and from the parents of the active neighbour tiles
+			__syncthreads();
+			co_parent_deps(T, dep, L.g, gc, L.nbr + (size_t)slot * MG_NBR_STRIDE);
+			if (!co_wait(P.ready[P.first] + 2 * gc.nt, dep, 7, P.tag, P.abort)) return;
+			cp_prolong_postsmooth_tile<real, MemAgent>(*Stop, L, gc, P.lv[P.first].y, slot, P.inner);
+		}
+		stamp();
+	}
 }
 
 // ------------------------------------------------------------------------------------------------ a whole solve in ONE launch
@@ -2260,6 +2296,7 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 	int co_max = MG_CO_MAX_TILES;
 	if (s->knobs.mg_co_max_tiles >= 0) co_max = s->knobs.mg_co_max_tiles;
 	const bool persist = !s->knobs.mg_no_persist && !s->co_disabled;
+	int top = -1, top_w = 0;  // level that runs inside k_mg_coarse with several tile slots per workgroup, and that launch's width
 	if (persist) {
 		// every workgroup of k_mg_coarse must be resident at the same time (they wait for each other): one workgroup per tile of
 		// its first level, LDS per workgroup grows with the number of levels inside
@@ -2268,6 +2305,7 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 			int n_cu = 0;
 			bool attr_set = false;
 			int per_cu[MG_CO_MAX_LEVELS + 1];  // resident workgroups per CU by the number of levels inside, -1: not asked yet
+			int per_cu_top[MG_CO_MAX_LEVELS + 1];  // the same with the LDS of a multi-slot top level
 		};
 		static DevInfo info[64];
 		static std::mutex info_mutex;
@@ -2280,6 +2318,7 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 				hipDeviceProp_t prop;
 				d.n_cu = (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
 				for (int &v : d.per_cu) v = -1;
+				for (int &v : d.per_cu_top) v = -1;
 			}
 			if (!d.attr_set) {
 				LFA_HIP(s, hipFuncSetAttribute((const void *)k_mg_coarse<real>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -2309,6 +2348,31 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		tail = last;
 		while (tail > 1 && tail - 1 >= D && fits(tail - 1)) --tail;
 		tail = std::max(tail, std::max(D, 1));
+		// the level above the first one inside (never the finest, never a distributed one) joins the launch with several tile slots
+		// per workgroup when the launch can hold at least a third of its tiles. OPT-IN (LFA_MG_TOP=1): measured at C3 it saves
+		// three launches per iteration and no time (0.138 -> 0.140 ms), and the wider launch costs the overlapped step 0.24 ms
+		if (s->knobs.mg_top && tail - 1 >= std::max(D, 1) && last - tail + 1 <= MG_CO_MAX_LEVELS) {
+			const int nlev = last - tail + 1;
+			const size_t lds = (size_t)nlev * sizeof(CoLevel<real>) + 512 * sizeof(real) + sizeof(CpTile<real>) + 512 * sizeof(real) + 64;
+			int per_cu = di.per_cu_top[nlev];
+			if (per_cu < 0) {
+				if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_mg_coarse<real>, 256, lds) != hipSuccess) {
+					(void)hipGetLastError();
+					per_cu = 0;
+				}
+				std::lock_guard<std::mutex> lk(info_mutex);
+				info[dslot].per_cu_top[nlev] = di.per_cu_top[nlev] = per_cu;
+			}
+			const size_t share = s->dist ? (size_t)std::max(1, s->dist->device_share) : 1;
+			// (a margin of an eighth: the occupancy query can be one block per CU high near a register-allocation edge -
+			// MI355X_MICROARCH.md, correctness boundaries - and a workgroup that is not resident is waited for until the ceiling)
+			const size_t cap = ((size_t)per_cu * (size_t)n_cu - (size_t)per_cu * (size_t)n_cu / 8) / share;
+			const size_t t_top = (size_t)M.lv[tail - 1].n_tiles, t_first = (size_t)M.lv[tail].n_tiles;
+			if (cap >= t_first && cap > 0 && 3 * cap >= t_top) {
+				top = tail - 1;
+				top_w = (int)std::max<size_t>(t_first, std::min(cap, t_top));
+			}
+		}
 	}
 	// cell-parallel kernels for levels of up to 1024 tiles (C4: levels 2 and 3; level 1 with 2048 tiles fills the chip with a
 	// wave per tile: 8.58 ms per step against 8.75 with cell-parallel kernels on every coarse level, 8.79 with none)
@@ -2324,6 +2388,7 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		const int G = mg_grid(L.n_tiles);
 		const bool cp = l >= 1 && !s->knobs.mg_no_cp && L.n_tiles <= cp_max;  // a workgroup per tile on the coarser levels (see k_mg_*_cp)
 		const int Gcp = std::max(1, std::min(L.n_tiles, 8192));  // (a slab rank may hold no tile of a level)
+		if (l == top) continue;  // (inside k_mg_coarse)
 		if (!(l == 0 && level0_presmoothed) && (parts & (l == 0 ? MG_PART_PRE0 : MG_PART_COARSE))) {
 			if (cp) hipLaunchKernelGGL(k_mg_presmooth_cp<real>, dim3(Gcp), dim3(256), 0, s->stream, L, MG_INNER_SWEEPS, st);
 			else hipLaunchKernelGGL(k_mg_presmooth<real>, dim3(G), dim3(256), 0, s->stream, L, st);
@@ -2348,6 +2413,11 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		for (int l = tail; l <= last; ++l) C.lv[l] = lvl(l);
 		C.first = tail;
 		C.last = last;
+		C.top = top;
+		if (top >= 0) {
+			C.lv[top] = lvl(top);
+			C.ready[top] = M.lv[top].ready;
+		}
 		C.nsw = MG_COARSEST_SWEEPS;
 		C.inner = MG_INNER_SWEEPS;
 		if (s->knobs.mg_tail_inner > 0) C.inner = s->knobs.mg_tail_inner;
@@ -2367,8 +2437,9 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 			M.co_phases = 3 * (last - tail) + 3;
 		}
 		// one workgroup per tile of its first level: every workgroup owns one tile slot on every level it reaches
-		const int W = std::max(1, M.lv[tail].n_tiles);
-		const size_t lds = (size_t)(last - tail + 1) * sizeof(CoLevel<real>) + 512 * sizeof(real);
+		const int W = top >= 0 ? top_w : std::max(1, M.lv[tail].n_tiles);
+		const size_t lds = (size_t)(last - tail + 1) * sizeof(CoLevel<real>) + 512 * sizeof(real) +
+		                   (top >= 0 ? sizeof(CpTile<real>) + 512 * sizeof(real) : 0);
 		CoGateScope gate(s);
 		hipLaunchKernelGGL(k_mg_coarse<real>, dim3(W), dim3(256), lds, s->stream, C, st);  // (dynamic LDS limit: set where `fits` is)
 		if (gate.done() != LFA_OK) return lfa_fail(s, LFA_E_HIP, "chaining k_mg_coarse behind the device's previous one failed");
@@ -2394,6 +2465,7 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 	for (int l = tail - 1; l >= 0; --l) {
 		const MgLv<real> L = lvl(l);
 		const int G = mg_grid(L.n_tiles);
+		if (l == top) continue;  // (inside k_mg_coarse)
 		if (!(parts & (l == 0 ? MG_PART_UP0 : MG_PART_COARSE))) continue;
 		if (l == 0)
 			launch_up0<real>(s->knobs.mg_mw_u, G, s->stream, L, M.lv[1].g, (const real *)M.lv[1].y, inv_scale, part_sigma, st);
@@ -2410,7 +2482,7 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 	}
 	if (parts == MG_PART_ALL) {
 		M.launches_per_cycle = launches + (level0_presmoothed ? 1 : 0);
-		M.first_co = persist ? tail : 0;
+		M.first_co = persist ? (top >= 0 ? top : tail) : 0;
 	}
 	return LFA_OK;
 }
@@ -2472,6 +2544,7 @@ template <typename real> static int pcg_small_t(lfa_sim *s, bool *ran) {
 	Q.C.stamps = nullptr;
 	Q.C.abort = s->pcg_state + 2;
 	Q.C.fault = 0;
+	Q.C.top = -1;
 	const int maxit = (int)s->prm.max_iterations;
 	// tags tag .. tag + maxit belong to this launch (one per V-cycle); 0 is what the flags are initialised to
 	if (M.co_tag > 0xFFFFFFFFu - (unsigned)(maxit + 4)) {

@@ -557,6 +557,39 @@ def test_pcg_warm_start_converges_to_the_same_pressure_in_fewer_iterations():
 
 
 @pytest.mark.parametrize("dtype", [lfa.PCG_F32, lfa.PCG_F64])
+@pytest.mark.parametrize("co_max", [40, 4])
+def test_multigrid_level_above_the_coarse_launch_inside_it_is_bitwise_the_launch_per_phase_path(dtype, co_max, monkeypatch):
+    """LFA_MG_TOP=1 (opt-in, round 4): the level above k_mg_coarse's first one runs inside that launch too, several tile slots per
+    workgroup, with the launch-per-phase arithmetic and the launch's ready flags. Same bits, same iteration counts."""
+    size, block = (136, 72, 104), ((0, 0, 0), (90, 50, 70))
+    res = []
+    for persist in (True, False):
+        monkeypatch.setenv("LFA_MG_CP_MAX_TILES", "1000000")
+        if persist:
+            monkeypatch.setenv("LFA_MG_TOP", "1")
+            monkeypatch.setenv("LFA_MG_CO_MAX_TILES", str(co_max))
+            monkeypatch.delenv("LFA_MG_NO_PERSIST", raising=False)
+        else:
+            monkeypatch.delenv("LFA_MG_TOP", raising=False)
+            monkeypatch.delenv("LFA_MG_CO_MAX_TILES", raising=False)
+            monkeypatch.setenv("LFA_MG_NO_PERSIST", "1")
+        s = lfa.Sim(size, precond=lfa.PRECOND_MULTIGRID, pcg_dtype=dtype)
+        s.seed_block(*block)
+        its = []
+        for _ in range(3):
+            r, it, rc = s.step_hot(util.DT)
+            assert rc == 0
+            its.append(it)
+        st = s.solver_stats()
+        if persist:
+            assert st["launches_per_iteration"] <= 5 and st["device_waits_given_up"] == 0, st
+        res.append((its, s.pressure().copy()))
+        s.close()
+    assert res[0][0] == res[1][0]
+    assert np.array_equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("dtype", [lfa.PCG_F32, lfa.PCG_F64])
 @pytest.mark.parametrize("co_max", [None, 1000000, 40, 4, 1])
 def test_multigrid_single_launch_coarse_levels_are_bitwise_the_launch_per_phase_path(dtype, co_max, monkeypatch):
     """k_mg_coarse runs every phase of the coarse levels (pre-smoothing, residual + restriction, coarsest solve, prolongation +
