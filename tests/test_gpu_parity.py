@@ -582,7 +582,8 @@ def test_multigrid_level_above_the_coarse_launch_inside_it_is_bitwise_the_launch
             its.append(it)
         st = s.solver_stats()
         if persist:
-            assert st["launches_per_iteration"] <= 5 and st["device_waits_given_up"] == 0, st
+            # (co_max 40: levels >= 2 inside, level 1 joins them - 5 launches per iteration; co_max 4: level 2 joins levels >= 3)
+            assert st["launches_per_iteration"] <= (5 if co_max == 40 else 8) and st["device_waits_given_up"] == 0, st
         res.append((its, s.pressure().copy()))
         s.close()
     assert res[0][0] == res[1][0]
