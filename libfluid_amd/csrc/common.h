@@ -84,6 +84,10 @@ struct lfa_knobs {
 	int mg_stop_at_single = 0;  // LFA_MG_STOP_AT_SINGLE=1
 	int mg_tail_tiles = -1;   // LFA_MG_TAIL_TILES
 	int mg_co_max_tiles = -1; // LFA_MG_CO_MAX_TILES
+	int mg_xcd = 0;           // LFA_MG_XCD=1: k_mg_coarse with its workgroups on one XCD (every eighth of 8 W works, workgroup-scope
+	                          // accesses). Round 4: inside the solver the placement the stand-alone probe showed does NOT hold - a
+	                          // consumer on XCC 6 never saw its producer's flag, the wait ran into its ceiling, the solve was repeated
+	                          // on every XCD (the retreat works; the mode buys nothing) - so it stays off
 	int mg_top = 0;           // LFA_MG_TOP=1: the level above k_mg_coarse's first one joins that launch, several tile slots per
 	                          // workgroup (round 4: measured at C3 - 8 -> 5 launches per iteration, 0.138 -> 0.140 ms per iteration,
 	                          // step 4.75 -> 4.98 ms beside the correction; does not fit at C4 - so it stays off)
@@ -211,8 +215,10 @@ struct lfa_sim {
 	// kernels whose workgroups wait for each other (k_mg_coarse, k_pcg_small): a wait that was given up (mg.hip: co_wait) ends
 	// their use on this handle; the solve that met it is repeated on the launch-per-phase path
 	bool last_rhs_zero = false;  // the previous solve was the early-out of a zero right-hand side (pcg.hip: k_check_rhs)
+	bool co_xcd_disabled = false;  // k_mg_coarse's one-XCD mode met a workgroup on another XCD (or a wait ran out in it): not used again
+	bool co_last_xcd = false;      // the last k_mg_coarse launch ran in that mode
 	bool co_disabled = false;
-	uint64_t stat_co_aborts = 0;
+	uint64_t stat_co_aborts = 0, stat_co_reason = 0;
 	bool gate_counted = false;  // this handle is in the device's count of live handles (lfa_co_gate_handle)
 	// warm start of the PCG (lfa_params.pcg_warm_start)
 	uint32_t *tile_epoch = nullptr;   // [nt] solve counter of the last solve a tile took part in

@@ -237,6 +237,7 @@ static void lfa_knobs_parse(lfa_knobs &k) {
 	k.mg_co_max_tiles = num("LFA_MG_CO_MAX_TILES", -1);
 	k.mg_no_persist = flag("LFA_MG_NO_PERSIST", 0);
 	k.mg_top = flag("LFA_MG_TOP", 0);
+	k.mg_xcd = flag("LFA_MG_XCD", 0);
 	k.mg_cp_max_tiles = num("LFA_MG_CP_MAX_TILES", -1);
 	k.mg_no_cp = flag("LFA_MG_NO_CP", 0);
 	k.mg_tail_inner = num("LFA_MG_TAIL_INNER", 0);

@@ -817,6 +817,13 @@ struct MemAgent {
 	template <typename T> static __device__ inline T ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 	template <typename T> static __device__ inline void st(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 };
+/// Workgroup-scope relaxed atomics (`sc0`: the access bypasses the CU's L1 and meets the others in the L2) - enough, and half the
+/// round trip of `sc1`, when every workgroup that takes part sits on ONE XCD and so shares one L2 (k_mg_coarse's XCD mode; the
+/// ready flags carry the producer's XCC id, so a consumer on another XCD notices before it reads anything).
+struct MemWg {
+	template <typename T> static __device__ inline T ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+	template <typename T> static __device__ inline void st(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+};
 
 /// Down, one tile, a workgroup of 256: x = `inner` red->black sweeps on A x = b from x = 0.
 template <typename real, typename MEM> __device__ inline void cp_presmooth_tile(CpTile<real> &S, const MgLv<real> &L, int slot, int inner) {
@@ -1045,8 +1052,17 @@ __device__ inline bool co_poll_expired(int tries, unsigned long long &t0, int *a
 	if (t0 == 0ull) t0 = wall_clock64();
 	return __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > CO_TIMEOUT_TICKS;
 }
+/// A ready flag = (launch tag << 4) | XCC id of the workgroup that raised it.
+__device__ inline unsigned co_xcc_id() {
+	unsigned x;
+	asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+	return x & 15u;
+}
 /// All threads: waits until every tile in dep[0 .. n) (n <= 8; -1 entries are skipped) carries this launch's tag in `flag`.
-/// Returns false (uniformly) when the wait was given up: the caller leaves the kernel.
+/// Returns false (uniformly) when the wait was given up: the caller leaves the kernel. MEM = MemWg (every workgroup of the launch
+/// is meant to sit on one XCD): a flag raised from another XCD ends the launch like a wait that has run out - the data behind it
+/// may sit in the other XCD's L2.
+template <typename MEM>
 __device__ inline bool co_wait(const unsigned *flag, const int *dep, int n, unsigned tag, int *abort_word) {
 	int bad = 0;
 	if ((int)threadIdx.x < n) {
@@ -1054,30 +1070,37 @@ __device__ inline bool co_wait(const unsigned *flag, const int *dep, int n, unsi
 		if (d >= 0) {
 			int tries = 0;
 			unsigned long long t0 = 0ull;
-			while (__hip_atomic_load(flag + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) {
+			unsigned f;
+			while (((f = MEM::ld(flag + d)) >> 4) != tag) {
 				co_backoff(tries);
 				if (co_poll_expired(tries, t0, abort_word)) {
-					__hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					bad = 1;
 					break;
 				}
+			}
+			if (!bad && !__is_same(MEM, MemAgent) && (f & 15u) != co_xcc_id()) bad = 2;
+			if (bad) {
+				// (why, for the record: abort_word[16] = 0x100 a wait ran out | 0x200 a flag from another XCD, with the two XCC ids)
+				if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+					abort_word[16] = (bad == 2 ? 0x200 : 0x100) | (int)co_xcc_id() | (int)((f & 15u) << 4);
+				__hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
 		}
 	}
 	return __syncthreads_or(bad) == 0;
 }
 /// All threads: this workgroup's stores so far have been acknowledged; then the tile's flag is raised.
-__device__ inline void co_post(unsigned *flag, int tile, unsigned tag) {
+template <typename MEM> __device__ inline void co_post(unsigned *flag, int tile, unsigned tag) {
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();
-	if (threadIdx.x == 0) __hip_atomic_store(flag + tile, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if (threadIdx.x == 0) MEM::st(flag + tile, (tag << 4) | co_xcc_id());
 }
 
 /// Per-thread constants of the dataflow kernels: the two cells of a thread are column (qx, qy), z = 2 j and 2 j + 1.
 struct CoThread {
 	int t, wg, qx, qy, qj, c0, c1, h0, h1;
-	__device__ inline CoThread() {
-		t = threadIdx.x; wg = blockIdx.x;
+	__device__ inline explicit CoThread(int wg_ = (int)blockIdx.x) {
+		t = threadIdx.x; wg = wg_;
 		qx = t & 7; qy = (t >> 3) & 7; qj = t >> 6;
 		c0 = qx + 8 * qy + 128 * qj; c1 = c0 + 64;
 		h0 = (qx + 1) + 10 * (qy + 1) + 100 * (2 * qj + 1); h1 = h0 + 100;
@@ -1108,7 +1131,7 @@ template <typename real> __device__ inline real co_residual_cell(const real *H, 
 }
 /// Restriction of the residuals in R (512 cells of tile `tile` of level grid g) to its share of the parent level's right-hand
 /// side: half the sum over the 8 children, in the order of the pair sums and the two shuffle steps of residual_restrict_tile.
-template <typename real>
+template <typename real, typename MEM>
 __device__ inline void co_restrict_store(const CoThread &T, const real *R, const GridDims &g, const GridDims &gc, int tile, real *b_coarse) {
 	if (T.t < 64) {
 		const int X = T.t & 3, Y = (T.t >> 2) & 3, Z = T.t >> 4;
@@ -1121,7 +1144,7 @@ __device__ inline void co_restrict_store(const CoThread &T, const real *R, const
 		int tx, ty, tz;
 		tile_coords(g, tile, tx, ty, tz);
 		const int ptile = (tx >> 1) + gc.ntx * ((ty >> 1) + gc.nty * (tz >> 1));
-		MemAgent::st(b_coarse + (size_t)ptile * 512 + ((tz & 1) * 4 + Z) * 64 + ((ty & 1) * 4 + Y) * 8 + (tx & 1) * 4 + X, (real)0.5 * v);
+		MEM::st(b_coarse + (size_t)ptile * 512 + ((tz & 1) * 4 + Z) * 64 + ((ty & 1) * 4 + Y) * 8 + (tx & 1) * 4 + X, (real)0.5 * v);
 	}
 }
 /// dep[0..8) = the active child tiles (level below, grid gf) of `tile` (grid g), -1 where there is none.
@@ -1149,14 +1172,14 @@ __device__ inline void co_parent_deps(const CoThread &T, int *dep, const GridDim
 	__syncthreads();
 }
 /// x += P e on the thread's two cells and on the ring cells that are unknowns of an active neighbour (cp_prolong_postsmooth_tile).
-template <typename real>
+template <typename real, typename MEM>
 __device__ inline void co_add_correction(const CoThread &T, real *H, uint32_t a0, uint32_t a1, const uint8_t *rab, const int *nb,
                                          const GridDims &g, const GridDims &gc, int tile, const real *e) {
 	int tx, ty, tz;
 	tile_coords(g, tile, tx, ty, tz);
 	{
 		// cells z = 2 j and 2 j + 1 of a column share their parent
-		const real corr = MemAgent::ld(e + blocked_index(gc, (tx * 8 + T.qx) >> 1, (ty * 8 + T.qy) >> 1, (tz * 8 + 2 * T.qj) >> 1));
+		const real corr = MEM::ld(e + blocked_index(gc, (tx * 8 + T.qx) >> 1, (ty * 8 + T.qy) >> 1, (tz * 8 + 2 * T.qj) >> 1));
 		if (a0 & AB_UNKNOWN) H[T.h0] = H[T.h0] + corr;
 		if (a1 & AB_UNKNOWN) H[T.h1] = H[T.h1] + corr;
 	}
@@ -1164,17 +1187,17 @@ __device__ inline void co_add_correction(const CoThread &T, real *H, uint32_t a0
 		int f, hidx, ncell, dx, dy, dz;
 		cp_ring(r, f, hidx, ncell, dx, dy, dz);
 		if (nb[f] >= 0 && (rab[r] & AB_UNKNOWN))
-			H[hidx] = H[hidx] + MemAgent::ld(e + blocked_index(gc, (tx * 8 + dx) >> 1, (ty * 8 + dy) >> 1, (tz * 8 + dz) >> 1));
+			H[hidx] = H[hidx] + MEM::ld(e + blocked_index(gc, (tx * 8 + dx) >> 1, (ty * 8 + dy) >> 1, (tz * 8 + dz) >> 1));
 	}
 	__syncthreads();
 }
 /// Ring of the halo block from the neighbour tiles' values in `v` (inactive neighbours: the ring keeps its zeros).
-template <typename real> __device__ inline void co_load_ring(const CoThread &T, real *H, const int *nb, const real *v) {
+template <typename real, typename MEM> __device__ inline void co_load_ring(const CoThread &T, real *H, const int *nb, const real *v) {
 	for (int r = T.t; r < 384; r += 256) {
 		int f, hidx, ncell, dx, dy, dz;
 		cp_ring(r, f, hidx, ncell, dx, dy, dz);
 		const int n = nb[f];
-		if (n >= 0) H[hidx] = MemAgent::ld(v + (size_t)n * 512 + ncell);
+		if (n >= 0) H[hidx] = MEM::ld(v + (size_t)n * 512 + ncell);
 	}
 	__syncthreads();
 }
@@ -1183,7 +1206,7 @@ template <typename real> __device__ inline void co_load_ring(const CoThread &T, 
 /// halo blocks are cleared. Two dependent round trips. `state` (may be null): read together with the first batch; returns false
 /// (uniformly) when the solve has converged. `prefetch_b`: the first level's right-hand side was written by an earlier kernel
 /// and is fetched here too.
-template <typename real>
+template <typename real, typename MEM>
 __device__ inline bool co_static(const MgCo<real> &P, const CoThread &T, CoLevel<real> *st, int lmax, const int *state, bool prefetch_b) {
 	const int t = T.t, nlev = P.last - P.first + 1;
 	int nbv = 0;
@@ -1220,8 +1243,8 @@ __device__ inline bool co_static(const MgCo<real> &P, const CoThread &T, CoLevel
 		if (prefetch_b && P.first <= lmax) {
 			// (issued behind the A bytes, consumed by the first phase: the right-hand side the previous kernel has restricted)
 			const size_t base0 = (size_t)st[0].nb[6] * 512;
-			fb0 = MemAgent::ld(P.lv[P.first].b + base0 + T.c0);
-			fb1 = MemAgent::ld(P.lv[P.first].b + base0 + T.c1);
+			fb0 = MEM::ld(P.lv[P.first].b + base0 + T.c0);
+			fb1 = MEM::ld(P.lv[P.first].b + base0 + T.c1);
 		}
 #pragma unroll
 		for (int k = 0; k < MG_CO_MAX_LEVELS; ++k)
@@ -1244,7 +1267,7 @@ __device__ inline bool co_static(const MgCo<real> &P, const CoThread &T, CoLevel
 /// `b_prefetched`: the first level's right-hand side is already in st[0].b (k_mg_coarse); otherwise it is waited for like
 /// every other level's (its children sit on level P.first - 1, whose flags P.ready[P.first - 1] must be valid).
 /// `post_first_y`: raise the result flag of the first level too (somebody inside this launch consumes it).
-template <typename real, typename STAMP>
+template <typename real, typename MEM, typename STAMP>
 __device__ inline bool co_cycle(const MgCo<real> &P, const CoThread &T, CoLevel<real> *st, real *R, int *dep, unsigned tag, int lmax,
                                 bool b_prefetched, bool post_first_y, STAMP &&stamp) {
 	const int t = T.t, c0 = T.c0, c1 = T.c1, h0 = T.h0, h1 = T.h1;
@@ -1259,12 +1282,12 @@ __device__ inline bool co_cycle(const MgCo<real> &P, const CoThread &T, CoLevel<
 		if (waited) {  // the right-hand side is the restricted residual of the child tiles (level l - 1)
 			const GridDims &gf = P.lv[l - 1].g;
 			co_child_deps(T, dep, L.g, gf, tile, S.nb[7]);
-			if (!co_wait(P.ready[l - 1] + gf.nt, dep, 8, tag, P.abort)) return false;
+			if (!co_wait<MEM>(P.ready[l - 1] + gf.nt, dep, 8, tag, P.abort)) return false;
 		}
 		real b0, b1;
 		if (waited) {
-			b0 = MemAgent::ld(L.b + base + c0);
-			b1 = MemAgent::ld(L.b + base + c1);
+			b0 = MEM::ld(L.b + base + c0);
+			b1 = MEM::ld(L.b + base + c1);
 			S.b[c0] = b0;
 			S.b[c1] = b1;
 		} else {  // fetched with the static data
@@ -1276,20 +1299,20 @@ __device__ inline bool co_cycle(const MgCo<real> &P, const CoThread &T, CoLevel<
 			co_half_sweep<real>(T, S.H, a0, a1, b0, b1, 0);
 			co_half_sweep<real>(T, S.H, a0, a1, b0, b1, 1);
 		}
-		MemAgent::st(L.x + base + c0, S.H[h0]);
-		MemAgent::st(L.x + base + c1, S.H[h1]);
-		if (!(P.fault && l == P.first && T.wg == P.fault - 1)) co_post(P.ready[l], tile, tag);  // (fault injection: see MgCo::fault)
+		MEM::st(L.x + base + c0, S.H[h0]);
+		MEM::st(L.x + base + c1, S.H[h1]);
+		if (!(P.fault && l == P.first && T.wg == P.fault - 1)) co_post<MEM>(P.ready[l], tile, tag);  // (fault injection: see MgCo::fault)
 		stamp();
 		// residual: the ring holds the neighbours' pre-smoothed values
 		if (t < 6) dep[t] = S.nb[t];
 		__syncthreads();
-		if (!co_wait(P.ready[l], dep, 6, tag, P.abort)) return false;
-		co_load_ring<real>(T, S.H, S.nb, L.x);
+		if (!co_wait<MEM>(P.ready[l], dep, 6, tag, P.abort)) return false;
+		co_load_ring<real, MEM>(T, S.H, S.nb, L.x);
 		R[c0] = co_residual_cell<real>(S.H, a0, b0, h0);
 		R[c1] = co_residual_cell<real>(S.H, a1, b1, h1);
 		__syncthreads();
-		co_restrict_store<real>(T, R, L.g, P.lv[l + 1].g, tile, P.lv[l + 1].b);
-		co_post(P.ready[l] + nt, tile, tag);
+		co_restrict_store<real, MEM>(T, R, L.g, P.lv[l + 1].g, tile, P.lv[l + 1].b);
+		co_post<MEM>(P.ready[l] + nt, tile, tag);
 		stamp();
 	}
 	// ---- coarsest level (one tile, workgroup 0): nsw sweeps red->black, nsw black->red from zero
@@ -1304,12 +1327,12 @@ __device__ inline bool co_cycle(const MgCo<real> &P, const CoThread &T, CoLevel<
 		if (waited) {
 			const GridDims &gf = P.lv[l - 1].g;
 			co_child_deps(T, dep, L.g, gf, tile, S.nb[7]);
-			if (!co_wait(P.ready[l - 1] + gf.nt, dep, 8, tag, P.abort)) return false;
+			if (!co_wait<MEM>(P.ready[l - 1] + gf.nt, dep, 8, tag, P.abort)) return false;
 		}
 		real b0, b1;
 		if (waited) {
-			b0 = MemAgent::ld(L.b + base + c0);
-			b1 = MemAgent::ld(L.b + base + c1);
+			b0 = MEM::ld(L.b + base + c0);
+			b1 = MEM::ld(L.b + base + c1);
 		} else {
 			b0 = S.b[c0];
 			b1 = S.b[c1];
@@ -1319,9 +1342,9 @@ __device__ inline bool co_cycle(const MgCo<real> &P, const CoThread &T, CoLevel<
 			co_half_sweep<real>(T, S.H, a0, a1, b0, b1, fc);
 			co_half_sweep<real>(T, S.H, a0, a1, b0, b1, fc ^ 1);
 		}
-		MemAgent::st(L.y + base + c0, S.H[h0]);
-		MemAgent::st(L.y + base + c1, S.H[h1]);
-		if (l > P.first || post_first_y) co_post(P.ready[l] + 2 * L.g.nt, tile, tag);
+		MEM::st(L.y + base + c0, S.H[h0]);
+		MEM::st(L.y + base + c1, S.H[h1]);
+		if (l > P.first || post_first_y) co_post<MEM>(P.ready[l] + 2 * L.g.nt, tile, tag);
 		stamp();
 	}
 	// ---- up
@@ -1335,25 +1358,29 @@ __device__ inline bool co_cycle(const MgCo<real> &P, const CoThread &T, CoLevel<
 		const real b0 = S.b[c0], b1 = S.b[c1];
 		// the corrections come from the parent tile and from the parents of the active neighbour tiles
 		co_parent_deps(T, dep, L.g, gc, S.nb);
-		if (!co_wait(P.ready[l + 1] + 2 * gc.nt, dep, 7, tag, P.abort)) return false;
-		co_add_correction<real>(T, S.H, a0, a1, S.rab, S.nb, L.g, gc, tile, P.lv[l + 1].y);
+		if (!co_wait<MEM>(P.ready[l + 1] + 2 * gc.nt, dep, 7, tag, P.abort)) return false;
+		co_add_correction<real, MEM>(T, S.H, a0, a1, S.rab, S.nb, L.g, gc, tile, P.lv[l + 1].y);
 		for (int it = 0; it < P.inner; ++it) {
 			co_half_sweep<real>(T, S.H, a0, a1, b0, b1, 1);
 			co_half_sweep<real>(T, S.H, a0, a1, b0, b1, 0);
 		}
-		MemAgent::st(L.y + base + c0, S.H[h0]);
-		MemAgent::st(L.y + base + c1, S.H[h1]);
-		if (l > P.first || post_first_y) co_post(P.ready[l] + 2 * L.g.nt, tile, tag);
+		MEM::st(L.y + base + c0, S.H[h0]);
+		MEM::st(L.y + base + c1, S.H[h1]);
+		if (l > P.first || post_first_y) co_post<MEM>(P.ready[l] + 2 * L.g.nt, tile, tag);
 		stamp();
 	}
 	return true;
 }
 
-template <typename real>
+/// XCD: launched with 8 W workgroups of which every eighth works (blockIdx % 8 == 0: one XCD under the dispatcher's round robin,
+/// checked through the flags), MEM = MemWg.
+template <typename real, typename MEM, bool XCD>
 __global__ void __launch_bounds__(256) k_mg_coarse(MgCo<real> P, const int *state) {
 	extern __shared__ unsigned char co_smem[];
 	__shared__ int dep[8];
-	const CoThread T;
+	if (XCD && (blockIdx.x & 7)) return;
+	const CoThread T(XCD ? (int)(blockIdx.x >> 3) : (int)blockIdx.x);
+	const int n_wg = XCD ? (int)(gridDim.x >> 3) : (int)gridDim.x;
 	const int nlev = P.last - P.first + 1;
 	CoLevel<real> *st = (CoLevel<real> *)co_smem;
 	real *R = (real *)(st + nlev);
@@ -1367,7 +1394,7 @@ __global__ void __launch_bounds__(256) k_mg_coarse(MgCo<real> P, const int *stat
 	for (int l = P.first; l <= P.last; ++l)
 		if (T.wg < P.lv[l].n_tiles) lmax = l;
 	const bool with_top = P.top >= 0;
-	if (!co_static<real>(P, T, st, lmax, state, !with_top)) return;
+	if (!co_static<real, MEM>(P, T, st, lmax, state, !with_top)) return;
 	stamp();
 	// The level above (round 4): more tiles than workgroups can be resident, so a workgroup takes the slots wg, wg + W, ... of it
 	// (C4: level 1, ~2 400 tiles on 768 workgroups) with the launch-per-phase arithmetic (cp_*_tile, state through the level
@@ -1378,29 +1405,29 @@ __global__ void __launch_bounds__(256) k_mg_coarse(MgCo<real> P, const int *stat
 	if (with_top) {
 		const MgLv<real> &L = P.lv[P.top];
 		const int nt = L.g.nt;
-		for (int slot = T.wg; slot < L.n_tiles; slot += (int)gridDim.x) {
-			cp_presmooth_tile<real, MemAgent>(*Stop, L, slot, P.inner);
-			co_post(P.ready[P.top], L.tiles[slot], P.tag);
+		for (int slot = T.wg; slot < L.n_tiles; slot += n_wg) {
+			cp_presmooth_tile<real, MEM>(*Stop, L, slot, P.inner);
+			co_post<MEM>(P.ready[P.top], L.tiles[slot], P.tag);
 		}
-		for (int slot = T.wg; slot < L.n_tiles; slot += (int)gridDim.x) {
+		for (int slot = T.wg; slot < L.n_tiles; slot += n_wg) {
 			if (T.t < 6) dep[T.t] = L.nbr[(size_t)slot * MG_NBR_STRIDE + T.t];
 			__syncthreads();
-			if (!co_wait(P.ready[P.top], dep, 6, P.tag, P.abort)) return;
-			cp_residual_restrict_tile<real, MemAgent>(*Stop, Rtop, L, P.lv[P.first].g, P.lv[P.first].b, slot);
-			co_post(P.ready[P.top] + nt, L.tiles[slot], P.tag);
+			if (!co_wait<MEM>(P.ready[P.top], dep, 6, P.tag, P.abort)) return;
+			cp_residual_restrict_tile<real, MEM>(*Stop, Rtop, L, P.lv[P.first].g, P.lv[P.first].b, slot);
+			co_post<MEM>(P.ready[P.top] + nt, L.tiles[slot], P.tag);
 		}
 		stamp();
 	}
-	if (!co_cycle<real>(P, T, st, R, dep, P.tag, lmax, !with_top, with_top, stamp)) return;
+	if (!co_cycle<real, MEM>(P, T, st, R, dep, P.tag, lmax, !with_top, with_top, stamp)) return;
 	if (with_top) {
 		const MgLv<real> &L = P.lv[P.top];
 		const GridDims &gc = P.lv[P.first].g;
-		for (int slot = T.wg; slot < L.n_tiles; slot += (int)gridDim.x) {
+		for (int slot = T.wg; slot < L.n_tiles; slot += n_wg) {
 			// the corrections come from the parent tile and from the parents of the active neighbour tiles
 			__syncthreads();
 			co_parent_deps(T, dep, L.g, gc, L.nbr + (size_t)slot * MG_NBR_STRIDE);
-			if (!co_wait(P.ready[P.first] + 2 * gc.nt, dep, 7, P.tag, P.abort)) return;
-			cp_prolong_postsmooth_tile<real, MemAgent>(*Stop, L, gc, P.lv[P.first].y, slot, P.inner);
+			if (!co_wait<MEM>(P.ready[P.first] + 2 * gc.nt, dep, 7, P.tag, P.abort)) return;
+			cp_prolong_postsmooth_tile<real, MEM>(*Stop, L, gc, P.lv[P.first].y, slot, P.inner);
 		}
 		stamp();
 	}
@@ -1516,7 +1543,7 @@ __global__ void __launch_bounds__(256) k_pcg_small(PcgSmall<real> Q) {
 	for (int l = P.first; l <= P.last; ++l)
 		if (wg < P.lv[l].n_tiles) lmax = l;
 	if (t < 8) nb0[t] = L0.nbr[(size_t)wg * MG_NBR_STRIDE + t];
-	co_static<real>(P, T, st, lmax, nullptr, false);  // (ends with a barrier: nb0 is visible)
+	co_static<real, MemAgent>(P, T, st, lmax, nullptr, false);  // (ends with a barrier: nb0 is visible)
 	const int tile0 = nb0[6];
 	const size_t base0 = (size_t)tile0 * 512;
 	const uint32_t a0 = L0.abits[base0 + c0], a1 = L0.abits[base0 + c1];
@@ -1544,11 +1571,11 @@ __global__ void __launch_bounds__(256) k_pcg_small(PcgSmall<real> Q) {
 			H0[h1] = s1;
 			MemAgent::st(Q.s + base0 + c0, s0);
 			MemAgent::st(Q.s + base0 + c1, s1);
-			co_post(Q.sflag, tile0, tag);
+			co_post<MemAgent>(Q.sflag, tile0, tag);
 			if (t < 6) dep[t] = nb0[t];
 			__syncthreads();
-			if (!co_wait(Q.sflag, dep, 6, tag, P.abort)) return;  // (p and r stay what they were: the host repeats the solve)
-			co_load_ring<real>(T, H0, nb0, Q.s);
+			if (!co_wait<MemAgent>(Q.sflag, dep, 6, tag, P.abort)) return;  // (p and r stay what they were: the host repeats the solve)
+			co_load_ring<real, MemAgent>(T, H0, nb0, Q.s);
 			double acc = 0.0;
 #pragma unroll
 			for (int k = 0; k < 2; ++k) {
@@ -1611,20 +1638,20 @@ __global__ void __launch_bounds__(256) k_pcg_small(PcgSmall<real> Q) {
 			}
 			MemAgent::st(Q.x0 + base0 + c0, H0[h0]);
 			MemAgent::st(Q.x0 + base0 + c1, H0[h1]);
-			co_post(P.ready[0], tile0, tag);
+			co_post<MemAgent>(P.ready[0], tile0, tag);
 			if (t < 6) dep[t] = nb0[t];
 			__syncthreads();
-			if (!co_wait(P.ready[0], dep, 6, tag, P.abort)) return;
-			co_load_ring<real>(T, H0, nb0, Q.x0);
+			if (!co_wait<MemAgent>(P.ready[0], dep, 6, tag, P.abort)) return;
+			co_load_ring<real, MemAgent>(T, H0, nb0, Q.x0);
 			R[c0] = co_residual_cell<real>(H0, a0, b0, h0);
 			R[c1] = co_residual_cell<real>(H0, a1, b1, h1);
 			__syncthreads();
-			co_restrict_store<real>(T, R, L0.g, g1, tile0, P.lv[1].b);
-			co_post(P.ready[0] + nt0, tile0, tag);
-			if (!co_cycle<real>(P, T, st, R, dep, tag, lmax, false, true, nostamp)) return;
+			co_restrict_store<real, MemAgent>(T, R, L0.g, g1, tile0, P.lv[1].b);
+			co_post<MemAgent>(P.ready[0] + nt0, tile0, tag);
+			if (!co_cycle<real, MemAgent>(P, T, st, R, dep, tag, lmax, false, true, nostamp)) return;
 			co_parent_deps(T, dep, L0.g, g1, nb0);
-			if (!co_wait(P.ready[1] + 2 * g1.nt, dep, 7, tag, P.abort)) return;
-			co_add_correction<real>(T, H0, a0, a1, rab0, nb0, L0.g, g1, tile0, P.lv[1].y);
+			if (!co_wait<MemAgent>(P.ready[1] + 2 * g1.nt, dep, 7, tag, P.abort)) return;
+			co_add_correction<real, MemAgent>(T, H0, a0, a1, rab0, nb0, L0.g, g1, tile0, P.lv[1].y);
 			for (int k = 0; k < P.inner; ++k) {
 				co_half_sweep<real>(T, H0, a0, a1, b0, b1, 1);
 				co_half_sweep<real>(T, H0, a0, a1, b0, b1, 0);
@@ -2297,6 +2324,7 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 	if (s->knobs.mg_co_max_tiles >= 0) co_max = s->knobs.mg_co_max_tiles;
 	const bool persist = !s->knobs.mg_no_persist && !s->co_disabled;
 	int top = -1, top_w = 0;  // level that runs inside k_mg_coarse with several tile slots per workgroup, and that launch's width
+	size_t xcd_cap = 0;       // workgroups of k_mg_coarse that one XCD holds at once (with a margin)
 	if (persist) {
 		// every workgroup of k_mg_coarse must be resident at the same time (they wait for each other): one workgroup per tile of
 		// its first level, LDS per workgroup grows with the number of levels inside
@@ -2321,7 +2349,8 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 				for (int &v : d.per_cu_top) v = -1;
 			}
 			if (!d.attr_set) {
-				LFA_HIP(s, hipFuncSetAttribute((const void *)k_mg_coarse<real>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+				LFA_HIP(s, hipFuncSetAttribute((const void *)k_mg_coarse<real, MemAgent, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+				LFA_HIP(s, hipFuncSetAttribute((const void *)k_mg_coarse<real, MemWg, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
 				d.attr_set = true;
 			}
 			di = d;
@@ -2333,7 +2362,7 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 			const size_t lds = (size_t)nlev * sizeof(CoLevel<real>) + 512 * sizeof(real) + 64;
 			int per_cu = di.per_cu[nlev];  // by registers and LDS together
 			if (per_cu < 0) {
-				if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_mg_coarse<real>, 256, lds) != hipSuccess) {
+				if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_mg_coarse<real, MemAgent, false>, 256, lds) != hipSuccess) {
 					(void)hipGetLastError();
 					per_cu = 0;
 				}
@@ -2348,6 +2377,12 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		tail = last;
 		while (tail > 1 && tail - 1 >= D && fits(tail - 1)) --tail;
 		tail = std::max(tail, std::max(D, 1));
+		(void)fits(tail);  // (makes sure the occupancy of this many levels has been asked)
+		{
+			const int pc = last - tail + 1 <= MG_CO_MAX_LEVELS ? di.per_cu[last - tail + 1] : 0;
+			const size_t all = pc > 0 ? (size_t)pc * (size_t)n_cu : 0;
+			xcd_cap = (all - all / 8) / 8;
+		}
 		// the level above the first one inside (never the finest, never a distributed one) joins the launch with several tile slots
 		// per workgroup when the launch can hold at least a third of its tiles. OPT-IN (LFA_MG_TOP=1): measured at C3 it saves
 		// three launches per iteration and no time (0.138 -> 0.140 ms), and the wider launch costs the overlapped step 0.24 ms
@@ -2356,7 +2391,7 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 			const size_t lds = (size_t)nlev * sizeof(CoLevel<real>) + 512 * sizeof(real) + sizeof(CpTile<real>) + 512 * sizeof(real) + 64;
 			int per_cu = di.per_cu_top[nlev];
 			if (per_cu < 0) {
-				if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_mg_coarse<real>, 256, lds) != hipSuccess) {
+				if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_mg_coarse<real, MemAgent, false>, 256, lds) != hipSuccess) {
 					(void)hipGetLastError();
 					per_cu = 0;
 				}
@@ -2423,8 +2458,12 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		if (s->knobs.mg_tail_inner > 0) C.inner = s->knobs.mg_tail_inner;
 		if (s->knobs.mg_nsw > 0) C.nsw = s->knobs.mg_nsw;
 		for (int l = tail; l <= last; ++l) C.ready[l] = M.lv[l].ready;
-		C.tag = ++M.co_tag;
-		if (C.tag == 0) C.tag = ++M.co_tag;  // (0 is what the flags are initialised to)
+		if (M.co_tag >= 0x0FFFFFF0u) {  // (a flag holds tag << 4 | XCC id: after 2^28 launches the flags start over)
+			for (int l = 1; l <= last; ++l)
+				if (M.lv[l].ready) LFA_HIP(s, hipMemsetAsync(M.lv[l].ready, 0, (size_t)3 * M.lv[l].g.nt * sizeof(unsigned), s->stream));
+			M.co_tag = 0;
+		}
+		C.tag = ++M.co_tag;  // (0 is what the flags are initialised to)
 		C.stamps = nullptr;
 		C.abort = s->pcg_state + 2;
 		C.fault = s->knobs.mg_co_fault;
@@ -2440,8 +2479,16 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		const int W = top >= 0 ? top_w : std::max(1, M.lv[tail].n_tiles);
 		const size_t lds = (size_t)(last - tail + 1) * sizeof(CoLevel<real>) + 512 * sizeof(real) +
 		                   (top >= 0 ? sizeof(CpTile<real>) + 512 * sizeof(real) : 0);
+		// One XCD (round 4, OPT-IN: LFA_MG_XCD=1 - see lfa_knobs::mg_xcd for what was measured): when the launch fits an eighth of the chip its workgroups are placed on ONE XCD - every eighth of
+		// 8 W workgroups works, the dispatcher deals consecutive workgroups round robin over the XCDs - and exchange through that
+		// XCD's L2 with workgroup-scope accesses: a hand-off takes 1.1 instead of 2.2 us (profiles/r03_xcd_barrier_probe.txt), and a
+		// V-cycle's coarse levels are a chain of ~13 of them. Nothing documents the round robin: every ready flag carries its
+		// producer's XCC id, a consumer that meets another id gives the launch up, and the solve is repeated without this mode.
+		const bool xcd = s->knobs.mg_xcd && !s->co_xcd_disabled && top < 0 && !s->dist && (size_t)W <= xcd_cap;
+		s->co_last_xcd = xcd;
 		CoGateScope gate(s);
-		hipLaunchKernelGGL(k_mg_coarse<real>, dim3(W), dim3(256), lds, s->stream, C, st);  // (dynamic LDS limit: set where `fits` is)
+		if (xcd) hipLaunchKernelGGL((k_mg_coarse<real, MemWg, true>), dim3(8 * W), dim3(256), lds, s->stream, C, st);
+		else hipLaunchKernelGGL((k_mg_coarse<real, MemAgent, false>), dim3(W), dim3(256), lds, s->stream, C, st);  // (dynamic LDS limit: set where `fits` is)
 		if (gate.done() != LFA_OK) return lfa_fail(s, LFA_E_HIP, "chaining k_mg_coarse behind the device's previous one failed");
 		LFA_LAUNCH_CHECK(s);
 		++launches;
@@ -2547,7 +2594,7 @@ template <typename real> static int pcg_small_t(lfa_sim *s, bool *ran) {
 	Q.C.top = -1;
 	const int maxit = (int)s->prm.max_iterations;
 	// tags tag .. tag + maxit belong to this launch (one per V-cycle); 0 is what the flags are initialised to
-	if (M.co_tag > 0xFFFFFFFFu - (unsigned)(maxit + 4)) {
+	if (M.co_tag > 0x0FFFFFFFu - (unsigned)(maxit + 4)) {  // (a flag holds tag << 4 | XCC id)
 		for (int l = 0; l <= last; ++l)
 			LFA_HIP(s, hipMemsetAsync(M.lv[l].ready, 0, (size_t)(l == 0 ? 4 : 3) * M.lv[l].g.nt * sizeof(unsigned), s->stream));
 		LFA_HIP(s, hipMemsetAsync(M.ps_part, 0, (size_t)3 * PS_MAX_TILES * sizeof(double) + (size_t)2 * PS_MAX_TILES * sizeof(unsigned), s->stream));

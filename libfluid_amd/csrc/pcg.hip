@@ -1781,7 +1781,7 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 	int *hstate = (int *)s->h_pinned;
 	int aborted = 0;  // a kernel whose workgroups wait for each other gave a wait up (mg.hip: co_wait)
 	if (small_ran) {
-		LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 72, hipMemcpyDeviceToHost, s->stream));
+		LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 80, hipMemcpyDeviceToHost, s->stream));
 		LFA_HIP(s, hipStreamSynchronize(s->stream));
 		done = hstate[0];
 		nan = hstate[1];
@@ -1885,7 +1885,7 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 		                   dist ? (const double *)lfa_dist_gather_buf(s, i & 1) : P + PART_RMAX, dist ? s->dist->nranks : GB,
 		                   s->prm.tolerance, i - 1, s->pcg_state, s->pcg_hist);
 		LFA_LAUNCH_CHECK(s);
-		LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 72, hipMemcpyDeviceToHost, s->stream));
+		LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 80, hipMemcpyDeviceToHost, s->stream));
 		LFA_HIP(s, hipStreamSynchronize(s->stream));
 		done = hstate[0];
 		nan = hstate[1];
@@ -1916,7 +1916,7 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 			                   s->pcg_state, s->abits, cx, (const int *)s->slot_l1, (const real *)s->c_x2, (const int *)s->l1_l2);
 			LFA_LAUNCH_CHECK(s);
 		}
-		LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 72, hipMemcpyDeviceToHost, s->stream));
+		LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 80, hipMemcpyDeviceToHost, s->stream));
 		LFA_HIP(s, hipStreamSynchronize(s->stream));
 		done = hstate[0];
 		nan = hstate[1];
@@ -1926,7 +1926,12 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 		// a fault). Whatever the iterations after it computed is void. This handle stops using the kernels that wait and the solve
 		// is repeated from the right-hand side on the launch-per-phase path - once: that path waits for nothing.
 		if (s->co_disabled) return lfa_fail(s, LFA_E_HIP, "a device-side wait of the pressure solve was given up twice");
-		s->co_disabled = true;
+		// (first the cheaper retreat: the one-XCD mode of k_mg_coarse rests on an undocumented placement - without it the kernel
+		// makes no assumption about where its workgroups run)
+		s->stat_co_reason = (uint64_t)(unsigned)hstate[18];  // (0x100: a wait ran out, 0x200: a flag from another XCD; | waiter's XCC id | flag's << 4)
+		if (s->co_last_xcd && !s->co_xcd_disabled) s->co_xcd_disabled = true;
+		else s->co_disabled = true;
+		s->co_last_xcd = false;
 		++s->stat_co_aborts;
 		s->system_valid = false;
 		s->warm_started = false;
