@@ -455,9 +455,8 @@ def main():
         out["in_step_kernels"] = kern
         # `traffic`: HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs of this same command,
         # tools/make_profiles.sh). It is NOT measured in this run: `traffic_source` names the committed file it is read from.
-        pmc = os.path.join(ROOT, "profiles", "r03_c4_pmc_traffic.json")
-        if not os.path.exists(pmc):
-            pmc = os.path.join(ROOT, "profiles", "r02_c4_pmc_traffic.json")
+        pmc = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_c4_pmc_traffic.json") for r in (4, 3, 2)) if os.path.exists(q)),
+                   os.path.join(ROOT, "profiles", "r04_c4_pmc_traffic.json"))
         pmc_names = {"p2g_scatter_kernel": "p2g_scatter", "correct_tiled_kernel": "correct_tiled", "g2p": "g2p",
                      "advect_collide": "advect_collide"}
         per_launch = {}

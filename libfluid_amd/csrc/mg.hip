@@ -1059,16 +1059,17 @@ __device__ inline unsigned co_xcc_id() {
 	return x & 15u;
 }
 /// All threads: waits until every tile in dep[0 .. n) (n <= 8; -1 entries are skipped) carries this launch's tag in `flag`.
-/// Returns false (uniformly) when the wait was given up: the caller leaves the kernel. MEM = MemWg (every workgroup of the launch
-/// is meant to sit on one XCD): a flag raised from another XCD ends the launch like a wait that has run out - the data behind it
-/// may sit in the other XCD's L2.
+/// A wait that is given up (the ceiling; MEM = MemWg: a flag raised from another XCD - the data behind it may sit in that XCD's L2)
+/// raises the abort word and RETURNS like any other: the workgroup runs on with void data, every later wait of the launch leaves
+/// at its first slow poll, the kernel ends within a millisecond and the host, which finds the word at its next poll, discards the
+/// solve. (A uniform early exit would need a workgroup-wide OR per wait: two barriers and an LDS round trip in a kernel whose
+/// phases are 2 us - measured: 47 -> 53 us per launch at C4.) Always returns true.
 template <typename MEM>
 __device__ inline bool co_wait(const unsigned *flag, const int *dep, int n, unsigned tag, int *abort_word) {
-	int bad = 0;
 	if ((int)threadIdx.x < n) {
 		const int d = dep[threadIdx.x];
 		if (d >= 0) {
-			int tries = 0;
+			int tries = 0, bad = 0;
 			unsigned long long t0 = 0ull;
 			unsigned f;
 			while (((f = MEM::ld(flag + d)) >> 4) != tag) {
@@ -1078,7 +1079,7 @@ __device__ inline bool co_wait(const unsigned *flag, const int *dep, int n, unsi
 					break;
 				}
 			}
-			if (!bad && !__is_same(MEM, MemAgent) && (f & 15u) != co_xcc_id()) bad = 2;
+			if (!__is_same(MEM, MemAgent) && !bad && (f & 15u) != co_xcc_id()) bad = 2;
 			if (bad) {
 				// (why, for the record: abort_word[16] = 0x100 a wait ran out | 0x200 a flag from another XCD, with the two XCC ids)
 				if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
@@ -1087,13 +1088,14 @@ __device__ inline bool co_wait(const unsigned *flag, const int *dep, int n, unsi
 			}
 		}
 	}
-	return __syncthreads_or(bad) == 0;
+	__syncthreads();
+	return true;
 }
 /// All threads: this workgroup's stores so far have been acknowledged; then the tile's flag is raised.
 template <typename MEM> __device__ inline void co_post(unsigned *flag, int tile, unsigned tag) {
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();
-	if (threadIdx.x == 0) MEM::st(flag + tile, (tag << 4) | co_xcc_id());
+	if (threadIdx.x == 0) MEM::st(flag + tile, (tag << 4) | (__is_same(MEM, MemAgent) ? 0u : co_xcc_id()));
 }
 
 /// Per-thread constants of the dataflow kernels: the two cells of a thread are column (qx, qy), z = 2 j and 2 j + 1.
@@ -1469,7 +1471,6 @@ template <bool MAXTOO>
 __device__ inline bool co_reduce(const double *sum_part, const double *max_part, const unsigned *flag, int W, unsigned tag, double *lds,
                                  double &sum, double &mx, int *abort_word) {
 	const int t = threadIdx.x;
-	int bad = 0;
 	if (t < 64) {
 		unsigned long long t0 = 0ull;
 		// ONE wave polls (a lane's four flags read together, one round trip per attempt, with back-off): every thread of every
@@ -1487,14 +1488,14 @@ __device__ inline bool co_reduce(const double *sum_part, const double *max_part,
 			for (int k = 0; k < PS_MAX_TILES / 64; ++k) all &= f[k] == tag;
 			if (all) break;
 			co_backoff(tries);
-			if (co_poll_expired(tries, t0, abort_word)) {
+			if (co_poll_expired(tries, t0, abort_word)) {  // (given up: the sums below are void, the host discards the solve - see co_wait)
+				if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) abort_word[16] = 0x100;
 				__hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				bad = 1;
 				break;
 			}
 		}
 	}
-	if (__syncthreads_or(bad)) return false;
+	__syncthreads();
 	double a = 0.0, m = -INFINITY;
 	bool nan = false;
 	for (int i = t; i < W; i += 256) {
@@ -1527,7 +1528,7 @@ __device__ inline bool co_reduce(const double *sum_part, const double *max_part,
 template <typename real>
 __global__ void __launch_bounds__(256) k_pcg_small(PcgSmall<real> Q) {
 	extern __shared__ unsigned char co_smem[];
-	__shared__ int dep[8], nb0[8];
+	__shared__ int dep[8], nb0[8], s_abort;
 	__shared__ uint8_t rab0[384];
 	__shared__ double red[8];
 	const MgCo<real> &P = Q.C;
@@ -1560,6 +1561,11 @@ __global__ void __launch_bounds__(256) k_pcg_small(PcgSmall<real> Q) {
 	int it = -1, done = -1;
 	bool nan_seen = false;
 	for (; it < Q.maxit; ++it) {
+		// (a wait given up anywhere: every workgroup leaves at the top of its next iteration - uniformly, through LDS - instead of
+		// running maxit iterations of waits that each take their slow path)
+		if (t == 0) s_abort = __hip_atomic_load(P.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__syncthreads();
+		if (s_abort != 0) return;
 		const unsigned tag = P.tag + (unsigned)(it + 1);
 		double m = -INFINITY;
 		bool nan = false;

@@ -2,7 +2,7 @@
 # Runs on the GPU box (gpurun): the bench line, the kernel-trace summary (mean / median / p95 per kernel) of the same command and
 # the two HBM PMC passes; everything lands under gpurun_out/ (copy what is to be judged into profiles/).
 # usage: tools/make_profiles.sh TAG [bench args...]
-TAG=${1:-r03_c4}; shift
+TAG=${1:-r04_c4}; shift
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp; mkdir -p gpurun_out
 python3 bench.py "$@" > gpurun_out/${TAG}_bench.json 2> /tmp/bench.err || tail -5 /tmp/bench.err
 # Per-kernel tables are taken with the stages of a step back to back (--no-overlap): in the default step the position correction
