@@ -1418,29 +1418,36 @@ int lfa_hash_particles_impl(lfa_sim *s, bool counts_done) {
 		s->n_own_first = s->n_own_last = s->n_ghost_lo = s->n_ghost_hi = 0;
 		s->ptiles = s->ptiles_all;
 	} else {
-		LFA_TRY(compact_tiles(s, s->tile_flag, all_lo, all_hi, s->ptiles_all, s->tile_pslot, &s->n_ptiles_all));
-	}
-	s->np_live = s->h_pinned[8];
-	if (s->dist) s->np = s->np_live;  // particles migrate: the resident count is the live count
-	s->holes = false;
-	s->n_arrivals = 0;
-	s->move_pending = false;  // (a binning re-uses the buffer the positions of before a split move were kept in)
-	// counts per layer group = differences of the scan at the layer boundaries
-	if (!one_sync) {
+		// Slabs: the same without the host in between (round 3 read seven counts back one by one: the particle tiles, the layer
+		// marks, the processed tiles, four halo lists). Collectives (the flag exchanges) are stream operations; the halo lists
+		// have fixed regions of one tile layer each, so no count is needed to place them.
+		uint32_t *tot = (uint32_t *)s->pcg_state + 20;  // [0] particle tiles [1..4] scan at the layer marks [5] processed tiles [6..9] halo lists
+		LFA_TRY(compact_tiles_async(s, s->tile_flag, all_lo, all_hi, s->ptiles_all, s->tile_pslot, tot));
 		int marks[4] = {own_lo, own_lo + L < own_hi ? own_lo + L : own_hi, own_hi - L > own_lo ? own_hi - L : own_lo, own_hi};
-		int vals[4];
 		int *didx = s->pcg_state + 12;
-		for (int k = 0; k < 4; ++k) {
-			if (marks[k] >= all_hi) vals[k] = s->n_ptiles_all;  // the scan has no entry at the end of the range
-			else vals[k] = -1;
-		}
 		LFA_HIP(s, hipMemcpyAsync(didx, marks, 16, hipMemcpyHostToDevice, s->stream));
-		hipLaunchKernelGGL(k_gather_u32, dim3(1), dim3(64), 0, s->stream, s->tile_scan, didx, 4, (uint32_t *)s->partials);
+		hipLaunchKernelGGL(k_gather_u32, dim3(1), dim3(64), 0, s->stream, s->tile_scan, didx, 4, tot + 1);  // (before the next scan reuses tile_scan)
 		LFA_LAUNCH_CHECK(s);
-		LFA_HIP(s, hipMemcpyAsync(s->h_pinned + 16, ((uint32_t *)s->partials), 16, hipMemcpyDeviceToHost, s->stream));
+		LFA_HIP(s, hipMemsetAsync(s->tile_flag, 0, (size_t)(nt + 1) * 4, s->stream));
+		hipLaunchKernelGGL(k_dilate_slots, dim3((nt + 255) / 256), dim3(256), 0, s->stream, (const int *)s->tile_pslot, s->tile_flag, g);
+		LFA_LAUNCH_CHECK(s);
+		if (own_lo > 0) LFA_HIP(s, hipMemsetAsync(s->tile_flag, 0, (size_t)own_lo * 4, s->stream));
+		if (own_hi < nt) LFA_HIP(s, hipMemsetAsync(s->tile_flag + own_hi, 0, (size_t)(nt - own_hi) * 4, s->stream));
+		LFA_TRY(lfa_dist_exchange_tile_layers_u32(s, s->tile_flag));
+		LFA_TRY(compact_tiles_async(s, s->tile_flag, own_lo, own_hi, s->dtiles, nullptr, tot + 5));
+		{
+			const int hlo[4] = {s->slab_lo * L, (s->slab_hi - 1) * L, (s->slab_lo - 1) * L, s->slab_hi * L};
+			const bool on[4] = {lfa_has_lo(s), lfa_has_hi(s), lfa_has_lo(s), lfa_has_hi(s)};
+			LFA_HIP(s, hipMemsetAsync(tot + 6, 0, 16, s->stream));
+			for (int w = 0; w < 4; ++w)
+				if (on[w]) LFA_TRY(compact_tiles_async(s, s->tile_flag, hlo[w], hlo[w] + L, s->halo_tiles + (size_t)w * L, nullptr, tot + 6 + w));
+		}
+		LFA_HIP(s, hipMemcpyAsync(s->h_pinned + 20, tot, 40, hipMemcpyDeviceToHost, s->stream));
 		LFA_HIP(s, hipStreamSynchronize(s->stream));
-		for (int k = 0; k < 4; ++k)
-			if (vals[k] < 0) vals[k] = (int)s->h_pinned[16 + k];
+		const uint32_t *h = s->h_pinned + 20;
+		s->n_ptiles_all = (int)h[0];
+		int vals[4];
+		for (int k = 0; k < 4; ++k) vals[k] = marks[k] >= all_hi ? s->n_ptiles_all : (int)h[1 + k];  // (the scan has no entry at the end of the range)
 		s->p_off = vals[0];
 		s->n_ptiles = vals[3] - vals[0];
 		s->n_own_first = vals[1] - vals[0];
@@ -1448,23 +1455,14 @@ int lfa_hash_particles_impl(lfa_sim *s, bool counts_done) {
 		s->n_ghost_lo = s->p_off;
 		s->n_ghost_hi = s->n_ptiles_all - vals[3];
 		s->ptiles = s->ptiles_all + s->p_off;
+		s->n_dtiles = (int)h[5];
+		for (int w = 0; w < 4; ++w) s->n_halo[w] = (int)h[6 + w];
 	}
-
-	// ---- processed (dilated) tiles: owned ones are the work list, the neighbours' adjacent layers arrive by message
-	if (!one_sync) {
-		LFA_HIP(s, hipMemsetAsync(s->tile_flag, 0, (size_t)(nt + 1) * 4, s->stream));
-		if (s->n_ptiles_all) {
-			hipLaunchKernelGGL(k_dilate, dim3((s->n_ptiles_all * 27 + 255) / 256), dim3(256), 0, s->stream, s->ptiles_all,
-			                   s->n_ptiles_all, s->tile_flag, g);
-			LFA_LAUNCH_CHECK(s);
-		}
-		if (own_lo > 0) LFA_HIP(s, hipMemsetAsync(s->tile_flag, 0, (size_t)own_lo * 4, s->stream));
-		if (own_hi < nt) LFA_HIP(s, hipMemsetAsync(s->tile_flag + own_hi, 0, (size_t)(nt - own_hi) * 4, s->stream));
-		LFA_TRY(lfa_dist_exchange_tile_layers_u32(s, s->tile_flag));
-		LFA_TRY(compact_tiles(s, s->tile_flag, own_lo, own_hi, s->dtiles, nullptr, &s->n_dtiles));
-		LFA_TRY(lfa_dist_build_halo_lists(s));
-	}
-
+	s->np_live = s->h_pinned[8];
+	if (s->dist) s->np = s->np_live;  // particles migrate: the resident count is the live count
+	s->holes = false;
+	s->n_arrivals = 0;
+	s->move_pending = false;  // (a binning re-uses the buffer the positions of before a split move were kept in)
 	if (n) {
 		// v and C (48 of the 68 bytes) stay behind and are read through vc_src by the P2G; the G2P writes the new ones in the
 		// new order (the slab migration, which packs whole records, completes the move first)
@@ -1541,16 +1539,15 @@ int lfa_hash_particles_impl(lfa_sim *s, bool counts_done) {
 	return LFA_OK;
 }
 
-/// Processed tiles of the four boundary layers: [own first | own last | ghost below | ghost above].
+/// Processed tiles of the four boundary layers: [own first | own last | ghost below | ghost above], each in its own region of
+/// one tile layer of halo_tiles (the binning builds them itself, with its other lists; this entry point re-builds them alone).
 int lfa_dist_build_halo_lists(lfa_sim *s) {
 	const int L = s->g.ntx * s->g.nty;
 	const int lo[4] = {s->slab_lo * L, (s->slab_hi - 1) * L, (s->slab_lo - 1) * L, s->slab_hi * L};
 	const bool on[4] = {lfa_has_lo(s), lfa_has_hi(s), lfa_has_lo(s), lfa_has_hi(s)};
-	int off = 0;
 	for (int w = 0; w < 4; ++w) {
 		s->n_halo[w] = 0;
-		if (on[w]) LFA_TRY(compact_tiles(s, s->tile_flag, lo[w], lo[w] + L, s->halo_tiles + off, nullptr, &s->n_halo[w]));
-		off += s->n_halo[w];
+		if (on[w]) LFA_TRY(compact_tiles(s, s->tile_flag, lo[w], lo[w] + L, s->halo_tiles + (size_t)w * L, nullptr, &s->n_halo[w]));
 	}
 	return LFA_OK;
 }

@@ -199,7 +199,8 @@ int lfa_dist_exchange_fields(lfa_sim *s, int nfields, void *const *fields, const
 		f.tile_words += f.words[i];
 	}
 	const size_t tb = (size_t)f.tile_words * 4;
-	int off[4] = {0, s->n_halo[0], s->n_halo[0] + s->n_halo[1], s->n_halo[0] + s->n_halo[1] + s->n_halo[2]};
+	const int Lh = s->g.ntx * s->g.nty;
+	const int off[4] = {0, Lh, 2 * Lh, 3 * Lh};  // (every list has a region of one tile layer: core.hip, the binning)
 	for (int w = 0; w < 4; ++w) LFA_TRY(lfa_dist_ensure_xbuf(s, w, (size_t)s->n_halo[w] * tb));
 	for (int w = 0; w < 2; ++w)
 		if (s->n_halo[w]) {
