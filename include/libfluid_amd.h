@@ -198,7 +198,8 @@ int lfa_step_hot(lfa_sim *s, double dt, double *residual, uint64_t *iterations);
  *                        per cell and every non-random field. New particles get the next ids (download order).
  * lfa_advect_collide applies the velocity coercion of _advect_particles (:227-238: velocity = the source's, C = 0 for every
  * particle inside a cell of an active coercing source) before it moves the particles; lfa_time_step runs the seeding
- * between its two binnings when a source is active. Not available with a slab decomposition. */
+ * between its two binnings when a source is active. Slab decompositions: every rank is handed the whole list (like the solid
+ * cells) and tops up the cells of its own tile layers; lfa_update_sources is a collective then (every rank calls it). */
 int lfa_clear_sources(lfa_sim *s);
 int lfa_add_source(lfa_sim *s, const int32_t *xyz, uint64_t k, const double velocity[3], uint64_t target_density_cubic_root,
                    int active, int coerce_velocity);
@@ -210,7 +211,8 @@ int lfa_correct_collide(lfa_sim *s, double dt);
  * (src/simulation.cpp:50-59) and _correct_positions -> callback -> _detect_collisions (:111-117). lfa_advect / lfa_correct move
  * the particles and keep the positions of before on the device; a download in between reports them as old_position;
  * lfa_collide runs _detect_collisions (:612-683) from there to the current positions. After an upload in between lfa_collide
- * starts from the uploaded positions (from = to: the skin push-out alone). Single domain only. */
+ * starts from the uploaded positions (from = to: the skin push-out alone). Slab decompositions: the particles change rank in
+ * lfa_collide, once they have their final positions (a collective: every rank calls it). */
 int lfa_advect(lfa_sim *s, double dt);
 int lfa_correct(lfa_sim *s, double dt);
 int lfa_collide(lfa_sim *s);

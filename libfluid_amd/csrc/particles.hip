@@ -1097,8 +1097,7 @@ static int advect_collide(lfa_sim *s, double dt, bool with_count, bool split = f
 	const size_t n = s->binned ? s->np_live : s->np;
 	MoveParams mp = move_params(s, dt);
 	s->move_pending = false;
-	if (split) {
-		if (s->dist) return lfa_fail(s, LFA_E_UNSUPPORTED, "lfa_advect: slab decompositions migrate inside lfa_advect_collide");
+	if (split) {  // (slabs: the particles migrate once they have their final positions, in lfa_collide)
 		LFA_TRY(save_old_positions(s, n));
 		mp.collide = 0;
 	}
@@ -1131,7 +1130,7 @@ static int advect_collide(lfa_sim *s, double dt, bool with_count, bool split = f
 		}
 		LFA_LAUNCH_CHECK(s);
 	}
-	LFA_TRY(lfa_dist_migrate(s));
+	if (!split) LFA_TRY(lfa_dist_migrate(s));
 	s->unknown_count_valid = false;
 	s->move_pending = split;
 	return LFA_OK;
@@ -1182,14 +1181,13 @@ static int save_old_positions(lfa_sim *s, size_t n) {
 
 extern "C" int lfa_collide(lfa_sim *s) {
 	if (!s) return LFA_E_INVALID;
-	if (s->dist) return lfa_fail(s, LFA_E_UNSUPPORTED, "lfa_collide: slab decompositions collide inside lfa_advect_collide / lfa_correct_collide");
 	LFA_HIP(s, hipSetDevice(s->device));
 	LFA_TRY(lfa_corr_commit(s));
 	const size_t n = s->binned ? s->np_live : s->np;
 	const bool pending = s->move_pending;
 	s->move_pending = false;
 	s->cell_sorted = false;
-	if (!n) return LFA_OK;
+	if (!n) return lfa_dist_migrate(s);  // (slabs: every rank takes part in the hand-over, also one without particles)
 	LFA_TRY(refresh_tile_clear(s));
 	ParticleSoA &cur = s->pb[s->cur], &oth = s->pb[s->cur ^ 1];
 	// nothing pending (an upload in between has replaced the particles): from = to, i.e. the skin push-out alone
@@ -1199,7 +1197,8 @@ extern "C" int lfa_collide(lfa_sim *s) {
 	                   (const uint8_t *)s->solid, move_params(s, 0.0).skin);
 	LFA_LAUNCH_CHECK(s);
 	s->unknown_count_valid = false;
-	return LFA_OK;
+	// slabs: the move that lfa_advect / lfa_correct left pending is complete now - particles that crossed a slab face change rank
+	return lfa_dist_migrate(s);
 }
 
 /// The correction's scratch for the cell-ordered positions: four consecutive v / c arrays that are free between the binning and
@@ -1289,16 +1288,15 @@ extern "C" int lfa_correct_collide(lfa_sim *s, double dt) {
 extern "C" int lfa_correct(lfa_sim *s, double dt) {
 	if (!s) return LFA_E_INVALID;
 	if (!s->binned) return lfa_fail(s, LFA_E_INVALID, "lfa_correct: call lfa_hash_particles first");
-	if (s->dist) return lfa_fail(s, LFA_E_UNSUPPORTED, "lfa_correct: slab decompositions collide and migrate inside lfa_correct_collide");
 	LFA_HIP(s, hipSetDevice(s->device));
 	LFA_TRY(lfa_corr_commit(s));
 	s->move_pending = false;
-	if (!s->np_live) return LFA_OK;
-	LFA_TRY(correct_build_index(s));
+	if (!s->np_live && !s->dist) return LFA_OK;
+	LFA_TRY(correct_build_index(s));  // (slabs: with the ghost exchange - every rank takes part)
 	// the positions of before: the keys are copied by correct_apply itself (other buffer), the fractions here
 	ParticleSoA &cur = s->pb[s->cur], &oth = s->pb[s->cur ^ 1];
-	for (int d = 0; d < 3; ++d) LFA_HIP(s, hipMemcpyAsync(oth.t[d], cur.t[d], s->np_live * 4, hipMemcpyDeviceToDevice, s->stream));
-	LFA_TRY(correct_apply(s, dt, true, false));
+	for (int d = 0; d < 3 && s->np_live; ++d) LFA_HIP(s, hipMemcpyAsync(oth.t[d], cur.t[d], s->np_live * 4, hipMemcpyDeviceToDevice, s->stream));
+	LFA_TRY(correct_apply(s, dt, false, false));  // (no migration yet: lfa_collide hands the particles over)
 	s->move_pending = true;
 	return LFA_OK;
 }

@@ -245,6 +245,69 @@ def test_virtual_slabs_extrapolate_with_several_sweeps(sweeps):
     assert np.abs(c0["vel"] - c1["vel"]).max() > 1e-3
 
 
+def test_virtual_slabs_split_move_and_collide_stages():
+    """lfa_advect / lfa_correct / lfa_collide (the stages a host with post_advection_callback / post_correction_callback calls,
+    src/simulation.cpp:51-59,111-117) on slabs: the particles change rank in lfa_collide, when their positions are final. Against
+    the fused stages of the single domain: same particles (by id), same positions."""
+    size, block, bounds = (16, 16, 32), ((2, 0, 9), (14, 12, 23)), [0, 1, 2, 3, 4]
+    solid = util.scenes.sphere_solid_cells(size, (8.0, 3.0, 16.0), 2.6)
+    solid = solid[(solid[:, 1] >= block[1][1])]
+
+    def run(bounds_, split):
+        n = 1 if bounds_ is None else len(bounds_) - 1
+        hub = lfa.LocalHub(n) if bounds_ is not None else None
+        sims = []
+        for r in range(n):
+            s = lfa.Sim(size, method=lfa.APIC, precond=lfa.PRECOND_MULTIGRID, pcg_dtype=lfa.PCG_F64)
+            if len(solid):
+                s.set_solid_cells(solid)
+            if hub is not None:
+                s.init_local_slab(hub.h, r, bounds_)
+            s.seed_block(*block)
+            sims.append(s)
+        errors = []
+
+        def worker(r):
+            try:
+                s = sims[r]
+                for _ in range(4):
+                    if split:
+                        s.advect(util.DT); s.collide()
+                    else:
+                        s.advect_collide(util.DT)
+                    res, it, rc = s.step_hot(util.DT)
+                    assert rc == 0
+                    if split:
+                        s.correct(util.DT); s.collide()
+                    else:
+                        s.correct_collide(util.DT)
+                    s.hash()
+            except Exception as e:  # noqa: BLE001
+                errors.append((r, repr(e)))
+        threads = [threading.Thread(target=worker, args=(r,)) for r in range(n)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=120)
+        assert not errors, errors
+        assert not any(t.is_alive() for t in threads), "slab threads hung"
+        parts = [s.download_particles() for s in sims]
+        ids = [s.particle_ids() if hub is not None else np.arange(s.num_particles) for s in sims]
+        for s in sims:
+            s.close()
+        if hub is not None:
+            hub.close()
+        parts, ids = np.concatenate(parts), np.concatenate(ids)
+        assert len(np.unique(ids)) == len(ids)
+        return parts[np.argsort(ids)]
+
+    want = run(None, False)
+    got = run(bounds, True)
+    assert len(got) == len(want)
+    assert np.abs(got["pos"] - want["pos"]).max() < 2e-3
+    util.assert_close(got["vel"], want["vel"], 1e-2, "velocities, split stages on slabs vs fused stages on one domain", atol=1e-3 * 981.0 * util.DT)
+
+
 def test_virtual_slabs_fluid_sources():
     """Fluid sources (simulation::sources, src/simulation.cpp:756-765,136-151) on slabs: every rank is handed the whole list and
     tops up the cells of its own tile layers; the new particles get ids that are unique over the job. Against the single
