@@ -7,6 +7,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "common.h"
 #include "pcg.h"
 #include "stream_set.h"
@@ -207,6 +209,7 @@ static hipError_t create_low_priority_stream(hipStream_t *st, int prio_knob) {
 	return hipStreamCreateWithPriority(st, hipStreamNonBlocking, least);
 }
 
+int lfa_pcg_grid_cap = 2048;  // (pcg.h: pcg_grid; PCG_MAX_GRID is the most the partial arrays hold)
 /// The process environment is read here and nowhere below an entry point (lfa_knobs, common.h).
 static void lfa_knobs_parse(lfa_knobs &k) {
 	auto flag = [](const char *name, int dflt) -> int {
@@ -251,6 +254,13 @@ static void lfa_knobs_parse(lfa_knobs &k) {
 	k.pcg_gb = num("LFA_PCG_GB", 0);
 	k.coarse_w1 = real_("LFA_COARSE_W1");
 	k.coarse_w2 = real_("LFA_COARSE_W2");
+	{
+		static std::once_flag once;
+		std::call_once(once, [&] {
+			const int cap = num("LFA_PCG_GRID_CAP", 2048);
+			lfa_pcg_grid_cap = cap < 64 ? 64 : (cap > 2048 ? 2048 : cap);
+		});
+	}
 }
 
 extern "C" int lfa_create(lfa_sim **out, uint64_t nx, uint64_t ny, uint64_t nz, int device) {

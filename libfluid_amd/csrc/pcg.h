@@ -10,10 +10,13 @@
 enum { PART_STRIDE = PCG_MAX_GRID + 64, PART_ZS = 0, PART_RMAX = PART_STRIDE, PART_SIG0 = 2 * PART_STRIDE,
        PART_SIG1 = 3 * PART_STRIDE, PART_B2 = 4 * PART_STRIDE, PART_TOTAL = 5 * PART_STRIDE };
 
+/// Workgroups of the wave-per-tile kernels of the solve (each wave walks tiles slot, slot + 4 G, ...). LFA_PCG_GRID_CAP (read once,
+/// process-wide: the partial-sum layout of every handle depends on it) lowers the cap for experiments.
+extern int lfa_pcg_grid_cap;  // core.hip
 static inline int pcg_grid(int n_ptiles) {
 	int g = (n_ptiles + PCG_WAVES - 1) / PCG_WAVES;
 	if (g < 1) g = 1;
-	return g < PCG_MAX_GRID ? g : PCG_MAX_GRID;
+	return g < lfa_pcg_grid_cap ? g : lfa_pcg_grid_cap;
 }
 
 int lfa_build_rhs(lfa_sim *s, double dt);
