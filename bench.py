@@ -347,7 +347,7 @@ def main():
         elapsed = float(t.item())
 
     counts = sim.counts()
-    corr_fallback = sim.correction_stats()
+    corr_fallback = sim.correction_stats_ex()
     npart, n_unknowns = counts["particles"], counts["unknowns"]
     npart_total = npart
     if dist is not None:
@@ -410,7 +410,7 @@ def main():
                     "`--precond multilevel` (same iteration counts as the reference's MIC(0)-PCG within a few per cent)",
         },
         "stage_ms_median": stage_med, "stage_ms_p95": stage_p95,
-        "correction_fallback_half_tiles": {"flagged": corr_fallback[0], "of": corr_fallback[1],
+        "correction_fallback_half_tiles": {"flagged": corr_fallback[0], "of": corr_fallback[1], "second_pass": corr_fallback[2],
                                            "note": "half tiles of the last step whose neighbourhood did not fit the LDS-tiled correction kernel"},
     }
     if overlapped and serial_ms is not None:
@@ -572,7 +572,7 @@ def main():
             t = torch.tensor([late_s], dtype=torch.float64, device=tdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             late_s = float(t.item())
-        lc, lf = sim.counts(), sim.correction_stats()
+        lc, lf = sim.counts(), sim.correction_stats_ex()
         late_names = [k for k in late_stage[0] if k not in ("pcg_iterations", "overlapped")]
         extras["late_phase"] = {
             "from_step": done_steps, "steps": args.late_steps, "ms_per_step": 1e3 * late_s / args.late_steps,
@@ -582,7 +582,7 @@ def main():
             "particle_tiles": lc["particle_tiles"], "processed_tiles": lc["processed_tiles"], "unknowns": lc["unknowns"],
             "particles_per_particle_tile": lc["particles"] / max(lc["particle_tiles"], 1),
             "particle_tiles_timed_region": counts["particle_tiles"], "processed_tiles_timed_region": counts["processed_tiles"],
-            "correction_fallback_half_tiles": {"flagged": lf[0], "of": lf[1]},
+            "correction_fallback_half_tiles": {"flagged": lf[0], "of": lf[1], "second_pass": lf[2]},
             "stage_ms_median": {k: med([s_[k] for s_ in late_stage]) for k in late_names},
         }
     if args.mesh and (world == 1 or slabs):

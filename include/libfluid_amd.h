@@ -379,9 +379,11 @@ int lfa_get_counts(lfa_sim *s, uint64_t counts[5]);
 #define LFA_NUM_SOLVER_STATS 8
 int lfa_get_solver_stats(lfa_sim *s, uint64_t stats[LFA_NUM_SOLVER_STATS]);
 /* The last position correction: [0] half tiles handled by the LDS-tiled kernel's fallback (a thread per particle gathering from
- * global memory: crowded blocks of more than 5632 staged particles) [1] half tiles in all. Joins a correction in
- * flight. A large [0] / [1] means the scene is far denser than 8 particles per cell and the correction runs slowly. */
+ * global memory: crowded blocks of more than 12288 staged particles) [1] half tiles in all. Joins a correction in
+ * flight. A large [0] / [1] means the scene is far denser than 8 particles per cell and the correction runs slowly.
+ * _ex adds [2]: half tiles that took the tiled kernel's second pass (more than 5632 staged particles: one workgroup per CU). */
 int lfa_get_correction_stats(lfa_sim *s, uint64_t stats[2]);
+int lfa_get_correction_stats_ex(lfa_sim *s, uint64_t stats[3]);
 
 /* Times `reps` back-to-back launches of one hot-path kernel on the state left by the last lfa_step_hot, with HIP
  * events on the handle's stream; returns the mean launch duration in milliseconds. For bench.py's roofline object. */

@@ -150,6 +150,7 @@ SIGNATURES = {
     "lfa_get_step_timings": (_int, [_vp, C.POINTER(_dbl * NUM_STEP_TIMERS)]),
     "lfa_set_step_overlap": (_int, [_vp, _int]),
     "lfa_get_correction_stats": (_int, [_vp, C.POINTER(_u64 * 2)]),
+    "lfa_get_correction_stats_ex": (_int, [_vp, C.POINTER(_u64 * 3)]),
     "lfa_correct_collide_begin": (_int, [_vp, _dbl]),
     "lfa_correct_collide_end": (_int, [_vp]),
     "lfa_correct_collide_undo": (_int, [_vp]),
@@ -664,6 +665,13 @@ class Sim:
         arr = (C.c_uint64 * 2)()
         self._chk(self.lib.lfa_get_correction_stats(self.h, C.byref(arr)))
         return int(arr[0]), int(arr[1])
+
+    def correction_stats_ex(self):
+        """(half tiles of the last correction's global-gather fallback, half tiles in all, half tiles of the tiled kernel's second,
+        one-workgroup-per-CU pass)."""
+        arr = (C.c_uint64 * 3)()
+        self._chk(self.lib.lfa_get_correction_stats_ex(self.h, C.byref(arr)))
+        return int(arr[0]), int(arr[1]), int(arr[2])
 
     def set_step_overlap(self, on):
         """time_step: position correction on a second stream beside the pressure solve (default on); off = back to back."""

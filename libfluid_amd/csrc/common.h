@@ -76,6 +76,7 @@ struct lfa_knobs {
 	int c_travels = 0;        // LFA_C_TRAVELS=1: PIC / FLIP move C with every binning (no home array)
 	int bin_shuffle = 0;      // LFA_BIN_SHUFFLE=1 (round-3 binning only)
 	int p2g_no_rot = 0;       // LFA_P2G_NO_ROT=1
+	int corr_no_big = 0;      // LFA_CORR_NO_BIG=1: crowded half tiles go straight to the global-gather kernel (before round 4)
 	int corr_prio = 0x7fffffff;  // LFA_CORR_PRIO: priority of the correction's stream (default: the lowest the device has)
 	// pressure solve (mg.hip, pcg.hip); -1 / 0 / NaN = the built-in default
 	int mg_mw_a = -1, mg_mw_u = -1;    // LFA_MG_MW_A / _U: minimum waves per SIMD of the two finest-level streaming kernels

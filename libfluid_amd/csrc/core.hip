@@ -209,7 +209,8 @@ static hipError_t create_low_priority_stream(hipStream_t *st, int prio_knob) {
 	return hipStreamCreateWithPriority(st, hipStreamNonBlocking, least);
 }
 
-int lfa_pcg_grid_cap = 2048;  // (pcg.h: pcg_grid; PCG_MAX_GRID is the most the partial arrays hold)
+int lfa_pcg_grid_cap = 768;  // (pcg.h: pcg_grid; PCG_MAX_GRID = 2048 is the most the partial arrays hold. 3 workgroups per CU: measured at
+                             // C4 / C3 / C2 per iteration: 2048: 0.282 / 0.138 / 0.076 ms, 768: 0.273 / 0.132 / 0.0755, 512: 0.308, 640: 0.289, 896: 0.292)
 /// The process environment is read here and nowhere below an entry point (lfa_knobs, common.h).
 static void lfa_knobs_parse(lfa_knobs &k) {
 	auto flag = [](const char *name, int dflt) -> int {
@@ -230,6 +231,7 @@ static void lfa_knobs_parse(lfa_knobs &k) {
 		const char *e = getenv(name);
 		return e ? atof(e) : __builtin_nan("");
 	};
+	k.corr_no_big = flag("LFA_CORR_NO_BIG", 0);
 	k.corr_prio = num("LFA_CORR_PRIO", 0x7fffffff);
 	k.mg_mw_a = num("LFA_MG_MW_A", -1);
 	k.mg_mw_u = num("LFA_MG_MW_U", -1);

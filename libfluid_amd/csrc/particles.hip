@@ -125,6 +125,8 @@ __device__ inline void split_position(double p, int n, int &cell, float &t) {
 #define CORR_PARTS 2                       // workgroups per tile of the LDS-tiled position correction (split in z; 4: 5.6 instead of 5.0 ms alone, and no better beside the pressure solve)
 #endif
 #define CORR_THREADS 512                   // 8 waves per workgroup, 2 workgroups per CU (LDS)
+#define CORR_THREADS_BIG 1024              // the second pass over crowded parts: 16 waves, one workgroup per CU
+#define CORR_BIG_SLICES 4                  // workgroups that share the own particles of one crowded part
 
 struct MoveParams {
 	double dt_over_h;   // dt / cell_size
@@ -284,8 +286,8 @@ __device__ inline float hash_unit(uint32_t a, uint32_t b, uint32_t k) {
 #define FB_N (FB * FB * FBZ)
 #define FB_ROWS (FB * FBZ)
 #define FINE_CAP 5632                       // staged particles (13 x 13 x 8 fine cells hold 4160 at 8 per cell)
-#define FINE_OWN (FINE_CNT * 2)  // own particles the u16 list holds (it lives in the count array); more are found through the row offsets
-#define FINE_CNT (((FB_N + 1 + CORR_THREADS - 1) / CORR_THREADS) * CORR_THREADS)  // >= FB_N + 1, a multiple of CORR_THREADS
+#define FINE_CAP_BIG 12288                   // the second pass over flagged parts: 144 KB of positions, one workgroup per CU
+// (own particles the u16 list of k_correct_fine holds: twice its count array, where it lives; more are found through the row offsets)
 #define FIDX_THREADS 512   // (256: 0.75 ms at C4, 512: 0.58; FIDX_STAGE and FIDX_CNT are multiples of it)
 #define FIDX_CNT 1536                       // index kernel: >= FT3 + 1, a multiple of FIDX_THREADS
 #define FIDX_STAGE 4608                      // records staged in LDS per tile by the index kernel (72 KB)
@@ -528,23 +530,35 @@ k_correct_collide(size_t n, ParticleSoA p, uint32_t *out_key, float *out_tx, flo
 
 /// LDS-tiled _correct_positions + _detect_collisions on the fine index. One workgroup per (particle tile, z part): part 0 moves the
 /// particles of FT_PL fine layers (the last part of what is left); the block staged in LDS is those layers + one fine cell all around.
-__global__ void __launch_bounds__(CORR_THREADS, 4)
+/// CAP: staged particles. <FINE_CAP, false> is the pass over every part (two workgroups per CU); <FINE_CAP_BIG, true> takes the parts
+/// the first pass has flagged in `only` (word 0: how many; a crowded neighbourhood late in a run) with the whole LDS of a CU to
+/// itself, and flags what does not fit even that for the global-gather kernel.
+template <int CAP, bool ONLY>
+__global__ void __launch_bounds__(ONLY ? CORR_THREADS_BIG : CORR_THREADS, 4)
 k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx, float *out_ty, float *out_tz, GridDims g,
                 const uint8_t *solid, const uint32_t *tile_count, const uint32_t *fine_start, const float4 *spos, MoveParams mp,
-                uint32_t *overflow_tiles, const uint8_t *tile_clear) {
-	__shared__ float px[FINE_CAP], py[FINE_CAP], pz[FINE_CAP];
-	__shared__ uint32_t fcnt[FINE_CNT];       // particles per block fine cell; afterwards the own list (u16)
+                uint32_t *overflow_tiles, const uint8_t *tile_clear, const uint32_t *only) {
+	constexpr int T = ONLY ? CORR_THREADS_BIG : CORR_THREADS;  // threads of the workgroup
+	constexpr int CNT = ((FB_N + 1 + T - 1) / T) * T;        // >= FB_N + 1, a multiple of T
+	__shared__ float px[CAP], py[CAP], pz[CAP];
+	__shared__ uint32_t fcnt[CNT];          // particles per block fine cell; afterwards the own list (u16)
 	__shared__ uint16_t foff[FB_N + 1];        // first staged slot of every block fine cell
 	__shared__ uint32_t rowsrc[FB_ROWS * 3];   // first source record of the three runs of a fine row (x-1 tile, own x tile, x+1 tile)
 	__shared__ uint32_t ownoff[FT * FT_PL + 1];
 	__shared__ int srct[27];                   // the source tiles around the own one
-	__shared__ uint32_t wsum[CORR_THREADS / 64];
+	__shared__ uint32_t wsum[T / 64];
 	uint16_t *own = (uint16_t *)fcnt;
-	static_assert(FINE_CNT > FB_N && FINE_CNT % CORR_THREADS == 0, "fcnt sizing");
-	constexpr int PER = FINE_CNT / CORR_THREADS;
+	static_assert(CNT > FB_N && CNT % T == 0, "fcnt sizing");
+	constexpr int PER = CNT / T;
 	const int nn[3] = {g.nx, g.ny, g.nz};
 	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-	for (int work = blockIdx.x; work < CORR_PARTS * n_ptiles; work += gridDim.x) {
+	if (ONLY && only[0] == 0) return;  // (as a rule)
+	// (second pass: CORR_BIG_SLICES workgroups per crowded part, each stages the block and moves every CORR_BIG_SLICES-th round of
+	// its own particles - the pair work of such a part is several times a normal one's, and there are fewer of them than CUs)
+	constexpr int SLICES = ONLY ? CORR_BIG_SLICES : 1;
+	for (int item = blockIdx.x; item < SLICES * CORR_PARTS * n_ptiles; item += gridDim.x) {
+		const int work = item / SLICES, slice = item % SLICES;
+		if (ONLY && !((only[1 + (work >> 5)] >> (work & 31)) & 1u)) continue;  // (uniform)
 		const int tile = ptiles[work / CORR_PARTS], part = work % CORR_PARTS;
 		int tx, ty, tz;
 		tile_coords(g, tile, tx, ty, tz);
@@ -564,7 +578,7 @@ k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx
 		__syncthreads();
 #pragma unroll
 		for (int k = 0; k < PER; ++k) {
-			const int f = threadIdx.x + CORR_THREADS * k;
+			const int f = threadIdx.x + T * k;
 			uint32_t cnt = 0, src0 = 0;
 			if (f < FB * nrows) {
 				const int bx = f % FB, row = f / FB, by = row % FB, bz = row / FB;
@@ -598,12 +612,12 @@ k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx
 		if (lane == 63) wsum[wid] = incl;
 		__syncthreads();
 		uint32_t woff = 0, total = 0;
-		for (int w = 0; w < CORR_THREADS / 64; ++w) {
+		for (int w = 0; w < T / 64; ++w) {
 			if (w < wid) woff += wsum[w];
 			total += wsum[w];
 		}
-		if (total > FINE_CAP) {  // uniform
-			if (threadIdx.x == 0) {
+		if (total > (uint32_t)CAP) {  // uniform
+			if (threadIdx.x == 0 && slice == 0) {
 				atomicOr(&overflow_tiles[1 + (work >> 5)], 1u << (work & 31));
 				atomicAdd(&overflow_tiles[0], 1u);
 			}
@@ -636,7 +650,7 @@ k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx
 			if (lane == 63) wsum[wid] = in2;
 			__syncthreads();
 			uint32_t wo = 0;
-			for (int w = 0; w < CORR_THREADS / 64; ++w) {
+			for (int w = 0; w < T / 64; ++w) {
 				if (w < wid) wo += wsum[w];
 				own_total += wsum[w];
 			}
@@ -645,11 +659,11 @@ k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx
 		}
 		// (a crowded part with more own particles than the list holds - it lives in the count array - finds them through the row
 		// offsets instead: uniform)
-		const bool listed = own_total <= FINE_OWN;
+		const bool listed = own_total <= 2u * CNT;
 		__syncthreads();  // (every count has been read: `own` may overwrite the array)
 		// ---- stage the rows: a wave per fine row copies its three runs - one cell of the x-1 tile, the own x tile's eleven, one
 		// of the x+1 tile - which follow each other in the block (positions relative to the own tile's origin, in cells)
-		for (int row = wid; row < nrows; row += CORR_THREADS / 64) {
+		for (int row = wid; row < nrows; row += T / 64) {
 			const int by = row % FB, bz = row / FB;
 			const int gy = by - 1, gz = gz0 + bz;
 			const int dy = gy < 0 ? -1 : (gy >= FT ? 1 : 0), dz = gz < 0 ? -1 : (gz >= FT ? 1 : 0);
@@ -674,7 +688,7 @@ k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx
 		}
 		__syncthreads();
 		// ---- one thread per own particle
-		for (uint32_t w = threadIdx.x; w < own_total; w += CORR_THREADS) {
+		for (uint32_t w = threadIdx.x + T * slice; w < own_total; w += T * SLICES) {
 			uint32_t me;
 			if (listed) {
 				me = own[w];
@@ -1241,31 +1255,41 @@ static int correct_apply(lfa_sim *s, double dt, bool migrate = true, bool with_c
 	float4 *spos = correction_scratch(s);
 	s->cell_sorted = false;  // (key, t) are rewritten in place
 	if (n) {
-		// LDS-tiled pass; half tiles whose neighbourhood exceeds the LDS capacity are flagged and redone by the global-gather
-		// kernel (restricted to those particles)
+		// LDS-tiled pass; half tiles whose neighbourhood exceeds the LDS capacity are flagged and redone, first by the same kernel
+		// with the whole LDS of a CU (round 4: late in a run a few hundred crowded half tiles cost the global-gather kernel more
+		// than the other 31 000 cost the tiled one), then - what exceeds even that - by the global-gather kernel
 		const size_t ovf_words = ((size_t)CORR_PARTS * s->n_ptiles + 31) / 32 + 2;  // word 0: how many are flagged
-		if (!s->corr_ovf) {  // 2 bits per tile of the grid; its own array: the pressure solve may be running beside this
-			hipError_t e = hipMalloc(&s->corr_ovf, (((size_t)CORR_PARTS * s->g.nt + 31) / 32 + 2) * 4);
-			if (e != hipSuccess) return lfa_fail(s, LFA_E_OOM, "hipMalloc of the correction's overflow bitmap failed");
+		const size_t ovf_stride = ((size_t)CORR_PARTS * s->g.nt + 31) / 32 + 2;     // second bitmap: what the big pass has flagged
+		if (!s->corr_ovf) {  // 2 x 2 bits per tile of the grid; its own array: the pressure solve may be running beside this
+			hipError_t e = hipMalloc(&s->corr_ovf, 2 * ovf_stride * 4);
+			if (e != hipSuccess) return lfa_fail(s, LFA_E_OOM, "hipMalloc of the correction's overflow bitmaps failed");
 		}
-		uint32_t *ovf = s->corr_ovf;
+		uint32_t *ovf = s->corr_ovf, *ovf2 = s->corr_ovf + ovf_stride;
 		s->corr_parts_tiles = s->n_ptiles;
 		LFA_HIP(s, hipMemsetAsync(ovf, 0, ovf_words * 4, s->stream));
+		LFA_HIP(s, hipMemsetAsync(ovf2, 0, ovf_words * 4, s->stream));
 		{
 			const int work = CORR_PARTS * s->n_ptiles, g2 = work < 65536 ? (work > 0 ? work : 1) : 65536;
 			// every neighbour position comes from the records of the index built above (the OLD positions), so the new ones are
 			// written in place; the fallback pass below takes its particles' old state from the records and the copy of the keys
 			// the index kernel has left in the other buffer
 			if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[41], s->stream));
-			hipLaunchKernelGGL(k_correct_fine, dim3(g2), dim3(CORR_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, cur.key, cur.t[0],
-			                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_count, s->fine_start, (const float4 *)spos, mpc, ovf,
-			                   (const uint8_t *)s->tile_clear);
+			hipLaunchKernelGGL((k_correct_fine<FINE_CAP, false>), dim3(g2), dim3(CORR_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, cur.key,
+			                   cur.t[0], cur.t[1], cur.t[2], s->g, s->solid, s->tile_count, s->fine_start, (const float4 *)spos, mpc, ovf,
+			                   (const uint8_t *)s->tile_clear, (const uint32_t *)nullptr);
 			LFA_LAUNCH_CHECK(s);
 			if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[42], s->stream));
+			// (a workgroup per CU and a few more: they return at once unless something is flagged)
+			if (!s->knobs.corr_no_big)
+				hipLaunchKernelGGL((k_correct_fine<FINE_CAP_BIG, true>), dim3(std::min(CORR_BIG_SLICES * g2, 2048)), dim3(CORR_THREADS_BIG), 0, s->stream, s->ptiles,
+				                   s->n_ptiles, cur.key, cur.t[0], cur.t[1], cur.t[2], s->g, s->solid, s->tile_count, s->fine_start,
+				                   (const float4 *)spos, mpc, ovf2, (const uint8_t *)s->tile_clear, (const uint32_t *)ovf);
+			LFA_LAUNCH_CHECK(s);
 		}
+		const uint32_t *fallback = s->knobs.corr_no_big ? ovf : ovf2;
 		hipLaunchKernelGGL(k_correct_collide, dim3((unsigned)std::min<size_t>((n + 255) / 256, 16384)), dim3(256), 0, s->stream, n, cur, cur.key, cur.t[0],
 		                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_count, s->fine_start, (const float4 *)spos, mpc,
-		                   (const uint32_t *)ovf, (const int *)s->tile_pslot, s->p_off, (const uint32_t *)oth.key);
+		                   fallback, (const int *)s->tile_pslot, s->p_off, (const uint32_t *)oth.key);
 		LFA_LAUNCH_CHECK(s);
 	}
 	if (migrate) LFA_TRY(lfa_dist_migrate(s));
@@ -1508,14 +1532,27 @@ extern "C" int lfa_time_step(lfa_sim *s, double dt, double *residual, uint64_t *
 extern "C" int lfa_get_correction_stats(lfa_sim *s, uint64_t stats[2]) {
 	if (!s || !stats) return LFA_E_INVALID;
 	stats[0] = stats[1] = 0;
-	if (!s->corr_ovf) return LFA_OK;  // no correction has run yet
+	uint64_t ex[3];
+	LFA_TRY(lfa_get_correction_stats_ex(s, ex));
+	stats[0] = ex[0];
+	stats[1] = ex[1];
+	return LFA_OK;
+}
+
+extern "C" int lfa_get_correction_stats_ex(lfa_sim *s, uint64_t stats[3]) {
+	if (!s || !stats) return LFA_E_INVALID;
+	stats[0] = stats[1] = stats[2] = 0;
+	if (!s->corr_ovf) return LFA_OK;
 	LFA_HIP(s, hipSetDevice(s->device));
 	LFA_TRY(lfa_corr_join(s));
-	uint32_t flagged = 0;
-	LFA_HIP(s, hipMemcpyAsync(&flagged, s->corr_ovf, 4, hipMemcpyDeviceToHost, s->stream));
+	const size_t ovf_stride = ((size_t)CORR_PARTS * s->g.nt + 31) / 32 + 2;
+	uint32_t first = 0, second = 0;
+	LFA_HIP(s, hipMemcpyAsync(&first, s->corr_ovf, 4, hipMemcpyDeviceToHost, s->stream));
+	LFA_HIP(s, hipMemcpyAsync(&second, s->corr_ovf + ovf_stride, 4, hipMemcpyDeviceToHost, s->stream));
 	LFA_HIP(s, hipStreamSynchronize(s->stream));
-	stats[0] = flagged;
+	stats[0] = s->knobs.corr_no_big ? first : second;
 	stats[1] = (uint64_t)CORR_PARTS * (uint64_t)s->corr_parts_tiles;
+	stats[2] = s->knobs.corr_no_big ? 0 : first;
 	return LFA_OK;
 }
 

@@ -174,16 +174,20 @@ def test_device_time_step_matches_reference(precond, dtype):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dense", ["all", "half"])
-def test_position_correction_fallback_for_crowded_tiles(dense):
-    """Half tiles whose 10 x 10 x 6-cell neighbourhood holds more particles than the LDS of the tiled kernel are redone by
-    the global-gather kernel (24 particles per cell here: every half tile, or - "half" - only those of the lower part of
-    the block, so that both kernels run in one call and the second one has to pick its particles by their keys from
-    BEFORE the first one moved the others in place). Checked against the oracle's _correct_positions + collisions."""
+@pytest.mark.parametrize("dense", ["all", "half", "second-pass", "all-no-second-pass"])
+def test_position_correction_fallback_for_crowded_tiles(dense, monkeypatch):
+    """Half tiles whose 10 x 10 x 6-cell neighbourhood holds more particles than the LDS of the tiled kernel (5632) are redone by
+    the same kernel with a CU's whole LDS to itself (12288), and what exceeds that by the global-gather kernel. 32 particles per
+    cell ("all": every half tile), 48 in the lower part of the block only ("half": all three kernels run in one call and the
+    later ones have to pick their particles by their keys from BEFORE the first one moved the others in place), or 16
+    ("second-pass": nothing is left for the gather kernel). Checked against the oracle's _correct_positions + collisions."""
+    if dense == "all-no-second-pass":
+        monkeypatch.setenv("LFA_CORR_NO_BIG", "1")
     size, lo, hi = (24, 24, 24), (2, 2, 2), (18, 16, 18)
-    parts = [util.scenes.seed_block(lo, hi, seed=util.scenes.SEED + 7 * k) for k in range(3 if dense == "all" else 1)]
+    layers = {"all": 4, "all-no-second-pass": 4, "half": 1, "second-pass": 2}[dense]
+    parts = [util.scenes.seed_block(lo, hi, seed=util.scenes.SEED + 7 * k) for k in range(layers)]
     if dense == "half":
-        parts += [util.scenes.seed_block(lo, (hi[0], 8, hi[2]), seed=util.scenes.SEED + 7 * k) for k in (1, 2)]
+        parts += [util.scenes.seed_block(lo, (hi[0], 8, hi[2]), seed=util.scenes.SEED + 7 * k) for k in range(1, 6)]
     parts = np.concatenate(parts)
     parts["cx"][:, 0] = np.arange(len(parts))  # ids, like fullstep_inputs (by_id reads them back)
     cpu = orc.CpuSim(size, method=orc.PIC)
@@ -197,8 +201,14 @@ def test_position_correction_fallback_for_crowded_tiles(dense):
     s.upload_particles(parts)
     s.hash()
     s.correct_collide(DT_CORR)
-    flagged, total = s.correction_stats()
-    assert 0 < flagged < total  # both kernels ran (also in "all": the sparsely filled half tiles at the block's edge fit the tiled one)
+    flagged, total, second = s.correction_stats_ex()
+    assert (flagged, total) == s.correction_stats()
+    if dense == "second-pass":
+        assert flagged == 0 and 0 < second < total
+    elif dense == "all-no-second-pass":
+        assert 0 < flagged < total and second == 0
+    else:  # every kernel ran (also in "all": the sparsely filled half tiles at the block's edge fit the first pass)
+        assert 0 < flagged < second < total
     out = s.download_particles(into=parts.copy(), write_positions=True)
     s.close()
     assert np.abs(out["pos"] - parts["pos"]).max() > 1e-2  # the correction did move particles
