@@ -76,6 +76,7 @@ struct lfa_knobs {
 	int c_travels = 0;        // LFA_C_TRAVELS=1: PIC / FLIP move C with every binning (no home array)
 	int bin_shuffle = 0;      // LFA_BIN_SHUFFLE=1 (round-3 binning only)
 	int p2g_no_rot = 0;       // LFA_P2G_NO_ROT=1
+	int dist_two_reductions = 0;  // LFA_DIST_TWO_REDUCTIONS=1: slab runs keep the textbook PCG (dot(q,s) in a collective of its own)
 	int corr_no_big = 0;      // LFA_CORR_NO_BIG=1: crowded half tiles go straight to the global-gather kernel (before round 4)
 	int corr_prio = 0x7fffffff;  // LFA_CORR_PRIO: priority of the correction's stream (default: the lowest the device has)
 	// pressure solve (mg.hip, pcg.hip); -1 / 0 / NaN = the built-in default
@@ -448,6 +449,8 @@ int lfa_dist_exchange_layer_slices(lfa_sim *s, void *vec, int elem_bytes, int ti
 int lfa_dist_allreduce(lfa_sim *s, const double *partials, int n, int slot, bool is_max);  // result in dist_red[slot]
 double *lfa_dist_gather_buf(lfa_sim *s, int parity);  // [max per rank | sum per rank] of the last lfa_dist_gather_pair
 int lfa_dist_gather_pair(lfa_sim *s, const double *pmax, int n_max, const double *psum, int n_sum, int parity);
+int lfa_dist_gather_triple(lfa_sim *s, const double *pmax, int n_max, const double *psum, int n_sum, const double *psum2, int n_sum2,
+                           int parity);  // [max | sum | sum2 per rank]
 int lfa_dist_ensure_xbuf(lfa_sim *s, int which, size_t bytes);
 int lfa_dist_migrate(lfa_sim *s, bool vc_dead = false);
 int lfa_dist_exchange_ghost_particles(lfa_sim *s);

@@ -133,10 +133,18 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const double *part, int
 /// out[0 .. 2 n) = 0 except out[rank] = max of the first list and out[n + rank] = sum of the second (the fixed-order
 /// reductions of k_reduce_partials): a SUM all-reduce of `out` then leaves every rank's pair on every rank (an all-gather
 /// that is exact in any order), and the consumers reduce n values instead of their per-workgroup partials.
-__global__ void __launch_bounds__(256) k_gather_pair(const double *pmax, int n_max, const double *psum, int n_sum, double *out, int n, int rank) {
-	__shared__ double lds[2][256];
-	double a = -INFINITY, b = 0.0;
-	bool nan_a = false, nan_b = false;
+/// (`psum2`: a third list, summed like the second, for out[2 n + rank]: the single-reduction CG of slab runs; out is 3 n long)
+__global__ void __launch_bounds__(256) k_gather_pair(const double *pmax, int n_max, const double *psum, int n_sum, const double *psum2,
+                                                     int n_sum2, double *out, int n, int rank) {
+	__shared__ double lds[3][256];
+	double a = -INFINITY, b = 0.0, c2 = 0.0;
+	bool nan_a = false, nan_b = false, nan_c = false;
+	for (int i = threadIdx.x; i < n_sum2; i += 256) {
+		const double x = psum2[i];
+		nan_c |= x != x;
+		c2 += x;
+	}
+	lds[2][threadIdx.x] = nan_c ? NAN : c2;
 	for (int i = threadIdx.x; i < n_max; i += 256) {
 		const double x = pmax[i];
 		nan_a |= x != x;
@@ -156,10 +164,13 @@ __global__ void __launch_bounds__(256) k_gather_pair(const double *pmax, int n_m
 			lds[0][threadIdx.x] = (x != x || y != y) ? NAN : (y > x ? y : x);
 			const double u = lds[1][threadIdx.x], w = lds[1][threadIdx.x + o];
 			lds[1][threadIdx.x] = (u != u || w != w) ? NAN : u + w;
+			const double u2 = lds[2][threadIdx.x], w2 = lds[2][threadIdx.x + o];
+			lds[2][threadIdx.x] = (u2 != u2 || w2 != w2) ? NAN : u2 + w2;
 		}
 		__syncthreads();
 	}
-	for (int i = threadIdx.x; i < 2 * n; i += 256) out[i] = i == rank ? lds[0][0] : (i == n + rank ? lds[1][0] : 0.0);
+	for (int i = threadIdx.x; i < 3 * n; i += 256)
+		out[i] = i == rank ? lds[0][0] : (i == n + rank ? lds[1][0] : (i == 2 * n + rank ? lds[2][0] : 0.0));
 }
 }  // namespace
 
@@ -314,14 +325,19 @@ int lfa_dist_allreduce(lfa_sim *s, const double *partials, int n, int slot, bool
 
 /// The signed max of `pmax` and the sum of `psum` of every rank in ONE collective: afterwards lfa_dist_gather_buf(s, parity)
 /// holds [max of rank 0 .. n-1 | sum of rank 0 .. n-1] on every rank.
-double *lfa_dist_gather_buf(lfa_sim *s, int parity) { return s->dist_red + 64 + (size_t)parity * 2 * s->dist->nranks; }
+double *lfa_dist_gather_buf(lfa_sim *s, int parity) { return s->dist_red + 64 + (size_t)parity * 3 * s->dist->nranks; }
 int lfa_dist_gather_pair(lfa_sim *s, const double *pmax, int n_max, const double *psum, int n_sum, int parity) {
+	return lfa_dist_gather_triple(s, pmax, n_max, psum, n_sum, nullptr, 0, parity);
+}
+/// The same with the sum of a third list behind them: [max | sum | sum2] of every rank, still ONE collective.
+int lfa_dist_gather_triple(lfa_sim *s, const double *pmax, int n_max, const double *psum, int n_sum, const double *psum2, int n_sum2,
+                           int parity) {
 	const int n = s->dist->nranks;
 	if (n > 32) return lfa_fail(s, LFA_E_UNSUPPORTED, "more than 32 slabs");
 	double *out = lfa_dist_gather_buf(s, parity);
-	hipLaunchKernelGGL(k_gather_pair, dim3(1), dim3(256), 0, s->stream, pmax, n_max, psum, n_sum, out, n, s->dist->rank);
+	hipLaunchKernelGGL(k_gather_pair, dim3(1), dim3(256), 0, s->stream, pmax, n_max, psum, n_sum, psum2, n_sum2, out, n, s->dist->rank);
 	LFA_LAUNCH_CHECK(s);
-	return s->dist->allreduce_buf(s, out, (size_t)2 * n, LFA_RED_F64, false);
+	return s->dist->allreduce_buf(s, out, (size_t)(psum2 ? 3 : 2) * n, LFA_RED_F64, false);
 }
 
 // ================================================================================================= particle migration
@@ -925,7 +941,7 @@ int attach(lfa_sim *s, lfa_dist *d, const int32_t *bounds) {
 	s->sources_valid = false;  // the seeding entries are the ones of this rank's own tile layers
 	s->grid_valid = false;
 	s->system_valid = false;
-	if (!s->dist_red) LFA_HIP(s, hipMalloc(&s->dist_red, (64 + 4 * 32) * 8));  // scalars | 2 gather buffers of 2 x nranks
+	if (!s->dist_red) LFA_HIP(s, hipMalloc(&s->dist_red, (64 + 6 * 32 + 8) * 8));  // scalars | 2 gather buffers of 3 x nranks | alpha of the single-reduction CG (2)
 	if (!s->halo_tiles) LFA_HIP(s, hipMalloc(&s->halo_tiles, (size_t)4 * s->g.ntx * s->g.nty * 4));
 	return LFA_OK;
 }

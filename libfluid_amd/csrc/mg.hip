@@ -662,6 +662,111 @@ k_mg_axpy_presmooth(const int *tiles, int n_tiles, const uint8_t *abits, real *p
 	}
 }
 
+/// The same stage for the single-reduction CG of slab runs (Chronopoulos / Gear). With w = A z (k_pcg_a on the V-cycle's result) the
+/// search direction and its image follow from recurrences, dir = z + beta dir, adir = w + beta adir, and
+/// alpha = gamma / (delta - beta gamma / alpha_prev) needs gamma = z.r and delta = w.z only: the three scalars of an iteration -
+/// gamma, delta and the signed max of r - travel in ONE collective (lfa_dist_gather_triple) where the textbook form needs dot(q, s)
+/// in a second one. Same iterates in exact arithmetic. The lists hold one value per rank (or one reduced value); the stopping rule
+/// of pressure_solver::solve (src/pressure_solver.cpp:54-58) on the residual of iteration iter - 1 is evaluated here, the way
+/// k_pcg_a does it for the textbook form. alpha_io[iter & 1] = alpha of the previous iteration, alpha_io[~iter & 1] is written.
+template <typename real>
+__global__ void __launch_bounds__(256, 2)
+k_mg_axpy_presmooth_cg(const int *tiles, int n_tiles, const uint8_t *abits, real *p, real *dir, real *adir, const real *z, real *r, real *w_x,
+                       const double *gamma, int n_gamma, const double *gamma_old, int n_gamma_old, const double *delta, int n_delta,
+                       const double *rmax_prev, int n_rmax, double tol, int iter, double *alpha_io, double *part_rmax, int *state,
+                       double *hist) {
+	__shared__ real halo[PCG_WAVES][LFA_HALO_CELLS];
+	__shared__ double lds[8];
+	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
+	double m = -INFINITY;
+	bool nan = false;
+	bool run = state[0] < 0;
+	if (run && iter > 0) {  // every workgroup evaluates the rule on the same values, workgroup 0 records it
+		double rm = rmax_prev[0];
+		for (int i = 1; i < n_rmax; ++i) rm = (rm != rm || rmax_prev[i] != rmax_prev[i]) ? NAN : (rmax_prev[i] > rm ? rmax_prev[i] : rm);
+		const bool stop = rm != rm || rm < tol;
+		if (blockIdx.x == 0 && threadIdx.x == 0) {
+			hist[iter - 1] = rm;
+			if (stop) {
+				if (rm != rm) state[1] = 1;
+				*(double *)(state + 16) = rm;
+				state[0] = iter;
+			}
+		}
+		run = !stop;
+	}
+	if (run) {
+		double g = 0.0, go = 0.0, d = 0.0;
+		for (int i = 0; i < n_gamma; ++i) g += gamma[i];
+		for (int i = 0; i < n_delta; ++i) d += delta[i];
+		double beta_d = 0.0, alpha_d = g / d;
+		if (iter > 0) {
+			for (int i = 0; i < n_gamma_old; ++i) go += gamma_old[i];
+			beta_d = g / go;
+			alpha_d = g / (d - beta_d * g / alpha_io[iter & 1]);
+		}
+		if (blockIdx.x == 0 && threadIdx.x == 0) alpha_io[(iter & 1) ^ 1] = alpha_d;
+		const real alpha = (real)alpha_d, beta = (real)beta_d;
+		const bool first = iter == 0;  // (dir, adir hold whatever the last solve left)
+		real *h = halo[wid];
+		for (int i = lane; i < LFA_HALO_CELLS; i += 64) h[i] = (real)0;
+		const int stride = gridDim.x * PCG_WAVES;
+		int slot = blockIdx.x * PCG_WAVES + wid;
+		uint32_t tab[8];
+		real tp[8], td[8], ta[8], tz[8], tr[8], tw[8];
+		size_t base = 0;
+		auto load_tile = [&](int sl) {
+			base = (size_t)tiles[sl] * 512;
+#pragma unroll
+			for (int zz = 0; zz < 8; ++zz) {
+				const size_t c = base + zz * 64 + lane;
+				tab[zz] = abits[c]; tp[zz] = p[c]; tz[zz] = z[c]; tr[zz] = r[c]; tw[zz] = w_x[c];
+				td[zz] = first ? (real)0 : dir[c];
+				ta[zz] = first ? (real)0 : adir[c];
+			}
+		};
+		if (slot < n_tiles) load_tile(slot);
+		while (slot < n_tiles) {
+			uint32_t ab[8];
+			real bb[8];
+			const size_t obase = base;
+#pragma unroll
+			for (int zz = 0; zz < 8; ++zz) {
+				const size_t c = obase + zz * 64 + lane;
+				ab[zz] = tab[zz];
+				real rn = (real)0;
+				if (ab[zz] & AB_UNKNOWN) {
+					const real dn = first ? tz[zz] : tz[zz] + beta * td[zz];
+					const real an = first ? tw[zz] : tw[zz] + beta * ta[zz];
+					dir[c] = dn;
+					adir[c] = an;
+					p[c] = tp[zz] + alpha * dn;
+					rn = tr[zz] + (-alpha) * an;
+					r[c] = rn;
+					nan |= rn != rn;
+					m = (double)rn > m ? (double)rn : m;
+				}
+				bb[zz] = rn;
+			}
+			slot += stride;
+			if (slot < n_tiles) load_tile(slot);
+			presmooth_column<real>(h, ab, bb, lx, ly, MG_INNER_SWEEPS);
+#pragma unroll
+			for (int zz = 0; zz < 8; ++zz) w_x[obase + zz * 64 + lane] = h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)];
+		}
+	}
+	m = wave_max(m);
+	nan = __any(nan);
+	__syncthreads();
+	if (lane == 0) lds[wid] = nan ? NAN : m;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		double v = lds[0];
+		for (int i = 1; i < 4; ++i) v = (v != v || lds[i] != lds[i]) ? NAN : (lds[i] > v ? lds[i] : v);
+		part_rmax[blockIdx.x] = v;
+	}
+}
+
 template <typename real>
 __global__ void __launch_bounds__(256) k_mg_residual_restrict(MgLv<real> L, GridDims gc, real *b_coarse, const int *state) {
 	__shared__ real halo[PCG_WAVES][LFA_HALO_CELLS];
@@ -2666,6 +2771,28 @@ static int mg_axpy_apply_t(lfa_sim *s, const void *sdir, const double *part_sigm
 	                            (const int *)s->pcg_state);
 	LFA_LAUNCH_CHECK(s);
 	return mg_apply_t<real>(s, part_sigma_new, true);
+}
+/// Slab runs, single-reduction CG (k_mg_axpy_presmooth_cg): direction in vs, its image in vs2, w = A z arrives in vq.
+template <typename real>
+static int mg_axpy_apply_cg_t(lfa_sim *s, const double *gamma, int n_gamma, const double *gamma_old, int n_gamma_old, const double *delta,
+                              int n_delta, const double *rmax_prev, int n_rmax, int iter, double *alpha_io, double *part_rmax,
+                              double *part_sigma_new) {
+	const int G = mg_grid(s->n_ptiles);
+	hipLaunchKernelGGL(k_mg_axpy_presmooth_cg<real>, dim3(G), dim3(256), 0, s->stream, (const int *)s->ptiles, s->n_ptiles,
+	                   (const uint8_t *)s->abits, (real *)s->vp, (real *)s->vs, (real *)s->vs2, (const real *)s->vz, (real *)s->vr, (real *)s->vq,
+	                   gamma, n_gamma, gamma_old, n_gamma_old, delta, n_delta, rmax_prev, n_rmax, s->prm.tolerance, iter, alpha_io, part_rmax,
+	                   s->pcg_state, s->pcg_hist);
+	LFA_LAUNCH_CHECK(s);
+	return mg_apply_t<real>(s, part_sigma_new, true);
+}
+int lfa_mg_axpy_apply_cg(lfa_sim *s, const double *gamma, int n_gamma, const double *gamma_old, int n_gamma_old, const double *delta,
+                         int n_delta, const double *rmax_prev, int n_rmax, int iter, double *alpha_io, double *part_rmax,
+                         double *part_sigma_new) {
+	return s->prm.pcg_dtype == LFA_PCG_F64
+	           ? mg_axpy_apply_cg_t<double>(s, gamma, n_gamma, gamma_old, n_gamma_old, delta, n_delta, rmax_prev, n_rmax, iter, alpha_io,
+	                                        part_rmax, part_sigma_new)
+	           : mg_axpy_apply_cg_t<float>(s, gamma, n_gamma, gamma_old, n_gamma_old, delta, n_delta, rmax_prev, n_rmax, iter, alpha_io,
+	                                       part_rmax, part_sigma_new);
 }
 int lfa_mg_axpy_apply(lfa_sim *s, const void *sdir, const double *part_sigma, int n_sigma, const double *part_qs, int n_qs,
                       double *part_rmax, double *part_sigma_new) {

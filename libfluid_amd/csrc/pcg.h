@@ -29,6 +29,10 @@ int lfa_mg_apply(lfa_sim *s, double *part_sigma);   // vz = V(vr) / scale (vq is
 // the AXPYs of a PCG iteration fused with the pre-smoothing of the finest level, then the rest of the V-cycle
 int lfa_mg_axpy_apply(lfa_sim *s, const void *sdir, const double *part_sigma, int n_sigma, const double *part_qs, int n_qs,
                       double *part_rmax, double *part_sigma_new);
+// slab runs: the single-reduction form (gamma = z.r, delta = (A z).z and max r in one collective; mg.hip: k_mg_axpy_presmooth_cg)
+int lfa_mg_axpy_apply_cg(lfa_sim *s, const double *gamma, int n_gamma, const double *gamma_old, int n_gamma_old, const double *delta,
+                         int n_delta, const double *rmax_prev, int n_rmax, int iter, double *alpha_io, double *part_rmax,
+                         double *part_sigma_new);
 int lfa_mg_bench_part(lfa_sim *s, int part);
 void lfa_mg_free(lfa_sim *s);
 bool lfa_pcg_small_eligible(const lfa_sim *s);  // the next solve takes the one-launch path: nothing may run beside it

@@ -1257,7 +1257,7 @@ k_pcg_a(int n_ptiles, const int *__restrict__ nbr, const uint8_t *__restrict__ a
 			ac[zz] = ab[zz];
 			if (COARSE && (ab[zz] & AB_UNKNOWN)) zj += xc;
 			const real sj = FIRST ? zj : zj + beta * si[zz];
-			s_new[obase + zz * 64 + lane] = sj;
+			if (s_new) s_new[obase + zz * 64 + lane] = sj;  // (nullptr: q = A z alone - the single-reduction CG of slab runs)
 			h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)] = sj;
 		}
 		real fv[6];
@@ -1809,7 +1809,67 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 	// slabs: boundary tile layers whose rows couple to the neighbour rank (k_ghost_face_rows)
 	const int n_face_lo = dist && lfa_has_lo(s) ? s->n_own_first : 0, n_face_hi = dist && lfa_has_hi(s) ? s->n_own_last : 0;
 	const int g_face_lo = std::min(16, (n_face_lo + PCG_WAVES - 1) / PCG_WAVES), g_face_hi = std::min(16, (n_face_hi + PCG_WAVES - 1) / PCG_WAVES);
-	while (fused && !aborted && i < maxit && done < 0) {
+	// Slab runs with the multigrid preconditioner: the single-reduction form of CG (Chronopoulos / Gear; mg.hip:
+	// k_mg_axpy_presmooth_cg). Step A_k: w = A z_k and delta_k = w.z_k (k_pcg_a without a search direction, the slice of z across
+	// the slab faces, the rows that needed it), then gamma_k = z_k.r_k, delta_k and the signed max of r_k of every rank in ONE
+	// collective (gather buffer k & 1). Step B_k: stopping rule on r_k, the recurrences, r_k+1, the V-cycle -> z_k+1.
+	// Per iteration 2 D + 2 transport calls (D distributed levels) instead of 2 D + 3; LFA_DIST_TWO_REDUCTIONS=1 keeps the textbook form.
+	const bool cg1 = fused && dist && is_mg(s) && !small_ran && !s->knobs.dist_two_reductions;
+	if (cg1) {
+		const int nr = s->dist->nranks;
+		double *alpha_io = s->dist_red + 64 + 6 * 32;
+		auto step_a = [&](int k, const double *rmax_part, int n_rmax_part, const double *gam_part, int n_gam_part) -> int {
+			launch_pcg_a<real>(true, false, GA, s->stream, s->n_ptiles, (const int *)s->nbr_table, (const uint8_t *)s->abits, (const real *)v.z,
+			                   (const real *)nullptr, (real *)nullptr, v.q, scale, (const double *)nullptr, 0, (const double *)nullptr, 0,
+			                   (const double *)nullptr, 0, s->prm.tolerance, 0, s->pcg_state, s->pcg_hist, P + PART_ZS, (const real *)nullptr,
+			                   (const real *)nullptr, (real *)nullptr);
+			LFA_LAUNCH_CHECK(s);
+			LFA_TRY(lfa_dist_exchange_slices(s, v.z, (int)sizeof(real)));
+			if (g_face_lo) {
+				hipLaunchKernelGGL(k_ghost_face_rows<real>, dim3(g_face_lo), dim3(256), 0, s->stream, tc, n_face_lo, 0, 0, s->abits,
+				                   (const real *)v.z, v.q, scale, P + PART_ZS + GA, (real *)nullptr, (const int *)s->slot_l1, s->pcg_state);
+				LFA_LAUNCH_CHECK(s);
+			}
+			if (g_face_hi) {
+				hipLaunchKernelGGL(k_ghost_face_rows<real>, dim3(g_face_hi), dim3(256), 0, s->stream, tc, 0, s->n_ptiles - n_face_hi,
+				                   n_face_hi, s->abits, (const real *)v.z, v.q, scale, P + PART_ZS + GA + g_face_lo, (real *)nullptr,
+				                   (const int *)s->slot_l1, s->pcg_state);
+				LFA_LAUNCH_CHECK(s);
+			}
+			return lfa_dist_gather_triple(s, rmax_part, n_rmax_part, gam_part, n_gam_part, P + PART_ZS, GA + g_face_lo + g_face_hi, k & 1);
+		};
+		const uint64_t calls_a0 = s->dist->calls;
+		LFA_TRY(step_a(0, P + PART_RMAX, 0, P + PART_SIG0, NS));
+		const uint64_t calls_a = s->dist->calls - calls_a0;
+		while (!aborted && i < maxit && done < 0) {
+			const int end = std::min(maxit, i + (i == 0 ? first_chunk : chunk));
+			for (; i < end; ++i) {
+				const int po = i & 1, pn = po ^ 1;
+				const uint64_t calls0 = s->dist->calls;
+				const double *cur = lfa_dist_gather_buf(s, po), *old = lfa_dist_gather_buf(s, pn);
+				double *sig_new_part = P + (pn ? PART_SIG1 : PART_SIG0);
+				LFA_TRY(lfa_mg_axpy_apply_cg(s, cur + nr, nr, old + nr, nr, cur + 2 * nr, nr, cur, nr, i, alpha_io, P + PART_RMAX, sig_new_part));
+				LFA_TRY(step_a(i + 1, P + PART_RMAX, GB, sig_new_part, NSB));
+				if (i == 0) {
+					s->stat_transport_iter = s->dist->calls - calls0;
+					uint64_t mgl = 0;
+					lfa_mg_stats(s, &mgl, &s->stat_mg_levels, &s->stat_mg_first_co);
+					s->stat_launches_iter = 1 + (g_face_lo > 0) + (g_face_hi > 0) + mgl;
+				}
+			}
+			hipLaunchKernelGGL(k_check_converged, dim3(1), dim3(256), 0, s->stream, (const double *)lfa_dist_gather_buf(s, i & 1), nr,
+			                   s->prm.tolerance, i - 1, s->pcg_state, s->pcg_hist);
+			LFA_LAUNCH_CHECK(s);
+			LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 80, hipMemcpyDeviceToHost, s->stream));
+			LFA_HIP(s, hipStreamSynchronize(s->stream));
+			done = hstate[0];
+			nan = hstate[1];
+			aborted = hstate[2];
+			if (aborted) break;
+		}
+		(void)calls_a;
+	}
+	while (fused && !cg1 && !aborted && i < maxit && done < 0) {
 		const int end = std::min(maxit, i + (i == 0 ? first_chunk : chunk));
 		for (; i < end; ++i) {
 			const int po = i & 1, pn = po ^ 1;

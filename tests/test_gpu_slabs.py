@@ -549,7 +549,8 @@ def test_fixed_c4_domain_on_eight_virtual_slabs():
     # transport calls of one PCG iteration: the search direction's slices, q.s, one slice exchange per distributed level on the
     # way down, the all-reduce of the first replicated level, one per distributed level >= 1 on the way up, (max r, z.r)
     D = 3
-    assert all(st["transport_calls_per_iteration"] == 2 * D + 3 for st in stats), stats
+    # single-reduction CG (round 4): gamma, delta and the signed max of the residual travel in one collective
+    assert all(st["transport_calls_per_iteration"] == 2 * D + 2 for st in stats), stats
     # launches: k_pcg_a, two ghost-face row kernels, AXPY + pre-smoothing, two per distributed level down (one on level 0), the
     # single coarse-level launch, one per distributed level up
     assert all(st["launches_per_iteration"] <= 14 for st in stats), stats
@@ -720,3 +721,59 @@ def test_shared_memory_transport_fails_instead_of_hanging(tmp_path):
         assert procs[1].returncode == 0, outs[1]
         assert procs[0].returncode == 3, (mode, outs[0][-1500:])
         assert "error after" in outs[0] and ("peer" in outs[0] or "attach" in outs[0] or "timed out" in outs[0]), outs[0][-800:]
+
+
+@pytest.mark.gpu
+def test_single_reduction_cg_matches_the_textbook_form_on_slabs(monkeypatch):
+    """Slab runs solve with the single-reduction form of CG (Chronopoulos / Gear: gamma = z.r, delta = (A z).z and the signed max
+    of r in one collective; mg.hip: k_mg_axpy_presmooth_cg). Same iterates in exact arithmetic: against the textbook form
+    (LFA_DIST_TWO_REDUCTIONS=1, dot(q, s) in a collective of its own) on the same four virtual slabs the iteration counts agree
+    within one, the particles to solver tolerance, and an iteration makes one transport call less."""
+    size, block, bounds = (32, 32, 64), ((0, 0, 0), (16, 32, 48)), [0, 2, 4, 6, 8]
+    out = {}
+    for mode in ("single", "two"):
+        if mode == "two":
+            monkeypatch.setenv("LFA_DIST_TWO_REDUCTIONS", "1")
+        else:
+            monkeypatch.delenv("LFA_DIST_TWO_REDUCTIONS", raising=False)
+        n = len(bounds) - 1
+        hub = lfa.LocalHub(n)
+        sims = []
+        for r in range(n):
+            q = lfa.Sim(size, method=lfa.APIC, precond=lfa.PRECOND_MULTIGRID)
+            q.init_local_slab(hub.h, r, bounds)
+            q.seed_block(*block)
+            sims.append(q)
+        iters, resid, errors = [[] for _ in range(n)], [[] for _ in range(n)], []
+
+        def worker(r):
+            try:
+                for _ in range(5):
+                    res, it, rc = sims[r].time_step(util.DT)
+                    assert rc == 0
+                    iters[r].append(it); resid[r].append(res)
+            except Exception as e:  # noqa: BLE001
+                errors.append((r, repr(e)))
+
+        threads = [threading.Thread(target=worker, args=(r,)) for r in range(n)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=120)
+        assert not errors, errors
+        assert not any(t.is_alive() for t in threads), "slab threads hung"
+        assert all(it == iters[0] for it in iters)
+        parts = np.concatenate([q.download_particles() for q in sims])
+        ids = np.concatenate([q.particle_ids() for q in sims])
+        out[mode] = dict(its=iters[0], res=resid[0], parts=parts[np.argsort(ids)], stats=sims[0].solver_stats())
+        for q in sims:
+            q.close()
+        hub.close()
+    a, b = out["single"], out["two"]
+    assert all(abs(x - y) <= 1 for x, y in zip(a["its"], b["its"])), (a["its"], b["its"])
+    assert min(a["its"]) > 3
+    assert max(a["res"]) < 1e-6 and max(b["res"]) < 1e-6, (a["res"], b["res"])  # (the reference's tolerance, pressure_solver.h)
+    util.assert_close(a["parts"]["pos"], b["parts"]["pos"], 1e-6, "positions", atol=2e-4)
+    util.assert_close(a["parts"]["vel"], b["parts"]["vel"], 1e-3, "velocities", atol=1e-3 * 981.0 * util.DT)
+    ca, cb = a["stats"]["transport_calls_per_iteration"], b["stats"]["transport_calls_per_iteration"]
+    assert ca + 1 == cb, (ca, cb)
