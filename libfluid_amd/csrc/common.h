@@ -232,6 +232,7 @@ struct lfa_sim {
 	// the G2P then writes the new v, C straight into the binned order. Anything else that reads v or C calls
 	// lfa_particles_materialize first.
 	uint32_t *vc_src = nullptr;             // index in pb[cur ^ 1] of the particle now at i (valid while vc_pending)
+	size_t vc_extent = 0;                   // records of pb[cur ^ 1] that vc_src may point at (slabs: arrivals append theirs behind)
 	bool vc_pending = false;
 	bool vmax2_valid = false;               // pcg_state[7] holds max |v|^2 of the particles (written by the last G2P, nothing has touched v since)
 	// PIC / FLIP never change C (their P2G does not read it, their G2P does not write it; the hosts' particle records carry it

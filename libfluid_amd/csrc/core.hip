@@ -1342,10 +1342,10 @@ int lfa_c_home_ensure(lfa_sim *s, size_t n) {
 		(void)hipFree(nh);
 		return lfa_fail(s, LFA_E_HIP, "%s failed: %s", what, hipGetErrorString(e));
 	};
-	if (s->c_home && s->c_home_valid && s->np_live)
+	if (s->c_home && s->c_home_valid && s->c_home_cap)  // (every entry: on slabs the resident ids are anywhere in the job's range)
 		for (int k = 0; k < 9; ++k) {
 			const hipError_t e = hipMemcpyAsync(nh + (size_t)k * cap, s->c_home + (size_t)k * s->c_home_cap,
-			                                    std::min(s->np_live, s->c_home_cap) * 4, hipMemcpyDeviceToDevice, s->stream);
+			                                    s->c_home_cap * 4, hipMemcpyDeviceToDevice, s->stream);
 			if (e != hipSuccess) return fail(e, "copying C to its larger home array");
 		}
 	if (s->c_home) {
@@ -1483,15 +1483,17 @@ int lfa_hash_particles_impl(lfa_sim *s, bool counts_done) {
 		// particle and only v stays behind
 		int defer = s->knobs.full_scatter ? 0 : (s->prm.simulation_method == LFA_APIC ? 1 : 2);
 		const dim3 sgrid((unsigned)((n + 255) / 256));
-		// PIC / FLIP, single domain: C goes to its home array once and stays there - the scatter then moves key, t, id alone, like
-		// APIC's (LFA_C_TRAVELS=1: the round-2 behaviour, C moves with every binning)
-		const bool home = defer == 2 && !s->dist && !s->knobs.c_travels;
+		// PIC / FLIP: C goes to its home array once and stays there - the scatter then moves key, t, id alone, like APIC's
+		// (LFA_C_TRAVELS=1: the round-2 behaviour, C moves with every binning). The array is indexed by the particle id: on slabs
+		// (round 4) by the job-wide id, so every rank holds room for every particle of the job - 36 bytes each, 2.4 GB at C4 - and a
+		// particle that changes ranks takes its nine floats along in its record (dist.hip: k_pack_leavers / k_unpack_arrivals)
+		const bool home = defer == 2 && !s->knobs.c_travels;
 		if (home && !s->c_home_valid) {
-			LFA_TRY(lfa_c_home_ensure(s, s->pcap));
+			LFA_TRY(lfa_c_home_ensure(s, s->dist ? std::max<size_t>(s->pcap, (size_t)s->next_global_id) : s->pcap));
 			hipLaunchKernelGGL(k_c_to_home, sgrid, dim3(256), 0, s->stream, n, src, s->c_home, s->c_home_cap);
 			LFA_LAUNCH_CHECK(s);
 			s->c_home_valid = true;
-		} else if (!home && s->c_home_valid) {  // the method has changed to APIC, or the handle has joined a slab decomposition
+		} else if (!home && s->c_home_valid) {  // the method has changed to APIC
 			LFA_TRY(lfa_c_home_restore(s));
 		}
 		if (home) defer = 3;
@@ -1511,6 +1513,7 @@ int lfa_hash_particles_impl(lfa_sim *s, bool counts_done) {
 			}
 			s->cur ^= 1;
 			s->vc_pending = true;
+			s->vc_extent = n;
 			s->vc_with_c = defer <= 1;  // (0: everything follows at once; 2: C follows at once, v stays deferred)
 			if (defer == 0) {
 				LFA_TRY(lfa_particles_materialize(s));
@@ -1537,6 +1540,7 @@ int lfa_hash_particles_impl(lfa_sim *s, bool counts_done) {
 		LFA_LAUNCH_CHECK(s);
 		s->cur ^= 1;
 		s->vc_pending = defer != 0;
+		s->vc_extent = n;
 		s->vc_with_c = defer == 1;
 	}
 	if (s->n_dtiles) {

@@ -346,7 +346,8 @@ namespace {
 /// appended to the lo / hi send buffer (wave-aggregated append) and their key is invalidated (the next binning drops it).
 __global__ void __launch_bounds__(256)
 k_pack_leavers(size_t n, ParticleSoA p, int tiles_per_layer, int slab_lo, int slab_hi, uint32_t *counters, uint32_t *buf_lo,
-               uint32_t *buf_hi, int count_only) {
+               uint32_t *buf_hi, int count_only, const float *c_home, size_t c_home_stride, ParticleSoA pvc, const uint32_t *from,
+               int c_deferred) {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	int dest = -1;
 	uint32_t key = 0xFFFFFFFFu;
@@ -369,13 +370,17 @@ k_pack_leavers(size_t n, ParticleSoA p, int tiles_per_layer, int slab_lo, int sl
 		if (dest == d && !count_only) {
 			uint32_t *rec = (d == 0 ? buf_lo : buf_hi) + (size_t)(base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) * 17;
 			rec[0] = key;
+			// (a deferred binning, lfa_sim::vc_pending: v - and APIC's C - are still where they were before it)
+			const size_t j = from ? (size_t)from[i] : i;
 #pragma unroll
 			for (int k = 0; k < 3; ++k) {
 				rec[1 + k] = __float_as_uint(p.t[k][i]);
-				rec[4 + k] = __float_as_uint(p.v[k][i]);
+				rec[4 + k] = __float_as_uint(from ? pvc.v[k][j] : p.v[k][i]);
 			}
 #pragma unroll
-			for (int k = 0; k < 9; ++k) rec[7 + k] = __float_as_uint(p.c[k][i]);
+			for (int k = 0; k < 9; ++k)
+				rec[7 + k] = __float_as_uint(c_home ? c_home[k * c_home_stride + p.id[i]]  // (lfa_sim::c_home)
+				                                    : (from && c_deferred ? pvc.c[k][j] : p.c[k][i]));
 			rec[16] = p.id[i];
 			p.key[i] = 0xFFFFFFFFu;
 		}
@@ -385,20 +390,27 @@ __global__ void k_offset_u32(const uint32_t *in, uint32_t *out, int n, uint32_t 
 	int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n) out[i] = in[i] + base;
 }
-__global__ void __launch_bounds__(256) k_unpack_arrivals(size_t n, const uint32_t *buf, ParticleSoA p, size_t at) {
+/// `from` (a deferred binning is pending): v and C of the arrival at d go to record `ext + i` of the other buffer and from[d] says so.
+__global__ void __launch_bounds__(256) k_unpack_arrivals(size_t n, const uint32_t *buf, ParticleSoA p, size_t at, float *c_home,
+                                                         size_t c_home_stride, ParticleSoA pvc, uint32_t *from, size_t ext) {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	const uint32_t *rec = buf + i * 17;
-	const size_t d = at + i;
+	const size_t d = at + i, e = from ? ext + i : d;
+	const ParticleSoA &q = from ? pvc : p;
 	p.key[d] = rec[0];
 #pragma unroll
 	for (int k = 0; k < 3; ++k) {
 		p.t[k][d] = __uint_as_float(rec[1 + k]);
-		p.v[k][d] = __uint_as_float(rec[4 + k]);
+		q.v[k][e] = __uint_as_float(rec[4 + k]);
 	}
 #pragma unroll
-	for (int k = 0; k < 9; ++k) p.c[k][d] = __uint_as_float(rec[7 + k]);
+	for (int k = 0; k < 9; ++k) {
+		if (c_home) c_home[k * c_home_stride + rec[16]] = __uint_as_float(rec[7 + k]);
+		else q.c[k][e] = __uint_as_float(rec[7 + k]);
+	}
 	p.id[d] = rec[16];
+	if (from) from[d] = (uint32_t)e;
 }
 }  // namespace
 
@@ -411,7 +423,9 @@ int lfa_particles_reserve(lfa_sim *s, size_t n_keep, size_t n_total);  // core.h
 /// records travel with whatever v / C the current buffer holds.
 int lfa_dist_migrate(lfa_sim *s, bool vc_dead) {
 	if (!s->dist) return LFA_OK;
-	if (!(vc_dead && s->prm.simulation_method != LFA_FLIP_BLEND)) LFA_TRY(lfa_particles_materialize(s));  // leavers travel as whole records
+	// (leavers travel as whole records. A deferred binning stays deferred - round 4: completing it for everybody cost a FLIP run
+	// 0.12 ms per migration at C3 -: the pack kernel reads v, C where they are, the arrivals' go behind the other buffer's records)
+	(void)vc_dead;
 	const size_t n = s->binned ? s->np_live : s->np;
 	uint32_t *cnt = (uint32_t *)(s->dist_red + 32);  // [0,1] leaving lo/hi, [2,3] arriving from lo/hi
 	LFA_HIP(s, hipMemsetAsync(cnt, 0, 16, s->stream));
@@ -419,7 +433,7 @@ int lfa_dist_migrate(lfa_sim *s, bool vc_dead) {
 	const dim3 grid((unsigned)((n + 255) / 256 ? (n + 255) / 256 : 1));
 	ParticleSoA &p = s->pb[s->cur];
 	hipLaunchKernelGGL(k_pack_leavers, grid, dim3(256), 0, s->stream, n, p, tpl, s->slab_lo, s->slab_hi, cnt, (uint32_t *)nullptr,
-	                   (uint32_t *)nullptr, 1);
+	                   (uint32_t *)nullptr, 1, (const float *)nullptr, (size_t)0, p, (const uint32_t *)nullptr, 0);
 	LFA_LAUNCH_CHECK(s);
 	// how many arrive: the neighbours' leave counts
 	LFA_TRY(s->dist->exchange(s, lfa_has_lo(s) ? cnt + 0 : nullptr, lfa_has_lo(s) ? 4 : 0, lfa_has_lo(s) ? cnt + 2 : nullptr,
@@ -432,11 +446,20 @@ int lfa_dist_migrate(lfa_sim *s, bool vc_dead) {
 	if (!lfa_has_hi(s)) h[1] = h[3] = 0;
 	// (no early-out when nothing crosses this rank's faces: every rank issues the same sequence of transport calls)
 	for (int w = 0; w < 4; ++w) LFA_TRY(lfa_dist_ensure_xbuf(s, w, (size_t)h[w] * 68));
-	LFA_TRY(lfa_particles_reserve(s, n, n + h[2] + h[3]));
+	// (room for the arrivals: in the current buffer behind the live records, and - a deferred binning - for their v, C in the other
+	// one behind the records vc_src points at; a reallocation completes the deferred binning first)
+	LFA_TRY(lfa_particles_reserve(s, n, std::max(n, s->vc_pending ? s->vc_extent : (size_t)0) + h[2] + h[3]));
 	ParticleSoA &q = s->pb[s->cur];
+	const bool pend = s->vc_pending;
+	const ParticleSoA &qo = s->pb[s->cur ^ 1];
+	uint32_t *from = pend ? s->vc_src : nullptr;
 	LFA_HIP(s, hipMemsetAsync(cnt, 0, 8, s->stream));
+	// (PIC / FLIP: C lives in its home array, indexed by the job-wide id - see lfa_sim::c_home)
+	if (s->c_home_valid) LFA_TRY(lfa_c_home_ensure(s, (size_t)s->next_global_id));
+	float *chome = s->c_home_valid ? s->c_home : nullptr;
 	hipLaunchKernelGGL(k_pack_leavers, grid, dim3(256), 0, s->stream, n, q, tpl, s->slab_lo, s->slab_hi, cnt,
-	                   (uint32_t *)s->xbuf[0], (uint32_t *)s->xbuf[1], 0);
+	                   (uint32_t *)s->xbuf[0], (uint32_t *)s->xbuf[1], 0, (const float *)chome, s->c_home_cap, pend ? qo : q,
+	                   (const uint32_t *)from, s->vc_with_c ? 1 : 0);
 	LFA_LAUNCH_CHECK(s);
 	LFA_TRY(s->dist->exchange(s, s->xbuf[0], (size_t)h[0] * 68, s->xbuf[2], (size_t)h[2] * 68, s->xbuf[1], (size_t)h[1] * 68,
 	                          s->xbuf[3], (size_t)h[3] * 68));
@@ -444,9 +467,10 @@ int lfa_dist_migrate(lfa_sim *s, bool vc_dead) {
 	for (int w = 2; w < 4; ++w)
 		if (h[w]) {
 			hipLaunchKernelGGL(k_unpack_arrivals, dim3((h[w] + 255) / 256), dim3(256), 0, s->stream, (size_t)h[w],
-			                   (const uint32_t *)s->xbuf[w], q, at);
+			                   (const uint32_t *)s->xbuf[w], q, at, chome, s->c_home_cap, pend ? qo : q, from, s->vc_extent);
 			LFA_LAUNCH_CHECK(s);
 			at += h[w];
+			if (pend) s->vc_extent += h[w];
 		}
 	// the next binning scans [0, at): leavers carry an invalid key and are dropped there
 	s->np_live = at;
@@ -925,7 +949,7 @@ int attach(lfa_sim *s, lfa_dist *d, const int32_t *bounds) {
 		delete d;
 		return lfa_fail(s, LFA_E_INVALID, "layer bounds must partition [0,%d) into non-empty slabs", s->g.ntz);
 	}
-	if (lfa_c_home_restore(s) < 0) {  // particles migrate between ranks with their C: it travels with the record on slabs
+	if (lfa_c_home_restore(s) < 0) {  // (the next binning takes C home again, into an array sized for the ids of the whole job)
 		delete d;
 		return LFA_E_HIP;
 	}

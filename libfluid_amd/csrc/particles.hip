@@ -1067,10 +1067,10 @@ extern "C" int lfa_update_sources(lfa_sim *s, uint64_t *n_seeded) {
 	const size_t base = s->np_live;
 	LFA_TRY(lfa_particles_materialize(s));  // the new particles bring their own v / C: a deferred binning is completed first
 	LFA_TRY(lfa_particles_reserve(s, base, base + total));  // keeps the live records
-	if (s->c_home_valid) {  // the new particles get the ids base .. base + total - 1 and C = 0
-		LFA_TRY(lfa_c_home_ensure(s, base + total));
-		for (int k = 0; k < 9; ++k)
-			LFA_HIP(s, hipMemsetAsync(s->c_home + (size_t)k * s->c_home_cap + base, 0, total * 4, s->stream));
+	if (s->c_home_valid) {  // the new particles get the ids id_base .. id_base + total - 1 (single domain: = base) and C = 0
+		LFA_TRY(lfa_c_home_ensure(s, s->dist ? (size_t)s->next_global_id : base + total));
+		for (int k = 0; k < 9 && total; ++k)
+			LFA_HIP(s, hipMemsetAsync(s->c_home + (size_t)k * s->c_home_cap + id_base, 0, total * 4, s->stream));
 	}
 	++s->source_epoch;
 	if (total) {
