@@ -86,6 +86,7 @@ struct lfa_mg {
 	int co_phases = 0;
 	int launches_per_cycle = 0;   // launches of the last V-cycle incl. the AXPY / pre-smoothing kernel (lfa_get_solver_stats)
 	int first_co = 0;             // first level inside k_mg_coarse at the last V-cycle (0: launch-per-phase path)
+	int *q = nullptr;             // k_mg_down01 / k_mg_up01: the words of their work queues (MgQueue), zero between launches
 };
 // A level stays distributed while no tile layer straddles a slab face, and its ghost types follow from the one fine ghost tile
 // layer a rank mirrors (8 cells = one slice of level 3).
@@ -384,6 +385,25 @@ __device__ inline double bit_select(double a, double b, int pick) {
 	return __builtin_bit_cast(double, x ^ ((x ^ y) & (0ull - (uint64_t)pick)));
 }
 
+/// How a kernel reaches the level arrays other workgroups write. MemPlain: ordinary accesses (one launch per phase, the kernel
+/// boundary makes them visible). MemAgent: agent-scope relaxed atomics (`sc1` on gfx950: the access is coherent across the eight
+/// per-XCD L2s by itself, no bulk write-back / invalidate) - what lets k_mg_coarse run its phases inside ONE launch.
+struct MemPlain {
+	template <typename T> static __device__ inline T ld(const T *p) { return *p; }
+	template <typename T> static __device__ inline void st(T *p, T v) { *p = v; }
+};
+struct MemAgent {
+	template <typename T> static __device__ inline T ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+	template <typename T> static __device__ inline void st(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+};
+/// Workgroup-scope relaxed atomics (`sc0`: the access bypasses the CU's L1 and meets the others in the L2) - enough, and half the
+/// round trip of `sc1`, when every workgroup that takes part sits on ONE XCD and so shares one L2 (k_mg_coarse's XCD mode; the
+/// ready flags carry the producer's XCC id, so a consumer on another XCD notices before it reads anything).
+struct MemWg {
+	template <typename T> static __device__ inline T ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+	template <typename T> static __device__ inline void st(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+};
+
 /// One colour of the Gauss-Seidel update on the column of a lane: x_i = (b_i + sum of coupled neighbours) / diag_i.
 /// `h` is the 10^3 halo block of the wave (current values, ring = values of the neighbour tiles or 0).
 template <typename real>
@@ -426,7 +446,10 @@ __device__ inline void presmooth_column(real *h, const uint32_t (&ab)[8], const 
 		MG_FENCE();
 	}
 }
-template <typename real> __device__ inline void presmooth_tile(const MgLv<real> &L, int slot, real *h, int lane, int inner) {
+/// (LD / ST: how the right-hand side is read and the iterate written - MemAgent where another workgroup of the SAME launch wrote or
+/// will read them, see k_mg_down01)
+template <typename real, typename LD = MemPlain, typename ST = MemPlain>
+__device__ inline void presmooth_tile(const MgLv<real> &L, int slot, real *h, int lane, int inner) {
 	const int lx = lane & 7, ly = lane >> 3;
 	const size_t base = (size_t)L.tiles[slot] * 512;
 	uint32_t ab[8];
@@ -434,27 +457,28 @@ template <typename real> __device__ inline void presmooth_tile(const MgLv<real> 
 #pragma unroll
 	for (int zz = 0; zz < 8; ++zz) {
 		ab[zz] = L.abits[base + zz * 64 + lane];
-		bb[zz] = L.b[base + zz * 64 + lane];
+		bb[zz] = LD::ld(L.b + base + zz * 64 + lane);
 	}
 	presmooth_column<real>(h, ab, bb, lx, ly, inner);
 #pragma unroll
-	for (int zz = 0; zz < 8; ++zz) L.x[base + zz * 64 + lane] = h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)];
+	for (int zz = 0; zz < 8; ++zz) ST::st(L.x + base + zz * 64 + lane, h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)]);
 }
 
 /// Halo block of a tile-major vector (k_spmv's layout): interior + the six faces of the neighbour tiles (0 if inactive).
-template <typename real> __device__ inline void load_halo(real *h, const real *v, size_t base, const int *nb, int lane, int lx, int ly) {
+template <typename real, typename LD = MemPlain>
+__device__ inline void load_halo(real *h, const real *v, size_t base, const int *nb, int lane, int lx, int ly) {
 #pragma unroll
-	for (int zz = 0; zz < 8; ++zz) h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)] = v[base + zz * 64 + lane];
-	h[0 + 10 * (lx + 1) + 100 * (ly + 1)] = nb[0] >= 0 ? v[(size_t)nb[0] * 512 + ly * 64 + lx * 8 + 7] : (real)0;
-	h[9 + 10 * (lx + 1) + 100 * (ly + 1)] = nb[1] >= 0 ? v[(size_t)nb[1] * 512 + ly * 64 + lx * 8 + 0] : (real)0;
-	h[(lx + 1) + 10 * 0 + 100 * (ly + 1)] = nb[2] >= 0 ? v[(size_t)nb[2] * 512 + ly * 64 + 7 * 8 + lx] : (real)0;
-	h[(lx + 1) + 10 * 9 + 100 * (ly + 1)] = nb[3] >= 0 ? v[(size_t)nb[3] * 512 + ly * 64 + 0 * 8 + lx] : (real)0;
-	h[(lx + 1) + 10 * (ly + 1) + 100 * 0] = nb[4] >= 0 ? v[(size_t)nb[4] * 512 + 7 * 64 + lane] : (real)0;
-	h[(lx + 1) + 10 * (ly + 1) + 100 * 9] = nb[5] >= 0 ? v[(size_t)nb[5] * 512 + 0 * 64 + lane] : (real)0;
+	for (int zz = 0; zz < 8; ++zz) h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)] = LD::ld(v + base + zz * 64 + lane);
+	h[0 + 10 * (lx + 1) + 100 * (ly + 1)] = nb[0] >= 0 ? LD::ld(v + (size_t)nb[0] * 512 + ly * 64 + lx * 8 + 7) : (real)0;
+	h[9 + 10 * (lx + 1) + 100 * (ly + 1)] = nb[1] >= 0 ? LD::ld(v + (size_t)nb[1] * 512 + ly * 64 + lx * 8 + 0) : (real)0;
+	h[(lx + 1) + 10 * 0 + 100 * (ly + 1)] = nb[2] >= 0 ? LD::ld(v + (size_t)nb[2] * 512 + ly * 64 + 7 * 8 + lx) : (real)0;
+	h[(lx + 1) + 10 * 9 + 100 * (ly + 1)] = nb[3] >= 0 ? LD::ld(v + (size_t)nb[3] * 512 + ly * 64 + 0 * 8 + lx) : (real)0;
+	h[(lx + 1) + 10 * (ly + 1) + 100 * 0] = nb[4] >= 0 ? LD::ld(v + (size_t)nb[4] * 512 + 7 * 64 + lane) : (real)0;
+	h[(lx + 1) + 10 * (ly + 1) + 100 * 9] = nb[5] >= 0 ? LD::ld(v + (size_t)nb[5] * 512 + 0 * 64 + lane) : (real)0;
 }
 
 /// Down, one tile: residual r = b - A x of the level and its restriction to the next: half the sum over the 8 children.
-template <typename real>
+template <typename real, typename LD = MemPlain, typename ST = MemPlain>
 __device__ inline void residual_restrict_tile(const MgLv<real> &L, const GridDims &gc, real *b_coarse, int slot, real *h, int lane) {
 	const int lx = lane & 7, ly = lane >> 3;
 	const int *nt = L.nbr + (size_t)slot * MG_NBR_STRIDE;
@@ -467,10 +491,10 @@ __device__ inline void residual_restrict_tile(const MgLv<real> &L, const GridDim
 #pragma unroll
 	for (int zz = 0; zz < 8; ++zz) {
 		ab[zz] = L.abits[base + zz * 64 + lane];
-		bb[zz] = L.b[base + zz * 64 + lane];
+		bb[zz] = LD::ld(L.b + base + zz * 64 + lane);
 	}
 	MG_FENCE();
-	load_halo<real>(h, L.x, base, nb, lane, lx, ly);
+	load_halo<real, LD>(h, L.x, base, nb, lane, lx, ly);
 	MG_FENCE();
 	real pair[4];
 #pragma unroll
@@ -501,7 +525,7 @@ __device__ inline void residual_restrict_tile(const MgLv<real> &L, const GridDim
 		t += __shfl_xor(t, 1, 64);
 		t += __shfl_xor(t, 8, 64);
 		if (!(lx & 1) && !(ly & 1))
-			b_coarse[(size_t)ptile * 512 + ((tz & 1) * 4 + j) * 64 + ((ty & 1) * 4 + (ly >> 1)) * 8 + (tx & 1) * 4 + (lx >> 1)] = (real)0.5 * t;
+			ST::st(b_coarse + (size_t)ptile * 512 + ((tz & 1) * 4 + j) * 64 + ((ty & 1) * 4 + (ly >> 1)) * 8 + (tx & 1) * 4 + (lx >> 1), (real)0.5 * t);
 	}
 }
 
@@ -776,16 +800,93 @@ __global__ void __launch_bounds__(256) k_mg_residual_restrict(MgLv<real> L, Grid
 		residual_restrict_tile<real>(L, gc, b_coarse, slot, halo[wid], lane);
 }
 
+// ------------------------------------------------------------------------------------------------ two levels per launch
+// Level 1 (C4: 2 400 tiles) is too large for k_mg_coarse - whose workgroups must all be resident - and too small for launches of its
+// own: three of them cost 28 us of a 280 us iteration for a few microseconds of work. k_mg_down01 / k_mg_up01 run level 1's phases
+// inside the level-0 launches next to them. What replaces the kernel boundary between two phases is an ORDERED WORK QUEUE: the
+// waves take (phase, tile) items from one counter in phase order, an item of phase k waits until the count of finished items of
+// phase k - 1 is complete. No workgroup has to be resident for another to get on: whoever holds an item of an earlier phase is
+// running (it took the item), and finishes it without waiting for anything later - so the waits end whatever the occupancy, other
+// kernels on the device, or the number of handles (unlike a grid barrier, and unlike k_mg_coarse, which needs lfa_co_gate).
+// What a phase hands to the next inside the launch travels with agent-scope accesses (MemAgent: coherent across the XCDs' L2s).
+// The waits are bounded like k_mg_coarse's (co_poll_expired: abort word, the solve is repeated on the launch-per-phase path).
+// Queue words (lfa_mg::q, zero between launches - the last wave to leave clears them): [0] next item, [1] waves that have left,
+// [2], [3] finished items of the first / second phase.
+__device__ inline void co_backoff(int &n);
+__device__ inline bool co_poll_expired(int tries, unsigned long long &t0, int *abort_word);
+struct MgQueue {
+	int *q;
+	int *abort_word;
+};
+/// Lane 0's view of "phase complete": polls q[w] until it reaches n. false: given up (abort word raised).
+__device__ inline bool mq_wait(const MgQueue &Q, int w, int n) {
+	int ok = 1;
+	if ((threadIdx.x & 63) == 0) {
+		int tries = 0;
+		unsigned long long t0 = 0ull;
+		while (__hip_atomic_load(Q.q + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) {
+			co_backoff(tries);
+			if (co_poll_expired(tries, t0, Q.abort_word)) {
+				if (__hip_atomic_load(Q.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) Q.abort_word[16] = 0x300 | w;
+				__hip_atomic_store(Q.abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				ok = 0;
+				break;
+			}
+		}
+	}
+	return __shfl(ok, 0, 64) != 0;
+}
+/// The wave's stores of this item have been acknowledged; then the phase's count goes up.
+__device__ inline void mq_done(const MgQueue &Q, int w) {
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(Q.q + w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline int mq_take(const MgQueue &Q) {
+	int item = 0;
+	if ((threadIdx.x & 63) == 0) item = __hip_atomic_fetch_add(Q.q + 0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	return __builtin_amdgcn_readfirstlane(item);
+}
+/// Every wave, on its way out: the last one clears the queue for the next launch.
+__device__ inline void mq_leave(const MgQueue &Q, int n_waves) {
+	if ((threadIdx.x & 63) == 0 && __hip_atomic_fetch_add(Q.q + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_waves - 1) {
+		__hip_atomic_store(Q.q + 0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__hip_atomic_store(Q.q + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__hip_atomic_store(Q.q + 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__hip_atomic_store(Q.q + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+}
+
 /// LEVEL0: the result is scaled by 1/scale and dot(z, r) is formed.
-template <typename real, bool LEVEL0, int MW>
+/// UP1 (with LEVEL0; see "two levels per launch" above): level 1's prolongation + post-smoothing runs in this launch first - the
+/// waves take its tiles from the queue, `e` (level 1's result) is complete when the count of finished tiles is, and is read
+/// with agent-scope loads. Same arithmetic per tile as the launch of its own: bit-identical results.
+template <typename real, bool LEVEL0, int MW, bool UP1 = false>
 __global__ void __launch_bounds__(256, MW)
-k_mg_prolong_postsmooth(MgLv<real> L, GridDims gc, const real *e, real inv_scale, double *part_sigma, const int *state) {
+k_mg_prolong_postsmooth(MgLv<real> L, GridDims gc, const real *e, real inv_scale, double *part_sigma, const int *state, MgLv<real> L1,
+                        GridDims g2, const real *e2, MgQueue Q) {
 	__shared__ real halo[PCG_WAVES][LFA_HALO_CELLS];
 	__shared__ double red[4];
 	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
 	real *h = halo[wid];
 	double acc = 0.0;
-	if (state[0] < 0) {
+	bool run = state[0] < 0;
+	if (UP1 && run) {
+		const int lxx = lane & 7, lyy = lane >> 3;
+		int item = mq_take(Q);
+		while (item < L1.n_tiles) {
+			const int next = mq_take(Q);
+			real bb1[8];
+			prolong_postsmooth_tile<real>(L1, g2, e2, item, h, lane, bb1, MG_INNER_SWEEPS);
+			const size_t b1 = (size_t)L1.nbr[(size_t)item * MG_NBR_STRIDE + 6] * 512;
+#pragma unroll
+			for (int zz = 0; zz < 8; ++zz) MemAgent::st(L1.y + b1 + zz * 64 + lane, h[(lxx + 1) + 10 * (lyy + 1) + 100 * (zz + 1)]);
+			mq_done(Q, 2);
+			item = next;
+		}
+		run = mq_wait(Q, 2, L1.n_tiles);
+		MG_FENCE();
+	}
+	if (run) {
 		// The body of prolong_postsmooth_tile as a software pipeline: every load of the wave's next tile (column, ring, the
 		// parents' corrections) is in flight while the current tile is swept in LDS.
 		const int stride = gridDim.x * PCG_WAVES;
@@ -800,7 +901,11 @@ k_mg_prolong_postsmooth(MgLv<real> L, GridDims gc, const real *e, real inv_scale
 			base = (size_t)tile * 512;
 			int tx_, ty_, tz_;
 			tile_coords(L.g, tile, tx_, ty_, tz_);
-			auto corr = [&](int X, int Y, int Z) -> real { return e ? e[blocked_index(gc, X >> 1, Y >> 1, Z >> 1)] : (real)0; };
+			auto corr = [&](int X, int Y, int Z) -> real {
+				if (!e) return (real)0;
+				const real *q = e + blocked_index(gc, X >> 1, Y >> 1, Z >> 1);
+				return UP1 ? MemAgent::ld(q) : *q;
+			};
 #pragma unroll
 			for (int zz = 0; zz < 8; ++zz) {
 				tab[zz] = L.abits[base + zz * 64 + lane];
@@ -878,6 +983,51 @@ k_mg_prolong_postsmooth(MgLv<real> L, GridDims gc, const real *e, real inv_scale
 		__syncthreads();
 		if (threadIdx.x == 0) part_sigma[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 	}
+	if (UP1) mq_leave(Q, (int)gridDim.x * PCG_WAVES);
+}
+
+/// Down: level 0's residual + restriction, level 1's pre-smoothing, level 1's residual + restriction - three launches before.
+/// Items [0, n0): a level-0 tile; [n0, n0 + n1): pre-smoothing of a level-1 tile (needs every restricted value: phase 0 complete);
+/// [n0 + n1, n0 + 2 n1): its residual (needs the neighbours' pre-smoothed iterate: phase 1 complete). Same arithmetic per tile as
+/// k_mg_residual_restrict / k_mg_presmooth: bit-identical results.
+template <typename real>
+__global__ void __launch_bounds__(256) k_mg_down01(MgLv<real> L0, MgLv<real> L1, GridDims g2, real *b2, MgQueue Q, const int *state) {
+	__shared__ real halo[PCG_WAVES][LFA_HALO_CELLS];
+	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	real *h = halo[wid];
+	const int n0 = L0.n_tiles, n1 = L1.n_tiles;
+	if (state[0] < 0) {
+		int phase = 0;
+		bool ok = true;
+		int item = mq_take(Q);
+		while (ok && item < n0 + 2 * n1) {
+			const int next = mq_take(Q);  // (in flight while this item is worked on)
+			if (item < n0) {
+				residual_restrict_tile<real, MemPlain, MemAgent>(L0, L1.g, L1.b, item, h, lane);
+				mq_done(Q, 2);
+			} else if (item < n0 + n1) {
+				if (phase < 1) {
+					ok = mq_wait(Q, 2, n0);
+					phase = 1;
+					MG_FENCE();
+					for (int i = lane; i < LFA_HALO_CELLS; i += 64) h[i] = (real)0;  // the ring stays zero through the pre-smoothing
+					MG_FENCE();
+				}
+				if (ok) presmooth_tile<real, MemAgent, MemAgent>(L1, item - n0, h, lane, MG_INNER_SWEEPS);
+				mq_done(Q, 3);
+			} else {
+				if (phase < 2) {
+					if (phase < 1) ok = mq_wait(Q, 2, n0);
+					if (ok) ok = mq_wait(Q, 3, n1);
+					phase = 2;
+					MG_FENCE();
+				}
+				if (ok) residual_restrict_tile<real, MemAgent, MemPlain>(L1, g2, b2, item - n0 - n1, h, lane);
+			}
+			item = next;
+		}
+	}
+	mq_leave(Q, (int)gridDim.x * PCG_WAVES);
 }
 
 /// gs_colour for ONE cell (halo index i): the same expression, term by term.
@@ -910,25 +1060,6 @@ template <typename real> __device__ inline void cp_half_sweep(CpTile<real> &S, i
 	__syncthreads();
 }
 __device__ inline int cp_hi(int cell) { return ((cell & 7) + 1) + 10 * (((cell >> 3) & 7) + 1) + 100 * ((cell >> 6) + 1); }
-
-/// How a kernel reaches the level arrays other workgroups write. MemPlain: ordinary accesses (one launch per phase, the kernel
-/// boundary makes them visible). MemAgent: agent-scope relaxed atomics (`sc1` on gfx950: the access is coherent across the eight
-/// per-XCD L2s by itself, no bulk write-back / invalidate) - what lets k_mg_coarse run its phases inside ONE launch.
-struct MemPlain {
-	template <typename T> static __device__ inline T ld(const T *p) { return *p; }
-	template <typename T> static __device__ inline void st(T *p, T v) { *p = v; }
-};
-struct MemAgent {
-	template <typename T> static __device__ inline T ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-	template <typename T> static __device__ inline void st(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-};
-/// Workgroup-scope relaxed atomics (`sc0`: the access bypasses the CU's L1 and meets the others in the L2) - enough, and half the
-/// round trip of `sc1`, when every workgroup that takes part sits on ONE XCD and so shares one L2 (k_mg_coarse's XCD mode; the
-/// ready flags carry the producer's XCC id, so a consumer on another XCD notices before it reads anything).
-struct MemWg {
-	template <typename T> static __device__ inline T ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-	template <typename T> static __device__ inline void st(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-};
 
 /// Down, one tile, a workgroup of 256: x = `inner` red->black sweeps on A x = b from x = 0.
 template <typename real, typename MEM> __device__ inline void cp_presmooth_tile(CpTile<real> &S, const MgLv<real> &L, int slot, int inner) {
@@ -1982,6 +2113,15 @@ template <typename real, typename... Args> static void launch_axpy_presmooth(int
 	default: hipLaunchKernelGGL((k_mg_axpy_presmooth<real, 1>), dim3(G), dim3(256), 0, st, a...); break;
 	}
 }
+template <typename real, typename... Args> static void launch_up01(int mw, int G, hipStream_t st, Args... a) {
+	switch (mw >= 0 ? mw : MG_MW_DEFAULT_U) {
+	case 4: hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true, 4, true>), dim3(G), dim3(256), 0, st, a...); break;
+	case 5: hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true, 5, true>), dim3(G), dim3(256), 0, st, a...); break;
+	case 6: hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true, 6, true>), dim3(G), dim3(256), 0, st, a...); break;
+	case 8: hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true, 8, true>), dim3(G), dim3(256), 0, st, a...); break;
+	default: hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true, 1, true>), dim3(G), dim3(256), 0, st, a...); break;
+	}
+}
 template <typename real, typename... Args> static void launch_up0(int mw, int G, hipStream_t st, Args... a) {
 	switch (mw >= 0 ? mw : MG_MW_DEFAULT_U) {
 	case 4: hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true, 4>), dim3(G), dim3(256), 0, st, a...); break;
@@ -2059,6 +2199,7 @@ void lfa_mg_free(lfa_sim *s) {
 	if (s->mg->l1_dirty) (void)hipFree(s->mg->l1_dirty);
 	if (s->mg->counts) (void)hipFree(s->mg->counts);
 	if (s->mg->ps_part) (void)hipFree(s->mg->ps_part);
+	if (s->mg->q) (void)hipFree(s->mg->q);
 	if (s->mg->co_stamps) {
 		unsigned long long h[3 * MG_CO_PHASES];
 		if (hipMemcpy(h, s->mg->co_stamps, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -2418,7 +2559,8 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 	if (last == 0) {  // a single level: the two sweeps alone
 		const MgLv<real> L = lvl(0);
 		if (!level0_presmoothed) hipLaunchKernelGGL(k_mg_presmooth<real>, dim3(1), dim3(256), 0, s->stream, L, st);
-		launch_up0<real>(s->knobs.mg_mw_u, 1, s->stream, L, L.g, (const real *)nullptr, inv_scale, part_sigma, st);
+		launch_up0<real>(s->knobs.mg_mw_u, 1, s->stream, L, L.g, (const real *)nullptr, inv_scale, part_sigma, st, MgLv<real>{}, GridDims{},
+		                 (const real *)nullptr, MgQueue{nullptr, nullptr});
 		LFA_LAUNCH_CHECK(s);
 		return LFA_OK;
 	}
@@ -2529,12 +2671,30 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		return lfa_dist_exchange_layer_slices(s, vec, (int)sizeof(real), M.lv[l].g.ntx * M.lv[l].g.nty, M.lv[l].lo_layer, M.lv[l].hi_layer);
 	};
 	int launches = 0;
+	// OPT-IN (LFA_MG_MERGE=1, measured slower - see lfa_knobs::mg_merge): level 1's three phases inside the level-0 launches next to
+	// them (k_mg_down01 / k_mg_up01: an ordered work queue in place of the kernel boundaries; nothing has to be resident). Single
+	// domain, the whole cycle, level 1 not inside k_mg_coarse already.
+	const bool merge01 = persist && s->knobs.mg_merge && D == 0 && tail >= 2 && top != 1 && parts == MG_PART_ALL && level0_presmoothed &&
+	                     M.lv[0].n_tiles > 0 && M.lv[1].n_tiles > 0;
+	if (merge01 && !M.q) {
+		LFA_HIP(s, hipMalloc(&M.q, 16 * sizeof(int)));
+		LFA_HIP(s, hipMemsetAsync(M.q, 0, 16 * sizeof(int), s->stream));
+	}
 	for (int l = 0; l < tail; ++l) {
 		const MgLv<real> L = lvl(l);
 		const int G = mg_grid(L.n_tiles);
 		const bool cp = l >= 1 && !s->knobs.mg_no_cp && L.n_tiles <= cp_max;  // a workgroup per tile on the coarser levels (see k_mg_*_cp)
 		const int Gcp = std::max(1, std::min(L.n_tiles, 8192));  // (a slab rank may hold no tile of a level)
 		if (l == top) continue;  // (inside k_mg_coarse)
+		if (merge01 && l <= 1) {
+			if (l == 0) {
+				hipLaunchKernelGGL(k_mg_down01<real>, dim3(G), dim3(256), 0, s->stream, L, lvl(1), M.lv[2].g, (real *)M.lv[2].b,
+				                   MgQueue{M.q, s->pcg_state + 2}, st);
+				LFA_LAUNCH_CHECK(s);
+				++launches;
+			}
+			continue;
+		}
 		if (!(l == 0 && level0_presmoothed) && (parts & (l == 0 ? MG_PART_PRE0 : MG_PART_COARSE))) {
 			if (cp) hipLaunchKernelGGL(k_mg_presmooth_cp<real>, dim3(Gcp), dim3(256), 0, s->stream, L, MG_INNER_SWEEPS, st);
 			else hipLaunchKernelGGL(k_mg_presmooth<real>, dim3(G), dim3(256), 0, s->stream, L, st);
@@ -2625,14 +2785,20 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		const int G = mg_grid(L.n_tiles);
 		if (l == top) continue;  // (inside k_mg_coarse)
 		if (!(parts & (l == 0 ? MG_PART_UP0 : MG_PART_COARSE))) continue;
-		if (l == 0)
-			launch_up0<real>(s->knobs.mg_mw_u, G, s->stream, L, M.lv[1].g, (const real *)M.lv[1].y, inv_scale, part_sigma, st);
+		if (merge01 && l == 1) continue;  // (inside level 0's launch)
+		if (l == 0 && merge01)
+			launch_up01<real>(s->knobs.mg_mw_u, G, s->stream, L, M.lv[1].g, (const real *)M.lv[1].y, inv_scale, part_sigma, st, lvl(1), M.lv[2].g,
+			                  (const real *)M.lv[2].y, MgQueue{M.q + 8, s->pcg_state + 2});
+		else if (l == 0)
+			launch_up0<real>(s->knobs.mg_mw_u, G, s->stream, L, M.lv[1].g, (const real *)M.lv[1].y, inv_scale, part_sigma, st, MgLv<real>{}, GridDims{},
+			                 (const real *)nullptr, MgQueue{nullptr, nullptr});
 		else if (!s->knobs.mg_no_cp && L.n_tiles <= cp_max)
 			hipLaunchKernelGGL(k_mg_prolong_postsmooth_cp<real>, dim3(std::max(1, std::min(L.n_tiles, 8192))), dim3(256), 0, s->stream, L, M.lv[l + 1].g,
 			                   (const real *)M.lv[l + 1].y, MG_INNER_SWEEPS, st);
 		else
 			hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, false, 1>), dim3(G), dim3(256), 0, s->stream, L, M.lv[l + 1].g,
-			                   (const real *)M.lv[l + 1].y, (real)1, (double *)nullptr, st);
+			                   (const real *)M.lv[l + 1].y, (real)1, (double *)nullptr, st, MgLv<real>{}, GridDims{}, (const real *)nullptr,
+			                   MgQueue{nullptr, nullptr});
 		LFA_LAUNCH_CHECK(s);
 		++launches;
 		// the finer level corrects its ring cells across a slab face with this level's result there

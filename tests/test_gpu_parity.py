@@ -591,6 +591,37 @@ def test_multigrid_level_above_the_coarse_launch_inside_it_is_bitwise_the_launch
 
 
 @pytest.mark.parametrize("dtype", [lfa.PCG_F32, lfa.PCG_F64])
+@pytest.mark.parametrize("co_max", [40, 4])
+def test_multigrid_level_one_inside_the_level_zero_launches_is_bitwise_the_launches_of_its_own(dtype, co_max, monkeypatch):
+    """k_mg_down01 / k_mg_up01 (round 4, opt-in LFA_MG_MERGE=1: correct and slower): level 1's pre-smoothing, residual + restriction
+    and prolongation + post-smoothing run inside the level-0 launches next to them, an ordered work queue in place of the kernel
+    boundaries (mg.hip: "two levels per launch"). Same arithmetic per tile: against the launches of their own the iteration
+    counts and the pressures are identical, and an iteration makes three launches less."""
+    size, block = (136, 72, 104), ((0, 0, 0), (90, 50, 70))
+    res = []
+    for merge in (True, False):
+        monkeypatch.setenv("LFA_MG_CO_MAX_TILES", str(co_max))
+        if merge:
+            monkeypatch.setenv("LFA_MG_MERGE", "1")
+        else:
+            monkeypatch.delenv("LFA_MG_MERGE", raising=False)
+        s = lfa.Sim(size, precond=lfa.PRECOND_MULTIGRID, pcg_dtype=dtype)
+        s.seed_block(*block)
+        its = []
+        for _ in range(3):
+            r, it, rc = s.step_hot(util.DT)
+            assert rc == 0
+            its.append(it)
+        st = s.solver_stats()
+        assert st["device_waits_given_up"] == 0, st
+        res.append((its, s.pressure().copy(), st["launches_per_iteration"]))
+        s.close()
+    assert res[0][0] == res[1][0] and min(res[0][0]) > 3
+    assert np.array_equal(res[0][1], res[1][1])
+    assert res[0][2] + 3 == res[1][2], (res[0][2], res[1][2])
+
+
+@pytest.mark.parametrize("dtype", [lfa.PCG_F32, lfa.PCG_F64])
 @pytest.mark.parametrize("co_max", [None, 1000000, 40, 4, 1])
 def test_multigrid_single_launch_coarse_levels_are_bitwise_the_launch_per_phase_path(dtype, co_max, monkeypatch):
     """k_mg_coarse runs every phase of the coarse levels (pre-smoothing, residual + restriction, coarsest solve, prolongation +
