@@ -162,7 +162,7 @@ def build_sim(args, cfg, lfa, torch, dist, tdev, rank, world, local_rank, n_dev,
                 # (the ghost-particle exchange of a slab face is the largest message: ~16 B per particle of one tile layer)
                 need_mb = int(16 * (bhi[0] - blo[0]) * (bhi[1] - blo[1]) * 8 * 8 * 2 / 2**20) + 8
                 transport_note = (f"RCCL communicator could not be created ({err or 'failed on another rank'}): host-staged fallback "
-                                  f"(needs LFA_SHM_SLOT_MB >= {need_mb} at this size)")
+                                  f"(LFA_SHM_SLOT_MB >= {need_mb} carries every message of this size in one round; smaller slots take several)")
                 os.environ.setdefault("LFA_SHM_SLOT_MB", str(max(32, need_mb)))
                 if rank == 0:
                     print(f"bench.py: {transport_note}", file=sys.stderr)

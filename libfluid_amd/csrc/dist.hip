@@ -664,6 +664,7 @@ struct RcclApi {
 	ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
 	ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
 	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+	ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // (optional)
 	ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
 	ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
 	ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
@@ -679,7 +680,7 @@ struct RcclApi {
 		if (!lib) return false;
 #define LOAD(f) f = (decltype(f))dlsym(lib, "nccl" #f)
 		LOAD(GetUniqueId); LOAD(CommInitRank); LOAD(CommDestroy); LOAD(Send); LOAD(Recv); LOAD(AllReduce);
-		LOAD(GroupStart); LOAD(GroupEnd); LOAD(GetErrorString);
+		LOAD(GroupStart); LOAD(GroupEnd); LOAD(GetErrorString); LOAD(CommAbort);
 #undef LOAD
 		return GetUniqueId && CommInitRank && CommDestroy && Send && Recv && AllReduce && GroupStart && GroupEnd;
 	}
@@ -689,7 +690,9 @@ RcclApi g_rccl;
 struct RcclDist : lfa_dist {
 	ncclComm_t comm = nullptr;
 	~RcclDist() override {
-		if (comm) g_rccl.CommDestroy(comm);
+		// (ncclCommAbort where the library has it: it releases the communicator without waiting for the peers - a handle is also
+		// closed when the job falls back to another transport because a PEER could not create its communicator, bench.py)
+		if (comm) (void)(g_rccl.CommAbort ? g_rccl.CommAbort(comm) : g_rccl.CommDestroy(comm));
 	}
 #define NCCL_TRY(s, call)                                                                                \
 	do {                                                                                                  \
@@ -792,57 +795,70 @@ struct ShmDist : lfa_dist {
 	                  size_t n_send_hi, void *recv_hi, size_t n_recv_hi) override {
 		if (rank == 0) n_send_lo = 0;  // as over RCCL: nothing leaves through a face without a neighbour
 		if (rank + 1 == nranks) n_send_hi = 0;
+		// Sizes first; then the messages in rounds of half a slot per direction (lo part at 0, hi part at half a slot) - a message
+		// larger than that (the ghost particles of the fixed C4 domain: 34 MB per face) takes several rounds, the same number on
+		// every rank: the maximum over everybody's posted sizes.
 		int rc = LFA_OK;
-		if (n_send_lo + n_send_hi > slot_bytes) {
-			rc = lfa_fail(s, LFA_E_INVALID, "slab exchange of %zu bytes does not fit the shared-memory slot (%zu; LFA_SHM_SLOT_MB)",
-			              n_send_lo + n_send_hi, slot_bytes);
-		} else {
+		mail[rank].n_lo = n_send_lo;
+		mail[rank].n_hi = n_send_hi;
+		if (!barrier()) return lfa_fail(s, LFA_E_HIP, "slab exchange: a peer rank failed or timed out");
+		if (rank > 0 && mail[rank - 1].n_hi != n_recv_lo)
+			rc = lfa_fail(s, LFA_E_INVALID, "slab exchange size mismatch with rank %d: %zu vs %zu", rank - 1, (size_t)mail[rank - 1].n_hi, n_recv_lo);
+		if (rank + 1 < nranks && rc == LFA_OK && mail[rank + 1].n_lo != n_recv_hi)
+			rc = lfa_fail(s, LFA_E_INVALID, "slab exchange size mismatch with rank %d: %zu vs %zu", rank + 1, (size_t)mail[rank + 1].n_lo, n_recv_hi);
+		const size_t half = (slot_bytes / 2) & ~(size_t)255;
+		size_t longest = 0;
+		for (int r = 0; r < nranks; ++r) longest = std::max(longest, std::max((size_t)mail[r].n_lo, (size_t)mail[r].n_hi));
+		const size_t rounds = longest ? (longest + half - 1) / half : 0;
+		if (rc != LFA_OK) fail();
+		auto part = [&](size_t total, size_t off) { return off < total ? std::min(half, total - off) : (size_t)0; };
+		for (size_t k = 0; k < rounds; ++k) {
+			const size_t off = k * half;
 			uint8_t *mine = slot(rank);
-			if (n_send_lo && hipMemcpyAsync(mine, send_lo, n_send_lo, hipMemcpyDeviceToHost, s->stream) != hipSuccess) rc = LFA_E_HIP;
-			if (n_send_hi && hipMemcpyAsync(mine + n_send_lo, send_hi, n_send_hi, hipMemcpyDeviceToHost, s->stream) != hipSuccess)
-				rc = LFA_E_HIP;
-			if (hipStreamSynchronize(s->stream) != hipSuccess) rc = LFA_E_HIP;
-			mail[rank].n_lo = n_send_lo;
-			mail[rank].n_hi = n_send_hi;
+			const size_t a = part(n_send_lo, off), b = part(n_send_hi, off);
+			if (rc == LFA_OK) {
+				if (a && hipMemcpyAsync(mine, (const uint8_t *)send_lo + off, a, hipMemcpyDeviceToHost, s->stream) != hipSuccess) rc = LFA_E_HIP;
+				if (b && hipMemcpyAsync(mine + half, (const uint8_t *)send_hi + off, b, hipMemcpyDeviceToHost, s->stream) != hipSuccess) rc = LFA_E_HIP;
+				if ((a || b) && hipStreamSynchronize(s->stream) != hipSuccess) rc = LFA_E_HIP;
+				if (rc != LFA_OK) fail();
+			}
+			if (!barrier()) return rc != LFA_OK ? rc : lfa_fail(s, LFA_E_HIP, "slab exchange: a peer rank failed or timed out");
+			const size_t c = rank > 0 ? part(n_recv_lo, off) : 0, d = rank + 1 < nranks ? part(n_recv_hi, off) : 0;
+			if (c && hipMemcpyAsync((uint8_t *)recv_lo + off, slot(rank - 1) + half, c, hipMemcpyHostToDevice, s->stream) != hipSuccess) rc = LFA_E_HIP;
+			if (d && hipMemcpyAsync((uint8_t *)recv_hi + off, slot(rank + 1), d, hipMemcpyHostToDevice, s->stream) != hipSuccess) rc = LFA_E_HIP;
+			if ((c || d) && hipStreamSynchronize(s->stream) != hipSuccess) rc = LFA_E_HIP;
+			if (rc != LFA_OK) fail();
+			if (!barrier() && rc == LFA_OK)  // nobody overwrites its slot before every copy out of it is done
+				rc = lfa_fail(s, LFA_E_HIP, "slab exchange: a peer rank failed or timed out");
+			if (rc != LFA_OK) return rc;
 		}
-		if (rc != LFA_OK) fail();
-		if (!barrier()) return rc != LFA_OK ? rc : lfa_fail(s, LFA_E_HIP, "slab exchange: a peer rank failed or timed out");
-		if (rank > 0) {
-			const ShmMail &nb = mail[rank - 1];
-			if (nb.n_hi != n_recv_lo)
-				rc = lfa_fail(s, LFA_E_INVALID, "slab exchange size mismatch with rank %d: %zu vs %zu", rank - 1, (size_t)nb.n_hi, n_recv_lo);
-			else if (n_recv_lo &&
-			         hipMemcpyAsync(recv_lo, slot(rank - 1) + nb.n_lo, n_recv_lo, hipMemcpyHostToDevice, s->stream) != hipSuccess)
-				rc = LFA_E_HIP;
-		}
-		if (rank + 1 < nranks && rc == LFA_OK) {
-			const ShmMail &nb = mail[rank + 1];
-			if (nb.n_lo != n_recv_hi)
-				rc = lfa_fail(s, LFA_E_INVALID, "slab exchange size mismatch with rank %d: %zu vs %zu", rank + 1, (size_t)nb.n_lo, n_recv_hi);
-			else if (n_recv_hi && hipMemcpyAsync(recv_hi, slot(rank + 1), n_recv_hi, hipMemcpyHostToDevice, s->stream) != hipSuccess)
-				rc = LFA_E_HIP;
-		}
-		if (rc == LFA_OK && hipStreamSynchronize(s->stream) != hipSuccess) rc = LFA_E_HIP;
-		if (rc != LFA_OK) fail();
-		if (!barrier() && rc == LFA_OK)  // nobody overwrites its slot before every copy out of it is done
-			rc = lfa_fail(s, LFA_E_HIP, "slab exchange: a peer rank failed or timed out");
+		// (an empty exchange still ends with a barrier: nobody posts the sizes of its next message while a peer reads these)
+		if (!rounds && !barrier() && rc == LFA_OK) rc = lfa_fail(s, LFA_E_HIP, "slab exchange: a peer rank failed or timed out");
 		return rc;
 	}
 	int allreduce_impl(lfa_sim *s, double *dev, int count, bool is_max) override {
 		return allreduce_buf_impl(s, dev, (size_t)count, LFA_RED_F64, is_max);
 	}
 	int allreduce_buf_impl(lfa_sim *s, void *dev, size_t count, int dtype, bool is_max) override {
+		const size_t es = dtype == LFA_RED_U8 ? 1 : (dtype == LFA_RED_F32 ? 4 : 8);
+		// (an array larger than the slot goes through in slot-sized pieces: the count is the same on every rank, so are the rounds)
+		const size_t per = (slot_bytes / es) & ~(size_t)63;
+		size_t first = 0;
+		do {
+			const size_t n = std::min(per, count - first);
+			const int rc = allreduce_piece(s, (uint8_t *)dev + first * es, n, dtype, is_max);
+			if (rc != LFA_OK) return rc;
+			first += n;
+		} while (first < count);
+		return LFA_OK;
+	}
+	int allreduce_piece(lfa_sim *s, void *dev, size_t count, int dtype, bool is_max) {
 		const size_t es = dtype == LFA_RED_U8 ? 1 : (dtype == LFA_RED_F32 ? 4 : 8), bytes = count * es;
 		int rc = LFA_OK;
-		if (bytes > slot_bytes) {
-			rc = lfa_fail(s, LFA_E_INVALID, "slab all-reduce of %zu bytes does not fit the shared-memory slot (%zu; LFA_SHM_SLOT_MB)", bytes,
-			              slot_bytes);
-		} else {
-			if (hipMemcpyAsync(slot(rank), dev, bytes, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
-			    hipStreamSynchronize(s->stream) != hipSuccess)
-				rc = LFA_E_HIP;
-			mail[rank].n_buf = bytes;
-		}
+		if (bytes && (hipMemcpyAsync(slot(rank), dev, bytes, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+		              hipStreamSynchronize(s->stream) != hipSuccess))
+			rc = LFA_E_HIP;
+		mail[rank].n_buf = bytes;
 		if (rc != LFA_OK) fail();
 		if (!barrier()) return rc != LFA_OK ? rc : lfa_fail(s, LFA_E_HIP, "slab all-reduce: a peer rank failed or timed out");
 		acc.resize(bytes);
@@ -869,21 +885,24 @@ struct ShmDist : lfa_dist {
 		}
 		if (!ok) fail();
 		if (!barrier() || !ok) return lfa_fail(s, LFA_E_HIP, "slab all-reduce: size mismatch or a peer rank failed");
-		LFA_HIP(s, hipMemcpyAsync(dev, acc.data(), bytes, hipMemcpyHostToDevice, s->stream));
-		LFA_HIP(s, hipStreamSynchronize(s->stream));
+		if (bytes) {
+			LFA_HIP(s, hipMemcpyAsync(dev, acc.data(), bytes, hipMemcpyHostToDevice, s->stream));
+			LFA_HIP(s, hipStreamSynchronize(s->stream));
+		}
 		return LFA_OK;
 	}
 	/// rank 0 creates the segment, the others wait for it; false with `why` set when it cannot be had
 	bool open(const char *name, int device, const char **why) {
-		size_t mb = 32;
+		size_t mb = 32, kb = 0;
 		if (const char *e = getenv("LFA_SHM_SLOT_MB")) mb = (size_t)std::max(1, atoi(e));
+		if (const char *e = getenv("LFA_SHM_SLOT_KB")) kb = (size_t)std::max(4, atoi(e));  // (tests: messages in several rounds)
 		const size_t head = 4096 + (((size_t)nranks * sizeof(ShmMail) + 4095) & ~(size_t)4095);
 		int fd = -1;
 		if (rank == 0) {
 			shm_unlink(name);
 			fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
 			if (fd < 0) { *why = "shm_open (create) failed"; return false; }
-			slot_bytes = mb << 20;
+			slot_bytes = kb ? kb << 10 : mb << 20;
 			map_bytes = head + (size_t)nranks * slot_bytes;
 			// posix_fallocate, not only ftruncate: a segment larger than /dev/shm must fail here, not with SIGBUS at the first touch
 			if (ftruncate(fd, (off_t)map_bytes) != 0 || posix_fallocate(fd, 0, (off_t)map_bytes) != 0) {

@@ -571,7 +571,7 @@ def test_fixed_c4_domain_on_eight_virtual_slabs():
     hub.close()
 
 
-def run_shm_processes(size, block, method, bounds, hot_steps, full_steps, tmp_path, precond, pcg_dtype):
+def run_shm_processes(size, block, method, bounds, hot_steps, full_steps, tmp_path, precond, pcg_dtype, env=None):
     """One PROCESS per slab over the shared-memory transport, all of them on this box's GPU (tests/shm_slab_worker.py)."""
     import json
     import subprocess
@@ -584,7 +584,7 @@ def run_shm_processes(size, block, method, bounds, hot_steps, full_steps, tmp_pa
         spec = dict(size=list(size), block=[list(block[0]), list(block[1])], method=method, bounds=list(bounds), rank=r, name=name,
                     hot_steps=hot_steps, full_steps=full_steps, precond=precond, pcg_dtype=pcg_dtype, out=str(tmp_path / f"rank{r}.npz"))
         procs.append(subprocess.Popen([sys.executable, "-m", "tests.shm_slab_worker", json.dumps(spec)], cwd=root,
-                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(os.environ, **(env or {}))))
     outs = []
     for p in procs:
         try:
@@ -599,14 +599,17 @@ def run_shm_processes(size, block, method, bounds, hot_steps, full_steps, tmp_pa
 
 
 @pytest.mark.parametrize("precond,dtype", [(lfa.PRECOND_MIC0_TILED, lfa.PCG_F64), (lfa.PRECOND_MULTIGRID, lfa.PCG_F32)])
-@pytest.mark.parametrize("bounds", [[0, 2, 4], [0, 1, 2, 4]])
-def test_shared_memory_transport_between_processes(bounds, precond, dtype, tmp_path):
+@pytest.mark.parametrize("bounds,slot_kb", [([0, 2, 4], None), ([0, 1, 2, 4], None), ([0, 1, 2, 4], 8)])
+def test_shared_memory_transport_between_processes(bounds, slot_kb, precond, dtype, tmp_path):
     """The N > 1 protocol with one process per rank (as bench.py --gpus N runs it): the shared-memory transport carries the
     same packed messages as the in-process one and reduces in the same rank order, so the hot path agrees with the
-    virtual-slab run bit for bit; the full steps (position correction uses atomics) agree to the slab tolerances."""
+    virtual-slab run bit for bit; the full steps (position correction uses atomics) agree to the slab tolerances.
+    slot_kb = 8: a staging slot of 8 KB per rank - field slices, ghost particles and the multigrid's array all-reduce are larger and
+    go through in several rounds (what the fixed C4 domain needs with the default 32 MB)."""
     size, block = (16, 16, 32), ((2, 0, 2), (14, 12, 16))
     kw = dict(precond=precond, pcg_dtype=dtype)
-    ranks = run_shm_processes(size, block, lfa.APIC, bounds, 3, 5, tmp_path, precond, dtype)
+    ranks = run_shm_processes(size, block, lfa.APIC, bounds, 3, 5, tmp_path, precond, dtype,
+                              env={"LFA_SHM_SLOT_KB": str(slot_kb)} if slot_kb else None)
     cells_v, parts_v, iters_v = run_slabs(size, block, lfa.APIC, 3, bounds, **kw)
     nx, ny, nz = size
     cells = np.zeros(nx * ny * nz, dtype=lfa.CELL_DTYPE)
