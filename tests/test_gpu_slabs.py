@@ -780,3 +780,72 @@ def test_single_reduction_cg_matches_the_textbook_form_on_slabs(monkeypatch):
     util.assert_close(a["parts"]["vel"], b["parts"]["vel"], 1e-3, "velocities", atol=1e-3 * 981.0 * util.DT)
     ca, cb = a["stats"]["transport_calls_per_iteration"], b["stats"]["transport_calls_per_iteration"]
     assert ca + 1 == cb, (ca, cb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", [lfa.PIC, lfa.FLIP_BLEND])
+def test_slab_migration_carries_c_of_pic_and_flip_particles(method):
+    """PIC / FLIP never touch a particle's C (the reference's transfers leave cx, cy, cz alone), so it stays in a home array indexed
+    by the job-wide particle id - on slabs too (round 4) - and a particle that changes ranks takes its nine floats along in the
+    migration record, while the deferred half of the binning (v) is read where it lies. Every particle is uploaded with its own
+    index written into C; after steps in which thousands of them cross the slab face every rank's download must show, for each
+    resident id, exactly that id's C - and velocities that match the single domain's."""
+    size, block, bounds = (64, 32, 32), ((0, 0, 0), (64, 24, 15)), [0, 2, 4]
+    parts = util.scenes.seed_block(*block)
+    n = len(parts)
+    tag = np.arange(n, dtype=np.float64)
+    parts["cx"][:, 0] = tag
+    parts["cy"][:, 1] = -tag
+    parts["cz"][:, 2] = 0.5 * tag
+    kw = dict(precond=lfa.PRECOND_MULTIGRID, blending=0.95)
+
+    one = lfa.Sim(size, method=method, **kw)
+    one.upload_particles(parts)
+    for _ in range(6):
+        assert one.time_step(util.DT)[2] == 0
+    ref = one.download_particles()[np.argsort(one.particle_ids())]
+    one.close()
+
+    nr = len(bounds) - 1
+    hub = lfa.LocalHub(nr)
+    sims = []
+    for r in range(nr):
+        s = lfa.Sim(size, method=method, **kw)
+        s.init_local_slab(hub.h, r, bounds)
+        s.upload_particles(parts)  # (every rank is handed the whole set and keeps what lies in its layers)
+        sims.append(s)
+    before = [s.num_particles for s in sims]
+    errors = []
+
+    def worker(r):
+        try:
+            for _ in range(6):
+                assert sims[r].time_step(util.DT)[2] == 0
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(nr)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    got, ids = [], []
+    for s in sims:
+        got.append(s.download_particles())
+        ids.append(s.particle_ids())
+    after = [len(g) for g in got]
+    for s in sims:
+        s.close()
+    hub.close()
+    assert abs(after[1] - before[1]) > 1000, (before, after)
+    got, ids = np.concatenate(got), np.concatenate(ids)
+    assert len(ids) == n and len(np.unique(ids)) == n
+    idf = ids.astype(np.float64)
+    assert np.array_equal(got["cx"][:, 0], idf) and np.array_equal(got["cy"][:, 1], -idf) and np.array_equal(got["cz"][:, 2], 0.5 * idf)
+    assert not got["cx"][:, 1:].any() and not got["cz"][:, :2].any()
+    got = got[np.argsort(ids)]
+    assert np.abs(got["pos"] - ref["pos"]).max() < 5e-3
+    util.assert_close(got["vel"], ref["vel"], 1e-2, "velocities, slabs vs single domain", atol=2e-3 * 981.0 * util.DT)
+    # (and the single domain kept its tags as well)
+    assert np.array_equal(ref["cx"][:, 0], tag)
