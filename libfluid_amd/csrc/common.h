@@ -77,6 +77,7 @@ struct lfa_knobs {
 	int bin_shuffle = 0;      // LFA_BIN_SHUFFLE=1 (round-3 binning only)
 	int p2g_no_rot = 0;       // LFA_P2G_NO_ROT=1
 	int dist_two_reductions = 0;  // LFA_DIST_TWO_REDUCTIONS=1: slab runs keep the textbook PCG (dot(q,s) in a collective of its own)
+	int corr_lds_pad = 0;     // LFA_CORR_LDS_PAD=bytes (experiment): unused dynamic LDS on the tiled correction's launch - 4096 leaves ONE workgroup per CU
 	int corr_no_big = 0;      // LFA_CORR_NO_BIG=1: crowded half tiles go straight to the global-gather kernel (before round 4)
 	int corr_prio = 0x7fffffff;  // LFA_CORR_PRIO: priority of the correction's stream (default: the lowest the device has)
 	// pressure solve (mg.hip, pcg.hip); -1 / 0 / NaN = the built-in default

@@ -232,6 +232,7 @@ static void lfa_knobs_parse(lfa_knobs &k) {
 		return e ? atof(e) : __builtin_nan("");
 	};
 	k.corr_no_big = flag("LFA_CORR_NO_BIG", 0);
+	k.corr_lds_pad = num("LFA_CORR_LDS_PAD", 0);
 	k.dist_two_reductions = flag("LFA_DIST_TWO_REDUCTIONS", 0);
 	k.corr_prio = num("LFA_CORR_PRIO", 0x7fffffff);
 	k.mg_mw_a = num("LFA_MG_MW_A", -1);

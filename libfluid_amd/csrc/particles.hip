@@ -1274,7 +1274,9 @@ static int correct_apply(lfa_sim *s, double dt, bool migrate = true, bool with_c
 			// written in place; the fallback pass below takes its particles' old state from the records and the copy of the keys
 			// the index kernel has left in the other buffer
 			if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[41], s->stream));
-			hipLaunchKernelGGL((k_correct_fine<FINE_CAP, false>), dim3(g2), dim3(CORR_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, cur.key,
+			if (s->knobs.corr_lds_pad > 0)
+				(void)hipFuncSetAttribute((const void *)k_correct_fine<FINE_CAP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, s->knobs.corr_lds_pad);
+			hipLaunchKernelGGL((k_correct_fine<FINE_CAP, false>), dim3(g2), dim3(CORR_THREADS), (size_t)std::max(0, s->knobs.corr_lds_pad), s->stream, s->ptiles, s->n_ptiles, cur.key,
 			                   cur.t[0], cur.t[1], cur.t[2], s->g, s->solid, s->tile_count, s->fine_start, (const float4 *)spos, mpc, ovf,
 			                   (const uint8_t *)s->tile_clear, (const uint32_t *)nullptr);
 			LFA_LAUNCH_CHECK(s);
