@@ -94,6 +94,9 @@ struct lfa_knobs {
 	int mg_top = 0;           // LFA_MG_TOP=1: the level above k_mg_coarse's first one joins that launch, several tile slots per
 	                          // workgroup (round 4: measured at C3 - 8 -> 5 launches per iteration, 0.138 -> 0.140 ms per iteration,
 	                          // step 4.75 -> 4.98 ms beside the correction; does not fit at C4 - so it stays off)
+	int mg_fold = 0;          // LFA_MG_FOLD=1 (OPT-IN): level 1's pre-smoothing behind level 0's restriction in one launch, a workgroup per
+	                          // level-1 tile (k_mg_restrict0_pre1). Bit-identical, 8 -> 7 launches, and SLOWER: C4 0.279 -> 0.287 ms per
+	                          // iteration, C3 0.137 -> 0.139 (a workgroup per parent loses the wave-per-tile kernel's even spread)
 	int mg_merge = 0;         // LFA_MG_MERGE=1 (OPT-IN): level 1's phases inside the level-0 launches next to them (k_mg_down01 / k_mg_up01:
 	                          // an ordered work queue in place of three kernel boundaries; bit-identical, deadlock-free at any occupancy -
 	                          // and 6x slower: 38 000 agent-scope atomics on ONE word per launch at ~22 ns each. docs/experiments.md)

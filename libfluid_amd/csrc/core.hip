@@ -243,6 +243,7 @@ static void lfa_knobs_parse(lfa_knobs &k) {
 	k.mg_tail_tiles = num("LFA_MG_TAIL_TILES", -1);
 	k.mg_co_max_tiles = num("LFA_MG_CO_MAX_TILES", -1);
 	k.mg_merge = flag("LFA_MG_MERGE", 0);
+	k.mg_fold = flag("LFA_MG_FOLD", 0);
 	k.mg_no_persist = flag("LFA_MG_NO_PERSIST", 0);
 	k.mg_top = flag("LFA_MG_TOP", 0);
 	k.mg_xcd = flag("LFA_MG_XCD", 0);

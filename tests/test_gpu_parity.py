@@ -591,6 +591,38 @@ def test_multigrid_level_above_the_coarse_launch_inside_it_is_bitwise_the_launch
 
 
 @pytest.mark.parametrize("dtype", [lfa.PCG_F32, lfa.PCG_F64])
+@pytest.mark.parametrize("co_max,cp_max", [(40, None), (4, None), (40, 0)])
+def test_multigrid_level_one_presmoothing_behind_the_level_zero_restriction_is_bitwise_a_launch_of_its_own(dtype, co_max, cp_max, monkeypatch):
+    """k_mg_restrict0_pre1 (round 4, opt-in LFA_MG_FOLD=1: correct and slower): a workgroup per level-1 tile computes the residual of
+    its eight children, restricts into LDS and pre-smooths the parent on the spot (a zero guess needs nothing from other tiles).
+    Against level 0's residual + restriction and level 1's pre-smoothing as two launches (cp_max 0: the wave-per-tile
+    pre-smoother): identical iteration counts and pressures, one launch less per iteration."""
+    size, block = (136, 72, 104), ((0, 0, 0), (90, 50, 70))
+    res = []
+    for fold in (True, False):
+        monkeypatch.setenv("LFA_MG_CO_MAX_TILES", str(co_max))
+        if cp_max is not None:
+            monkeypatch.setenv("LFA_MG_CP_MAX_TILES", str(cp_max))
+        if fold:
+            monkeypatch.setenv("LFA_MG_FOLD", "1")
+        else:
+            monkeypatch.delenv("LFA_MG_FOLD", raising=False)
+        s = lfa.Sim(size, precond=lfa.PRECOND_MULTIGRID, pcg_dtype=dtype)
+        s.seed_block(*block)
+        its = []
+        for _ in range(3):
+            r, it, rc = s.step_hot(util.DT)
+            assert rc == 0
+            its.append(it)
+        st = s.solver_stats()
+        res.append((its, s.pressure().copy(), st["launches_per_iteration"]))
+        s.close()
+    assert res[0][0] == res[1][0] and min(res[0][0]) > 3
+    assert np.array_equal(res[0][1], res[1][1])
+    assert res[0][2] + 1 == res[1][2], (res[0][2], res[1][2])
+
+
+@pytest.mark.parametrize("dtype", [lfa.PCG_F32, lfa.PCG_F64])
 @pytest.mark.parametrize("co_max", [40, 4])
 def test_multigrid_level_one_inside_the_level_zero_launches_is_bitwise_the_launches_of_its_own(dtype, co_max, monkeypatch):
     """k_mg_down01 / k_mg_up01 (round 4, opt-in LFA_MG_MERGE=1: correct and slower): level 1's pre-smoothing, residual + restriction
