@@ -226,6 +226,8 @@ def main():
     ap.add_argument("--weak", action="store_true", help="N > 1: make the weak-scaling run (domain and block grow along z with N, every rank "
                     "owns a single-GPU-sized slab) the headline `value` instead of the fixed domain")
     ap.add_argument("--no-secondary", action="store_true", help="N > 1: skip the other scaling mode's run (reported under `weak` / `strong`)")
+    ap.add_argument("--watchdog-s", type=int, default=1500, help="N > 1: a rank that has printed no result after this many seconds exits with "
+                    "code 124 instead of waiting for ever on a peer (0 = off)")
     args = ap.parse_args()
     if args.weak and args.strong:
         raise SystemExit("--weak and --strong exclude each other")
@@ -249,6 +251,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would not describe the run")
+    if world > 1 and args.watchdog_s > 0:
+        # A rank that waits for a message that never comes (a peer died, a collective out of step) would hang the job for ever:
+        # a stream synchronisation has no timeout. The run ends with an error instead of holding the node.
+        import threading
+
+        def expired():
+            print(f"bench.py: rank {rank}: no result after {args.watchdog_s} s (--watchdog-s) - a rank is stuck in a collective or died; "
+                  "aborting", file=sys.stderr, flush=True)
+            os._exit(124)
+        wd = threading.Timer(args.watchdog_s, expired)
+        wd.daemon = True
+        wd.start()
 
     import torch
     import libfluid_amd as lfa
