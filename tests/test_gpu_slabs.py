@@ -727,7 +727,8 @@ def test_shared_memory_transport_fails_instead_of_hanging(tmp_path):
 
 
 @pytest.mark.gpu
-def test_single_reduction_cg_matches_the_textbook_form_on_slabs(monkeypatch):
+@pytest.mark.parametrize("dtype", [lfa.PCG_F32, lfa.PCG_F64])
+def test_single_reduction_cg_matches_the_textbook_form_on_slabs(dtype, monkeypatch):
     """Slab runs solve with the single-reduction form of CG (Chronopoulos / Gear: gamma = z.r, delta = (A z).z and the signed max
     of r in one collective; mg.hip: k_mg_axpy_presmooth_cg). Same iterates in exact arithmetic: against the textbook form
     (LFA_DIST_TWO_REDUCTIONS=1, dot(q, s) in a collective of its own) on the same four virtual slabs the iteration counts agree
@@ -743,7 +744,7 @@ def test_single_reduction_cg_matches_the_textbook_form_on_slabs(monkeypatch):
         hub = lfa.LocalHub(n)
         sims = []
         for r in range(n):
-            q = lfa.Sim(size, method=lfa.APIC, precond=lfa.PRECOND_MULTIGRID)
+            q = lfa.Sim(size, method=lfa.APIC, precond=lfa.PRECOND_MULTIGRID, pcg_dtype=dtype)
             q.init_local_slab(hub.h, r, bounds)
             q.seed_block(*block)
             sims.append(q)
