@@ -151,6 +151,7 @@ def build_sim(args, cfg, lfa, torch, dist, tdev, rank, world, local_rank, n_dev,
                 if args.transport == "rccl":
                     raise SystemExit(f"rank {rank}: RCCL communicator could not be created: {err or 'failed on another rank'}")
                 # the handle that tried keeps no half-built communicator: a fresh one takes the host-staged transport
+                sim.abandon_transport()  # (a peer has no communicator: release ours without waiting for it)
                 sim.close()
                 sim = lfa.Sim(size, method=cfg["method"], blending=cfg["blending"], device=local_rank,
                               precond={"exact": lfa.PRECOND_MIC0_EXACT, "tiled": lfa.PRECOND_MIC0_TILED,
@@ -630,6 +631,9 @@ def main():
                             "windows": world if slabs else 1}
         m.close()
     out.update(extras)
+    if dist is not None:  # every rank has finished with the transport before any rank closes its side of it
+        sim.synchronize()
+        dist.barrier()
     sim.close()
     if slabs and world > 1 and not args.no_secondary:
         # the other scaling mode, beside the headline: same step, same lead-in, same barrier + max-over-ranks timing, no stage breakdown
@@ -676,6 +680,7 @@ def main():
             "scaling": "strong" if other else "weak", "particles": int(n2), "grid": size2, "parallelism": par2, "transport": tr2,
             "pcg_iterations_per_step": it2 / max(args.steps, 1),
             "note": "the other scaling mode of the same command (the line's `value` is the " + ("weak" if other else "fixed-domain") + " run)"}
+        barrier2()
         sim2.close()
 
     if rank == 0:

@@ -275,6 +275,10 @@ int lfa_dist_init_local(lfa_sim *s, lfa_hub *h, int rank, const int32_t *layer_b
 int lfa_dist_init_shm(lfa_sim *s, const char *name, int rank, int nranks, const int32_t *layer_bounds);
 /* Owned tile layers of this handle ([0, ntz) without a decomposition). */
 int lfa_dist_get_slab(const lfa_sim *s, int32_t *lo, int32_t *hi);
+/* Marks the handle's transport as given up by the job (a PEER failed to create its communicator, a rank died): lfa_destroy then
+ * releases it without waiting for the peers (ncclCommAbort). A healthy handle is not marked: its communicator is drained and
+ * destroyed. Nothing in the reference (it is single-process). */
+int lfa_dist_abandon(lfa_sim *s);
 
 /* -- solid-boundary voxelizer ----------------------------------------------------------------
  * Replaces fluid::voxelizer (include/fluid/voxelizer.h:14-74, src/voxelizer.cpp:12-136) as the Maya VoxelizerNode

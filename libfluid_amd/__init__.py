@@ -161,6 +161,7 @@ SIGNATURES = {
     "lfa_dist_init_local": (_int, [_vp, _vp, _int, _vp]),
     "lfa_dist_init_shm": (_int, [_vp, C.c_char_p, _int, _int, _vp]),
     "lfa_dist_get_slab": (_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "lfa_dist_abandon": (_int, [_vp]),
 }
 KERNELS = {"spmv_dot": 0, "axpy_max": 1, "mic_apply_dot": 2, "update_s": 3, "p2g_scatter": 4, "p2g_finalize": 5,
            "g2p": 6, "bin": 7, "mic_fine": 8, "coarse_levels": 9, "pcg_a": 10, "pcg_b": 11,
@@ -691,6 +692,10 @@ class Sim:
         """one process per rank, messages staged through the POSIX shared-memory segment `name` (lfa_dist_init_shm)"""
         b = np.ascontiguousarray(layer_bounds, dtype=np.int32)
         self._chk(self.lib.lfa_dist_init_shm(self.h, str(name).encode(), int(rank), int(nranks), _ptr(b)))
+
+    def abandon_transport(self):
+        """the job gives this handle's transport up (a peer failed): close() will not wait for the peers (lfa_dist_abandon)"""
+        self._chk(self.lib.lfa_dist_abandon(self.h))
 
     def slab(self):
         lo, hi = C.c_int32(0), C.c_int32(0)

@@ -2,6 +2,8 @@
 
 hipcc cross-compiles without a GPU, so this runs in the build container; the .so travels to the GPU box in-tree.
 """
+import hashlib
+import json
 import os
 import subprocess
 import sys
@@ -22,24 +24,39 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _digest(paths, extra=""):
+    h = hashlib.sha256(extra.encode())
+    for p in sorted(paths):
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def build(force=False, verbose=False):
+    """Content-driven: an object is recompiled when the hash of its source, of every header and of the compiler flags differs from
+    the one recorded with it (csrc/.build_stamps.json) - file times play no part, so a checkout, a copy to another machine or a
+    `touch` neither force nor hide a rebuild. Returns the library path; `last_build_report` says what was compiled and what was
+    reused."""
+    global last_build_report
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "libfluid_amd.h"))
-    objs, jobs = [], []
+    stamp_path = os.path.join(CSRC, ".build_stamps.json")
+    try:
+        with open(stamp_path) as f:
+            stamps = json.load(f)
+    except (OSError, ValueError):
+        stamps = {}
+    objs, jobs, todo = [], [], {}
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or _stale(o, [s] + headers):
+        d = _digest([s] + headers, " ".join(FLAGS))
+        if force or not os.path.exists(o) or stamps.get(src) != d:
             jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
+            todo[src] = d
 
     def run(cmd):
         if verbose:
@@ -53,9 +70,19 @@ def build(force=False, verbose=False):
         for w in ex.map(run, jobs):
             if verbose and w:
                 print(w)
-    if force or jobs or _stale(LIB, objs):
+    link_digest = _digest(objs)
+    relinked = force or bool(jobs) or not os.path.exists(LIB) or stamps.get("__link__") != link_digest
+    if relinked:
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl", "-lpthread"])
+    stamps.update(todo)
+    stamps["__link__"] = link_digest
+    with open(stamp_path, "w") as f:
+        json.dump(stamps, f, indent=1, sort_keys=True)
+    last_build_report = {"compiled": sorted(todo), "reused": sorted(set(SOURCES) - set(todo)), "relinked": relinked}
     return LIB
+
+
+last_build_report = None
 
 
 def build_variant(name, defs, sources):
@@ -85,3 +112,4 @@ if __name__ == "__main__":
         print(build_variant(sys.argv[2], [a[2:] for a in sys.argv[4:]], sys.argv[3].split(",")))
     else:
         print(build(force="--force" in sys.argv, verbose=True))
+        print(last_build_report)

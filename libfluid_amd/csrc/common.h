@@ -437,6 +437,7 @@ struct lfa_dist {
 		return allreduce_buf_impl(s, dev, count, dtype, is_max);
 	}
 	uint64_t calls = 0;
+	bool broken = false;  // a transport call failed, or the job abandons this transport (lfa_dist_abandon): close without waiting for peers
 	virtual int exchange_impl(lfa_sim *s, const void *send_lo, size_t n_send_lo, void *recv_lo, size_t n_recv_lo,
 	                          const void *send_hi, size_t n_send_hi, void *recv_hi, size_t n_recv_hi) = 0;
 	virtual int allreduce_impl(lfa_sim *s, double *dev, int count, bool is_max) = 0;
@@ -455,6 +456,7 @@ int lfa_dist_exchange_slices(lfa_sim *s, void *vec, int elem_bytes);  // elem_by
 /// layer lo_layer goes down, slice 7 of layer hi_layer - 1 goes up; they land in layers lo_layer - 1 and hi_layer.
 int lfa_dist_exchange_layer_slices(lfa_sim *s, void *vec, int elem_bytes, int tiles_per_layer, int lo_layer, int hi_layer);
 int lfa_dist_allreduce(lfa_sim *s, const double *partials, int n, int slot, bool is_max);  // result in dist_red[slot]
+#define LFA_DIST_ALPHA_OFF (64 + 2 * (3 * 32 + 1))  // dist_red: [0, 64) scalars | two gather buffers (<= 32 ranks) | alpha of the single-reduction CG
 double *lfa_dist_gather_buf(lfa_sim *s, int parity);  // [max per rank | sum per rank] of the last lfa_dist_gather_pair
 int lfa_dist_gather_pair(lfa_sim *s, const double *pmax, int n_max, const double *psum, int n_sum, int parity);
 int lfa_dist_gather_triple(lfa_sim *s, const double *pmax, int n_max, const double *psum, int n_sum, const double *psum2, int n_sum2,

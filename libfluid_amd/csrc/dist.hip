@@ -134,8 +134,10 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const double *part, int
 /// reductions of k_reduce_partials): a SUM all-reduce of `out` then leaves every rank's pair on every rank (an all-gather
 /// that is exact in any order), and the consumers reduce n values instead of their per-workgroup partials.
 /// (`psum2`: a third list, summed like the second, for out[2 n + rank]: the single-reduction CG of slab runs; out is 3 n long)
+/// out[3 n] = 1 when a device-side wait of this rank's solve has been given up (pcg_state[2], sticky): summed over the ranks it
+/// tells EVERY rank at its next poll, so that all of them leave the loop and repeat the solve together (pcg.hip).
 __global__ void __launch_bounds__(256) k_gather_pair(const double *pmax, int n_max, const double *psum, int n_sum, const double *psum2,
-                                                     int n_sum2, double *out, int n, int rank) {
+                                                     int n_sum2, double *out, int n, int rank, const int *pcg_state) {
 	__shared__ double lds[3][256];
 	double a = -INFINITY, b = 0.0, c2 = 0.0;
 	bool nan_a = false, nan_b = false, nan_c = false;
@@ -171,6 +173,7 @@ __global__ void __launch_bounds__(256) k_gather_pair(const double *pmax, int n_m
 	}
 	for (int i = threadIdx.x; i < 3 * n; i += 256)
 		out[i] = i == rank ? lds[0][0] : (i == n + rank ? lds[1][0] : (i == 2 * n + rank ? lds[2][0] : 0.0));
+	if (threadIdx.x == 0) out[3 * n] = pcg_state && pcg_state[2] ? 1.0 : 0.0;
 }
 }  // namespace
 
@@ -325,7 +328,7 @@ int lfa_dist_allreduce(lfa_sim *s, const double *partials, int n, int slot, bool
 
 /// The signed max of `pmax` and the sum of `psum` of every rank in ONE collective: afterwards lfa_dist_gather_buf(s, parity)
 /// holds [max of rank 0 .. n-1 | sum of rank 0 .. n-1] on every rank.
-double *lfa_dist_gather_buf(lfa_sim *s, int parity) { return s->dist_red + 64 + (size_t)parity * 3 * s->dist->nranks; }
+double *lfa_dist_gather_buf(lfa_sim *s, int parity) { return s->dist_red + 64 + (size_t)parity * (3 * s->dist->nranks + 1); }
 int lfa_dist_gather_pair(lfa_sim *s, const double *pmax, int n_max, const double *psum, int n_sum, int parity) {
 	return lfa_dist_gather_triple(s, pmax, n_max, psum, n_sum, nullptr, 0, parity);
 }
@@ -335,9 +338,10 @@ int lfa_dist_gather_triple(lfa_sim *s, const double *pmax, int n_max, const doub
 	const int n = s->dist->nranks;
 	if (n > 32) return lfa_fail(s, LFA_E_UNSUPPORTED, "more than 32 slabs");
 	double *out = lfa_dist_gather_buf(s, parity);
-	hipLaunchKernelGGL(k_gather_pair, dim3(1), dim3(256), 0, s->stream, pmax, n_max, psum, n_sum, psum2, n_sum2, out, n, s->dist->rank);
+	hipLaunchKernelGGL(k_gather_pair, dim3(1), dim3(256), 0, s->stream, pmax, n_max, psum, n_sum, psum2, n_sum2, out, n, s->dist->rank,
+	                   (const int *)s->pcg_state);
 	LFA_LAUNCH_CHECK(s);
-	return s->dist->allreduce_buf(s, out, (size_t)(psum2 ? 3 : 2) * n, LFA_RED_F64, false);
+	return s->dist->allreduce_buf(s, out, (size_t)3 * n + 1, LFA_RED_F64, false);  // [max | sum | sum2 | ranks that gave a wait up]
 }
 
 // ================================================================================================= particle migration
@@ -690,15 +694,22 @@ RcclApi g_rccl;
 struct RcclDist : lfa_dist {
 	ncclComm_t comm = nullptr;
 	~RcclDist() override {
-		// (ncclCommAbort where the library has it: it releases the communicator without waiting for the peers - a handle is also
-		// closed when the job falls back to another transport because a PEER could not create its communicator, bench.py)
-		if (comm) (void)(g_rccl.CommAbort ? g_rccl.CommAbort(comm) : g_rccl.CommDestroy(comm));
+		// A healthy communicator is drained and destroyed (lfa_destroy has synchronised the handle's stream: every send / recv /
+		// all-reduce this rank enqueued is complete, so a faster rank never tears its side down under a slower peer's last call).
+		// ncclCommAbort - which releases the communicator without waiting for anybody - is for the broken case only: a transport
+		// call failed, or the job gives the communicator up because a PEER could not create its own (bench.py's fallback:
+		// lfa_dist_abandon).
+		if (!comm) return;
+		if (broken && g_rccl.CommAbort) (void)g_rccl.CommAbort(comm);
+		else (void)g_rccl.CommDestroy(comm);
 	}
 #define NCCL_TRY(s, call)                                                                                \
 	do {                                                                                                  \
 		ncclResult_t r_ = (call);                                                                         \
-		if (r_ != ncclSuccess)                                                                            \
+		if (r_ != ncclSuccess) {                                                                          \
+			broken = true;                                                                                \
 			return lfa_fail((s), LFA_E_HIP, "%s failed: %s", #call, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?"); \
+		}                                                                                                 \
 	} while (0)
 	int exchange_impl(lfa_sim *s, const void *send_lo, size_t n_send_lo, void *recv_lo, size_t n_recv_lo, const void *send_hi,
 	             size_t n_send_hi, void *recv_hi, size_t n_recv_hi) override {
@@ -981,10 +992,11 @@ int attach(lfa_sim *s, lfa_dist *d, const int32_t *bounds) {
 	s->slab_hi = hi;
 	s->binned = false;
 	s->cell_sorted = false;
-	s->sources_valid = false;  // the seeding entries are the ones of this rank's own tile layers
+	s->sources_valid = false;  // the seeding entries are the ones of this rank's own tile layers ...
+	s->sources_built.clear();  // ... so entries flattened for another range (the whole domain, earlier bounds) are not "the same list"
 	s->grid_valid = false;
 	s->system_valid = false;
-	if (!s->dist_red) LFA_HIP(s, hipMalloc(&s->dist_red, (64 + 6 * 32 + 8) * 8));  // scalars | 2 gather buffers of 3 x nranks | alpha of the single-reduction CG (2)
+	if (!s->dist_red) LFA_HIP(s, hipMalloc(&s->dist_red, (LFA_DIST_ALPHA_OFF + 8) * 8));  // scalars | 2 gather buffers of 3 x nranks + 1 | alpha of the single-reduction CG (2)
 	if (!s->halo_tiles) LFA_HIP(s, hipMalloc(&s->halo_tiles, (size_t)4 * s->g.ntx * s->g.nty * 4));
 	return LFA_OK;
 }
@@ -1051,6 +1063,12 @@ extern "C" int lfa_dist_init_local(lfa_sim *s, lfa_hub *h, int rank, const int32
 	d->device_share = h->n;  // (an upper bound: handles of one hub may sit on different devices)
 	d->hub = h;
 	return attach(s, d, layer_bounds);
+}
+
+extern "C" int lfa_dist_abandon(lfa_sim *s) {
+	if (!s) return LFA_E_INVALID;
+	if (s->dist) s->dist->broken = true;
+	return LFA_OK;
 }
 
 extern "C" int lfa_dist_get_slab(const lfa_sim *s, int32_t *lo, int32_t *hi) {

@@ -618,8 +618,12 @@ k_dot_zr(TileCtx tc, Vecs<real> v, double *part_sigma, const int *state) {
 /// Stopping rule of pressure_solver::solve (src/pressure_solver.cpp:54-58): signed max(r) < tolerance ends the solve
 /// with iteration count i+1. One workgroup; later kernels of the stream see state[0] >= 0 and do nothing.
 __global__ void __launch_bounds__(256)
-k_check_converged(const double *part_rmax, int n_part, double tol, int iter, int *state, double *hist) {
+k_check_converged(const double *part_rmax, int n_part, double tol, int iter, int *state, double *hist, const double *gave_up = nullptr) {
 	__shared__ double lds[256];
+	// slabs: how many ranks gave a device-side wait up (the last word of the gather, dist.hip: k_gather_pair). The retreat is
+	// collective: a rank that leaves the loop alone would redo the system build and its collectives while its peers carry on
+	// with the V-cycle's, and the transport sequences would no longer pair up.
+	if (gave_up && threadIdx.x == 0 && *gave_up > 0.0 && state[2] == 0) state[2] = 1;
 	if (state[0] >= 0) return;
 	const double rmax = reduce_partials_max(part_rmax, n_part, lds);
 	if (threadIdx.x == 0) {
@@ -1817,7 +1821,7 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 	const bool cg1 = fused && dist && is_mg(s) && !small_ran && !s->knobs.dist_two_reductions;
 	if (cg1) {
 		const int nr = s->dist->nranks;
-		double *alpha_io = s->dist_red + 64 + 6 * 32;
+		double *alpha_io = s->dist_red + LFA_DIST_ALPHA_OFF;
 		auto step_a = [&](int k, const double *rmax_part, int n_rmax_part, const double *gam_part, int n_gam_part) -> int {
 			launch_pcg_a<real>(true, false, GA, s->stream, s->n_ptiles, (const int *)s->nbr_table, (const uint8_t *)s->abits, (const real *)v.z,
 			                   (const real *)nullptr, (real *)nullptr, v.q, scale, (const double *)nullptr, 0, (const double *)nullptr, 0,
@@ -1858,7 +1862,7 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 				}
 			}
 			hipLaunchKernelGGL(k_check_converged, dim3(1), dim3(256), 0, s->stream, (const double *)lfa_dist_gather_buf(s, i & 1), nr,
-			                   s->prm.tolerance, i - 1, s->pcg_state, s->pcg_hist);
+			                   s->prm.tolerance, i - 1, s->pcg_state, s->pcg_hist, (const double *)lfa_dist_gather_buf(s, i & 1) + 3 * nr);
 			LFA_LAUNCH_CHECK(s);
 			LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 80, hipMemcpyDeviceToHost, s->stream));
 			LFA_HIP(s, hipStreamSynchronize(s->stream));
@@ -1943,7 +1947,8 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 		// the residual of the last iteration of the chunk is tested here (k_pcg_a tests the one before it)
 		hipLaunchKernelGGL(k_check_converged, dim3(1), dim3(256), 0, s->stream,
 		                   dist ? (const double *)lfa_dist_gather_buf(s, i & 1) : P + PART_RMAX, dist ? s->dist->nranks : GB,
-		                   s->prm.tolerance, i - 1, s->pcg_state, s->pcg_hist);
+		                   s->prm.tolerance, i - 1, s->pcg_state, s->pcg_hist,
+		                   dist ? (const double *)lfa_dist_gather_buf(s, i & 1) + 3 * s->dist->nranks : (const double *)nullptr);
 		LFA_LAUNCH_CHECK(s);
 		LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 80, hipMemcpyDeviceToHost, s->stream));
 		LFA_HIP(s, hipStreamSynchronize(s->stream));
@@ -1968,7 +1973,7 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 			LFA_LAUNCH_CHECK(s);
 			if (dist) LFA_TRY(lfa_dist_allreduce(s, P + PART_RMAX, G, 2, true));
 			hipLaunchKernelGGL(k_check_converged, dim3(1), dim3(256), 0, s->stream, dist ? red + 2 : P + PART_RMAX, n_max,
-			                   s->prm.tolerance, i, s->pcg_state, s->pcg_hist);
+			                   s->prm.tolerance, i, s->pcg_state, s->pcg_hist, (const double *)nullptr);
 			LFA_LAUNCH_CHECK(s);
 			LFA_TRY(mic_apply<real>(s, sig_new_part, true));
 			if (dist) LFA_TRY(lfa_dist_allreduce(s, sig_new_part, NS, 3 + pn, false));

@@ -10,17 +10,11 @@
 #include <ostream>
 #include <vector>
 
-#include "simulation.h"
+#include "types.h"
 
+#ifndef LFA_HOST_REFERENCE_TYPES  // with the reference's headers on the include path fluid_amd::mesh IS fluid::mesh (types.h)
 namespace fluid_amd {
-	template <typename T> struct vec2 {
-		T x{}, y{};
-		vec2() = default;
-		vec2(T a, T b) : x(a), y(b) {}
-	};
-
-	template <typename PosT = double, typename IndexT = std::size_t, typename NormalT = double, typename UvT = double,
-	          typename ColorT = vec3d>
+	template <typename PosT, typename IndexT, typename NormalT, typename UvT, typename ColorT>
 	struct mesh {
 		std::vector<vec3<PosT>> positions;
 		std::vector<vec3<NormalT>> normals;
@@ -86,3 +80,4 @@ namespace fluid_amd {
 		}
 	};
 }
+#endif

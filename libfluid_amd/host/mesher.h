@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "mesh.h"
+#include "simulation.h"
 
 namespace fluid_amd {
 	class mesher {

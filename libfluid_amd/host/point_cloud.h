@@ -10,7 +10,7 @@
 #include <ostream>
 #include <vector>
 
-#include "simulation.h"
+#include "types.h"
 
 namespace fluid_amd {
 	namespace point_cloud {

@@ -43,97 +43,9 @@
 #include <vector>
 
 #include "../../include/libfluid_amd.h"
+#include "types.h"
 
 namespace fluid_amd {
-	template <typename T> struct vec3 {
-		T x{}, y{}, z{};
-		vec3() = default;
-		vec3(T a, T b, T c) : x(a), y(b), z(c) {}
-		template <typename U> explicit vec3(const vec3<U> &o) : x(static_cast<T>(o.x)), y(static_cast<T>(o.y)), z(static_cast<T>(o.z)) {}
-		T &operator[](std::size_t i) { return (&x)[i]; }
-		T operator[](std::size_t i) const { return (&x)[i]; }
-		vec3 &operator+=(const vec3 &o) { x += o.x; y += o.y; z += o.z; return *this; }
-		vec3 &operator-=(const vec3 &o) { x -= o.x; y -= o.y; z -= o.z; return *this; }
-		friend vec3 operator+(vec3 a, const vec3 &b) { return a += b; }
-		friend vec3 operator-(vec3 a, const vec3 &b) { return a -= b; }
-		friend vec3 operator*(vec3 a, T s) { a.x *= s; a.y *= s; a.z *= s; return a; }
-		friend vec3 operator*(T s, vec3 a) { return a * s; }
-		friend vec3 operator/(vec3 a, T s) { a.x /= s; a.y /= s; a.z /= s; return a; }
-		T squared_length() const { T r{}; r += x * x; r += y * y; r += z * z; return r; }
-	};
-	using vec3d = vec3<double>;
-	using vec3s = vec3<std::size_t>;
-	using vec3i = vec3<int>;
-	inline double dot(const vec3d &a, const vec3d &b) { double r = 0.0; r += a.x * b.x; r += a.y * b.y; r += a.z * b.z; return r; }
-
-	/// Dense x-fastest 3-D array with the indexing surface of fluid::grid3 (include/fluid/data_structures/grid.h:13-246).
-	template <typename Cell> class grid3 {
-	public:
-		grid3() = default;
-		explicit grid3(vec3s size, const Cell &c = Cell{}) : _cells(size.x * size.y * size.z, c), _size(size) {}
-		Cell &operator()(std::size_t x, std::size_t y, std::size_t z) { return _cells[index_to_raw(vec3s(x, y, z))]; }
-		const Cell &operator()(std::size_t x, std::size_t y, std::size_t z) const { return _cells[index_to_raw(vec3s(x, y, z))]; }
-		Cell &operator()(vec3s i) { return _cells[index_to_raw(i)]; }
-		const Cell &operator()(vec3s i) const { return _cells[index_to_raw(i)]; }
-		Cell &operator[](std::size_t raw) { return _cells[raw]; }
-		const Cell &operator[](std::size_t raw) const { return _cells[raw]; }
-		vec3s get_size() const { return _size; }
-		std::size_t get_array_size() const { return _cells.size(); }
-		void fill(const Cell &c) { std::fill(_cells.begin(), _cells.end(), c); }
-		std::size_t index_to_raw(vec3s i) const { return i.x + _size.x * (i.y + _size.y * i.z); }
-		vec3s index_from_raw(std::size_t r) const {
-			vec3s v;
-			v.x = r % _size.x; r /= _size.x;
-			v.y = r % _size.y; r /= _size.y;
-			v.z = r;
-			return v;
-		}
-		template <typename Cb> void for_each(Cb &&cb) {
-			for (std::size_t z = 0; z < _size.z; ++z)
-				for (std::size_t y = 0; y < _size.y; ++y)
-					for (std::size_t x = 0; x < _size.x; ++x) cb(vec3s(x, y, z), (*this)(x, y, z));
-		}
-		Cell *data() { return _cells.data(); }
-		const Cell *data() const { return _cells.data(); }
-	private:
-		std::vector<Cell> _cells;
-		vec3s _size;
-	};
-
-	/// fluid::mac_grid (include/fluid/mac_grid.h:12-73): 32-byte cells, out-of-range == solid.
-	class mac_grid {
-	public:
-		struct cell {
-			enum class type : unsigned char { air = 0x1, fluid = 0x2, solid = 0x4 };
-			vec3d velocities_posface;
-			type cell_type = type::air;
-		};
-		mac_grid() = default;
-		explicit mac_grid(vec3s n) : _grid(n) {}
-		cell *get_cell(vec3s i) {
-			vec3s n = _grid.get_size();
-			return (i.x >= n.x || i.y >= n.y || i.z >= n.z) ? nullptr : &_grid(i);
-		}
-		std::pair<cell*, cell::type> get_cell_and_type(vec3s i) {
-			if (cell *c = get_cell(i)) return {c, c->cell_type};
-			return {nullptr, cell::type::solid};
-		}
-		grid3<cell> &grid() { return _grid; }
-		const grid3<cell> &grid() const { return _grid; }
-	private:
-		grid3<cell> _grid;
-	};
-	static_assert(sizeof(mac_grid::cell) == 32, "cell layout must match the reference (32-B AoS)");
-
-	/// fluid::source (include/fluid/data_structures/source.h:12-22).
-	class source {
-	public:
-		std::vector<vec3s> cells;
-		vec3d velocity;
-		std::size_t target_density_cubic_root = 2;
-		bool active = true, coerce_velocity = false;
-	};
-
 	/// pcg32 (XSH-RR 64/32, the generator family of the reference's `pcg32 random` member, simulation.h:177), own code.
 	class pcg32 {
 	public:
@@ -156,7 +68,13 @@ namespace fluid_amd {
 		struct particle {
 			vec3d position, velocity, cx, cy, cz, old_position;
 			std::size_t raw_cell_index = 0;
+			/// src/simulation.cpp:13-23 (truncation, no clamp: positions are kept inside the grid by the collision handling)
 			vec3s compute_cell_index(vec3d off, double h) const { return vec3s((position - off) / h); }
+			std::pair<vec3s, vec3d> compute_cell_index_and_position(vec3d off, double h) const {
+				const vec3d f = (position - off) / h;
+				const vec3s i(f);
+				return {i, f - vec3d(i)};
+			}
 		};
 		static_assert(sizeof(std::size_t) == 8, "64-bit host expected");
 		enum class method : unsigned char { pic, flip_blend, apic };
@@ -169,7 +87,7 @@ namespace fluid_amd {
 		~simulation() { if (_dev) lfa_destroy(_dev); }
 
 		void resize(vec3s sz) {
-			_grid = mac_grid(sz);
+			_grid = detail::make_mac_grid(sz);
 			_space_hash = grid3<_cell_particles>(sz);
 			if (_dev) { lfa_destroy(_dev); _dev = nullptr; }
 			const auto t0 = std::chrono::steady_clock::now();
@@ -315,14 +233,14 @@ namespace fluid_amd {
 		}
 		void _rehash_particles() { _particles_hash = _hash_words(_particles.data(), _particles.size() * sizeof(particle), 19, 0, 19); }
 		void _rehash_grid() {
-			const std::size_t bytes = _grid.grid().get_array_size() * sizeof(mac_grid::cell);
-			_grid_vel_hash = _hash_words(_grid.grid().data(), bytes, 4, 0, 3);
+			const std::size_t bytes = detail::cell_count(_grid.grid()) * sizeof(mac_grid::cell);
+			_grid_vel_hash = _hash_words(detail::cell_data(_grid.grid()), bytes, 4, 0, 3);
 			_grid_solid_hash = _solid_hash();
 		}
 		std::uint64_t _solid_hash() const {
 			// only WHICH cells are solid matters to the device (air / fluid are recomputed by every P2G)
-			const mac_grid::cell *c = _grid.grid().data();
-			const std::size_t n = _grid.grid().get_array_size();
+			const mac_grid::cell *c = detail::cell_data(_grid.grid());
+			const std::size_t n = detail::cell_count(_grid.grid());
 			std::uint64_t h = 0x2545F4914F6CDD1Dull;
 			for (std::size_t i = 0; i < n; ++i)
 				if (c[i].cell_type == mac_grid::cell::type::solid) { h ^= i + 0x9E3779B97F4A7C15ull; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 29; }
@@ -347,7 +265,7 @@ namespace fluid_amd {
 		}
 		void _sync_grid() {
 			if (_grid_stale && _dev) {
-				_ok(lfa_download_cells(_dev, _grid.grid().data()));
+				_ok(lfa_download_cells(_dev, detail::cell_data(_grid.grid())));
 				_grid_stale = false;
 				_rehash_grid();
 				_grid_handed_out = false;
@@ -435,7 +353,10 @@ namespace fluid_amd {
 		vec3d base = grid_offset + vec3d(cell) * cell_size;
 		for (; num < target; ++num) {
 			particle p;
-			double a = dist(random), b = dist(random), c = dist(random);
+			// `vec3d(dist(random), dist(random), dist(random))` (simulation.cpp:145): the language leaves the order of the three draws
+			// open; g++ - what the reference is built with here (oracle/Makefile) - makes them right to left, so z gets the first
+			// draw. With the same generator state this seeds the very particles the reference does (tests/test_ref_callers.py).
+			const double c = dist(random), b = dist(random), a = dist(random);
 			p.old_position = p.position = base + vec3d(a, b, c);
 			p.velocity = velocity;
 			p.raw_cell_index = index;
@@ -459,7 +380,7 @@ namespace fluid_amd {
 					for (std::size_t sx = 0; sx < dens; ++sx)
 						for (std::size_t sy = 0; sy < dens; ++sy)
 							for (std::size_t sz = 0; sz < dens; ++sz) {
-								double a = dist(random), b = dist(random), c = dist(random);
+								const double c = dist(random), b = dist(random), a = dist(random);  // z first: see seed_cell
 								vec3d pos = grid_offset + cell_off + vec3d(vec3s(sx, sy, sz)) * sub + vec3d(a, b, c);
 								if (pred(pos)) {
 									particle p;
@@ -522,7 +443,7 @@ namespace fluid_amd {
 			if (_grid_solid_hash != solid_before) _solids_dirty = true;
 			if (_solids_dirty && !_take_back_correction()) return false;  // the correction collides against the solid cells
 			if (_in_step && (_grid_vel_hash != vel_before || _grid_solid_hash != solid_before)) {
-				if (!_ok(lfa_upload_cells(_dev, _grid.grid().data()))) return false;
+				if (!_ok(lfa_upload_cells(_dev, detail::cell_data(_grid.grid())))) return false;
 				_solids_dirty = false;
 			}
 			_grid_handed_out = false;

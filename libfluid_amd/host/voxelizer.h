@@ -19,6 +19,7 @@
 #include <utility>
 #include <vector>
 
+#include "../../include/libfluid_amd.h"
 #include "mesh.h"
 
 namespace fluid_amd {
@@ -51,6 +52,12 @@ namespace fluid_amd {
 			grid_offset = ref_grid_offset + vec3d(grid_min) * cell_size;
 			voxels = grid3<cell_type>(vec3s(grid_max - grid_min), cell_type::interior);
 			return grid_min;
+		}
+		/// The five-argument form the Maya VoxelizerNode calls (plugins/maya/nodes/voxelizer_node.cpp:261-270: it also passes the
+		/// reference grid's size, which the reference's own header no longer takes - include/fluid/voxelizer.h:44); the size
+		/// plays no part in the placement (it is used afterwards, by get_overlapping_cell_range).
+		vec3i resize_reposition_grid_constrained(vec3d min, vec3d max, double ref_cell_size, vec3d ref_grid_offset, vec3s) {
+			return resize_reposition_grid_constrained(min, max, ref_cell_size, ref_grid_offset);
 		}
 		/// src/voxelizer.cpp:41-57
 		std::pair<vec3s, vec3s> get_overlapping_cell_range(vec3i offset, vec3s ref_grid_size) const {
@@ -103,7 +110,7 @@ namespace fluid_amd {
 			lfa_voxels_info(v, gmin, n, goff, &cell_size);
 			grid_offset = vec3d(goff[0], goff[1], goff[2]);
 			voxels = grid3<cell_type>(vec3s(n[0], n[1], n[2]), cell_type::interior);
-			_status = lfa_voxels_download(v, reinterpret_cast<std::uint8_t *>(voxels.data()));
+			_status = lfa_voxels_download(v, reinterpret_cast<std::uint8_t *>(detail::cell_data(voxels)));
 			if (_status != LFA_OK) _error = lfa_voxels_last_error(v);
 			lfa_voxels_destroy(v);
 			return vec3i(gmin[0], gmin[1], gmin[2]);
@@ -138,7 +145,7 @@ namespace fluid_amd {
 		/// voxels -> device, stage, device -> voxels.
 		template <typename Stage> void _on_device(Stage &&stage) {
 			const vec3s n = voxels.get_size();
-			if (voxels.get_array_size() == 0) return;
+			if (detail::cell_count(voxels) == 0) return;
 			const std::uint64_t size[3] = {n.x, n.y, n.z};
 			const double off[3] = {grid_offset.x, grid_offset.y, grid_offset.z};
 			lfa_voxels *v = nullptr;
@@ -147,9 +154,9 @@ namespace fluid_amd {
 				_error = lfa_last_error(nullptr);
 				return;
 			}
-			_status = lfa_voxels_upload(v, reinterpret_cast<const std::uint8_t *>(voxels.data()));
+			_status = lfa_voxels_upload(v, reinterpret_cast<const std::uint8_t *>(detail::cell_data(voxels)));
 			if (_status == LFA_OK) _status = stage(v);
-			if (_status == LFA_OK) _status = lfa_voxels_download(v, reinterpret_cast<std::uint8_t *>(voxels.data()));
+			if (_status == LFA_OK) _status = lfa_voxels_download(v, reinterpret_cast<std::uint8_t *>(detail::cell_data(voxels)));
 			if (_status != LFA_OK) _error = lfa_voxels_last_error(v);
 			lfa_voxels_destroy(v);
 		}
@@ -162,7 +169,7 @@ namespace fluid_amd {
 	/// own loop bounds mix voxel- and reference-grid coordinates and are not reproduced (include/libfluid_amd.h).
 	class obstacle {
 	public:
-		using mesh_t = mesh<double, std::size_t>;
+		using mesh_t = mesh<double, std::size_t, double, double, vec3d>;  // obstacle.h:13
 		obstacle() = default;
 		obstacle(mesh_t m, double cell_size, vec3d ref_grid_offset, vec3s ref_grid_size) : obstacle_mesh(std::move(m)) {
 			voxelizer vox;

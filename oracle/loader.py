@@ -38,6 +38,17 @@ def build(force=False):
     if os.path.isdir(os.environ.get("REFERENCE_DIR", "/root/reference")):
         if force or not os.path.exists(REF_SO) or os.path.getmtime(REF_SO) < os.path.getmtime(ref_src):
             subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+        # the caller-shaped host program (tests/callers/reference_callers.cpp): against the real reference, and - once
+        # libfluid_amd.so exists - against the shim headers in front of the reference's headers (runs on the GPU box)
+        root = os.path.dirname(HERE)
+        deps = [os.path.join(root, "tests", "callers", "reference_callers.cpp"), os.path.join(HERE, "ref_callers_main.cpp")]
+        host = os.path.join(root, "libfluid_amd", "host")
+        deps += [os.path.join(d, f) for d, _, fs in os.walk(host) for f in fs]
+        lib = os.path.join(root, "libfluid_amd", "libfluid_amd.so")
+        outs = [os.path.join(HERE, "_ref", "callers_ref")] + ([os.path.join(HERE, "_ref", "callers_dev_reftypes")] if os.path.exists(lib) else [])
+        newest = max(os.path.getmtime(f) for f in deps if os.path.exists(f))
+        if force or any(not os.path.exists(o) or os.path.getmtime(o) < newest for o in outs):
+            subprocess.check_call(["make", "-s", "-C", HERE, "callers"])
 
 
 def have_ref():

@@ -46,7 +46,7 @@ int main(int argc, char **argv) {
 	std::printf("%d %d %d %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", o.x, o.y, o.z, n.x, n.y, n.z, range.first.x, range.first.y,
 	            range.first.z, range.second.x, range.second.y, range.second.z);
 	f = std::fopen(argv[9], "wb");
-	std::fwrite(vox.voxels.data(), 1, vox.voxels.get_array_size(), f);
+	std::fwrite(detail::cell_data(vox.voxels), 1, detail::cell_count(vox.voxels), f);
 	std::fclose(f);
 
 	obstacle obs(m, cs, off, ref);

@@ -29,12 +29,24 @@ def run_single(size, block, method, steps, solid=None, vel=None, **kw):
     return cells, parts, out
 
 
-def run_slabs(size, block, method, steps, bounds, solid=None, **kw):
+def run_slabs(size, block, method, steps, bounds, solid=None, rank_env=None, stats=None, **kw):
+    """rank_env: {rank: {variable: value}} set while that rank's handle is created (a handle reads the environment once, in
+    lfa_create); stats: a list that receives every rank's solver statistics."""
     n = len(bounds) - 1
     hub = lfa.LocalHub(n)
     sims = []
     for r in range(n):
-        s = lfa.Sim(size, method=method, blending=0.95, **kw)
+        env = (rank_env or {}).get(r, {})
+        saved = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            s = lfa.Sim(size, method=method, blending=0.95, **kw)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
         if solid is not None:
             s.set_solid_cells(solid)
         s.init_local_slab(hub.h, r, bounds)
@@ -70,6 +82,8 @@ def run_slabs(size, block, method, steps, bounds, solid=None, **kw):
         cells.reshape(nz, ny, nx)[z0:z1] = c[z0:z1]
         p = s.download_particles()
         parts.append(p[: 0] if len(p) == 0 else p)
+        if stats is not None:
+            stats.append(s.solver_stats())
     for s in sims:
         s.close()
     hub.close()
@@ -104,6 +118,25 @@ def test_virtual_slabs_match_single_domain(size, block, method, bounds, precond)
     if precond == lfa.PRECOND_MIC0_TILED:
         # the tile-local preconditioner does not depend on the decomposition: same iteration counts
         assert itn[0] == it1
+
+
+@pytest.mark.parametrize("faulty", [0, 1])
+def test_a_wait_given_up_on_one_slab_makes_every_slab_retreat_together(faulty, monkeypatch):
+    """LFA_MG_CO_FAULT on ONE rank: its k_mg_coarse (the replicated coarse levels run in it on every rank) gives a wait up. The
+    abort word travels in the per-iteration gather, every rank finds it at the same poll, all of them retire the waiting kernels
+    and repeat the solve in step - transport sequences stay paired (no hang), and the result is the launch-per-phase one."""
+    size, block, bounds = (32, 32, 128), ((0, 0, 0), (32, 12, 128)), [0, 8, 16]
+    kw = dict(precond=lfa.PRECOND_MULTIGRID, pcg_dtype=lfa.PCG_F64)
+    monkeypatch.delenv("LFA_MG_CO_FAULT", raising=False)
+    monkeypatch.delenv("LFA_MG_NO_PERSIST", raising=False)
+    stats = []
+    cf, pf, itf = run_slabs(size, block, lfa.APIC, 2, bounds, rank_env={faulty: {"LFA_MG_CO_FAULT": "1"}}, stats=stats, **kw)
+    assert all(it == itf[0] for it in itf)
+    assert [st["device_waits_given_up"] for st in stats] == [1, 1], stats
+    monkeypatch.setenv("LFA_MG_NO_PERSIST", "1")
+    cn, pn, itn = run_slabs(size, block, lfa.APIC, 2, bounds, **kw)
+    assert itn == itf
+    assert np.array_equal(cn["type"], cf["type"]) and np.array_equal(cn["vel"], cf["vel"])
 
 
 MG_CASES = [
