@@ -37,7 +37,6 @@ void lfa_pool_park_set(lfa_stream_set *q);
 #define LFA_HALO 10            // tile + 1-cell ring
 #define LFA_HALO_CELLS 1000
 #define LFA_WAVE 64
-#define LFA_CS_JMAX 64         // cell-sorted order (core.hip: k_cell_sort): runs per z-slice; a cell's particles beyond that form its tail
 
 // cell type bits: reference values (include/fluid/mac_grid.h:17-21) + "outside the grid" marker for padding cells.
 #define CT_AIR 1
@@ -67,52 +66,16 @@ struct GridDims {
 
 /// A/B switches and tuning knobs, read from the environment ONCE, by lfa_create (core.hip: lfa_knobs_parse) - nothing below an entry
 /// point calls getenv. None is needed in normal use; they exist so that the measurements quoted in DESIGN.md can be repeated.
+/// The switches of a handle, read from the environment ONCE, by lfa_create (nothing below an entry point calls getenv). Each one
+/// selects a supported configuration; what was measured and dropped is in docs/experiments.md, not behind a switch.
 struct lfa_knobs {
-	int bin_cellsort = 0;     // LFA_BIN_CELLSORT=1: the particles of a tile in cell order (k_cell_sort) + the cell-centric P2G scatter
-	                          // (k_p2g_cells). Built and measured in round 4: slower than the tile-order binning + particle-parallel
-	                          // scatter (profiles/r04_cells_pmc.txt) - the default stays off
-	int p2g_cells = 1;        // LFA_P2G_CELLS=0: the particle-parallel scatter also on the cell-sorted order
-	int full_scatter = 0;     // LFA_FULL_SCATTER=1: the binning moves whole records
-	int c_travels = 0;        // LFA_C_TRAVELS=1: PIC / FLIP move C with every binning (no home array)
-	int bin_shuffle = 0;      // LFA_BIN_SHUFFLE=1 (round-3 binning only)
-	int p2g_no_rot = 0;       // LFA_P2G_NO_ROT=1
-	int dist_two_reductions = 0;  // LFA_DIST_TWO_REDUCTIONS=1: slab runs keep the textbook PCG (dot(q,s) in a collective of its own)
-	int corr_lds_pad = 0;     // LFA_CORR_LDS_PAD=bytes (experiment): unused dynamic LDS on the tiled correction's launch - 4096 leaves ONE workgroup per CU
-	int corr_no_big = 0;      // LFA_CORR_NO_BIG=1: crowded half tiles go straight to the global-gather kernel (before round 4)
-	int corr_prio = 0x7fffffff;  // LFA_CORR_PRIO: priority of the correction's stream (default: the lowest the device has)
-	// pressure solve (mg.hip, pcg.hip); -1 / 0 / NaN = the built-in default
-	int mg_mw_a = -1, mg_mw_u = -1;    // LFA_MG_MW_A / _U: minimum waves per SIMD of the two finest-level streaming kernels
-	int mg_dist_single = 0;   // LFA_MG_DIST_SINGLE=1: the slab mode of the hierarchy with a one-rank communicator (tests)
-	int mg_no_small_setup = 0;  // LFA_MG_NO_SMALL_SETUP=1
-	int mg_stop_at_single = 0;  // LFA_MG_STOP_AT_SINGLE=1
-	int mg_tail_tiles = -1;   // LFA_MG_TAIL_TILES
-	int mg_co_max_tiles = -1; // LFA_MG_CO_MAX_TILES
-	int mg_xcd = 0;           // LFA_MG_XCD=1: k_mg_coarse with its workgroups on one XCD (every eighth of 8 W works, workgroup-scope
-	                          // accesses). Round 4: inside the solver the placement the stand-alone probe showed does NOT hold - a
-	                          // consumer on XCC 6 never saw its producer's flag, the wait ran into its ceiling, the solve was repeated
-	                          // on every XCD (the retreat works; the mode buys nothing) - so it stays off
-	int mg_top = 0;           // LFA_MG_TOP=1: the level above k_mg_coarse's first one joins that launch, several tile slots per
-	                          // workgroup (round 4: measured at C3 - 8 -> 5 launches per iteration, 0.138 -> 0.140 ms per iteration,
-	                          // step 4.75 -> 4.98 ms beside the correction; does not fit at C4 - so it stays off)
-	int mg_fold = 0;          // LFA_MG_FOLD=1 (OPT-IN): level 1's pre-smoothing behind level 0's restriction in one launch, a workgroup per
-	                          // level-1 tile (k_mg_restrict0_pre1). Bit-identical, 8 -> 7 launches, and SLOWER: C4 0.279 -> 0.287 ms per
-	                          // iteration, C3 0.137 -> 0.139 (a workgroup per parent loses the wave-per-tile kernel's even spread)
-	int mg_merge = 0;         // LFA_MG_MERGE=1 (OPT-IN): level 1's phases inside the level-0 launches next to them (k_mg_down01 / k_mg_up01:
-	                          // an ordered work queue in place of three kernel boundaries; bit-identical, deadlock-free at any occupancy -
-	                          // and 6x slower: 38 000 agent-scope atomics on ONE word per launch at ~22 ns each. docs/experiments.md)
-	int mg_no_persist = 0;    // LFA_MG_NO_PERSIST=1: a launch per coarse-level phase (the bitwise A/B of k_mg_coarse)
-	int mg_cp_max_tiles = -1; // LFA_MG_CP_MAX_TILES
-	int mg_no_cp = 0;         // LFA_MG_NO_CP=1
-	int mg_tail_inner = 0;    // LFA_MG_TAIL_INNER
-	int mg_nsw = 0;           // LFA_MG_NSW
-	int mg_co_stamps = 0;     // LFA_MG_CO_STAMPS=1
-	int mg_no_chain = 0;      // LFA_MG_NO_CHAIN=1
+	int mg_no_persist = 0;    // LFA_MG_NO_PERSIST=1: a launch per coarse-level phase instead of k_mg_coarse (the path a handle falls back
+	                          // to when a device-side wait was given up; bit-identical: the A/B of the tests)
+	int mg_dist_single = 0;   // LFA_MG_DIST_SINGLE=1: the slab mode of the hierarchy with a one-rank communicator (tests, one-rank overhead)
 	int mg_co_fault = 0;      // LFA_MG_CO_FAULT=n (tests): workgroup n - 1 of k_mg_coarse never raises its first flag
-	int pcg_small = 0;        // LFA_PCG_SMALL=1: the whole solve of a small system in one launch
-	int pcg_small_max = -1;   // LFA_PCG_SMALL_MAX
-	int pcg_ga = 0, pcg_gb = 0;  // LFA_PCG_GA / _GB
-	double coarse_w1 = __builtin_nan(""), coarse_w2 = __builtin_nan("");  // LFA_COARSE_W1 / _W2
 };
+// (process-wide, read once: LFA_PCG_GRID_CAP - workgroups of the solve's streaming kernels, core.hip; LFA_POOL_MAX_BYTES - the block
+// cache, pool.hip; LFA_SHM_TIMEOUT_S / LFA_SHM_SLOT_MB - the host-staged transport, dist.hip)
 
 struct lfa_sim {
 	int device = 0;
@@ -143,10 +106,6 @@ struct lfa_sim {
 	int cur = 0;
 	uint32_t *rank = nullptr;
 	bool binned = false;
-	// the particles of every tile are in CELL order (core.hip: k_cell_sort - per 64-cell z-slice of the tile the k-th particles of
-	// its cells, then the (k+1)-th ...) and cell_count describes exactly that order: true from a binning until anything moves a
-	// particle. The cell-centric P2G scatter (p2g.hip: k_p2g_cells) needs it.
-	bool cell_sorted = false;
 
 	// z-slab domain decomposition (dist.hip). Every rank indexes the GLOBAL grid; it owns the tile layers
 	// [slab_lo, slab_hi) and mirrors one ghost tile layer on each side. dist == nullptr: single domain.
@@ -220,12 +179,10 @@ struct lfa_sim {
 	double last_residual = 0.0;
 	uint64_t last_iters = 0;
 	// lfa_get_solver_stats
-	uint64_t stat_launches_iter = 0, stat_transport_iter = 0, stat_transport_solve = 0, stat_mg_levels = 0, stat_mg_first_co = 0, stat_whole_solve = 0;
+	uint64_t stat_launches_iter = 0, stat_transport_iter = 0, stat_transport_solve = 0, stat_mg_levels = 0, stat_mg_first_co = 0;
 	// kernels whose workgroups wait for each other (k_mg_coarse, k_pcg_small): a wait that was given up (mg.hip: co_wait) ends
 	// their use on this handle; the solve that met it is repeated on the launch-per-phase path
 	bool last_rhs_zero = false;  // the previous solve was the early-out of a zero right-hand side (pcg.hip: k_check_rhs)
-	bool co_xcd_disabled = false;  // k_mg_coarse's one-XCD mode met a workgroup on another XCD (or a wait ran out in it): not used again
-	bool co_last_xcd = false;      // the last k_mg_coarse launch ran in that mode
 	bool co_disabled = false;
 	uint64_t stat_co_aborts = 0, stat_co_reason = 0;
 	bool gate_counted = false;  // this handle is in the device's count of live handles (lfa_co_gate_handle)

@@ -202,10 +202,9 @@ __global__ void k_init_ctype(uint8_t *ctype, uint8_t *solid, GridDims g, size_t 
 }
 
 /// The correction's stream yields to the main one: the solve's short kernels should not queue behind a long VALU-bound launch.
-static hipError_t create_low_priority_stream(hipStream_t *st, int prio_knob) {
+static hipError_t create_low_priority_stream(hipStream_t *st) {
 	int least = 0, greatest = 0;
 	if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
-	if (prio_knob != 0x7fffffff) least = prio_knob;
 	return hipStreamCreateWithPriority(st, hipStreamNonBlocking, least);
 }
 
@@ -217,49 +216,13 @@ static void lfa_knobs_parse(lfa_knobs &k) {
 		const char *e = getenv(name);
 		return e ? (atoi(e) != 0 ? 1 : 0) : dflt;
 	};
-	k.bin_cellsort = flag("LFA_BIN_CELLSORT", 0);
-	k.p2g_cells = flag("LFA_P2G_CELLS", 1);
-	k.full_scatter = flag("LFA_FULL_SCATTER", 0);
-	k.c_travels = flag("LFA_C_TRAVELS", 0);
-	k.bin_shuffle = flag("LFA_BIN_SHUFFLE", 0);
-	k.p2g_no_rot = flag("LFA_P2G_NO_ROT", 0);
 	auto num = [](const char *name, int dflt) -> int {
 		const char *e = getenv(name);
 		return e ? atoi(e) : dflt;
 	};
-	auto real_ = [](const char *name) -> double {
-		const char *e = getenv(name);
-		return e ? atof(e) : __builtin_nan("");
-	};
-	k.corr_no_big = flag("LFA_CORR_NO_BIG", 0);
-	k.corr_lds_pad = num("LFA_CORR_LDS_PAD", 0);
-	k.dist_two_reductions = flag("LFA_DIST_TWO_REDUCTIONS", 0);
-	k.corr_prio = num("LFA_CORR_PRIO", 0x7fffffff);
-	k.mg_mw_a = num("LFA_MG_MW_A", -1);
-	k.mg_mw_u = num("LFA_MG_MW_U", -1);
-	k.mg_dist_single = flag("LFA_MG_DIST_SINGLE", 0);
-	k.mg_no_small_setup = flag("LFA_MG_NO_SMALL_SETUP", 0);
-	k.mg_stop_at_single = flag("LFA_MG_STOP_AT_SINGLE", 0);
-	k.mg_tail_tiles = num("LFA_MG_TAIL_TILES", -1);
-	k.mg_co_max_tiles = num("LFA_MG_CO_MAX_TILES", -1);
-	k.mg_merge = flag("LFA_MG_MERGE", 0);
-	k.mg_fold = flag("LFA_MG_FOLD", 0);
 	k.mg_no_persist = flag("LFA_MG_NO_PERSIST", 0);
-	k.mg_top = flag("LFA_MG_TOP", 0);
-	k.mg_xcd = flag("LFA_MG_XCD", 0);
-	k.mg_cp_max_tiles = num("LFA_MG_CP_MAX_TILES", -1);
-	k.mg_no_cp = flag("LFA_MG_NO_CP", 0);
-	k.mg_tail_inner = num("LFA_MG_TAIL_INNER", 0);
-	k.mg_nsw = num("LFA_MG_NSW", 0);
-	k.mg_co_stamps = flag("LFA_MG_CO_STAMPS", 0);
-	k.mg_no_chain = flag("LFA_MG_NO_CHAIN", 0);
+	k.mg_dist_single = flag("LFA_MG_DIST_SINGLE", 0);
 	k.mg_co_fault = num("LFA_MG_CO_FAULT", 0);
-	k.pcg_small = flag("LFA_PCG_SMALL", 0);
-	k.pcg_small_max = num("LFA_PCG_SMALL_MAX", -1);
-	k.pcg_ga = num("LFA_PCG_GA", 0);
-	k.pcg_gb = num("LFA_PCG_GB", 0);
-	k.coarse_w1 = real_("LFA_COARSE_W1");
-	k.coarse_w2 = real_("LFA_COARSE_W2");
 	{
 		static std::once_flag once;
 		std::call_once(once, [&] {
@@ -314,7 +277,7 @@ extern "C" int lfa_create(lfa_sim **out, uint64_t nx, uint64_t ny, uint64_t nz, 
 			return lfa_fail(nullptr, LFA_E_HIP, "hipStreamCreate failed");
 		}
 		if (hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking) != hipSuccess ||
-		    create_low_priority_stream(&s->stream3, s->knobs.corr_prio) != hipSuccess ||
+		    create_low_priority_stream(&s->stream3) != hipSuccess ||
 		    hipEventCreateWithFlags(&s->ev_cfork, hipEventDisableTiming) != hipSuccess ||
 		    hipEventCreateWithFlags(&s->ev_cjoin, hipEventDisableTiming) != hipSuccess ||
 		    hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -609,7 +572,6 @@ extern "C" int lfa_upload_particles(lfa_sim *s, const void *aos152, uint64_t n) 
 	s->np_live = n;
 	s->next_global_id = n;  // (slabs: every rank is handed the whole set, ids = upload index)
 	s->binned = false;  // the grid stays what it was (G2P re-uploads corrected positions between apply and gather)
-	s->cell_sorted = false;
 	s->system_valid = false;
 	s->unknown_count_valid = false;
 	s->cur = 0;
@@ -813,7 +775,6 @@ extern "C" int lfa_seed_block(lfa_sim *s, const int64_t lo[3], const int64_t hi[
 	s->c_home_valid = false;
 	s->vmax2_valid = false;
 	s->binned = false;
-	s->cell_sorted = false;
 	s->grid_valid = false;
 	s->system_valid = false;
 	s->unknown_count_valid = false;
@@ -1008,10 +969,8 @@ __global__ void k_dilate(const int *ptiles, int n_ptiles, uint32_t *flag, GridDi
 /// Pass 2: move every particle to its tile's segment. With `shuffle` the slot inside the segment is a multiplicative
 /// permutation of the rank, which separates particles of one cell (uploads arrive cell-sorted; neighbouring lanes
 /// hitting one cell would serialise the LDS atomics of the P2G scatter).
-/// DEFER 1 (APIC): only key, t, id move (20 of the 68 bytes); from[d] records the source index, v and C follow through it
-/// (k_p2g_*, k_g2p FLIP, k_gather_vc) - see lfa_sim::vc_pending. DEFER 2 (PIC, FLIP): v alone stays behind - their G2P
-/// never writes C, so C has to travel with the particle. DEFER 0: the whole record moves.
-template <int DEFER>
+/// Only key, t, id move (20 of the 68 bytes); from[d] records the source index, v and C follow through it (k_p2g_binned,
+/// k_g2p, k_gather_vc) - see lfa_sim::vc_pending. (PIC / FLIP keep C in its home array, indexed by the particle id.)
 __global__ void k_tile_scatter(size_t n, ParticleSoA src, ParticleSoA dst, const uint32_t *rank,
                                const uint32_t *tile_start, const uint32_t *tile_count, int shuffle, uint32_t *from) {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1027,201 +986,8 @@ __global__ void k_tile_scatter(size_t n, ParticleSoA src, ParticleSoA dst, const
 #pragma unroll
 	for (int k = 0; k < 3; ++k) dst.t[k][d] = src.t[k][i];
 	dst.id[d] = src.id[i];
-	if (DEFER) from[d] = (uint32_t)i;
-	if (DEFER == 0) {
-#pragma unroll
-		for (int k = 0; k < 3; ++k) dst.v[k][d] = src.v[k][i];
-	}
-	if (DEFER != 1) {
-#pragma unroll
-		for (int k = 0; k < 9; ++k) dst.c[k][d] = src.c[k][i];
-	}
+	from[d] = (uint32_t)i;
 }
-// ---- cell-sorted binning (round 4) ------------------------------------------------------------------------------------------
-// The reference sorts its particles by cell (src/simulation.cpp:266-291) and its transfers consume the sorted runs (:346-398).
-// Here the tile is the unit of storage; INSIDE a tile the particles are put in an order a wave can consume with one lane per
-// cell and coalesced loads: the tile's eight z-slices (64 cells each, cell = lane) one after the other, and inside a slice the
-// 0-th particles of its cells (in cell order, cells without one skipped), then the 1-st particles, ... ("jagged diagonal" order),
-// LFA_CS_JMAX deep; what a crowded cell holds beyond that follows cell by cell. A particle's rank inside its cell is its rank by
-// source index - i.e. by where it stood in the order of the step before - so the order is a function of the particle state and
-// the previous order alone, not of which workgroup's atomics came first: the per-cell float sums of k_p2g_cells are reproducible.
-// Pass 2a moves nothing but an index (12 bytes per particle); pass 2b gathers key, t, id through it and writes every record once,
-// straight into its final place (through LDS: the stores leave as contiguous runs), together with the per-cell counts that
-// k_cell_count used to produce in a pass of its own.
-__global__ void k_tile_scatter_idx(size_t n, const uint32_t *key, const uint32_t *rank, const uint32_t *tile_start, uint32_t *from_tmp) {
-	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	const uint32_t k = key[i];
-	if (k == 0xFFFFFFFFu) return;
-	from_tmp[(size_t)tile_start[k >> 9] + rank[i]] = (uint32_t)i;
-}
-
-#define CS_THREADS 512
-#define CS_RPT 12                        // particles per thread of a tile that is ranked canonically and staged (registers)
-#define CS_MAXT (CS_THREADS * CS_RPT)    // 6144: more crowded tiles take the slow path (provisional ranks, scattered stores)
-#define CS_CHUNK 2560                    // records staged in LDS per pass (24 bytes each)
-static_assert(LFA_CS_JMAX == 64, "the slice tables are sized for 64 runs");
-
-/// Position of the particle with rank j in cell l of a tile (relative to the tile's first record): the tables are the sort kernel's.
-__device__ inline uint32_t cs_position(uint32_t l, uint32_t j, const uint32_t *sbase, const uint32_t (*jrun)[LFA_CS_JMAX + 1],
-                                       const unsigned long long (*jmask)[LFA_CS_JMAX], const uint32_t *tail_off) {
-	const uint32_t w = l >> 6, c = l & 63;
-	if (j < LFA_CS_JMAX) return sbase[w] + jrun[w][j] + (uint32_t)__popcll(jmask[w][j] & ((1ull << c) - 1ull));
-	return sbase[w] + jrun[w][LFA_CS_JMAX] + tail_off[l] + (j - LFA_CS_JMAX);
-}
-
-__global__ void __launch_bounds__(CS_THREADS)
-k_cell_sort(const int *dtiles, int n_dtiles, ParticleSoA src, ParticleSoA dst, const uint32_t *from_tmp, const uint32_t *tile_start,
-            uint32_t *from_out, uint32_t *cell_count) {
-	__shared__ uint32_t cnt[LFA_TILE_CELLS];      // particles per cell
-	__shared__ uint32_t cstart[LFA_TILE_CELLS];   // first slot of the cell in the provisional (cell-major) order; slow path: cursor
-	__shared__ uint32_t tail_off[LFA_TILE_CELLS]; // start of the cell's tail (rank >= JMAX) among the tails of its slice
-	__shared__ unsigned long long jmask[8][LFA_CS_JMAX];  // cells of the slice that hold more than j particles
-	__shared__ uint32_t jrun[8][LFA_CS_JMAX + 1];         // first record of run j inside the slice; [JMAX]: start of the tails
-	__shared__ uint32_t sbase[9];                 // first record of every slice; [8] = particles of the tile
-	__shared__ uint32_t wsum[8];
-	__shared__ uint32_t buf[6 * CS_CHUNK];        // the sources in provisional order (ranking), then the staged records
-	static_assert(6 * CS_CHUNK >= CS_MAXT, "the staging area doubles as the ranking array");
-	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-	for (int slot = blockIdx.x; slot < n_dtiles; slot += gridDim.x) {
-		const int tile = dtiles[slot];
-		const uint32_t b = tile_start[tile], e = tile_start[tile + 1], nt = e - b;
-		if (nt == 0) {  // (uniform) a tile of the dilated set without particles
-			cell_count[(size_t)tile * LFA_TILE_CELLS + threadIdx.x] = 0;
-			continue;
-		}
-		const bool fast = nt <= CS_MAXT;  // (uniform)
-		__syncthreads();
-		cnt[threadIdx.x] = 0;
-		__syncthreads();
-		// ---- phase 1: where every particle comes from, its key (cell), and the histogram; the fast path keeps what it has read
-		uint32_t rs[CS_RPT], rk[CS_RPT], rid[CS_RPT], r0[CS_RPT];
-		float rt0[CS_RPT], rt1[CS_RPT], rt2[CS_RPT];
-		if (fast) {
-#pragma unroll
-			for (int r = 0; r < CS_RPT; ++r) {
-				const uint32_t i = b + threadIdx.x + CS_THREADS * r;
-				rs[r] = 0xFFFFFFFFu;
-				if (i < e) {
-					const uint32_t sidx = from_tmp[i];
-					rs[r] = sidx;
-					rk[r] = src.key[sidx];
-					rt0[r] = src.t[0][sidx]; rt1[r] = src.t[1][sidx]; rt2[r] = src.t[2][sidx];
-					rid[r] = src.id[sidx];
-				}
-			}
-#pragma unroll
-			for (int r = 0; r < CS_RPT; ++r)
-				if (rs[r] != 0xFFFFFFFFu) r0[r] = atomicAdd(&cnt[rk[r] & 511u], 1u);
-		} else {
-			for (uint32_t i = b + threadIdx.x; i < e; i += CS_THREADS) atomicAdd(&cnt[src.key[from_tmp[i]] & 511u], 1u);
-		}
-		__syncthreads();
-		// ---- phase 2: wave w owns slice w (lane = cell): slice totals, the run tables, the tails
-		const uint32_t c = cnt[threadIdx.x];
-		cell_count[(size_t)tile * LFA_TILE_CELLS + threadIdx.x] = c;
-		uint32_t incl = c;
-#pragma unroll
-		for (int o = 1; o < 64; o <<= 1) {
-			const uint32_t t = __shfl_up(incl, o, 64);
-			if (lane >= o) incl += t;
-		}
-		if (lane == 63) wsum[wid] = incl;
-		{
-			uint32_t run = 0;
-			for (uint32_t j = 0; j < LFA_CS_JMAX; ++j) {
-				const unsigned long long m = __ballot(c > j);
-				if (m == 0ull) break;
-				if (lane == 0) {
-					jmask[wid][j] = m;
-					jrun[wid][j] = run;
-				}
-				run += (uint32_t)__popcll(m);
-			}
-			if (lane == 0) jrun[wid][LFA_CS_JMAX] = run;
-			const uint32_t tc = c > LFA_CS_JMAX ? c - LFA_CS_JMAX : 0u;
-			uint32_t ti = tc;
-#pragma unroll
-			for (int o = 1; o < 64; o <<= 1) {
-				const uint32_t t = __shfl_up(ti, o, 64);
-				if (lane >= o) ti += t;
-			}
-			tail_off[threadIdx.x] = ti - tc;
-		}
-		__syncthreads();
-		if (threadIdx.x == 0) {
-			uint32_t a = 0;
-			for (int w = 0; w < 8; ++w) {
-				sbase[w] = a;
-				a += wsum[w];
-			}
-			sbase[8] = a;
-		}
-		__syncthreads();
-		cstart[threadIdx.x] = fast ? sbase[wid] + incl - c : 0u;
-		__syncthreads();
-		if (fast) {
-			// ---- phase 3: the sources, grouped by cell (in the order the atomics came back)
-#pragma unroll
-			for (int r = 0; r < CS_RPT; ++r)
-				if (rs[r] != 0xFFFFFFFFu) buf[cstart[rk[r] & 511u] + r0[r]] = rs[r];
-			__syncthreads();
-			// ---- phase 4 + 5: rank inside the cell = number of its particles with a smaller source index; the final position
-			uint32_t rp[CS_RPT];
-#pragma unroll
-			for (int r = 0; r < CS_RPT; ++r) {
-				rp[r] = 0xFFFFFFFFu;
-				if (rs[r] != 0xFFFFFFFFu) {
-					const uint32_t l = rk[r] & 511u, cb = cstart[l], cn = cnt[l];
-					uint32_t j = 0;
-					for (uint32_t k = 0; k < cn; ++k) j += buf[cb + k] < rs[r] ? 1u : 0u;
-					rp[r] = cs_position(l, j, sbase, jrun, jmask, tail_off);
-				}
-			}
-			__syncthreads();  // (the ranking array is dead: the records are staged over it)
-			// ---- phase 6: records to their places, a chunk of positions at a time, written out as contiguous runs
-			for (uint32_t lo = 0; lo < nt; lo += CS_CHUNK) {
-#pragma unroll
-				for (int r = 0; r < CS_RPT; ++r) {
-					const uint32_t q = rp[r] - lo;  // (0xFFFFFFFF - lo is out of range as well)
-					if (rp[r] != 0xFFFFFFFFu && q < CS_CHUNK) {
-						buf[q] = rk[r];
-						buf[CS_CHUNK + q] = __float_as_uint(rt0[r]);
-						buf[2 * CS_CHUNK + q] = __float_as_uint(rt1[r]);
-						buf[3 * CS_CHUNK + q] = __float_as_uint(rt2[r]);
-						buf[4 * CS_CHUNK + q] = rid[r];
-						buf[5 * CS_CHUNK + q] = rs[r];
-					}
-				}
-				__syncthreads();
-				const uint32_t m = nt - lo < CS_CHUNK ? nt - lo : CS_CHUNK;
-				for (uint32_t q = threadIdx.x; q < m; q += CS_THREADS) {
-					const size_t d = (size_t)b + lo + q;
-					dst.key[d] = buf[q];
-					dst.t[0][d] = __uint_as_float(buf[CS_CHUNK + q]);
-					dst.t[1][d] = __uint_as_float(buf[2 * CS_CHUNK + q]);
-					dst.t[2][d] = __uint_as_float(buf[3 * CS_CHUNK + q]);
-					dst.id[d] = buf[4 * CS_CHUNK + q];
-					from_out[d] = buf[5 * CS_CHUNK + q];
-				}
-				__syncthreads();
-			}
-		} else {
-			// ---- a tile with more particles than the fast path holds: ranks in the order the atomics come back (a valid cell order,
-			// not a reproducible one), stores straight to their places
-			for (uint32_t i = b + threadIdx.x; i < e; i += CS_THREADS) {
-				const uint32_t sidx = from_tmp[i], k = src.key[sidx], l = k & 511u;
-				const uint32_t j = atomicAdd(&cstart[l], 1u);
-				const size_t d = (size_t)b + cs_position(l, j, sbase, jrun, jmask, tail_off);
-				dst.key[d] = k;
-				dst.t[0][d] = src.t[0][sidx]; dst.t[1][d] = src.t[1][sidx]; dst.t[2][d] = src.t[2][sidx];
-				dst.id[d] = src.id[sidx];
-				from_out[d] = sidx;
-			}
-		}
-	}
-}
-
 /// C to / from its home array (indexed by particle id): see lfa_sim::c_home.
 __global__ void k_c_to_home(size_t n, ParticleSoA p, float *home, size_t stride) {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1248,15 +1014,6 @@ __global__ void k_gather_vc(size_t n, ParticleSoA old, ParticleSoA cur, const ui
 #pragma unroll
 		for (int k = 0; k < 9; ++k) cur.c[k][d] = old.c[k][i];
 	}
-}
-
-/// DEFER 2 on the cell-sorted path: C follows the particle at once (v stays behind).
-__global__ void k_gather_c(size_t n, ParticleSoA old, ParticleSoA cur, const uint32_t *from) {
-	size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (d >= n) return;
-	const uint32_t i = from[d];
-#pragma unroll
-	for (int k = 0; k < 9; ++k) cur.c[k][d] = old.c[k][i];
 }
 
 /// Particles per cell for every processed tile (the `count` half of _space_hash, src/simulation.cpp:266-291);
@@ -1481,16 +1238,13 @@ int lfa_hash_particles_impl(lfa_sim *s, bool counts_done) {
 	s->move_pending = false;  // (a binning re-uses the buffer the positions of before a split move were kept in)
 	if (n) {
 		// v and C (48 of the 68 bytes) stay behind and are read through vc_src by the P2G; the G2P writes the new ones in the
-		// new order (the slab migration, which packs whole records, completes the move first)
-		// PIC and FLIP carry C through the step unchanged (the reference's G2P does not touch it), so there C travels with the
-		// particle and only v stays behind
-		int defer = s->knobs.full_scatter ? 0 : (s->prm.simulation_method == LFA_APIC ? 1 : 2);
+		// new order (the slab migration, which packs whole records, completes the move first).
+		// PIC and FLIP carry C through the step unchanged (the reference's G2P does not touch it): C goes to its home array once and
+		// stays there, so their scatter moves key, t, id alone, like APIC's. The array is indexed by the particle id: on slabs by the
+		// job-wide id, so every rank holds room for every particle of the job - 36 bytes each, 2.4 GB at C4 - and a particle that
+		// changes ranks takes its nine floats along in its record (dist.hip: k_pack_leavers / k_unpack_arrivals)
 		const dim3 sgrid((unsigned)((n + 255) / 256));
-		// PIC / FLIP: C goes to its home array once and stays there - the scatter then moves key, t, id alone, like APIC's
-		// (LFA_C_TRAVELS=1: the round-2 behaviour, C moves with every binning). The array is indexed by the particle id: on slabs
-		// (round 4) by the job-wide id, so every rank holds room for every particle of the job - 36 bytes each, 2.4 GB at C4 - and a
-		// particle that changes ranks takes its nine floats along in its record (dist.hip: k_pack_leavers / k_unpack_arrivals)
-		const bool home = defer == 2 && !s->knobs.c_travels;
+		const bool home = s->prm.simulation_method != LFA_APIC;
 		if (home && !s->c_home_valid) {
 			LFA_TRY(lfa_c_home_ensure(s, s->dist ? std::max<size_t>(s->pcap, (size_t)s->next_global_id) : s->pcap));
 			hipLaunchKernelGGL(k_c_to_home, sgrid, dim3(256), 0, s->stream, n, src, s->c_home, s->c_home_cap);
@@ -1499,52 +1253,15 @@ int lfa_hash_particles_impl(lfa_sim *s, bool counts_done) {
 		} else if (!home && s->c_home_valid) {  // the method has changed to APIC
 			LFA_TRY(lfa_c_home_restore(s));
 		}
-		if (home) defer = 3;
-		if (s->knobs.bin_cellsort) {
-			// pass 2a: the destination of every particle as an index (into a particle array that is free right now: the last C
-			// array of the buffer being filled - the gathers that write it, if any, come after the sort); pass 2b: the records,
-			// once, into cell order
-			uint32_t *from_tmp = (uint32_t *)dst.c[8];
-			hipLaunchKernelGGL(k_tile_scatter_idx, sgrid, dim3(256), 0, s->stream, n, (const uint32_t *)src.key, (const uint32_t *)s->rank,
-			                   (const uint32_t *)s->tile_start, from_tmp);
-			LFA_LAUNCH_CHECK(s);
-			if (s->n_dtiles) {
-				const int grid = s->n_dtiles < 16384 ? s->n_dtiles : 16384;
-				hipLaunchKernelGGL(k_cell_sort, dim3(grid), dim3(CS_THREADS), 0, s->stream, (const int *)s->dtiles, s->n_dtiles, src, dst,
-				                   (const uint32_t *)from_tmp, (const uint32_t *)s->tile_start, s->vc_src, s->cell_count);
-				LFA_LAUNCH_CHECK(s);
-			}
-			s->cur ^= 1;
-			s->vc_pending = true;
-			s->vc_extent = n;
-			s->vc_with_c = defer <= 1;  // (0: everything follows at once; 2: C follows at once, v stays deferred)
-			if (defer == 0) {
-				LFA_TRY(lfa_particles_materialize(s));
-			} else if (defer == 2) {
-				hipLaunchKernelGGL(k_gather_c, sgrid, dim3(256), 0, s->stream, n, s->pb[s->cur ^ 1], s->pb[s->cur], (const uint32_t *)s->vc_src);
-				LFA_LAUNCH_CHECK(s);
-			}
-			s->binned = true;
-			s->cell_sorted = true;
-			s->system_valid = false;
-			s->unknown_count_valid = false;
-			return LFA_OK;
-		}
-		const int shuffle = (!s->binned || s->knobs.bin_shuffle) ? 1 : 0;
-		if (defer == 1 || defer == 3)
-			hipLaunchKernelGGL(k_tile_scatter<1>, sgrid, dim3(256), 0, s->stream, n, src, dst, s->rank, s->tile_start, s->tile_count,
-			                   shuffle, s->vc_src);
-		else if (defer == 2)
-			hipLaunchKernelGGL(k_tile_scatter<2>, sgrid, dim3(256), 0, s->stream, n, src, dst, s->rank, s->tile_start, s->tile_count,
-			                   shuffle, s->vc_src);
-		else
-			hipLaunchKernelGGL(k_tile_scatter<0>, sgrid, dim3(256), 0, s->stream, n, src, dst, s->rank, s->tile_start, s->tile_count,
-			                   shuffle, (uint32_t *)nullptr);
+		// (an upload arrives cell-sorted: the first binning permutes the slots inside a tile so that neighbouring lanes of the P2G
+		// do not hit one cell)
+		hipLaunchKernelGGL(k_tile_scatter, sgrid, dim3(256), 0, s->stream, n, src, dst, s->rank, s->tile_start, s->tile_count,
+		                   s->binned ? 0 : 1, s->vc_src);
 		LFA_LAUNCH_CHECK(s);
 		s->cur ^= 1;
-		s->vc_pending = defer != 0;
+		s->vc_pending = true;
 		s->vc_extent = n;
-		s->vc_with_c = defer == 1;
+		s->vc_with_c = !home;
 	}
 	if (s->n_dtiles) {
 		int grid = s->n_dtiles < 8192 ? s->n_dtiles : 8192;
@@ -1553,7 +1270,6 @@ int lfa_hash_particles_impl(lfa_sim *s, bool counts_done) {
 		LFA_LAUNCH_CHECK(s);
 	}
 	s->binned = true;
-	s->cell_sorted = false;
 	s->system_valid = false;
 	s->unknown_count_valid = false;
 	return LFA_OK;

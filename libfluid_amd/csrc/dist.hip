@@ -478,7 +478,6 @@ int lfa_dist_migrate(lfa_sim *s, bool vc_dead) {
 		}
 	// the next binning scans [0, at): leavers carry an invalid key and are dropped there
 	s->np_live = at;
-	s->cell_sorted = false;
 	// lfa_num_particles: the resident count follows the hand-over at once (binned: np counted the live particles of the last
 	// binning; unbinned: np is the extent of the array, holes included, until the next binning compacts it)
 	if (!s->binned) s->np = at;
@@ -991,7 +990,6 @@ int attach(lfa_sim *s, lfa_dist *d, const int32_t *bounds) {
 	s->slab_lo = lo;
 	s->slab_hi = hi;
 	s->binned = false;
-	s->cell_sorted = false;
 	s->sources_valid = false;  // the seeding entries are the ones of this rank's own tile layers ...
 	s->sources_built.clear();  // ... so entries flattened for another range (the whole domain, earlier bounds) are not "the same list"
 	s->grid_valid = false;

@@ -80,18 +80,13 @@ struct lfa_mg {
 	uint8_t *l1_dirty = nullptr;  // device, per level-1 tile: a child tile was flagged at the last set-up (k_mg_types_from_fine_dirty)
 	unsigned solid_epoch = 0;     // solid mask the level-1 types were computed for
 	uint32_t *counts = nullptr;   // device, active tiles per level (single-domain set-up, read back once)
-	double *ps_part = nullptr;    // k_pcg_small: [3][PS_MAX_TILES] partials, then (as unsigned) [2][PS_MAX_TILES] their tags
 	unsigned co_tag = 0;          // k_mg_coarse: launch counter = the value its ready flags are raised to (lfa_mg_level::ready)
-	unsigned long long *co_stamps = nullptr;  // LFA_MG_CO_STAMPS=1: phase stamps of the last k_mg_coarse launch, printed by lfa_mg_free
-	int co_phases = 0;
 	int launches_per_cycle = 0;   // launches of the last V-cycle incl. the AXPY / pre-smoothing kernel (lfa_get_solver_stats)
 	int first_co = 0;             // first level inside k_mg_coarse at the last V-cycle (0: launch-per-phase path)
-	int *q = nullptr;             // k_mg_down01 / k_mg_up01: the words of their work queues (MgQueue), zero between launches
 };
 // A level stays distributed while no tile layer straddles a slab face, and its ghost types follow from the one fine ghost tile
 // layer a rank mirrors (8 cells = one slice of level 3).
 #define MG_DIST_MAX 4
-#define MG_CO_PHASES 64
 #define MG_CO_MAX_LEVELS 8  // levels inside k_mg_coarse (a 2048^3 grid has 9 levels in all)
 
 namespace {
@@ -396,14 +391,6 @@ struct MemAgent {
 	template <typename T> static __device__ inline T ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 	template <typename T> static __device__ inline void st(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 };
-/// Workgroup-scope relaxed atomics (`sc0`: the access bypasses the CU's L1 and meets the others in the L2) - enough, and half the
-/// round trip of `sc1`, when every workgroup that takes part sits on ONE XCD and so shares one L2 (k_mg_coarse's XCD mode; the
-/// ready flags carry the producer's XCC id, so a consumer on another XCD notices before it reads anything).
-struct MemWg {
-	template <typename T> static __device__ inline T ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-	template <typename T> static __device__ inline void st(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-};
-
 /// One colour of the Gauss-Seidel update on the column of a lane: x_i = (b_i + sum of coupled neighbours) / diag_i.
 /// `h` is the 10^3 halo block of the wave (current values, ring = values of the neighbour tiles or 0).
 template <typename real>
@@ -447,7 +434,7 @@ __device__ inline void presmooth_column(real *h, const uint32_t (&ab)[8], const 
 	}
 }
 /// (LD / ST: how the right-hand side is read and the iterate written - MemAgent where another workgroup of the SAME launch wrote or
-/// will read them, see k_mg_down01)
+/// will read them: k_mg_coarse)
 template <typename real, typename LD = MemPlain, typename ST = MemPlain>
 __device__ inline void presmooth_tile(const MgLv<real> &L, int slot, real *h, int lane, int inner) {
 	const int lx = lane & 7, ly = lane >> 3;
@@ -805,92 +792,16 @@ __global__ void __launch_bounds__(256) k_mg_residual_restrict(MgLv<real> L, Grid
 		residual_restrict_tile<real>(L, gc, b_coarse, slot, halo[wid], lane);
 }
 
-// ------------------------------------------------------------------------------------------------ two levels per launch
-// Level 1 (C4: 2 400 tiles) is too large for k_mg_coarse - whose workgroups must all be resident - and too small for launches of its
-// own: three of them cost 28 us of a 280 us iteration for a few microseconds of work. k_mg_down01 / k_mg_up01 run level 1's phases
-// inside the level-0 launches next to them. What replaces the kernel boundary between two phases is an ORDERED WORK QUEUE: the
-// waves take (phase, tile) items from one counter in phase order, an item of phase k waits until the count of finished items of
-// phase k - 1 is complete. No workgroup has to be resident for another to get on: whoever holds an item of an earlier phase is
-// running (it took the item), and finishes it without waiting for anything later - so the waits end whatever the occupancy, other
-// kernels on the device, or the number of handles (unlike a grid barrier, and unlike k_mg_coarse, which needs lfa_co_gate).
-// What a phase hands to the next inside the launch travels with agent-scope accesses (MemAgent: coherent across the XCDs' L2s).
-// The waits are bounded like k_mg_coarse's (co_poll_expired: abort word, the solve is repeated on the launch-per-phase path).
-// Queue words (lfa_mg::q, zero between launches - the last wave to leave clears them): [0] next item, [1] waves that have left,
-// [2], [3] finished items of the first / second phase.
-__device__ inline void co_backoff(int &n);
-__device__ inline bool co_poll_expired(int tries, unsigned long long &t0, int *abort_word);
-struct MgQueue {
-	int *q;
-	int *abort_word;
-};
-/// Lane 0's view of "phase complete": polls q[w] until it reaches n. false: given up (abort word raised).
-__device__ inline bool mq_wait(const MgQueue &Q, int w, int n) {
-	int ok = 1;
-	if ((threadIdx.x & 63) == 0) {
-		int tries = 0;
-		unsigned long long t0 = 0ull;
-		while (__hip_atomic_load(Q.q + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) {
-			co_backoff(tries);
-			if (co_poll_expired(tries, t0, Q.abort_word)) {
-				if (__hip_atomic_load(Q.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) Q.abort_word[16] = 0x300 | w;
-				__hip_atomic_store(Q.abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				ok = 0;
-				break;
-			}
-		}
-	}
-	return __shfl(ok, 0, 64) != 0;
-}
-/// The wave's stores of this item have been acknowledged; then the phase's count goes up.
-__device__ inline void mq_done(const MgQueue &Q, int w) {
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(Q.q + w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ inline int mq_take(const MgQueue &Q) {
-	int item = 0;
-	if ((threadIdx.x & 63) == 0) item = __hip_atomic_fetch_add(Q.q + 0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	return __builtin_amdgcn_readfirstlane(item);
-}
-/// Every wave, on its way out: the last one clears the queue for the next launch.
-__device__ inline void mq_leave(const MgQueue &Q, int n_waves) {
-	if ((threadIdx.x & 63) == 0 && __hip_atomic_fetch_add(Q.q + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_waves - 1) {
-		__hip_atomic_store(Q.q + 0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		__hip_atomic_store(Q.q + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		__hip_atomic_store(Q.q + 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		__hip_atomic_store(Q.q + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	}
-}
-
 /// LEVEL0: the result is scaled by 1/scale and dot(z, r) is formed.
-/// UP1 (with LEVEL0; see "two levels per launch" above): level 1's prolongation + post-smoothing runs in this launch first - the
-/// waves take its tiles from the queue, `e` (level 1's result) is complete when the count of finished tiles is, and is read
-/// with agent-scope loads. Same arithmetic per tile as the launch of its own: bit-identical results.
-template <typename real, bool LEVEL0, int MW, bool UP1 = false>
+template <typename real, bool LEVEL0, int MW>
 __global__ void __launch_bounds__(256, MW)
-k_mg_prolong_postsmooth(MgLv<real> L, GridDims gc, const real *e, real inv_scale, double *part_sigma, const int *state, MgLv<real> L1,
-                        GridDims g2, const real *e2, MgQueue Q) {
+k_mg_prolong_postsmooth(MgLv<real> L, GridDims gc, const real *e, real inv_scale, double *part_sigma, const int *state) {
 	__shared__ real halo[PCG_WAVES][LFA_HALO_CELLS];
 	__shared__ double red[4];
 	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
 	real *h = halo[wid];
 	double acc = 0.0;
-	bool run = state[0] < 0;
-	if (UP1 && run) {
-		const int lxx = lane & 7, lyy = lane >> 3;
-		int item = mq_take(Q);
-		while (item < L1.n_tiles) {
-			const int next = mq_take(Q);
-			real bb1[8];
-			prolong_postsmooth_tile<real>(L1, g2, e2, item, h, lane, bb1, MG_INNER_SWEEPS);
-			const size_t b1 = (size_t)L1.nbr[(size_t)item * MG_NBR_STRIDE + 6] * 512;
-#pragma unroll
-			for (int zz = 0; zz < 8; ++zz) MemAgent::st(L1.y + b1 + zz * 64 + lane, h[(lxx + 1) + 10 * (lyy + 1) + 100 * (zz + 1)]);
-			mq_done(Q, 2);
-			item = next;
-		}
-		run = mq_wait(Q, 2, L1.n_tiles);
-		MG_FENCE();
-	}
+	const bool run = state[0] < 0;
 	if (run) {
 		// The body of prolong_postsmooth_tile as a software pipeline: every load of the wave's next tile (column, ring, the
 		// parents' corrections) is in flight while the current tile is swept in LDS.
@@ -908,8 +819,7 @@ k_mg_prolong_postsmooth(MgLv<real> L, GridDims gc, const real *e, real inv_scale
 			tile_coords(L.g, tile, tx_, ty_, tz_);
 			auto corr = [&](int X, int Y, int Z) -> real {
 				if (!e) return (real)0;
-				const real *q = e + blocked_index(gc, X >> 1, Y >> 1, Z >> 1);
-				return UP1 ? MemAgent::ld(q) : *q;
+				return e[blocked_index(gc, X >> 1, Y >> 1, Z >> 1)];
 			};
 #pragma unroll
 			for (int zz = 0; zz < 8; ++zz) {
@@ -988,51 +898,6 @@ k_mg_prolong_postsmooth(MgLv<real> L, GridDims gc, const real *e, real inv_scale
 		__syncthreads();
 		if (threadIdx.x == 0) part_sigma[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 	}
-	if (UP1) mq_leave(Q, (int)gridDim.x * PCG_WAVES);
-}
-
-/// Down: level 0's residual + restriction, level 1's pre-smoothing, level 1's residual + restriction - three launches before.
-/// Items [0, n0): a level-0 tile; [n0, n0 + n1): pre-smoothing of a level-1 tile (needs every restricted value: phase 0 complete);
-/// [n0 + n1, n0 + 2 n1): its residual (needs the neighbours' pre-smoothed iterate: phase 1 complete). Same arithmetic per tile as
-/// k_mg_residual_restrict / k_mg_presmooth: bit-identical results.
-template <typename real>
-__global__ void __launch_bounds__(256) k_mg_down01(MgLv<real> L0, MgLv<real> L1, GridDims g2, real *b2, MgQueue Q, const int *state) {
-	__shared__ real halo[PCG_WAVES][LFA_HALO_CELLS];
-	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	real *h = halo[wid];
-	const int n0 = L0.n_tiles, n1 = L1.n_tiles;
-	if (state[0] < 0) {
-		int phase = 0;
-		bool ok = true;
-		int item = mq_take(Q);
-		while (ok && item < n0 + 2 * n1) {
-			const int next = mq_take(Q);  // (in flight while this item is worked on)
-			if (item < n0) {
-				residual_restrict_tile<real, MemPlain, MemAgent>(L0, L1.g, L1.b, item, h, lane);
-				mq_done(Q, 2);
-			} else if (item < n0 + n1) {
-				if (phase < 1) {
-					ok = mq_wait(Q, 2, n0);
-					phase = 1;
-					MG_FENCE();
-					for (int i = lane; i < LFA_HALO_CELLS; i += 64) h[i] = (real)0;  // the ring stays zero through the pre-smoothing
-					MG_FENCE();
-				}
-				if (ok) presmooth_tile<real, MemAgent, MemAgent>(L1, item - n0, h, lane, MG_INNER_SWEEPS);
-				mq_done(Q, 3);
-			} else {
-				if (phase < 2) {
-					if (phase < 1) ok = mq_wait(Q, 2, n0);
-					if (ok) ok = mq_wait(Q, 3, n1);
-					phase = 2;
-					MG_FENCE();
-				}
-				if (ok) residual_restrict_tile<real, MemAgent, MemPlain>(L1, g2, b2, item - n0 - n1, h, lane);
-			}
-			item = next;
-		}
-	}
-	mq_leave(Q, (int)gridDim.x * PCG_WAVES);
 }
 
 /// gs_colour for ONE cell (halo index i): the same expression, term by term.
@@ -1222,48 +1087,6 @@ __global__ void __launch_bounds__(256) k_mg_residual_restrict_cp(MgLv<real> L, G
 	if (state[0] >= 0) return;
 	for (int slot = blockIdx.x; slot < L.n_tiles; slot += gridDim.x) cp_residual_restrict_tile<real, MemPlain>(S, R, L, gc, b_coarse, slot);
 }
-/// Level 0's residual + restriction and level 1's pre-smoothing in ONE launch (round 4; the judge's "fold"): a workgroup per
-/// LEVEL-1 tile takes that tile's (up to) eight children - two per wave, the wave-per-tile arithmetic of k_mg_residual_restrict -,
-/// collects the restricted values in LDS, and, since a pre-smoothing from a zero guess needs nothing from other tiles, sweeps the
-/// parent right there (the cell-parallel form of k_mg_presmooth_cp). Writes level 1's right-hand side and iterate. Same operations
-/// in the same order per cell: bit-identical to the two launches it replaces. `pslot0`: level-0 tile -> slot of its list.
-template <typename real>
-__global__ void __launch_bounds__(256) k_mg_restrict0_pre1(MgLv<real> L0, MgLv<real> L1, const int *pslot0, int inner, const int *state) {
-	__shared__ real halo[PCG_WAVES][LFA_HALO_CELLS];
-	__shared__ CpTile<real> S;
-	if (state[0] >= 0) return;
-	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, t = threadIdx.x;
-	for (int item = blockIdx.x; item < L1.n_tiles; item += gridDim.x) {
-		const int *row = L1.nbr + (size_t)item * MG_NBR_STRIDE;
-		const int tile1 = row[6], mask = row[7];
-		int tx, ty, tz;
-		tile_coords(L1.g, tile1, tx, ty, tz);
-		const size_t base1 = (size_t)tile1 * 512;
-		for (int c = t; c < 512; c += 256) S.ab[c] = L1.abits[base1 + c];
-		for (int k = 2 * wid; k < 2 * wid + 2; ++k) {
-			const int cx = 2 * tx + (k & 1), cy = 2 * ty + ((k >> 1) & 1), cz = 2 * tz + (k >> 2);
-			const int slot0 = ((mask >> k) & 1) ? pslot0[cx + L0.g.ntx * (cy + L0.g.nty * cz)] : -1;
-			if (slot0 >= 0) {
-				residual_restrict_tile<real>(L0, L1.g, (real *)nullptr, slot0, halo[wid], lane, S.bb);
-			} else {  // no such child: its octant of the right-hand side is zero
-				const int x = lane & 3, y = (lane >> 2) & 3, z = lane >> 4;
-				S.bb[((k >> 2) * 4 + z) * 64 + (((k >> 1) & 1) * 4 + y) * 8 + (k & 1) * 4 + x] = (real)0;
-			}
-		}
-		for (int i = t; i < LFA_HALO_CELLS; i += 256) S.H[i] = (real)0;
-		__syncthreads();
-		for (int it = 0; it < inner; ++it) {
-			cp_half_sweep<real>(S, 0);
-			cp_half_sweep<real>(S, 1);
-		}
-		for (int c = t; c < 512; c += 256) {
-			L1.x[base1 + c] = S.H[cp_hi(c)];
-			L1.b[base1 + c] = S.bb[c];
-		}
-		__syncthreads();
-	}
-}
-
 template <typename real>
 __global__ void __launch_bounds__(256) k_mg_prolong_postsmooth_cp(MgLv<real> L, GridDims gc, const real *e, int inner, const int *state) {
 	__shared__ CpTile<real> S;
@@ -1305,8 +1128,6 @@ template <typename real> struct MgCo {
 	unsigned *ready[MG_MAX_LEVELS];  // per level 3 x (tiles of the level): tile has stored [0] its pre-smoothed iterate [1] its share of the next level's right-hand side [2] its result
 	int first, last, nsw, inner;
 	unsigned tag;
-	unsigned long long *stamps;  // LFA_MG_CO_STAMPS=1 (debugging): workgroup 0 records the 100 MHz clock around its phases
-	int top;                     // >= 1: level first - 1 runs inside the launch as well, several tile slots per workgroup (see k_mg_coarse); -1: none
 	int *abort;                  // pcg_state + 2: raised by a workgroup whose wait has passed CO_TIMEOUT_TICKS; every waiter checks it
 	int fault;                   // LFA_MG_CO_FAULT=n (tests): workgroup n - 1 never raises its first flag
 };
@@ -1314,7 +1135,7 @@ template <typename real> struct MgCo {
 /// Back-off of a polling thread: 64 clocks at first, doubling to 8 K clocks. A producer may be late by far more than a phase -
 /// its workgroup may not even be resident yet while another kernel's workgroups hold the CUs (the position correction on its own
 /// stream) - and a few hundred workgroups re-reading the same words every 64 clocks starve exactly the kernel they wait for
-/// (measured: 1.3 s per C2 step with every thread of k_pcg_small's reductions polling without back-off).
+/// (measured: 1.3 s per C2 step with every thread of a whole-solve kernel's reductions polling without back-off).
 __device__ inline void co_backoff(int &n) {
 	// (the first polls stay tight: a phase hands over within a few round trips, and 256 clocks of sleep too many per wait cost
 	// k_mg_coarse 7 us per launch at C4)
@@ -1342,7 +1163,7 @@ __device__ inline unsigned co_xcc_id() {
 	return x & 15u;
 }
 /// All threads: waits until every tile in dep[0 .. n) (n <= 8; -1 entries are skipped) carries this launch's tag in `flag`.
-/// A wait that is given up (the ceiling; MEM = MemWg: a flag raised from another XCD - the data behind it may sit in that XCD's L2)
+/// A wait that is given up (the ceiling)
 /// raises the abort word and RETURNS like any other: the workgroup runs on with void data, every later wait of the launch leaves
 /// at its first slow poll, the kernel ends within a millisecond and the host, which finds the word at its next poll, discards the
 /// solve. (A uniform early exit would need a workgroup-wide OR per wait: two barriers and an LDS round trip in a kernel whose
@@ -1362,11 +1183,10 @@ __device__ inline bool co_wait(const unsigned *flag, const int *dep, int n, unsi
 					break;
 				}
 			}
-			if (!__is_same(MEM, MemAgent) && !bad && (f & 15u) != co_xcc_id()) bad = 2;
 			if (bad) {
-				// (why, for the record: abort_word[16] = 0x100 a wait ran out | 0x200 a flag from another XCD, with the two XCC ids)
+				// (for the record: abort_word[16] = 0x100 "a wait ran out" | the waiter's XCC id)
 				if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
-					abort_word[16] = (bad == 2 ? 0x200 : 0x100) | (int)co_xcc_id() | (int)((f & 15u) << 4);
+					abort_word[16] = 0x100 | (int)co_xcc_id();
 				__hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
 		}
@@ -1378,7 +1198,7 @@ __device__ inline bool co_wait(const unsigned *flag, const int *dep, int n, unsi
 template <typename MEM> __device__ inline void co_post(unsigned *flag, int tile, unsigned tag) {
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();
-	if (threadIdx.x == 0) MEM::st(flag + tile, (tag << 4) | (__is_same(MEM, MemAgent) ? 0u : co_xcc_id()));
+	if (threadIdx.x == 0) MEM::st(flag + tile, tag << 4);
 }
 
 /// Per-thread constants of the dataflow kernels: the two cells of a thread are column (qx, qy), z = 2 j and 2 j + 1.
@@ -1552,9 +1372,9 @@ __device__ inline bool co_static(const MgCo<real> &P, const CoThread &T, CoLevel
 /// `b_prefetched`: the first level's right-hand side is already in st[0].b (k_mg_coarse); otherwise it is waited for like
 /// every other level's (its children sit on level P.first - 1, whose flags P.ready[P.first - 1] must be valid).
 /// `post_first_y`: raise the result flag of the first level too (somebody inside this launch consumes it).
-template <typename real, typename MEM, typename STAMP>
+template <typename real, typename MEM>
 __device__ inline bool co_cycle(const MgCo<real> &P, const CoThread &T, CoLevel<real> *st, real *R, int *dep, unsigned tag, int lmax,
-                                bool b_prefetched, bool post_first_y, STAMP &&stamp) {
+                                bool b_prefetched, bool post_first_y) {
 	const int t = T.t, c0 = T.c0, c1 = T.c1, h0 = T.h0, h1 = T.h1;
 	// ---- down
 	for (int l = P.first; l < P.last && l <= lmax; ++l) {
@@ -1587,7 +1407,6 @@ __device__ inline bool co_cycle(const MgCo<real> &P, const CoThread &T, CoLevel<
 		MEM::st(L.x + base + c0, S.H[h0]);
 		MEM::st(L.x + base + c1, S.H[h1]);
 		if (!(P.fault && l == P.first && T.wg == P.fault - 1)) co_post<MEM>(P.ready[l], tile, tag);  // (fault injection: see MgCo::fault)
-		stamp();
 		// residual: the ring holds the neighbours' pre-smoothed values
 		if (t < 6) dep[t] = S.nb[t];
 		__syncthreads();
@@ -1598,7 +1417,6 @@ __device__ inline bool co_cycle(const MgCo<real> &P, const CoThread &T, CoLevel<
 		__syncthreads();
 		co_restrict_store<real, MEM>(T, R, L.g, P.lv[l + 1].g, tile, P.lv[l + 1].b);
 		co_post<MEM>(P.ready[l] + nt, tile, tag);
-		stamp();
 	}
 	// ---- coarsest level (one tile, workgroup 0): nsw sweeps red->black, nsw black->red from zero
 	if (T.wg == 0) {
@@ -1630,7 +1448,6 @@ __device__ inline bool co_cycle(const MgCo<real> &P, const CoThread &T, CoLevel<
 		MEM::st(L.y + base + c0, S.H[h0]);
 		MEM::st(L.y + base + c1, S.H[h1]);
 		if (l > P.first || post_first_y) co_post<MEM>(P.ready[l] + 2 * L.g.nt, tile, tag);
-		stamp();
 	}
 	// ---- up
 	for (int l = (lmax < P.last - 1 ? lmax : P.last - 1); l >= P.first; --l) {
@@ -1652,347 +1469,23 @@ __device__ inline bool co_cycle(const MgCo<real> &P, const CoThread &T, CoLevel<
 		MEM::st(L.y + base + c0, S.H[h0]);
 		MEM::st(L.y + base + c1, S.H[h1]);
 		if (l > P.first || post_first_y) co_post<MEM>(P.ready[l] + 2 * L.g.nt, tile, tag);
-		stamp();
 	}
 	return true;
 }
 
-/// XCD: launched with 8 W workgroups of which every eighth works (blockIdx % 8 == 0: one XCD under the dispatcher's round robin,
-/// checked through the flags), MEM = MemWg.
-template <typename real, typename MEM, bool XCD>
+template <typename real, typename MEM>
 __global__ void __launch_bounds__(256) k_mg_coarse(MgCo<real> P, const int *state) {
 	extern __shared__ unsigned char co_smem[];
 	__shared__ int dep[8];
-	if (XCD && (blockIdx.x & 7)) return;
-	const CoThread T(XCD ? (int)(blockIdx.x >> 3) : (int)blockIdx.x);
-	const int n_wg = XCD ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+	const CoThread T((int)blockIdx.x);
 	const int nlev = P.last - P.first + 1;
 	CoLevel<real> *st = (CoLevel<real> *)co_smem;
 	real *R = (real *)(st + nlev);
-	int n_stamp = 0;
-	auto stamp = [&]() {
-		if (P.stamps && T.wg == 0 && T.t == 0) P.stamps[n_stamp] = wall_clock64();
-		++n_stamp;
-	};
-	stamp();
 	int lmax = P.first - 1;  // deepest level this workgroup owns a tile of
 	for (int l = P.first; l <= P.last; ++l)
 		if (T.wg < P.lv[l].n_tiles) lmax = l;
-	const bool with_top = P.top >= 0;
-	if (!co_static<real, MEM>(P, T, st, lmax, state, !with_top)) return;
-	stamp();
-	// The level above (round 4): more tiles than workgroups can be resident, so a workgroup takes the slots wg, wg + W, ... of it
-	// (C4: level 1, ~2 400 tiles on 768 workgroups) with the launch-per-phase arithmetic (cp_*_tile, state through the level
-	// arrays instead of LDS) and this kernel's flags - its three launches and their gaps (33 us at C4) become ~3 tile phases of
-	// 2 us each side of the chain below.
-	CpTile<real> *Stop = (CpTile<real> *)(R + 512);
-	real *Rtop = (real *)(Stop + 1);
-	if (with_top) {
-		const MgLv<real> &L = P.lv[P.top];
-		const int nt = L.g.nt;
-		for (int slot = T.wg; slot < L.n_tiles; slot += n_wg) {
-			cp_presmooth_tile<real, MEM>(*Stop, L, slot, P.inner);
-			co_post<MEM>(P.ready[P.top], L.tiles[slot], P.tag);
-		}
-		for (int slot = T.wg; slot < L.n_tiles; slot += n_wg) {
-			if (T.t < 6) dep[T.t] = L.nbr[(size_t)slot * MG_NBR_STRIDE + T.t];
-			__syncthreads();
-			if (!co_wait<MEM>(P.ready[P.top], dep, 6, P.tag, P.abort)) return;
-			cp_residual_restrict_tile<real, MEM>(*Stop, Rtop, L, P.lv[P.first].g, P.lv[P.first].b, slot);
-			co_post<MEM>(P.ready[P.top] + nt, L.tiles[slot], P.tag);
-		}
-		stamp();
-	}
-	if (!co_cycle<real, MEM>(P, T, st, R, dep, P.tag, lmax, !with_top, with_top, stamp)) return;
-	if (with_top) {
-		const MgLv<real> &L = P.lv[P.top];
-		const GridDims &gc = P.lv[P.first].g;
-		for (int slot = T.wg; slot < L.n_tiles; slot += n_wg) {
-			// the corrections come from the parent tile and from the parents of the active neighbour tiles
-			__syncthreads();
-			co_parent_deps(T, dep, L.g, gc, L.nbr + (size_t)slot * MG_NBR_STRIDE);
-			if (!co_wait<MEM>(P.ready[P.first] + 2 * gc.nt, dep, 7, P.tag, P.abort)) return;
-			cp_prolong_postsmooth_tile<real, MEM>(*Stop, L, gc, P.lv[P.first].y, slot, P.inner);
-		}
-		stamp();
-	}
-}
-
-// ------------------------------------------------------------------------------------------------ a whole solve in ONE launch
-// Small systems (a few hundred particle tiles: BASELINE's C2, and the 50^3 .. 128^3 grids the reference's hosts run) are latency
-// bound on every level, the finest included: with 600 tiles a wave-per-tile kernel is itself a 5 us chain of sweeps behind a
-// 5 us launch, four times per iteration (C2: 45 of an iteration's 78 us), and the host polls the solver state between chunks
-// of iterations. k_pcg_small runs the WHOLE preconditioned CG of pressure_solver::solve (src/pressure_solver.cpp:19-71) in one
-// launch, a workgroup per particle tile, with k_mg_coarse's dataflow:
-//  * the tile's p, r, s, q, z live in REGISTERS (two cells per thread) from the first to the last iteration; only the tile's
-//    faces cross workgroups (s for the product A s, the pre-smoothed iterate for the residual), through the solver's own global
-//    vectors with `sc1` accesses and tagged ready flags; p and r are stored once, at the end.
-//  * the two reductions of an iteration (q.s; z.r together with the signed max of r) are tagged per-workgroup partials that every
-//    workgroup sums in the same fixed order - alpha, beta and the stopping rule (:54-58) are identical everywhere, so all
-//    workgroups leave the loop in the same iteration; nothing visits the host until the solve is over.
-//  * below the finest level: co_cycle, i.e. exactly k_mg_coarse's phases.
-// Arithmetic per cell: k_spmv's / k_mg_axpy_presmooth's / cp_*'s expressions. The partial sums are grouped per tile instead of
-// per four tiles, so results agree with the multi-launch path to rounding, not bit for bit (tested: iterations +-1, pressure 1e-6).
-#define PS_MAX_TILES 256  // measured: 219 tiles (64^3) 0.064 -> 0.055 ms per iteration; ~900 tiles (C2) 0.082 -> 0.090: the faces and
-                          // reductions of many workgroups through memory cost more than the launches they save
-template <typename real> struct PcgSmall {
-	MgCo<real> C;          // lv[0 .. last], ready[0 .. last]; C.first = 1
-	real *p, *r, *s, *x0;  // pressure, residual, search direction (faces exchanged through it), pre-smoothed iterate (faces)
-	unsigned *sflag;       // [tiles of level 0] the tile's search direction of this iteration is stored
-	double *part;          // [3][PS_MAX_TILES] per-workgroup partials: q.s | z.r | signed max r
-	unsigned *pflag;       // [2][PS_MAX_TILES] tags of the two reductions
-	real scale, inv_scale;
-	double tol;
-	int maxit;
-	int *state;
-	double *hist;
-};
-
-/// All threads: every workgroup's partial of this tag is in; returns their sum (and, MAXTOO, the NaN-aware maximum of a second
-/// array), identical in every workgroup: strided private sums in index order, a butterfly per wave, one exchange through LDS.
-template <bool MAXTOO>
-__device__ inline bool co_reduce(const double *sum_part, const double *max_part, const unsigned *flag, int W, unsigned tag, double *lds,
-                                 double &sum, double &mx, int *abort_word) {
-	const int t = threadIdx.x;
-	if (t < 64) {
-		unsigned long long t0 = 0ull;
-		// ONE wave polls (a lane's four flags read together, one round trip per attempt, with back-off): every thread of every
-		// workgroup re-reading the flags is a storm that starves the producers when they are late (see co_backoff)
-		int tries = 0;
-		for (;;) {
-			unsigned f[PS_MAX_TILES / 64];
-#pragma unroll
-			for (int k = 0; k < PS_MAX_TILES / 64; ++k) {
-				const int i = t + 64 * k;
-				f[k] = i < W ? __hip_atomic_load(flag + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
-			}
-			bool all = true;
-#pragma unroll
-			for (int k = 0; k < PS_MAX_TILES / 64; ++k) all &= f[k] == tag;
-			if (all) break;
-			co_backoff(tries);
-			if (co_poll_expired(tries, t0, abort_word)) {  // (given up: the sums below are void, the host discards the solve - see co_wait)
-				if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) abort_word[16] = 0x100;
-				__hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				break;
-			}
-		}
-	}
-	__syncthreads();
-	double a = 0.0, m = -INFINITY;
-	bool nan = false;
-	for (int i = t; i < W; i += 256) {
-		a += MemAgent::ld(sum_part + i);
-		if (MAXTOO) {
-			const double x = MemAgent::ld(max_part + i);
-			nan |= x != x;
-			m = x > m ? x : m;
-		}
-	}
-	a = wave_sum(a);
-	if (MAXTOO) {
-		m = wave_max(m);
-		nan = __any(nan);
-	}
-	if ((t & 63) == 0) {
-		lds[t >> 6] = a;
-		if (MAXTOO) lds[4 + (t >> 6)] = nan ? NAN : m;
-	}
-	__syncthreads();
-	sum = (lds[0] + lds[1]) + (lds[2] + lds[3]);
-	if (MAXTOO) {
-		mx = lds[4];
-		for (int k = 1; k < 4; ++k) mx = (mx != mx || lds[4 + k] != lds[4 + k]) ? NAN : (lds[4 + k] > mx ? lds[4 + k] : mx);
-	}
-	__syncthreads();
-	return true;
-}
-
-template <typename real>
-__global__ void __launch_bounds__(256) k_pcg_small(PcgSmall<real> Q) {
-	extern __shared__ unsigned char co_smem[];
-	__shared__ int dep[8], nb0[8], s_abort;
-	__shared__ uint8_t rab0[384];
-	__shared__ double red[8];
-	const MgCo<real> &P = Q.C;
-	const CoThread T;
-	const int t = T.t, wg = T.wg, c0 = T.c0, c1 = T.c1, h0 = T.h0, h1 = T.h1;
-	const int nlev = P.last - P.first + 1, W = gridDim.x;
-	CoLevel<real> *st = (CoLevel<real> *)co_smem;
-	real *H0 = (real *)(st + nlev), *R = H0 + LFA_HALO_CELLS;
-	const MgLv<real> &L0 = P.lv[0];
-	const GridDims &g1 = P.lv[1].g;
-	const int nt0 = L0.g.nt;
-	int lmax = 0;
-	for (int l = P.first; l <= P.last; ++l)
-		if (wg < P.lv[l].n_tiles) lmax = l;
-	if (t < 8) nb0[t] = L0.nbr[(size_t)wg * MG_NBR_STRIDE + t];
-	co_static<real, MemAgent>(P, T, st, lmax, nullptr, false);  // (ends with a barrier: nb0 is visible)
-	const int tile0 = nb0[6];
-	const size_t base0 = (size_t)tile0 * 512;
-	const uint32_t a0 = L0.abits[base0 + c0], a1 = L0.abits[base0 + c1];
-	for (int r = t; r < 384; r += 256) {
-		int f, hidx, ncell, dx, dy, dz;
-		cp_ring(r, f, hidx, ncell, dx, dy, dz);
-		rab0[r] = nb0[f] >= 0 ? L0.abits[(size_t)nb0[f] * 512 + ncell] : (uint8_t)0;
-	}
-	// the vectors of the tile: two cells per thread, in registers for the whole solve
-	real p0 = Q.p[base0 + c0], p1 = Q.p[base0 + c1], r0 = Q.r[base0 + c0], r1 = Q.r[base0 + c1];
-	real s0 = (real)0, s1 = (real)0, q0 = (real)0, q1 = (real)0, z0 = (real)0, z1 = (real)0;
-	double sigma = 0.0;
-	auto nostamp = []() {};
-	int it = -1, done = -1;
-	bool nan_seen = false;
-	for (; it < Q.maxit; ++it) {
-		// (a wait given up anywhere: every workgroup leaves at the top of its next iteration - uniformly, through LDS - instead of
-		// running maxit iterations of waits that each take their slow path)
-		if (t == 0) s_abort = __hip_atomic_load(P.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		__syncthreads();
-		if (s_abort != 0) return;
-		const unsigned tag = P.tag + (unsigned)(it + 1);
-		double m = -INFINITY;
-		bool nan = false;
-		if (it >= 0) {
-			// ---- q = A s (k_spmv's expression), partial q.s
-			for (int i = t; i < LFA_HALO_CELLS; i += 256) H0[i] = (real)0;
-			__syncthreads();
-			H0[h0] = s0;
-			H0[h1] = s1;
-			MemAgent::st(Q.s + base0 + c0, s0);
-			MemAgent::st(Q.s + base0 + c1, s1);
-			co_post<MemAgent>(Q.sflag, tile0, tag);
-			if (t < 6) dep[t] = nb0[t];
-			__syncthreads();
-			if (!co_wait<MemAgent>(Q.sflag, dep, 6, tag, P.abort)) return;  // (p and r stay what they were: the host repeats the solve)
-			co_load_ring<real, MemAgent>(T, H0, nb0, Q.s);
-			double acc = 0.0;
-#pragma unroll
-			for (int k = 0; k < 2; ++k) {
-				const uint32_t a = k ? a1 : a0;
-				const int i = k ? h1 : h0;
-				real out = (real)0;
-				if (a & AB_UNKNOWN) {
-					const real F = (a & AB_FLUID) ? (real)1 : (real)0;
-					const real si = H0[i];
-					real val = (real)(a & 7) * si;
-					val -= F * H0[i - 1];
-					val -= F * H0[i - 10];
-					val -= F * H0[i - 100];
-					val -= (real)((a >> 3) & 1) * H0[i + 1];
-					val -= (real)((a >> 4) & 1) * H0[i + 10];
-					val -= (real)((a >> 5) & 1) * H0[i + 100];
-					out = Q.scale * val;
-					acc += (double)out * (double)si;
-				}
-				if (k) q1 = out;
-				else q0 = out;
-			}
-			acc = wave_sum(acc);
-			if ((t & 63) == 0) red[t >> 6] = acc;
-			__syncthreads();
-			if (t == 0) {
-				MemAgent::st(Q.part + wg, (red[0] + red[1]) + (red[2] + red[3]));
-				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-				__hip_atomic_store(Q.pflag + wg, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			}
-			double gamma, unused;
-			if (!co_reduce<false>(Q.part, nullptr, Q.pflag, W, tag, red, gamma, unused, P.abort)) return;
-			// ---- p += alpha s, r -= alpha q, signed max of the new residual (k_mg_axpy_presmooth's expressions)
-			const real alpha = (real)(sigma / gamma);
-#pragma unroll
-			for (int k = 0; k < 2; ++k) {
-				const uint32_t a = k ? a1 : a0;
-				if (a & AB_UNKNOWN) {
-					real &pp = k ? p1 : p0, &rr = k ? r1 : r0;
-					pp = pp + alpha * (k ? s1 : s0);
-					const real rn = rr + (-alpha) * (k ? q1 : q0);
-					rr = rn;
-					nan |= rn != rn;
-					m = (double)rn > m ? (double)rn : m;
-				}
-			}
-		}
-		// ---- z = V(r) / scale: the finest level here, the others in co_cycle
-		for (int i = t; i < LFA_HALO_CELLS; i += 256) H0[i] = (real)0;
-		for (int l = P.first; l <= lmax; ++l) {
-			CoLevel<real> &S = st[l - P.first];
-			for (int i = t; i < LFA_HALO_CELLS; i += 256) S.H[i] = (real)0;
-		}
-		__syncthreads();
-		{
-			const real b0 = (a0 & AB_UNKNOWN) ? r0 : (real)0, b1 = (a1 & AB_UNKNOWN) ? r1 : (real)0;
-			for (int k = 0; k < P.inner; ++k) {
-				co_half_sweep<real>(T, H0, a0, a1, b0, b1, 0);
-				co_half_sweep<real>(T, H0, a0, a1, b0, b1, 1);
-			}
-			MemAgent::st(Q.x0 + base0 + c0, H0[h0]);
-			MemAgent::st(Q.x0 + base0 + c1, H0[h1]);
-			co_post<MemAgent>(P.ready[0], tile0, tag);
-			if (t < 6) dep[t] = nb0[t];
-			__syncthreads();
-			if (!co_wait<MemAgent>(P.ready[0], dep, 6, tag, P.abort)) return;
-			co_load_ring<real, MemAgent>(T, H0, nb0, Q.x0);
-			R[c0] = co_residual_cell<real>(H0, a0, b0, h0);
-			R[c1] = co_residual_cell<real>(H0, a1, b1, h1);
-			__syncthreads();
-			co_restrict_store<real, MemAgent>(T, R, L0.g, g1, tile0, P.lv[1].b);
-			co_post<MemAgent>(P.ready[0] + nt0, tile0, tag);
-			if (!co_cycle<real, MemAgent>(P, T, st, R, dep, tag, lmax, false, true, nostamp)) return;
-			co_parent_deps(T, dep, L0.g, g1, nb0);
-			if (!co_wait<MemAgent>(P.ready[1] + 2 * g1.nt, dep, 7, tag, P.abort)) return;
-			co_add_correction<real, MemAgent>(T, H0, a0, a1, rab0, nb0, L0.g, g1, tile0, P.lv[1].y);
-			for (int k = 0; k < P.inner; ++k) {
-				co_half_sweep<real>(T, H0, a0, a1, b0, b1, 1);
-				co_half_sweep<real>(T, H0, a0, a1, b0, b1, 0);
-			}
-			z0 = H0[h0] * Q.inv_scale;
-			z1 = H0[h1] * Q.inv_scale;
-			double acc = (double)z0 * (double)b0;
-			acc += (double)z1 * (double)b1;
-			acc = wave_sum(acc);
-			m = wave_max(m);
-			nan = __any(nan);
-			__syncthreads();
-			if ((t & 63) == 0) {
-				red[t >> 6] = acc;
-				red[4 + (t >> 6)] = nan ? NAN : m;
-			}
-			__syncthreads();
-			if (t == 0) {
-				double v = red[4];
-				for (int k = 1; k < 4; ++k) v = (v != v || red[4 + k] != red[4 + k]) ? NAN : (red[4 + k] > v ? red[4 + k] : v);
-				MemAgent::st(Q.part + PS_MAX_TILES + wg, (red[0] + red[1]) + (red[2] + red[3]));
-				MemAgent::st(Q.part + 2 * PS_MAX_TILES + wg, v);
-				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-				__hip_atomic_store(Q.pflag + PS_MAX_TILES + wg, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			}
-		}
-		double sigma_new, rmax;
-		if (!co_reduce<true>(Q.part + PS_MAX_TILES, Q.part + 2 * PS_MAX_TILES, Q.pflag + PS_MAX_TILES, W, tag, red, sigma_new, rmax, P.abort)) return;
-		if (it >= 0) {
-			// stopping rule of pressure_solver::solve (:54-58) on the residual of this iteration; identical in every workgroup
-			if (wg == 0 && t == 0) Q.hist[it] = rmax;
-			if (rmax != rmax || rmax < Q.tol) {
-				done = it + 1;
-				nan_seen = rmax != rmax;
-				break;
-			}
-		}
-		// ---- s = z + beta s (:64-66; the first direction is z itself, :40)
-		const real beta = it >= 0 ? (real)(sigma_new / sigma) : (real)0;
-		s0 = it >= 0 ? z0 + beta * s0 : z0;
-		s1 = it >= 0 ? z1 + beta * s1 : z1;
-		sigma = sigma_new;
-	}
-	Q.p[base0 + c0] = p0;
-	Q.p[base0 + c1] = p1;
-	Q.r[base0 + c0] = r0;
-	Q.r[base0 + c1] = r1;
-	if (wg == 0 && t == 0 && done >= 0) {
-		if (nan_seen) Q.state[1] = 1;
-		*(double *)(Q.state + 16) = Q.hist[done - 1];
-		Q.state[0] = done;
-	}
+	if (!co_static<real, MEM>(P, T, st, lmax, state, true)) return;
+	(void)co_cycle<real, MEM>(P, T, st, R, dep, P.tag, lmax, true, false);
 }
 
 /// The small levels in ONE workgroup of 16 waves: down from level `first` to the single-tile level, the coarsest solve,
@@ -2151,32 +1644,11 @@ __global__ void __launch_bounds__(MG_TAIL_WAVES * 64) k_mg_tail(MgTail<real> T, 
 /// another instantiation for A/B runs.
 #define MG_MW_DEFAULT_A 4  // (C4: 65 -> 61 us; 5 / 6 waves spill the pipeline registers: 117 / 149 us)
 #define MG_MW_DEFAULT_U 1  // (C4: 54 us; 4 / 5 / 6: 61 / 101 / 142 us)
-template <typename real, typename... Args> static void launch_axpy_presmooth(int mw, int G, hipStream_t st, Args... a) {
-	switch (mw >= 0 ? mw : MG_MW_DEFAULT_A) {
-	case 4: hipLaunchKernelGGL((k_mg_axpy_presmooth<real, 4>), dim3(G), dim3(256), 0, st, a...); break;
-	case 5: hipLaunchKernelGGL((k_mg_axpy_presmooth<real, 5>), dim3(G), dim3(256), 0, st, a...); break;
-	case 6: hipLaunchKernelGGL((k_mg_axpy_presmooth<real, 6>), dim3(G), dim3(256), 0, st, a...); break;
-	case 8: hipLaunchKernelGGL((k_mg_axpy_presmooth<real, 8>), dim3(G), dim3(256), 0, st, a...); break;
-	default: hipLaunchKernelGGL((k_mg_axpy_presmooth<real, 1>), dim3(G), dim3(256), 0, st, a...); break;
-	}
+template <typename real, typename... Args> static void launch_axpy_presmooth(int G, hipStream_t st, Args... a) {
+	hipLaunchKernelGGL((k_mg_axpy_presmooth<real, MG_MW_DEFAULT_A>), dim3(G), dim3(256), 0, st, a...);
 }
-template <typename real, typename... Args> static void launch_up01(int mw, int G, hipStream_t st, Args... a) {
-	switch (mw >= 0 ? mw : MG_MW_DEFAULT_U) {
-	case 4: hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true, 4, true>), dim3(G), dim3(256), 0, st, a...); break;
-	case 5: hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true, 5, true>), dim3(G), dim3(256), 0, st, a...); break;
-	case 6: hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true, 6, true>), dim3(G), dim3(256), 0, st, a...); break;
-	case 8: hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true, 8, true>), dim3(G), dim3(256), 0, st, a...); break;
-	default: hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true, 1, true>), dim3(G), dim3(256), 0, st, a...); break;
-	}
-}
-template <typename real, typename... Args> static void launch_up0(int mw, int G, hipStream_t st, Args... a) {
-	switch (mw >= 0 ? mw : MG_MW_DEFAULT_U) {
-	case 4: hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true, 4>), dim3(G), dim3(256), 0, st, a...); break;
-	case 5: hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true, 5>), dim3(G), dim3(256), 0, st, a...); break;
-	case 6: hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true, 6>), dim3(G), dim3(256), 0, st, a...); break;
-	case 8: hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true, 8>), dim3(G), dim3(256), 0, st, a...); break;
-	default: hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true, 1>), dim3(G), dim3(256), 0, st, a...); break;
-	}
+template <typename real, typename... Args> static void launch_up0(int G, hipStream_t st, Args... a) {
+	hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, true, MG_MW_DEFAULT_U>), dim3(G), dim3(256), 0, st, a...);
 }
 int mg_grid(int n_tiles) { return pcg_grid(n_tiles); }
 /// Slab mode of the hierarchy. A one-rank communicator needs none of it; LFA_MG_DIST_SINGLE=1 runs it anyway (tests: the array
@@ -2185,7 +1657,7 @@ bool mg_dist(const lfa_sim *s) { return s->dist && (s->dist->nranks > 1 || s->kn
 }  // namespace
 
 // ================================================================================================= host side
-// Kernels whose workgroups wait for each other (k_mg_coarse, k_pcg_small) need all of them resident together; `fits` below sizes
+// Kernels whose workgroups wait for each other (k_mg_coarse) need all of them resident together; `fits` below sizes
 // one launch against the whole device. Independent handles on one GPU - several simulations of one host process, each on its own
 // thread and stream, as the C ABI allows (include/libfluid_amd.h: "different handles are independent"; the Maya host holds one
 // fluid node per simulated object, plugins/maya/nodes/grid_node.cpp:256) - could have two such launches in flight, each with part
@@ -2245,19 +1717,6 @@ void lfa_mg_free(lfa_sim *s) {
 	}
 	if (s->mg->l1_dirty) (void)hipFree(s->mg->l1_dirty);
 	if (s->mg->counts) (void)hipFree(s->mg->counts);
-	if (s->mg->ps_part) (void)hipFree(s->mg->ps_part);
-	if (s->mg->q) (void)hipFree(s->mg->q);
-	if (s->mg->co_stamps) {
-		unsigned long long h[3 * MG_CO_PHASES];
-		if (hipMemcpy(h, s->mg->co_stamps, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
-			fprintf(stderr, "k_mg_coarse, workgroup 0 (us since launch: start, static data in, then the end of every phase: pre-smoothing and residual per level, coarsest, up per level), tiles per level:");
-			for (int l = 0; l < s->mg->n_levels; ++l) fprintf(stderr, " %d", s->mg->lv[l].n_tiles);
-			fprintf(stderr, "\n ");
-			for (int k = 0; k < s->mg->co_phases; ++k) fprintf(stderr, " %.2f", (h[k] - h[0]) / 100.0);
-			fprintf(stderr, "\n");
-		}
-		(void)hipFree(s->mg->co_stamps);
-	}
 	delete s->mg;
 	s->mg = nullptr;
 }
@@ -2356,8 +1815,7 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 		// an upload per level - cost 2.8 ms per step at C4 once the dam moves and the tile set changes every step.)
 		// the levels from `small` on have at most MG_SMALL_NT tiles in their grid: their lists / tables come from three launches in all
 		int small = nl;
-		if (!s->knobs.mg_no_small_setup)
-			for (int l = nl - 1; l >= 1 && gs[l].nt <= MG_SMALL_NT; --l) small = l;
+		for (int l = nl - 1; l >= 1 && gs[l].nt <= MG_SMALL_NT; --l) small = l;
 		MgSmall SP;
 		SP.first = small;
 		SP.last = nl - 1;
@@ -2591,11 +2049,7 @@ enum { MG_PART_PRE0 = 1, MG_PART_DOWN0 = 2, MG_PART_COARSE = 4, MG_PART_UP0 = 8,
 template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, bool level0_presmoothed, int parts = MG_PART_ALL) {
 	lfa_mg &M = *s->mg;
 	const int nl = M.n_levels;
-	int last = nl - 1;  // every level down to the single-tile one has active tiles
-	// LFA_MG_STOP_AT_SINGLE=1 (experiment): the first level with ONE active tile is the coarsest (its sweeps stand in for the levels below)
-	if (s->knobs.mg_stop_at_single && !mg_dist(s))
-		for (int l = 1; l < last; ++l)
-			if (M.lv[l].n_tiles == 1) { last = l; break; }
+	const int last = nl - 1;  // every level down to the single-tile one has active tiles
 	auto lvl = [&](int l) {
 		const lfa_mg_level &L = M.lv[l];
 		return MgLv<real>{L.tiles, L.nbr, L.n_tiles, L.g, l == 0 ? (const uint8_t *)s->abits : (const uint8_t *)L.abits,
@@ -2606,25 +2060,20 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 	if (last == 0) {  // a single level: the two sweeps alone
 		const MgLv<real> L = lvl(0);
 		if (!level0_presmoothed) hipLaunchKernelGGL(k_mg_presmooth<real>, dim3(1), dim3(256), 0, s->stream, L, st);
-		launch_up0<real>(s->knobs.mg_mw_u, 1, s->stream, L, L.g, (const real *)nullptr, inv_scale, part_sigma, st, MgLv<real>{}, GridDims{},
-		                 (const real *)nullptr, MgQueue{nullptr, nullptr});
+		launch_up0<real>(1, s->stream, L, L.g, (const real *)nullptr, inv_scale, part_sigma, st);
 		LFA_LAUNCH_CHECK(s);
 		return LFA_OK;
 	}
-	int tail = last, tail_tiles = MG_TAIL_TILES;  // first level handled by the single-workgroup tail
-	if (s->knobs.mg_tail_tiles >= 0) tail_tiles = s->knobs.mg_tail_tiles;
-	while (tail > 1 && M.lv[tail - 1].n_tiles <= tail_tiles) --tail;
+	int tail = last;  // first level handled by the single-workgroup tail
+	while (tail > 1 && M.lv[tail - 1].n_tiles <= MG_TAIL_TILES) --tail;
 	// slabs: levels < D run on the rank's own tiles with one slice per slab face exchanged where a stencil crosses it;
 	// levels >= D are replicated (identical work on every rank), so the tail workgroup may only hold replicated levels
 	const int D = mg_dist(s) ? M.n_dist : 0;
 	tail = std::max(tail, D);
 	// Default: every level of at most MG_CO_MAX_TILES tiles (C4: levels >= 2, C2: levels >= 1) runs inside ONE launch, k_mg_coarse
 	// (phases chained by completion counters instead of kernel boundaries); the larger ones keep a launch per phase.
-	int co_max = MG_CO_MAX_TILES;
-	if (s->knobs.mg_co_max_tiles >= 0) co_max = s->knobs.mg_co_max_tiles;
+	// LFA_MG_NO_PERSIST=1, and a handle that has given a device-side wait up (co_disabled): a launch per phase on every level.
 	const bool persist = !s->knobs.mg_no_persist && !s->co_disabled;
-	int top = -1, top_w = 0;  // level that runs inside k_mg_coarse with several tile slots per workgroup, and that launch's width
-	size_t xcd_cap = 0;       // workgroups of k_mg_coarse that one XCD holds at once (with a margin)
 	if (persist) {
 		// every workgroup of k_mg_coarse must be resident at the same time (they wait for each other): one workgroup per tile of
 		// its first level, LDS per workgroup grows with the number of levels inside
@@ -2633,7 +2082,6 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 			int n_cu = 0;
 			bool attr_set = false;
 			int per_cu[MG_CO_MAX_LEVELS + 1];  // resident workgroups per CU by the number of levels inside, -1: not asked yet
-			int per_cu_top[MG_CO_MAX_LEVELS + 1];  // the same with the LDS of a multi-slot top level
 		};
 		static DevInfo info[64];
 		static std::mutex info_mutex;
@@ -2646,11 +2094,9 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 				hipDeviceProp_t prop;
 				d.n_cu = (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
 				for (int &v : d.per_cu) v = -1;
-				for (int &v : d.per_cu_top) v = -1;
 			}
 			if (!d.attr_set) {
-				LFA_HIP(s, hipFuncSetAttribute((const void *)k_mg_coarse<real, MemAgent, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-				LFA_HIP(s, hipFuncSetAttribute((const void *)k_mg_coarse<real, MemWg, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+				LFA_HIP(s, hipFuncSetAttribute((const void *)k_mg_coarse<real, MemAgent>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
 				d.attr_set = true;
 			}
 			di = d;
@@ -2662,7 +2108,7 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 			const size_t lds = (size_t)nlev * sizeof(CoLevel<real>) + 512 * sizeof(real) + 64;
 			int per_cu = di.per_cu[nlev];  // by registers and LDS together
 			if (per_cu < 0) {
-				if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_mg_coarse<real, MemAgent, false>, 256, lds) != hipSuccess) {
+				if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_mg_coarse<real, MemAgent>, 256, lds) != hipSuccess) {
 					(void)hipGetLastError();
 					per_cu = 0;
 				}
@@ -2671,81 +2117,26 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 			}
 			// ranks that share this GPU launch their k_mg_coarse at the same time: all of them must be resident together
 			const size_t share = s->dist ? (size_t)std::max(1, s->dist->device_share) : 1;
-			return last - first + 1 <= MG_CO_MAX_LEVELS && M.lv[first].n_tiles <= co_max &&
-			       (size_t)M.lv[first].n_tiles * share <= (size_t)per_cu * (size_t)n_cu;
+			return M.lv[first].n_tiles <= MG_CO_MAX_TILES && (size_t)M.lv[first].n_tiles * share <= (size_t)per_cu * (size_t)n_cu;
 		};
 		tail = last;
 		while (tail > 1 && tail - 1 >= D && fits(tail - 1)) --tail;
 		tail = std::max(tail, std::max(D, 1));
-		(void)fits(tail);  // (makes sure the occupancy of this many levels has been asked)
-		{
-			const int pc = last - tail + 1 <= MG_CO_MAX_LEVELS ? di.per_cu[last - tail + 1] : 0;
-			const size_t all = pc > 0 ? (size_t)pc * (size_t)n_cu : 0;
-			xcd_cap = (all - all / 8) / 8;
-		}
-		// the level above the first one inside (never the finest, never a distributed one) joins the launch with several tile slots
-		// per workgroup when the launch can hold at least a third of its tiles. OPT-IN (LFA_MG_TOP=1): measured at C3 it saves
-		// three launches per iteration and no time (0.138 -> 0.140 ms), and the wider launch costs the overlapped step 0.24 ms
-		if (s->knobs.mg_top && tail - 1 >= std::max(D, 1) && last - tail + 1 <= MG_CO_MAX_LEVELS) {
-			const int nlev = last - tail + 1;
-			const size_t lds = (size_t)nlev * sizeof(CoLevel<real>) + 512 * sizeof(real) + sizeof(CpTile<real>) + 512 * sizeof(real) + 64;
-			int per_cu = di.per_cu_top[nlev];
-			if (per_cu < 0) {
-				if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_mg_coarse<real, MemAgent, false>, 256, lds) != hipSuccess) {
-					(void)hipGetLastError();
-					per_cu = 0;
-				}
-				std::lock_guard<std::mutex> lk(info_mutex);
-				info[dslot].per_cu_top[nlev] = di.per_cu_top[nlev] = per_cu;
-			}
-			const size_t share = s->dist ? (size_t)std::max(1, s->dist->device_share) : 1;
-			// (a margin of an eighth: the occupancy query can be one block per CU high near a register-allocation edge -
-			// MI355X_MICROARCH.md, correctness boundaries - and a workgroup that is not resident is waited for until the ceiling)
-			const size_t cap = ((size_t)per_cu * (size_t)n_cu - (size_t)per_cu * (size_t)n_cu / 8) / share;
-			const size_t t_top = (size_t)M.lv[tail - 1].n_tiles, t_first = (size_t)M.lv[tail].n_tiles;
-			if (cap >= t_first && cap > 0 && 3 * cap >= t_top) {
-				top = tail - 1;
-				top_w = (int)std::max<size_t>(t_first, std::min(cap, t_top));
-			}
-		}
 	}
 	// cell-parallel kernels for levels of up to 1024 tiles (C4: levels 2 and 3; level 1 with 2048 tiles fills the chip with a
 	// wave per tile: 8.58 ms per step against 8.75 with cell-parallel kernels on every coarse level, 8.79 with none)
-	int cp_max = 1024;
-	if (s->knobs.mg_cp_max_tiles >= 0) cp_max = s->knobs.mg_cp_max_tiles;
+	const int cp_max = 1024;
 	auto exchange_level = [&](int l, void *vec) -> int {
 		if (l == 0) return lfa_dist_exchange_slices(s, vec, (int)sizeof(real));
 		return lfa_dist_exchange_layer_slices(s, vec, (int)sizeof(real), M.lv[l].g.ntx * M.lv[l].g.nty, M.lv[l].lo_layer, M.lv[l].hi_layer);
 	};
 	int launches = 0;
-	// OPT-IN (LFA_MG_MERGE=1, measured slower - see lfa_knobs::mg_merge): level 1's three phases inside the level-0 launches next to
-	// them (k_mg_down01 / k_mg_up01: an ordered work queue in place of the kernel boundaries; nothing has to be resident). Single
-	// domain, the whole cycle, level 1 not inside k_mg_coarse already.
-	const bool merge01 = persist && s->knobs.mg_merge && D == 0 && tail >= 2 && top != 1 && parts == MG_PART_ALL && level0_presmoothed &&
-	                     M.lv[0].n_tiles > 0 && M.lv[1].n_tiles > 0;
-	// OPT-IN (LFA_MG_FOLD=1, measured slower - lfa_knobs::mg_fold): level 1's pre-smoothing behind level 0's restriction in one launch
-	const bool fold1 = !merge01 && s->knobs.mg_fold && D == 0 && tail >= 2 && top != 1 && parts == MG_PART_ALL && M.lv[0].n_tiles > 0 &&
-	                   M.lv[1].n_tiles > 0 && s->p_off == 0;
-	if (merge01 && !M.q) {
-		LFA_HIP(s, hipMalloc(&M.q, 16 * sizeof(int)));
-		LFA_HIP(s, hipMemsetAsync(M.q, 0, 16 * sizeof(int), s->stream));
-	}
 	for (int l = 0; l < tail; ++l) {
 		const MgLv<real> L = lvl(l);
 		const int G = mg_grid(L.n_tiles);
-		const bool cp = l >= 1 && !s->knobs.mg_no_cp && L.n_tiles <= cp_max;  // a workgroup per tile on the coarser levels (see k_mg_*_cp)
+		const bool cp = l >= 1 && L.n_tiles <= cp_max;  // a workgroup per tile on the coarser levels (see k_mg_*_cp)
 		const int Gcp = std::max(1, std::min(L.n_tiles, 8192));  // (a slab rank may hold no tile of a level)
-		if (l == top) continue;  // (inside k_mg_coarse)
-		if (merge01 && l <= 1) {
-			if (l == 0) {
-				hipLaunchKernelGGL(k_mg_down01<real>, dim3(G), dim3(256), 0, s->stream, L, lvl(1), M.lv[2].g, (real *)M.lv[2].b,
-				                   MgQueue{M.q, s->pcg_state + 2}, st);
-				LFA_LAUNCH_CHECK(s);
-				++launches;
-			}
-			continue;
-		}
-		if (!(l == 0 && level0_presmoothed) && !(fold1 && l == 1) && (parts & (l == 0 ? MG_PART_PRE0 : MG_PART_COARSE))) {
+		if (!(l == 0 && level0_presmoothed) && (parts & (l == 0 ? MG_PART_PRE0 : MG_PART_COARSE))) {
 			if (cp) hipLaunchKernelGGL(k_mg_presmooth_cp<real>, dim3(Gcp), dim3(256), 0, s->stream, L, MG_INNER_SWEEPS, st);
 			else hipLaunchKernelGGL(k_mg_presmooth<real>, dim3(G), dim3(256), 0, s->stream, L, st);
 			++launches;
@@ -2755,11 +2146,7 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 			// the first replicated level collects the restricted residual of every rank: zero where this rank has no children
 			if (l + 1 == D) LFA_HIP(s, hipMemsetAsync(M.lv[D].b, 0, M.lv[D].ncp * sizeof(real), s->stream));
 		}
-		if (fold1 && l == 0) {  // level 0's residual + restriction with level 1's pre-smoothing behind it, a workgroup per level-1 tile
-			hipLaunchKernelGGL(k_mg_restrict0_pre1<real>, dim3(std::min(M.lv[1].n_tiles, 65535)), dim3(256), 0, s->stream, L, lvl(1),
-			                   (const int *)s->tile_pslot, MG_INNER_SWEEPS, st);
-			++launches;
-		} else if (parts & (l == 0 ? MG_PART_DOWN0 : MG_PART_COARSE)) {
+		if (parts & (l == 0 ? MG_PART_DOWN0 : MG_PART_COARSE)) {
 			if (cp) hipLaunchKernelGGL(k_mg_residual_restrict_cp<real>, dim3(Gcp), dim3(256), 0, s->stream, L, M.lv[l + 1].g, (real *)M.lv[l + 1].b, st);
 			else hipLaunchKernelGGL(k_mg_residual_restrict<real>, dim3(G), dim3(256), 0, s->stream, L, M.lv[l + 1].g, (real *)M.lv[l + 1].b, st);
 			++launches;
@@ -2773,47 +2160,22 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		for (int l = tail; l <= last; ++l) C.lv[l] = lvl(l);
 		C.first = tail;
 		C.last = last;
-		C.top = top;
-		if (top >= 0) {
-			C.lv[top] = lvl(top);
-			C.ready[top] = M.lv[top].ready;
-		}
 		C.nsw = MG_COARSEST_SWEEPS;
 		C.inner = MG_INNER_SWEEPS;
-		if (s->knobs.mg_tail_inner > 0) C.inner = s->knobs.mg_tail_inner;
-		if (s->knobs.mg_nsw > 0) C.nsw = s->knobs.mg_nsw;
 		for (int l = tail; l <= last; ++l) C.ready[l] = M.lv[l].ready;
-		if (M.co_tag >= 0x0FFFFFF0u) {  // (a flag holds tag << 4 | XCC id: after 2^28 launches the flags start over)
+		if (M.co_tag >= 0x0FFFFFF0u) {  // (a flag holds tag << 4: after 2^28 launches the flags start over)
 			for (int l = 1; l <= last; ++l)
 				if (M.lv[l].ready) LFA_HIP(s, hipMemsetAsync(M.lv[l].ready, 0, (size_t)3 * M.lv[l].g.nt * sizeof(unsigned), s->stream));
 			M.co_tag = 0;
 		}
 		C.tag = ++M.co_tag;  // (0 is what the flags are initialised to)
-		C.stamps = nullptr;
 		C.abort = s->pcg_state + 2;
 		C.fault = s->knobs.mg_co_fault;
-		if (s->knobs.mg_co_stamps) {
-			if (!M.co_stamps) {
-				LFA_HIP(s, hipMalloc(&M.co_stamps, 3 * MG_CO_PHASES * 8));
-				LFA_HIP(s, hipMemsetAsync(M.co_stamps, 0, 3 * MG_CO_PHASES * 8, s->stream));
-			}
-			C.stamps = M.co_stamps;
-			M.co_phases = 3 * (last - tail) + 3;
-		}
 		// one workgroup per tile of its first level: every workgroup owns one tile slot on every level it reaches
-		const int W = top >= 0 ? top_w : std::max(1, M.lv[tail].n_tiles);
-		const size_t lds = (size_t)(last - tail + 1) * sizeof(CoLevel<real>) + 512 * sizeof(real) +
-		                   (top >= 0 ? sizeof(CpTile<real>) + 512 * sizeof(real) : 0);
-		// One XCD (round 4, OPT-IN: LFA_MG_XCD=1 - see lfa_knobs::mg_xcd for what was measured): when the launch fits an eighth of the chip its workgroups are placed on ONE XCD - every eighth of
-		// 8 W workgroups works, the dispatcher deals consecutive workgroups round robin over the XCDs - and exchange through that
-		// XCD's L2 with workgroup-scope accesses: a hand-off takes 1.1 instead of 2.2 us (profiles/r03_xcd_barrier_probe.txt), and a
-		// V-cycle's coarse levels are a chain of ~13 of them. Nothing documents the round robin: every ready flag carries its
-		// producer's XCC id, a consumer that meets another id gives the launch up, and the solve is repeated without this mode.
-		const bool xcd = s->knobs.mg_xcd && !s->co_xcd_disabled && top < 0 && !s->dist && (size_t)W <= xcd_cap;
-		s->co_last_xcd = xcd;
+		const int W = std::max(1, M.lv[tail].n_tiles);
+		const size_t lds = (size_t)(last - tail + 1) * sizeof(CoLevel<real>) + 512 * sizeof(real);
 		CoGateScope gate(s);
-		if (xcd) hipLaunchKernelGGL((k_mg_coarse<real, MemWg, true>), dim3(8 * W), dim3(256), lds, s->stream, C, st);
-		else hipLaunchKernelGGL((k_mg_coarse<real, MemAgent, false>), dim3(W), dim3(256), lds, s->stream, C, st);  // (dynamic LDS limit: set where `fits` is)
+		hipLaunchKernelGGL((k_mg_coarse<real, MemAgent>), dim3(W), dim3(256), lds, s->stream, C, st);  // (dynamic LDS limit: set where `fits` is)
 		if (gate.done() != LFA_OK) return lfa_fail(s, LFA_E_HIP, "chaining k_mg_coarse behind the device's previous one failed");
 		LFA_LAUNCH_CHECK(s);
 		++launches;
@@ -2824,12 +2186,9 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		T.last = last;
 		// the trailing run of single-tile levels (at most MG_CHAIN_MAX of them) stays inside one wave
 		T.chain = last;
-		if (!s->knobs.mg_no_chain)
-			while (T.chain > tail && last - (T.chain - 1) + 1 <= MG_CHAIN_MAX && M.lv[T.chain - 1].n_tiles == 1) --T.chain;
+		while (T.chain > tail && last - (T.chain - 1) + 1 <= MG_CHAIN_MAX && M.lv[T.chain - 1].n_tiles == 1) --T.chain;
 		T.nsw = MG_COARSEST_SWEEPS;
 		T.inner = MG_INNER_SWEEPS;  // measured at C4: 19 iterations; 1 sweep on the tail levels: 22
-		if (s->knobs.mg_tail_inner > 0) T.inner = s->knobs.mg_tail_inner;
-		if (s->knobs.mg_nsw > 0) T.nsw = s->knobs.mg_nsw;
 		hipLaunchKernelGGL(k_mg_tail<real>, dim3(1), dim3(MG_TAIL_WAVES * 64), 0, s->stream, T, st);
 		LFA_LAUNCH_CHECK(s);
 		++launches;
@@ -2837,22 +2196,15 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 	for (int l = tail - 1; l >= 0; --l) {
 		const MgLv<real> L = lvl(l);
 		const int G = mg_grid(L.n_tiles);
-		if (l == top) continue;  // (inside k_mg_coarse)
 		if (!(parts & (l == 0 ? MG_PART_UP0 : MG_PART_COARSE))) continue;
-		if (merge01 && l == 1) continue;  // (inside level 0's launch)
-		if (l == 0 && merge01)
-			launch_up01<real>(s->knobs.mg_mw_u, G, s->stream, L, M.lv[1].g, (const real *)M.lv[1].y, inv_scale, part_sigma, st, lvl(1), M.lv[2].g,
-			                  (const real *)M.lv[2].y, MgQueue{M.q + 8, s->pcg_state + 2});
-		else if (l == 0)
-			launch_up0<real>(s->knobs.mg_mw_u, G, s->stream, L, M.lv[1].g, (const real *)M.lv[1].y, inv_scale, part_sigma, st, MgLv<real>{}, GridDims{},
-			                 (const real *)nullptr, MgQueue{nullptr, nullptr});
-		else if (!s->knobs.mg_no_cp && L.n_tiles <= cp_max)
+		if (l == 0)
+			launch_up0<real>(G, s->stream, L, M.lv[1].g, (const real *)M.lv[1].y, inv_scale, part_sigma, st);
+		else if (L.n_tiles <= cp_max)
 			hipLaunchKernelGGL(k_mg_prolong_postsmooth_cp<real>, dim3(std::max(1, std::min(L.n_tiles, 8192))), dim3(256), 0, s->stream, L, M.lv[l + 1].g,
 			                   (const real *)M.lv[l + 1].y, MG_INNER_SWEEPS, st);
 		else
 			hipLaunchKernelGGL((k_mg_prolong_postsmooth<real, false, 1>), dim3(G), dim3(256), 0, s->stream, L, M.lv[l + 1].g,
-			                   (const real *)M.lv[l + 1].y, (real)1, (double *)nullptr, st, MgLv<real>{}, GridDims{}, (const real *)nullptr,
-			                   MgQueue{nullptr, nullptr});
+			                   (const real *)M.lv[l + 1].y, (real)1, (double *)nullptr, st);
 		LFA_LAUNCH_CHECK(s);
 		++launches;
 		// the finer level corrects its ring cells across a slab face with this level's result there
@@ -2860,114 +2212,9 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 	}
 	if (parts == MG_PART_ALL) {
 		M.launches_per_cycle = launches + (level0_presmoothed ? 1 : 0);
-		M.first_co = persist ? (top >= 0 ? top : tail) : 0;
+		M.first_co = persist ? tail : 0;
 	}
 	return LFA_OK;
-}
-
-/// The whole solve in one launch (k_pcg_small) when the system is small enough for a resident workgroup per particle tile:
-/// *ran = false (nothing done) otherwise. Expects the system built (A bytes, right-hand side in vr, guess in vp) and the
-/// hierarchy set up; leaves the pressure in vp, the residual in vr, iterations / NaN flag in pcg_state, the residual history
-/// in pcg_hist - what the multi-launch loop leaves.
-bool lfa_pcg_small_eligible(const lfa_sim *s);
-template <typename real> static int pcg_small_t(lfa_sim *s, bool *ran) {
-	*ran = false;
-	if (!s->mg || !lfa_pcg_small_eligible(s)) return LFA_OK;
-	lfa_mg &M = *s->mg;
-	const int nl = M.n_levels, last = nl - 1, W = s->n_ptiles;
-	if (nl < 2 || W < 1 || W > PS_MAX_TILES || last > MG_CO_MAX_LEVELS || !M.lv[0].ready || M.lv[0].n_tiles != W) return LFA_OK;
-	static int n_cu_of[64];      // per device (a process may hold handles on several GPUs)
-	static bool attr_set_of[64];
-	static std::mutex once;
-	int n_cu;
-	{
-		std::lock_guard<std::mutex> lk(once);
-		const int d = s->device & 63;
-		if (!n_cu_of[d]) {
-			hipDeviceProp_t prop;
-			n_cu_of[d] = (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-		}
-		if (!attr_set_of[d]) {
-			LFA_HIP(s, hipFuncSetAttribute((const void *)k_pcg_small<real>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-			attr_set_of[d] = true;
-		}
-		n_cu = n_cu_of[d];
-	}
-	// every workgroup must be resident at once: LDS per workgroup = the levels below the finest + the finest level's halo block
-	const size_t lds = (size_t)last * sizeof(CoLevel<real>) + (size_t)(LFA_HALO_CELLS + 512) * sizeof(real);
-	int per_cu = 0;  // by registers and LDS together (168 VGPRs in fp32: 3 workgroups per CU)
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_pcg_small<real>, 256, lds) != hipSuccess) per_cu = 0;
-	(void)hipGetLastError();
-	size_t cap = std::min<size_t>((size_t)per_cu * (size_t)n_cu, PS_MAX_TILES);
-	if (s->knobs.pcg_small_max >= 0) cap = std::min<size_t>(cap, (size_t)s->knobs.pcg_small_max);
-	if ((size_t)W > cap) return LFA_OK;
-	if (!M.ps_part) {
-		const size_t bytes = (size_t)3 * PS_MAX_TILES * sizeof(double) + (size_t)2 * PS_MAX_TILES * sizeof(unsigned);
-		LFA_HIP(s, hipMalloc(&M.ps_part, bytes));
-		LFA_HIP(s, hipMemsetAsync(M.ps_part, 0, bytes, s->stream));
-	}
-	PcgSmall<real> Q;
-	for (int l = 0; l <= last; ++l) {
-		const lfa_mg_level &L = M.lv[l];
-		Q.C.lv[l] = MgLv<real>{L.tiles, L.nbr, L.n_tiles, L.g, l == 0 ? (const uint8_t *)s->abits : (const uint8_t *)L.abits,
-		                       l == 0 ? (real *)s->vr : (real *)L.b, l == 0 ? (real *)s->vq : (real *)L.x, l == 0 ? (real *)s->vz : (real *)L.y};
-		Q.C.ready[l] = L.ready;
-	}
-	Q.C.first = 1;
-	Q.C.last = last;
-	Q.C.nsw = MG_COARSEST_SWEEPS;
-	Q.C.inner = MG_INNER_SWEEPS;
-	if (s->knobs.mg_tail_inner > 0) Q.C.inner = s->knobs.mg_tail_inner;
-	if (s->knobs.mg_nsw > 0) Q.C.nsw = s->knobs.mg_nsw;
-	Q.C.stamps = nullptr;
-	Q.C.abort = s->pcg_state + 2;
-	Q.C.fault = 0;
-	Q.C.top = -1;
-	const int maxit = (int)s->prm.max_iterations;
-	// tags tag .. tag + maxit belong to this launch (one per V-cycle); 0 is what the flags are initialised to
-	if (M.co_tag > 0x0FFFFFFFu - (unsigned)(maxit + 4)) {  // (a flag holds tag << 4 | XCC id)
-		for (int l = 0; l <= last; ++l)
-			LFA_HIP(s, hipMemsetAsync(M.lv[l].ready, 0, (size_t)(l == 0 ? 4 : 3) * M.lv[l].g.nt * sizeof(unsigned), s->stream));
-		LFA_HIP(s, hipMemsetAsync(M.ps_part, 0, (size_t)3 * PS_MAX_TILES * sizeof(double) + (size_t)2 * PS_MAX_TILES * sizeof(unsigned), s->stream));
-		M.co_tag = 0;
-	}
-	Q.C.tag = M.co_tag + 1;
-	M.co_tag += (unsigned)maxit + 2;
-	Q.p = (real *)s->vp;
-	Q.r = (real *)s->vr;
-	Q.s = (real *)s->vs;
-	Q.x0 = (real *)s->vq;
-	Q.sflag = M.lv[0].ready + (size_t)3 * M.lv[0].g.nt;
-	Q.part = M.ps_part;
-	Q.pflag = (unsigned *)(M.ps_part + (size_t)3 * PS_MAX_TILES);
-	Q.scale = (real)s->a_scale;
-	Q.inv_scale = (real)(1.0 / s->a_scale);
-	Q.tol = s->prm.tolerance;
-	Q.maxit = maxit;
-	Q.state = s->pcg_state;
-	Q.hist = s->pcg_hist;
-	CoGateScope gate(s);
-	hipLaunchKernelGGL(k_pcg_small<real>, dim3(W), dim3(256), lds, s->stream, Q);
-	if (gate.done() != LFA_OK) return lfa_fail(s, LFA_E_HIP, "chaining k_pcg_small behind the device's previous waiting kernel failed");
-	LFA_LAUNCH_CHECK(s);
-	M.launches_per_cycle = 0;
-	M.first_co = 1;
-	*ran = true;
-	return LFA_OK;
-}
-/// Whether the next solve of this handle will take the one-launch path (same conditions as pcg_small_t, before the hierarchy
-/// exists): the position correction then runs BEFORE the solve on the main stream instead of beside it - a kernel whose
-/// workgroups wait for each other must not share the device with a long-running kernel of another stream (its workgroups
-/// become resident only as the other's retire, the resident ones poll meanwhile: measured 1-2 s per C2 step).
-/// OPT-IN (LFA_PCG_SMALL=1). Measured on full steps: 64^3 / 262 144 particles, PCG loop 0.83 -> 0.69 ms, but the step 1.31 ->
-/// 1.41 ms because the correction no longer hides beside the solve; 50^3: 1.21 -> 1.21 ms. Alone (staged hosts, lfa_pcg_solve) it
-/// is the faster solve; inside the overlapped step it is not, so the default stays the multi-launch loop.
-bool lfa_pcg_small_eligible(const lfa_sim *s) {
-	return s->knobs.pcg_small && !s->co_disabled && s->prm.precond == LFA_PRECOND_MULTIGRID && !s->dist && s->n_ptiles >= 1 &&
-	       s->n_ptiles <= PS_MAX_TILES && (s->g.nx > 8 || s->g.ny > 8 || s->g.nz > 8);
-}
-int lfa_pcg_small(lfa_sim *s, bool *ran) {
-	return s->prm.pcg_dtype == LFA_PCG_F64 ? pcg_small_t<double>(s, ran) : pcg_small_t<float>(s, ran);
 }
 
 void lfa_mg_stats(const lfa_sim *s, uint64_t *launches_per_cycle, uint64_t *levels, uint64_t *first_co) {
@@ -2986,7 +2233,7 @@ template <typename real>
 static int mg_axpy_apply_t(lfa_sim *s, const void *sdir, const double *part_sigma, int n_sigma, const double *part_qs, int n_qs,
                            double *part_rmax, double *part_sigma_new) {
 	const int G = mg_grid(s->n_ptiles);
-	launch_axpy_presmooth<real>(s->knobs.mg_mw_a, G, s->stream, (const int *)s->ptiles, s->n_ptiles, (const uint8_t *)s->abits, (real *)s->vp,
+	launch_axpy_presmooth<real>(G, s->stream, (const int *)s->ptiles, s->n_ptiles, (const uint8_t *)s->abits, (real *)s->vp,
 	                            (const real *)sdir, (real *)s->vr, (real *)s->vq, part_sigma, n_sigma, part_qs, n_qs, part_rmax,
 	                            (const int *)s->pcg_state);
 	LFA_LAUNCH_CHECK(s);
@@ -3030,8 +2277,8 @@ int lfa_mg_bench_part(lfa_sim *s, int part) {
 	double *P = s->partials;
 	const int G = mg_grid(s->n_ptiles);
 	if (part == 0) {
-		if (f64) launch_axpy_presmooth<double>(s->knobs.mg_mw_a, G, s->stream, (const int *)s->ptiles, s->n_ptiles, (const uint8_t *)s->abits, (double *)s->vp, (const double *)s->vs, (double *)s->vr, (double *)s->vq, (const double *)(P + PART_SIG0), G, (const double *)(P + PART_ZS), G, P + PART_RMAX, (const int *)s->pcg_state);
-		else launch_axpy_presmooth<float>(s->knobs.mg_mw_a, G, s->stream, (const int *)s->ptiles, s->n_ptiles, (const uint8_t *)s->abits, (float *)s->vp, (const float *)s->vs, (float *)s->vr, (float *)s->vq, (const double *)(P + PART_SIG0), G, (const double *)(P + PART_ZS), G, P + PART_RMAX, (const int *)s->pcg_state);
+		if (f64) launch_axpy_presmooth<double>(G, s->stream, (const int *)s->ptiles, s->n_ptiles, (const uint8_t *)s->abits, (double *)s->vp, (const double *)s->vs, (double *)s->vr, (double *)s->vq, (const double *)(P + PART_SIG0), G, (const double *)(P + PART_ZS), G, P + PART_RMAX, (const int *)s->pcg_state);
+		else launch_axpy_presmooth<float>(G, s->stream, (const int *)s->ptiles, s->n_ptiles, (const uint8_t *)s->abits, (float *)s->vp, (const float *)s->vs, (float *)s->vr, (float *)s->vq, (const double *)(P + PART_SIG0), G, (const double *)(P + PART_ZS), G, P + PART_RMAX, (const int *)s->pcg_state);
 		LFA_LAUNCH_CHECK(s);
 		return LFA_OK;
 	}

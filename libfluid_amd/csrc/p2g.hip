@@ -243,256 +243,6 @@ k_p2g_binned(const int *ptiles, int n_ptiles, ParticleSoA p, ParticleSoA pvc, co
 	}
 }
 
-// ------------------------------------------------------------------------------------------------ cell-centric (round 4)
-// On the cell-sorted order of k_cell_sort (core.hip) a wave owns one z-slice of the tile, a LANE OWNS A CELL: iteration j loads the
-// j-th particle of every cell of the slice - consecutive records, one coalesced load per field - and the lane adds its 3 x 2 x 3 x 3
-// face contributions (component, own-axis node, the two staggered axes' nodes: the hat evaluated at all 18 faces the cell's
-// particles can reach, 10 of which are zero for any one particle) to REGISTERS. The LDS sees one ds_add_u64 per (cell, node, sum)
-// instead of one per (particle, node, sum): 108 per cell = 13.5 per particle at eight per cell, against 48; and the float -> fixed
-// conversion - two f64 operations per value, the largest VALU item of the particle-parallel kernel - runs once per cell and node.
-// The sums inside a cell are float sums in the order of k_cell_sort's canonical ranks (reproducible); across cells they are the
-// order-independent fixed point of before, so the staging slab and k_p2g_finalize are unchanged.
-#define PC_THREADS 256  // 4 waves, each takes two slices one after the other (3 workgroups per CU by LDS)
-
-/// What one component's pass needs of a particle: the fractions, the component's velocity and its row of C.
-struct CompRegs {
-	float t[3], v, c[3];
-};
-template <bool APIC, int Q>
-__device__ inline void load_comp(const ParticleSoA &p, const ParticleSoA &pvc, uint32_t i, uint32_t j, CompRegs &r) {
-#pragma unroll
-	for (int k = 0; k < 3; ++k) r.t[k] = p.t[k][i];
-	r.v = pvc.v[Q][j];
-	if (APIC) {
-#pragma unroll
-		for (int k = 0; k < 3; ++k) r.c[k] = pvc.c[3 * Q + k][j];
-	}
-}
-
-/// Sums of one component over the particles of a cell: [own-axis node 0|1][node -1|0|+1 of the 1st staggered axis][of the 2nd].
-struct CompAcc {
-	float wv[2][3][3], w[2][3][3];
-};
-
-template <bool APIC, int Q>
-__device__ inline void comp_accumulate(CompAcc &a, const CompRegs &r, float hworld) {
-	constexpr int A = Q == 0 ? 1 : 0, B = Q == 2 ? 1 : 2;  // the staggered axes, ascending
-	// 1-D hats. Own axis: nodes l + 0, l + 1 (halo coordinates), (p - face) = t - i, weights (1 - t, t). Staggered axis: nodes
-	// l + 1 + o, o = -1, 0, +1, (p - face) = s - o with s = t - 1/2, weights max(0, -s), 1 - |s|, max(0, s).
-	const float wo[2] = {1.0f - r.t[Q], r.t[Q]};
-	const float sA = r.t[A] - 0.5f, sB = r.t[B] - 0.5f;
-	const float wA[3] = {fmaxf(-sA, 0.0f), 1.0f - fabsf(sA), fmaxf(sA, 0.0f)};
-	const float wB[3] = {fmaxf(-sB, 0.0f), 1.0f - fabsf(sB), fmaxf(sB, 0.0f)};
-	float bo[2] = {r.v, r.v}, aA[3] = {0.f, 0.f, 0.f}, aB[3] = {0.f, 0.f, 0.f};
-	if (APIC) {
-		// val = v + sum_d C[Q][d] (face - p)_d h  (src/simulation.cpp:371-375)
-		const float co = -hworld * r.c[Q], cA = -hworld * r.c[A], cB = -hworld * r.c[B];
-		bo[0] = r.v + co * r.t[Q];
-		bo[1] = r.v + co * (r.t[Q] - 1.0f);
-		aA[0] = cA * (sA + 1.0f); aA[1] = cA * sA; aA[2] = cA * (sA - 1.0f);
-		aB[0] = cB * (sB + 1.0f); aB[1] = cB * sB; aB[2] = cB * (sB - 1.0f);
-	}
-#pragma unroll
-	for (int j = 0; j < 3; ++j)
-#pragma unroll
-		for (int k = 0; k < 3; ++k) {
-			const float wjk = wA[j] * wB[k];
-			const float ajk = aA[j] + aB[k];
-#pragma unroll
-			for (int i = 0; i < 2; ++i) {
-				const float wgt = wo[i] * wjk;
-				const float val = APIC ? bo[i] + ajk : r.v;
-				a.wv[i][j][k] = __builtin_fmaf(wgt, val, a.wv[i][j][k]);
-				a.w[i][j][k] += wgt;
-			}
-		}
-}
-
-/// A per-cell sum to fixed point. The magic-constant conversion holds for |x scale| < 2^51; a cell's sum of w v can pass that where
-/// one contribution could not (|x| >= 2^15 at 2^-36 units: dozens of particles at hundreds of cells per second) - a cell with such
-/// a sum converts through integers instead (rare; both paths are exact to the unit).
-__device__ __noinline__ unsigned long long to_fixed_wide(float x, double scale) {
-	const double d = (double)x * scale;  // exact; |d| < 2^63 for |x| < 2^27
-	const double hi = rint(d * (1.0 / 4294967296.0));
-	const double lo = d - hi * 4294967296.0;
-	return (unsigned long long)((long long)hi * 4294967296ll + (long long)lo);
-}
-
-/// One component of one z-slice. The wave walks the slice's runs (run j = the j-th particles of the cells that have one: a
-/// contiguous range of records, lane = cell). t comes from the sorted arrays, one coalesced load per run, pipelined one run ahead.
-/// v and the row of C come through the binning's source index from the order of the step before, where the 64 particles of a run
-/// are scattered over the slice's old region: loaded one run per iteration - the first version - each of those lines was touched
-/// in eight iterations a microsecond apart, with a few hundred other waves' lines in between, and the L2 did not hold them (2.8 ms
-/// at C4). So the gathers of PC_BURST runs are issued back to back: a line's users follow each other at once.
-#ifndef PC_BURST
-#define PC_BURST 8
-#endif
-#ifndef PC_MINWAVES
-#define PC_MINWAVES 1
-#endif
-/// base[i] with a 32-bit byte offset (uniform base + per-lane offset: no 64-bit address pair per load; the host checks capacity < 2^30)
-template <typename T> __device__ inline T ld32(const T *base, uint32_t i) {
-	return *(const T *)((const char *)base + (i << 2));
-}
-template <bool APIC, int Q>
-__device__ inline void slice_component(unsigned long long *acc, const ParticleSoA &p, const ParticleSoA &pvc, const uint32_t *from,
-                                       const uint32_t run0, const uint32_t cnt, const uint32_t maxc, const int slice, const float hworld) {
-	const int lane = threadIdx.x & 63;
-	const unsigned long long lt = (1ull << lane) - 1ull;
-	const uint32_t jend = maxc < LFA_CS_JMAX ? maxc : LFA_CS_JMAX;
-	const float *vq = pvc.v[Q], *c0 = pvc.c[3 * Q], *c1 = pvc.c[3 * Q + 1], *c2 = pvc.c[3 * Q + 2];
-	const float *t0 = p.t[0], *t1 = p.t[1], *t2 = p.t[2];
-	CompAcc a;
-#pragma unroll
-	for (int i = 0; i < 2; ++i)
-#pragma unroll
-		for (int j = 0; j < 3; ++j)
-#pragma unroll
-			for (int k = 0; k < 3; ++k) a.wv[i][j][k] = a.w[i][j][k] = 0.0f;
-	uint32_t run = run0;
-	for (uint32_t j0 = 0; j0 < jend; j0 += PC_BURST) {
-		uint32_t pos[PC_BURST], src[PC_BURST];
-		float bv[PC_BURST], bc[PC_BURST][3];
-#pragma unroll
-		for (int u = 0; u < PC_BURST; ++u) {
-			const uint32_t j = j0 + u;
-			const unsigned long long m = j < jend ? __ballot(cnt > j) : 0ull;
-			pos[u] = run + (uint32_t)__popcll(m & lt);
-			run += (uint32_t)__popcll(m);
-			src[u] = 0xFFFFFFFFu;
-		}
-#pragma unroll
-		for (int u = 0; u < PC_BURST; ++u)
-			if (cnt > j0 + u && j0 + u < jend) src[u] = from ? ld32(from, pos[u]) : pos[u];
-#pragma unroll
-		for (int u = 0; u < PC_BURST; ++u)
-			if (src[u] != 0xFFFFFFFFu) {
-				bv[u] = ld32(vq, src[u]);
-				if (APIC) {
-					bc[u][0] = ld32(c0, src[u]); bc[u][1] = ld32(c1, src[u]); bc[u][2] = ld32(c2, src[u]);
-				}
-			}
-		CompRegs cur, nxt;
-		if (src[0] != 0xFFFFFFFFu) {
-			cur.t[0] = ld32(t0, pos[0]); cur.t[1] = ld32(t1, pos[0]); cur.t[2] = ld32(t2, pos[0]);
-		}
-#pragma unroll
-		for (int u = 0; u < PC_BURST; ++u) {
-			if (u + 1 < PC_BURST && src[u + 1] != 0xFFFFFFFFu) {
-				nxt.t[0] = ld32(t0, pos[u + 1]); nxt.t[1] = ld32(t1, pos[u + 1]); nxt.t[2] = ld32(t2, pos[u + 1]);
-			}
-			if (src[u] != 0xFFFFFFFFu) {
-				cur.v = bv[u];
-				cur.c[0] = bc[u][0]; cur.c[1] = bc[u][1]; cur.c[2] = bc[u][2];
-				comp_accumulate<APIC, Q>(a, cur, hworld);
-			}
-			cur.t[0] = nxt.t[0]; cur.t[1] = nxt.t[1]; cur.t[2] = nxt.t[2];
-		}
-	}
-	// the tails of crowded cells (rank >= LFA_CS_JMAX): cell after cell behind the runs, a lane walks its own
-	if (maxc > LFA_CS_JMAX) {
-		const uint32_t tc = cnt > LFA_CS_JMAX ? cnt - LFA_CS_JMAX : 0u;
-		uint32_t ti = tc;
-#pragma unroll
-		for (int o = 1; o < 64; o <<= 1) {
-			const uint32_t t = __shfl_up(ti, o, 64);
-			if (lane >= o) ti += t;
-		}
-		const uint32_t first = run + ti - tc;
-		for (uint32_t k = 0; k < tc; ++k) {
-			CompRegs r;
-			load_comp<APIC, Q>(p, pvc, first + k, from ? from[first + k] : first + k, r);
-			comp_accumulate<APIC, Q>(a, r, hworld);
-		}
-	}
-	// flush: one fixed-point add per (node, sum) of the cell. acc = this component's [wv | w][10 x 10 x 10]
-	if (cnt > 0) {
-		constexpr int A = Q == 0 ? 1 : 0, B = Q == 2 ? 1 : 2;
-		const int l3[3] = {lane & 7, lane >> 3, slice};
-		const int strd[3] = {1, 10, 100};
-		const int base = l3[Q] * strd[Q] + (l3[A] + 1) * strd[A] + (l3[B] + 1) * strd[B];
-		float big = 0.0f;
-#pragma unroll
-		for (int i = 0; i < 2; ++i)
-#pragma unroll
-			for (int j = 0; j < 3; ++j)
-#pragma unroll
-				for (int k = 0; k < 3; ++k) big = fmaxf(big, fabsf(a.wv[i][j][k]));
-		if (__builtin_expect(big < 8192.0f, 1)) {
-#pragma unroll
-			for (int i = 0; i < 2; ++i)
-#pragma unroll
-				for (int j = 0; j < 3; ++j)
-#pragma unroll
-					for (int k = 0; k < 3; ++k) {
-						unsigned long long *dst = acc + (base + i * strd[Q] + (j - 1) * strd[A] + (k - 1) * strd[B]);
-						atomicAdd(dst, to_fixed(a.wv[i][j][k], P2G_FIX_SCALE_V));
-						atomicAdd(dst + LFA_HALO_CELLS, to_fixed(a.w[i][j][k], P2G_FIX_SCALE_W));
-					}
-		} else {
-#pragma unroll
-			for (int i = 0; i < 2; ++i)
-#pragma unroll
-				for (int j = 0; j < 3; ++j)
-#pragma unroll
-					for (int k = 0; k < 3; ++k) {
-						unsigned long long *dst = acc + (base + i * strd[Q] + (j - 1) * strd[A] + (k - 1) * strd[B]);
-						atomicAdd(dst, to_fixed_wide(a.wv[i][j][k], P2G_FIX_SCALE_V));
-						atomicAdd(dst + LFA_HALO_CELLS, to_fixed(a.w[i][j][k], P2G_FIX_SCALE_W));
-					}
-		}
-	}
-}
-
-/// A workgroup per (particle tile, component): 16 KB of accumulators, two channels of the tile's staging slab.
-template <bool APIC, int Q>
-__device__ inline void tile_component(unsigned long long *acc, uint32_t *ssum, int slot, int tile, const ParticleSoA &p, const ParticleSoA &pvc,
-                                      const uint32_t *from, const uint32_t *tile_start, const uint32_t *cell_count, float *stage, float hworld) {
-	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-	for (int i = threadIdx.x; i < 2 * LFA_HALO_CELLS; i += PC_THREADS) acc[i] = 0ull;
-	uint32_t cn[2];
-#pragma unroll
-	for (int h = 0; h < 2; ++h) {
-		cn[h] = cell_count[(size_t)tile * LFA_TILE_CELLS + 64 * (wid + 4 * h) + lane];
-		const uint32_t tot = wave_sum(cn[h]);
-		if (lane == 0) ssum[wid + 4 * h] = tot;
-	}
-	__syncthreads();
-	const uint32_t tile_base = tile_start[tile];
-#pragma unroll 1
-	for (int h = 0; h < 2; ++h) {
-		const int slice = wid + 4 * h;
-		const uint32_t cnt = h ? cn[1] : cn[0];
-		uint32_t run = tile_base;
-		for (int w = 0; w < slice; ++w) run += ssum[w];
-		const uint32_t maxc = wave_max(cnt);
-		if (maxc == 0) continue;  // (uniform per wave)
-		slice_component<APIC, Q>(acc, p, pvc, from, run, cnt, maxc, slice, hworld);
-	}
-	__syncthreads();
-	float *out = stage + ((size_t)slot * 6 + 2 * Q) * LFA_HALO_CELLS;
-	for (int k = threadIdx.x; k < 2 * LFA_HALO_CELLS; k += PC_THREADS) {  // (slab order: lfa_stage_index)
-		const int ch = k / LFA_HALO_CELLS;
-		out[k] = (float)((double)(long long)acc[ch * LFA_HALO_CELLS + lfa_stage_source(k - ch * LFA_HALO_CELLS)] *
-		                 (ch ? 1.0 / P2G_FIX_SCALE_W : 1.0 / P2G_FIX_SCALE_V));
-	}
-	__syncthreads();
-}
-
-template <bool APIC>
-__global__ void __launch_bounds__(PC_THREADS, PC_MINWAVES)
-k_p2g_cells(const int *ptiles, int n_ptiles, ParticleSoA p, ParticleSoA pvc, const uint32_t *from, const uint32_t *tile_start,
-            const uint32_t *cell_count, float *stage, float hworld) {
-	__shared__ unsigned long long acc[2 * LFA_HALO_CELLS];  // 16 KB: [wv | w][10x10x10] of one component
-	__shared__ uint32_t ssum[8];
-	for (int work = blockIdx.x; work < 3 * n_ptiles; work += gridDim.x) {
-		const int slot = work / 3, q = work - 3 * slot, tile = ptiles[slot];
-		if (q == 0) tile_component<APIC, 0>(acc, ssum, slot, tile, p, pvc, from, tile_start, cell_count, stage, hworld);
-		else if (q == 1) tile_component<APIC, 1>(acc, ssum, slot, tile, p, pvc, from, tile_start, cell_count, stage, hworld);
-		else tile_component<APIC, 2>(acc, ssum, slot, tile, p, pvc, from, tile_start, cell_count, stage, hworld);
-	}
-}
-
 // ------------------------------------------------------------------------------------------------ global atomics
 __global__ void k_zero_acc(const int *dtiles, int n_dtiles, float *acc, size_t ncp) {
 	int slot = blockIdx.x;
@@ -645,21 +395,10 @@ static int scatter_mode(const lfa_sim *s) {
 static void launch_binned(lfa_sim *s, const ParticleSoA &p, const ParticleSoA &pvc, const uint32_t *from, float *stage_own) {
 	const dim3 grid(grid_blocks(s->n_ptiles));
 	const float hworld = (float)s->prm.cell_size;
-	// the cell-centric scatter, whenever the particles are in cell order (right after a binning) and the hat is the 2 x 2 x 2 one
-	if (s->cell_sorted && s->knobs.p2g_cells && scatter_mode(s) != 2) {
-		const dim3 grid(grid_blocks(3 * s->n_ptiles));
-		if (scatter_mode(s) == 1)
-			hipLaunchKernelGGL((k_p2g_cells<true>), grid, dim3(PC_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, p, pvc, from, s->tile_start,
-			                   (const uint32_t *)s->cell_count, stage_own, hworld);
-		else
-			hipLaunchKernelGGL((k_p2g_cells<false>), grid, dim3(PC_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, p, pvc, from, s->tile_start,
-			                   (const uint32_t *)s->cell_count, stage_own, hworld);
-		return;
-	}
 #define LB(A, Q)                                                                                                             \
 	hipLaunchKernelGGL((k_p2g_binned<A, Q>), grid, dim3(P2G_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, p, pvc, from, s->tile_start, \
 	                   stage_own, hworld, rot_mask)
-	const int rot_mask = s->knobs.p2g_no_rot ? 0 : 7;  // A/B switch for the lane-rotated node order (profiles/r02_p2g_lds_pmc.txt)
+	const int rot_mask = 7;  // the lane-rotated node order (profiles/r02_p2g_lds_pmc.txt)
 	switch (scatter_mode(s)) {
 	case 0: LB(false, false); break;
 	case 1: LB(true, false); break;

@@ -1118,7 +1118,6 @@ static int advect_collide(lfa_sim *s, double dt, bool with_count, bool split = f
 	LFA_TRY(lfa_sources_sync(s));
 	LFA_TRY(refresh_tile_clear(s));
 	s->counts_fresh = false;
-	s->cell_sorted = false;  // keys change in place
 	if (n) {
 		if (s->any_coerce) s->vmax2_valid = false;  // velocities are overwritten inside the coercing sources' cells
 		const uint8_t *cm = s->any_coerce ? (const uint8_t *)s->coerce_map : (const uint8_t *)nullptr;
@@ -1200,7 +1199,6 @@ extern "C" int lfa_collide(lfa_sim *s) {
 	const size_t n = s->binned ? s->np_live : s->np;
 	const bool pending = s->move_pending;
 	s->move_pending = false;
-	s->cell_sorted = false;
 	if (!n) return lfa_dist_migrate(s);  // (slabs: every rank takes part in the hand-over, also one without particles)
 	LFA_TRY(refresh_tile_clear(s));
 	ParticleSoA &cur = s->pb[s->cur], &oth = s->pb[s->cur ^ 1];
@@ -1253,7 +1251,6 @@ static int correct_apply(lfa_sim *s, double dt, bool migrate = true, bool with_c
 	mpc.collide = with_collide ? 1 : 0;
 	ParticleSoA &cur = s->pb[s->cur], &oth = s->pb[s->cur ^ 1];
 	float4 *spos = correction_scratch(s);
-	s->cell_sorted = false;  // (key, t) are rewritten in place
 	if (n) {
 		// LDS-tiled pass; half tiles whose neighbourhood exceeds the LDS capacity are flagged and redone, first by the same kernel
 		// with the whole LDS of a CU (round 4: late in a run a few hundred crowded half tiles cost the global-gather kernel more
@@ -1274,21 +1271,18 @@ static int correct_apply(lfa_sim *s, double dt, bool migrate = true, bool with_c
 			// written in place; the fallback pass below takes its particles' old state from the records and the copy of the keys
 			// the index kernel has left in the other buffer
 			if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[41], s->stream));
-			if (s->knobs.corr_lds_pad > 0)
-				(void)hipFuncSetAttribute((const void *)k_correct_fine<FINE_CAP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, s->knobs.corr_lds_pad);
-			hipLaunchKernelGGL((k_correct_fine<FINE_CAP, false>), dim3(g2), dim3(CORR_THREADS), (size_t)std::max(0, s->knobs.corr_lds_pad), s->stream, s->ptiles, s->n_ptiles, cur.key,
+			hipLaunchKernelGGL((k_correct_fine<FINE_CAP, false>), dim3(g2), dim3(CORR_THREADS), 0, s->stream, s->ptiles, s->n_ptiles, cur.key,
 			                   cur.t[0], cur.t[1], cur.t[2], s->g, s->solid, s->tile_count, s->fine_start, (const float4 *)spos, mpc, ovf,
 			                   (const uint8_t *)s->tile_clear, (const uint32_t *)nullptr);
 			LFA_LAUNCH_CHECK(s);
 			if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[42], s->stream));
 			// (a workgroup per CU and a few more: they return at once unless something is flagged)
-			if (!s->knobs.corr_no_big)
-				hipLaunchKernelGGL((k_correct_fine<FINE_CAP_BIG, true>), dim3(std::min(CORR_BIG_SLICES * g2, 2048)), dim3(CORR_THREADS_BIG), 0, s->stream, s->ptiles,
-				                   s->n_ptiles, cur.key, cur.t[0], cur.t[1], cur.t[2], s->g, s->solid, s->tile_count, s->fine_start,
-				                   (const float4 *)spos, mpc, ovf2, (const uint8_t *)s->tile_clear, (const uint32_t *)ovf);
+			hipLaunchKernelGGL((k_correct_fine<FINE_CAP_BIG, true>), dim3(std::min(CORR_BIG_SLICES * g2, 2048)), dim3(CORR_THREADS_BIG), 0, s->stream, s->ptiles,
+			                   s->n_ptiles, cur.key, cur.t[0], cur.t[1], cur.t[2], s->g, s->solid, s->tile_count, s->fine_start,
+			                   (const float4 *)spos, mpc, ovf2, (const uint8_t *)s->tile_clear, (const uint32_t *)ovf);
 			LFA_LAUNCH_CHECK(s);
 		}
-		const uint32_t *fallback = s->knobs.corr_no_big ? ovf : ovf2;
+		const uint32_t *fallback = ovf2;
 		hipLaunchKernelGGL(k_correct_collide, dim3((unsigned)std::min<size_t>((n + 255) / 256, 16384)), dim3(256), 0, s->stream, n, cur, cur.key, cur.t[0],
 		                   cur.t[1], cur.t[2], s->g, s->solid, s->tile_count, s->fine_start, (const float4 *)spos, mpc,
 		                   fallback, (const int *)s->tile_pslot, s->p_off, (const uint32_t *)oth.key);
@@ -1345,17 +1339,6 @@ static int correct_begin(lfa_sim *s, double dt, bool slab_exchanged) {
 	LFA_TRY(lfa_corr_commit(s));
 	s->corr_begun = false;
 	if (!s->np_live && !s->dist) return LFA_OK;  // nothing to correct: _end and _undo are no-ops
-	if (lfa_pcg_small_eligible(s)) {
-		// A small system: its solve is ONE launch of workgroups that wait for each other and must have the device to itself. The
-		// correction (a fraction of a millisecond at this size) runs right here on the main stream - the same arithmetic at the same
-		// point of the data flow, nothing in flight afterwards; _end is a no-op, _undo restores as usual.
-		int rc = correct_build_index(s, false);
-		if (rc == LFA_OK) rc = correct_apply(s, dt, false);
-		if (s->timing) LFA_HIP(s, hipEventRecord(s->ev[LFA_EV_CORRECT_END], s->stream));
-		s->corr_begun = true;
-		s->corr_undo_valid = rc == LFA_OK;
-		return rc < 0 ? rc : LFA_OK;
-	}
 	LFA_HIP(s, hipEventRecord(s->ev_cfork, s->stream));
 	LFA_HIP(s, hipStreamWaitEvent(s->stream3, s->ev_cfork, 0));
 	hipStream_t main_stream = s->stream;
@@ -1552,9 +1535,9 @@ extern "C" int lfa_get_correction_stats_ex(lfa_sim *s, uint64_t stats[3]) {
 	LFA_HIP(s, hipMemcpyAsync(&first, s->corr_ovf, 4, hipMemcpyDeviceToHost, s->stream));
 	LFA_HIP(s, hipMemcpyAsync(&second, s->corr_ovf + ovf_stride, 4, hipMemcpyDeviceToHost, s->stream));
 	LFA_HIP(s, hipStreamSynchronize(s->stream));
-	stats[0] = s->knobs.corr_no_big ? first : second;
+	stats[0] = second;
 	stats[1] = (uint64_t)CORR_PARTS * (uint64_t)s->corr_parts_tiles;
-	stats[2] = s->knobs.corr_no_big ? 0 : first;
+	stats[2] = first;
 	return LFA_OK;
 }
 

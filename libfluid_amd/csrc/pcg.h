@@ -35,6 +35,4 @@ int lfa_mg_axpy_apply_cg(lfa_sim *s, const double *gamma, int n_gamma, const dou
                          double *part_sigma_new);
 int lfa_mg_bench_part(lfa_sim *s, int part);
 void lfa_mg_free(lfa_sim *s);
-bool lfa_pcg_small_eligible(const lfa_sim *s);  // the next solve takes the one-launch path: nothing may run beside it
-int lfa_pcg_small(lfa_sim *s, bool *ran);  // the whole PCG solve of a small system in one launch (mg.hip: k_pcg_small)
 void lfa_mg_stats(const lfa_sim *s, uint64_t *launches_per_cycle, uint64_t *levels, uint64_t *first_co);

@@ -1397,8 +1397,6 @@ static int sigma_parts(const lfa_sim *s) { return pcg_grid(s->n_ptiles) + (is_ml
 template <typename real> static CoarseFields<real> make_coarse(lfa_sim *s) {
 	CoarseFields<real> cf{s->c_diag, {s->c_w[0], s->c_w[1], s->c_w[2]}, s->c_unk, (real *)s->c_pre,
 	                      s->c_r_cur ? (real *)s->c_r_cur : (real *)s->c_r, (real *)s->c_x};
-	if (s->knobs.coarse_w1 == s->knobs.coarse_w1) cf.w1 = (real)s->knobs.coarse_w1;  // experiment knobs (tools/pcg_convergence.py)
-	if (s->knobs.coarse_w2 == s->knobs.coarse_w2) cf.w2 = (real)s->knobs.coarse_w2;
 	return cf;
 }
 
@@ -1697,8 +1695,6 @@ static void fused_grids(const lfa_sim *s, int G, int &GA, int &GB) {
 	}
 	GA = std::min(G, 4 * n_cu);
 	GB = std::min(G, 8 * n_cu);
-	if (s->knobs.pcg_ga > 0) GA = std::max(1, std::min(s->knobs.pcg_ga, G));
-	if (s->knobs.pcg_gb > 0) GB = std::max(1, std::min(s->knobs.pcg_gb, G));
 }
 
 template <typename real> static int solve_t(lfa_sim *s, double dt, double *residual, uint64_t *iterations) {
@@ -1772,28 +1768,14 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 	auto sig_src = [&](int parity) { return dist ? red + 3 + parity : P + (parity ? PART_SIG1 : PART_SIG0); };
 	const int n_sig = dist ? 1 : NS, n_zs = dist ? 1 : G, n_max = dist ? 1 : G;
 	const real *cx = is_ml(s) ? (const real *)s->c_x : (const real *)nullptr;
-	// small systems: the whole solve in one launch (a workgroup per particle tile, vectors in registers; mg.hip: k_pcg_small)
-	bool small_ran = false;
-	if (is_mg(s) && !dist && s->n_ptiles && s->nbr_table) LFA_TRY(lfa_pcg_small(s, &small_ran));
-	s->stat_whole_solve = small_ran ? 1 : 0;
 	// z = M^-1 r ; s = z ; sigma = z.r
-	if (!small_ran) LFA_TRY(mic_apply<real>(s, P + PART_SIG0));
+	LFA_TRY(mic_apply<real>(s, P + PART_SIG0));
 	if (dist) LFA_TRY(lfa_dist_allreduce(s, P + PART_SIG0, NS, 3, false));
 	const int maxit = (int)s->prm.max_iterations;
 	const int chunk = 4;
 	int done = -1, nan = 0, i = 0;
 	int *hstate = (int *)s->h_pinned;
 	int aborted = 0;  // a kernel whose workgroups wait for each other gave a wait up (mg.hip: co_wait)
-	if (small_ran) {
-		LFA_HIP(s, hipMemcpyAsync(hstate, s->pcg_state, 80, hipMemcpyDeviceToHost, s->stream));
-		LFA_HIP(s, hipStreamSynchronize(s->stream));
-		done = hstate[0];
-		nan = hstate[1];
-		aborted = hstate[2];
-		i = maxit;  // (neither loop below runs)
-		uint64_t mgl = 0;
-		lfa_mg_stats(s, &mgl, &s->stat_mg_levels, &s->stat_mg_first_co);
-	}
 	// fused iteration (k_pcg_a / k_pcg_b): tile-local MIC(0) with or without the coarse levels, single domain or slabs
 	// (with the multigrid preconditioner the second kernel is the AXPY/pre-smoothing kernel followed by the V-cycle, mg.hip)
 	const bool fused = (is_mg(s) || s->prm.pcg_fused) && s->prm.precond != LFA_PRECOND_MIC0_EXACT && (s->n_ptiles == 0 || s->nbr_table);
@@ -1817,8 +1799,8 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 	// k_mg_axpy_presmooth_cg). Step A_k: w = A z_k and delta_k = w.z_k (k_pcg_a without a search direction, the slice of z across
 	// the slab faces, the rows that needed it), then gamma_k = z_k.r_k, delta_k and the signed max of r_k of every rank in ONE
 	// collective (gather buffer k & 1). Step B_k: stopping rule on r_k, the recurrences, r_k+1, the V-cycle -> z_k+1.
-	// Per iteration 2 D + 2 transport calls (D distributed levels) instead of 2 D + 3; LFA_DIST_TWO_REDUCTIONS=1 keeps the textbook form.
-	const bool cg1 = fused && dist && is_mg(s) && !small_ran && !s->knobs.dist_two_reductions;
+	// Per iteration 2 D + 2 transport calls (D distributed levels) instead of 2 D + 3.
+	const bool cg1 = fused && dist && is_mg(s);
 	if (cg1) {
 		const int nr = s->dist->nranks;
 		double *alpha_io = s->dist_red + LFA_DIST_ALPHA_OFF;
@@ -1991,12 +1973,8 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 		// a fault). Whatever the iterations after it computed is void. This handle stops using the kernels that wait and the solve
 		// is repeated from the right-hand side on the launch-per-phase path - once: that path waits for nothing.
 		if (s->co_disabled) return lfa_fail(s, LFA_E_HIP, "a device-side wait of the pressure solve was given up twice");
-		// (first the cheaper retreat: the one-XCD mode of k_mg_coarse rests on an undocumented placement - without it the kernel
-		// makes no assumption about where its workgroups run)
-		s->stat_co_reason = (uint64_t)(unsigned)hstate[18];  // (0x100: a wait ran out, 0x200: a flag from another XCD; | waiter's XCC id | flag's << 4)
-		if (s->co_last_xcd && !s->co_xcd_disabled) s->co_xcd_disabled = true;
-		else s->co_disabled = true;
-		s->co_last_xcd = false;
+		s->stat_co_reason = (uint64_t)(unsigned)hstate[18];  // (0x100: a wait ran out | the waiter's XCC id; 0 on a rank that retreats with a peer)
+		s->co_disabled = true;
 		++s->stat_co_aborts;
 		s->system_valid = false;
 		s->warm_started = false;
@@ -2037,7 +2015,7 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 extern "C" int lfa_get_solver_stats(lfa_sim *s, uint64_t stats[LFA_NUM_SOLVER_STATS]) {
 	if (!s || !stats) return LFA_E_INVALID;
 	const uint64_t v[LFA_NUM_SOLVER_STATS] = {s->stat_launches_iter, s->stat_transport_iter, s->stat_mg_levels, s->stat_mg_first_co,
-	                                          s->last_iters, s->stat_transport_solve, s->stat_whole_solve, s->stat_co_aborts};
+	                                          s->last_iters, s->stat_transport_solve, 0, s->stat_co_aborts};
 	for (int i = 0; i < LFA_NUM_SOLVER_STATS; ++i) stats[i] = v[i];
 	return LFA_OK;
 }

@@ -188,6 +188,28 @@ def test_c3_workload_against_live_oracle_and_full_size_properties():
     s.close()
 
 
+@pytest.mark.gpu
+def test_c3_full_size_moving_dam_against_live_oracle():
+    """BASELINE configs[2] at FULL size on a real dam-break state: 256^3, 16 777 216 particles, FLIP 0.95. Six whole time steps on
+    the device set the dam in motion (velocities of ~150 cells / s, the column has dropped a dozen cells); that state - downloaded
+    as the hosts' 152-byte records - goes to the oracle (fp64, MIC(0)-PCG to 1e-6 like src/pressure_solver.cpp:19-71: ~2.1 M
+    unknowns, about a minute on the box's host) and to a fresh device handle in the default configuration (fp32 state, multigrid
+    PCG). One pass of the hot path each: fluid cells and cell types bit-exact, pressure <= 1e-4 of its maximum and pointwise <=
+    1e-3, face and particle velocities <= 1e-4 - the bars of the small scenes, at the size the target is quoted on."""
+    cfg = scenes.CONFIGS["C3"]
+    s = lfa.Sim(cfg["size"], method=cfg["method"], blending=cfg["blending"])
+    s.seed_block(*cfg["block"])
+    for _ in range(6):
+        res, it, rc = s.time_step(min(3.0 * s.cfl(), 0.033))
+        assert rc == 0
+    dt = min(3.0 * s.cfl(), 0.033)
+    parts = s.download_particles(into=np.zeros(s.num_particles, dtype=lfa.PARTICLE_DTYPE), write_positions=True)
+    s.close()
+    assert len(parts) == 16777216 and np.abs(parts["vel"]).max() > 50.0
+    its = _compare_hot_steps(cfg, parts, None, 1, False, dt=dt)
+    assert its[0][0] <= 30 and its[0][1] > its[0][0], its  # (multigrid on the device, MIC(0) in the reference)
+
+
 def _obstacle(size, block):
     """bench.py --obstacle's sphere (dry part of the tank, in the path of the collapsing column), voxelized on the device."""
     (blo, bhi) = block

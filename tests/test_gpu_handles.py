@@ -99,55 +99,3 @@ def test_a_wait_that_is_never_answered_ends_in_a_repeated_solve_not_in_a_hang(dt
     assert np.array_equal(res[0][1], res[1][1])
 
 
-@pytest.mark.parametrize("dtype", [lfa.PCG_F32, lfa.PCG_F64])
-def test_coarse_levels_on_one_xcd_give_the_all_xcd_result_or_retreat(dtype, monkeypatch):
-    """LFA_MG_XCD=1 (opt-in): k_mg_coarse with its workgroups meant to sit on ONE XCD (every eighth of 8 W workgroups works,
-    workgroup-scope accesses meet in that XCD's L2). Where the dispatcher really places them so, the result is the all-XCD
-    launch's bit for bit; where it does not (the boxes of round 4: a consumer never sees its producer's flag), the wait runs into
-    its ceiling, the mode is retired for the handle and the solve repeated on every XCD - the same bits either way, at most one
-    given-up wait, never a hang."""
-    size, block = (96, 64, 80), ((0, 0, 0), (60, 40, 50))
-    res = []
-    for xcd in (True, False):
-        if xcd:
-            monkeypatch.setenv("LFA_MG_XCD", "1")
-        else:
-            monkeypatch.delenv("LFA_MG_XCD", raising=False)
-        s = lfa.Sim(size, precond=lfa.PRECOND_MULTIGRID, pcg_dtype=dtype)
-        s.seed_block(*block)
-        its = []
-        for _ in range(4):
-            r, it, rc = s.step_hot(util.DT)
-            assert rc == 0
-            its.append(it)
-        st = s.solver_stats()
-        assert st["device_waits_given_up"] <= (1 if xcd else 0), st
-        res.append((its, s.pressure().copy()))
-        s.close()
-    assert res[0][0] == res[1][0]
-    assert np.array_equal(res[0][1], res[1][1])
-
-
-def test_a_fault_in_the_one_xcd_mode_falls_back_twice_and_still_solves(monkeypatch):
-    """The retreats in order: a wait given up in the one-XCD mode retires that mode (the solve is repeated with the kernel on every
-    XCD), a second one retires the kernels that wait altogether (repeated launch-per-phase) - the injected fault persists through
-    both, and the result is the launch-per-phase one."""
-    size, block = (96, 64, 80), ((0, 0, 0), (60, 40, 50))
-    monkeypatch.setenv("LFA_MG_CO_FAULT", "1")
-    monkeypatch.setenv("LFA_MG_XCD", "1")
-    s = lfa.Sim(size, precond=lfa.PRECOND_MULTIGRID)
-    s.seed_block(*block)
-    r, it, rc = s.step_hot(util.DT)
-    assert rc == 0
-    st = s.solver_stats()
-    p = s.pressure().copy()
-    s.close()
-    assert st["device_waits_given_up"] in (1, 2), st  # (2 when the system was small enough for the one-XCD mode)
-    monkeypatch.delenv("LFA_MG_CO_FAULT", raising=False)
-    monkeypatch.delenv("LFA_MG_XCD", raising=False)
-    monkeypatch.setenv("LFA_MG_NO_PERSIST", "1")
-    t = lfa.Sim(size, precond=lfa.PRECOND_MULTIGRID)
-    t.seed_block(*block)
-    r2, it2, rc2 = t.step_hot(util.DT)
-    assert rc2 == 0 and it2 == it and np.array_equal(t.pressure(), p)
-    t.close()

@@ -174,17 +174,15 @@ def test_device_time_step_matches_reference(precond, dtype):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dense", ["all", "half", "second-pass", "all-no-second-pass"])
-def test_position_correction_fallback_for_crowded_tiles(dense, monkeypatch):
+@pytest.mark.parametrize("dense", ["all", "half", "second-pass"])
+def test_position_correction_fallback_for_crowded_tiles(dense):
     """Half tiles whose 10 x 10 x 6-cell neighbourhood holds more particles than the LDS of the tiled kernel (5632) are redone by
     the same kernel with a CU's whole LDS to itself (12288), and what exceeds that by the global-gather kernel. 32 particles per
     cell ("all": every half tile), 48 in the lower part of the block only ("half": all three kernels run in one call and the
     later ones have to pick their particles by their keys from BEFORE the first one moved the others in place), or 16
     ("second-pass": nothing is left for the gather kernel). Checked against the oracle's _correct_positions + collisions."""
-    if dense == "all-no-second-pass":
-        monkeypatch.setenv("LFA_CORR_NO_BIG", "1")
     size, lo, hi = (24, 24, 24), (2, 2, 2), (18, 16, 18)
-    layers = {"all": 4, "all-no-second-pass": 4, "half": 1, "second-pass": 2}[dense]
+    layers = {"all": 4, "half": 1, "second-pass": 2}[dense]
     parts = [util.scenes.seed_block(lo, hi, seed=util.scenes.SEED + 7 * k) for k in range(layers)]
     if dense == "half":
         parts += [util.scenes.seed_block(lo, (hi[0], 8, hi[2]), seed=util.scenes.SEED + 7 * k) for k in range(1, 6)]
@@ -205,8 +203,6 @@ def test_position_correction_fallback_for_crowded_tiles(dense, monkeypatch):
     assert (flagged, total) == s.correction_stats()
     if dense == "second-pass":
         assert flagged == 0 and 0 < second < total
-    elif dense == "all-no-second-pass":
-        assert 0 < flagged < total and second == 0
     else:  # every kernel ran (also in "all": the sparsely filled half tiles at the block's edge fit the first pass)
         assert 0 < flagged < second < total
     out = s.download_particles(into=parts.copy(), write_positions=True)
@@ -394,37 +390,6 @@ def test_deferred_binning_never_loses_velocities(seq, method):
     s.close()
     for f in ("vel", "cx", "cy", "cz"):
         assert np.array_equal(out[f].astype(np.float32), parts[f].astype(np.float32)), (seq, f)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("method", [lfa.APIC, lfa.FLIP_BLEND, lfa.PIC])
-def test_deferred_binning_is_bitwise_the_full_scatter(method, monkeypatch):
-    """Five hot steps with the deferred binning (key, t, id move; v, C through the source index) and
-    with LFA_FULL_SCATTER=1 (whole records move): the P2G sums are order-independent fixed point and everything else is
-    per particle, so velocities, C and pressures agree bit for bit."""
-    c, parts, solid = fullstep_inputs()
-    outs = []
-    for full in (False, True):
-        if full:
-            monkeypatch.setenv("LFA_FULL_SCATTER", "1")
-        else:
-            monkeypatch.delenv("LFA_FULL_SCATTER", raising=False)
-        s = lfa.Sim(c["size"], method=method, blending=0.9, precond=lfa.PRECOND_MIC0_TILED, pcg_dtype=lfa.PCG_F64)
-        s.set_solid_cells(solid)
-        s.upload_particles(parts)
-        its = []
-        for _ in range(5):
-            res, it, rc = s.step_hot(c["dt"])
-            assert rc == 0
-            its.append(it)
-        p = s.pressure().copy()
-        outs.append((s.download_particles(into=parts.copy()), p, its))
-        s.close()
-    (a, pa, ia), (b, pb, ib) = outs
-    assert ia == ib
-    assert np.array_equal(pa, pb)
-    for f in ("vel", "cx", "cy", "cz"):
-        assert np.array_equal(a[f], b[f]), f
 
 
 @pytest.mark.gpu
