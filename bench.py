@@ -474,12 +474,13 @@ def main():
                                        "how": "lfa_bench_stream: float4 grid-stride kernels over 1 GiB, mean of 10 launches, best of 5 copy "
                                               "variants (" + getattr(sim, "stream_variant", "") + "); MI355X_MICROARCH.md records 6.29 TB/s for a float4 copy"}
         # ---- in-step kernels / kernel groups: MEDIAN device time inside the timed steps (HIP events on the handle's stream)
-        # algorithmic bytes: SURVEY 8(d). P2G scatter 60 Np (APIC) / 24 Np; PCG iteration 91 n (92.5 n for the V-cycle's own
+        # algorithmic bytes: SURVEY 8(d). P2G scatter 60 Np (APIC) / 24 Np; PCG iteration 91 n (the per-kernel split below adds up to 92.5 n for the V-cycle's own
         # passes); G2P 60 Np + 12 Nc (APIC), 36 Np + 24 Nc (FLIP), 24 Np + 12 Nc (PIC); binning: the bytes the deferred scheme
         # moves (key, t, id both ways + source index = 44 Np, + 2 x 36 Np for PIC/FLIP whose C travels with the particle);
         # position correction: positions in and out, 24 Np (the reference's OMP loop reads and writes vec3d positions,
         # src/simulation.cpp:562-610; pair interactions are arithmetic, not traffic)
-        pcg_iter_bytes = (sum(PCG_BYTES.values()) if args.precond == "multigrid" else 91) * n_unknowns * (2 if args.pcg_dtype == "f64" else 1)
+        # (the iteration is priced at SURVEY 8(d)'s 91 n whatever the preconditioner: what the V-cycle's own passes add is overhead)
+        pcg_iter_bytes = 91 * n_unknowns * (2 if args.pcg_dtype == "f64" else 1)
         in_step = {
             "p2g_scatter_kernel": ((60 if apic else 24) * npart, 1.0),
             "pcg_iteration_mean": (pcg_iter_bytes, it_per_step),
@@ -497,12 +498,12 @@ def main():
         out["in_step_kernels"] = kern
         # `traffic`: HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs of this same command,
         # tools/make_profiles.sh). It is NOT measured in this run: `traffic_source` names the committed file it is read from.
-        pmc = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_c4_pmc_traffic.json") for r in (4, 3, 2)) if os.path.exists(q)),
-                   os.path.join(ROOT, "profiles", "r04_c4_pmc_traffic.json"))
+        pmc = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_{cfg_name.lower()}_pmc_traffic.json") for r in (5, 4, 3, 2))
+                    if os.path.exists(q)), os.path.join(ROOT, "profiles", f"r05_{cfg_name.lower()}_pmc_traffic.json"))
         pmc_names = {"p2g_scatter_kernel": "p2g_scatter", "correct_tiled_kernel": "correct_tiled", "g2p": "g2p",
                      "advect_collide": "advect_collide"}
         per_launch = {}
-        if cfg_name == "C4" and args.pcg_dtype == "f32" and os.path.exists(pmc):
+        if args.pcg_dtype == "f32" and args.p2g == "binned" and os.path.exists(pmc):  # (C4 and C3 have committed PMC passes)
             per_launch = json.load(open(pmc))["hbm_bytes_per_launch"]
 
         def roofline_of(k, note):
@@ -544,7 +545,7 @@ def main():
                               "GBps": kern["pcg_iteration_mean"]["GBps"], "frac": kern["pcg_iteration_mean"]["frac"]},
             "p2g_plus_pcg": {"ms": p2g_pcg_ms, "algorithmic_bytes": int(p2g_pcg_b), "GBps": p2g_pcg_b / p2g_pcg_ms * 1e-6,
                              "frac": p2g_pcg_b / p2g_pcg_ms * 1e-6 / HBM_PEAK_GBS,
-                             "note": "the north star's target group (>= 0.40): in-step medians, 60 Np + 14 Nc + 91(92.5) n x iterations"},
+                             "note": "the north star's target group (>= 0.40): in-step medians, 60 Np + 14 Nc + 91 n x iterations (SURVEY 8d)"},
         }
         # ---- isolated kernels, back to back on the state of the last step (lfa_bench_kernel): the PCG loop's launches
         kernels = {}
