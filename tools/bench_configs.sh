@@ -1,7 +1,7 @@
 #!/bin/bash
 # The other BASELINE configurations through the same bench command (C4 is the default line): JSON lines under gpurun_out/.
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out
-TAG=${1:-r04}
+TAG=${1:-r05}
 python3 bench.py --config C2 --steps 30 --warmup 20 --no-cpu-baseline > gpurun_out/${TAG}_c2_bench.json 2>/tmp/c2.err || tail -3 /tmp/c2.err
 python3 bench.py --config C3 --steps 30 --warmup 20 --no-cpu-baseline > gpurun_out/${TAG}_c3_bench.json 2>/tmp/c3.err || tail -3 /tmp/c3.err
 python3 bench.py --config C5 --steps 20 --warmup 20 --no-cpu-baseline --obstacle --mesh > gpurun_out/${TAG}_c5_bench.json 2>/tmp/c5.err || tail -3 /tmp/c5.err
@@ -11,9 +11,9 @@ python3 bench.py --config C2 --p2g atomic --steps 30 --warmup 20 --no-cpu-baseli
 python3 bench.py --p2g atomic --steps 20 --warmup 20 --no-cpu-baseline --no-mic0-record --no-hot-path > gpurun_out/${TAG}_c4_p2g_atomic_bench.json 2>/tmp/c4a.err || tail -3 /tmp/c4a.err
 # late in the run: the sheet has spread over many partly filled tiles
 python3 bench.py --config C3 --late 550 --late-steps 20 --steps 30 --warmup 20 --no-cpu-baseline --no-hot-path --no-mic0-record --no-kernel-timing > gpurun_out/${TAG}_c3_late_bench.json 2>/tmp/c3l.err || tail -3 /tmp/c3l.err
-python3 - <<'P'
-import json, glob
-for f in sorted(glob.glob("gpurun_out/r04_c*_bench.json")):
+TAG=$TAG python3 - <<'P'
+import json, glob, os
+for f in sorted(glob.glob("gpurun_out/" + os.environ["TAG"] + "_c*_bench.json")):
     try:
         b = json.load(open(f))
     except Exception as e:
