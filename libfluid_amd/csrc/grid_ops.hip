@@ -485,7 +485,9 @@ int lfa_build_rhs(lfa_sim *s, double dt) {
 	hipLaunchKernelGGL(k_abits, dim3(grid_blocks(s->n_ptiles)), dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, gv,
 	                   s->abits);
 	LFA_LAUNCH_CHECK(s);
-	const int G = pcg_grid(s->n_ptiles);
+	// (once per solve and bandwidth bound: as many workgroups as the partial-sum array holds - the cap of the iteration's kernels,
+	// lfa_pcg_grid_cap = 768, is tuned for their latency chains and costs this kernel 83 us at C4: 94 -> 177)
+	const int G = pcg_grid_uncapped(s->n_ptiles);
 	const float inv_h = (float)(1.0 / s->prm.cell_size);
 	// warm start: only for the solver's own preconditioners (the exact MIC(0) schedule is the reference-parity path and keeps
 	// the reference's zero guess, src/pressure_solver.cpp:36), only from the pressure of the immediately preceding solve

@@ -19,6 +19,13 @@ static inline int pcg_grid(int n_ptiles) {
 	return g < lfa_pcg_grid_cap ? g : lfa_pcg_grid_cap;
 }
 
+/// The same without the tuning cap: up to PCG_MAX_GRID workgroups (kernels that run once per solve and stream).
+static inline int pcg_grid_uncapped(int n_ptiles) {
+	int g = (n_ptiles + PCG_WAVES - 1) / PCG_WAVES;
+	if (g < 1) g = 1;
+	return g < PCG_MAX_GRID ? g : PCG_MAX_GRID;
+}
+
 int lfa_build_rhs(lfa_sim *s, double dt);
 int lfa_p2g_run(lfa_sim *s, bool fuse_gravity, double dt);
 int lfa_dist_refresh_grid(lfa_sim *s, bool with_topology);

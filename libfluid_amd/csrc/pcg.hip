@@ -1730,12 +1730,12 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 		double tot = 0.0;
 		if (dist) {
 			if (!s->n_ptiles) LFA_HIP(s, hipMemsetAsync(P + PART_B2, 0, 8, s->stream));
-			LFA_TRY(lfa_dist_allreduce(s, P + PART_B2, G, 0, false));
+			LFA_TRY(lfa_dist_allreduce(s, P + PART_B2, pcg_grid_uncapped(s->n_ptiles), 0, false));
 			LFA_HIP(s, hipMemcpyAsync(&tot, s->dist_red, 8, hipMemcpyDeviceToHost, s->stream));
 			LFA_HIP(s, hipStreamSynchronize(s->stream));
 		} else {
-			std::vector<double> hb(G);
-			LFA_HIP(s, hipMemcpyAsync(hb.data(), P + PART_B2, (size_t)G * 8, hipMemcpyDeviceToHost, s->stream));
+			std::vector<double> hb(pcg_grid_uncapped(s->n_ptiles));
+			LFA_HIP(s, hipMemcpyAsync(hb.data(), P + PART_B2, (size_t)pcg_grid_uncapped(s->n_ptiles) * 8, hipMemcpyDeviceToHost, s->stream));
 			LFA_HIP(s, hipStreamSynchronize(s->stream));
 			for (double x : hb) tot += x;
 		}
@@ -1750,7 +1750,7 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 			return LFA_OK;
 		}
 	} else {
-		hipLaunchKernelGGL(k_check_rhs, dim3(1), dim3(256), 0, s->stream, (const double *)(P + PART_B2), G, s->pcg_state);
+		hipLaunchKernelGGL(k_check_rhs, dim3(1), dim3(256), 0, s->stream, (const double *)(P + PART_B2), pcg_grid_uncapped(s->n_ptiles), s->pcg_state);
 		LFA_LAUNCH_CHECK(s);
 	}
 	if (s->warm_started) {

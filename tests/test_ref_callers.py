@@ -102,6 +102,10 @@ def test_fixture_is_what_the_live_reference_computes(tmp_path):
             if name != "testbed_scene4" and k.endswith((".pos", ".points")) and len(rec[k]):
                 order[k.split(".")[0]] = cu.match_particles(rec[k], want[k], 1e-9, strays=0.002)
         for k, v in rec.items():
+            if k == "obstacle_cells":
+                # fluid::obstacle reads past the end of its voxel rows (test_voxelizer_node_outputs): what it lists depends on the
+                # heap - under the sanitizer run of `make asan` the same binary returns 1 728 instead of 1 557 cells for the sphere
+                continue
             w = np.asarray(want[k], dtype=np.float64)
             v = np.asarray(v, dtype=np.float64)
             assert v.shape == w.shape, (name, k)
