@@ -66,6 +66,10 @@ struct lfa_mg_level {
 	int lo_layer = 0, hi_layer = 0;  // owned tile layers of this level (slabs: distributed levels only)
 	uint32_t *flag = nullptr, *prev_flag = nullptr;  // device, per tile of the level: active now / at the last set-up (single domain)
 	unsigned *ready = nullptr;  // device, 3 x tiles of the level: ready flags of k_mg_coarse (levels >= 1; never cleared: tags are unique)
+	// device, 3 x whole padded grid of 8-byte words {launch tag, fp32 value}: what the workgroups of ONE k_mg_coarse launch hand to
+	// each other - the pre-smoothed iterate, the right-hand side (children's shares), the result (round 5: the tagged hand-off;
+	// allocated when the level first runs inside the launch, fp32 vectors only)
+	unsigned long long *xq = nullptr;
 };
 struct lfa_mg {
 	int n_levels = 0;
@@ -1128,6 +1132,8 @@ template <typename real> struct MgCo {
 	unsigned *ready[MG_MAX_LEVELS];  // per level 3 x (tiles of the level): tile has stored [0] its pre-smoothed iterate [1] its share of the next level's right-hand side [2] its result
 	int first, last, nsw, inner;
 	unsigned tag;
+	unsigned long long *xq[MG_MAX_LEVELS];  // TAGGED hand-off: per level [x | b | y], each the level's padded grid of {tag, value} words
+	size_t ncp[MG_MAX_LEVELS];
 	int *abort;                  // pcg_state + 2: raised by a workgroup whose wait has passed CO_TIMEOUT_TICKS; every waiter checks it
 	int fault;                   // LFA_MG_CO_FAULT=n (tests): workgroup n - 1 never raises its first flag
 };
@@ -1307,6 +1313,121 @@ template <typename real, typename MEM> __device__ inline void co_load_ring(const
 	__syncthreads();
 }
 
+// ---- the tagged hand-off (round 5). A value travels as ONE 8-byte word {launch tag, fp32 bits}, stored and loaded with agent-scope
+// relaxed 64-bit accesses (single-copy atomic): the consumer polls the very words it needs until they carry this launch's tag.
+// Against "store the data, wait for the acknowledgement, barrier, store a flag / poll the flag, barrier, load the data" that is one
+// trip through the memory side instead of three: tools/handoff_probe.hip measures 1.1-1.35 us per hand-off against 1.7-2.6
+// (16-384 pairs of workgroups), and a V-cycle's coarse levels are a chain of 10-13 hand-offs. Every thread polls only words of its
+// own (no two workgroups spin on one address: the "storm" of co_backoff's comment does not arise); waits are bounded like co_wait's.
+// fp32 vectors only (a double leaves no room for the tag); fp64 solves keep the flags.
+__device__ inline unsigned long long co_tagged(unsigned tag, float v) { return ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v); }
+__device__ inline void co_put(unsigned long long *p, unsigned tag, float v) {
+	__hip_atomic_store(p, co_tagged(tag, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void co_put(unsigned long long *, unsigned, double) {}  // (never called: TAGGED is fp32 only)
+/// Polls N words (p[k] == nullptr: none, the value stays 0) until each carries `tag`; all N loads of a round are in flight
+/// together. A wait that passes the ceiling raises the abort word and returns what it has (see co_wait).
+template <int N> __device__ inline void co_get(const unsigned long long *const (&p)[N], unsigned tag, int *abort_word, float (&v)[N]) {
+	unsigned long long w[N];
+	bool all = true;
+#pragma unroll
+	for (int k = 0; k < N; ++k) {
+		w[k] = p[k] ? __hip_atomic_load(p[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32);
+		all &= (unsigned)(w[k] >> 32) == tag;
+	}
+	if (!all) {
+		int tries = 0;
+		unsigned long long t0 = 0ull;
+		do {
+			co_backoff(tries);
+			if (co_poll_expired(tries, t0, abort_word)) {
+				if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) abort_word[16] = 0x400 | (int)co_xcc_id();
+				__hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				break;
+			}
+			all = true;
+#pragma unroll
+			for (int k = 0; k < N; ++k) {
+				if ((unsigned)(w[k] >> 32) != tag) w[k] = __hip_atomic_load(p[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				all &= (unsigned)(w[k] >> 32) == tag;
+			}
+		} while (!all);
+	}
+#pragma unroll
+	for (int k = 0; k < N; ++k) v[k] = __uint_as_float((unsigned)w[k]);
+}
+/// co_restrict_store with the parent's share going out as tagged words.
+template <typename real>
+__device__ inline void co_restrict_put(const CoThread &T, const real *R, const GridDims &g, const GridDims &gc, int tile, unsigned long long *bq,
+                                       unsigned tag) {
+	if (T.t < 64) {
+		const int X = T.t & 3, Y = (T.t >> 2) & 3, Z = T.t >> 4;
+		auto pair = [&](int x, int y) { real p = R[x + 8 * y + 64 * (2 * Z)]; p += R[x + 8 * y + 64 * (2 * Z + 1)]; return p; };
+		real v = pair(2 * X, 2 * Y);
+		v += pair(2 * X + 1, 2 * Y);
+		real w = pair(2 * X, 2 * Y + 1);
+		w += pair(2 * X + 1, 2 * Y + 1);
+		v += w;
+		int tx, ty, tz;
+		tile_coords(g, tile, tx, ty, tz);
+		const int ptile = (tx >> 1) + gc.ntx * ((ty >> 1) + gc.nty * (tz >> 1));
+		co_put(bq + (size_t)ptile * 512 + ((tz & 1) * 4 + Z) * 64 + ((ty & 1) * 4 + Y) * 8 + (tx & 1) * 4 + X, tag, (real)0.5 * v);
+	}
+}
+/// The thread's two right-hand-side values of a tile whose children hand their shares over as tagged words: a cell of an
+/// inactive child (bit of `child_mask` clear) is zero and nobody writes it.
+template <typename real>
+__device__ inline void co_get_rhs(const CoThread &T, const unsigned long long *bq, size_t base, int child_mask, unsigned tag, int *abort_word,
+                                  real &b0, real &b1) {
+	const int child = (T.qx >> 2) + 2 * (T.qy >> 2) + 4 * (T.qj >> 1);  // (cells z = 2 j and 2 j + 1 lie in the same child)
+	const bool on = (child_mask >> child) & 1;
+	const unsigned long long *const p[2] = {on ? bq + base + T.c0 : nullptr, on ? bq + base + T.c1 : nullptr};
+	float v[2];
+	co_get<2>(p, tag, abort_word, v);
+	b0 = (real)v[0];
+	b1 = (real)v[1];
+}
+/// co_load_ring on tagged words.
+template <typename real> __device__ inline void co_get_ring(const CoThread &T, real *H, const int *nb, const unsigned long long *xq, unsigned tag,
+                                                               int *abort_word) {
+	int f0, f1, h0, h1, n0, n1, dx, dy, dz;
+	const int r1 = T.t + 256;
+	cp_ring(T.t, f0, h0, n0, dx, dy, dz);
+	cp_ring(r1 < 384 ? r1 : 0, f1, h1, n1, dx, dy, dz);
+	const bool on0 = nb[f0] >= 0, on1 = r1 < 384 && nb[f1] >= 0;
+	const unsigned long long *const p[2] = {on0 ? xq + (size_t)nb[f0] * 512 + n0 : nullptr, on1 ? xq + (size_t)nb[f1] * 512 + n1 : nullptr};
+	float v[2];
+	co_get<2>(p, tag, abort_word, v);
+	if (on0) H[h0] = (real)v[0];
+	if (on1) H[h1] = (real)v[1];
+	__syncthreads();
+}
+/// co_add_correction on tagged words (the parents' results).
+template <typename real>
+__device__ inline void co_get_correction(const CoThread &T, real *H, uint32_t a0, uint32_t a1, const uint8_t *rab, const int *nb, const GridDims &g,
+                                         const GridDims &gc, int tile, const unsigned long long *yq, unsigned tag, int *abort_word) {
+	int tx, ty, tz;
+	tile_coords(g, tile, tx, ty, tz);
+	int f0, f1, h0, h1, n0, n1, dx0, dy0, dz0, dx1, dy1, dz1;
+	const int r1 = T.t + 256;
+	cp_ring(T.t, f0, h0, n0, dx0, dy0, dz0);
+	cp_ring(r1 < 384 ? r1 : 0, f1, h1, n1, dx1, dy1, dz1);
+	const bool on0 = nb[f0] >= 0 && (rab[T.t] & AB_UNKNOWN), on1 = r1 < 384 && nb[f1] >= 0 && (rab[r1 < 384 ? r1 : 0] & AB_UNKNOWN);
+	// cells z = 2 j and 2 j + 1 of a column share their parent
+	const unsigned long long *const p[3] = {
+		yq + blocked_index(gc, (tx * 8 + T.qx) >> 1, (ty * 8 + T.qy) >> 1, (tz * 8 + 2 * T.qj) >> 1),
+		on0 ? yq + blocked_index(gc, (tx * 8 + dx0) >> 1, (ty * 8 + dy0) >> 1, (tz * 8 + dz0) >> 1) : nullptr,
+		on1 ? yq + blocked_index(gc, (tx * 8 + dx1) >> 1, (ty * 8 + dy1) >> 1, (tz * 8 + dz1) >> 1) : nullptr};
+	float v[3];
+	co_get<3>(p, tag, abort_word, v);
+	const real corr = (real)v[0];
+	if (a0 & AB_UNKNOWN) H[T.h0] = H[T.h0] + corr;
+	if (a1 & AB_UNKNOWN) H[T.h1] = H[T.h1] + corr;
+	if (on0) H[h0] = H[h0] + (real)v[1];
+	if (on1) H[h1] = H[h1] + (real)v[2];
+	__syncthreads();
+}
+
 /// Static data of levels P.first .. lmax into st[] (LDS): neighbour-table rows, A bytes of the own tile and of its ring; the
 /// halo blocks are cleared. Two dependent round trips. `state` (may be null): read together with the first batch; returns false
 /// (uniformly) when the solve has converged. `prefetch_b`: the first level's right-hand side was written by an earlier kernel
@@ -1372,10 +1493,15 @@ __device__ inline bool co_static(const MgCo<real> &P, const CoThread &T, CoLevel
 /// `b_prefetched`: the first level's right-hand side is already in st[0].b (k_mg_coarse); otherwise it is waited for like
 /// every other level's (its children sit on level P.first - 1, whose flags P.ready[P.first - 1] must be valid).
 /// `post_first_y`: raise the result flag of the first level too (somebody inside this launch consumes it).
-template <typename real, typename MEM>
+/// TAGGED: what the workgroups hand to each other travels as {tag, value} words (P.xq) instead of through the level arrays + ready
+/// flags - see co_put / co_get; the first level's right-hand side (in) and result (out) stay plain: other kernels own them.
+template <typename real, typename MEM, bool TAGGED>
 __device__ inline bool co_cycle(const MgCo<real> &P, const CoThread &T, CoLevel<real> *st, real *R, int *dep, unsigned tag, int lmax,
                                 bool b_prefetched, bool post_first_y) {
 	const int t = T.t, c0 = T.c0, c1 = T.c1, h0 = T.h0, h1 = T.h1;
+	auto xq = [&](int l) { return P.xq[l]; };
+	auto bq = [&](int l) { return P.xq[l] + P.ncp[l]; };
+	auto yq = [&](int l) { return P.xq[l] + 2 * P.ncp[l]; };
 	// ---- down
 	for (int l = P.first; l < P.last && l <= lmax; ++l) {
 		CoLevel<real> &S = st[l - P.first];
@@ -1384,13 +1510,15 @@ __device__ inline bool co_cycle(const MgCo<real> &P, const CoThread &T, CoLevel<
 		const size_t base = (size_t)tile * 512;
 		const uint32_t a0 = S.ab[c0], a1 = S.ab[c1];
 		const bool waited = l > P.first || !b_prefetched;
-		if (waited) {  // the right-hand side is the restricted residual of the child tiles (level l - 1)
+		real b0, b1;
+		if (waited && TAGGED) {  // the right-hand side is the restricted residual of the child tiles (level l - 1)
+			co_get_rhs<real>(T, bq(l), base, S.nb[7], tag, P.abort, b0, b1);
+			S.b[c0] = b0;
+			S.b[c1] = b1;
+		} else if (waited) {
 			const GridDims &gf = P.lv[l - 1].g;
 			co_child_deps(T, dep, L.g, gf, tile, S.nb[7]);
 			if (!co_wait<MEM>(P.ready[l - 1] + gf.nt, dep, 8, tag, P.abort)) return false;
-		}
-		real b0, b1;
-		if (waited) {
 			b0 = MEM::ld(L.b + base + c0);
 			b1 = MEM::ld(L.b + base + c1);
 			S.b[c0] = b0;
@@ -1404,19 +1532,33 @@ __device__ inline bool co_cycle(const MgCo<real> &P, const CoThread &T, CoLevel<
 			co_half_sweep<real>(T, S.H, a0, a1, b0, b1, 0);
 			co_half_sweep<real>(T, S.H, a0, a1, b0, b1, 1);
 		}
-		MEM::st(L.x + base + c0, S.H[h0]);
-		MEM::st(L.x + base + c1, S.H[h1]);
-		if (!(P.fault && l == P.first && T.wg == P.fault - 1)) co_post<MEM>(P.ready[l], tile, tag);  // (fault injection: see MgCo::fault)
-		// residual: the ring holds the neighbours' pre-smoothed values
-		if (t < 6) dep[t] = S.nb[t];
-		__syncthreads();
-		if (!co_wait<MEM>(P.ready[l], dep, 6, tag, P.abort)) return false;
-		co_load_ring<real, MEM>(T, S.H, S.nb, L.x);
+		const bool faulty = P.fault && l == P.first && T.wg == P.fault - 1;  // (fault injection: see MgCo::fault)
+		if (TAGGED) {
+			if (!faulty) {
+				co_put(xq(l) + base + c0, tag, S.H[h0]);
+				co_put(xq(l) + base + c1, tag, S.H[h1]);
+			}
+			// residual: the ring holds the neighbours' pre-smoothed values
+			co_get_ring<real>(T, S.H, S.nb, xq(l), tag, P.abort);
+		} else {
+			MEM::st(L.x + base + c0, S.H[h0]);
+			MEM::st(L.x + base + c1, S.H[h1]);
+			if (!faulty) co_post<MEM>(P.ready[l], tile, tag);
+			if (t < 6) dep[t] = S.nb[t];
+			__syncthreads();
+			if (!co_wait<MEM>(P.ready[l], dep, 6, tag, P.abort)) return false;
+			co_load_ring<real, MEM>(T, S.H, S.nb, L.x);
+		}
 		R[c0] = co_residual_cell<real>(S.H, a0, b0, h0);
 		R[c1] = co_residual_cell<real>(S.H, a1, b1, h1);
 		__syncthreads();
-		co_restrict_store<real, MEM>(T, R, L.g, P.lv[l + 1].g, tile, P.lv[l + 1].b);
-		co_post<MEM>(P.ready[l] + nt, tile, tag);
+		if (TAGGED) {
+			co_restrict_put<real>(T, R, L.g, P.lv[l + 1].g, tile, bq(l + 1), tag);
+			__syncthreads();  // (R is rewritten by the next level)
+		} else {
+			co_restrict_store<real, MEM>(T, R, L.g, P.lv[l + 1].g, tile, P.lv[l + 1].b);
+			co_post<MEM>(P.ready[l] + nt, tile, tag);
+		}
 	}
 	// ---- coarsest level (one tile, workgroup 0): nsw sweeps red->black, nsw black->red from zero
 	if (T.wg == 0) {
@@ -1427,13 +1569,13 @@ __device__ inline bool co_cycle(const MgCo<real> &P, const CoThread &T, CoLevel<
 		const size_t base = (size_t)tile * 512;
 		const uint32_t a0 = S.ab[c0], a1 = S.ab[c1];
 		const bool waited = l > P.first || !b_prefetched;
-		if (waited) {
+		real b0, b1;
+		if (waited && TAGGED) {
+			co_get_rhs<real>(T, bq(l), base, S.nb[7], tag, P.abort, b0, b1);
+		} else if (waited) {
 			const GridDims &gf = P.lv[l - 1].g;
 			co_child_deps(T, dep, L.g, gf, tile, S.nb[7]);
 			if (!co_wait<MEM>(P.ready[l - 1] + gf.nt, dep, 8, tag, P.abort)) return false;
-		}
-		real b0, b1;
-		if (waited) {
 			b0 = MEM::ld(L.b + base + c0);
 			b1 = MEM::ld(L.b + base + c1);
 		} else {
@@ -1445,9 +1587,14 @@ __device__ inline bool co_cycle(const MgCo<real> &P, const CoThread &T, CoLevel<
 			co_half_sweep<real>(T, S.H, a0, a1, b0, b1, fc);
 			co_half_sweep<real>(T, S.H, a0, a1, b0, b1, fc ^ 1);
 		}
-		MEM::st(L.y + base + c0, S.H[h0]);
-		MEM::st(L.y + base + c1, S.H[h1]);
-		if (l > P.first || post_first_y) co_post<MEM>(P.ready[l] + 2 * L.g.nt, tile, tag);
+		if (TAGGED && l > P.first) {
+			co_put(yq(l) + base + c0, tag, S.H[h0]);
+			co_put(yq(l) + base + c1, tag, S.H[h1]);
+		} else {
+			MEM::st(L.y + base + c0, S.H[h0]);
+			MEM::st(L.y + base + c1, S.H[h1]);
+			if (l > P.first || post_first_y) co_post<MEM>(P.ready[l] + 2 * L.g.nt, tile, tag);
+		}
 	}
 	// ---- up
 	for (int l = (lmax < P.last - 1 ? lmax : P.last - 1); l >= P.first; --l) {
@@ -1459,21 +1606,30 @@ __device__ inline bool co_cycle(const MgCo<real> &P, const CoThread &T, CoLevel<
 		const uint32_t a0 = S.ab[c0], a1 = S.ab[c1];
 		const real b0 = S.b[c0], b1 = S.b[c1];
 		// the corrections come from the parent tile and from the parents of the active neighbour tiles
-		co_parent_deps(T, dep, L.g, gc, S.nb);
-		if (!co_wait<MEM>(P.ready[l + 1] + 2 * gc.nt, dep, 7, tag, P.abort)) return false;
-		co_add_correction<real, MEM>(T, S.H, a0, a1, S.rab, S.nb, L.g, gc, tile, P.lv[l + 1].y);
+		if (TAGGED) {
+			co_get_correction<real>(T, S.H, a0, a1, S.rab, S.nb, L.g, gc, tile, yq(l + 1), tag, P.abort);
+		} else {
+			co_parent_deps(T, dep, L.g, gc, S.nb);
+			if (!co_wait<MEM>(P.ready[l + 1] + 2 * gc.nt, dep, 7, tag, P.abort)) return false;
+			co_add_correction<real, MEM>(T, S.H, a0, a1, S.rab, S.nb, L.g, gc, tile, P.lv[l + 1].y);
+		}
 		for (int it = 0; it < P.inner; ++it) {
 			co_half_sweep<real>(T, S.H, a0, a1, b0, b1, 1);
 			co_half_sweep<real>(T, S.H, a0, a1, b0, b1, 0);
 		}
-		MEM::st(L.y + base + c0, S.H[h0]);
-		MEM::st(L.y + base + c1, S.H[h1]);
-		if (l > P.first || post_first_y) co_post<MEM>(P.ready[l] + 2 * L.g.nt, tile, tag);
+		if (TAGGED && l > P.first) {
+			co_put(yq(l) + base + c0, tag, S.H[h0]);
+			co_put(yq(l) + base + c1, tag, S.H[h1]);
+		} else {
+			MEM::st(L.y + base + c0, S.H[h0]);
+			MEM::st(L.y + base + c1, S.H[h1]);
+			if (l > P.first || post_first_y) co_post<MEM>(P.ready[l] + 2 * L.g.nt, tile, tag);
+		}
 	}
 	return true;
 }
 
-template <typename real, typename MEM>
+template <typename real, typename MEM, bool TAGGED>
 __global__ void __launch_bounds__(256) k_mg_coarse(MgCo<real> P, const int *state) {
 	extern __shared__ unsigned char co_smem[];
 	__shared__ int dep[8];
@@ -1485,7 +1641,7 @@ __global__ void __launch_bounds__(256) k_mg_coarse(MgCo<real> P, const int *stat
 	for (int l = P.first; l <= P.last; ++l)
 		if (T.wg < P.lv[l].n_tiles) lmax = l;
 	if (!co_static<real, MEM>(P, T, st, lmax, state, true)) return;
-	(void)co_cycle<real, MEM>(P, T, st, R, dep, P.tag, lmax, true, false);
+	(void)co_cycle<real, MEM, TAGGED>(P, T, st, R, dep, P.tag, lmax, true, false);
 }
 
 /// The small levels in ONE workgroup of 16 waves: down from level `first` to the single-tile level, the coarsest solve,
@@ -1711,7 +1867,7 @@ void lfa_co_gate_handle(int device, int delta) {
 void lfa_mg_free(lfa_sim *s) {
 	if (!s->mg) return;
 	for (auto &L : s->mg->lv) {
-		void *ptrs[] = {L.tiles, L.nbr, L.ctype, L.abits, L.x, L.b, L.y, L.flag, L.prev_flag, L.ready};
+		void *ptrs[] = {L.tiles, L.nbr, L.ctype, L.abits, L.x, L.b, L.y, L.flag, L.prev_flag, L.ready, L.xq};
 		for (void *p : ptrs)
 			if (p) (void)hipFree(p);
 	}
@@ -1743,7 +1899,7 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 	if (realloc_all) {
 		LFA_HIP(s, hipStreamSynchronize(s->stream));
 		for (auto &L : M.lv) {
-			void *ptrs[] = {L.tiles, L.nbr, L.ctype, L.abits, L.x, L.b, L.y, L.flag, L.prev_flag, L.ready};
+			void *ptrs[] = {L.tiles, L.nbr, L.ctype, L.abits, L.x, L.b, L.y, L.flag, L.prev_flag, L.ready, L.xq};
 			for (void *p : ptrs)
 				if (p) LFA_HIP(s, hipFree(p));
 			L = lfa_mg_level();
@@ -2074,6 +2230,8 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 	// (phases chained by completion counters instead of kernel boundaries); the larger ones keep a launch per phase.
 	// LFA_MG_NO_PERSIST=1, and a handle that has given a device-side wait up (co_disabled): a launch per phase on every level.
 	const bool persist = !s->knobs.mg_no_persist && !s->co_disabled;
+	// the tagged hand-off inside the launch (co_put / co_get): fp32 vectors, and the exchange arrays of the levels inside allocated
+	bool tagged = persist && sizeof(real) == 4 && !s->knobs.mg_no_tagged;
 	if (persist) {
 		// every workgroup of k_mg_coarse must be resident at the same time (they wait for each other): one workgroup per tile of
 		// its first level, LDS per workgroup grows with the number of levels inside
@@ -2081,7 +2239,7 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		struct DevInfo {
 			int n_cu = 0;
 			bool attr_set = false;
-			int per_cu[MG_CO_MAX_LEVELS + 1];  // resident workgroups per CU by the number of levels inside, -1: not asked yet
+			int per_cu[2][MG_CO_MAX_LEVELS + 1];  // resident workgroups per CU by [tagged][levels inside], -1: not asked yet
 		};
 		static DevInfo info[64];
 		static std::mutex info_mutex;
@@ -2093,35 +2251,57 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 			if (!d.n_cu) {
 				hipDeviceProp_t prop;
 				d.n_cu = (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-				for (int &v : d.per_cu) v = -1;
+				for (auto &row : d.per_cu)
+					for (int &v : row) v = -1;
 			}
 			if (!d.attr_set) {
-				LFA_HIP(s, hipFuncSetAttribute((const void *)k_mg_coarse<real, MemAgent>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+				LFA_HIP(s, hipFuncSetAttribute((const void *)k_mg_coarse<real, MemAgent, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+				LFA_HIP(s, hipFuncSetAttribute((const void *)k_mg_coarse<real, MemAgent, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
 				d.attr_set = true;
 			}
 			di = d;
 		}
 		const int n_cu = di.n_cu;
-		auto fits = [&](int first) {
+		auto fits = [&](int first, bool tg) {
 			const int nlev = last - first + 1;
 			if (nlev > MG_CO_MAX_LEVELS) return false;
 			const size_t lds = (size_t)nlev * sizeof(CoLevel<real>) + 512 * sizeof(real) + 64;
-			int per_cu = di.per_cu[nlev];  // by registers and LDS together
+			int per_cu = di.per_cu[tg][nlev];  // by registers and LDS together
 			if (per_cu < 0) {
-				if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_mg_coarse<real, MemAgent>, 256, lds) != hipSuccess) {
+				const void *fn = tg ? (const void *)k_mg_coarse<real, MemAgent, true> : (const void *)k_mg_coarse<real, MemAgent, false>;
+				if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds) != hipSuccess) {
 					(void)hipGetLastError();
 					per_cu = 0;
 				}
 				std::lock_guard<std::mutex> lk(info_mutex);
-				info[dslot].per_cu[nlev] = di.per_cu[nlev] = per_cu;
+				info[dslot].per_cu[tg][nlev] = di.per_cu[tg][nlev] = per_cu;
 			}
 			// ranks that share this GPU launch their k_mg_coarse at the same time: all of them must be resident together
 			const size_t share = s->dist ? (size_t)std::max(1, s->dist->device_share) : 1;
 			return M.lv[first].n_tiles <= MG_CO_MAX_TILES && (size_t)M.lv[first].n_tiles * share <= (size_t)per_cu * (size_t)n_cu;
 		};
-		tail = last;
-		while (tail > 1 && tail - 1 >= D && fits(tail - 1)) --tail;
-		tail = std::max(tail, std::max(D, 1));
+		auto plan = [&](bool tg) {
+			int tl = last;
+			while (tl > 1 && tl - 1 >= D && fits(tl - 1, tg)) --tl;
+			return std::max(tl, std::max(D, 1));
+		};
+		tail = plan(tagged);
+		if (tagged) {
+			// 3 x 8 bytes per padded cell of every level inside (C4: level 2 is 128^3 cells = 50 MB); a level whose GRID is huge
+			// although few of its tiles are active (a small pool in a 2048^3 domain) keeps the flags instead
+			for (int l = tail; l <= last && tagged; ++l) {
+				lfa_mg_level &L = M.lv[l];
+				if (L.xq) continue;
+				if (L.ncp > ((size_t)1 << 26) || hipMalloc(&L.xq, L.ncp * 24) != hipSuccess) {
+					(void)hipGetLastError();
+					L.xq = nullptr;
+					tagged = false;
+				} else {
+					LFA_HIP(s, hipMemsetAsync(L.xq, 0, L.ncp * 24, s->stream));  // (tag 0 is never used)
+				}
+			}
+			if (!tagged) tail = plan(false);
+		}
 	}
 	// cell-parallel kernels for levels of up to 1024 tiles (C4: levels 2 and 3; level 1 with 2048 tiles fills the chip with a
 	// wave per tile: 8.58 ms per step against 8.75 with cell-parallel kernels on every coarse level, 8.79 with none)
@@ -2168,14 +2348,23 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 				if (M.lv[l].ready) LFA_HIP(s, hipMemsetAsync(M.lv[l].ready, 0, (size_t)3 * M.lv[l].g.nt * sizeof(unsigned), s->stream));
 			M.co_tag = 0;
 		}
+		if (M.co_tag == 0)  // (first launch, or the tags start over: the tagged words too)
+			for (int l = 1; l <= last; ++l)
+				if (M.lv[l].xq) LFA_HIP(s, hipMemsetAsync(M.lv[l].xq, 0, M.lv[l].ncp * 24, s->stream));
 		C.tag = ++M.co_tag;  // (0 is what the flags are initialised to)
+		for (int l = tail; l <= last; ++l) {
+			C.xq[l] = tagged ? M.lv[l].xq : nullptr;
+			C.ncp[l] = M.lv[l].ncp;
+		}
 		C.abort = s->pcg_state + 2;
 		C.fault = s->knobs.mg_co_fault;
 		// one workgroup per tile of its first level: every workgroup owns one tile slot on every level it reaches
 		const int W = std::max(1, M.lv[tail].n_tiles);
 		const size_t lds = (size_t)(last - tail + 1) * sizeof(CoLevel<real>) + 512 * sizeof(real);
 		CoGateScope gate(s);
-		hipLaunchKernelGGL((k_mg_coarse<real, MemAgent>), dim3(W), dim3(256), lds, s->stream, C, st);  // (dynamic LDS limit: set where `fits` is)
+		// (dynamic LDS limit: set where `fits` is)
+		if (tagged) hipLaunchKernelGGL((k_mg_coarse<real, MemAgent, true>), dim3(W), dim3(256), lds, s->stream, C, st);
+		else hipLaunchKernelGGL((k_mg_coarse<real, MemAgent, false>), dim3(W), dim3(256), lds, s->stream, C, st);
 		if (gate.done() != LFA_OK) return lfa_fail(s, LFA_E_HIP, "chaining k_mg_coarse behind the device's previous one failed");
 		LFA_LAUNCH_CHECK(s);
 		++launches;

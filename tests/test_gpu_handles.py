@@ -67,14 +67,19 @@ def test_four_independent_handles_step_concurrently(overlap):
         assert abs(np.median(ia) - np.median(ib)) <= 1
 
 
-@pytest.mark.parametrize("dtype", [lfa.PCG_F32, lfa.PCG_F64])
-def test_a_wait_that_is_never_answered_ends_in_a_repeated_solve_not_in_a_hang(dtype, monkeypatch):
+@pytest.mark.parametrize("dtype,flags", [(lfa.PCG_F32, False), (lfa.PCG_F32, True), (lfa.PCG_F64, False)])
+def test_a_wait_that_is_never_answered_ends_in_a_repeated_solve_not_in_a_hang(dtype, flags, monkeypatch):
     """LFA_MG_CO_FAULT=1: workgroup 0 of k_mg_coarse never raises its first flag. Its neighbours' waits pass the ceiling (50 ms),
     the kernel leaves, the host finds the abort word at its next poll, retires the kernels that wait for this handle and repeats
     the solve on the launch-per-phase path: same iteration count and the same bits as a run that never used k_mg_coarse, one
     given-up wait in the solver statistics, and the handle keeps working."""
     size, block = (136, 72, 104), ((0, 0, 0), (90, 50, 70))
     res = []
+    # (fp32: the tagged hand-off - the neighbours poll the words the faulty workgroup never writes - and, `flags`, the ready flags)
+    if flags:
+        monkeypatch.setenv("LFA_MG_NO_TAGGED", "1")
+    else:
+        monkeypatch.delenv("LFA_MG_NO_TAGGED", raising=False)
     for fault in (True, False):
         if fault:
             monkeypatch.setenv("LFA_MG_CO_FAULT", "1")

@@ -488,11 +488,15 @@ def test_multigrid_single_launch_coarse_levels_are_bitwise_the_launch_per_phase_
     pressures - on a ragged three-level grid, a small one (everything below the finest level inside the launch) and one whose
     level 1 (375 tiles) is the launch's first level."""
     res = []
-    for persist in (True, False):
-        if persist:
-            monkeypatch.delenv("LFA_MG_NO_PERSIST", raising=False)
-        else:
+    # "tagged": the default with fp32 vectors - values travel between the workgroups as {tag, value} words (fp64: the same as
+    # "flags"); "flags": level arrays + ready flags (LFA_MG_NO_TAGGED=1); "phase": a launch per phase
+    for mode in ("tagged", "flags", "phase"):
+        monkeypatch.delenv("LFA_MG_NO_PERSIST", raising=False)
+        monkeypatch.delenv("LFA_MG_NO_TAGGED", raising=False)
+        if mode == "phase":
             monkeypatch.setenv("LFA_MG_NO_PERSIST", "1")
+        elif mode == "flags":
+            monkeypatch.setenv("LFA_MG_NO_TAGGED", "1")
         s = lfa.Sim(size, precond=lfa.PRECOND_MULTIGRID, pcg_dtype=dtype)
         s.seed_block(*block)
         its = []
@@ -501,11 +505,12 @@ def test_multigrid_single_launch_coarse_levels_are_bitwise_the_launch_per_phase_
             assert rc == 0
             its.append(it)
         st = s.solver_stats()
-        assert (st["mg_first_level_in_coarse_launch"] >= 1) == persist and st["device_waits_given_up"] == 0, st
+        assert (st["mg_first_level_in_coarse_launch"] >= 1) == (mode != "phase") and st["device_waits_given_up"] == 0, st
         res.append((its, s.pressure().copy()))
         s.close()
-    assert res[0][0] == res[1][0]
-    assert np.array_equal(res[0][1], res[1][1])
+    for other in res[1:]:
+        assert res[0][0] == other[0]
+        assert np.array_equal(res[0][1], other[1])
 
 
 def test_multigrid_single_launch_coarse_levels_repeat_bitwise_over_many_solves():
