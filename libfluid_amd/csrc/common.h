@@ -73,6 +73,8 @@ struct lfa_knobs {
 	                          // to when a device-side wait was given up; bit-identical: the A/B of the tests)
 	int mg_dist_single = 0;   // LFA_MG_DIST_SINGLE=1: the slab mode of the hierarchy with a one-rank communicator (tests, one-rank overhead)
 	int mg_co_fault = 0;      // LFA_MG_CO_FAULT=n (tests): workgroup n - 1 of k_mg_coarse never raises its first flag
+	int mg_no_top = 0;        // LFA_MG_NO_TOP=1: the level above k_mg_coarse's first one keeps its three launches (the A/B of fusing it
+	                          // into the launch in launch order)
 	int mg_no_tagged = 0;     // LFA_MG_NO_TAGGED=1: k_mg_coarse hands over through the level arrays + ready flags also with fp32 vectors
 	                          // (what fp64 vectors always do; the bitwise A/B of the tagged hand-off)
 };

@@ -70,6 +70,7 @@ struct lfa_mg_level {
 	// each other - the pre-smoothed iterate, the right-hand side (children's shares), the result (round 5: the tagged hand-off;
 	// allocated when the level first runs inside the launch, fp32 vectors only)
 	unsigned long long *xq = nullptr;
+	int xq_sections = 0;  // 3: [x | b | y] (a level inside the launch), 1: x alone (the level fused in front of it)
 };
 struct lfa_mg {
 	int n_levels = 0;
@@ -1131,6 +1132,8 @@ template <typename real> struct MgCo {
 	MgLv<real> lv[MG_MAX_LEVELS];
 	unsigned *ready[MG_MAX_LEVELS];  // per level 3 x (tiles of the level): tile has stored [0] its pre-smoothed iterate [1] its share of the next level's right-hand side [2] its result
 	int first, last, nsw, inner;
+	int top;  // >= 1: level first - 1 runs in the launch as well, top_wgs workgroups per phase in launch order (TAGGED only); -1: none
+	int top_wgs;
 	unsigned tag;
 	unsigned long long *xq[MG_MAX_LEVELS];  // TAGGED hand-off: per level [x | b | y], each the level's padded grid of {tag, value} words
 	size_t ncp[MG_MAX_LEVELS];
@@ -1587,7 +1590,7 @@ __device__ inline bool co_cycle(const MgCo<real> &P, const CoThread &T, CoLevel<
 			co_half_sweep<real>(T, S.H, a0, a1, b0, b1, fc);
 			co_half_sweep<real>(T, S.H, a0, a1, b0, b1, fc ^ 1);
 		}
-		if (TAGGED && l > P.first) {
+		if (TAGGED && (l > P.first || post_first_y)) {
 			co_put(yq(l) + base + c0, tag, S.H[h0]);
 			co_put(yq(l) + base + c1, tag, S.H[h1]);
 		} else {
@@ -1617,7 +1620,7 @@ __device__ inline bool co_cycle(const MgCo<real> &P, const CoThread &T, CoLevel<
 			co_half_sweep<real>(T, S.H, a0, a1, b0, b1, 1);
 			co_half_sweep<real>(T, S.H, a0, a1, b0, b1, 0);
 		}
-		if (TAGGED && l > P.first) {
+		if (TAGGED && (l > P.first || post_first_y)) {
 			co_put(yq(l) + base + c0, tag, S.H[h0]);
 			co_put(yq(l) + base + c1, tag, S.H[h1]);
 		} else {
@@ -1629,19 +1632,208 @@ __device__ inline bool co_cycle(const MgCo<real> &P, const CoThread &T, CoLevel<
 	return true;
 }
 
+// ---- the level above, fused into the launch in LAUNCH ORDER (round 5, tagged hand-off only)
+// The first level inside k_mg_coarse is the largest whose tiles are all resident at once; the level above it (C4: level 1, 2 400
+// tiles; C3: ~600) kept three launches of its own - pre-smoothing, residual + restriction, prolongation + post-smoothing: 28 us of a
+// 258 us iteration at C4 for a few microseconds of work. They now run inside the same launch as extra workgroups in front of and
+// behind the resident ones, a workgroup per (phase, tile):
+//     [0, n)  pre-smoothing   [n, 2 n)  residual + restriction   [2 n, 2 n + W)  the resident workgroups   [2 n + W, 3 n + W)  the way up
+// Every value a workgroup waits for is a tagged word written by a workgroup with a LOWER index (its neighbours' or children's
+// earlier phase, or its parent in the resident block). The dispatcher hands out workgroups in index order per XCD, and a workgroup
+// that has started never waits for a later one: whoever is waited for is running or done - no residency requirement for the n-tile
+// phases, nothing to deadlock. (Round 4's ordered work queue reached the same guarantee with 38 000 same-address atomics per launch
+// and was 6x slower; here nothing is shared but the data itself.) The waits are bounded like every other (co_get).
+// Arithmetic per cell: cp_presmooth_tile / cp_residual_restrict_tile / cp_prolong_postsmooth_tile = the wave-per-tile kernels'.
+/// Phase 1 of the top level: cp_presmooth_tile with the iterate going out as tagged words.
+template <typename real>
+__device__ inline void top_presmooth(CpTile<real> &S, const MgLv<real> &L, int slot, int inner, unsigned long long *xq, unsigned tag) {
+	const int t = threadIdx.x;
+	const size_t base = (size_t)L.tiles[slot] * 512;
+	for (int c = t; c < 512; c += 256) {
+		S.ab[c] = L.abits[base + c];
+		S.bb[c] = L.b[base + c];  // (restricted by the previous launch)
+	}
+	for (int i = t; i < LFA_HALO_CELLS; i += 256) S.H[i] = (real)0;
+	__syncthreads();
+	for (int it = 0; it < inner; ++it) {
+		cp_half_sweep<real>(S, 0);
+		cp_half_sweep<real>(S, 1);
+	}
+	for (int c = t; c < 512; c += 256) co_put(xq + base + c, tag, S.H[cp_hi(c)]);
+}
+/// Phase 2: cp_residual_restrict_tile; the iterate (own cells and ring) comes in, the parent's share goes out, as tagged words.
+template <typename real>
+__device__ inline void top_residual_restrict(CpTile<real> &S, real *R, const MgLv<real> &L, const GridDims &gc, int slot,
+                                             const unsigned long long *xq, unsigned long long *bq_coarse, unsigned tag, int *abort_word) {
+	const int t = threadIdx.x;
+	const int *nt = L.nbr + (size_t)slot * MG_NBR_STRIDE;
+	const int tile = nt[6];
+	const size_t base = (size_t)tile * 512;
+	int f0, f1, h0, h1, n0, n1, dx, dy, dz;
+	const int r1 = t + 256;
+	cp_ring(t, f0, h0, n0, dx, dy, dz);
+	cp_ring(r1 < 384 ? r1 : 0, f1, h1, n1, dx, dy, dz);
+	const int nb0 = nt[f0], nb1 = r1 < 384 ? nt[f1] : -1;
+	const unsigned long long *const p[4] = {xq + base + t, xq + base + t + 256, nb0 >= 0 ? xq + (size_t)nb0 * 512 + n0 : nullptr,
+	                                        nb1 >= 0 ? xq + (size_t)nb1 * 512 + n1 : nullptr};
+	for (int c = t; c < 512; c += 256) {
+		S.ab[c] = L.abits[base + c];
+		S.bb[c] = L.b[base + c];
+	}
+	float v[4];
+	co_get<4>(p, tag, abort_word, v);
+	S.H[cp_hi(t)] = (real)v[0];
+	S.H[cp_hi(t + 256)] = (real)v[1];
+	S.H[h0] = (real)v[2];  // (0 where the neighbour tile is inactive)
+	if (r1 < 384) S.H[h1] = (real)v[3];
+	__syncthreads();
+	for (int c = t; c < 512; c += 256) {
+		const int i = cp_hi(c);
+		const uint32_t a = S.ab[c];
+		real r = (real)0;
+		if (a & AB_UNKNOWN) {
+			const real F = (a & AB_FLUID) ? (real)1 : (real)0;
+			real val = (real)(a & 7) * S.H[i];
+			val -= F * S.H[i - 1];
+			val -= F * S.H[i - 10];
+			val -= F * S.H[i - 100];
+			val -= (real)((a >> 3) & 1) * S.H[i + 1];
+			val -= (real)((a >> 4) & 1) * S.H[i + 10];
+			val -= (real)((a >> 5) & 1) * S.H[i + 100];
+			r = S.bb[c] - val;
+		}
+		R[c] = r;
+	}
+	__syncthreads();
+	if (t < 64) {  // one coarse cell each: its 8 children in the order of the pair sums and the two shuffle steps
+		const int X = t & 3, Y = (t >> 2) & 3, Z = t >> 4;
+		auto pair = [&](int x, int y) { real q = R[x + 8 * y + 64 * (2 * Z)]; q += R[x + 8 * y + 64 * (2 * Z + 1)]; return q; };
+		real v2 = pair(2 * X, 2 * Y);
+		v2 += pair(2 * X + 1, 2 * Y);
+		real w = pair(2 * X, 2 * Y + 1);
+		w += pair(2 * X + 1, 2 * Y + 1);
+		v2 += w;
+		int tx, ty, tz;
+		tile_coords(L.g, tile, tx, ty, tz);
+		const int ptile = (tx >> 1) + gc.ntx * ((ty >> 1) + gc.nty * (tz >> 1));
+		co_put(bq_coarse + (size_t)ptile * 512 + ((tz & 1) * 4 + Z) * 64 + ((ty & 1) * 4 + Y) * 8 + (tx & 1) * 4 + X, tag, (real)0.5 * v2);
+	}
+}
+/// Phase 3: cp_prolong_postsmooth_tile; the iterate and the parents' corrections come in as tagged words, the result goes to the
+/// level's plain array (the finer level's launch reads it).
+template <typename real>
+__device__ inline void top_prolong_postsmooth(CpTile<real> &S, const MgLv<real> &L, const GridDims &gc, int slot, int inner,
+                                              const unsigned long long *xq, const unsigned long long *yq_coarse, unsigned tag, int *abort_word) {
+	const int t = threadIdx.x;
+	const int *nt = L.nbr + (size_t)slot * MG_NBR_STRIDE;
+	const int tile = nt[6];
+	const size_t base = (size_t)tile * 512;
+	int tx, ty, tz;
+	tile_coords(L.g, tile, tx, ty, tz);
+	auto parent = [&](int X, int Y, int Z) { return yq_coarse + blocked_index(gc, X >> 1, Y >> 1, Z >> 1); };
+	int f0, f1, h0, h1, n0, n1, dx0, dy0, dz0, dx1, dy1, dz1;
+	const int r1 = t + 256;
+	cp_ring(t, f0, h0, n0, dx0, dy0, dz0);
+	cp_ring(r1 < 384 ? r1 : 0, f1, h1, n1, dx1, dy1, dz1);
+	const int nb0 = nt[f0], nb1 = r1 < 384 ? nt[f1] : -1;
+	const int c0 = t, c1 = t + 256;
+	const uint8_t a0 = L.abits[base + c0], a1 = L.abits[base + c1];
+	const bool ru0 = nb0 >= 0 && (L.abits[(size_t)nb0 * 512 + n0] & AB_UNKNOWN), ru1 = nb1 >= 0 && (L.abits[(size_t)nb1 * 512 + n1] & AB_UNKNOWN);
+	const unsigned long long *const p[8] = {
+		xq + base + c0, xq + base + c1,
+		(a0 & AB_UNKNOWN) ? parent(tx * 8 + (c0 & 7), ty * 8 + ((c0 >> 3) & 7), tz * 8 + (c0 >> 6)) : nullptr,
+		(a1 & AB_UNKNOWN) ? parent(tx * 8 + (c1 & 7), ty * 8 + ((c1 >> 3) & 7), tz * 8 + (c1 >> 6)) : nullptr,
+		nb0 >= 0 ? xq + (size_t)nb0 * 512 + n0 : nullptr, nb1 >= 0 ? xq + (size_t)nb1 * 512 + n1 : nullptr,
+		ru0 ? parent(tx * 8 + dx0, ty * 8 + dy0, tz * 8 + dz0) : nullptr, ru1 ? parent(tx * 8 + dx1, ty * 8 + dy1, tz * 8 + dz1) : nullptr};
+	S.ab[c0] = a0;
+	S.ab[c1] = a1;
+	S.bb[c0] = L.b[base + c0];
+	S.bb[c1] = L.b[base + c1];
+	float v[8];
+	co_get<8>(p, tag, abort_word, v);
+	{
+		real x0 = (real)v[0], x1 = (real)v[1];
+		if (a0 & AB_UNKNOWN) x0 += (real)v[2];
+		if (a1 & AB_UNKNOWN) x1 += (real)v[3];
+		S.H[cp_hi(c0)] = x0;
+		S.H[cp_hi(c1)] = x1;
+		real g0 = (real)0, g1 = (real)0;
+		if (nb0 >= 0) {
+			g0 = (real)v[4];
+			if (ru0) g0 += (real)v[6];
+		}
+		if (nb1 >= 0) {
+			g1 = (real)v[5];
+			if (ru1) g1 += (real)v[7];
+		}
+		S.H[h0] = g0;
+		if (r1 < 384) S.H[h1] = g1;
+	}
+	__syncthreads();
+	for (int it = 0; it < inner; ++it) {
+		cp_half_sweep<real>(S, 1);
+		cp_half_sweep<real>(S, 0);
+	}
+	for (int c = t; c < 512; c += 256) L.y[base + c] = S.H[cp_hi(c)];
+}
+
 template <typename real, typename MEM, bool TAGGED>
 __global__ void __launch_bounds__(256) k_mg_coarse(MgCo<real> P, const int *state) {
 	extern __shared__ unsigned char co_smem[];
 	__shared__ int dep[8];
-	const CoThread T((int)blockIdx.x);
+	// P.top >= 1 (TAGGED only): the level above runs in this launch too - see "fused in launch order" above. Its n tiles are dealt
+	// to P.top_wgs workgroups per phase (slot = workgroup, + top_wgs, ...): fewer, longer workgroups to dispatch around the resident ones.
+	const int n_top = TAGGED && P.top >= 0 ? P.top_wgs : 0, W = (int)gridDim.x - 3 * n_top;
+	if (TAGGED && n_top) {
+		const int b = (int)blockIdx.x;
+		if (b < 2 * n_top || b >= 2 * n_top + W) {
+			if (state[0] >= 0 || state[2] != 0) return;  // converged, or a wait was given up
+			CpTile<real> &S = *(CpTile<real> *)co_smem;
+			real *R = (real *)(&S + 1);
+			const MgLv<real> &L = P.lv[P.top];
+			unsigned long long *xq = P.xq[P.top], *q1 = P.xq[P.first];
+			if (b < n_top) {
+				for (int slot = b; slot < L.n_tiles; slot += n_top) {
+					top_presmooth<real>(S, L, slot, P.inner, xq, P.tag);
+					__syncthreads();
+				}
+			} else if (b < 2 * n_top) {
+				for (int slot = b - n_top; slot < L.n_tiles; slot += n_top) {
+					top_residual_restrict<real>(S, R, L, P.lv[P.first].g, slot, xq, q1 + P.ncp[P.first], P.tag, P.abort);
+					__syncthreads();
+				}
+			} else {
+				// The way up waits for the whole chain of the resident workgroups (tens of microseconds) and hundreds of these
+				// workgroups are waiting: ONE thread polls ONE word - the parent's result for the tile's first cell - and only when
+				// that has arrived do the 256 threads ask for their eight words each (which are then there, or a microsecond away).
+				// Everybody polling everything from the start is 500 000 threads re-reading 64 bytes each: the storm co_backoff's
+				// comment describes.
+				for (int slot = b - 2 * n_top - W; slot < L.n_tiles; slot += n_top) {
+					if (threadIdx.x == 0) {
+						int tx, ty, tz;
+						tile_coords(L.g, L.nbr[(size_t)slot * MG_NBR_STRIDE + 6], tx, ty, tz);
+						const unsigned long long *const gate[1] = {q1 + 2 * P.ncp[P.first] + blocked_index(P.lv[P.first].g, (tx * 8) >> 1, (ty * 8) >> 1, (tz * 8) >> 1)};
+						float unused[1];
+						co_get<1>(gate, P.tag, P.abort, unused);
+					}
+					__syncthreads();
+					top_prolong_postsmooth<real>(S, L, P.lv[P.first].g, slot, P.inner, xq, q1 + 2 * P.ncp[P.first], P.tag, P.abort);
+					__syncthreads();
+				}
+			}
+			return;
+		}
+	}
+	const CoThread T((int)blockIdx.x - 2 * n_top);
 	const int nlev = P.last - P.first + 1;
 	CoLevel<real> *st = (CoLevel<real> *)co_smem;
 	real *R = (real *)(st + nlev);
 	int lmax = P.first - 1;  // deepest level this workgroup owns a tile of
 	for (int l = P.first; l <= P.last; ++l)
 		if (T.wg < P.lv[l].n_tiles) lmax = l;
-	if (!co_static<real, MEM>(P, T, st, lmax, state, true)) return;
-	(void)co_cycle<real, MEM, TAGGED>(P, T, st, R, dep, P.tag, lmax, true, false);
+	const bool with_top = n_top > 0;
+	if (!co_static<real, MEM>(P, T, st, lmax, state, !with_top)) return;
+	(void)co_cycle<real, MEM, TAGGED>(P, T, st, R, dep, P.tag, lmax, !with_top, with_top);
 }
 
 /// The small levels in ONE workgroup of 16 waves: down from level `first` to the single-tile level, the coarsest solve,
@@ -2201,6 +2393,12 @@ int lfa_mg_setup(lfa_sim *s) {
                          // levels only the single-tile ones are worth keeping there (C2 / C4: 1.52 / 8.63 ms per step, 8: 1.55 / 8.69)
 #define MG_COARSEST_SWEEPS 2  // measured (moving dam, C2 / C3 / C4): 4: 14.0 / 15.05 / 16.15 iterations, 3: 14.05 / 15.0 / 16.0, 2: 14.1 / 15.05 / 15.85 - and 8 fewer half sweeps of latency per V-cycle
 #define MG_CO_MAX_TILES 512  // levels of at most this many tiles run inside k_mg_coarse
+#ifndef MG_TOP_MAX_TILES
+#define MG_TOP_MAX_TILES 1024  // the level above joins the launch (in launch order) when it has at most this many tiles
+#endif
+#ifndef MG_TOP_MAX_WGS
+#define MG_TOP_MAX_WGS 1024    // ... dealt to at most this many workgroups per phase
+#endif
 enum { MG_PART_PRE0 = 1, MG_PART_DOWN0 = 2, MG_PART_COARSE = 4, MG_PART_UP0 = 8, MG_PART_ALL = 15 };
 template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, bool level0_presmoothed, int parts = MG_PART_ALL) {
 	lfa_mg &M = *s->mg;
@@ -2232,6 +2430,7 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 	const bool persist = !s->knobs.mg_no_persist && !s->co_disabled;
 	// the tagged hand-off inside the launch (co_put / co_get): fp32 vectors, and the exchange arrays of the levels inside allocated
 	bool tagged = persist && sizeof(real) == 4 && !s->knobs.mg_no_tagged;
+	int top = -1;  // level fused in front of / behind the resident workgroups of k_mg_coarse
 	if (persist) {
 		// every workgroup of k_mg_coarse must be resident at the same time (they wait for each other): one workgroup per tile of
 		// its first level, LDS per workgroup grows with the number of levels inside
@@ -2286,22 +2485,37 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 			return std::max(tl, std::max(D, 1));
 		};
 		tail = plan(tagged);
+		auto ensure_xq = [&](int l, int sections) -> bool {
+			lfa_mg_level &L = M.lv[l];
+			if (L.xq && L.xq_sections >= sections) return true;
+			if (L.ncp > ((size_t)1 << 26)) return false;
+			if (L.xq) {
+				if (hipStreamSynchronize(s->stream) != hipSuccess || hipFree(L.xq) != hipSuccess) return false;
+				L.xq = nullptr;
+			}
+			if (hipMalloc(&L.xq, L.ncp * 8 * (size_t)sections) != hipSuccess) {
+				(void)hipGetLastError();
+				L.xq = nullptr;
+				L.xq_sections = 0;
+				return false;
+			}
+			L.xq_sections = sections;
+			return hipMemsetAsync(L.xq, 0, L.ncp * 8 * (size_t)sections, s->stream) == hipSuccess;  // (tag 0 is never used)
+		};
 		if (tagged) {
 			// 3 x 8 bytes per padded cell of every level inside (C4: level 2 is 128^3 cells = 50 MB); a level whose GRID is huge
 			// although few of its tiles are active (a small pool in a 2048^3 domain) keeps the flags instead
-			for (int l = tail; l <= last && tagged; ++l) {
-				lfa_mg_level &L = M.lv[l];
-				if (L.xq) continue;
-				if (L.ncp > ((size_t)1 << 26) || hipMalloc(&L.xq, L.ncp * 24) != hipSuccess) {
-					(void)hipGetLastError();
-					L.xq = nullptr;
-					tagged = false;
-				} else {
-					LFA_HIP(s, hipMemsetAsync(L.xq, 0, L.ncp * 24, s->stream));  // (tag 0 is never used)
-				}
-			}
+			for (int l = tail; l <= last && tagged; ++l) tagged = ensure_xq(l, 3);
 			if (!tagged) tail = plan(false);
 		}
+		// the level above the first one inside joins the launch in launch order (k_mg_coarse: "fused in launch order"): never the
+		// finest level, never a distributed one, only the whole cycle (the bench entry points run parts of it)
+		// Up to MG_TOP_MAX_TILES tiles: measured (profiles/r05_top_ab.txt) C3 - level 1, ~600 tiles - 0.1223 -> 0.1150 ms per
+		// iteration; C4 - level 1, 2 400 tiles - 0.2610 -> 0.2658 and the overlapped step + 0.34 ms: 7 200 short workgroups have to be
+		// dispatched in front of / behind the resident ones, and the waiting ones hold slots the position correction wants.
+		if (tagged && parts == MG_PART_ALL && tail - 1 >= std::max(D, 1) && M.lv[tail - 1].n_tiles > 0 && !s->knobs.mg_no_top &&
+		    M.lv[tail - 1].n_tiles <= MG_TOP_MAX_TILES && ensure_xq(tail - 1, 1))
+			top = tail - 1;
 	}
 	// cell-parallel kernels for levels of up to 1024 tiles (C4: levels 2 and 3; level 1 with 2048 tiles fills the chip with a
 	// wave per tile: 8.58 ms per step against 8.75 with cell-parallel kernels on every coarse level, 8.79 with none)
@@ -2316,6 +2530,7 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		const int G = mg_grid(L.n_tiles);
 		const bool cp = l >= 1 && L.n_tiles <= cp_max;  // a workgroup per tile on the coarser levels (see k_mg_*_cp)
 		const int Gcp = std::max(1, std::min(L.n_tiles, 8192));  // (a slab rank may hold no tile of a level)
+		if (l == top) continue;  // (inside k_mg_coarse)
 		if (!(l == 0 && level0_presmoothed) && (parts & (l == 0 ? MG_PART_PRE0 : MG_PART_COARSE))) {
 			if (cp) hipLaunchKernelGGL(k_mg_presmooth_cp<real>, dim3(Gcp), dim3(256), 0, s->stream, L, MG_INNER_SWEEPS, st);
 			else hipLaunchKernelGGL(k_mg_presmooth<real>, dim3(G), dim3(256), 0, s->stream, L, st);
@@ -2350,17 +2565,24 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		}
 		if (M.co_tag == 0)  // (first launch, or the tags start over: the tagged words too)
 			for (int l = 1; l <= last; ++l)
-				if (M.lv[l].xq) LFA_HIP(s, hipMemsetAsync(M.lv[l].xq, 0, M.lv[l].ncp * 24, s->stream));
+				if (M.lv[l].xq) LFA_HIP(s, hipMemsetAsync(M.lv[l].xq, 0, M.lv[l].ncp * 8 * (size_t)M.lv[l].xq_sections, s->stream));
 		C.tag = ++M.co_tag;  // (0 is what the flags are initialised to)
 		for (int l = tail; l <= last; ++l) {
 			C.xq[l] = tagged ? M.lv[l].xq : nullptr;
 			C.ncp[l] = M.lv[l].ncp;
 		}
+		C.top = top;
+		C.top_wgs = top >= 0 ? std::min(M.lv[top].n_tiles, MG_TOP_MAX_WGS) : 0;
+		if (top >= 0) {
+			C.lv[top] = lvl(top);
+			C.xq[top] = M.lv[top].xq;
+			C.ncp[top] = M.lv[top].ncp;
+		}
 		C.abort = s->pcg_state + 2;
 		C.fault = s->knobs.mg_co_fault;
 		// one workgroup per tile of its first level: every workgroup owns one tile slot on every level it reaches
-		const int W = std::max(1, M.lv[tail].n_tiles);
-		const size_t lds = (size_t)(last - tail + 1) * sizeof(CoLevel<real>) + 512 * sizeof(real);
+		const int W = std::max(1, M.lv[tail].n_tiles) + 3 * C.top_wgs;
+		const size_t lds = std::max((size_t)(last - tail + 1) * sizeof(CoLevel<real>) + 512 * sizeof(real), sizeof(CpTile<real>) + 512 * sizeof(real));
 		CoGateScope gate(s);
 		// (dynamic LDS limit: set where `fits` is)
 		if (tagged) hipLaunchKernelGGL((k_mg_coarse<real, MemAgent, true>), dim3(W), dim3(256), lds, s->stream, C, st);
@@ -2385,6 +2607,7 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 	for (int l = tail - 1; l >= 0; --l) {
 		const MgLv<real> L = lvl(l);
 		const int G = mg_grid(L.n_tiles);
+		if (l == top) continue;  // (inside k_mg_coarse)
 		if (!(parts & (l == 0 ? MG_PART_UP0 : MG_PART_COARSE))) continue;
 		if (l == 0)
 			launch_up0<real>(G, s->stream, L, M.lv[1].g, (const real *)M.lv[1].y, inv_scale, part_sigma, st);
@@ -2401,7 +2624,7 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 	}
 	if (parts == MG_PART_ALL) {
 		M.launches_per_cycle = launches + (level0_presmoothed ? 1 : 0);
-		M.first_co = persist ? tail : 0;
+		M.first_co = persist ? (top >= 0 ? top : tail) : 0;
 	}
 	return LFA_OK;
 }

@@ -490,13 +490,16 @@ def test_multigrid_single_launch_coarse_levels_are_bitwise_the_launch_per_phase_
     res = []
     # "tagged": the default with fp32 vectors - values travel between the workgroups as {tag, value} words (fp64: the same as
     # "flags"); "flags": level arrays + ready flags (LFA_MG_NO_TAGGED=1); "phase": a launch per phase
-    for mode in ("tagged", "flags", "phase"):
-        monkeypatch.delenv("LFA_MG_NO_PERSIST", raising=False)
-        monkeypatch.delenv("LFA_MG_NO_TAGGED", raising=False)
+    # "tagged" (fp32) also runs the level above the launch's first one inside it, in launch order; "tagged-no-top": without that
+    for mode in ("tagged", "tagged-no-top", "flags", "phase"):
+        for k in ("LFA_MG_NO_PERSIST", "LFA_MG_NO_TAGGED", "LFA_MG_NO_TOP"):
+            monkeypatch.delenv(k, raising=False)
         if mode == "phase":
             monkeypatch.setenv("LFA_MG_NO_PERSIST", "1")
         elif mode == "flags":
             monkeypatch.setenv("LFA_MG_NO_TAGGED", "1")
+        elif mode == "tagged-no-top":
+            monkeypatch.setenv("LFA_MG_NO_TOP", "1")
         s = lfa.Sim(size, precond=lfa.PRECOND_MULTIGRID, pcg_dtype=dtype)
         s.seed_block(*block)
         its = []

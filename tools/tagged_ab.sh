@@ -3,8 +3,10 @@
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out
 L="--no-cpu-baseline --no-hot-path --no-mic0-record --no-kernel-timing"
 for C in C2 C3 C4; do
-  for V in tagged flags tagged flags; do
-    if [ $V = flags ]; then export LFA_MG_NO_TAGGED=1; else unset LFA_MG_NO_TAGGED; fi
+  for V in top notop flags top notop flags; do
+    unset LFA_MG_NO_TAGGED LFA_MG_NO_TOP
+    if [ $V = flags ]; then export LFA_MG_NO_TAGGED=1; fi
+    if [ $V = notop ]; then export LFA_MG_NO_TOP=1; fi
     python3 bench.py --config $C --steps 30 --warmup 20 $L 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); sm=d['stage_ms_median']
