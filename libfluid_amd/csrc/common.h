@@ -183,6 +183,10 @@ struct lfa_sim {
 	double last_residual = 0.0;
 	uint64_t last_iters = 0;
 	// lfa_get_solver_stats
+	// single domain, multigrid: the iteration whose residual maxima (cur_rmax_parts, one per workgroup of the AXPY kernel) the
+	// V-cycle's first kernel may test (-1: none) - mg.hip: MgStop
+	int cur_iter = -1, cur_rmax_n = 0;
+	const double *cur_rmax_parts = nullptr;
 	uint64_t stat_launches_iter = 0, stat_transport_iter = 0, stat_transport_solve = 0, stat_mg_levels = 0, stat_mg_first_co = 0;
 	// kernels whose workgroups wait for each other (k_mg_coarse, k_pcg_small): a wait that was given up (mg.hip: co_wait) ends
 	// their use on this handle; the solve that met it is repeated on the launch-per-phase path

@@ -788,10 +788,49 @@ k_mg_axpy_presmooth_cg(const int *tiles, int n_tiles, const uint8_t *abits, real
 	}
 }
 
+/// The stopping rule of pressure_solver::solve on the residual the AXPY kernel in front of this one has just produced
+/// (src/pressure_solver.cpp:52-57: the reference leaves its loop BEFORE applying the preconditioner to a converged residual).
+/// Without it the rule is evaluated by the NEXT iteration's k_pcg_a, i.e. after a whole V-cycle whose result nobody reads: 0.19 of an
+/// iteration's 0.25 ms at C4, once per solve. Every workgroup reduces the same per-workgroup maxima (as k_pcg_a does), workgroup 0
+/// records the verdict exactly as k_pcg_a / k_check_converged would (hist[iter], state[0] = iter + 1); the kernels behind this one
+/// see state[0] and return.
+struct MgStop {
+	const double *part_rmax;  // null: no test here (slabs: the maximum is another collective; levels >= 1)
+	int n_part, iter;
+	double tol;
+	int *state;
+	double *hist;
+};
 template <typename real>
-__global__ void __launch_bounds__(256) k_mg_residual_restrict(MgLv<real> L, GridDims gc, real *b_coarse, const int *state) {
+__global__ void __launch_bounds__(256) k_mg_residual_restrict(MgLv<real> L, GridDims gc, real *b_coarse, const int *state, MgStop stop) {
 	__shared__ real halo[PCG_WAVES][LFA_HALO_CELLS];
+	__shared__ double red[4];
 	if (state[0] >= 0) return;
+	if (stop.part_rmax) {
+		double a = -INFINITY;
+		bool nan = false;
+		for (int i = threadIdx.x; i < stop.n_part; i += 256) {
+			const double x = stop.part_rmax[i];
+			nan |= x != x;
+			a = x > a ? x : a;
+		}
+		a = wave_max(a);
+		nan = __any(nan);
+		if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = nan ? NAN : a;
+		__syncthreads();
+		double rmax = red[0];
+		for (int k = 1; k < 4; ++k) rmax = (rmax != rmax || red[k] != red[k]) ? NAN : (red[k] > rmax ? red[k] : rmax);
+		const bool done = rmax != rmax || rmax < stop.tol;
+		if (blockIdx.x == 0 && threadIdx.x == 0) {
+			stop.hist[stop.iter] = rmax;
+			if (done) {
+				if (rmax != rmax) stop.state[1] = 1;
+				*(double *)(stop.state + 16) = rmax;
+				stop.state[0] = stop.iter + 1;
+			}
+		}
+		if (done) return;
+	}
 	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	for (int slot = blockIdx.x * PCG_WAVES + wid; slot < L.n_tiles; slot += gridDim.x * PCG_WAVES)
 		residual_restrict_tile<real>(L, gc, b_coarse, slot, halo[wid], lane);
@@ -2393,6 +2432,9 @@ int lfa_mg_setup(lfa_sim *s) {
                          // levels only the single-tile ones are worth keeping there (C2 / C4: 1.52 / 8.63 ms per step, 8: 1.55 / 8.69)
 #define MG_COARSEST_SWEEPS 2  // measured (moving dam, C2 / C3 / C4): 4: 14.0 / 15.05 / 16.15 iterations, 3: 14.05 / 15.0 / 16.0, 2: 14.1 / 15.05 / 15.85 - and 8 fewer half sweeps of latency per V-cycle
 #define MG_CO_MAX_TILES 512  // levels of at most this many tiles run inside k_mg_coarse
+#ifndef MG_RR_GRID
+#define MG_RR_GRID 2048
+#endif
 #ifndef MG_TOP_MAX_TILES
 #define MG_TOP_MAX_TILES 1024  // the level above joins the launch (in launch order) when it has at most this many tiles
 #endif
@@ -2533,7 +2575,7 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		if (l == top) continue;  // (inside k_mg_coarse)
 		if (!(l == 0 && level0_presmoothed) && (parts & (l == 0 ? MG_PART_PRE0 : MG_PART_COARSE))) {
 			if (cp) hipLaunchKernelGGL(k_mg_presmooth_cp<real>, dim3(Gcp), dim3(256), 0, s->stream, L, MG_INNER_SWEEPS, st);
-			else hipLaunchKernelGGL(k_mg_presmooth<real>, dim3(G), dim3(256), 0, s->stream, L, st);
+			else hipLaunchKernelGGL(k_mg_presmooth<real>, dim3(std::max(1, std::min((L.n_tiles + PCG_WAVES - 1) / PCG_WAVES, MG_RR_GRID))), dim3(256), 0, s->stream, L, st);  // (like the residual kernel: no partials, no pipeline)
 			++launches;
 		}
 		if (l < D) {
@@ -2543,7 +2585,15 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		}
 		if (parts & (l == 0 ? MG_PART_DOWN0 : MG_PART_COARSE)) {
 			if (cp) hipLaunchKernelGGL(k_mg_residual_restrict_cp<real>, dim3(Gcp), dim3(256), 0, s->stream, L, M.lv[l + 1].g, (real *)M.lv[l + 1].b, st);
-			else hipLaunchKernelGGL(k_mg_residual_restrict<real>, dim3(G), dim3(256), 0, s->stream, L, M.lv[l + 1].g, (real *)M.lv[l + 1].b, st);
+			// (no partial sums, no software pipeline, 63 VGPRs: this kernel hides its loads with waves, not with the tuned 768-workgroup
+			// grid of its neighbours - MG_RR_GRID workgroups)
+			else {
+				// (the finest level's launch also evaluates the stopping rule on the residual the AXPY kernel has just written)
+				MgStop stop{nullptr, 0, 0, 0.0, nullptr, nullptr};
+				if (l == 0 && level0_presmoothed && D == 0 && s->cur_iter >= 0 && s->cur_rmax_parts)
+					stop = MgStop{s->cur_rmax_parts, s->cur_rmax_n, s->cur_iter, s->prm.tolerance, s->pcg_state, s->pcg_hist};
+				hipLaunchKernelGGL(k_mg_residual_restrict<real>, dim3(std::max(1, std::min((L.n_tiles + PCG_WAVES - 1) / PCG_WAVES, MG_RR_GRID))), dim3(256), 0, s->stream, L, M.lv[l + 1].g, (real *)M.lv[l + 1].b, st, stop);
+			}
 			++launches;
 		}
 		LFA_LAUNCH_CHECK(s);

@@ -1897,7 +1897,14 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 			double *sig_new_part = P + (pn ? PART_SIG1 : PART_SIG0);
 			CoarseFields<real> cf = is_ml(s) ? make_coarse<real>(s) : CoarseFields<real>{};
 			if (is_mg(s)) {
-				LFA_TRY(lfa_mg_axpy_apply(s, sbuf[pn], sig_po, n_sig_po, zs_src, n_zs_src, P + PART_RMAX, sig_new_part));
+				// (single domain: the V-cycle's first kernel tests the residual this AXPY produces - the reference does not
+				// precondition a converged residual either)
+				s->cur_iter = dist ? -1 : i;
+				s->cur_rmax_parts = P + PART_RMAX;
+				s->cur_rmax_n = GB;
+				const int rc_mg = lfa_mg_axpy_apply(s, sbuf[pn], sig_po, n_sig_po, zs_src, n_zs_src, P + PART_RMAX, sig_new_part);
+				s->cur_iter = -1;
+				LFA_TRY(rc_mg);
 			} else if (embed) {
 				cf.r = crbuf[po];
 				cf.as = (const real *)s->c_as;

@@ -1,0 +1,15 @@
+#!/bin/bash
+# LFA_PCG_GRID_CAP sweep (workgroups of the iteration's streaming kernels) on the GPU box: tools/cap_sweep.sh "C4" 640 768 896 1024
+cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out
+CFGS=$1; shift
+L="--no-cpu-baseline --no-hot-path --no-mic0-record --no-kernel-timing"
+for C in $CFGS; do
+  for R in 1 2; do
+    for V in "$@"; do
+      LFA_PCG_GRID_CAP=$V python3 bench.py --config $C --steps 30 --warmup 20 $L 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); sm=d['stage_ms_median']
+print('$C cap $V step %.3f ms  pcg_loop %.3f  iteration %.4f  it/step %.2f' % (d['ms_per_step'], sm['pcg_loop'], sm['pcg_iteration_mean'], d['pcg']['iterations_per_step']))"
+    done
+  done
+done
