@@ -370,12 +370,7 @@ template <typename real> struct MgLv {
 	real *b, *x, *y;
 };
 
-/// 1 / (number of non-solid neighbours), 1..6: a table lookup by selects instead of an IEEE division in the smoother.
-template <typename real> __device__ inline real rcp_diag(uint32_t n) {
-	return n == 6 ? (real)(1.0 / 6.0) : n == 5 ? (real)0.2 : n == 4 ? (real)0.25 : n == 3 ? (real)(1.0 / 3.0) : n == 2 ? (real)0.5 : (real)1;
-}
-
-/// pick ? b : a on the bit patterns (exact, and immune to being rewritten into an indexed load).
+/// pick ? b : a on the bit patterns (exact, and immune to being rewritten into an indexed load - or into branches).
 __device__ inline float bit_select(float a, float b, int pick) {
 	const uint32_t x = __builtin_bit_cast(uint32_t, a), y = __builtin_bit_cast(uint32_t, b);
 	return __builtin_bit_cast(float, x ^ ((x ^ y) & (0u - (uint32_t)pick)));
@@ -384,6 +379,18 @@ __device__ inline double bit_select(double a, double b, int pick) {
 	const uint64_t x = __builtin_bit_cast(uint64_t, a), y = __builtin_bit_cast(uint64_t, b);
 	return __builtin_bit_cast(double, x ^ ((x ^ y) & (0ull - (uint64_t)pick)));
 }
+/// 1 / (number of non-solid neighbours), 1..6: a table lookup instead of an IEEE division in the smoother - as three levels of bit
+/// selects on the bits of n. (Written as `n == 6 ? 1/6 : n == 5 ? ...` hipcc turns the chain into nested exec-mask BRANCHES, ~40
+/// scalar instructions and eight s_cbranch per Gauss-Seidel update: a third of the smoothing kernels' instruction stream.)
+template <typename real> __device__ inline real rcp_diag(uint32_t n) {
+	const int b0 = (int)(n & 1u), b1 = (int)((n >> 1) & 1u), b2 = (int)((n >> 2) & 1u);
+	const real t1 = bit_select((real)0.5, (real)(1.0 / 3.0), b0);   // n = 2, 3
+	const real t2 = bit_select((real)0.25, (real)0.2, b0);          // n = 4, 5
+	const real u0 = bit_select((real)1, t1, b1);                    // n = (0,) 1 | 2, 3
+	const real u1 = bit_select(t2, (real)(1.0 / 6.0), b1);          // n = 4, 5 | 6 (, 7)
+	return bit_select(u0, u1, b2);
+}
+
 
 /// How a kernel reaches the level arrays other workgroups write. MemPlain: ordinary accesses (one launch per phase, the kernel
 /// boundary makes them visible). MemAgent: agent-scope relaxed atomics (`sc1` on gfx950: the access is coherent across the eight
