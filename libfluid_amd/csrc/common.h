@@ -340,6 +340,11 @@ __device__ inline void lfa_wave_tile_ranks(const uint32_t (&tile)[CH], uint32_t 
 	}
 }
 
+/// s + c v for a coupling c that is exactly 0 or 1 (or -1): the product is exact, so the fused form rounds once - in the addition,
+/// like `s += c * v` compiled with -ffp-contract=off. Bit-identical, one instruction instead of two; the stencil sums of the
+/// smoothers, residuals and the matrix-vector product are made of these.
+__device__ inline float madd01(float c, float v, float s) { return __builtin_fmaf(c, v, s); }
+__device__ inline double madd01(double c, double v, double s) { return __builtin_fma(c, v, s); }
 template <typename T> __device__ inline T wave_sum(T v) {
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

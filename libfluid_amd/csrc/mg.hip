@@ -420,12 +420,12 @@ __device__ inline void gs_colour(real *h, const uint32_t (&ab)[8], const real (&
 		const int i = (lx + 1) + 10 * (ly + 1) + 100 * (2 * j + z0 + 1);
 		const real F = (a & AB_FLUID) ? (real)1 : (real)0;
 		real sum = bv;
-		sum += F * h[i - 1];
-		sum += F * h[i - 10];
-		sum += F * h[i - 100];
-		sum += (real)((a >> 3) & 1) * h[i + 1];
-		sum += (real)((a >> 4) & 1) * h[i + 10];
-		sum += (real)((a >> 5) & 1) * h[i + 100];
+		sum = madd01(F, h[i - 1], sum);
+		sum = madd01(F, h[i - 10], sum);
+		sum = madd01(F, h[i - 100], sum);
+		sum = madd01((real)((a >> 3) & 1), h[i + 1], sum);
+		sum = madd01((real)((a >> 4) & 1), h[i + 10], sum);
+		sum = madd01((real)((a >> 5) & 1), h[i + 100], sum);
 		h[i] = h[i] + (real)MG_OMEGA * (sum * rcp_diag<real>(a & 7) - h[i]);
 	}
 }
@@ -506,12 +506,12 @@ __device__ inline void residual_restrict_tile(const MgLv<real> &L, const GridDim
 		if (a & AB_UNKNOWN) {
 			const real F = (a & AB_FLUID) ? (real)1 : (real)0;
 			real val = (real)(a & 7) * h[i];
-			val -= F * h[i - 1];
-			val -= F * h[i - 10];
-			val -= F * h[i - 100];
-			val -= (real)((a >> 3) & 1) * h[i + 1];
-			val -= (real)((a >> 4) & 1) * h[i + 10];
-			val -= (real)((a >> 5) & 1) * h[i + 100];
+			val = madd01(-F, h[i - 1], val);
+			val = madd01(-F, h[i - 10], val);
+			val = madd01(-F, h[i - 100], val);
+			val = madd01(-(real)((a >> 3) & 1), h[i + 1], val);
+			val = madd01(-(real)((a >> 4) & 1), h[i + 10], val);
+			val = madd01(-(real)((a >> 5) & 1), h[i + 100], val);
 			r = bb[zz] - val;
 		}
 		if (zz & 1) pair[zz >> 1] += r;
@@ -956,12 +956,12 @@ template <typename real> __device__ inline void gs_cell(real *H, uint32_t a, rea
 	if (!(a & AB_UNKNOWN) || !(a & 7)) return;
 	const real F = (a & AB_FLUID) ? (real)1 : (real)0;
 	real sum = bv;
-	sum += F * H[i - 1];
-	sum += F * H[i - 10];
-	sum += F * H[i - 100];
-	sum += (real)((a >> 3) & 1) * H[i + 1];
-	sum += (real)((a >> 4) & 1) * H[i + 10];
-	sum += (real)((a >> 5) & 1) * H[i + 100];
+	sum = madd01(F, H[i - 1], sum);
+	sum = madd01(F, H[i - 10], sum);
+	sum = madd01(F, H[i - 100], sum);
+	sum = madd01((real)((a >> 3) & 1), H[i + 1], sum);
+	sum = madd01((real)((a >> 4) & 1), H[i + 10], sum);
+	sum = madd01((real)((a >> 5) & 1), H[i + 100], sum);
 	H[i] = H[i] + (real)MG_OMEGA * (sum * rcp_diag<real>(a & 7) - H[i]);
 }
 // ------------------------------------------------------------------------------------------------ cell-parallel variants
@@ -1040,12 +1040,12 @@ __device__ inline void cp_residual_restrict_tile(CpTile<real> &S, real *R, const
 		if (a & AB_UNKNOWN) {
 			const real F = (a & AB_FLUID) ? (real)1 : (real)0;
 			real val = (real)(a & 7) * S.H[i];
-			val -= F * S.H[i - 1];
-			val -= F * S.H[i - 10];
-			val -= F * S.H[i - 100];
-			val -= (real)((a >> 3) & 1) * S.H[i + 1];
-			val -= (real)((a >> 4) & 1) * S.H[i + 10];
-			val -= (real)((a >> 5) & 1) * S.H[i + 100];
+			val = madd01(-F, S.H[i - 1], val);
+			val = madd01(-F, S.H[i - 10], val);
+			val = madd01(-F, S.H[i - 100], val);
+			val = madd01(-(real)((a >> 3) & 1), S.H[i + 1], val);
+			val = madd01(-(real)((a >> 4) & 1), S.H[i + 10], val);
+			val = madd01(-(real)((a >> 5) & 1), S.H[i + 100], val);
 			r = S.bb[c] - val;
 		}
 		R[c] = r;
@@ -1279,12 +1279,12 @@ template <typename real> __device__ inline real co_residual_cell(const real *H, 
 	if (a & AB_UNKNOWN) {
 		const real F = (a & AB_FLUID) ? (real)1 : (real)0;
 		real val = (real)(a & 7) * H[i];
-		val -= F * H[i - 1];
-		val -= F * H[i - 10];
-		val -= F * H[i - 100];
-		val -= (real)((a >> 3) & 1) * H[i + 1];
-		val -= (real)((a >> 4) & 1) * H[i + 10];
-		val -= (real)((a >> 5) & 1) * H[i + 100];
+		val = madd01(-F, H[i - 1], val);
+		val = madd01(-F, H[i - 10], val);
+		val = madd01(-F, H[i - 100], val);
+		val = madd01(-(real)((a >> 3) & 1), H[i + 1], val);
+		val = madd01(-(real)((a >> 4) & 1), H[i + 10], val);
+		val = madd01(-(real)((a >> 5) & 1), H[i + 100], val);
 		r = b - val;
 	}
 	return r;
@@ -1740,12 +1740,12 @@ __device__ inline void top_residual_restrict(CpTile<real> &S, real *R, const MgL
 		if (a & AB_UNKNOWN) {
 			const real F = (a & AB_FLUID) ? (real)1 : (real)0;
 			real val = (real)(a & 7) * S.H[i];
-			val -= F * S.H[i - 1];
-			val -= F * S.H[i - 10];
-			val -= F * S.H[i - 100];
-			val -= (real)((a >> 3) & 1) * S.H[i + 1];
-			val -= (real)((a >> 4) & 1) * S.H[i + 10];
-			val -= (real)((a >> 5) & 1) * S.H[i + 100];
+			val = madd01(-F, S.H[i - 1], val);
+			val = madd01(-F, S.H[i - 10], val);
+			val = madd01(-F, S.H[i - 100], val);
+			val = madd01(-(real)((a >> 3) & 1), S.H[i + 1], val);
+			val = madd01(-(real)((a >> 4) & 1), S.H[i + 10], val);
+			val = madd01(-(real)((a >> 5) & 1), S.H[i + 100], val);
 			r = S.bb[c] - val;
 		}
 		R[c] = r;
@@ -1940,12 +1940,12 @@ __device__ inline void single_tile_chain(const MgTail<real> &T, real *H, real (*
 			if (a & AB_UNKNOWN) {
 				const real F = (a & AB_FLUID) ? (real)1 : (real)0;
 				real val = (real)(a & 7) * H[hi];
-				val -= F * H[hi - 1];
-				val -= F * H[hi - 10];
-				val -= F * H[hi - 100];
-				val -= (real)((a >> 3) & 1) * H[hi + 1];
-				val -= (real)((a >> 4) & 1) * H[hi + 10];
-				val -= (real)((a >> 5) & 1) * H[hi + 100];
+				val = madd01(-F, H[hi - 1], val);
+				val = madd01(-F, H[hi - 10], val);
+				val = madd01(-F, H[hi - 100], val);
+				val = madd01(-(real)((a >> 3) & 1), H[hi + 1], val);
+				val = madd01(-(real)((a >> 4) & 1), H[hi + 10], val);
+				val = madd01(-(real)((a >> 5) & 1), H[hi + 100], val);
 				r = cb[k][cell] - val;
 			}
 			R[cell] = r;

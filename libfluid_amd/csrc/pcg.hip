@@ -147,12 +147,12 @@ k_spmv(TileCtx tc, const uint8_t *abits, const real *s, real *z, real scale, dou
 					const real F = (a & AB_FLUID) ? (real)1 : (real)0;
 					const real si = h[i];
 					real val = (real)(a & 7) * si;
-					val -= F * h[i - 1];
-					val -= F * h[i - 10];
-					val -= F * h[i - 100];
-					val -= (real)((a >> 3) & 1) * h[i + 1];
-					val -= (real)((a >> 4) & 1) * h[i + 10];
-					val -= (real)((a >> 5) & 1) * h[i + 100];
+					val = madd01(-F, h[i - 1], val);
+					val = madd01(-F, h[i - 10], val);
+					val = madd01(-F, h[i - 100], val);
+					val = madd01(-(real)((a >> 3) & 1), h[i + 1], val);
+					val = madd01(-(real)((a >> 4) & 1), h[i + 10], val);
+					val = madd01(-(real)((a >> 5) & 1), h[i + 100], val);
 					out = scale * val;
 					acc += (double)out * (double)si;
 				}
@@ -1020,12 +1020,12 @@ k_ghost_face_rows(TileCtx tc, int n_lo, int hi_slot0, int n_hi, const uint8_t *a
 				const real sym = ly > 0 ? s[base + idx - 8] : at(nb[2], idx + 56), syp = ly < 7 ? s[base + idx + 8] : at(nb[3], idx - 56);
 				const real szm = zs > 0 ? s[base + idx - 64] : at(nb[4], idx + 448), szp = zs < 7 ? s[base + idx + 64] : at(nb[5], idx - 448);
 				real val = (real)(a & 7) * si;
-				val -= F * sxm;
-				val -= F * sym;
-				val -= F * szm;
-				val -= (real)((a >> 3) & 1) * sxp;
-				val -= (real)((a >> 4) & 1) * syp;
-				val -= (real)((a >> 5) & 1) * szp;
+				val = madd01(-F, sxm, val);
+				val = madd01(-F, sym, val);
+				val = madd01(-F, szm, val);
+				val = madd01(-(real)((a >> 3) & 1), sxp, val);
+				val = madd01(-(real)((a >> 4) & 1), syp, val);
+				val = madd01(-(real)((a >> 5) & 1), szp, val);
 				const real out = scale * val;
 				dq = (double)out - (double)q[base + idx];
 				q[base + idx] = out;
@@ -1291,12 +1291,12 @@ k_pcg_a(int n_ptiles, const int *__restrict__ nbr, const uint8_t *__restrict__ a
 				const real F = (a & AB_FLUID) ? (real)1 : (real)0;
 				const real sc = h[i];
 				real val = (real)(a & 7) * sc;
-				val -= F * h[i - 1];
-				val -= F * h[i - 10];
-				val -= F * h[i - 100];
-				val -= (real)((a >> 3) & 1) * h[i + 1];
-				val -= (real)((a >> 4) & 1) * h[i + 10];
-				val -= (real)((a >> 5) & 1) * h[i + 100];
+				val = madd01(-F, h[i - 1], val);
+				val = madd01(-F, h[i - 10], val);
+				val = madd01(-F, h[i - 100], val);
+				val = madd01(-(real)((a >> 3) & 1), h[i + 1], val);
+				val = madd01(-(real)((a >> 4) & 1), h[i + 10], val);
+				val = madd01(-(real)((a >> 5) & 1), h[i + 100], val);
 				out = scale * val;
 				acc += (double)out * (double)sc;
 				sq += (double)out;
