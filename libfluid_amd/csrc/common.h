@@ -345,6 +345,9 @@ __device__ inline void lfa_wave_tile_ranks(const uint32_t (&tile)[CH], uint32_t 
 /// smoothers, residuals and the matrix-vector product are made of these.
 __device__ inline float madd01(float c, float v, float s) { return __builtin_fmaf(c, v, s); }
 __device__ inline double madd01(double c, double v, double s) { return __builtin_fma(c, v, s); }
+/// a b + c in one rounding (the sources are compiled with -ffp-contract=off: fusing is always written out)
+__device__ inline float fma_r(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ inline double fma_r(double a, double b, double c) { return __builtin_fma(a, b, c); }
 template <typename T> __device__ inline T wave_sum(T v) {
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

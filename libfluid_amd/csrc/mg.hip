@@ -405,29 +405,58 @@ struct MemAgent {
 };
 /// One colour of the Gauss-Seidel update on the column of a lane: x_i = (b_i + sum of coupled neighbours) / diag_i.
 /// `h` is the 10^3 halo block of the wave (current values, ring = values of the neighbour tiles or 0).
+/// What one Gauss-Seidel update needs of a cell's A byte: the couplings as 0 / 1 factors and the over-relaxed update
+///   x <- x + omega (sum / diag - x)  =  (1 - omega) x + (omega / diag) sum
+/// as two coefficients. A cell that is no unknown (or has no non-solid neighbour) gets (keep, gain) = (1, 0): the update leaves
+/// it as it is, WITHOUT a branch - so the four updates of a colour are one basic block whose 28 LDS reads are issued together
+/// instead of four exec-masked blocks that each wait for their own.
+template <typename real> struct GsCoef {
+	real lo, xp, yp, zp, keep, gain;
+};
+template <typename real> __device__ inline GsCoef<real> gs_coef(uint32_t a) {
+	const int on = ((a & AB_UNKNOWN) && (a & 7)) ? 1 : 0;
+	GsCoef<real> c;
+	c.lo = (a & AB_FLUID) ? (real)1 : (real)0;
+	c.xp = (real)((a >> 3) & 1);
+	c.yp = (real)((a >> 4) & 1);
+	c.zp = (real)((a >> 5) & 1);
+	c.keep = bit_select((real)1, (real)(1.0 - MG_OMEGA), on);
+	c.gain = bit_select((real)0, (real)MG_OMEGA * rcp_diag<real>(a & 7), on);
+	return c;
+}
+template <typename real> __device__ inline real gs_update(const GsCoef<real> &c, real bv, real xm, real ym, real zm, real xp, real yp, real zp, real x) {
+	real sum = bv;
+	sum = madd01(c.lo, xm, sum);
+	sum = madd01(c.lo, ym, sum);
+	sum = madd01(c.lo, zm, sum);
+	sum = madd01(c.xp, xp, sum);
+	sum = madd01(c.yp, yp, sum);
+	sum = madd01(c.zp, zp, sum);
+	return fma_r(sum, c.gain, c.keep * x);
+}
+/// One colour of the Gauss-Seidel update on the column of a lane: x_i = (b_i + sum of coupled neighbours) / diag_i.
+/// `h` is the 10^3 halo block of the wave (current values, ring = values of the neighbour tiles or 0).
 template <typename real>
 __device__ inline void gs_colour(real *h, const uint32_t (&ab)[8], const real (&bb)[8], int lx, int ly, int colour) {
 	// the cells of one colour in the column of lane (x, y) are z = 2 j + z0, z0 = (x + y + colour) & 1: four updates with every
 	// lane active (looping over z and skipping the other colour would idle half the wave)
 	const int z0 = (lx + ly + colour) & 1;
 	const uint32_t zmask = 0u - (uint32_t)z0;
+	real out[4];
 #pragma unroll
 	for (int j = 0; j < 4; ++j) {
 		// (a select written as arithmetic: `z0 ? ab[2j+1] : ab[2j]` is turned into a dynamically indexed load from scratch)
-		const uint32_t a = ab[2 * j] ^ ((ab[2 * j] ^ ab[2 * j + 1]) & zmask);
+		uint32_t a = ab[2 * j] ^ ((ab[2 * j] ^ ab[2 * j + 1]) & zmask);
 		const real bv = bit_select(bb[2 * j], bb[2 * j + 1], z0);
-		if (!(a & AB_UNKNOWN) || !(a & 7)) continue;
 		const int i = (lx + 1) + 10 * (ly + 1) + 100 * (2 * j + z0 + 1);
-		const real F = (a & AB_FLUID) ? (real)1 : (real)0;
-		real sum = bv;
-		sum = madd01(F, h[i - 1], sum);
-		sum = madd01(F, h[i - 10], sum);
-		sum = madd01(F, h[i - 100], sum);
-		sum = madd01((real)((a >> 3) & 1), h[i + 1], sum);
-		sum = madd01((real)((a >> 4) & 1), h[i + 10], sum);
-		sum = madd01((real)((a >> 5) & 1), h[i + 100], sum);
-		h[i] = h[i] + (real)MG_OMEGA * (sum * rcp_diag<real>(a & 7) - h[i]);
+#if MG_GS_NO_HOIST
+		asm volatile("" : "+v"(a));  // the coefficients are decoded per update, not kept in registers across the sweeps
+#endif
+		out[j] = gs_update<real>(gs_coef<real>(a), bv, h[i - 1], h[i - 10], h[i - 100], h[i + 1], h[i + 10], h[i + 100], h[i]);
 	}
+	// (cells of one colour do not read each other: the four results are stored behind all the reads)
+#pragma unroll
+	for (int j = 0; j < 4; ++j) h[(lx + 1) + 10 * (ly + 1) + 100 * (2 * j + z0 + 1)] = out[j];
 }
 
 /// Down, one tile: x = one red->black sweep on A x = b from x = 0 (`h`: ring already zero). With a zero guess the values
@@ -953,16 +982,7 @@ k_mg_prolong_postsmooth(MgLv<real> L, GridDims gc, const real *e, real inv_scale
 
 /// gs_colour for ONE cell (halo index i): the same expression, term by term.
 template <typename real> __device__ inline void gs_cell(real *H, uint32_t a, real bv, int i) {
-	if (!(a & AB_UNKNOWN) || !(a & 7)) return;
-	const real F = (a & AB_FLUID) ? (real)1 : (real)0;
-	real sum = bv;
-	sum = madd01(F, H[i - 1], sum);
-	sum = madd01(F, H[i - 10], sum);
-	sum = madd01(F, H[i - 100], sum);
-	sum = madd01((real)((a >> 3) & 1), H[i + 1], sum);
-	sum = madd01((real)((a >> 4) & 1), H[i + 10], sum);
-	sum = madd01((real)((a >> 5) & 1), H[i + 100], sum);
-	H[i] = H[i] + (real)MG_OMEGA * (sum * rcp_diag<real>(a & 7) - H[i]);
+	H[i] = gs_update<real>(gs_coef<real>(a), bv, H[i - 1], H[i - 10], H[i - 100], H[i + 1], H[i + 10], H[i + 100], H[i]);
 }
 // ------------------------------------------------------------------------------------------------ cell-parallel variants
 // The levels below the finest hold 1/8, 1/64, ... of the tiles: with one wave per tile (4 cells per lane and colour) a
@@ -2036,8 +2056,12 @@ __global__ void __launch_bounds__(MG_TAIL_WAVES * 64) k_mg_tail(MgTail<real> T, 
 /// Minimum waves per SIMD the two streaming kernels of the finest level are compiled for (their software pipelines hold a whole
 /// tile's loads in registers: unconstrained they take 134 / 154 VGPRs = 3 waves per SIMD). LFA_MG_MW_A / LFA_MG_MW_U select
 /// another instantiation for A/B runs.
-#define MG_MW_DEFAULT_A 4  // (C4: 65 -> 61 us; 5 / 6 waves spill the pipeline registers: 117 / 149 us)
-#define MG_MW_DEFAULT_U 1  // (C4: 54 us; 4 / 5 / 6: 61 / 101 / 142 us)
+#ifndef MG_MW_DEFAULT_A
+#define MG_MW_DEFAULT_A 3
+#endif  // (C4: 65 -> 61 us; 5 / 6 waves spill the pipeline registers: 117 / 149 us)
+#ifndef MG_MW_DEFAULT_U
+#define MG_MW_DEFAULT_U 3
+#endif  // (C4: 54 us; 4 / 5 / 6: 61 / 101 / 142 us)
 template <typename real, typename... Args> static void launch_axpy_presmooth(int G, hipStream_t st, Args... a) {
 	hipLaunchKernelGGL((k_mg_axpy_presmooth<real, MG_MW_DEFAULT_A>), dim3(G), dim3(256), 0, st, a...);
 }
