@@ -348,6 +348,43 @@ __device__ inline double madd01(double c, double v, double s) { return __builtin
 /// a b + c in one rounding (the sources are compiled with -ffp-contract=off: fusing is always written out)
 __device__ inline float fma_r(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ inline double fma_r(double a, double b, double c) { return __builtin_fma(a, b, c); }
+/// A thread's share of the per-workgroup partials of the previous kernel (256 threads, n <= 8 x 256 + a tail): all of its loads are
+/// issued before the first is consumed - ONE round trip to the L2, where `for (i = tid; i < n; i += 256) a += p[i]` waits for each
+/// load in turn (three in a row at 768 partials, in front of everything else the kernel does). Same order of additions.
+__device__ inline double strided_partial_sum(const double *p, int n) {
+	double v[8];
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		const int i = (int)threadIdx.x + 256 * k;
+		v[k] = i < n ? p[i] : 0.0;
+	}
+	double a = v[0];
+#pragma unroll
+	for (int k = 1; k < 8; ++k) a += v[k];
+	for (int i = (int)threadIdx.x + 2048; i < n; i += 256) a += p[i];
+	return a;
+}
+/// The same for a maximum; `nan` is set if any partial is a NaN.
+__device__ inline double strided_partial_max(const double *p, int n, bool &nan) {
+	double v[8];
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		const int i = (int)threadIdx.x + 256 * k;
+		v[k] = i < n ? p[i] : -INFINITY;
+	}
+	double a = -INFINITY;
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		nan |= v[k] != v[k];
+		a = v[k] > a ? v[k] : a;
+	}
+	for (int i = (int)threadIdx.x + 2048; i < n; i += 256) {
+		const double x = p[i];
+		nan |= x != x;
+		a = x > a ? x : a;
+	}
+	return a;
+}
 template <typename T> __device__ inline T wave_sum(T v) {
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -652,13 +652,34 @@ k_mg_axpy_presmooth(const int *tiles, int n_tiles, const uint8_t *abits, real *p
                     const double *part_sigma, int n_sigma, const double *part_qs, int n_qs, double *part_rmax, const int *state) {
 	__shared__ real halo[PCG_WAVES][LFA_HALO_CELLS];
 	__shared__ double lds[16];
-	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
+	const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
 	double m = -INFINITY;
 	bool nan = false;
 	if (state[0] < 0) {
-		double a = 0.0, b = 0.0;
-		for (int i = threadIdx.x; i < n_sigma; i += 256) a += part_sigma[i];
-		for (int i = threadIdx.x; i < n_qs; i += 256) b += part_qs[i];
+		// software pipeline: the loads of the wave's next tile are in flight during the sweeps of the current one - and those of
+		// its first tile while the scalars of the previous kernel are reduced. The tile ids of the wave's next 64 slots sit in
+		// the lanes of one register (one load, v_readlane per tile): a load of the id in front of each tile's loads is a second,
+		// dependent round trip per tile.
+		const int stride = gridDim.x * PCG_WAVES;
+		int slot = blockIdx.x * PCG_WAVES + wid, turn = 0;
+		auto load_ids = [&](int first) -> int {
+			const long long sl = (long long)first + (long long)lane * stride;
+			return sl < n_tiles ? tiles[sl] : 0;
+		};
+		int ids = load_ids(slot);
+		uint32_t tab[8];
+		real tp[8], ts[8], tr[8], tq[8];
+		size_t base = 0;
+		auto load_tile = [&](int tile) {
+			base = (size_t)tile * 512;
+#pragma unroll
+			for (int zz = 0; zz < 8; ++zz) {
+				const size_t c = base + zz * 64 + lane;
+				tab[zz] = abits[c]; tp[zz] = p[c]; ts[zz] = sdir[c]; tr[zz] = r[c]; tq[zz] = q_x[c];
+			}
+		};
+		if (slot < n_tiles) load_tile(__builtin_amdgcn_readlane(ids, 0));
+		double a = strided_partial_sum(part_sigma, n_sigma), b = strided_partial_sum(part_qs, n_qs);
 		a = wave_sum(a);
 		b = wave_sum(b);
 		if (lane == 0) { lds[wid] = a; lds[4 + wid] = b; }
@@ -667,21 +688,6 @@ k_mg_axpy_presmooth(const int *tiles, int n_tiles, const uint8_t *abits, real *p
 		__syncthreads();
 		real *h = halo[wid];
 		for (int i = lane; i < LFA_HALO_CELLS; i += 64) h[i] = (real)0;
-		// software pipeline: the loads of the wave's next tile are in flight during the sweeps of the current one
-		const int stride = gridDim.x * PCG_WAVES;
-		int slot = blockIdx.x * PCG_WAVES + wid;
-		uint32_t tab[8];
-		real tp[8], ts[8], tr[8], tq[8];
-		size_t base = 0;
-		auto load_tile = [&](int sl) {
-			base = (size_t)tiles[sl] * 512;
-#pragma unroll
-			for (int zz = 0; zz < 8; ++zz) {
-				const size_t c = base + zz * 64 + lane;
-				tab[zz] = abits[c]; tp[zz] = p[c]; ts[zz] = sdir[c]; tr[zz] = r[c]; tq[zz] = q_x[c];
-			}
-		};
-		if (slot < n_tiles) load_tile(slot);
 		while (slot < n_tiles) {
 			uint32_t ab[8];
 			real bb[8];
@@ -701,7 +707,9 @@ k_mg_axpy_presmooth(const int *tiles, int n_tiles, const uint8_t *abits, real *p
 				bb[zz] = rn;
 			}
 			slot += stride;
-			if (slot < n_tiles) load_tile(slot);
+			turn = (turn + 1) & 63;
+			if (turn == 0 && slot < n_tiles) ids = load_ids(slot);  // (a wave with more than 64 tiles: rare)
+			if (slot < n_tiles) load_tile(__builtin_amdgcn_readlane(ids, turn));
 			presmooth_column<real>(h, ab, bb, lx, ly, MG_INNER_SWEEPS);
 #pragma unroll
 			for (int zz = 0; zz < 8; ++zz) q_x[obase + zz * 64 + lane] = h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)];
@@ -842,14 +850,42 @@ __global__ void __launch_bounds__(256) k_mg_residual_restrict(MgLv<real> L, Grid
 	__shared__ real halo[PCG_WAVES][LFA_HALO_CELLS];
 	__shared__ double red[4];
 	if (state[0] >= 0) return;
-	if (stop.part_rmax) {
-		double a = -INFINITY;
-		bool nan = false;
-		for (int i = threadIdx.x; i < stop.n_part; i += 256) {
-			const double x = stop.part_rmax[i];
-			nan |= x != x;
-			a = x > a ? x : a;
+	const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
+	real *h = halo[wid];
+	const int stride = gridDim.x * PCG_WAVES;
+	int slot = blockIdx.x * PCG_WAVES + wid;
+	int nrow = 0, cur_tile = 0;  // (lane k: entry k & 7 of the table row of the slot after the next, see k_mg_prolong_postsmooth)
+	auto load_row = [&](int sl) {
+		if (sl < L.n_tiles) nrow = L.nbr[(size_t)sl * MG_NBR_STRIDE + (lane & 7)];
+	};
+	uint32_t tab[8];
+	real tb[8], tx[8], rx[6];
+	bool rv[6];
+	auto load_tile = [&](const int row) {
+		const int nt[6] = {__builtin_amdgcn_readlane(row, 0), __builtin_amdgcn_readlane(row, 1), __builtin_amdgcn_readlane(row, 2),
+		                   __builtin_amdgcn_readlane(row, 3), __builtin_amdgcn_readlane(row, 4), __builtin_amdgcn_readlane(row, 5)};
+		cur_tile = __builtin_amdgcn_readlane(row, 6);
+		const size_t base = (size_t)cur_tile * 512;
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) {
+			tab[zz] = L.abits[base + zz * 64 + lane];
+			tb[zz] = L.b[base + zz * 64 + lane];
+			tx[zz] = L.x[base + zz * 64 + lane];
 		}
+		// ring: face lanes = (a, b) over the two in-face axes; a missing neighbour reads the tile's own cell (masked when consumed)
+		const int cell[6] = {ly * 64 + lx * 8 + 7, ly * 64 + lx * 8, ly * 64 + 56 + lx, ly * 64 + lx, 7 * 64 + lane, lane};
+#pragma unroll
+		for (int k = 0; k < 6; ++k) {
+			rv[k] = nt[k] >= 0;
+			rx[k] = L.x[(size_t)(rv[k] ? nt[k] : cur_tile) * 512 + cell[k]];
+		}
+	};
+	load_row(slot);
+	if (slot < L.n_tiles) load_tile(nrow);
+	load_row(slot + stride);
+	if (stop.part_rmax) {
+		bool nan = false;
+		double a = strided_partial_max(stop.part_rmax, stop.n_part, nan);
 		a = wave_max(a);
 		nan = __any(nan);
 		if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = nan ? NAN : a;
@@ -867,9 +903,66 @@ __global__ void __launch_bounds__(256) k_mg_residual_restrict(MgLv<real> L, Grid
 		}
 		if (done) return;
 	}
-	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	for (int slot = blockIdx.x * PCG_WAVES + wid; slot < L.n_tiles; slot += gridDim.x * PCG_WAVES)
-		residual_restrict_tile<real>(L, gc, b_coarse, slot, halo[wid], lane);
+	// residual_restrict_tile as a software pipeline with branch-free loads (k_mg_prolong_postsmooth): the table row a tile ahead,
+	// every load of the next tile in flight while the current one is worked on - and those of the first during the test above.
+	while (slot < L.n_tiles) {
+		uint32_t ab[8];
+		real bb[8];
+		const int tile = cur_tile;
+		MG_FENCE();
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) {
+			ab[zz] = tab[zz];
+			bb[zz] = tb[zz];
+			h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)] = tx[zz];
+		}
+		h[0 + 10 * (lx + 1) + 100 * (ly + 1)] = rv[0] ? rx[0] : (real)0;
+		h[9 + 10 * (lx + 1) + 100 * (ly + 1)] = rv[1] ? rx[1] : (real)0;
+		h[(lx + 1) + 10 * 0 + 100 * (ly + 1)] = rv[2] ? rx[2] : (real)0;
+		h[(lx + 1) + 10 * 9 + 100 * (ly + 1)] = rv[3] ? rx[3] : (real)0;
+		h[(lx + 1) + 10 * (ly + 1) + 100 * 0] = rv[4] ? rx[4] : (real)0;
+		h[(lx + 1) + 10 * (ly + 1) + 100 * 9] = rv[5] ? rx[5] : (real)0;
+		slot += stride;
+		{
+			const int crow = nrow;
+			load_row(slot + stride);
+			if (slot < L.n_tiles) load_tile(crow);
+		}
+		MG_FENCE();
+		real pair[4];
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) {
+			const int i = (lx + 1) + 10 * (ly + 1) + 100 * (zz + 1);
+			const uint32_t a = ab[zz];
+			real r = (real)0;
+			if (a & AB_UNKNOWN) {
+				const real F = (a & AB_FLUID) ? (real)1 : (real)0;
+				real val = (real)(a & 7) * h[i];
+				val = madd01(-F, h[i - 1], val);
+				val = madd01(-F, h[i - 10], val);
+				val = madd01(-F, h[i - 100], val);
+				val = madd01(-(real)((a >> 3) & 1), h[i + 1], val);
+				val = madd01(-(real)((a >> 4) & 1), h[i + 10], val);
+				val = madd01(-(real)((a >> 5) & 1), h[i + 100], val);
+				r = bb[zz] - val;
+			}
+			if (zz & 1) pair[zz >> 1] += r;
+			else pair[zz >> 1] = r;
+		}
+		int tx_, ty_, tz_;
+		tile_coords(L.g, tile, tx_, ty_, tz_);
+		const int ptile = (tx_ >> 1) + gc.ntx * ((ty_ >> 1) + gc.nty * (tz_ >> 1));
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			real t = pair[j];
+			t += __shfl_xor(t, 1, 64);
+			t += __shfl_xor(t, 8, 64);
+			if (!(lx & 1) && !(ly & 1)) {
+				const int o = ((tz_ & 1) * 4 + j) * 64 + ((ty_ & 1) * 4 + (ly >> 1)) * 8 + (tx_ & 1) * 4 + (lx >> 1);
+				b_coarse[(size_t)ptile * 512 + o] = (real)0.5 * t;
+			}
+		}
+	}
 }
 
 /// LEVEL0: the result is scaled by 1/scale and dot(z, r) is formed.
@@ -878,7 +971,7 @@ __global__ void __launch_bounds__(256, MW)
 k_mg_prolong_postsmooth(MgLv<real> L, GridDims gc, const real *e, real inv_scale, double *part_sigma, const int *state) {
 	__shared__ real halo[PCG_WAVES][LFA_HALO_CELLS];
 	__shared__ double red[4];
-	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
+	const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
 	real *h = halo[wid];
 	double acc = 0.0;
 	const bool run = state[0] < 0;
@@ -891,14 +984,27 @@ k_mg_prolong_postsmooth(MgLv<real> L, GridDims gc, const real *e, real inv_scale
 		real tb[8], tx[8], tc[4], rx[6], rc[6];
 		bool rv[6];
 		size_t base = 0;
-		auto load_tile = [&](int sl) {
-			const int *nt = L.nbr + (size_t)sl * MG_NBR_STRIDE;
-			const int tile = nt[6];
+		// The table row (six neighbour tiles, own tile) of the slot AFTER the next: requested a whole tile ahead, so that the loads of
+		// the next tile never wait for their addresses.
+		// (lane k holds entry k & 7 - a per-lane value, which the compiler cannot move into scalar registers - and wait for - the
+		// moment it is loaded; the entries are taken out with v_readlane when the row is used)
+		int nrow = 0;
+		auto load_row = [&](int sl) {
+			if (sl < L.n_tiles) nrow = L.nbr[(size_t)sl * MG_NBR_STRIDE + (lane & 7)];
+		};
+		auto load_tile = [&](const int row) {
+			// Branch-free: every address follows from the table row and no load sits behind a condition, so all loads of the tile
+			// are in flight together. (With the six entries read one by one and the ring's corrections behind `neighbour
+			// present ?` the compiler had put an `s_waitcnt vmcnt(0)` behind each of seven dependent loads: seven serialized
+			// round trips per tile.)
+			const int nt[6] = {__builtin_amdgcn_readlane(row, 0), __builtin_amdgcn_readlane(row, 1), __builtin_amdgcn_readlane(row, 2),
+			                   __builtin_amdgcn_readlane(row, 3), __builtin_amdgcn_readlane(row, 4), __builtin_amdgcn_readlane(row, 5)};
+			const int tile = __builtin_amdgcn_readlane(row, 6);
 			base = (size_t)tile * 512;
 			int tx_, ty_, tz_;
 			tile_coords(L.g, tile, tx_, ty_, tz_);
 			auto corr = [&](int X, int Y, int Z) -> real {
-				if (!e) return (real)0;
+				if (!e) return (real)0;  // (uniform)
 				return e[blocked_index(gc, X >> 1, Y >> 1, Z >> 1)];
 			};
 #pragma unroll
@@ -920,10 +1026,14 @@ k_mg_prolong_postsmooth(MgLv<real> L, GridDims gc, const real *e, real inv_scale
 				const size_t j = (size_t)(rv[k] ? nt[k] : tile) * 512 + cell[k];
 				rab[k] = L.abits[j];
 				rx[k] = L.x[j];
-				rc[k] = rv[k] ? corr(RX[k], RY[k], RZ[k]) : (real)0;
+				// (no neighbour: the parent of the tile's own face cell, 8 cells back along the face axis - in range, masked later)
+				const int back = rv[k] ? 0 : ((k & 1) ? -8 : 8);
+				rc[k] = corr(RX[k] + (k < 2 ? back : 0), RY[k] + ((k >> 1) == 1 ? back : 0), RZ[k] + (k >= 4 ? back : 0));
 			}
 		};
-		if (slot < L.n_tiles) load_tile(slot);
+		load_row(slot);
+		if (slot < L.n_tiles) load_tile(nrow);
+		load_row(slot + stride);
 		while (slot < L.n_tiles) {
 			uint32_t ab[8];
 			real bb[8];
@@ -951,7 +1061,11 @@ k_mg_prolong_postsmooth(MgLv<real> L, GridDims gc, const real *e, real inv_scale
 			h[(lx + 1) + 10 * (ly + 1) + 100 * 0] = fv[4];
 			h[(lx + 1) + 10 * (ly + 1) + 100 * 9] = fv[5];
 			slot += stride;
-			if (slot < L.n_tiles) load_tile(slot);
+			{
+				const int crow = nrow;  // (the row of the next tile: here since the last iteration)
+				load_row(slot + stride);
+				if (slot < L.n_tiles) load_tile(crow);
+			}
 			MG_FENCE();
 			for (int it = 0; it < MG_INNER_SWEEPS; ++it) {
 				gs_colour<real>(h, ab, bb, lx, ly, 1);

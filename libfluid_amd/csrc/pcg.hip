@@ -61,8 +61,7 @@ __device__ inline void face_neighbours(const TileCtx &tc, int tile, int nb[6]) {
 /// Sum / max of the per-workgroup partials of the previous kernel, identical in every workgroup (256 threads): strided
 /// private sums, an xor butterfly inside each wave (every lane ends with the wave's total), one exchange through LDS.
 __device__ inline double reduce_partials_sum(const double *part, int n, double *lds) {
-	double a = 0.0;
-	for (int i = threadIdx.x; i < n; i += 256) a += part[i];
+	double a = strided_partial_sum(part, n);
 	a = wave_sum(a);
 	if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = a;
 	__syncthreads();
@@ -72,9 +71,7 @@ __device__ inline double reduce_partials_sum(const double *part, int n, double *
 }
 /// Two sums at once (one LDS exchange).
 __device__ inline void reduce_partials_sum2(const double *pa, int na, const double *pb, int nb, double *lds, double &ra, double &rb) {
-	double a = 0.0, b = 0.0;
-	for (int i = threadIdx.x; i < na; i += 256) a += pa[i];
-	for (int i = threadIdx.x; i < nb; i += 256) b += pb[i];
+	double a = strided_partial_sum(pa, na), b = strided_partial_sum(pb, nb);
 	a = wave_sum(a);
 	b = wave_sum(b);
 	if ((threadIdx.x & 63) == 0) {
@@ -88,13 +85,8 @@ __device__ inline void reduce_partials_sum2(const double *pa, int na, const doub
 }
 __device__ inline double nan_max(double x, double y) { return (x != x || y != y) ? NAN : (y > x ? y : x); }
 __device__ inline double reduce_partials_max(const double *part, int n, double *lds) {
-	double a = -INFINITY;
 	bool nan = false;
-	for (int i = threadIdx.x; i < n; i += 256) {
-		double x = part[i];
-		nan |= x != x;
-		a = x > a ? x : a;
-	}
+	double a = strided_partial_max(part, n, nan);
 	a = wave_max(a);
 	nan = __any(nan);
 	if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = nan ? NAN : a;
