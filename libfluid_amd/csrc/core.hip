@@ -229,7 +229,7 @@ static void lfa_knobs_parse(lfa_knobs &k) {
 		static std::once_flag once;
 		std::call_once(once, [&] {
 			const int cap = num("LFA_PCG_GRID_CAP", lfa_pcg_grid_cap);  // (unset: the measured best above, not the array bound)
-			lfa_pcg_grid_cap = cap < 64 ? 64 : (cap > 2048 ? 2048 : cap);
+			lfa_pcg_grid_cap = cap < 1 ? 1 : (cap > 2048 ? 2048 : cap);  // (small caps: tests - a wave then walks hundreds of tiles)
 		});
 	}
 }
