@@ -446,12 +446,11 @@ __device__ inline void gs_colour(real *h, const uint32_t (&ab)[8], const real (&
 #pragma unroll
 	for (int j = 0; j < 4; ++j) {
 		// (a select written as arithmetic: `z0 ? ab[2j+1] : ab[2j]` is turned into a dynamically indexed load from scratch)
-		uint32_t a = ab[2 * j] ^ ((ab[2 * j] ^ ab[2 * j + 1]) & zmask);
+		const uint32_t a = ab[2 * j] ^ ((ab[2 * j] ^ ab[2 * j + 1]) & zmask);
 		const real bv = bit_select(bb[2 * j], bb[2 * j + 1], z0);
 		const int i = (lx + 1) + 10 * (ly + 1) + 100 * (2 * j + z0 + 1);
-#if MG_GS_NO_HOIST
-		asm volatile("" : "+v"(a));  // the coefficients are decoded per update, not kept in registers across the sweeps
-#endif
+		// (the compiler keeps the decoded coefficients of all eight cells in registers across the sweeps: 3 waves per SIMD for the
+		// finest-level kernels; decoding per update instead - an opaque `asm` on `a` - measured no better, docs/experiments.md)
 		out[j] = gs_update<real>(gs_coef<real>(a), bv, h[i - 1], h[i - 10], h[i - 100], h[i + 1], h[i + 10], h[i + 100], h[i]);
 	}
 	// (cells of one colour do not read each other: the four results are stored behind all the reads)
