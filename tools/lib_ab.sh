@@ -11,7 +11,7 @@ for C in $CFGS; do
       python3 bench.py --config $C --steps 30 --warmup 20 $L 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); sm=d['stage_ms_median']
-print('$C $V step %.3f ms  pcg_loop %.3f  iteration %.4f  it/step %.2f  p2g %.3f' % (d['ms_per_step'], sm['pcg_loop'], sm['pcg_iteration_mean'], d['pcg']['iterations_per_step'], sm['p2g']))"
+print('$C $V step %.3f ms  pcg_loop %.3f  iteration %.4f  it/step %.2f  p2g %.3f  g2p %.3f  advect %.3f  bin %.3f' % (d['ms_per_step'], sm['pcg_loop'], sm['pcg_iteration_mean'], d['pcg']['iterations_per_step'], sm['p2g'], sm['g2p'], sm['advect_collide'], sm['bin']))"
     done
   done
 done
