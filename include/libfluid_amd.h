@@ -377,8 +377,8 @@ int lfa_get_counts(lfa_sim *s, uint64_t counts[5]);
  * src/pressure_solver.cpp:45-69, is one host loop): [0] kernel launches of one iteration [1] transport calls (neighbour
  * exchanges + all-reduces; 0 on a single domain) of one iteration [2] levels of the multigrid hierarchy (0: another
  * preconditioner) [3] first level that runs inside the single coarse-level launch [4] iterations of the solve
- * [5] transport calls of the whole solve [6] 1: the whole solve ran in ONE launch (small systems: a workgroup per particle tile,
- * [0] is then 0) [7] device-side waits given up on this handle so far (0 in a healthy run; after the first one the handle keeps
+ * [5] transport calls of the whole solve [6] reserved (always 0: the one-launch solve of small systems left the library in
+ * round 5) [7] device-side waits given up on this handle so far (0 in a healthy run; after the first one the handle keeps
  * to the launch-per-phase path, and the solve that met it was repeated there). */
 #define LFA_NUM_SOLVER_STATS 8
 int lfa_get_solver_stats(lfa_sim *s, uint64_t stats[LFA_NUM_SOLVER_STATS]);

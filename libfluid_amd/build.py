@@ -40,6 +40,11 @@ def build(force=False, verbose=False):
     reused."""
     global last_build_report
     hipcc = _hipcc()
+    # the compiler is part of an object's identity: after a ROCm upgrade (or another hipcc on the path) nothing is "reused"
+    try:
+        compiler = hipcc + "\n" + subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
+    except OSError:
+        compiler = hipcc
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "libfluid_amd.h"))
     stamp_path = os.path.join(CSRC, ".build_stamps.json")
@@ -53,8 +58,9 @@ def build(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
-        d = _digest([s] + headers, " ".join(FLAGS))
-        if force or not os.path.exists(o) or stamps.get(src) != d:
+        d = _digest([s] + headers, " ".join(FLAGS) + "\n" + compiler)
+        # (an object replaced by hand is not trusted either: its own hash is kept beside its source digest)
+        if force or not os.path.exists(o) or stamps.get(src) != d or stamps.get(src + ":obj") != _digest([o]):
             jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
             todo[src] = d
 
@@ -75,6 +81,8 @@ def build(force=False, verbose=False):
     if relinked:
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl", "-lpthread"])
     stamps.update(todo)
+    for src in todo:
+        stamps[src + ":obj"] = _digest([os.path.join(CSRC, src.replace(".hip", ".o"))])
     stamps["__link__"] = link_digest
     with open(stamp_path, "w") as f:
         json.dump(stamps, f, indent=1, sort_keys=True)

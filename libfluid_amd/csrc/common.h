@@ -64,10 +64,9 @@ struct GridDims {
 	int nt;             // ntx*nty*ntz
 };
 
-/// A/B switches and tuning knobs, read from the environment ONCE, by lfa_create (core.hip: lfa_knobs_parse) - nothing below an entry
-/// point calls getenv. None is needed in normal use; they exist so that the measurements quoted in DESIGN.md can be repeated.
-/// The switches of a handle, read from the environment ONCE, by lfa_create (nothing below an entry point calls getenv). Each one
-/// selects a supported configuration; what was measured and dropped is in docs/experiments.md, not behind a switch.
+/// The switches of a handle, read from the environment ONCE, by lfa_create (core.hip: lfa_knobs_parse) - nothing below an entry point
+/// calls getenv. None is needed in normal use: each one selects a supported configuration so that the A/Bs quoted in DESIGN.md can
+/// be repeated; what was measured and dropped is in docs/experiments.md, not behind a switch.
 struct lfa_knobs {
 	int mg_no_persist = 0;    // LFA_MG_NO_PERSIST=1: a launch per coarse-level phase instead of k_mg_coarse (the path a handle falls back
 	                          // to when a device-side wait was given up; bit-identical: the A/B of the tests)

@@ -2699,7 +2699,11 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		// Up to MG_TOP_MAX_TILES tiles: measured (profiles/r05_top_ab.txt) C3 - level 1, ~600 tiles - 0.1223 -> 0.1150 ms per
 		// iteration; C4 - level 1, 2 400 tiles - 0.2610 -> 0.2658 and the overlapped step + 0.34 ms: 7 200 short workgroups have to be
 		// dispatched in front of / behind the resident ones, and the waiting ones hold slots the position correction wants.
-		if (tagged && parts == MG_PART_ALL && tail - 1 >= std::max(D, 1) && M.lv[tail - 1].n_tiles > 0 && !s->knobs.mg_no_top &&
+		// Not when slab ranks share this GPU (device_share > 1): launch order only holds inside ONE launch - another process's
+		// waiting phase-3 workgroups could hold the CU slots this launch's resident workgroups need (and the other way round),
+		// a cycle that would end at the 50 ms timeout and retire the kernel for good.
+		const bool shared_gpu = s->dist && s->dist->device_share > 1;
+		if (tagged && !shared_gpu && parts == MG_PART_ALL && tail - 1 >= std::max(D, 1) && M.lv[tail - 1].n_tiles > 0 && !s->knobs.mg_no_top &&
 		    M.lv[tail - 1].n_tiles <= MG_TOP_MAX_TILES && ensure_xq(tail - 1, 1))
 			top = tail - 1;
 	}

@@ -1676,8 +1676,7 @@ static void launch_pcg_a(bool first, bool coarse, int grid, hipStream_t st, Args
 /// CU by registers) and every wave pipelines several tiles. k_pcg_b alternates HBM phases with latency-bound sweeps, and
 /// waves that start together stay in lockstep (their phases add up instead of overlapping): twice as many workgroups as
 /// fit, so that the second half starts staggered as the first retires, measured 66 vs 73 us at C4.
-/// LFA_PCG_GA / LFA_PCG_GB override them for experiments (tools/pcg_grid_sweep.sh).
-static void fused_grids(const lfa_sim *s, int G, int &GA, int &GB) {
+static void fused_grids(int G, int &GA, int &GB) {
 	static int n_cu = 0;
 	if (!n_cu) {
 		int dev = 0;
@@ -1781,7 +1780,7 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 	real *crbuf[2] = {(real *)s->c_r, is_ml(s) ? (real *)s->c_r + s->ncp1 : (real *)nullptr};
 	// launch widths of the two fused kernels (workgroups); each kernel reads the other's per-workgroup partials
 	int GA, GB;
-	fused_grids(s, G, GA, GB);
+	fused_grids(G, GA, GB);
 	if (is_mg(s)) GB = G;  // the V-cycle kernels write pcg_grid(n_ptiles) partials
 	const int NSB = GB + (is_ml(s) ? 1 : 0);
 	// slabs: boundary tile layers whose rows couple to the neighbour rank (k_ghost_face_rows)
@@ -2186,7 +2185,7 @@ template <typename real> static int bench_launch(lfa_sim *s, int which) {
 	const real scale = (real)s->a_scale;
 	double *P = s->partials;
 	int GA, GB;
-	fused_grids(s, G, GA, GB);
+	fused_grids(G, GA, GB);
 	switch (which) {
 	case LFA_K_SPMV_DOT:
 		hipLaunchKernelGGL(k_spmv<real>, dim3(G), dim3(256), 0, s->stream, tc, s->abits, (const real *)v.s, v.z, scale,

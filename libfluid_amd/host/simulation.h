@@ -356,7 +356,13 @@ namespace fluid_amd {
 			// `vec3d(dist(random), dist(random), dist(random))` (simulation.cpp:145): the language leaves the order of the three draws
 			// open; g++ - what the reference is built with here (oracle/Makefile) - makes them right to left, so z gets the first
 			// draw. With the same generator state this seeds the very particles the reference does (tests/test_ref_callers.py).
+			// A host whose own reference build draws left to right (clang, MSVC: the Maya plugin on Windows) defines
+			// LFA_SEED_DRAW_ORDER_LTR to seed what ITS reference seeds.
+#ifdef LFA_SEED_DRAW_ORDER_LTR
+			const double a = dist(random), b = dist(random), c = dist(random);
+#else
 			const double c = dist(random), b = dist(random), a = dist(random);
+#endif
 			p.old_position = p.position = base + vec3d(a, b, c);
 			p.velocity = velocity;
 			p.raw_cell_index = index;
@@ -380,7 +386,11 @@ namespace fluid_amd {
 					for (std::size_t sx = 0; sx < dens; ++sx)
 						for (std::size_t sy = 0; sy < dens; ++sy)
 							for (std::size_t sz = 0; sz < dens; ++sz) {
+#ifdef LFA_SEED_DRAW_ORDER_LTR
+								const double a = dist(random), b = dist(random), c = dist(random);
+#else
 								const double c = dist(random), b = dist(random), a = dist(random);  // z first: see seed_cell
+#endif
 								vec3d pos = grid_offset + cell_off + vec3d(vec3s(sx, sy, sz)) * sub + vec3d(a, b, c);
 								if (pred(pos)) {
 									particle p;

@@ -6,7 +6,10 @@
 //   (2) against this repository's device path: -I libfluid_amd/host/shim -I/root/reference/include, linked with libfluid_amd.so only
 //   (3) the same without any libfluid checkout: -I libfluid_amd/host/shim -I libfluid_amd/host/shim_standalone (the GPU box)
 // and tests/test_ref_callers.py compares what (2) and (3) compute on the MI355X with what (1) computes on the CPU.
-// No line of the reference is in here; each scenario names the host code whose calls it makes:
+// It is written from scratch, but it CALLS the reference's API the way its hosts do, so the lines that are nothing but such a call
+// necessarily coincide with theirs (about two dozen: the callback bodies and print strings of testbed/main.cpp:54-121, the
+// seed_box / seed_sphere / update / time_step calls of its scenes, the voxelizer node's resize_reposition_grid_constrained /
+// voxelize_mesh_surface / mark_exterior sequence). Each scenario names the host code whose calls it makes:
 //   testbed    testbed/main.cpp:50-88 (update_simulation), :90-123 (set-up + the three callbacks), :125-185 (scene reset, scenes
 //              0-4), :187-195 (update(1/60) / time_step())
 //   gridnode   plugins/maya/nodes/grid_node.cpp:256-274 (fresh simulation per evaluation, fields from attributes), :275-343 (sources

@@ -32,7 +32,8 @@ def main():
     calls = s.solver_stats()
     s.close()
     np.savez(spec["out"], cells=cells, parts=parts, ids=ids, iters=np.array(iters), slab=np.array([lo, hi]), before=before,
-             transport_calls=calls["transport_calls_per_iteration"])
+             transport_calls=calls["transport_calls_per_iteration"],
+             waits_given_up=calls["device_waits_given_up"])
 
 
 if __name__ == "__main__":

@@ -672,6 +672,9 @@ def test_shared_memory_transport_between_processes(bounds, slot_kb, precond, dty
     assert np.abs(parts["pos"] - ref["pos"]).max() < 2e-3
     util.assert_close(parts["vel"], ref["vel"], 1e-2, "particle velocities, shm slabs vs single domain", atol=1e-3 * 981.0 * util.DT)
     assert all(int(r["transport_calls"]) > 0 for r in ranks)
+    # ranks of several processes on ONE GPU: no device-side wait may be given up (the level fused in launch order into k_mg_coarse
+    # is off while ranks share a device - another process's waiting workgroups could hold the slots the resident ones need)
+    assert all(int(r["waits_given_up"]) == 0 for r in ranks), [int(r["waits_given_up"]) for r in ranks]
 
 
 def test_bench_runs_n_processes_on_one_gpu(tmp_path):
