@@ -189,6 +189,9 @@ struct lfa_sim {
 	uint64_t stat_launches_iter = 0, stat_transport_iter = 0, stat_transport_solve = 0, stat_mg_levels = 0, stat_mg_first_co = 0;
 	// kernels whose workgroups wait for each other (k_mg_coarse, k_pcg_small): a wait that was given up (mg.hip: co_wait) ends
 	// their use on this handle; the solve that met it is repeated on the launch-per-phase path
+	// The solver's arrays may hold non-finite values (a solve that met a NaN; lfa_bench_kernel's repeated launches): entries
+	// that are no unknowns are assumed to be zero and are never rewritten, so the next system build re-creates them (pcg_scrub)
+	bool pcg_poisoned = false;
 	bool last_rhs_zero = false;  // the previous solve was the early-out of a zero right-hand side (pcg.hip: k_check_rhs)
 	bool co_disabled = false;
 	uint64_t stat_co_aborts = 0, stat_co_reason = 0;

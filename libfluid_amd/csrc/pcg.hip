@@ -1650,7 +1650,24 @@ template <typename real> static int mic_apply(lfa_sim *s, double *part_sigma, bo
 	return LFA_OK;
 }
 
+/// After a solve that met a NaN (or lfa_bench_kernel's repeated launches, which blow the vectors up): entries of the solver's
+/// arrays that are no unknowns are assumed to be zero and no kernel rewrites them - since round 5 the smoother computes
+/// x + 0 * sum there, which a non-finite neighbour turns into NaN for good. The handle would fail every later solve; instead the
+/// vectors are cleared and the multigrid hierarchy is built afresh (its set-up zeroes what it allocates). Failure path only.
+static int pcg_scrub(lfa_sim *s) {
+	LFA_HIP(s, hipStreamSynchronize(s->stream));
+	lfa_mg_free(s);
+	void *vs[] = {s->vp, s->vr, s->vz, s->vs, s->vpre, s->vq, s->vs2};
+	for (void *v : vs)
+		if (v) LFA_HIP(s, hipMemsetAsync(v, 0, s->ncp * s->vec_elem, s->stream));
+	s->pressure_epoch = 0;
+	s->warm_started = false;
+	s->pcg_poisoned = false;
+	return LFA_OK;
+}
+
 template <typename real> static int build_system_t(lfa_sim *s, double dt) {
+	if (s->pcg_poisoned) LFA_TRY(pcg_scrub(s));
 	LFA_TRY(lfa_build_rhs(s, dt));
 	if (s->n_ptiles || (s->dist && is_mg(s))) LFA_TRY(mic_factor<real>(s));  // the multigrid set-up has collectives: every rank takes part
 	s->system_valid = true;
@@ -1730,7 +1747,10 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 			LFA_HIP(s, hipStreamSynchronize(s->stream));
 			for (double x : hb) tot += x;
 		}
-		if (tot != tot) return lfa_fail(s, LFA_E_NAN, "NaN in the divergence right-hand side");
+		if (tot != tot) {
+			s->pcg_poisoned = true;
+			return lfa_fail(s, LFA_E_NAN, "NaN in the divergence right-hand side");
+		}
 		s->last_rhs_zero = tot < 1e-6;
 		if (tot < 1e-6) {
 			if (s->warm_started) {  // the reference returns p = 0 here (src/pressure_solver.cpp:33-35), not the guess
@@ -1980,7 +2000,10 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 		return solve_t<real>(s, dt, residual, iterations);
 	}
 	if (!host_check) {  // what k_check_rhs found
-		if (hstate[3] == 2) return lfa_fail(s, LFA_E_NAN, "NaN in the divergence right-hand side");
+		if (hstate[3] == 2) {
+			s->pcg_poisoned = true;
+			return lfa_fail(s, LFA_E_NAN, "NaN in the divergence right-hand side");
+		}
 		s->last_rhs_zero = hstate[3] == 1;
 		if (hstate[3] == 1) {
 			if (s->warm_started) {  // the reference returns p = 0 here (src/pressure_solver.cpp:33-35), not the guess
@@ -2005,7 +2028,10 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 	s->stat_transport_solve = s->dist ? s->dist->calls - calls_at_start : 0;
 	if (residual) *residual = res;
 	if (iterations) *iterations = (uint64_t)iters;
-	if (nan) return lfa_fail(s, LFA_E_NAN, "NaN in the PCG residual at iteration %d", iters);
+	if (nan) {
+		s->pcg_poisoned = true;
+		return lfa_fail(s, LFA_E_NAN, "NaN in the PCG residual at iteration %d", iters);
+	}
 	if (done >= 0) s->pressure_epoch = s->solve_epoch;
 	return done >= 0 ? LFA_OK : LFA_W_PCG_NOT_CONVERGED;
 }
@@ -2292,5 +2318,6 @@ extern "C" int lfa_bench_kernel(lfa_sim *s, int which, int reps, double *mean_ms
 	}
 	*mean_ms = (double)ms / reps;
 	s->system_valid = is_pcg ? s->system_valid : false;
+	s->pcg_poisoned = s->pcg_poisoned || is_pcg;  // (repeated AXPYs with the same scalars: the vectors may have overflowed)
 	return LFA_OK;
 }

@@ -104,3 +104,39 @@ def test_a_wait_that_is_never_answered_ends_in_a_repeated_solve_not_in_a_hang(dt
     assert np.array_equal(res[0][1], res[1][1])
 
 
+
+
+def test_a_handle_recovers_from_a_nan_solve_and_from_the_kernel_bench():
+    """Entries of the solver's arrays that are no unknowns are assumed to be zero and no kernel rewrites them; a non-finite value
+    next to one makes it NaN for good (the smoother computes x + 0 * sum there). A solve that met a NaN, and lfa_bench_kernel's
+    repeated launches (whose AXPYs overflow: round 6, `bench.py --config C4 --late 300` failed on the step after them), must not
+    leave a handle that fails every later solve: the next system build re-creates the arrays (pcg.hip: pcg_scrub)."""
+    size, block = (64, 64, 64), ((0, 0, 0), (32, 40, 32))
+    ref = lfa.Sim(size)
+    ref.seed_block(*block)
+    s = lfa.Sim(size)
+    s.seed_block(*block)
+    for q in (ref, s):
+        for _ in range(12):
+            q.time_step(util.DT)
+    good = s.download_particles()
+    s.params.gravity[1] = float("nan")  # (the fixed-point P2G swallows a NaN particle velocity; gravity reaches every face)
+    s.set_params()
+    with pytest.raises(lfa.LibfluidError, match="NaN"):
+        s.step_hot(util.DT)
+    s.params.gravity[1] = -981.0
+    s.set_params()
+    s.upload_particles(good)
+    for name in ("pcg_a", "mg_axpy_presmooth", "mg_down0", "mg_coarse", "mg_up0"):  # bench.py's sequence
+        _, it0, rc0 = s.step_hot(util.DT) if name == "pcg_a" else (0, 1, 0)
+        assert rc0 == 0 and it0 > 0
+        s.bench_kernel(name, 20)
+    ref.upload_particles(good)  # (same state on both handles: the reference handle steps from the same particles)
+    ref.step_hot(util.DT)
+    want = [ref.time_step(util.DT)[1] for _ in range(3)]
+    got = [s.time_step(util.DT) for _ in range(3)]
+    assert all(rc == 0 for _, _, rc in got)
+    assert all(abs(it - w) <= 1 for (_, it, _), w in zip(got, want)), (got, want)
+    assert np.isfinite(s.download_particles()["vel"]).all()
+    s.close()
+    ref.close()
