@@ -90,8 +90,17 @@ def cpu_baseline(sample, steps, lfa, skip_full=False):
     except OSError:
         pass
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+    hot = {"value": len(parts) * steps / dt, "unit": "particle-steps/s", "cores": 1, "steps": steps, "seconds": dt,
+           "what": "the serial hot path alone: _transfer_to_grid / pressure_solver::solve / _transfer_from_grid "
+                   "(src/simulation.cpp:293-398, src/pressure_solver.cpp:19-71), no advection / collision / correction"}
+    # `value` is the SAME metric as the GPU line's `value`: particle-steps/s of the full simulation::time_step (the hot-path-only
+    # figure sits beside it under `hot_path`); when the full step was skipped (--cpu-skip-full-step) it is the hot path and says so
     out = {
-        "value": len(parts) * steps / dt, "unit": "particle-steps/s", "cores": 1,
+        "value": full["value"] if full else hot["value"], "unit": "particle-steps/s",
+        "cores": (threads if kind == "ref" else 1) if full else 1,
+        "what": ("full simulation::time_step (same metric as `value` of this line), OpenMP regions on `cores` threads, "
+                 "P2G / PCG / G2P serial as in the reference") if full else hot["what"],
+        "hot_path": hot,
         "host": {"cpu_model": cpu_model, "nproc": os.cpu_count(), "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS"),
                  "omp_threads_in_parallel_regions": threads if kind == "ref" else 1},
         "full_time_step": full,
@@ -173,8 +182,11 @@ def build_sim(args, cfg, lfa, torch, dist, tdev, rank, world, local_rank, n_dev,
                 dist.all_reduce(t, op=dist.ReduceOp.MIN)
                 ok = int(t.item())
             if not ok:
-                if args.transport == "rccl":
-                    raise SystemExit(f"rank {rank}: RCCL communicator could not be created: {err or 'failed on another rank'}")
+                if args.transport != "auto-shm":
+                    # one GPU per rank and no communicator: a host-staged run would be a PCIe number under the headline's name.
+                    # `--transport auto-shm` asks for that fallback explicitly (the line then says so in `transport`).
+                    raise SystemExit(f"rank {rank}: RCCL communicator could not be created: {err or 'failed on another rank'} "
+                                     "(--transport auto-shm falls back to the host-staged transport)")
                 # the handle that tried keeps no half-built communicator: a fresh one takes the host-staged transport
                 sim.abandon_transport()  # (a peer has no communicator: release ours without waiting for it)
                 sim.close()
@@ -245,10 +257,11 @@ def main():
     ap.add_argument("--late", type=int, default=0, help="after everything else: run on to step N of the dam break (untimed), then time "
                     "`--late-steps` full steps there and report them as `late_phase` (the fluid has spread over many partly filled tiles)")
     ap.add_argument("--late-steps", type=int, default=20)
-    ap.add_argument("--transport", choices=["auto", "rccl", "shm"], default="auto", help="z-slab messages: RCCL send/recv + all-reduce on "
+    ap.add_argument("--transport", choices=["auto", "rccl", "shm", "auto-shm"], default="auto", help="z-slab messages: RCCL send/recv + all-reduce on "
                     "the handle's stream, or staged through host shared memory (lfa_dist_init_shm: functional, two PCIe crossings per "
-                    "message). auto = rccl when every rank has its own GPU (falling back to shm only if the communicator cannot be "
-                    "created), shm when ranks share a GPU")
+                    "message). auto = rccl when every rank has its own GPU (a communicator that cannot be created ENDS the run with an "
+                    "error: a host-staged number must not appear under the headline's name), shm when ranks share a GPU; auto-shm = as "
+                    "auto, but fall back to shm if the communicator cannot be created")
     ap.add_argument("--strong", action="store_true", help="N > 1: the FIXED BASELINE domain (configs[3]/[4]) split into N z-slabs - the "
                     "configuration BASELINE.json quotes its multi-GPU target on, and the default headline of an N > 1 run")
     ap.add_argument("--weak", action="store_true", help="N > 1: make the weak-scaling run (domain and block grow along z with N, every rank "
@@ -362,8 +375,11 @@ def main():
             c = float(t.item())
         return c
 
+    marks = []  # host clock each time the CFL read-back returns: the device has finished the step before (one stamp per step)
+
     def one_step():
         dt = min(3.0 * global_cfl(), args.dt_max)
+        marks.append(time.perf_counter())
         res, it, rc = sim.time_step(dt)
         return dt, it, rc
 
@@ -383,6 +399,11 @@ def main():
         per_step.append(sim.step_timings())
     barrier()
     elapsed = time.perf_counter() - t0
+    # wall time of each timed step (CFL read-back to CFL read-back; the last one ends at the closing barrier): min / median / max
+    # beside the device's own span of lfa_time_step, so that a gap between `ms_per_step` and the device time is attributable -
+    # a constant host cost per step shows in the median, outlier steps in max and p95
+    stamps = marks[-args.steps:] + [t0 + elapsed]
+    wall = sorted(1e3 * (b - a) for a, b in zip(stamps[:-1], stamps[1:]))
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -452,6 +473,11 @@ def main():
                     "`--precond multilevel` (same iteration counts as the reference's MIC(0)-PCG within a few per cent)",
         },
         "stage_ms_median": stage_med, "stage_ms_p95": stage_p95,
+        "step_wall_ms": {"min": wall[0], "median": med(wall), "p95": wall[min(len(wall) - 1, int(0.95 * len(wall)))], "max": wall[-1],
+                         "device_span_median": (stage_overlapped or stage_med).get("time_step"),
+                         "note": "host clock between the CFL read-backs of consecutive timed steps (ms_per_step is their mean); "
+                                 "device_span_median = lfa_time_step's own HIP-event span in the same steps: the difference is host-side "
+                                 "(the CFL read-back, launch latency after it)"},
         "correction_fallback_half_tiles": {"flagged": corr_fallback[0], "of": corr_fallback[1], "second_pass": corr_fallback[2],
                                            "note": "half tiles of the last step whose neighbourhood did not fit the LDS-tiled correction kernel"},
     }
@@ -495,30 +521,62 @@ def main():
             if ms > 0:
                 kern[k] = {"ms_median": ms, "ms_p95": stage_p95[k], "algorithmic_bytes": int(b), "GBps": b / ms * 1e-6,
                            "frac": b / ms * 1e-6 / HBM_PEAK_GBS, "share_of_step_ms": ms * mult}
-        out["in_step_kernels"] = kern
+        out["in_step_kernels"] = dict(kern)
         # `traffic`: HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs of this same command,
         # tools/make_profiles.sh). It is NOT measured in this run: `traffic_source` names the committed file it is read from.
-        pmc = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_{cfg_name.lower()}_pmc_traffic.json") for r in (5, 4, 3, 2))
-                    if os.path.exists(q)), os.path.join(ROOT, "profiles", f"r05_{cfg_name.lower()}_pmc_traffic.json"))
+        pmc = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_{cfg_name.lower()}_pmc_traffic.json") for r in (6, 5, 4, 3, 2))
+                    if os.path.exists(q)), os.path.join(ROOT, "profiles", f"r06_{cfg_name.lower()}_pmc_traffic.json"))
         pmc_names = {"p2g_scatter_kernel": "p2g_scatter", "correct_tiled_kernel": "correct_tiled", "g2p": "g2p",
-                     "advect_collide": "advect_collide"}
-        per_launch = {}
+                     "advect_collide": "advect_collide", "bin": "bin_scatter", "pcg_a": "pcg_a", "mg_axpy_presmooth": "mg_axpy_presmooth",
+                     "mg_down0": "mg_down0", "mg_up0": "mg_up0", "mg_coarse": "mg_coarse"}
+        # the source file a kernel lives in: a traffic figure is only as young as that file and the shared headers
+        pmc_files = {"p2g_scatter": "p2g.hip", "correct_tiled": "particles.hip", "g2p": "grid_ops.hip", "advect_collide": "particles.hip",
+                     "bin_scatter": "core.hip", "pcg_a": "pcg.hip", "mg_axpy_presmooth": "mg.hip", "mg_down0": "mg.hip", "mg_up0": "mg.hip",
+                     "mg_coarse": "mg.hip"}
+        per_launch, pmc_sha = {}, {}
         if args.pcg_dtype == "f32" and args.p2g == "binned" and os.path.exists(pmc):  # (C4 and C3 have committed PMC passes)
-            per_launch = json.load(open(pmc))["hbm_bytes_per_launch"]
+            rec = json.load(open(pmc))
+            per_launch, pmc_sha = rec["hbm_bytes_per_launch"], rec.get("source_sha256", {})
+
+        def traffic_of(k):
+            """(bytes, source, age): the PMC figure of kernel k if its passes were taken on THIS code - the kernel's source file and
+            the shared headers hash to what tools/pmc_traffic.py recorded beside the figure - else (None, None, why)."""
+            name = pmc_names.get(k, "")
+            if name not in per_launch:
+                return None, None, "no PMC pass of this kernel is committed for this configuration"
+            import hashlib
+            csrc = os.path.join(ROOT, "libfluid_amd", "csrc")
+            stale = [f for f in (pmc_files.get(name), "common.h", "pcg.h") if f and
+                     pmc_sha.get(f) != hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest()]
+            if stale:
+                return None, None, ("refused: " + os.path.relpath(pmc, ROOT) + " was taken on other code (" + ", ".join(stale) +
+                                    (" changed since" if pmc_sha else ": the file records no source hashes") + "); re-run tools/make_profiles.sh")
+            return per_launch[name]["total"], os.path.relpath(pmc, ROOT) + " (rocprofv3 --pmc passes of the same command, not this run)", \
+                "current: kernel source and shared headers hash to what the PMC passes recorded"
 
         def roofline_of(k, note):
+            tb, tsrc, tage = traffic_of(k)
             return {"bound": "hbm", "kernel": k, "achieved": kern[k]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": kern[k]["frac"], "traffic": per_launch.get(pmc_names.get(k, ""), {}).get("total"),
-                    "traffic_source": (os.path.relpath(pmc, ROOT) + " (rocprofv3 --pmc passes of the same command, not this run)")
-                                      if per_launch.get(pmc_names.get(k, "")) else None,
+                    "frac": kern[k]["frac"], "traffic": tb, "traffic_source": tsrc, "traffic_age": tage,
                     "algorithmic_bytes": kern[k]["algorithmic_bytes"], "ms": kern[k]["ms_median"],
                     "share_of_step_ms": kern[k]["share_of_step_ms"], "note": note}
         # `roofline`: the dominant single kernel of the HOT PATH (SURVEY 8a rows: binning, P2G, PCG, G2P - the path north_star
         # names) inside the timed full steps. The PCG loop is 17 launches per iteration, none of them larger than 1.1 ms per step
         # in total; its iteration as a whole is priced under roofline_groups. `roofline_full_step`: the largest kernel of the
         # whole step, which is the position correction's pair kernel (a SURVEY 8f "next" row; VALU bound, not a bandwidth story).
-        hot = [k for k in ("p2g_scatter_kernel", "g2p", "bin") if k in kern]
+        # The candidates are every kernel measured in this run that belongs to the hot path - the in-step ones and the PCG loop's
+        # launches (isolated time x iterations per step) -, the dominant one is picked from that table, not from a fixed list.
+        for name in PCG_BYTES:
+            if PCG_BYTES[name] <= 0:
+                continue  # (the coarse levels' single launch is latency bound: no byte figure to price)
+            ms = sim.bench_kernel(name, 20)
+            b = int(PCG_BYTES[name] * n_unknowns * (2 if args.pcg_dtype == "f64" else 1))
+            kern[name] = {"ms_median": ms, "ms_p95": ms, "algorithmic_bytes": b, "GBps": b / ms * 1e-6, "frac": b / ms * 1e-6 / HBM_PEAK_GBS,
+                          "share_of_step_ms": ms * it_per_step, "how": "lfa_bench_kernel: 20 launches back to back on the last state"}
+        NOT_HOT = ("correct_tiled_kernel", "advect_collide", "pcg_iteration_mean")  # SURVEY 8f rows; a group of launches
+        hot = [k for k in kern if k not in NOT_HOT]
         dom = max(hot, key=lambda k: kern[k]["share_of_step_ms"])
+        out["roofline_candidates"] = {k: round(kern[k]["share_of_step_ms"], 4) for k in sorted(hot, key=lambda k: -kern[k]["share_of_step_ms"])}
         out["roofline"] = roofline_of(dom, "dominant single kernel of the hot path (SURVEY 8a) by share of the median full step; "
                                            "duration = in-step median (HIP events on the handle's stream)")
         if stage_overlapped is not None and stage_overlapped.get(dom, 0) > 0:
@@ -550,7 +608,7 @@ def main():
         # ---- isolated kernels, back to back on the state of the last step (lfa_bench_kernel): the PCG loop's launches
         kernels = {}
         for name in PCG_BYTES:
-            ms = sim.bench_kernel(name, 20)
+            ms = kern[name]["ms_median"] if name in kern else sim.bench_kernel(name, 20)
             b = int(PCG_BYTES[name] * n_unknowns * (2 if args.pcg_dtype == "f64" else 1))
             kernels[name] = {"ms": ms, "algorithmic_bytes": b, "GBps": b / ms * 1e-6}
         out["kernels_isolated"] = kernels

@@ -382,6 +382,10 @@ int lfa_get_counts(lfa_sim *s, uint64_t counts[5]);
  * to the launch-per-phase path, and the solve that met it was repeated there). */
 #define LFA_NUM_SOLVER_STATS 8
 int lfa_get_solver_stats(lfa_sim *s, uint64_t stats[LFA_NUM_SOLVER_STATS]);
+/* Active tiles (8^3 cells of the level) per level of the last multigrid hierarchy, finest first; levels beyond the hierarchy
+ * are 0. Diagnostic (sparse scenes: a kernel of the V-cycle pays per tile); no member of the reference corresponds. */
+#define LFA_MAX_MG_LEVELS 12
+int lfa_get_mg_level_tiles(lfa_sim *s, uint64_t tiles[LFA_MAX_MG_LEVELS]);
 /* The last position correction: [0] half tiles handled by the LDS-tiled kernel's fallback (a thread per particle gathering from
  * global memory: crowded blocks of more than 12288 staged particles) [1] half tiles in all. Joins a correction in
  * flight. A large [0] / [1] means the scene is far denser than 8 particles per cell and the correction runs slowly.

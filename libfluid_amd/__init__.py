@@ -98,6 +98,7 @@ SIGNATURES = {
     "lfa_apply_a": (_int, [_vp, _vp, _vp, _u64]),
     "lfa_pcg_solve": (_int, [_vp, _dbl, C.POINTER(_dbl), C.POINTER(_u64)]),
     "lfa_get_solver_stats": (_int, [_vp, _vp]),
+    "lfa_get_mg_level_tiles": (_int, [_vp, _vp]),
     "lfa_download_pressure": (_int, [_vp, _vp, _u64]),
     "lfa_upload_pressure": (_int, [_vp, _vp, _u64]),
     "lfa_apply_pressure": (_int, [_vp, _dbl]),
@@ -728,6 +729,14 @@ class Sim:
         self._chk(self.lib.lfa_get_solver_stats(self.h, C.byref(arr)))
         return dict(zip(["launches_per_iteration", "transport_calls_per_iteration", "mg_levels", "mg_first_level_in_coarse_launch",
                          "iterations", "transport_calls_per_solve", "whole_solve_in_one_launch", "device_waits_given_up"], list(arr)))
+
+    def mg_level_tiles(self):
+        arr = (C.c_uint64 * 12)()
+        self._chk(self.lib.lfa_get_mg_level_tiles(self.h, C.byref(arr)))
+        out = list(arr)
+        while out and out[-1] == 0:
+            out.pop()
+        return out
 
     def counts(self):
         arr = (C.c_uint64 * 5)()

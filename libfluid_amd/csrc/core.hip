@@ -1392,8 +1392,8 @@ extern "C" int lfa_cfl(lfa_sim *s, double *out) {
 	LFA_TRY(lfa_corr_join(s));
 	double m = 0.0;
 	if (s->vmax2_valid && s->np_live) {
-		// the last G2P reduced max |v|^2 while it wrote the velocities: 4 bytes instead of a pass over the particles
-		LFA_HIP(s, hipMemcpyAsync(s->h_pinned + 100, s->pcg_state + 7, 4, hipMemcpyDeviceToHost, s->stream));
+		// the last G2P reduced max |v|^2 while it wrote the velocities and sent the 4 bytes to the host behind itself
+		// (grid_ops.hip: g2p_run): no pass over the particles, no copy of its own
 		LFA_HIP(s, hipStreamSynchronize(s->stream));
 		float f;
 		memcpy(&f, s->h_pinned + 100, 4);

@@ -618,6 +618,9 @@ static int g2p_run(lfa_sim *s, bool stale) {
 #undef G2P_LAUNCH
 	LFA_LAUNCH_CHECK(s);
 	s->vc_pending = false;
+	// max |v|^2 goes to the host behind the kernels that reduce it: lfa_cfl (the next step's dt) then only waits for the stream
+	// instead of queueing a copy of its own behind an idle device
+	LFA_HIP(s, hipMemcpyAsync(s->h_pinned + 100, s->pcg_state + 7, 4, hipMemcpyDeviceToHost, s->stream));
 	s->vmax2_valid = true;  // every live particle has just got its velocity: the binned ones, the leavers and (slabs) the arrivals
 	return LFA_OK;
 }

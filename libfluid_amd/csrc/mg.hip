@@ -2881,6 +2881,13 @@ int lfa_mg_axpy_apply(lfa_sim *s, const void *sdir, const double *part_sigma, in
 /// For lfa_bench_kernel: one part of an iteration on the state left by the last solve. 0: AXPYs + level-0 pre-smoothing,
 /// 1: level-0 residual + restriction, 2: all coarser levels (down, single-workgroup tail, up), 3: level-0 prolongation +
 /// post-smoothing + dot.
+extern "C" int lfa_get_mg_level_tiles(lfa_sim *s, uint64_t tiles[LFA_MAX_MG_LEVELS]) {
+	if (!s || !tiles) return LFA_E_INVALID;
+	static_assert(LFA_MAX_MG_LEVELS == MG_MAX_LEVELS, "public and internal level caps differ");
+	for (int l = 0; l < MG_MAX_LEVELS; ++l) tiles[l] = (s->mg && l < s->mg->n_levels) ? (uint64_t)s->mg->lv[l].n_tiles : 0;
+	return LFA_OK;
+}
+
 int lfa_mg_bench_part(lfa_sim *s, int part) {
 	if (!s->mg || !s->mg->n_levels || !s->n_ptiles) return lfa_fail(s, LFA_E_INVALID, "multigrid bench: solve with LFA_PRECOND_MULTIGRID first");
 	const bool f64 = s->prm.pcg_dtype == LFA_PCG_F64;

@@ -83,9 +83,10 @@ def test_oracle_matches_reference_on_c1_and_testbed_setup_0(name):
 
 
 # --------------------------------------------------------------------------------------------------- GPU vs live oracle
-def _compare_hot_steps(cfg, parts, solid, steps, exact_iters, dt=DT, **extra):
-    """`steps` passes of the hot path on the device and on the oracle from the same particles; returns the iteration counts."""
-    o = cpu_of(cfg, "oracle", solid)
+def _compare_hot_steps(cfg, parts, solid, steps, exact_iters, dt=DT, kind="oracle", **extra):
+    """`steps` passes of the hot path on the device and on the oracle (`kind` "ref": the reference compiled in place, oracle/_ref)
+    from the same particles; returns the iteration counts."""
+    o = cpu_of(cfg, kind, solid)
     o.set_particles(parts)
     s = gpu_of(cfg, solid, **extra)
     s.upload_particles(parts)
@@ -103,6 +104,7 @@ def _compare_hot_steps(cfg, parts, solid, steps, exact_iters, dt=DT, **extra):
         util.assert_close(s.pressure(), po, P_REL, f"pressure step {st}", pw=P_PW)
         util.assert_close(gc["vel"], oc["vel"], V_REL, f"grid velocities step {st}", atol=1e-5 * 981.0 * dt)
         its.append((int(it), int(ito)))
+        del oc, gc, po  # (C4: 4.3 GB each)
     got = s.download_particles(into=parts.copy())
     want = o.particles()
     gi, wi = util.order_by_position(got), util.order_by_position(want)
@@ -208,6 +210,36 @@ def test_c3_full_size_moving_dam_against_live_oracle():
     assert len(parts) == 16777216 and np.abs(parts["vel"]).max() > 50.0
     its = _compare_hot_steps(cfg, parts, None, 1, False, dt=dt)
     assert its[0][0] <= 30 and its[0][1] > its[0][0], its  # (multigrid on the device, MIC(0) in the reference)
+
+
+@pytest.mark.gpu
+def test_c4_full_size_moving_dam_against_the_compiled_reference():
+    """BASELINE configs[3] - the configuration the headline metric is quoted on - at FULL size from a MOVING dam: 512^3,
+    67 108 864 particles, APIC, ~8.4 M unknowns. Twenty whole time steps on the device set the dam in motion; the downloaded
+    152-byte records go to the REFERENCE ITSELF (oracle/_ref/libref.so: src/simulation.cpp:346-398 _transfer_to_grid_apic,
+    src/pressure_solver.cpp:19-71 MIC(0)-PCG to 1e-6, src/simulation.cpp:523-546 _transfer_from_grid_apic; ~190 iterations, 1-2
+    minutes on the box's host) when that build travelled, else to the plain-C oracle, and to a fresh device handle in the default
+    configuration (fp32 state, multigrid-preconditioned CG). One pass of the hot path each. ~35 GB of host memory.
+    Bars, both written here because the north star's "within 1e-4 relative on pressure" names no norm:
+      * max-norm: |p - p_ref|_max <= 1e-4 |p_ref|_max                                           (P_REL; the north-star bar)
+      * pointwise: |p - p_ref| <= 1e-3 (|p_ref| + 1e-4 |p_ref|_max) in EVERY unknown            (P_PW)
+        A pointwise 1e-4 without a floor is not a property of the reference either: both solvers stop on max r < 1e-6
+        (pressure_solver.cpp:54), which bounds the error of neither below ~1e-8 |p|_max, and a cell at the free surface holds
+        a pressure of that size. The measured figures are printed (round 5's record: 3.7e-6 and 1.8e-4).
+      * fluid cells, cell types, raw particle cell indices: bit-exact; face / particle velocities <= 1e-4, C <= 2e-4."""
+    cfg = scenes.CONFIGS["C4"]
+    s = lfa.Sim(cfg["size"], method=cfg["method"], blending=cfg["blending"])
+    s.seed_block(*cfg["block"])
+    for _ in range(20):
+        res, it, rc = s.time_step(min(3.0 * s.cfl(), 0.033))
+        assert rc == 0
+    dt = min(3.0 * s.cfl(), 0.033)
+    parts = s.download_particles(into=np.zeros(s.num_particles, dtype=lfa.PARTICLE_DTYPE), write_positions=True)
+    s.close()
+    assert len(parts) == 67108864 and np.abs(parts["vel"]).max() > 100.0
+    its = _compare_hot_steps(cfg, parts, None, 1, False, dt=dt, kind="ref" if orc.have_ref() else "oracle")
+    assert its[0][0] <= 30 and its[0][1] > 100, its  # (multigrid on the device, MIC(0) in the reference)
+    print("C4 full size vs", "reference" if orc.have_ref() else "oracle", "iterations (device, cpu)", its)
 
 
 def _obstacle(size, block):
