@@ -126,6 +126,9 @@ __device__ inline void split_position(double p, int n, int &cell, float &t) {
 #endif
 #define CORR_THREADS 512                   // 8 waves per workgroup, 2 workgroups per CU (LDS)
 #define CORR_THREADS_BIG 1024              // the second pass over crowded parts: 16 waves, one workgroup per CU
+#ifndef CORR_STAGE_DEPTH
+#define CORR_STAGE_DEPTH 4                  // staged records per thread in flight (k_correct_fine)
+#endif
 #define CORR_BIG_SLICES 4                  // workgroups that share the own particles of one crowded part
 
 struct MoveParams {
@@ -533,6 +536,20 @@ k_correct_collide(size_t n, ParticleSoA p, uint32_t *out_key, float *out_tx, flo
 /// CAP: staged particles. <FINE_CAP, false> is the pass over every part (two workgroups per CU); <FINE_CAP_BIG, true> takes the parts
 /// the first pass has flagged in `only` (word 0: how many; a crowded neighbourhood late in a run) with the whole LDS of a CU to
 /// itself, and flags what does not fit even that for the global-gather kernel.
+#ifdef CORR_PROFILE
+// (variant builds only: where a work item's time goes - wall-clock ticks of thread 0 summed over the work items of every launch)
+__device__ unsigned long long g_corr_prof[8];
+#define CORR_STAMP(k)                                                                   \
+	do {                                                                                \
+		if (!ONLY && threadIdx.x == 0) {                                                \
+			const unsigned long long now_ = wall_clock64();                             \
+			atomicAdd(&g_corr_prof[k], now_ - stamp_);                                  \
+			stamp_ = now_;                                                              \
+		}                                                                               \
+	} while (0)
+#else
+#define CORR_STAMP(k) do { } while (0)
+#endif
 template <int CAP, bool ONLY>
 __global__ void __launch_bounds__(ONLY ? CORR_THREADS_BIG : CORR_THREADS, 4)
 k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx, float *out_ty, float *out_tz, GridDims g,
@@ -568,6 +585,10 @@ k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx
 		const int nrows = FB * nzb, nown_rows = FT * (nzb - 2);
 		const bool open_water = (tile_clear[tile] & 1) != 0;  // no solid cell within a tile of this one
 		__syncthreads();
+#ifdef CORR_PROFILE
+		unsigned long long stamp_ = wall_clock64();
+		if (!ONLY && threadIdx.x == 0) atomicAdd(&g_corr_prof[7], 1ull);
+#endif
 		// ---- the 27 source tiles (-1: outside the grid or without particles), then the block's fine cells: where their records
 		// are, how many
 		if (threadIdx.x < 27) {
@@ -661,33 +682,71 @@ k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx
 		// offsets instead: uniform)
 		const bool listed = own_total <= 2u * CNT;
 		__syncthreads();  // (every count has been read: `own` may overwrite the array)
+		CORR_STAMP(0);  // counts, scans, own offsets
 		// ---- stage the rows: a wave per fine row copies its three runs - one cell of the x-1 tile, the own x tile's eleven, one
 		// of the x+1 tile - which follow each other in the block (positions relative to the own tile's origin, in cells)
-		for (int row = wid; row < nrows; row += T / 64) {
-			const int by = row % FB, bz = row / FB;
-			const int gy = by - 1, gz = gz0 + bz;
-			const int dy = gy < 0 ? -1 : (gy >= FT ? 1 : 0), dz = gz < 0 ? -1 : (gz >= FT ? 1 : 0);
-			const int fy = gy - FT * dy, fz = gz - FT * dz;
-			const uint32_t d0 = foff[row * FB], d1 = foff[row * FB + 1], d2 = foff[row * FB + FB - 1], d3 = foff[row * FB + FB];
-			const uint32_t s0 = rowsrc[row * 3], s1 = rowsrc[row * 3 + 1], s2 = rowsrc[row * 3 + 2];
-			for (uint32_t slot = d0 + lane; slot < d3; slot += 64) {
-				const int seg = slot < d1 ? 0 : (slot < d2 ? 1 : 2);
-				const uint32_t src = seg == 0 ? s0 + (slot - d0) : (seg == 1 ? s1 + (slot - d1) : s2 + (slot - d2));
+		// Flat: a thread per staged SLOT, its row found by a seven-step search over the rows' first slots - every thread's record
+		// load is issued at once, two per thread in flight. (Round 5 and before: a wave per fine row, one row after the other - 13
+		// dependent HBM round trips per wave and work item. Measured, round 6: C4 4.91 -> 4.84 ms, the late C3 sheet 2.07 -> 1.89;
+		// 2, 4 or 8 records in flight make no difference - the kernel is bound by its instruction count, not by this latency.)
+		{
+			auto locate = [&](uint32_t slot, uint32_t &src, int &seg, int &dy, int &dz, int &fy, int &fz, int &ownslot) {
+				int r = 0;
+#pragma unroll
+				for (int step = 64; step; step >>= 1) {
+					const int c = r + step;
+					if (c < nrows && (uint32_t)foff[c * FB] <= slot) r = c;
+				}
+				const int by = r % FB, bz = r / FB;
+				const int gy = by - 1, gz = gz0 + bz;
+				dy = gy < 0 ? -1 : (gy >= FT ? 1 : 0); dz = gz < 0 ? -1 : (gz >= FT ? 1 : 0);
+				fy = gy - FT * dy; fz = gz - FT * dz;
+				const uint32_t d0 = foff[r * FB], d1 = foff[r * FB + 1], d2 = foff[r * FB + FB - 1];
+				seg = slot < d1 ? 0 : (slot < d2 ? 1 : 2);
+				src = rowsrc[r * 3 + seg] + (slot - (seg == 0 ? d0 : (seg == 1 ? d1 : d2)));
+				// the own list: slot order = fine-cell order
+				ownslot = (listed && seg == 1 && by >= 1 && by <= FT && bz >= 1 && bz <= nzb - 2)
+				              ? (int)(ownoff[(by - 1) + FT * (bz - 1)] + (slot - d1)) : -1;
+			};
+			auto put = [&](uint32_t slot, const float4 &rec, int seg, int dy, int dz, int fy, int fz, int ownslot) {
 				float t[3];
 				int l[3];
-				fine_decode(spos[src], fy, fz, t, l);
+				fine_decode(rec, fy, fz, t, l);
 				px[slot] = (float)(8 * (seg - 1) + l[0]) + t[0];
 				py[slot] = (float)(8 * dy + l[1]) + t[1];
 				pz[slot] = (float)(8 * dz + l[2]) + t[2];
-			}
-			// the own list: slot order = fine-cell order
-			if (listed && by >= 1 && by <= FT && bz >= 1 && bz <= nzb - 2) {
-				const uint32_t o = ownoff[(by - 1) + FT * (bz - 1)];
-				for (uint32_t k = lane; k < d2 - d1; k += 64) own[o + k] = (uint16_t)(d1 + k);
+				if (ownslot >= 0) own[ownslot] = (uint16_t)slot;
+			};
+			// CORR_STAGE_DEPTH records per thread in flight (a dense item stages ~3 600 = 7 per thread)
+			for (uint32_t slot0 = threadIdx.x; slot0 < total; slot0 += CORR_STAGE_DEPTH * T) {
+				uint32_t src[CORR_STAGE_DEPTH];
+				int meta[CORR_STAGE_DEPTH], ownslot[CORR_STAGE_DEPTH];  // meta: seg | (dy + 1) << 2 | (dz + 1) << 4 | fy << 6 | fz << 10
+				float4 rec[CORR_STAGE_DEPTH];
+#pragma unroll
+				for (int u = 0; u < CORR_STAGE_DEPTH; ++u) {
+					const uint32_t slot = slot0 + u * T;
+					src[u] = 0; meta[u] = 0; ownslot[u] = -1;
+					if (slot < total) {
+						int seg, dy, dz, fy, fz;
+						locate(slot, src[u], seg, dy, dz, fy, fz, ownslot[u]);
+						meta[u] = seg | ((dy + 1) << 2) | ((dz + 1) << 4) | (fy << 6) | (fz << 10);
+					}
+				}
+#pragma unroll
+				for (int u = 0; u < CORR_STAGE_DEPTH; ++u) rec[u] = spos[src[u]];  // (src 0 for a slot beyond the end: any valid record)
+#pragma unroll
+				for (int u = 0; u < CORR_STAGE_DEPTH; ++u) {
+					const uint32_t slot = slot0 + u * T;
+					if (slot < total)
+						put(slot, rec[u], meta[u] & 3, ((meta[u] >> 2) & 3) - 1, ((meta[u] >> 4) & 3) - 1, (meta[u] >> 6) & 15, (meta[u] >> 10) & 15, ownslot[u]);
+				}
 			}
 		}
 		__syncthreads();
-		// ---- one thread per own particle
+		CORR_STAMP(1);  // staging
+#ifdef CORR_PROFILE
+		if (!ONLY && threadIdx.x == 0) { atomicAdd(&g_corr_prof[5], (unsigned long long)total); atomicAdd(&g_corr_prof[6], (unsigned long long)own_total); }
+#endif
 		for (uint32_t w = threadIdx.x + T * slice; w < own_total; w += T * SLICES) {
 			uint32_t me;
 			if (listed) {
@@ -701,6 +760,9 @@ k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx
 				}
 				me = (uint32_t)foff[((1 + lo % FT) + FB * (1 + lo / FT)) * FB + 1] + (w - ownoff[lo]);
 			}
+#ifdef CORR_PROFILE
+			const unsigned long long w0_ = wall_clock64();
+#endif
 			const float mx = px[me], my = py[me], mz = pz[me];
 			// block coordinates of its fine cell (the same arithmetic the index was built with: mx = (float)lx + t exactly)
 			int fx = (int)(mx * FT_INV), fy = (int)(my * FT_INV), fz = (int)(mz * FT_INV);
@@ -798,6 +860,9 @@ k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx
 			sx += s2x.x + s2x.y;
 			sy += s2y.x + s2y.y;
 			sz += s2z.x + s2z.y;
+#ifdef CORR_PROFILE
+			if (!ONLY && threadIdx.x == 0) atomicAdd(&g_corr_prof[4], wall_clock64() - w0_);
+#endif
 			// the particle's exact cell and fractions (the staged copy is tile-relative fp32) and its index
 			float tme[3];
 			int lme[3];
@@ -828,10 +893,27 @@ k_correct_fine(const int *ptiles, int n_ptiles, uint32_t *out_key, float *out_tx
 			out_key[jj] = blocked_index(g, nc[0], nc[1], nc[2]);
 			out_tx[jj] = nt[0]; out_ty[jj] = nt[1]; out_tz[jj] = nt[2];
 		}
+#ifdef CORR_PROFILE
+		CORR_STAMP(2);  // thread 0's own particles
+		__syncthreads();
+		CORR_STAMP(3);  // waiting for the workgroup's slowest thread
+#endif
 	}
 }
 
 }  // namespace
+#ifdef CORR_PROFILE
+extern "C" int lfa_debug_corr_prof(uint64_t out[8], int reset) {
+	unsigned long long h[8] = {0};
+	if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_corr_prof), sizeof h) != hipSuccess) return -1;
+	for (int i = 0; i < 8; ++i) out[i] = h[i];
+	if (reset) {
+		unsigned long long z[8] = {0};
+		if (hipMemcpyToSymbol(HIP_SYMBOL(g_corr_prof), z, sizeof z) != hipSuccess) return -1;
+	}
+	return 0;
+}
+#endif
 
 static MoveParams move_params(const lfa_sim *s, double dt) {
 	MoveParams mp;
