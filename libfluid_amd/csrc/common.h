@@ -74,6 +74,8 @@ struct lfa_knobs {
 	int mg_co_fault = 0;      // LFA_MG_CO_FAULT=n (tests): workgroup n - 1 of k_mg_coarse never raises its first flag
 	int mg_no_top = 0;        // LFA_MG_NO_TOP=1: the level above k_mg_coarse's first one keeps its three launches (the A/B of fusing it
 	                          // into the launch in launch order)
+	int mg_no_prune = 0;      // LFA_MG_NO_PRUNE=1: every parent of a particle tile is an active level-1 tile, also one that holds no unknown
+	                          // (the bitwise A/B of round 6's pruned level-1 set)
 	int mg_no_tagged = 0;     // LFA_MG_NO_TAGGED=1: k_mg_coarse hands over through the level arrays + ready flags also with fp32 vectors
 	                          // (what fp64 vectors always do; the bitwise A/B of the tagged hand-off)
 };

@@ -225,6 +225,7 @@ static void lfa_knobs_parse(lfa_knobs &k) {
 	k.mg_co_fault = num("LFA_MG_CO_FAULT", 0);
 	k.mg_no_tagged = flag("LFA_MG_NO_TAGGED", 0);
 	k.mg_no_top = flag("LFA_MG_NO_TOP", 0);
+	k.mg_no_prune = flag("LFA_MG_NO_PRUNE", 0);
 	{
 		static std::once_flag once;
 		std::call_once(once, [&] {

@@ -83,6 +83,10 @@ struct lfa_mg {
 	int n_dist = 0;
 	std::vector<int> host_top;    // active tiles of level n_dist (all ranks') the replicated lists were built for
 	uint8_t *l1_dirty = nullptr;  // device, per level-1 tile: a child tile was flagged at the last set-up (k_mg_types_from_fine_dirty)
+	// device, per level-1 tile: the tile holds an unknown of level 1 (k_mg_types_from_fine_dirty). Round 6: a level-1 tile WITHOUT
+	// one - the parent of spray, of a film thinner than a coarse cell - is no longer active (single domain): it computed zeros.
+	// Late in the C3 run 805 instead of 2 996 level-1 tiles (and 95 .. 200 instead of 458 on level 2) are left; bit-identical.
+	uint8_t *l1_has_fluid = nullptr;
 	unsigned solid_epoch = 0;     // solid mask the level-1 types were computed for
 	uint32_t *counts = nullptr;   // device, active tiles per level (single-domain set-up, read back once)
 	unsigned co_tag = 0;          // k_mg_coarse: launch counter = the value its ready flags are raised to (lfa_mg_level::ready)
@@ -143,7 +147,7 @@ __global__ void k_mg_types_from_fine(GridDims gf, GridDims gc, size_t c0, size_t
 /// At C4 2 600 of 32 768 tiles are recomputed per step: 217 -> 45 us.
 __global__ void __launch_bounds__(256)
 k_mg_types_from_fine_dirty(GridDims gf, GridDims gc, const uint32_t *tile_flag, const uint32_t *cell_count, const uint8_t *ctype,
-                           const uint8_t *solid, uint8_t *out, uint8_t *was_dirty, int force) {
+                           const uint8_t *solid, uint8_t *out, uint8_t *was_dirty, int force, uint8_t *has_fluid) {
 	for (int tile = blockIdx.x; tile < gc.nt; tile += gridDim.x) {
 		int tx, ty, tz;
 		tile_coords(gc, tile, tx, ty, tz);
@@ -154,6 +158,7 @@ k_mg_types_from_fine_dirty(GridDims gf, GridDims gc, const uint32_t *tile_flag, 
 		}
 		const int dirty = __syncthreads_or(mine);
 		if (!force && !dirty && !was_dirty[tile]) continue;  // uniform per workgroup
+		int unknowns = 0;
 		for (int l = threadIdx.x; l < 512; l += 256) {
 			const int X = tx * 8 + (l & 7), Y = ty * 8 + ((l >> 3) & 7), Z = tz * 8 + (l >> 6);
 			bool any_air = false, any_fluid = false;
@@ -164,10 +169,16 @@ k_mg_types_from_fine_dirty(GridDims gf, GridDims gc, const uint32_t *tile_flag, 
 				any_air |= t == MT_AIR;
 				any_fluid |= t == MT_FLUID;
 			}
-			out[(size_t)tile * 512 + l] = (uint8_t)(!in_grid(gc, X, Y, Z) ? MT_SOLID : (any_air ? MT_AIR : (any_fluid ? MT_FLUID : MT_SOLID)));
+			const int ty_ = !in_grid(gc, X, Y, Z) ? MT_SOLID : (any_air ? MT_AIR : (any_fluid ? MT_FLUID : MT_SOLID));
+			out[(size_t)tile * 512 + l] = (uint8_t)ty_;
+			unknowns |= ty_ == MT_FLUID;
 		}
-		__syncthreads();  // was_dirty[tile] was read by every thread above
-		if (threadIdx.x == 0) was_dirty[tile] = (uint8_t)dirty;
+		// (the barrier: was_dirty[tile] was read by every thread above; a tile that is skipped keeps its types, hence its has_fluid)
+		const int any_unknown = __syncthreads_or(unknowns);
+		if (threadIdx.x == 0) {
+			was_dirty[tile] = (uint8_t)dirty;
+			has_fluid[tile] = (uint8_t)(any_unknown != 0);
+		}
 	}
 }
 /// Types of level l + 1 from level l.
@@ -216,7 +227,8 @@ __global__ void k_mg_flag_level0(const int *tile_pslot, uint32_t *flag, int nt) 
 	if (t < nt) flag[t] = tile_pslot[t] >= 0 ? 1u : 0u;
 }
 /// a tile is active if one of its (up to 8) child tiles is
-__global__ void k_mg_flag_parents(GridDims gf, GridDims gc, const uint32_t *ff, uint32_t *fc) {
+/// (`has_unknown`, level 1 of a single domain: ... and holds an unknown of its own - lfa_mg::l1_has_fluid)
+__global__ void k_mg_flag_parents(GridDims gf, GridDims gc, const uint32_t *ff, uint32_t *fc, const uint8_t *has_unknown) {
 	const int t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= gc.nt) return;
 	int tx, ty, tz;
@@ -226,6 +238,7 @@ __global__ void k_mg_flag_parents(GridDims gf, GridDims gc, const uint32_t *ff, 
 		const int cx = 2 * tx + (k & 1), cy = 2 * ty + ((k >> 1) & 1), cz = 2 * tz + (k >> 2);
 		if (cx < gf.ntx && cy < gf.nty && cz < gf.ntz) any |= ff[cx + gf.ntx * (cy + gf.nty * cz)];
 	}
+	if (has_unknown && !has_unknown[t]) any = 0;
 	fc[t] = any ? 1u : 0u;
 }
 __global__ void k_mg_compact(const uint32_t *flag, const uint32_t *scan, int *list, int nt) {
@@ -269,6 +282,7 @@ struct MgSmall {
 	int *tiles[MG_MAX_LEVELS], *nbr[MG_MAX_LEVELS];
 	void *x[MG_MAX_LEVELS], *b[MG_MAX_LEVELS], *y[MG_MAX_LEVELS];
 	uint8_t *abits[MG_MAX_LEVELS];
+	const uint8_t *l1_has_unknown;     // level 1 (when it is among these levels): only tiles that hold an unknown are active; null: all
 };
 /// flags from the children's flags, exclusive scan, ascending list, count: level after level, one workgroup
 __global__ void __launch_bounds__(1024) k_mg_small_lists(MgSmall P, uint32_t *counts) {
@@ -296,6 +310,7 @@ __global__ void __launch_bounds__(1024) k_mg_small_lists(MgSmall P, uint32_t *co
 					}
 				}
 				any = any ? 1u : 0u;
+				if (l == 1 && P.l1_has_unknown && !P.l1_has_unknown[t]) any = 0u;
 				fl[cur][t] = any;
 				P.flag[l][t] = any;
 			}
@@ -335,7 +350,8 @@ template <typename real> __global__ void __launch_bounds__(256) k_mg_small_table
 	const int lane = threadIdx.x & 63, nt = P.g[l].nt;
 	for (int t0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63; t0 < nt; t0 += gridDim.x * blockDim.x) {
 		const int t = t0 + lane;
-		unsigned long long gone = __ballot(t < nt && prev[t] && !cur[t]);
+		// (departed OR arrived: while a level-1 tile without unknowns is inactive its children still restrict into its right-hand side)
+		unsigned long long gone = __ballot(t < nt && (prev[t] != 0) != (cur[t] != 0));
 		while (gone) {
 			const int k = __ffsll((long long)gone) - 1;
 			gone &= gone - 1;
@@ -352,7 +368,7 @@ template <typename real>
 __global__ void __launch_bounds__(256)
 k_mg_clear_departed(const uint32_t *prev, const uint32_t *cur, int nt, real *x, real *b, real *y, uint8_t *abits) {
 	for (int t = blockIdx.x; t < nt; t += gridDim.x) {
-		if (!prev[t] || cur[t]) continue;
+		if ((prev[t] != 0) == (cur[t] != 0)) continue;  // (departed or arrived, see k_mg_small_tables)
 		for (int l = threadIdx.x; l < 512; l += 256) {
 			const size_t c = (size_t)t * 512 + l;
 			x[c] = (real)0; b[c] = (real)0; y[c] = (real)0; abits[c] = 0;
@@ -2247,6 +2263,7 @@ void lfa_mg_free(lfa_sim *s) {
 			if (p) (void)hipFree(p);
 	}
 	if (s->mg->l1_dirty) (void)hipFree(s->mg->l1_dirty);
+	if (s->mg->l1_has_fluid) (void)hipFree(s->mg->l1_has_fluid);
 	if (s->mg->counts) (void)hipFree(s->mg->counts);
 	delete s->mg;
 	s->mg = nullptr;
@@ -2288,6 +2305,12 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 		M.l1_dirty = nullptr;
 		M.solid_epoch = 0;  // forces a full pass
 		if (nl > 1) LFA_HIP(s, hipMalloc(&M.l1_dirty, (size_t)gs[1].nt));
+		if (M.l1_has_fluid) LFA_HIP(s, hipFree(M.l1_has_fluid));
+		M.l1_has_fluid = nullptr;
+		if (nl > 1) {
+			LFA_HIP(s, hipMalloc(&M.l1_has_fluid, (size_t)gs[1].nt));
+			LFA_HIP(s, hipMemsetAsync(M.l1_has_fluid, 0, (size_t)gs[1].nt, s->stream));  // (a tile no pass has visited has no flagged child either)
+		}
 		if (!M.counts) LFA_HIP(s, hipMalloc(&M.counts, MG_MAX_LEVELS * 4));
 		for (int l = 0; l < nl; ++l) {
 			lfa_mg_level &L = M.lv[l];
@@ -2356,11 +2379,20 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 			SP.flag[l] = L.flag; SP.prev[l] = L.prev_flag; SP.tiles[l] = L.tiles; SP.nbr[l] = L.nbr;
 			SP.x[l] = L.x; SP.b[l] = L.b; SP.y[l] = L.y; SP.abits[l] = L.abits;
 		}
+		// level 1's types first: its active set is the parents of the particle tiles THAT HOLD AN UNKNOWN of level 1 (round 6)
+		const uint8_t *l1_has = (nl > 1 && !s->knobs.mg_no_prune) ? (const uint8_t *)M.l1_has_fluid : (const uint8_t *)nullptr;
+		if (nl > 1) {
+			hipLaunchKernelGGL(k_mg_types_from_fine_dirty, dim3(std::min(gs[1].nt, 8192)), dim3(256), 0, s->stream, gs[0], gs[1],
+			                   (const uint32_t *)s->tile_flag, (const uint32_t *)s->cell_count, (const uint8_t *)s->ctype,
+			                   (const uint8_t *)s->solid, M.lv[1].ctype, M.l1_dirty, M.solid_epoch != s->solid_epoch ? 1 : 0, M.l1_has_fluid);
+			M.solid_epoch = s->solid_epoch;
+		}
+		SP.l1_has_unknown = l1_has;
 		hipLaunchKernelGGL(k_mg_flag_level0, dim3((gs[0].nt + 255) / 256), dim3(256), 0, s->stream, (const int *)s->tile_pslot,
 		                   M.lv[0].flag, gs[0].nt);
 		for (int l = 1; l < small; ++l)
 			hipLaunchKernelGGL(k_mg_flag_parents, dim3((gs[l].nt + 255) / 256), dim3(256), 0, s->stream, gs[l - 1], gs[l],
-			                   (const uint32_t *)M.lv[l - 1].flag, M.lv[l].flag);
+			                   (const uint32_t *)M.lv[l - 1].flag, M.lv[l].flag, l == 1 ? l1_has : (const uint8_t *)nullptr);
 		LFA_LAUNCH_CHECK(s);
 		for (int l = 0; l < small; ++l) {
 			lfa_mg_level &L = M.lv[l];
@@ -2528,10 +2560,7 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 		const size_t c0 = (size_t)t0 * 512, count = (size_t)(t1 - t0) * 512;
 		const unsigned grid = (unsigned)((count + 255) / 256);
 		if (l == 1 && !dist) {
-			hipLaunchKernelGGL(k_mg_types_from_fine_dirty, dim3(std::min(gs[1].nt, 8192)), dim3(256), 0, s->stream, gs[0], gs[1],
-			                   (const uint32_t *)s->tile_flag, (const uint32_t *)s->cell_count, (const uint8_t *)s->ctype,
-			                   (const uint8_t *)s->solid, L.ctype, M.l1_dirty, M.solid_epoch != s->solid_epoch ? 1 : 0);
-			M.solid_epoch = s->solid_epoch;
+			// (done in front of the tile lists above)
 		} else if (l == 1)
 			hipLaunchKernelGGL(k_mg_types_from_fine, dim3(grid), dim3(256), 0, s->stream, gs[0], gs[1], c0, count, zlo, zhi,
 			                   (const uint32_t *)s->tile_flag, (const uint32_t *)s->cell_count, (const uint8_t *)s->ctype,
@@ -2589,7 +2618,9 @@ enum { MG_PART_PRE0 = 1, MG_PART_DOWN0 = 2, MG_PART_COARSE = 4, MG_PART_UP0 = 8,
 template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, bool level0_presmoothed, int parts = MG_PART_ALL) {
 	lfa_mg &M = *s->mg;
 	const int nl = M.n_levels;
-	const int last = nl - 1;  // every level down to the single-tile one has active tiles
+	// every level down to the single-tile one has active tiles - unless level 1 has none (nothing but spray: no coarse cell is an
+	// unknown), which leaves the finest level's sweeps alone
+	const int last = (nl > 1 && M.lv[1].n_tiles == 0 && !mg_dist(s)) ? 0 : nl - 1;
 	auto lvl = [&](int l) {
 		const lfa_mg_level &L = M.lv[l];
 		return MgLv<real>{L.tiles, L.nbr, L.n_tiles, L.g, l == 0 ? (const uint8_t *)s->abits : (const uint8_t *)L.abits,
@@ -2597,11 +2628,17 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 	};
 	const real inv_scale = (real)(1.0 / s->a_scale);
 	const int *st = (const int *)s->pcg_state;
-	if (last == 0) {  // a single level: the two sweeps alone
+	if (last == 0) {  // a single level (a grid of one tile, or no coarse unknown anywhere): the two sweeps alone
 		const MgLv<real> L = lvl(0);
-		if (!level0_presmoothed) hipLaunchKernelGGL(k_mg_presmooth<real>, dim3(1), dim3(256), 0, s->stream, L, st);
-		launch_up0<real>(1, s->stream, L, L.g, (const real *)nullptr, inv_scale, part_sigma, st);
+		if (!level0_presmoothed && (parts & MG_PART_PRE0))
+			hipLaunchKernelGGL(k_mg_presmooth<real>, dim3(std::max(1, std::min((L.n_tiles + PCG_WAVES - 1) / PCG_WAVES, MG_RR_GRID))), dim3(256), 0,
+			                   s->stream, L, st);
+		if (parts & MG_PART_UP0) launch_up0<real>(mg_grid(L.n_tiles), s->stream, L, L.g, (const real *)nullptr, inv_scale, part_sigma, st);
 		LFA_LAUNCH_CHECK(s);
+		if (parts == MG_PART_ALL) {
+			M.launches_per_cycle = 1 + 1;
+			M.first_co = 0;
+		}
 		return LFA_OK;
 	}
 	int tail = last;  // first level handled by the single-workgroup tail

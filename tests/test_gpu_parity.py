@@ -516,6 +516,62 @@ def test_multigrid_single_launch_coarse_levels_are_bitwise_the_launch_per_phase_
         assert np.array_equal(res[0][1], other[1])
 
 
+@pytest.mark.parametrize("dtype", [lfa.PCG_F32, lfa.PCG_F64])
+@pytest.mark.parametrize("scene", ["pool_and_spray", "spray_only", "moving"])
+def test_level_1_tiles_without_unknowns_are_left_out_bitwise(scene, dtype, monkeypatch):
+    """Round 6: a level-1 tile that holds no unknown of level 1 - the parent of spray, of a film thinner than a coarse cell (a coarse
+    cell is AIR as soon as one child is) - is no longer in level 1's active set; levels 2.. are the parents of what is left. Such a
+    tile only ever computed zeros, so the V-cycle is the same operator: identical iteration counts and bit-identical pressures
+    against LFA_MG_NO_PRUNE=1, fewer tiles on the coarse levels. "spray_only": NO coarse cell is an unknown - the hierarchy is the
+    finest level's sweeps alone. "moving": the active set changes from step to step (tiles arrive in and leave level 1 while their
+    children keep restricting into them)."""
+    size = (96, 64, 80)
+    rng = np.random.default_rng(5)
+    if scene == "moving":
+        parts = util.scenes.seed_block((0, 0, 0), (40, 40, 30))
+    else:
+        # droplets: single cells with 8 particles each, scattered over the air
+        cells = np.unique(rng.integers([0, 30, 0], [96, 64, 80], size=(400, 3)), axis=0)
+        sub = np.array([(a, b, c) for a in (0.25, 0.75) for b in (0.25, 0.75) for c in (0.25, 0.75)])
+        pos = (cells[:, None, :] + sub[None, :, :]).reshape(-1, 3)
+        spray = np.zeros(len(pos), dtype=lfa.PARTICLE_DTYPE)
+        spray["pos"] = pos
+        spray["vel"] = rng.normal(size=pos.shape) * 20.0
+        parts = spray if scene == "spray_only" else np.concatenate([util.scenes.seed_block((0, 0, 0), (96, 20, 80)), spray])
+    res = []
+    for prune in (True, False):
+        monkeypatch.delenv("LFA_MG_NO_PRUNE", raising=False)
+        if not prune:
+            monkeypatch.setenv("LFA_MG_NO_PRUNE", "1")
+        s = lfa.Sim(size, precond=lfa.PRECOND_MULTIGRID, pcg_dtype=dtype)
+        s.upload_particles(parts)
+        its, ps, tiles = [], [], []
+        for k in range(12 if scene == "moving" else 2):
+            if scene == "moving":
+                r, it, rc = s.time_step(min(3.0 * s.cfl(), 0.033))
+            else:
+                r, it, rc = s.step_hot(util.DT)
+            assert rc == 0
+            its.append(it)
+            tiles.append(s.mg_level_tiles())
+            if scene != "moving" or k >= 10:
+                ps.append(s.pressure().copy())
+        assert s.solver_stats()["device_waits_given_up"] == 0
+        res.append((its, ps, tiles))
+        s.close()
+    (its_p, ps_p, tiles_p), (its_n, ps_n, tiles_n) = res
+    if scene == "moving":  # (full steps: the position correction sums in atomic order - the runs drift apart in the last bits)
+        assert all(abs(a - b) <= 1 for a, b in zip(its_p, its_n)), (its_p, its_n)
+    else:
+        assert its_p == its_n, (its_p, its_n)
+        assert all(np.array_equal(a, b) for a, b in zip(ps_p, ps_n))
+        # fewer level-1 tiles: the droplets' parents hold no coarse unknown
+        l1 = lambda t: t[1] if len(t) > 1 else 0  # (mg_level_tiles drops trailing empty levels)
+        assert l1(tiles_p[-1]) < l1(tiles_n[-1]), (tiles_p[-1], tiles_n[-1])
+        if scene == "spray_only":
+            assert len(tiles_p[-1]) == 1, tiles_p[-1]
+
+
 def test_multigrid_single_launch_coarse_levels_repeat_bitwise_over_many_solves():
     """The hand-off between the phases of k_mg_coarse is a race if it is wrong: 40 solves of the same system must all return the
     same bits."""
