@@ -58,6 +58,8 @@ struct ParticleSoA {
 	void *base = nullptr;
 };
 
+#define LFA_CLOSED_MAX_UNKNOWNS 64  // a closed tile (lfa_sim::tile_closed) holds at most this many unknowns: a few dozen sweeps solve it
+
 struct GridDims {
 	int nx, ny, nz;     // real grid
 	int ntx, nty, ntz;  // tiles
@@ -76,6 +78,7 @@ struct lfa_knobs {
 	                          // into the launch in launch order)
 	int mg_no_prune = 0;      // LFA_MG_NO_PRUNE=1: every parent of a particle tile is an active level-1 tile, also one that holds no unknown
 	                          // (the bitwise A/B of round 6's pruned level-1 set)
+	int mg_no_closed = 0;     // LFA_MG_NO_CLOSED=1: closed tiles (lfa_sim::tile_closed) stay in the PCG like every other tile (the A/B)
 	int mg_no_tagged = 0;     // LFA_MG_NO_TAGGED=1: k_mg_coarse hands over through the level arrays + ready flags also with fp32 vectors
 	                          // (what fp64 vectors always do; the bitwise A/B of the tagged hand-off)
 };
@@ -200,6 +203,9 @@ struct lfa_sim {
 	bool gate_counted = false;  // this handle is in the device's count of live handles (lfa_co_gate_handle)
 	// warm start of the PCG (lfa_params.pcg_warm_start)
 	uint32_t *tile_epoch = nullptr;   // [nt] solve counter of the last solve a tile took part in
+	// [nt] 1: the tile's unknowns couple to nothing outside the tile (spray) and are few: its block of the pressure matrix is solved on
+	// its own, once, and the tile stays out of the PCG's tile list (k_abits writes it for every particle tile; mg.hip, round 6)
+	uint8_t *tile_closed = nullptr;
 	uint32_t solve_epoch = 0;         // counter of system builds
 	uint32_t pressure_epoch = 0;      // solve the pressure in vp belongs to (0: none / replaced by an upload)
 	bool warm_started = false;        // the system just built starts from the previous pressure: r = b - A p is still due

@@ -226,6 +226,7 @@ static void lfa_knobs_parse(lfa_knobs &k) {
 	k.mg_no_tagged = flag("LFA_MG_NO_TAGGED", 0);
 	k.mg_no_top = flag("LFA_MG_NO_TOP", 0);
 	k.mg_no_prune = flag("LFA_MG_NO_PRUNE", 0);
+	k.mg_no_closed = flag("LFA_MG_NO_CLOSED", 0);
 	{
 		static std::once_flag once;
 		std::call_once(once, [&] {
@@ -346,7 +347,7 @@ extern "C" void lfa_destroy(lfa_sim *s) {
 	lfa_pool_nosync_begin();
 	free_soa(s->pb[0]);
 	free_soa(s->pb[1]);
-	void *ptrs[] = {s->c_home, s->fine_start, s->corr_ovf, s->tile_clear, s->tile_epoch, s->src_cell, s->src_lo, s->src_target, s->src_of, s->src_need, s->src_vel, s->coerce_map, s->grid_flag, s->rank, s->vc_src, s->tile_count, s->tile_start, s->tile_flag, s->tile_scan, s->ptiles_all, s->dtiles, s->halo_tiles, s->dist_red,
+	void *ptrs[] = {s->c_home, s->fine_start, s->corr_ovf, s->tile_clear, s->tile_epoch, s->tile_closed, s->src_cell, s->src_lo, s->src_target, s->src_of, s->src_need, s->src_vel, s->coerce_map, s->grid_flag, s->rank, s->vc_src, s->tile_count, s->tile_start, s->tile_flag, s->tile_scan, s->ptiles_all, s->dtiles, s->halo_tiles, s->dist_red,
 	                s->xbuf[0], s->xbuf[1], s->xbuf[2], s->xbuf[3],
 	                s->tile_pslot, s->scan_tmp, s->u, s->v, s->w, s->uo, s->vo, s->wo, s->ctype, s->solid,
 	                s->cell_count, s->stage, s->acc, s->abits, s->vp, s->vr, s->vz, s->vs, s->vpre, s->vq, s->vs2, s->c_as, s->nbr_table,

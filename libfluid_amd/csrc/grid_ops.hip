@@ -44,7 +44,10 @@ __device__ inline int halo_index(int l) { return ((l & 7) + 1) + 10 * (((l >> 3)
 // ---------------------------------------------------------------------------------------------- a10: A bits
 /// pressure_solver::_compute_a_matrix (src/pressure_solver.cpp:160-178) for every cell of every particle tile;
 /// non-unknown cells get 0 so that the PCG kernels can use the byte as a mask.
-__global__ void __launch_bounds__(256) k_abits(const int *ptiles, int n_ptiles, GridView gv, uint8_t *abits) {
+/// `tile_closed` (may be null): 1 for a tile whose unknowns couple to nothing outside the tile - no unknown on a tile face has a
+/// coupling across it (the +d bit of the cell, or, towards -d, a fluid cell next to an unknown: pressure_solver.cpp:334-362) - and
+/// are at most LFA_CLOSED_MAX_UNKNOWNS: spray. Its block of the matrix is solved on its own (mg.hip: k_mg_solve_closed).
+__global__ void __launch_bounds__(256) k_abits(const int *ptiles, int n_ptiles, GridView gv, uint8_t *abits, uint8_t *tile_closed) {
 	__shared__ uint8_t H[LFA_HALO_CELLS];
 	for (int slot = blockIdx.x; slot < n_ptiles; slot += gridDim.x) {
 		const int tile = ptiles[slot];
@@ -52,6 +55,7 @@ __global__ void __launch_bounds__(256) k_abits(const int *ptiles, int n_ptiles, 
 		tile_coords(gv.g, tile, tx, ty, tz);
 		__syncthreads();
 		stage_halo_types(gv, tx, ty, tz, H);
+		int n_unknown = 0, open = 0;
 #pragma unroll
 		for (int half = 0; half < 2; ++half) {
 			const int l = threadIdx.x + 256 * half;
@@ -63,10 +67,21 @@ __global__ void __launch_bounds__(256) k_abits(const int *ptiles, int n_ptiles, 
 				const int txp = H[h + 1] & 7, typ = H[h + 10] & 7, tzp = H[h + 100] & 7;
 				int ns = (txp != CT_SOLID) + (typ != CT_SOLID) + (tzp != CT_SOLID) + ((H[h - 1] & 7) != CT_SOLID) +
 				         ((H[h - 10] & 7) != CT_SOLID) + ((H[h - 100] & 7) != CT_SOLID);
+				const bool fluid = (H[h] & 7) == CT_FLUID;
 				a = (uint8_t)(ns | ((txp == CT_FLUID) << 3) | ((typ == CT_FLUID) << 4) | ((tzp == CT_FLUID) << 5) |
-				              AB_UNKNOWN | (((H[h] & 7) == CT_FLUID) ? AB_FLUID : 0));
+				              AB_UNKNOWN | (fluid ? AB_FLUID : 0));
+				++n_unknown;
+				// a coupling that leaves the tile: upwards the cell's own bit, downwards a fluid cell beside an unknown
+				const int lx = l & 7, ly = (l >> 3) & 7, lz = l >> 6;
+				open |= (lx == 7 && txp == CT_FLUID) | (ly == 7 && typ == CT_FLUID) | (lz == 7 && tzp == CT_FLUID);
+				open |= fluid && ((lx == 0 && (H[h - 1] & HT_UNKNOWN)) | (ly == 0 && (H[h - 10] & HT_UNKNOWN)) | (lz == 0 && (H[h - 100] & HT_UNKNOWN)));
 			}
 			abits[b] = a;
+		}
+		if (tile_closed) {  // (uniform)
+			const int any_open = __syncthreads_or(open);
+			const int n1 = __syncthreads_count(n_unknown >= 1), n2 = __syncthreads_count(n_unknown >= 2);
+			if (threadIdx.x == 0) tile_closed[tile] = (uint8_t)(!any_open && n1 + n2 >= 1 && n1 + n2 <= LFA_CLOSED_MAX_UNKNOWNS);
 		}
 	}
 }
@@ -482,8 +497,12 @@ int lfa_build_rhs(lfa_sim *s, double dt) {
 	s->sys_dt = dt;
 	if (!s->n_ptiles) return LFA_OK;
 	GridView gv = make_view(s);
+	if (!s->tile_closed) {
+		LFA_HIP(s, hipMalloc(&s->tile_closed, (size_t)s->g.nt));
+		LFA_HIP(s, hipMemsetAsync(s->tile_closed, 0, (size_t)s->g.nt, s->stream));
+	}
 	hipLaunchKernelGGL(k_abits, dim3(grid_blocks(s->n_ptiles)), dim3(256), 0, s->stream, s->ptiles, s->n_ptiles, gv,
-	                   s->abits);
+	                   s->abits, s->tile_closed);
 	LFA_LAUNCH_CHECK(s);
 	// (once per solve and bandwidth bound: as many workgroups as the partial-sum array holds - the cap of the iteration's kernels,
 	// lfa_pcg_grid_cap = 768, is tuned for their latency chains and costs this kernel 83 us at C4: 94 -> 177)

@@ -82,6 +82,11 @@ struct lfa_mg {
 	// restricted residual is combined by a sum all-reduce and each rank runs the identical remaining V-cycle.
 	int n_dist = 0;
 	std::vector<int> host_top;    // active tiles of level n_dist (all ranks') the replicated lists were built for
+	// Round 6: closed tiles (lfa_sim::tile_closed - spray whose unknowns couple to nothing outside their tile) are no tiles of level 0:
+	// the PCG iterates over lv[0].tiles, a compacted list, and finds a neighbour's slot in slot0 (device, per tile of the grid, -1:
+	// not in the list). Off (null, lv[0].tiles = the binning's list): slabs, LFA_MG_NO_CLOSED=1, a grid of one tile.
+	int *slot0 = nullptr;
+	bool closed_out = false;  // the last set-up left closed tiles out
 	uint8_t *l1_dirty = nullptr;  // device, per level-1 tile: a child tile was flagged at the last set-up (k_mg_types_from_fine_dirty)
 	// device, per level-1 tile: the tile holds an unknown of level 1 (k_mg_types_from_fine_dirty). Round 6: a level-1 tile WITHOUT
 	// one - the parent of spray, of a film thinner than a coarse cell - is no longer active (single domain): it computed zeros.
@@ -222,9 +227,17 @@ __global__ void __launch_bounds__(256) k_mg_abits(const int *tiles, int n_tiles,
 }
 // ---- single domain: active-tile lists and neighbour tables of every level without a host round trip per level
 /// flag0[t] = tile t holds particles (slot table of the binning)
-__global__ void k_mg_flag_level0(const int *tile_pslot, uint32_t *flag, int nt) {
+/// (`closed`, may be null: ... and is not a closed tile, lfa_sim::tile_closed)
+__global__ void k_mg_flag_level0(const int *tile_pslot, const uint8_t *closed, uint32_t *flag, int nt) {
 	const int t = blockIdx.x * blockDim.x + threadIdx.x;
-	if (t < nt) flag[t] = tile_pslot[t] >= 0 ? 1u : 0u;
+	if (t < nt) flag[t] = (tile_pslot[t] >= 0 && !(closed && closed[t])) ? 1u : 0u;
+}
+/// k_mg_compact that also leaves every tile's slot in the list (-1: not in it)
+__global__ void k_mg_compact_slots(const uint32_t *flag, const uint32_t *scan, int *list, int *slot, int nt) {
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= nt) return;
+	if (flag[t]) list[scan[t]] = t;
+	slot[t] = flag[t] ? (int)scan[t] : -1;
 }
 /// a tile is active if one of its (up to 8) child tiles is
 /// (`has_unknown`, level 1 of a single domain: ... and holds an unknown of its own - lfa_mg::l1_has_fluid)
@@ -2264,6 +2277,7 @@ void lfa_mg_free(lfa_sim *s) {
 	}
 	if (s->mg->l1_dirty) (void)hipFree(s->mg->l1_dirty);
 	if (s->mg->l1_has_fluid) (void)hipFree(s->mg->l1_has_fluid);
+	if (s->mg->slot0) (void)hipFree(s->mg->slot0);
 	if (s->mg->counts) (void)hipFree(s->mg->counts);
 	delete s->mg;
 	s->mg = nullptr;
@@ -2307,6 +2321,8 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 		if (nl > 1) LFA_HIP(s, hipMalloc(&M.l1_dirty, (size_t)gs[1].nt));
 		if (M.l1_has_fluid) LFA_HIP(s, hipFree(M.l1_has_fluid));
 		M.l1_has_fluid = nullptr;
+		if (M.slot0) LFA_HIP(s, hipFree(M.slot0));
+		M.slot0 = nullptr;
 		if (nl > 1) {
 			LFA_HIP(s, hipMalloc(&M.l1_has_fluid, (size_t)gs[1].nt));
 			LFA_HIP(s, hipMemsetAsync(M.l1_has_fluid, 0, (size_t)gs[1].nt, s->stream));  // (a tile no pass has visited has no flagged child either)
@@ -2388,16 +2404,27 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 			M.solid_epoch = s->solid_epoch;
 		}
 		SP.l1_has_unknown = l1_has;
+		// closed tiles are solved on their own (k_mg_solve_closed): level 0 is what is left of the particle tiles
+		const bool closed_out = nl > 1 && !s->dist && !s->knobs.mg_no_closed && s->tile_closed;
+		M.closed_out = closed_out;
+		if (closed_out && !M.slot0) LFA_HIP(s, hipMalloc(&M.slot0, (size_t)gs[0].nt * 4));
 		hipLaunchKernelGGL(k_mg_flag_level0, dim3((gs[0].nt + 255) / 256), dim3(256), 0, s->stream, (const int *)s->tile_pslot,
-		                   M.lv[0].flag, gs[0].nt);
+		                   closed_out ? (const uint8_t *)s->tile_closed : (const uint8_t *)nullptr, M.lv[0].flag, gs[0].nt);
 		for (int l = 1; l < small; ++l)
 			hipLaunchKernelGGL(k_mg_flag_parents, dim3((gs[l].nt + 255) / 256), dim3(256), 0, s->stream, gs[l - 1], gs[l],
 			                   (const uint32_t *)M.lv[l - 1].flag, M.lv[l].flag, l == 1 ? l1_has : (const uint8_t *)nullptr);
 		LFA_LAUNCH_CHECK(s);
 		for (int l = 0; l < small; ++l) {
 			lfa_mg_level &L = M.lv[l];
-			if (l == 0) {  // the binning's own list
+			if (l == 0 && !closed_out) {  // the binning's own list
 				LFA_HIP(s, hipMemcpyAsync(L.tiles, s->ptiles, (size_t)s->n_ptiles * 4, hipMemcpyDeviceToDevice, s->stream));
+				continue;
+			}
+			if (l == 0) {
+				LFA_TRY(lfa_exclusive_scan_u32(s, L.flag, s->tile_scan, (size_t)gs[0].nt, M.counts));
+				hipLaunchKernelGGL(k_mg_compact_slots, dim3((gs[0].nt + 255) / 256), dim3(256), 0, s->stream, (const uint32_t *)L.flag,
+				                   (const uint32_t *)s->tile_scan, L.tiles, M.slot0, gs[0].nt);
+				LFA_LAUNCH_CHECK(s);
 				continue;
 			}
 			LFA_TRY(lfa_exclusive_scan_u32(s, L.flag, s->tile_scan, (size_t)gs[l].nt, M.counts + l));  // gs[l].nt <= nt / 8
@@ -2421,7 +2448,7 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 		}
 		for (int l = 0; l < small; ++l) {
 			lfa_mg_level &L = M.lv[l];
-			L.n_tiles = l == 0 ? s->n_ptiles : (int)hc[l];
+			L.n_tiles = (l == 0 && !closed_out) ? s->n_ptiles : (int)hc[l];
 			if (L.n_tiles) {
 				hipLaunchKernelGGL(k_mg_build_nbr, dim3((L.n_tiles + 255) / 256), dim3(256), 0, s->stream, (const int *)L.tiles, L.n_tiles,
 				                   gs[l], (const uint32_t *)L.flag, L.nbr, gs[l > 0 ? l - 1 : 0],
@@ -2879,8 +2906,10 @@ int lfa_mg_apply(lfa_sim *s, double *part_sigma) {
 template <typename real>
 static int mg_axpy_apply_t(lfa_sim *s, const void *sdir, const double *part_sigma, int n_sigma, const double *part_qs, int n_qs,
                            double *part_rmax, double *part_sigma_new) {
-	const int G = mg_grid(s->n_ptiles);
-	launch_axpy_presmooth<real>(G, s->stream, (const int *)s->ptiles, s->n_ptiles, (const uint8_t *)s->abits, (real *)s->vp,
+	const int *tiles0;
+	const int n0 = lfa_mg_level0(s, &tiles0, nullptr);
+	const int G = mg_grid(n0);
+	launch_axpy_presmooth<real>(G, s->stream, tiles0, n0, (const uint8_t *)s->abits, (real *)s->vp,
 	                            (const real *)sdir, (real *)s->vr, (real *)s->vq, part_sigma, n_sigma, part_qs, n_qs, part_rmax,
 	                            (const int *)s->pcg_state);
 	LFA_LAUNCH_CHECK(s);
@@ -2918,6 +2947,103 @@ int lfa_mg_axpy_apply(lfa_sim *s, const void *sdir, const double *part_sigma, in
 /// For lfa_bench_kernel: one part of an iteration on the state left by the last solve. 0: AXPYs + level-0 pre-smoothing,
 /// 1: level-0 residual + restriction, 2: all coarser levels (down, single-workgroup tail, up), 3: level-0 prolongation +
 /// post-smoothing + dot.
+/// The tiles the PCG iterates over (the finest level's list), their number, and (may be null: the binning's slot table) the slot of
+/// every tile of the grid in that list. After lfa_mg_setup.
+int lfa_mg_level0(const lfa_sim *s, const int **tiles, const int **slot) {
+	const lfa_mg &M = *s->mg;
+	if (tiles) *tiles = M.closed_out ? (const int *)M.lv[0].tiles : (const int *)s->ptiles;
+	if (slot) *slot = M.closed_out ? (const int *)M.slot0 : (const int *)s->tile_pslot;
+	return M.closed_out ? M.lv[0].n_tiles : s->n_ptiles;
+}
+
+namespace {
+/// A closed tile's block of A p = b, solved where it stands: red-black SOR sweeps from zero in LDS (a wave per tile, the smoother's
+/// own update; the ring stays zero - nothing outside the tile couples to it) until the residual's maximum is below `tol` or the
+/// rounding floor of the right-hand side, at most MG_CLOSED_SWEEPS sweeps (<= 64 unknowns with air all around: a few dozen do).
+/// p = x / scale (the operator here is unscaled, like the multigrid's). A NaN raises the solve's NaN word.
+#define MG_CLOSED_SWEEPS 512
+template <typename real>
+__global__ void __launch_bounds__(256)
+k_mg_solve_closed(const int *ptiles, int n_ptiles, const uint8_t *closed, const uint8_t *abits, const real *b, real *p, real inv_scale,
+                  real tol, int *state) {
+	__shared__ real halo[PCG_WAVES][LFA_HALO_CELLS];
+	if (state[0] >= 0) return;  // (the zero right-hand side's early-out: p stays 0 like the reference's, src/pressure_solver.cpp:33-35)
+	const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
+	real *h = halo[wid];
+	for (int slot = blockIdx.x * PCG_WAVES + wid; slot < n_ptiles; slot += gridDim.x * PCG_WAVES) {
+		const int tile = ptiles[slot];
+		if (!closed[tile]) continue;  // (uniform per wave)
+		const size_t base = (size_t)tile * 512;
+		uint32_t ab[8];
+		real bb[8];
+		real bmax = (real)0;
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) {
+			ab[zz] = abits[base + zz * 64 + lane];
+			bb[zz] = b[base + zz * 64 + lane];
+			bmax = fmax(bmax, fabs(bb[zz]));
+		}
+		MG_FENCE();
+		for (int i = lane; i < LFA_HALO_CELLS; i += 64) h[i] = (real)0;
+		MG_FENCE();
+#pragma unroll
+		for (int o = 32; o; o >>= 1) bmax = fmax(bmax, __shfl_xor(bmax, o, 64));
+		const real floor_ = bmax * (real)(sizeof(real) == 4 ? 4e-7 : 1e-15);
+		const real stop = tol > floor_ ? tol : floor_;
+		bool bad = bmax != bmax;
+		for (int sweep = 0; sweep < MG_CLOSED_SWEEPS && !bad; sweep += 4) {
+			for (int k = 0; k < 4; ++k) {
+				gs_colour<real>(h, ab, bb, lx, ly, 0);
+				MG_FENCE();
+				gs_colour<real>(h, ab, bb, lx, ly, 1);
+				MG_FENCE();
+			}
+			real rmax = (real)0;
+#pragma unroll
+			for (int zz = 0; zz < 8; ++zz) {
+				const int i = (lx + 1) + 10 * (ly + 1) + 100 * (zz + 1);
+				const uint32_t a = ab[zz];
+				if (a & AB_UNKNOWN) {
+					const real F = (a & AB_FLUID) ? (real)1 : (real)0;
+					real val = (real)(a & 7) * h[i];
+					val -= F * (h[i - 1] + h[i - 10] + h[i - 100]);
+					val -= (real)((a >> 3) & 1) * h[i + 1] + (real)((a >> 4) & 1) * h[i + 10] + (real)((a >> 5) & 1) * h[i + 100];
+					const real r = fabs(bb[zz] - val);
+					rmax = r > rmax || r != r ? r : rmax;
+				}
+			}
+#pragma unroll
+			for (int o = 32; o; o >>= 1) {
+				const real other = __shfl_xor(rmax, o, 64);
+				rmax = other > rmax || other != other ? other : rmax;
+			}
+			if (rmax != rmax) bad = true;
+			else if (rmax <= stop) break;
+		}
+		if (bad && lane == 0) state[1] = 1;
+#pragma unroll
+		for (int zz = 0; zz < 8; ++zz) p[base + zz * 64 + lane] = h[(lx + 1) + 10 * (ly + 1) + 100 * (zz + 1)] * inv_scale;
+		MG_FENCE();
+	}
+}
+}  // namespace
+
+/// Solves the closed tiles (after lfa_mg_setup and the right-hand side, before or beside the PCG: nothing is shared with it).
+int lfa_mg_solve_closed(lfa_sim *s) {
+	if (!s->mg || !s->mg->closed_out || !s->n_ptiles) return LFA_OK;
+	const int G = std::max(1, std::min((s->n_ptiles + PCG_WAVES - 1) / PCG_WAVES, 4096));
+	if (s->prm.pcg_dtype == LFA_PCG_F64)
+		hipLaunchKernelGGL(k_mg_solve_closed<double>, dim3(G), dim3(256), 0, s->stream, (const int *)s->ptiles, s->n_ptiles,
+		                   (const uint8_t *)s->tile_closed, (const uint8_t *)s->abits, (const double *)s->vr, (double *)s->vp,
+		                   1.0 / s->a_scale, 0.05 * s->prm.tolerance, s->pcg_state);
+	else
+		hipLaunchKernelGGL(k_mg_solve_closed<float>, dim3(G), dim3(256), 0, s->stream, (const int *)s->ptiles, s->n_ptiles,
+		                   (const uint8_t *)s->tile_closed, (const uint8_t *)s->abits, (const float *)s->vr, (float *)s->vp,
+		                   (float)(1.0 / s->a_scale), (float)(0.05 * s->prm.tolerance), s->pcg_state);
+	LFA_LAUNCH_CHECK(s);
+	return LFA_OK;
+}
+
 extern "C" int lfa_get_mg_level_tiles(lfa_sim *s, uint64_t tiles[LFA_MAX_MG_LEVELS]) {
 	if (!s || !tiles) return LFA_E_INVALID;
 	static_assert(LFA_MAX_MG_LEVELS == MG_MAX_LEVELS, "public and internal level caps differ");
@@ -2929,10 +3055,12 @@ int lfa_mg_bench_part(lfa_sim *s, int part) {
 	if (!s->mg || !s->mg->n_levels || !s->n_ptiles) return lfa_fail(s, LFA_E_INVALID, "multigrid bench: solve with LFA_PRECOND_MULTIGRID first");
 	const bool f64 = s->prm.pcg_dtype == LFA_PCG_F64;
 	double *P = s->partials;
-	const int G = mg_grid(s->n_ptiles);
+	const int *tiles0;
+	const int n0 = lfa_mg_level0(s, &tiles0, nullptr);
+	const int G = mg_grid(n0);
 	if (part == 0) {
-		if (f64) launch_axpy_presmooth<double>(G, s->stream, (const int *)s->ptiles, s->n_ptiles, (const uint8_t *)s->abits, (double *)s->vp, (const double *)s->vs, (double *)s->vr, (double *)s->vq, (const double *)(P + PART_SIG0), G, (const double *)(P + PART_ZS), G, P + PART_RMAX, (const int *)s->pcg_state);
-		else launch_axpy_presmooth<float>(G, s->stream, (const int *)s->ptiles, s->n_ptiles, (const uint8_t *)s->abits, (float *)s->vp, (const float *)s->vs, (float *)s->vr, (float *)s->vq, (const double *)(P + PART_SIG0), G, (const double *)(P + PART_ZS), G, P + PART_RMAX, (const int *)s->pcg_state);
+		if (f64) launch_axpy_presmooth<double>(G, s->stream, tiles0, n0, (const uint8_t *)s->abits, (double *)s->vp, (const double *)s->vs, (double *)s->vr, (double *)s->vq, (const double *)(P + PART_SIG0), G, (const double *)(P + PART_ZS), G, P + PART_RMAX, (const int *)s->pcg_state);
+		else launch_axpy_presmooth<float>(G, s->stream, tiles0, n0, (const uint8_t *)s->abits, (float *)s->vp, (const float *)s->vs, (float *)s->vr, (float *)s->vq, (const double *)(P + PART_SIG0), G, (const double *)(P + PART_ZS), G, P + PART_RMAX, (const int *)s->pcg_state);
 		LFA_LAUNCH_CHECK(s);
 		return LFA_OK;
 	}

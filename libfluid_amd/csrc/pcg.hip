@@ -1353,6 +1353,7 @@ int lfa_pcg_alloc(lfa_sim *s) {
 }
 
 static TileCtx make_ctx(lfa_sim *s) { return TileCtx{s->ptiles, s->n_ptiles, s->tile_pslot, s->g}; }
+
 template <typename real> static Vecs<real> make_vecs(lfa_sim *s) {
 	return Vecs<real>{(real *)s->vp, (real *)s->vr, (real *)s->vz, (real *)s->vs, (real *)s->vpre, (real *)s->vq};
 }
@@ -1383,8 +1384,16 @@ static int build_levels(lfa_sim *s) {
 // ---- multilevel preconditioner: host-side set-up -----------------------------------------------------------
 static bool is_ml(const lfa_sim *s) { return s->prm.precond == LFA_PRECOND_MULTILEVEL; }
 static bool is_mg(const lfa_sim *s) { return s->prm.precond == LFA_PRECOND_MULTIGRID; }
+/// The tiles the PCG ITERATES over: every particle tile - or, with the multigrid preconditioner on a single domain, those that are
+/// not closed (lfa_sim::tile_closed: spray, solved on its own by lfa_mg_solve_closed). Valid after the preconditioner's set-up.
+static TileCtx iter_ctx(lfa_sim *s) {
+	if (!is_mg(s) || !s->mg) return make_ctx(s);
+	const int *tiles, *slot;
+	const int n = lfa_mg_level0(s, &tiles, &slot);
+	return TileCtx{tiles, n, slot, s->g};
+}
 /// number of partial sums the consumers of sigma add up: one per workgroup (+1 for the coarse part of z.r)
-static int sigma_parts(const lfa_sim *s) { return pcg_grid(s->n_ptiles) + (is_ml(s) ? 1 : 0); }
+static int sigma_parts(lfa_sim *s) { return pcg_grid(iter_ctx(s).n_ptiles) + (is_ml(s) ? 1 : 0); }
 
 template <typename real> static CoarseFields<real> make_coarse(lfa_sim *s) {
 	CoarseFields<real> cf{s->c_diag, {s->c_w[0], s->c_w[1], s->c_w[2]}, s->c_unk, (real *)s->c_pre,
@@ -1591,9 +1600,13 @@ template <typename real> static int mic_factor(lfa_sim *s) {
 		if (is_ml(s)) LFA_TRY(coarse_setup<real>(s));
 		if ((s->prm.pcg_fused || is_mg(s)) && s->n_ptiles) {
 			if (!s->nbr_table) LFA_HIP(s, hipMalloc(&s->nbr_table, (size_t)s->g.nt * NBR_STRIDE * sizeof(int)));
-			hipLaunchKernelGGL(k_build_nbr_table, dim3((s->n_ptiles + 255) / 256), dim3(256), 0, s->stream, tc, s->p_off,
-			                   is_ml(s) ? (const int *)s->slot_l1 : (const int *)nullptr, (const int *)s->l1_l2, s->nbr_table);
-			LFA_LAUNCH_CHECK(s);
+			// (multigrid, single domain: the rows of the tiles the PCG iterates over - closed tiles are no neighbours of anybody)
+			TileCtx tcs = iter_ctx(s);
+			if (tcs.n_ptiles) {
+				hipLaunchKernelGGL(k_build_nbr_table, dim3((tcs.n_ptiles + 255) / 256), dim3(256), 0, s->stream, tcs, s->p_off,
+				                   is_ml(s) ? (const int *)s->slot_l1 : (const int *)nullptr, (const int *)s->l1_l2, s->nbr_table);
+				LFA_LAUNCH_CHECK(s);
+			}
 		}
 	}
 	return LFA_OK;
@@ -1723,7 +1736,9 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 	if (!s->n_ptiles && !s->dist) return LFA_OK;
 	TileCtx tc = make_ctx(s);
 	Vecs<real> v = make_vecs<real>(s);
-	const int G = pcg_grid(s->n_ptiles);
+	// the tiles the iteration runs over (multigrid, single domain: without the closed ones, which lfa_mg_solve_closed takes below)
+	const int n_it = iter_ctx(s).n_ptiles;
+	const int G = pcg_grid(n_it);
 	const real scale = (real)s->a_scale;
 	double *P = s->partials;
 	const bool dist = s->dist != nullptr;
@@ -1772,6 +1787,11 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 		LFA_LAUNCH_CHECK(s);
 	}
 	s->pressure_epoch = 0;  // set to this solve's epoch once it has converged: a NaN or a capped solve is no guess for the next one
+	if (is_mg(s)) LFA_TRY(lfa_mg_solve_closed(s));  // (spray: tiles whose unknowns couple to nothing outside - exact, once; a no-op after the early-out)
+	if (!n_it && !dist) {  // nothing but closed tiles: no iteration
+		s->pressure_epoch = s->solve_epoch;
+		return LFA_OK;
+	}
 	const int NS = sigma_parts(s);
 	// where the consumers find a reduced scalar: the per-workgroup partials (they re-add them in a fixed order), or -
 	// with slabs - the all-reduced value
@@ -1881,7 +1901,7 @@ template <typename real> static int solve_t(lfa_sim *s, double dt, double *resid
 			const int n_sig_po = dist ? (i == 0 ? 1 : nr) : (i == 0 ? NS : NSB), n_sig_pn = dist ? (i <= 1 ? 1 : nr) : (i <= 1 ? NS : NSB);
 			const double *rmax_prev = !dist ? P + PART_RMAX : (i == 0 ? red + 2 : lfa_dist_gather_buf(s, po));
 			const int n_rmax_prev = dist ? (i == 0 ? 1 : nr) : GB;
-			launch_pcg_a<real>(i == 0, is_ml(s), GA, s->stream, s->n_ptiles, (const int *)s->nbr_table, (const uint8_t *)s->abits,
+			launch_pcg_a<real>(i == 0, is_ml(s), GA, s->stream, n_it, (const int *)s->nbr_table, (const uint8_t *)s->abits,
 			                   (const real *)v.z, (const real *)sbuf[po], sbuf[pn], v.q, scale, sig_po, n_sig_po, sig_pn, n_sig_pn,
 			                   rmax_prev, n_rmax_prev, s->prm.tolerance, i, s->pcg_state,
 			                   s->pcg_hist, P + PART_ZS, cx, (const real *)s->c_x2, is_ml(s) ? (real *)s->c_as : (real *)nullptr);
@@ -2207,7 +2227,8 @@ int lfa_g2p_bench(lfa_sim *s);              // grid_ops.hip
 template <typename real> static int bench_launch(lfa_sim *s, int which) {
 	TileCtx tc = make_ctx(s);
 	Vecs<real> v = make_vecs<real>(s);
-	const int G = pcg_grid(s->n_ptiles);
+	const int n_it = iter_ctx(s).n_ptiles;  // (the fused kernels' rows: lfa_sim::nbr_table)
+	const int G = pcg_grid(which == LFA_K_PCG_A || which == LFA_K_PCG_B ? n_it : s->n_ptiles);
 	const real scale = (real)s->a_scale;
 	double *P = s->partials;
 	int GA, GB;
@@ -2234,7 +2255,7 @@ template <typename real> static int bench_launch(lfa_sim *s, int which) {
 		return coarse_apply<real>(s, P + PART_SIG1, s->stream);
 	case LFA_K_PCG_A:
 		if (!s->nbr_table || !(s->prm.pcg_fused || is_mg(s))) return lfa_fail(s, LFA_E_INVALID, "fused kernels: solve with pcg_fused = 1 first");
-		launch_pcg_a<real>(false, is_ml(s), is_mg(s) ? G : GA, s->stream, s->n_ptiles, (const int *)s->nbr_table, (const uint8_t *)s->abits,
+		launch_pcg_a<real>(false, is_ml(s), is_mg(s) ? G : GA, s->stream, n_it, (const int *)s->nbr_table, (const uint8_t *)s->abits,
 		                   (const real *)v.z, (const real *)v.s, (real *)s->vs2, v.q, scale, (const double *)(P + PART_SIG0), G,
 		                   (const double *)(P + PART_SIG0), G, (const double *)(P + PART_RMAX), G, -HUGE_VAL, 1, s->pcg_state,
 		                   s->pcg_hist + 4095, P + PART_ZS, is_ml(s) ? (const real *)s->c_x : (const real *)nullptr,

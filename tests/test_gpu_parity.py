@@ -572,6 +572,74 @@ def test_level_1_tiles_without_unknowns_are_left_out_bitwise(scene, dtype, monke
             assert len(tiles_p[-1]) == 1, tiles_p[-1]
 
 
+def _pool_and_droplets(size, pool_top, n_drops, seed, clusters=True):
+    """A pool wall to wall + droplets in the air above it: single cells and small clusters (some of them across a tile face)."""
+    rng = np.random.default_rng(seed)
+    nx, ny, nz = size
+    cells = rng.integers([1, pool_top + 3, 1], [nx - 2, ny - 2, nz - 2], size=(n_drops, 3))
+    if clusters:
+        grow = cells[::3] + rng.integers(0, 2, size=(len(cells[::3]), 3))  # a second cell beside every third droplet
+        cells = np.concatenate([cells, grow, np.array([[7, pool_top + 5, 8], [8, pool_top + 5, 8]])])  # one pair across a tile face (x = 7 | 8)
+    cells = np.unique(cells, axis=0)
+    sub = np.array([(a, b, c) for a in (0.25, 0.75) for b in (0.25, 0.75) for c in (0.25, 0.75)])
+    pos = (cells[:, None, :] + sub[None, :, :]).reshape(-1, 3)
+    spray = np.zeros(len(pos), dtype=lfa.PARTICLE_DTYPE)
+    spray["pos"] = pos
+    spray["vel"] = np.repeat(rng.normal(size=(len(cells), 3)) * 30.0, 8, axis=0) + rng.normal(size=pos.shape) * 3.0
+    pool = util.scenes.seed_block((0, 0, 0), (nx, pool_top, nz))
+    pool["vel"] = rng.normal(size=(len(pool), 3)) * 2.0
+    return np.concatenate([pool, spray]), len(cells)
+
+
+@pytest.mark.parametrize("dtype", [lfa.PCG_F32, lfa.PCG_F64])
+def test_closed_tiles_are_solved_on_their_own(dtype, monkeypatch):
+    """Round 6: a particle tile whose unknowns couple to nothing outside the tile (spray: at step 550 of the C3 run a third of the
+    tiles) is a block of the pressure matrix on its own. It is solved once, exactly (k_mg_solve_closed), and stays out of the tile
+    list the PCG iterates over. What must hold: fewer tiles in the iteration, the same pressures as with LFA_MG_NO_CLOSED=1 and as
+    the ORACLE's (the reference's PCG solves the droplets with everything else) under the usual bars - a droplet pair ACROSS a tile
+    face is not closed and stays in the PCG -, face and particle velocities after the whole hot pass likewise; and the early-out of a
+    zero right-hand side still returns p = 0 exactly."""
+    from oracle import loader as orc
+    size = (40, 40, 32)
+    parts, n_drops = _pool_and_droplets(size, 10, 90, 3)
+    o = orc.CpuSim(size, method=orc.APIC)
+    o.set_particles(parts)
+    po, reso, ito = o.hot_step(util.DT)
+    oc = o.cells()
+    res = []
+    for closed in (True, False):
+        monkeypatch.delenv("LFA_MG_NO_CLOSED", raising=False)
+        if not closed:
+            monkeypatch.setenv("LFA_MG_NO_CLOSED", "1")
+        s = lfa.Sim(size, precond=lfa.PRECOND_MULTIGRID, pcg_dtype=dtype)
+        s.upload_particles(parts)
+        r, it, rc = s.step_hot(util.DT)
+        assert rc == 0 and r < 1e-6
+        assert np.array_equal(s.fluid_cells(), o.fluid_cells())
+        p = s.pressure()
+        util.assert_close(p, po, P_REL, f"pressure, closed tiles {'out' if closed else 'in'}", pw=(1e-3, 1e-4))
+        gc = s.cells()
+        assert np.array_equal(gc["type"], oc["type"])
+        util.assert_close(gc["vel"], oc["vel"], 1e-4, "face velocities", atol=1e-5 * 981.0 * util.DT)
+        res.append((it, p, s.mg_level_tiles(), s.counts()["particle_tiles"]))
+        s.close()
+    (it_c, p_c, tiles_c, nt_c), (it_n, p_n, tiles_n, nt_n) = res
+    assert nt_c == nt_n == tiles_n[0] and tiles_c[0] < tiles_n[0] - 20, (tiles_c, tiles_n)  # dozens of droplet tiles left the iteration
+    assert abs(it_c - it_n) <= 1, (it_c, it_n)
+    # the droplets' own pressures (small against the pool's): the two device runs agree to the solvers' tolerance
+    util.assert_close(p_c, p_n, 1e-5, "pressure with / without the closed tiles in the PCG", pw=(2e-3, 1e-6))
+    # a block in free fall: divergence-free, the reference returns p = 0 without iterating (src/pressure_solver.cpp:33-35)
+    s = lfa.Sim(size, precond=lfa.PRECOND_MULTIGRID, pcg_dtype=dtype)
+    drops, _ = _pool_and_droplets(size, 0, 40, 4)
+    drops = drops[drops["pos"][:, 1] > 3.0]
+    drops["vel"] = (3.0, -20.0, 1.0)
+    s.upload_particles(drops)
+    r, it, rc = s.step_hot(util.DT)
+    assert rc == 0 and it == 0 and not s.pressure().any()
+    s.close()
+    o.close()
+
+
 def test_multigrid_single_launch_coarse_levels_repeat_bitwise_over_many_solves():
     """The hand-off between the phases of k_mg_coarse is a race if it is wrong: 40 solves of the same system must all return the
     same bits."""
