@@ -613,6 +613,41 @@ def main():
             kernels[name] = {"ms": ms, "algorithmic_bytes": b, "GBps": b / ms * 1e-6}
         out["kernels_isolated"] = kernels
 
+    if args.late > 0:
+        # (Before the hot-path and MIC(0) sections below: their lfa_step_hot calls - gravity kicks of dt_max without advection - would
+        # perturb the flow the window is meant to measure; round 5 had it behind them.)
+        # A second timed window late in the run: the sheet has spread, tiles are partly filled, the solve has more of them to visit
+        # and the position correction meets crowded blocks where the fluid has piled up. Same step, same accounting.
+        done_steps = preroll + args.warmup + args.steps * (2 if (overlapped and not args.no_serial_stages) else 1)
+        while done_steps < args.late:
+            one_step()
+            done_steps += 1
+        barrier()
+        tl = time.perf_counter()
+        late_it, late_stage = 0, []
+        for _ in range(args.late_steps):
+            _, it, _ = one_step()
+            late_it += it
+            late_stage.append(sim.step_timings())
+        barrier()
+        late_s = time.perf_counter() - tl
+        if dist is not None:
+            t = torch.tensor([late_s], dtype=torch.float64, device=tdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            late_s = float(t.item())
+        lc, lf = sim.counts(), sim.correction_stats_ex()
+        late_names = [k for k in late_stage[0] if k not in ("pcg_iterations", "overlapped")]
+        extras["late_phase"] = {
+            "from_step": done_steps, "steps": args.late_steps, "ms_per_step": 1e3 * late_s / args.late_steps,
+            "ratio_to_timed_region": (late_s / args.late_steps) / (elapsed / args.steps),
+            "particle_steps_per_sec": lc["particles"] * args.late_steps / late_s,
+            "pcg_iterations_per_step": late_it / args.late_steps,
+            "particle_tiles": lc["particle_tiles"], "processed_tiles": lc["processed_tiles"], "unknowns": lc["unknowns"],
+            "particles_per_particle_tile": lc["particles"] / max(lc["particle_tiles"], 1),
+            "particle_tiles_timed_region": counts["particle_tiles"], "processed_tiles_timed_region": counts["processed_tiles"],
+            "correction_fallback_half_tiles": {"flagged": lf[0], "of": lf[1], "second_pass": lf[2]},
+            "stage_ms_median": {k: med([s_[k] for s_ in late_stage]) for k in late_names},
+        }
     if world == 1 and not slabs and not args.no_hot_path:
         # secondary figure: the hot path alone (no advection / correction) on the state the dam has reached
         hot_ms, hot_it = [], 0
@@ -653,39 +688,6 @@ def main():
                            "algorithmic_GBps": 91 * n_unknowns * sum(its) / (sum(ms) * 1e-3) * 1e-9 if sum(ms) > 0 else None,
                            "note": "91 n bytes per iteration (SURVEY 8d); the reference does 58 MIC(0) iterations at C2 where this does 77"}
         sim.set_params(precond=lfa.PRECOND_MULTIGRID)
-    if args.late > 0:
-        # A second timed window late in the run: the sheet has spread, tiles are partly filled, the solve has more of them to visit
-        # and the position correction meets crowded blocks where the fluid has piled up. Same step, same accounting.
-        done_steps = preroll + args.warmup + args.steps * (2 if (overlapped and not args.no_serial_stages) else 1)
-        while done_steps < args.late:
-            one_step()
-            done_steps += 1
-        barrier()
-        tl = time.perf_counter()
-        late_it, late_stage = 0, []
-        for _ in range(args.late_steps):
-            _, it, _ = one_step()
-            late_it += it
-            late_stage.append(sim.step_timings())
-        barrier()
-        late_s = time.perf_counter() - tl
-        if dist is not None:
-            t = torch.tensor([late_s], dtype=torch.float64, device=tdev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            late_s = float(t.item())
-        lc, lf = sim.counts(), sim.correction_stats_ex()
-        late_names = [k for k in late_stage[0] if k not in ("pcg_iterations", "overlapped")]
-        extras["late_phase"] = {
-            "from_step": done_steps, "steps": args.late_steps, "ms_per_step": 1e3 * late_s / args.late_steps,
-            "ratio_to_timed_region": (late_s / args.late_steps) / (elapsed / args.steps),
-            "particle_steps_per_sec": lc["particles"] * args.late_steps / late_s,
-            "pcg_iterations_per_step": late_it / args.late_steps,
-            "particle_tiles": lc["particle_tiles"], "processed_tiles": lc["processed_tiles"], "unknowns": lc["unknowns"],
-            "particles_per_particle_tile": lc["particles"] / max(lc["particle_tiles"], 1),
-            "particle_tiles_timed_region": counts["particle_tiles"], "processed_tiles_timed_region": counts["processed_tiles"],
-            "correction_fallback_half_tiles": {"flagged": lf[0], "of": lf[1], "second_pass": lf[2]},
-            "stage_ms_median": {k: med([s_[k] for s_ in late_stage]) for k in late_names},
-        }
     if args.mesh and (world == 1 or slabs):
         # BASELINE configs[4]: the surface of the resident particles (mesher settings of testbed/main.cpp:101-107 at cell size 1).
         # On slabs every rank meshes its own cell layers (lfa_mesher_create_window) from its own particles and the ghost copies of
