@@ -539,6 +539,7 @@ def test_level_1_tiles_without_unknowns_are_left_out_bitwise(scene, dtype, monke
         spray["vel"] = rng.normal(size=pos.shape) * 20.0
         parts = spray if scene == "spray_only" else np.concatenate([util.scenes.seed_block((0, 0, 0), (96, 20, 80)), spray])
     res = []
+    monkeypatch.setenv("LFA_MG_NO_CLOSED", "1")  # (the droplets stay in the PCG here: it is their PARENTS this test is about)
     for prune in (True, False):
         monkeypatch.delenv("LFA_MG_NO_PRUNE", raising=False)
         if not prune:
