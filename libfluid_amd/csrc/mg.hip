@@ -3029,17 +3029,17 @@ k_mg_solve_closed(const int *ptiles, int n_ptiles, const uint8_t *closed, const 
 }  // namespace
 
 /// Solves the closed tiles (after lfa_mg_setup and the right-hand side, before or beside the PCG: nothing is shared with it).
-int lfa_mg_solve_closed(lfa_sim *s) {
+int lfa_mg_solve_closed(lfa_sim *s, void *out) {
 	if (!s->mg || !s->mg->closed_out || !s->n_ptiles) return LFA_OK;
 	if (s->mg->lv[0].n_tiles == s->n_ptiles) return LFA_OK;  // (no tile is closed: early in a run, as a rule)
 	const int G = std::max(1, std::min((s->n_ptiles + PCG_WAVES - 1) / PCG_WAVES, 4096));
 	if (s->prm.pcg_dtype == LFA_PCG_F64)
 		hipLaunchKernelGGL(k_mg_solve_closed<double>, dim3(G), dim3(256), 0, s->stream, (const int *)s->ptiles, s->n_ptiles,
-		                   (const uint8_t *)s->tile_closed, (const uint8_t *)s->abits, (const double *)s->vr, (double *)s->vp,
+		                   (const uint8_t *)s->tile_closed, (const uint8_t *)s->abits, (const double *)s->vr, (double *)(out ? out : s->vp),
 		                   1.0 / s->a_scale, 0.05 * s->prm.tolerance, s->pcg_state);
 	else
 		hipLaunchKernelGGL(k_mg_solve_closed<float>, dim3(G), dim3(256), 0, s->stream, (const int *)s->ptiles, s->n_ptiles,
-		                   (const uint8_t *)s->tile_closed, (const uint8_t *)s->abits, (const float *)s->vr, (float *)s->vp,
+		                   (const uint8_t *)s->tile_closed, (const uint8_t *)s->abits, (const float *)s->vr, (float *)(out ? out : s->vp),
 		                   (float)(1.0 / s->a_scale), (float)(0.05 * s->prm.tolerance), s->pcg_state);
 	LFA_LAUNCH_CHECK(s);
 	return LFA_OK;

@@ -42,6 +42,6 @@ int lfa_mg_axpy_apply_cg(lfa_sim *s, const double *gamma, int n_gamma, const dou
                          double *part_sigma_new);
 int lfa_mg_bench_part(lfa_sim *s, int part);
 int lfa_mg_level0(const lfa_sim *s, const int **tiles, const int **slot);  // the tiles the PCG iterates over (closed ones left out)
-int lfa_mg_solve_closed(lfa_sim *s);                                       // the closed tiles' own solves (lfa_sim::tile_closed)
+int lfa_mg_solve_closed(lfa_sim *s, void *out = nullptr);                  // the closed tiles' own solves of A x = vr (lfa_sim::tile_closed) -> out (null: the pressure)
 void lfa_mg_free(lfa_sim *s);
 void lfa_mg_stats(const lfa_sim *s, uint64_t *launches_per_cycle, uint64_t *levels, uint64_t *first_co);

@@ -2135,6 +2135,8 @@ template <typename real> static int apply_precon_t(lfa_sim *s, const double *r, 
 	LFA_HIP(s, hipMemcpyAsync(s->pcg_state, init_state, 16, hipMemcpyHostToDevice, s->stream));
 	if (s->n_ptiles) {
 		LFA_TRY(mic_apply<real>(s, s->partials + PART_SIG0));
+		// (the closed tiles are no part of the V-cycle: their share of M^-1 is their exact inverse)
+		if (is_mg(s)) LFA_TRY(lfa_mg_solve_closed(s, s->vz));
 		if (is_ml(s)) {
 			hipLaunchKernelGGL(k_add_coarse<real>, dim3(pcg_grid(s->n_ptiles)), dim3(256), 0, s->stream, make_ctx(s), s->abits,
 			                   (real *)s->vz, (const real *)s->c_x, (const int *)s->slot_l1, (const real *)s->c_x2,

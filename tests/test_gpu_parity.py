@@ -629,6 +629,26 @@ def test_closed_tiles_are_solved_on_their_own(dtype, monkeypatch):
     assert abs(it_c - it_n) <= 1, (it_c, it_n)
     # the droplets' own pressures (small against the pool's): the two device runs agree to the solvers' tolerance
     util.assert_close(p_c, p_n, 1e-5, "pressure with / without the closed tiles in the PCG", pw=(2e-3, 1e-6))
+    # lfa_apply_preconditioner with closed tiles: their share of M^-1 is their exact inverse - the operator stays symmetric
+    # positive definite, and a residual that lives on the droplets alone comes back solved (A z = r there)
+    monkeypatch.delenv("LFA_MG_NO_CLOSED", raising=False)
+    s = lfa.Sim(size, precond=lfa.PRECOND_MULTIGRID, pcg_dtype=dtype)
+    s.upload_particles(parts)
+    s.hash(); s.p2g(); s.add_gravity(util.DT); s.build_system(util.DT)
+    fc = s.fluid_cells().astype(np.int64)
+    n = len(fc)
+    rng = np.random.default_rng(12)
+    x, y = rng.normal(size=n), rng.normal(size=n)
+    mx, my = s.apply_precon(x), s.apply_precon(y)
+    assert abs(y @ mx - x @ my) <= (2e-5 if dtype == lfa.PCG_F32 else 1e-11) * (abs(y @ mx) + np.linalg.norm(x) * np.linalg.norm(my))
+    assert x @ mx > 0 and y @ my > 0
+    high = (fc // size[0]) % size[1] >= 16  # unknowns in the tile layers above the pool's: droplets
+    r = np.where(high, rng.normal(size=n), 0.0)
+    z = s.apply_precon(r)
+    az = s.apply_a(z)
+    closed_rows = high & (np.abs(az - r) < 1e-4 * np.abs(r).max())
+    assert closed_rows.sum() > 0.7 * high.sum(), (int(closed_rows.sum()), int(high.sum()))  # (droplets across a tile face are smoothed, not solved)
+    s.close()
     # a block in free fall: divergence-free, the reference returns p = 0 without iterating (src/pressure_solver.cpp:33-35)
     s = lfa.Sim(size, precond=lfa.PRECOND_MULTIGRID, pcg_dtype=dtype)
     drops, _ = _pool_and_droplets(size, 0, 40, 4)
