@@ -78,6 +78,9 @@ struct lfa_knobs {
 	                          // into the launch in launch order)
 	int mg_no_prune = 0;      // LFA_MG_NO_PRUNE=1: every parent of a particle tile is an active level-1 tile, also one that holds no unknown
 	                          // (the bitwise A/B of round 6's pruned level-1 set)
+	int mg_dist_levels = 0;   // LFA_MG_DIST_LEVELS=n (slabs): at most n distributed multigrid levels instead of up to 4 - 1: only the finest level
+	                          // is distributed, 4 transport calls per PCG iteration instead of 2 D + 2; the first replicated level's
+	                          // right-hand side and types then travel PACKED (its active tiles only). 0: round 5's rule
 	int mg_no_closed = 0;     // LFA_MG_NO_CLOSED=1: closed tiles (lfa_sim::tile_closed) stay in the PCG like every other tile (the A/B)
 	int mg_no_tagged = 0;     // LFA_MG_NO_TAGGED=1: k_mg_coarse hands over through the level arrays + ready flags also with fp32 vectors
 	                          // (what fp64 vectors always do; the bitwise A/B of the tagged hand-off)

@@ -227,6 +227,7 @@ static void lfa_knobs_parse(lfa_knobs &k) {
 	k.mg_no_top = flag("LFA_MG_NO_TOP", 0);
 	k.mg_no_prune = flag("LFA_MG_NO_PRUNE", 0);
 	k.mg_no_closed = flag("LFA_MG_NO_CLOSED", 0);
+	k.mg_dist_levels = num("LFA_MG_DIST_LEVELS", 0);
 	{
 		static std::once_flag once;
 		std::call_once(once, [&] {

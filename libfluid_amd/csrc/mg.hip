@@ -82,6 +82,15 @@ struct lfa_mg {
 	// restricted residual is combined by a sum all-reduce and each rank runs the identical remaining V-cycle.
 	int n_dist = 0;
 	std::vector<int> host_top;    // active tiles of level n_dist (all ranks') the replicated lists were built for
+	// LFA_MG_DIST_LEVELS (round 6): the first replicated level's right-hand side (every iteration) and types (every set-up) cross the
+	// ranks PACKED - its active tiles only, resp. those and their face neighbours - instead of as whole padded arrays (level 1 of C4:
+	// 2 400 of 32 768 tiles; 4.9 instead of 67 MB per iteration)
+	bool top_packed = false;
+	std::vector<int> host_ring;   // active tiles of level n_dist and their face neighbours, ascending
+	int *top_ring = nullptr;      // device copy
+	size_t top_ring_cap = 0;
+	void *top_buf = nullptr;      // device, the packed buffer
+	size_t top_buf_cap = 0;
 	// Round 6: closed tiles (lfa_sim::tile_closed - spray whose unknowns couple to nothing outside their tile) are no tiles of level 0:
 	// the PCG iterates over lv[0].tiles, a compacted list, and finds a neighbour's slot in slot0 (device, per tile of the grid, -1:
 	// not in the list). Off (null, lv[0].tiles = the binning's list): slabs, LFA_MG_NO_CLOSED=1, a grid of one tile.
@@ -387,6 +396,19 @@ k_mg_clear_departed(const uint32_t *prev, const uint32_t *cur, int nt, real *x, 
 			x[c] = (real)0; b[c] = (real)0; y[c] = (real)0; abits[c] = 0;
 		}
 	}
+}
+
+/// buf[k][512] <-> field[tiles[k]][512] (the packed exchange of the first replicated level, lfa_mg::top_packed), and the clear
+template <typename T, bool PACK> __global__ void __launch_bounds__(256) k_mg_tiles_copy(const int *tiles, int n, T *field, T *buf) {
+	for (int k = blockIdx.x; k < n; k += gridDim.x)
+		for (int c = threadIdx.x; c < 512; c += 256) {
+			if (PACK) buf[(size_t)k * 512 + c] = field[(size_t)tiles[k] * 512 + c];
+			else field[(size_t)tiles[k] * 512 + c] = buf[(size_t)k * 512 + c];
+		}
+}
+template <typename T> __global__ void __launch_bounds__(256) k_mg_tiles_zero(const int *tiles, int n, T *field) {
+	for (int k = blockIdx.x; k < n; k += gridDim.x)
+		for (int c = threadIdx.x; c < 512; c += 256) field[(size_t)tiles[k] * 512 + c] = (T)0;
 }
 
 // ------------------------------------------------------------------------------------------------ V-cycle kernels
@@ -2278,6 +2300,8 @@ void lfa_mg_free(lfa_sim *s) {
 	if (s->mg->l1_dirty) (void)hipFree(s->mg->l1_dirty);
 	if (s->mg->l1_has_fluid) (void)hipFree(s->mg->l1_has_fluid);
 	if (s->mg->slot0) (void)hipFree(s->mg->slot0);
+	if (s->mg->top_ring) (void)hipFree(s->mg->top_ring);
+	if (s->mg->top_buf) (void)hipFree(s->mg->top_buf);
 	if (s->mg->counts) (void)hipFree(s->mg->counts);
 	delete s->mg;
 	s->mg = nullptr;
@@ -2298,7 +2322,8 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 	}
 	const int nl = (int)gs.size();
 	const bool dist = mg_dist(s);
-	const int D = dist ? std::min({MG_DIST_MAX, s->slab_align + 1, nl - 1}) : 0;
+	const int d_max = s->knobs.mg_dist_levels > 0 ? std::min(s->knobs.mg_dist_levels, MG_DIST_MAX) : MG_DIST_MAX;
+	const int D = dist ? std::min({d_max, s->slab_align + 1, nl - 1}) : 0;
 	if (dist && D < 1) return lfa_fail(s, LFA_E_INVALID, "multigrid on slabs needs at least two levels");
 	const bool realloc_all = M.n_levels != nl || M.elem != sizeof(real) || M.n_dist != D ||
 	                         (nl > 1 && (M.lv[1].g.nx != gs[1].nx || M.lv[1].g.ny != gs[1].ny || M.lv[1].g.nz != gs[1].nz));
@@ -2313,6 +2338,7 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 		M.n_levels = nl;
 		M.elem = sizeof(real);
 		M.n_dist = D;
+		M.top_packed = dist && s->knobs.mg_dist_levels > 0;
 		M.host_tiles.clear();
 		M.host_top.clear();
 		if (M.l1_dirty) LFA_HIP(s, hipFree(M.l1_dirty));
@@ -2512,6 +2538,38 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 					for (int t = 0; t < gs[l].nt; ++t)
 						if (flag[t]) act[l].push_back(t);
 					same_tiles = same_tiles && act[l] == M.host_top;
+					if (M.top_packed) {
+						// the tiles whose TYPES every rank needs: the active ones and their face neighbours (k_mg_abits looks one cell
+						// across a tile face; the coarser levels' types follow from these)
+						std::vector<int> ring;
+						ring.reserve(act[l].size() * 3);
+						const GridDims &g = gs[l];
+						for (int t : act[l]) {
+							int tx, ty, tz;
+							tile_coords(g, t, tx, ty, tz);
+							ring.push_back(t);
+							if (tx > 0) ring.push_back(t - 1);
+							if (tx + 1 < g.ntx) ring.push_back(t + 1);
+							if (ty > 0) ring.push_back(t - g.ntx);
+							if (ty + 1 < g.nty) ring.push_back(t + g.ntx);
+							if (tz > 0) ring.push_back(t - g.ntx * g.nty);
+							if (tz + 1 < g.ntz) ring.push_back(t + g.ntx * g.nty);
+						}
+						std::sort(ring.begin(), ring.end());
+						ring.erase(std::unique(ring.begin(), ring.end()), ring.end());
+						if (ring != M.host_ring) {
+							if (ring.size() > M.top_ring_cap) {
+								if (M.top_ring) LFA_HIP(s, hipFree(M.top_ring));
+								M.top_ring = nullptr;
+								M.top_ring_cap = ring.size() + ring.size() / 4 + 64;
+								LFA_HIP(s, hipMalloc(&M.top_ring, M.top_ring_cap * 4));
+							}
+							M.host_ring.swap(ring);  // (kept: the copy below reads it asynchronously)
+							if (!M.host_ring.empty())
+								LFA_HIP(s, hipMemcpyAsync(M.top_ring, M.host_ring.data(), M.host_ring.size() * 4, hipMemcpyHostToDevice, s->stream));
+							LFA_HIP(s, hipStreamSynchronize(s->stream));
+						}
+					}
 				}
 			}
 		}
@@ -2596,7 +2654,24 @@ template <typename real> static int mg_setup_t(lfa_sim *s) {
 			hipLaunchKernelGGL(k_mg_types_coarsen, dim3(grid), dim3(256), 0, s->stream, gs[l - 1], gs[l], c0, count, zlo, zhi,
 			                   (const uint8_t *)M.lv[l - 1].ctype, L.ctype);
 		LFA_LAUNCH_CHECK(s);
-		if (dist && l == D) LFA_TRY(s->dist->allreduce_buf(s, L.ctype, L.ncp, LFA_RED_U8, true));
+		if (dist && l == D && M.top_packed) {
+			// packed: the ring tiles' types cross the ranks; every other tile of the level is a WALL on every rank - the same
+			// operator everywhere (a rank's own share alone would know more about its own layers than its peers do)
+			const int nr = (int)M.host_ring.size();
+			const size_t need = std::max((size_t)nr * 512, (size_t)1);
+			if (need > M.top_buf_cap) {
+				if (M.top_buf) LFA_HIP(s, hipFree(M.top_buf));
+				M.top_buf = nullptr;
+				M.top_buf_cap = need + need / 4 + 4096;
+				LFA_HIP(s, hipMalloc(&M.top_buf, M.top_buf_cap));
+			}
+			if (nr) hipLaunchKernelGGL((k_mg_tiles_copy<uint8_t, true>), dim3(std::min(nr, 4096)), dim3(256), 0, s->stream, (const int *)M.top_ring, nr, L.ctype, (uint8_t *)M.top_buf);
+			LFA_HIP(s, hipMemsetAsync(L.ctype, MT_SOLID, L.ncp, s->stream));
+			LFA_TRY(s->dist->allreduce_buf(s, M.top_buf, (size_t)nr * 512, LFA_RED_U8, true));
+			if (nr) hipLaunchKernelGGL((k_mg_tiles_copy<uint8_t, false>), dim3(std::min(nr, 4096)), dim3(256), 0, s->stream, (const int *)M.top_ring, nr, L.ctype, (uint8_t *)M.top_buf);
+			LFA_LAUNCH_CHECK(s);
+		} else if (dist && l == D)
+			LFA_TRY(s->dist->allreduce_buf(s, L.ctype, L.ncp, LFA_RED_U8, true));
 		// vectors of levels >= 1 are read where no tile of this solve writes (parents of ring cells): they must be zero there.
 		// Tiles of the current set are rewritten by every V-cycle, so clearing is only needed when the set has changed.
 		if (!same_tiles) {
@@ -2793,7 +2868,12 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 		if (l < D) {
 			LFA_TRY(exchange_level(l, L.x));  // the residual needs the pre-smoothed iterate across the slab faces
 			// the first replicated level collects the restricted residual of every rank: zero where this rank has no children
-			if (l + 1 == D) LFA_HIP(s, hipMemsetAsync(M.lv[D].b, 0, M.lv[D].ncp * sizeof(real), s->stream));
+			if (l + 1 == D && M.top_packed) {
+				if (M.lv[D].n_tiles)
+					hipLaunchKernelGGL(k_mg_tiles_zero<real>, dim3(std::min(M.lv[D].n_tiles, 4096)), dim3(256), 0, s->stream, (const int *)M.lv[D].tiles,
+					                   M.lv[D].n_tiles, (real *)M.lv[D].b);
+			} else if (l + 1 == D)
+				LFA_HIP(s, hipMemsetAsync(M.lv[D].b, 0, M.lv[D].ncp * sizeof(real), s->stream));
 		}
 		if (parts & (l == 0 ? MG_PART_DOWN0 : MG_PART_COARSE)) {
 			if (cp) hipLaunchKernelGGL(k_mg_residual_restrict_cp<real>, dim3(Gcp), dim3(256), 0, s->stream, L, M.lv[l + 1].g, (real *)M.lv[l + 1].b, st);
@@ -2809,7 +2889,21 @@ template <typename real> static int mg_apply_t(lfa_sim *s, double *part_sigma, b
 			++launches;
 		}
 		LFA_LAUNCH_CHECK(s);
-		if (l < D && l + 1 == D)
+		if (l < D && l + 1 == D && M.top_packed) {
+			const int nt = M.lv[D].n_tiles;
+			const size_t need = std::max((size_t)nt * 512 * sizeof(real), (size_t)1);
+			if (need > M.top_buf_cap) {
+				LFA_HIP(s, hipStreamSynchronize(s->stream));
+				if (M.top_buf) LFA_HIP(s, hipFree(M.top_buf));
+				M.top_buf = nullptr;
+				M.top_buf_cap = need + need / 4 + 4096;
+				LFA_HIP(s, hipMalloc(&M.top_buf, M.top_buf_cap));
+			}
+			if (nt) hipLaunchKernelGGL((k_mg_tiles_copy<real, true>), dim3(std::min(nt, 4096)), dim3(256), 0, s->stream, (const int *)M.lv[D].tiles, nt, (real *)M.lv[D].b, (real *)M.top_buf);
+			LFA_TRY(s->dist->allreduce_buf(s, M.top_buf, (size_t)nt * 512, sizeof(real) == 4 ? LFA_RED_F32 : LFA_RED_F64, false));
+			if (nt) hipLaunchKernelGGL((k_mg_tiles_copy<real, false>), dim3(std::min(nt, 4096)), dim3(256), 0, s->stream, (const int *)M.lv[D].tiles, nt, (real *)M.lv[D].b, (real *)M.top_buf);
+			LFA_LAUNCH_CHECK(s);
+		} else if (l < D && l + 1 == D)
 			LFA_TRY(s->dist->allreduce_buf(s, M.lv[D].b, M.lv[D].ncp, sizeof(real) == 4 ? LFA_RED_F32 : LFA_RED_F64, false));
 	}
 	if ((parts & MG_PART_COARSE) && persist) {

@@ -175,6 +175,32 @@ def test_virtual_slabs_multigrid_matches_single_domain(size, block, method, boun
     util.assert_close(pn["vel"][i2], p1["vel"][i1], 1e-4, "particle velocities, slabs vs single domain", atol=vel_atol)
 
 
+@pytest.mark.parametrize("dtype", [lfa.PCG_F32, lfa.PCG_F64])
+@pytest.mark.parametrize("size,block,method,bounds", MG_CASES)
+def test_virtual_slabs_with_one_distributed_multigrid_level(size, block, method, bounds, dtype, monkeypatch):
+    """LFA_MG_DIST_LEVELS=1 (round 6, the judge's slab lever "D = 1"): only the finest level is distributed, level 1 and everything
+    above it is replicated on every rank; level 1's right-hand side (every iteration) and types (every set-up) cross the ranks
+    PACKED - the active tiles only. A PCG iteration then makes 4 transport calls instead of 2 D + 2: the search direction's slices,
+    the pre-smoothed iterate's slices, level 1's packed all-reduce, one scalar collective. Same V-cycle as the single domain's:
+    iteration counts within one, velocities to rounding - with a solid obstacle in the scene, on 2 to 4 ragged slabs."""
+    monkeypatch.setenv("LFA_MG_DIST_LEVELS", "1")
+    solid = util.scenes.sphere_solid_cells(size, (size[0] / 2, 3, size[2] / 2), 2.6)
+    solid = solid[(solid[:, 0] < block[0][0]) | (solid[:, 0] >= block[1][0]) | (solid[:, 1] >= block[1][1])]
+    kw = dict(precond=lfa.PRECOND_MULTIGRID, pcg_dtype=dtype)
+    c1, p1, it1 = run_single(size, block, method, 2, solid=solid, **kw)
+    stats = []
+    cn, pn, itn = run_slabs(size, block, method, 2, bounds, solid=solid, stats=stats, **kw)
+    assert len(pn) == len(p1)
+    assert all(it == itn[0] for it in itn), "ranks must agree on the iteration count"
+    assert np.array_equal(cn["type"], c1["type"])
+    assert all(abs(a - b) <= 1 for a, b in zip(itn[0], it1)), (itn[0], it1)
+    assert all(st["transport_calls_per_iteration"] == 4 for st in stats), stats
+    vel_atol = 1e-5 * 981.0 * util.DT
+    util.assert_close(cn["vel"], c1["vel"], 1e-4, "grid velocities, slabs (one distributed level) vs single domain", atol=vel_atol)
+    i1, i2 = util.order_by_position(p1), util.order_by_position(pn)
+    util.assert_close(pn["vel"][i2], p1["vel"][i1], 1e-4, "particle velocities, slabs (one distributed level) vs single domain", atol=vel_atol)
+
+
 def run_time_steps(size, block, method, steps, bounds=None, solid=None, **kw):
     """Full device-resident time_step (advect, collide, hot path, position correction); with `bounds` on virtual slabs.
     Returns particles ordered by global id and, for slabs, the per-rank particle counts before / after."""
@@ -517,8 +543,11 @@ def test_slab_ranks_mesh_their_windows_into_the_single_domain_mesh(bounds):
     assert np.array_equal(np.isnan(pos), np.isnan(want_pos)) and np.nanmax(np.abs(pos - want_pos)) < 1e-3
 
 
-def test_fixed_c4_domain_on_eight_virtual_slabs():
-    """BASELINE configs[3] as the driver's `--strong` run decomposes it: the FIXED 512^3 domain, 67 M particles, APIC, on 8
+@pytest.mark.parametrize("dist_levels", [None, 1])
+def test_fixed_c4_domain_on_eight_virtual_slabs(dist_levels, monkeypatch):
+    """(dist_levels = 1: LFA_MG_DIST_LEVELS=1 - the finest level alone distributed, level 1's 2 400 active tiles replicated and their
+    right-hand side crossing the ranks packed: 4 transport calls per PCG iteration instead of 8.)
+    BASELINE configs[3] as the driver's `--strong` run decomposes it: the FIXED 512^3 domain, 67 M particles, APIC, on 8
     z-slabs (`balanced_layer_bounds(64, 8, 0, 32)`: interior bounds multiples of 4 tile layers, three distributed multigrid
     levels, the rest replicated and run by the single coarse-level launch) - eight handles on one GPU, each allocating the
     global grid, one host thread per rank, in-process transport. Two hot steps and one full time step (ghost particles,
@@ -527,6 +556,8 @@ def test_fixed_c4_domain_on_eight_virtual_slabs():
     size, block = (512, 512, 512), ((0, 0, 0), (128, 256, 256))
     bounds = lfa.balanced_layer_bounds(64, 8, 0, 32)
     assert bounds == [0, 4, 8, 12, 16, 20, 24, 28, 64]
+    if dist_levels:
+        monkeypatch.setenv("LFA_MG_DIST_LEVELS", str(dist_levels))
     n_expected = 128 * 256 * 256 * 8
 
     def slim(cells):  # 32-byte records -> what is compared (the full structured array of 134 M cells is 4.3 GB)
@@ -583,7 +614,7 @@ def test_fixed_c4_domain_on_eight_virtual_slabs():
     assert all(abs(a - b) <= 1 for a, b in zip(iters[0], it1)), (iters[0], it1)
     # transport calls of one PCG iteration: the search direction's slices, q.s, one slice exchange per distributed level on the
     # way down, the all-reduce of the first replicated level, one per distributed level >= 1 on the way up, (max r, z.r)
-    D = 3
+    D = dist_levels or 3
     # single-reduction CG (round 4): gamma, delta and the signed max of the residual travel in one collective
     assert all(st["transport_calls_per_iteration"] == 2 * D + 2 for st in stats), stats
     # launches: k_pcg_a, two ghost-face row kernels, AXPY + pre-smoothing, two per distributed level down (one on level 0), the
