@@ -708,6 +708,27 @@ def test_shared_memory_transport_between_processes(bounds, slot_kb, precond, dty
     assert all(int(r["waits_given_up"]) == 0 for r in ranks), [int(r["waits_given_up"]) for r in ranks]
 
 
+def test_one_distributed_level_between_processes(tmp_path, monkeypatch):
+    """LFA_MG_DIST_LEVELS=1 with one PROCESS per rank over the shared-memory transport: the packed all-reduces of level 1 (right-hand
+    side per iteration, types per set-up) carry the same values as between the virtual slabs - the hot path agrees bit for bit."""
+    size, block = (16, 16, 32), ((2, 0, 2), (14, 12, 16))
+    bounds = [0, 1, 2, 4]
+    kw = dict(precond=lfa.PRECOND_MULTIGRID, pcg_dtype=lfa.PCG_F32)
+    ranks = run_shm_processes(size, block, lfa.APIC, bounds, 3, 2, tmp_path, lfa.PRECOND_MULTIGRID, lfa.PCG_F32, env={"LFA_MG_DIST_LEVELS": "1"})
+    monkeypatch.setenv("LFA_MG_DIST_LEVELS", "1")
+    cells_v, parts_v, iters_v = run_slabs(size, block, lfa.APIC, 3, bounds, **kw)
+    nx, ny, nz = size
+    cells = np.zeros(nx * ny * nz, dtype=lfa.CELL_DTYPE)
+    for r in ranks:
+        lo, hi = r["slab"]
+        z0, z1 = lo * 8, min(hi * 8, nz)
+        cells.reshape(nz, ny, nx)[z0:z1] = r["cells"].reshape(nz, ny, nx)[z0:z1]
+        assert list(r["iters"]) == iters_v[0]
+        assert int(r["transport_calls"]) == 4 and int(r["waits_given_up"]) == 0
+    assert np.array_equal(cells["type"], cells_v["type"])
+    assert np.array_equal(cells["vel"], cells_v["vel"])
+
+
 def test_bench_runs_n_processes_on_one_gpu(tmp_path):
     """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), on a box with ONE GPU: the
     ranks share the device, torch.distributed falls to gloo and the slab messages to the shared-memory transport. Checks the
