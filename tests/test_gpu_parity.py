@@ -661,6 +661,29 @@ def test_closed_tiles_are_solved_on_their_own(dtype, monkeypatch):
     o.close()
 
 
+@pytest.mark.parametrize("dtype", [lfa.PCG_F32, lfa.PCG_F64])
+def test_nothing_but_closed_tiles_needs_no_iteration(dtype):
+    """Spray alone: every particle tile is closed, the PCG has no tile to iterate over - zero iterations, and the droplets' pressures
+    (each its own little system, solved by k_mg_solve_closed) are the oracle's."""
+    from oracle import loader as orc
+    size = (40, 40, 32)
+    parts, _ = _pool_and_droplets(size, 0, 60, 8, clusters=False)
+    parts = parts[parts["pos"][:, 1] > 2.0]  # (pool_top = 0: no pool)
+    o = orc.CpuSim(size, method=orc.APIC)
+    o.set_particles(parts)
+    po, reso, ito = o.hot_step(util.DT)
+    assert ito > 0 and np.abs(po).max() > 0
+    s = lfa.Sim(size, precond=lfa.PRECOND_MULTIGRID, pcg_dtype=dtype)
+    s.upload_particles(parts)
+    r, it, rc = s.step_hot(util.DT)
+    assert rc == 0 and it == 0, (rc, it)
+    assert np.array_equal(s.fluid_cells(), o.fluid_cells())
+    util.assert_close(s.pressure(), po, P_REL, "droplet pressures", pw=(1e-3, 1e-4))
+    util.assert_close(s.cells()["vel"], o.cells()["vel"], 1e-4, "face velocities", atol=1e-5 * 981.0 * util.DT)
+    assert s.mg_level_tiles() in ([], [0]) and s.counts()["particle_tiles"] > 20
+    s.close(); o.close()
+
+
 def test_multigrid_single_launch_coarse_levels_repeat_bitwise_over_many_solves():
     """The hand-off between the phases of k_mg_coarse is a race if it is wrong: 40 solves of the same system must all return the
     same bits."""
