@@ -201,6 +201,39 @@ def test_virtual_slabs_with_one_distributed_multigrid_level(size, block, method,
     util.assert_close(pn["vel"][i2], p1["vel"][i1], 1e-4, "particle velocities, slabs (one distributed level) vs single domain", atol=vel_atol)
 
 
+@pytest.mark.parametrize("levels", [None, "1"])
+@pytest.mark.parametrize("size,block,method,bounds", [((16, 16, 32), ((2, 0, 3), (14, 10, 29)), lfa.APIC, [0, 2, 4]),
+                                                      ((24, 16, 40), ((0, 0, 0), (24, 8, 40)), lfa.FLIP_BLEND, [0, 1, 2, 3, 5])])
+def test_virtual_slabs_against_the_oracle_directly(size, block, method, bounds, levels, monkeypatch):
+    """The slab tests above compare N slabs with the single-domain DEVICE result (which the parity suite pins to the oracle); this
+    one leaves the middleman out: two hot passes on 2 / 4 slabs (the default hierarchy and LFA_MG_DIST_LEVELS=1) against the
+    ORACLE's (src/simulation.cpp:293-398, src/pressure_solver.cpp:19-148 restated) - cell types bit-exact, face velocities of the
+    stitched grid and particle velocities to 1e-4."""
+    from oracle import loader as orc
+    if levels:
+        monkeypatch.setenv("LFA_MG_DIST_LEVELS", levels)
+    solid = util.scenes.sphere_solid_cells(size, (size[0] / 2, 3, size[2] / 2), 2.6)
+    solid = solid[(solid[:, 0] < block[0][0]) | (solid[:, 0] >= block[1][0]) | (solid[:, 1] >= block[1][1])]
+    cn, pn, itn = run_slabs(size, block, method, 2, bounds, solid=solid, precond=lfa.PRECOND_MULTIGRID)
+    o = orc.CpuSim(size, method=method, blending=0.95)
+    o.set_solid_cells(solid)
+    # (the ranks seeded their own layers on the device: the oracle gets exactly those positions - a hot pass moves nobody -, at
+    # rest like the seeding leaves them, so that the two particle sets pair up by position without a tie to break)
+    start = np.zeros(len(pn), dtype=lfa.PARTICLE_DTYPE)
+    start["pos"] = pn["pos"]
+    o.set_particles(start)
+    for _ in range(2):
+        o.hot_step(util.DT)
+    oc, op = o.cells(), o.particles()
+    assert np.array_equal(cn["type"], oc["type"])
+    vel_atol = 1e-5 * 981.0 * util.DT
+    util.assert_close(cn["vel"], oc["vel"], 1e-4, "grid velocities, slabs vs oracle", atol=vel_atol)
+    i1, i2 = util.order_by_position(op), util.order_by_position(pn)
+    assert np.array_equal(pn["raw"][i2], op["raw"][i1])
+    util.assert_close(pn["vel"][i2], op["vel"][i1], 1e-4, "particle velocities, slabs vs oracle", atol=vel_atol)
+    o.close()
+
+
 def run_time_steps(size, block, method, steps, bounds=None, solid=None, **kw):
     """Full device-resident time_step (advect, collide, hot path, position correction); with `bounds` on virtual slabs.
     Returns particles ordered by global id and, for slabs, the per-rank particle counts before / after."""
