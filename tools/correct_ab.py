@@ -6,14 +6,15 @@ import libfluid_amd as lfa
 from libfluid_amd import scenes
 import statistics
 
-which = sys.argv[1] if len(sys.argv) > 1 else "C4"
-cfg = scenes.CONFIGS["C3" if which == "C3late" else which]
+which = sys.argv[1] if len(sys.argv) > 1 else "C4"  # C4 | C3late | CONFIG@STEP (e.g. C4@650)
+cfg = scenes.CONFIGS["C3" if which == "C3late" else which.split("@")[0]]
 s = lfa.Sim(cfg["size"], method=cfg["method"], blending=cfg["blending"])
 s.seed_block(*cfg["block"])
-s.set_step_overlap(False)
-lead = 550 if which == "C3late" else 30
+s.set_step_overlap(True)  # (the lead-in as the default step runs it)
+lead = 550 if which == "C3late" else (int(which.split("@")[1]) if "@" in which else 30)
 for _ in range(lead):
     s.time_step(min(3.0 * s.cfl(), 0.033))
+s.set_step_overlap(False)
 s.enable_timing(True)
 rec = {}
 for _ in range(20):
